@@ -1,0 +1,371 @@
+"""CPU tests of the oracle (oracle/polee_oracle.c) against the reference's fixtures and
+mathematical identities.  No GPU needed."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from conftest import random_tree
+
+
+def test_fixture_tree_deserialises_to_full_binary_tree(prep_fixture):
+    """Pins src/ptt.jl:89-116 on reference-produced node_parent_idxs/node_js."""
+    p, js = prep_fixture["node_parent_idxs"], prep_fixture["node_js"]
+    t = O.PTT(p, js)
+    idx = t.index
+    N, n = t.N, t.n
+    assert N == 625 and n == 313
+    leaves = idx[0][idx[0] > 0]
+    assert sorted(leaves.tolist()) == list(range(1, n + 1))
+    internal = idx[0] == 0
+    assert internal.sum() == n - 1
+    assert (idx[1][internal] > 0).all() and (idx[2][internal] > 0).all()
+    assert (idx[1][~internal] == 0).all() and (idx[2][~internal] == 0).all()
+    # DFS pre-order, right child first: right child is the next node
+    ii = np.nonzero(internal)[0]
+    assert (idx[2][ii] == ii + 2).all()
+    # parents precede children
+    assert (idx[3][1:] < np.arange(2, N + 1)).all() and idx[3][0] == 0
+    l, r, f = O.make_inverse_ptt_params(p, js)
+    assert (l == idx[1] - 1).all() and (r == idx[2] - 1).all() and (f == idx[0] - 1).all()
+
+
+def test_fixture_leaf_ranges_contiguous(prep_fixture):
+    """Every subtree's leaves are contiguous in DFS-leaf order, right subtree first."""
+    t = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    idx = t.index
+    N = t.N
+    lo = np.zeros(N, int); hi = np.zeros(N, int)
+    pos = 0
+    leafpos = {}
+    for i in range(N):
+        if idx[0][i] > 0:
+            leafpos[i] = pos; pos += 1
+    for i in range(N - 1, -1, -1):
+        if idx[0][i] > 0:
+            lo[i] = hi[i] = leafpos[i]
+        else:
+            l, r = idx[1][i] - 1, idx[2][i] - 1
+            assert hi[r] + 1 == lo[l]
+            lo[i], hi[i] = lo[r], hi[l]
+    assert lo[0] == 0 and hi[0] == t.n - 1
+
+
+@pytest.mark.parametrize("kind", ["random", "spine", "balanced"])
+def test_ptt_roundtrip_and_simplex(kind):
+    rng = np.random.default_rng(1)
+    n = 30 if kind == "spine" else 200  # a 200-deep spine underflows x below the 1e-16 leaf floor
+    p, js = random_tree(n, rng, kind)
+    t = O.PTT(p, js)
+    ys = rng.uniform(0.05, 0.95, n - 1)
+    xs, ladj = t.transform(ys, True)
+    assert abs(xs.astype(np.float64).sum() - 1) < 1e-5
+    ys2, ladj_inv = t.inverse_transform(xs)
+    np.testing.assert_allclose(ys2, ys, rtol=2e-5)
+    assert abs(ladj + ladj_inv) < 1e-3 * max(1, abs(ladj))
+    # TF ops agree with the Julia functions
+    l, r, f = O.make_inverse_ptt_params(p, js)
+    logit = np.log(ys / (1 - ys)).astype(np.float32)
+    x_tf = O.hsb(logit, l, r, f)[0]
+    np.testing.assert_allclose(x_tf, xs, rtol=1e-5)
+    y_tf, ladj_tf = O.inv_hsb(xs, l, r, f)
+    np.testing.assert_allclose(y_tf[0], ys2, rtol=1e-12)
+    assert abs(ladj_tf[0, 0] - ladj_inv) < 1e-3 * max(1, abs(ladj_inv))
+
+
+def test_ptt_transform_gradients_fd():
+    """src/ptt.jl:167-209 against finite differences of f(T(y)) + log|det J|(y)."""
+    rng = np.random.default_rng(2)
+    n = 40
+    p, js = random_tree(n, rng)
+    t = O.PTT(p, js)
+    ys = rng.uniform(0.2, 0.8, n - 1)
+    c = rng.normal(size=n)
+
+    def obj(y):
+        x, ladj = t.transform(y, True)
+        # transform! rounds x to f32; use us for an f64-accurate objective
+        us = t.us
+        leaf = t.index[0]
+        xx = np.zeros(n)
+        xx[leaf[leaf > 0] - 1] = us[leaf > 0]
+        return float(c @ xx + ladj)
+
+    t.transform(ys, True)
+    g = t.transform_gradients(ys, c)
+    t2 = O.PTT(p, js)
+    g_nl = (t2.transform(ys, False), t2.transform_gradients_no_ladj(ys, c))[1]
+    for k in rng.choice(n - 1, 12, replace=False):
+        e = np.zeros(n - 1); e[k] = 1e-6
+        fd = (obj(ys + e) - obj(ys - e)) / 2e-6
+        assert abs(fd - g[k]) < 2e-4 * max(1, abs(fd)), (k, fd, g[k])
+
+    def obj_nl(y):
+        t.transform(y, False)
+        us = t.us; leaf = t.index[0]
+        xx = np.zeros(n); xx[leaf[leaf > 0] - 1] = us[leaf > 0]
+        return float(c @ xx)
+    for k in rng.choice(n - 1, 6, replace=False):
+        e = np.zeros(n - 1); e[k] = 1e-6
+        fd = (obj_nl(ys + e) - obj_nl(ys - e)) / 2e-6
+        assert abs(fd - g_nl[k]) < 2e-4 * max(1, abs(fd))
+
+
+def test_inv_hsb_grad_fd():
+    """hsb_ops.cpp:342-391 against finite differences of sum(cy*y) + cl*ladj, on the simplex
+    parametrised through unconstrained coordinates (the op assumes sum(x)=1: u[0]=1)."""
+    rng = np.random.default_rng(3)
+    n = 30
+    p, js = random_tree(n, rng)
+    l, r, f = O.make_inverse_ptt_params(p, js)
+    x = rng.dirichlet(np.ones(n)).astype(np.float32)
+    x = (x / x.astype(np.float64).sum()).astype(np.float32)
+    cy = rng.normal(size=n - 1)
+    cl = 0.7
+    y, ladj = O.inv_hsb(x, l, r, f)
+    bp = O.inv_hsb_grad(cy[None], np.array([cl], np.float32), y, l, r, f)[0].astype(np.float64)
+
+    tj = O.PTT(p, js)
+
+    def obj(xx):
+        # f64-accurate inverse via the Julia-side oracle on the same tree
+        idx = tj.index; N = tj.N
+        u = np.zeros(N); val = 0.0; la = 0.0; k = n - 2
+        for i in range(N - 1, -1, -1):
+            if idx[0][i] > 0:
+                u[i] = xx[idx[0][i] - 1]
+            else:
+                a, b = u[idx[1][i] - 1], u[idx[2][i] - 1]
+                u[i] = a + b
+                val += cy[k] * a / u[i]; la -= np.log(u[i]); k -= 1
+        return val + cl * la
+    x64 = x.astype(np.float64)
+    # directional derivative along tangent directions of the simplex (sum of d = 0)
+    for _ in range(8):
+        d = rng.normal(size=n); d -= d.mean()
+        h = 1e-7
+        fd = (obj(x64 + h * d) - obj(x64 - h * d)) / (2 * h)
+        an = float(bp @ d)
+        assert abs(fd - an) < 1e-3 * max(1, abs(fd)), (fd, an)
+
+
+def test_fixture_log_likelihood_bands(lm_fixture):
+    """Sanity bands from SURVEY 8(c) (independent NumPy restatement, not reference output)."""
+    s = O.Sample(lm_fixture["m"], lm_fixture["n"], lm_fixture["colptr"], lm_fixture["rowval"], lm_fixture["nzval"])
+    n = s.n
+    x = np.full(n, 1.0 / n, np.float32)
+    lp, g = s.log_likelihood(x)
+    assert abs(lp - (-364724.4)) < 1.0
+    # homogeneity: sum_j x_j dlp/dx_j = m
+    assert abs(float(g @ x.astype(np.float64)) - s.m) < 1e-6 * s.m
+    # CSR == CSC: recompute with numpy from the CSC arrays
+    colptr = lm_fixture["colptr"].astype(np.int64) - 1
+    rows = lm_fixture["rowval"].astype(np.int64) - 1
+    cols = np.repeat(np.arange(n), np.diff(colptr))
+    sp = np.zeros(s.m)
+    np.add.at(sp, rows, (x[cols] * lm_fixture["nzval"]).astype(np.float64))
+    np.testing.assert_allclose(s.frag_probs, sp, rtol=1e-12)
+    assert abs(np.log(sp).sum() - lp) < 1e-6
+    g2 = np.zeros(n)
+    np.add.at(g2, cols, lm_fixture["nzval"].astype(np.float64) / sp[rows])
+    np.testing.assert_allclose(g, g2, rtol=1e-12)
+    # factored likelihood with ks = 1 equals the plain one
+    lpf, gf = s.factored_log_likelihood(np.ones(s.m, np.int64), x)
+    assert abs(lpf - lp) < 1e-6
+    np.testing.assert_allclose(gf, g, rtol=1e-10)
+    # gradonly returns 0 and the same gradient
+    lp0, g0 = s.log_likelihood(x, gradonly=True)
+    assert lp0 == 0.0
+    np.testing.assert_array_equal(g0, g)
+
+
+def test_efflen_jacobian(lm_fixture):
+    rng = np.random.default_rng(5)
+    n = lm_fixture["n"]
+    x = rng.dirichlet(np.ones(n)).astype(np.float32)
+    l = lm_fixture["effective_lengths"]
+    xls, g = O.effective_length_jacobian_adjustment(l, x, np.zeros(n))
+    c = (x.astype(np.float64) / l).sum()
+    np.testing.assert_allclose(g, -n / l.astype(np.float64) / c, rtol=1e-6)
+    assert abs(xls.astype(np.float64).sum() - 1) < 1e-5
+
+
+def test_elementwise_gradients_fd():
+    rng = np.random.default_rng(6)
+    k = 50
+    mu = rng.normal(size=k).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.5, size=k)).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=k).astype(np.float32)
+    z0 = rng.normal(size=k).astype(np.float32)
+    cy = rng.normal(size=k).astype(np.float32)
+
+    def obj(mu_, sg_, al_):  # f64 objective: sum(cy*y) + ladj_ln + ladj_skew
+        c = al_ + np.arcsinh(z0.astype(np.float64))
+        z = np.sinh(c)
+        y = 1 / (1 + np.exp(-(mu_ + z * sg_)))
+        return float((cy * y).sum() + np.log(sg_ * y * (1 - y)).sum()
+                     + (np.log(np.cosh(c)) - 0.5 * np.log1p(z0.astype(np.float64) ** 2)).sum())
+
+    zs, skew = O.sinh_asinh_transform(alpha, z0, True)
+    ys, lnl = O.logit_normal_transform(mu, sigma, zs, True)
+    zg, mg, sg = O.logit_normal_transform_gradients(zs, ys, mu, sigma, cy)
+    ag = O.sinh_asinh_transform_gradients(z0, alpha, zg)
+    m64, s64, a64 = (v.astype(np.float64) for v in (mu, sigma, alpha))
+    assert abs(obj(m64, s64, a64) - ((cy * ys).sum() + lnl + skew)) < 1e-3
+    h = 1e-5
+    for i in range(0, k, 7):
+        e = np.zeros(k); e[i] = h
+        assert abs((obj(m64 + e, s64, a64) - obj(m64 - e, s64, a64)) / (2 * h) - mg[i]) < 2e-3
+        assert abs((obj(m64, s64 + e, a64) - obj(m64, s64 - e, a64)) / (2 * h) - sg[i]) < 2e-3 * max(1, abs(sg[i]))
+        assert abs((obj(m64, s64, a64 + e) - obj(m64, s64, a64 - e)) / (2 * h) - ag[i]) < 2e-3 * max(1, abs(ag[i]))
+
+
+def test_kumaraswamy_fd():
+    rng = np.random.default_rng(7)
+    k = 20
+    a = rng.uniform(0.5, 3, k).astype(np.float32)
+    b = rng.uniform(0.5, 3, k).astype(np.float32)
+    z = rng.uniform(0.05, 0.95, k).astype(np.float32)
+    cy = rng.normal(size=k).astype(np.float32)
+
+    def obj(a_, b_):
+        c = 1 - (1 - z.astype(np.float64)) ** (1 / b_)
+        y = c ** (1 / a_)
+        ladj = ((1 / b_ - 1) * np.log(1 - z.astype(np.float64)) + (1 / a_ - 1) * np.log(c) - np.log(a_ * b_)).sum()
+        return float((cy * y).sum() + ladj)
+    ys, ladj = O.kumaraswamy_transform(a, b, z, True)
+    assert abs(obj(a.astype(np.float64), b.astype(np.float64)) - ((cy * ys).sum() + ladj)) < 1e-6
+    ag, bg = O.kumaraswamy_transform_gradients(z, a, b, cy)
+    h = 1e-6
+    for i in range(0, k, 3):
+        e = np.zeros(k); e[i] = h
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        assert abs((obj(a64 + e, b64) - obj(a64 - e, b64)) / (2 * h) - ag[i]) < 1e-3 * max(1, abs(ag[i]))
+        assert abs((obj(a64, b64 + e) - obj(a64, b64 - e)) / (2 * h) - bg[i]) < 1e-3 * max(1, abs(bg[i]))
+
+
+def test_adam_schedule():
+    assert O.adam_learning_rate(0) == 1.0
+    assert abs(O.adam_learning_rate(100) - np.exp(-2.0)) < 1e-15
+    assert O.adam_learning_rate(499) == 1e-3
+
+
+def test_initial_mu_identity(lm_fixture, prep_fixture):
+    """mu0 = logit(inverse_transform(1/n)) depends only on the tree
+    (likelihood-approximation.jl:451-453): for each internal node y = leaves(left)/leaves(node)."""
+    s = O.Sample(lm_fixture["m"], lm_fixture["n"], lm_fixture["colptr"], lm_fixture["rowval"], lm_fixture["nzval"])
+    t = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    r = O.approximate_likelihood(s, t, lm_fixture["effective_lengths"], init_only=True)
+    idx = t.index; N = t.N
+    cnt = np.zeros(N)
+    for i in range(N - 1, -1, -1):
+        cnt[i] = 1 if idx[0][i] > 0 else cnt[idx[1][i] - 1] + cnt[idx[2][i] - 1]
+    ii = np.nonzero(idx[0] == 0)[0]
+    y = cnt[idx[1][ii] - 1] / cnt[ii]
+    np.testing.assert_allclose(r["mu"], np.log(y / (1 - y)), rtol=2e-5, atol=2e-6)
+    assert np.allclose(r["omega"], np.log(np.float32(0.1))) and (r["alpha"] == 0).all()
+
+
+def _expected_loglik(sample, ptt, mu, omega, alpha, efflens, ndraws, seed):
+    sigma = np.exp(omega)
+    lps, pm = [], np.zeros(ptt.n)
+    for d in range(ndraws):
+        z0 = O.randn(ptt.n - 1, seed + d)
+        x = O.sampler_draw(ptt, mu, sigma, alpha, z0)
+        xc = np.clip(x, np.float32(1e-10), np.float32(1.0))
+        lps.append(sample.log_likelihood(xc)[0])
+        xe = x.astype(np.float64) / efflens
+        pm += xe / xe.sum()
+    return np.array(lps), pm / ndraws
+
+
+def test_fit_matches_reference_fit_statistically(lm_fixture, prep_fixture):
+    """Statistical pin of the VI loop (a21) on the reference's own fit of the same X:
+    the oracle's fit and prep.h5's mu/omega/alpha give the same expected log-likelihood
+    (within MC error) and correlated posterior means."""
+    s = O.Sample(lm_fixture["m"], lm_fixture["n"], lm_fixture["colptr"], lm_fixture["rowval"], lm_fixture["nzval"])
+    t = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    l = lm_fixture["effective_lengths"]
+    fit = O.approximate_likelihood(s, t, l, num_steps=500, num_mc=6, seed=123456789)
+    lp_ref, pm_ref = _expected_loglik(s, t, prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"], l, 200, 1000)
+    lp_fit, pm_fit = _expected_loglik(s, t, fit["mu"], fit["omega"], fit["alpha"], l, 200, 5000)
+    # SURVEY 8(c) band for the reference fit: mean -327171 +- 13 (sd)
+    assert abs(lp_ref.mean() - (-327171)) < 15
+    assert abs(lp_fit.mean() - lp_ref.mean()) < 6 * np.hypot(lp_ref.std(), lp_fit.std()) / np.sqrt(200) + 5
+    expressed = pm_ref > 1e-4
+    r = np.corrcoef(np.log(pm_ref[expressed]), np.log(pm_fit[expressed]))[0, 1]
+    assert r > 0.99, r
+    # fitted parameter ranges comparable to the fixture's
+    assert np.abs(fit["mu"]).max() < 12 and fit["omega"].min() > -6 and fit["omega"].max() < 2
+
+
+def test_vi_gradonly_equals_full_mode(lm_fixture, prep_fixture):
+    """gradonly (production) and !gradonly differ only by the values computed."""
+    s = O.Sample(lm_fixture["m"], lm_fixture["n"], lm_fixture["colptr"], lm_fixture["rowval"], lm_fixture["nzval"])
+    t = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    l = lm_fixture["effective_lengths"]
+    z0 = O.randn(3 * 2 * (s.n - 1), 11)
+    a = O.approximate_likelihood(s, t, l, num_steps=3, num_mc=2, z0=z0, gradonly=True)
+    b = O.approximate_likelihood(s, t, l, num_steps=3, num_mc=2, z0=z0, gradonly=False)
+    for k in ("mu", "omega", "alpha"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert (a["elbo"] == 0).all() and np.isfinite(b["elbo"]).all() and (b["lp_mean"] < -3e5).all()
+
+
+def test_approx_log_prob_gradient_fd(prep_fixture):
+    rng = np.random.default_rng(9)
+    n = 25
+    p, js = random_tree(n, rng)
+    l, r, f = O.make_inverse_ptt_params(p, js)
+    S = 2
+    x = rng.normal(0, 1.5, size=(S, n)).astype(np.float32)
+    eff = rng.uniform(200, 3000, size=(S, n)).astype(np.float32)
+    mu = rng.normal(0, 1, size=(S, n - 1)).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.3, size=(S, n - 1))).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=(S, n - 1)).astype(np.float32)
+    L, R, F = (np.tile(a, (S, 1)) for a in (l, r, f))
+    lp, g = O.approx_log_prob(x, eff, mu, sigma, alpha, L, R, F, want_grad=True)
+    assert np.isfinite(lp).all()
+    # f64 restatement of polee_approx_likelihood.py:367-450 for the FD check
+    t = O.PTT(p, js)
+
+    def lp64(xs, s):
+        xs = xs.astype(np.float64)
+        ladj = xs.sum() - (n - 1) * np.log(np.exp(xs).sum())
+        pr = np.exp(xs) / np.exp(xs).sum()
+        sc = pr * eff[s]; ssum = sc.sum(); q = sc / ssum
+        ladj += np.log(eff[s].astype(np.float64)).sum() - np.log(ssum)
+        idx = t.index; N = t.N; u = np.zeros(N); y = np.zeros(n - 1); k = n - 2
+        for i in range(N - 1, -1, -1):
+            if idx[0][i] > 0:
+                u[i] = q[idx[0][i] - 1]
+            else:
+                a, b = u[idx[1][i] - 1], u[idx[2][i] - 1]
+                u[i] = a + b; y[k] = a / u[i]; ladj -= np.log(u[i]); k -= 1
+        logit = np.log(y) - np.log1p(-y)
+        ladj += (-np.log(y) - np.log1p(-y)).sum()
+        zs = (logit - mu[s]) / sigma[s]
+        ladj -= np.log(sigma[s].astype(np.float64)).sum()
+        za = np.arcsinh(zs); z = np.sinh(za - alpha[s])
+        ladj += (np.log(np.cosh(alpha[s] - za)) - 0.5 * np.log1p(zs ** 2)).sum()
+        return float(((-np.log(2 * np.pi) - z ** 2) / 2).sum() + ladj)
+    for s in range(S):
+        assert abs(lp64(x[s], s) - lp[s]) < 2e-3 * max(1, abs(lp[s]))
+        for j in range(0, n, 4):
+            e = np.zeros(n); e[j] = 1e-5
+            fd = (lp64(x[s] + e, s) - lp64(x[s] - e, s)) / 2e-5
+            assert abs(fd - g[s, j]) < 2e-3 * max(1, abs(fd)), (s, j, fd, g[s, j])
+
+
+def test_tf_sampler_matches_julia_sampler(prep_fixture, lm_fixture):
+    t = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    l, r, f = O.make_inverse_ptt_params(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    mu, sigma, alpha = prep_fixture["mu"], np.exp(prep_fixture["omega"]), prep_fixture["alpha"]
+    eff = lm_fixture["effective_lengths"]
+    z0 = O.randn(t.n - 1, 77)
+    xj = O.sampler_draw(t, mu, sigma, alpha, z0).astype(np.float64) / eff
+    xj /= xj.sum()
+    xt = O.tf_sampler(z0, eff, mu, sigma, alpha, l, r, f)[0]
+    big = xj > 1e-12
+    np.testing.assert_allclose(xt[big], xj[big], rtol=3e-4)
+    x0 = O.x0_draw(t, mu, sigma, alpha, eff, z0)
+    np.testing.assert_allclose(x0[big], xj[big], rtol=3e-4)
