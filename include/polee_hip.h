@@ -1,0 +1,256 @@
+/*
+ * polee_hip.h -- C ABI of libpolee_hip.so, the MI355X (gfx950) approximate-likelihood
+ * engine for Polee.  This is the drop-in boundary: the reference's Julia host code
+ * reaches these symbols with `ccall` (see INTEGRATION.md and julia/PoleeHIP.jl); they
+ * replace the PyCall + TensorFlow + hsb_ops.so path entirely.
+ *
+ * Conventions
+ *   - Every function returns a polee_status (0 = ok).  A message for the last failure
+ *     on a context is available from polee_last_error(ctx); failures that happen
+ *     before a context exists are reported by polee_last_error(NULL).
+ *   - Host pointers are borrowed for the duration of the call only (Julia callers
+ *     must GC.@preserve them).  The library copies what it needs to the device.
+ *     Pointers named d_* are DEVICE pointers.
+ *   - Index arrays use the reference's on-disk conventions: node_parent_idxs, node_js,
+ *     colptr, rowval are 1-based exactly as in the prep / likelihood-matrix HDF5 files;
+ *     left/right/leaf_index are 0-based with -1 = none as make_inverse_ptt_params
+ *     (src/ptt.jl:293-309) produces them for the TF ops.
+ *   - Batched arrays are row-major [B][len].
+ *   - One HIP stream per context; a handle must not be used from two host threads at
+ *     once; different contexts (different GPUs) may be driven concurrently.  The
+ *     library calls hipSetDevice itself on every entry (safe from any OS thread).
+ *   - Nothing here falls back to the CPU: without a usable GPU polee_ctx_create fails.
+ *
+ * Citations are reference file:line, relative to the reference repository root.
+ */
+#ifndef POLEE_HIP_H
+#define POLEE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int polee_status;
+enum {
+    POLEE_OK = 0,
+    POLEE_ERR_BAD_ARG = 1,     /* size / NULL / malformed tree or matrix                  */
+    POLEE_ERR_OOM = 2,         /* host or device allocation failed                        */
+    POLEE_ERR_HIP = 3,         /* a HIP runtime call or kernel launch failed              */
+    POLEE_ERR_NONFINITE = 4,   /* non-finite gradient / likelihood (mirrors the @assert   */
+                               /* isfinite at likelihood-approximation.jl:559,564,        */
+                               /* likelihood.jl:50, ptt.jl:156-157)                       */
+    POLEE_ERR_UNSUPPORTED = 5, /* valid input outside what the kernels are built for      */
+    POLEE_ERR_COMM = 6         /* collective / communicator failure                       */
+};
+
+typedef struct polee_ctx polee_ctx;       /* device + stream + error state               */
+typedef struct polee_ptt polee_ptt;       /* one Polya tree transform (device resident)  */
+typedef struct polee_loglik polee_loglik; /* one sample's X, device resident             */
+typedef struct polee_vi polee_vi;         /* state of one likelihood-approximation fit   */
+typedef struct polee_approx polee_approx; /* S fitted approximations (regression input)  */
+
+/* ---- context -------------------------------------------------------------------- */
+polee_status polee_ctx_create(int device, polee_ctx **out);
+void polee_ctx_destroy(polee_ctx *ctx);
+const char *polee_last_error(const polee_ctx *ctx_or_null);
+polee_status polee_ctx_synchronize(polee_ctx *ctx);
+void *polee_ctx_stream(polee_ctx *ctx); /* the context's hipStream_t */
+/* HIP-event stopwatch on the context's stream (bench.py times the hot path with it). */
+polee_status polee_ctx_timer_start(polee_ctx *ctx);
+polee_status polee_ctx_timer_stop(polee_ctx *ctx, double *elapsed_ms);
+const char *polee_version(void);
+
+/* ---- Polya tree transform ---------------------------------------------------------
+ * Replaces PolyaTreeTransform (src/ptt.jl:6-27) and the three TF custom ops of
+ * src/tensorflow_ext/hsb_ops.cpp.  The tree is given exactly as serialised in the
+ * prep HDF5 (src/ptt.jl:89-116): N = 2n-1 nodes in DFS pre-order, right child first;
+ * node_parent_idxs[i] = 1-based parent (0 for the root), node_js[i] = 1-based
+ * transcript id of a leaf (0 for an internal node).  The k-th internal node in node
+ * order owns ys[k]. */
+polee_status polee_ptt_create(polee_ctx *ctx, const int32_t *node_parent_idxs,
+                              const int32_t *node_js, int32_t N, polee_ptt **out);
+/* Same tree given as the TF-op index arrays (src/ptt.jl:293-309; hsb_ops.cpp:17-22). */
+polee_status polee_ptt_create_from_index(polee_ctx *ctx, const int32_t *left_index,
+                                         const int32_t *right_index, const int32_t *leaf_index,
+                                         int32_t N, polee_ptt **out);
+void polee_ptt_destroy(polee_ptt *t);
+int32_t polee_ptt_n(const polee_ptt *t); /* number of leaves (transcripts) */
+/* make_inverse_ptt_params (src/ptt.jl:293-309), host only. */
+polee_status polee_make_inverse_ptt_params(const int32_t *node_parent_idxs, const int32_t *node_js,
+                                           int32_t N, int32_t *left_index, int32_t *right_index,
+                                           int32_t *leaf_index);
+
+/* transform! (src/ptt.jl:125-160): ys f64 [B][n-1] in (0,1) -> xs f32 [B][n] on the
+ * simplex, leaves floored at 1e-16; ladj (optional, [B]) = sum over internal nodes of
+ * log u.  The node values u of the last call stay on the device for
+ * polee_ptt_transform_gradients, like t.us does in the reference. */
+polee_status polee_ptt_transform(polee_ptt *t, const double *ys, int32_t B, float *xs,
+                                 double *ladj_or_null);
+/* transform_gradients! (src/ptt.jl:167-209) when with_ladj != 0, else
+ * transform_gradients_no_ladj! (src/ptt.jl:217-251).  x_grad f64 [B][n] ->
+ * y_grad f64 [B][n-1] (the reference stores f32; callers may round). */
+polee_status polee_ptt_transform_gradients(polee_ptt *t, const double *ys, const double *x_grad,
+                                           int32_t B, int with_ladj, double *y_grad);
+/* inverse_transform! (src/ptt.jl:257-285): xs f32 [B][n] -> ys f64 [B][n-1],
+ * ladj [B] = -sum log u. */
+polee_status polee_ptt_inverse_transform(polee_ptt *t, const float *xs, int32_t B, double *ys,
+                                         double *ladj_or_null);
+/* TF op HSB (hsb_ops.cpp:17-120): logits f32 [B][n-1] -> x f32 [B][n]; no floor. */
+polee_status polee_hsb(polee_ptt *t, const float *y_logit, int32_t B, float *x);
+/* TF op InvHSB (hsb_ops.cpp:128-249): x f32 [B][n] -> y f64 [B][n-1], ladj f32 [B]. */
+polee_status polee_inv_hsb(polee_ptt *t, const float *x, int32_t B, double *y, float *ladj);
+/* TF op InvHSBGrad (hsb_ops.cpp:252-402): VJP of InvHSB. */
+polee_status polee_inv_hsb_grad(polee_ptt *t, const double *y_grad, const float *ladj_grad,
+                                const double *y, int32_t B, float *backprops);
+
+/* ---- sparse fragment x transcript log-likelihood -----------------------------------
+ * Replaces Model + log_likelihood + factored_log_likelihood (src/likelihood.jl:2-85)
+ * and pAt_mul_B!/pAt_mulinv_B! (src/sparse.jl:6-40).  X is m x n in CSC form exactly
+ * as stored in the likelihood-matrix HDF5 (src/rnaseq_sample.jl:505-519): colptr
+ * [n+1] and rowval [nnz] 1-based; colptr may be uint32 (as the reference's UInt32
+ * index type) or uint64 (colptr_bytes = 4 or 8).  ks (optional, [m]) are the integer
+ * row multiplicities of the factored likelihood. */
+polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr,
+                                 int colptr_bytes, const uint32_t *rowval, const float *nzval,
+                                 const int64_t *ks_or_null, polee_loglik **out);
+/* Same sample given as Xt (n x m CSC == X in CSR), which the reference materialises
+ * anyway (likelihood-approximation.jl:407): tcolptr [m+1] uint64 1-based row offsets,
+ * trowval [nnz] 1-based transcript ids. */
+polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n,
+                                         const uint64_t *tcolptr, const uint32_t *trowval,
+                                         const float *tnzval, const int64_t *ks_or_null,
+                                         polee_loglik **out);
+void polee_loglik_destroy(polee_loglik *ll);
+
+typedef struct {
+    int64_t m, n, nnz;
+    int64_t num_slices;      /* 64-row slices of the device layout                      */
+    int64_t num_tiles;       /* workgroup-sized groups of slices                        */
+    int64_t padded_nnz;      /* stored entries including padding                        */
+    int64_t device_bytes;    /* bytes of X resident in HBM                              */
+    int64_t stream_bytes;    /* bytes one likelihood pass streams from HBM (X only)     */
+    int64_t num_empty_rows;  /* fragments with no compatible transcript (skipped)       */
+    int32_t max_row_nnz;
+    int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
+} polee_loglik_info;
+polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info);
+
+/* log_likelihood (src/likelihood.jl:36-56) for K expression vectors at once:
+ * xs f32 [K][n] -> x_grad f64 [K][n] = sum_i X_ij / s_i  (x ks_i if factored);
+ * lp [K] = sum_i log s_i (x ks_i) unless lp_or_null == NULL ("gradonly"). 1 <= K <= 8. */
+polee_status polee_loglik_eval(polee_loglik *ll, const float *xs, int32_t K, double *x_grad,
+                               double *lp_or_null);
+/* effective_length_jacobian_adjustment! (src/likelihood.jl:93-110), batched:
+ * x_grad[k][j] -= n / (efflens[j] * sum_i xs[k][i]/efflens[i]); xls optional out. */
+polee_status polee_efflen_jacobian_adjustment(polee_ctx *ctx, const float *efflens, const float *xs,
+                                              int32_t K, int64_t n, double *x_grad,
+                                              float *xls_or_null);
+
+/* ---- likelihood approximation (the VI loop) ----------------------------------------
+ * Replaces approximate_likelihood(::LogitSkewNormalPTTApprox, sample)
+ * (src/likelihood-approximation.jl:395-575), its factored variant (:248-392), ADAM
+ * (:107-146) and the element-wise reparameterisations (src/logitnormal.jl:8-55,
+ * src/sinh_arcsinh.jl:10-38).  Defaults are the reference's constants
+ * (src/constants.jl:48-65, likelihood-approximation.jl:421-423). */
+typedef struct {
+    int32_t num_steps;           /* LIKAP_NUM_STEPS = 500                                  */
+    int32_t num_mc_samples;      /* LIKAP_NUM_MC_SAMPLES = 6 (1..8)                        */
+    int32_t use_efflen_jacobian; /* default 1 (--no-efflen-jacobian clears it)             */
+    int32_t gradonly;            /* default 1: no ELBO / log-likelihood values             */
+    uint64_t seed;               /* device Philox seed (reference default 123456789)       */
+    const float *z0;             /* optional HOST noise [num_steps][num_mc][n-1]; when set */
+                                 /* it replaces the device RNG (deterministic parity runs) */
+    double y_eps;                /* LIKAP_Y_EPS = 1e-10 clamp of ys and xs                 */
+    double adam_initial_learning_rate; /* 1.0  */
+    double adam_learning_rate_decay;   /* 2e-2 */
+    double adam_min_learning_rate;     /* 1e-3 */
+    double adam_eps;                   /* 1e-8 */
+    double adam_rv;                    /* 0.9  */
+    double adam_rm;                    /* 0.7  */
+    double max_mu_step, max_omega_step, max_alpha_step; /* 0.2, 0.2, 0.02 */
+    int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events  */
+    int32_t reserved;
+} polee_vi_opts;
+void polee_vi_default_opts(polee_vi_opts *opts);
+
+typedef struct {
+    int32_t steps_done;
+    int32_t nonfinite_step;        /* first step with a non-finite gradient, 0 if none    */
+    double loglik_kernel_ms_avg;   /* profile=1: mean duration of the sparse kernel       */
+    int64_t loglik_kernel_launches;
+    double last_elbo;              /* !gradonly: reference-style elbo of the last step    */
+    double last_lp_mean;           /* !gradonly: mean log-likelihood over the K draws     */
+} polee_vi_stats;
+
+/* Builds the state and the initial values mu = logit(inverse_transform(1/n)),
+ * omega = log 0.1, alpha = 0 (likelihood-approximation.jl:451-456). */
+polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflens,
+                             const polee_vi_opts *opts, polee_vi **out);
+void polee_vi_destroy(polee_vi *vi);
+/* Enqueues nsteps VI iterations (K draws + one ADAM update each) on the context's
+ * stream without host synchronisation. */
+polee_status polee_vi_run(polee_vi *vi, int32_t nsteps);
+/* Waits for the stream; returns POLEE_ERR_NONFINITE if any step met a non-finite
+ * gradient (likelihood-approximation.jl:559). */
+polee_status polee_vi_sync(polee_vi *vi);
+polee_status polee_vi_get_params(polee_vi *vi, float *mu, float *omega, float *alpha);
+polee_status polee_vi_set_params(polee_vi *vi, const float *mu, const float *omega,
+                                 const float *alpha);
+polee_status polee_vi_get_stats(polee_vi *vi, polee_vi_stats *stats);
+/* Per-step values recorded when gradonly == 0: elbo [steps_done] as the reference
+ * computes it (last draw's lp + ladj, divided by K: likelihood-approximation.jl:537,
+ * 561) and the mean log-likelihood over draws.  Either pointer may be NULL. */
+polee_status polee_vi_get_trace(polee_vi *vi, double *elbo, double *lp_mean);
+/* The noise the device RNG uses at (step, draw): z0 f32 [K][n-1] for 1-based step. */
+polee_status polee_vi_export_noise(polee_vi *vi, int32_t step, float *z0);
+/* Test hook: evaluates the K draws of the NEXT step at the current parameters and
+ * returns the step's averaged gradients (what ADAM would consume), without updating
+ * anything.  Any output may be NULL.  xs [K][n], x_grad [K][n] (after the effective
+ * length adjustment), y_grad [K][n-1], *_grad [n-1], lp [K], ladj [K]. */
+polee_status polee_vi_eval_gradients(polee_vi *vi, float *xs, double *x_grad, double *y_grad,
+                                     float *mu_grad, float *omega_grad, float *alpha_grad,
+                                     double *lp, double *ladj);
+/* approximate_likelihood in one call: create + run(num_steps) + sync + get_params. */
+polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens,
+                          const polee_vi_opts *opts, float *mu, float *omega, float *alpha,
+                          polee_vi_stats *stats_or_null);
+
+/* ---- sampler ------------------------------------------------------------------------
+ * rand!(::ApproxLikelihoodSampler) (src/approx-sampler.jl:37-44): draws x f32
+ * [ndraws][n] from a fitted approximation.  z0 (optional host [ndraws][n-1]) replaces
+ * the device RNG.  No clamp, leaves floored at 1e-16 by transform!. */
+polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigma,
+                                const float *alpha, const float *z0_or_null, int32_t ndraws,
+                                uint64_t seed, float *xs);
+
+/* ---- density of fitted approximations (regression consumer) --------------------------
+ * Replaces RNASeqApproxLikelihoodDist._log_prob (src/polee_approx_likelihood.py:367-450)
+ * and, with it, the InvHSB/InvHSBGrad ops inside TF's autodiff.  S samples, each with
+ * its own tree (or one shared tree when shared_tree != 0: index arrays are [1][N]).
+ * Arrays follow create_tensorflow_variables! (src/estimate.jl:502-556): efflens
+ * [S][n], la_mu/la_sigma/la_alpha [S][n-1], left/right/leaf_index int32 [S][N]. */
+polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const float *efflens,
+                                 const float *la_mu, const float *la_sigma, const float *la_alpha,
+                                 const int32_t *left_index, const int32_t *right_index,
+                                 const int32_t *leaf_index, int shared_tree, polee_approx **out);
+void polee_approx_destroy(polee_approx *ap);
+/* x f32 [S][n] unnormalised log-expression -> lp f32 [S]; x_grad (optional, [S][n]) =
+ * d lp[s] / d x[s][:]. */
+polee_status polee_approx_logprob(polee_approx *ap, const float *x, float *lp,
+                                  float *x_grad_or_null);
+/* Same on device buffers, enqueued on the context's stream (no host sync). */
+polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, float *d_lp,
+                                         float *d_x_grad_or_null);
+/* rnaseq_approx_likelihood_sampler (src/polee_approx_likelihood.py:35-59): one draw per
+ * sample, divided by efflens, renormalised and clipped to [1e-16, 0.99999999].
+ * z0 optional host [S][n-1]. */
+polee_status polee_approx_sample(polee_approx *ap, const float *z0_or_null, uint64_t seed,
+                                 float *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLEE_HIP_H */

@@ -1,0 +1,46 @@
+/*
+ * polee_hip_debug.h -- host-only introspection of the device layouts libpolee_hip builds.
+ * These entry points never touch the GPU; the CPU test-suite uses them to check the tree
+ * plan (Euler tour, leaf ranges) and the PSELL matrix layout against the oracle by
+ * emulating the kernels in NumPy.  Not part of the drop-in boundary.
+ */
+#ifndef POLEE_HIP_DEBUG_H
+#define POLEE_HIP_DEBUG_H
+
+#include "polee_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tree plan of polee_ptt_create (see polee_amd/csrc/ptt_internal.hpp for the encoding).
+ * Caller-provided arrays: tour_code u32[3n-2], tour_tgt i32[3n-2], leaf_tid i32[n],
+ * lo/mid/hi1 i32[n-1]; max_depth optional. */
+polee_status polee_debug_ptt_plan(const int32_t *node_parent_idxs, const int32_t *node_js, int32_t N,
+                                  uint32_t *tour_code, int32_t *tour_tgt, int32_t *leaf_tid,
+                                  int32_t *lo, int32_t *mid, int32_t *hi1, int32_t *max_depth);
+
+typedef struct polee_psell_debug polee_psell_debug;
+typedef struct {
+    int64_t m, n, nnz, num_slices, num_tiles, padded_nnz, num_empty_rows;
+    int64_t data_bytes, dict_len;
+    int32_t max_row_nnz, max_tile_cols;
+    const uint8_t *data;        /* slice blocks: float val[w][64]; uint16 lcol[w][64]      */
+    const uint32_t *slice_off;  /* [num_slices+1], 128-byte units                          */
+    const uint32_t *tile_slice; /* [num_tiles+1]                                           */
+    const uint32_t *tile_dict;  /* [num_tiles+1]                                           */
+    const uint32_t *dict;       /* [dict_len] 0-based transcript ids                       */
+    const uint32_t *row_order;  /* [num_slices*64] 0-based fragment per lane, ~0 = empty   */
+    const float *slice_ks;      /* [num_slices*64] or NULL                                 */
+} polee_psell_view;
+/* Same arguments as polee_loglik_create, minus the context. */
+polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                     const uint32_t *rowval, const float *nzval,
+                                     const int64_t *ks_or_null, polee_psell_debug **out);
+polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *view);
+void polee_debug_psell_free(polee_psell_debug *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,22 @@
+"""polee_amd -- host side of the MI355X approximate-likelihood engine for Polee.
+
+A Python mirror of the reference's Julia interface for the hot path (Julia is not
+available in the build image; julia/PoleeHIP.jl holds the ccall wrappers a maintainer
+would use).  Names, argument meaning and error behaviour follow the reference:
+
+  PolyaTreeTransform, transform!, transform_gradients!, inverse_transform!   src/ptt.jl
+  make_inverse_ptt_params                                                    src/ptt.jl:293-309
+  hsb / inv_hsb / inv_hsb_grad  (TF custom ops)                              src/tensorflow_ext/hsb_ops.cpp
+  RNASeqSample.X + log_likelihood / factored_log_likelihood                  src/likelihood.jl
+  approximate_likelihood(LogitSkewNormalPTTApprox(), sample)                 src/likelihood-approximation.jl
+  ApproxLikelihoodSampler / rand!                                            src/approx-sampler.jl
+  RNASeqApproxLikelihood(...).log_prob, rnaseq_approx_likelihood_sampler     src/polee_approx_likelihood.py
+
+All numerics run in libpolee_hip.so on the GPU; nothing here computes on the CPU.
+"""
+from ._lib import PoleeError, NonFiniteError, lib, LIB_PATH  # noqa: F401
+from .core import (Context, PolyaTreeTransform, make_inverse_ptt_params, hsb, inv_hsb, inv_hsb_grad,  # noqa: F401
+                   RNASeqSample, log_likelihood, factored_log_likelihood,
+                   effective_length_jacobian_adjustment, LogitSkewNormalPTTApprox, approximate_likelihood,
+                   LikelihoodApproximationFit, ApproxLikelihoodSampler, RNASeqApproxLikelihood,
+                   rnaseq_approx_likelihood_sampler, LIKAP_NUM_STEPS, LIKAP_NUM_MC_SAMPLES)

@@ -1,0 +1,451 @@
+"""Host-side mirror of the reference interface over the C ABI (see package docstring)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import arr, check, ptr, f32p, f64p, i32p, i64p, u32p, u64p
+
+LIKAP_NUM_STEPS = 500      # src/constants.jl:64
+LIKAP_NUM_MC_SAMPLES = 6   # src/constants.jl:65
+
+
+class Context:
+    """One GPU + one HIP stream (polee_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(L.lib().polee_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            L.lib().polee_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(L.lib().polee_ctx_synchronize(self._h), self._h)
+
+    @property
+    def stream(self):
+        return L.lib().polee_ctx_stream(self._h)
+
+    def timer_start(self):
+        check(L.lib().polee_ctx_timer_start(self._h), self._h)
+
+    def timer_stop(self):
+        ms = C.c_double()
+        check(L.lib().polee_ctx_timer_stop(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def make_inverse_ptt_params(node_parent_idxs, node_js):
+    """src/ptt.jl:293-309 -> (left_index, right_index, leaf_index), 0-based, -1 = none."""
+    p, j = arr(node_parent_idxs, np.int32), arr(node_js, np.int32)
+    N = p.size
+    l, r, f = (np.empty(N, np.int32) for _ in range(3))
+    check(L.lib().polee_make_inverse_ptt_params(ptr(p, i32p), ptr(j, i32p), N, ptr(l, i32p), ptr(r, i32p),
+                                                ptr(f, i32p)))
+    return l, r, f
+
+
+class PolyaTreeTransform:
+    """src/ptt.jl:6-27.  Built from the serialised tree (ptt.jl:89-116) or from the TF-op
+    index arrays (left, right, leaf)."""
+
+    def __init__(self, node_parent_idxs=None, node_js=None, ctx=None, index=None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        if index is not None:
+            l, r, f = (arr(a, np.int32).reshape(-1) for a in index)
+            check(L.lib().polee_ptt_create_from_index(self.ctx._h, ptr(l, i32p), ptr(r, i32p), ptr(f, i32p),
+                                                      int(l.size), C.byref(self._h)), self.ctx._h)
+            self.node_parent_idxs = self.node_js = None
+        else:
+            self.node_parent_idxs = arr(node_parent_idxs, np.int32)
+            self.node_js = arr(node_js, np.int32)
+            if self.node_parent_idxs.size != self.node_js.size:
+                raise ValueError("node_parent_idxs and node_js differ in length")  # @assert ptt.jl:91
+            check(L.lib().polee_ptt_create(self.ctx._h, ptr(self.node_parent_idxs, i32p), ptr(self.node_js, i32p),
+                                           int(self.node_js.size), C.byref(self._h)), self.ctx._h)
+        self.n = int(L.lib().polee_ptt_n(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_ptt_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _rows(self, a, dtype, width):
+        a = arr(a, dtype)
+        single = a.ndim == 1
+        a = a.reshape(1, -1) if single else a
+        if a.shape[1] != width:
+            raise ValueError("expected rows of length %d, got %d" % (width, a.shape[1]))
+        return a, single
+
+    def transform(self, ys, compute_ladj=False):
+        """transform!(t, ys, xs, Val(compute_ladj)) (ptt.jl:125-160) -> (xs, ladj)."""
+        ys, single = self._rows(ys, np.float64, self.n - 1)
+        B = ys.shape[0]
+        xs = np.empty((B, self.n), np.float32)
+        ladj = np.zeros(B, np.float64) if compute_ladj else None
+        check(L.lib().polee_ptt_transform(self._h, ptr(ys, f64p), B, ptr(xs, f32p), ptr(ladj, f64p)), self.ctx._h)
+        if single:
+            return xs[0], (float(ladj[0]) if compute_ladj else 0.0)
+        return xs, (ladj if compute_ladj else np.zeros(B))
+
+    def transform_gradients(self, ys, x_grad, with_ladj=True):
+        """transform_gradients! (ptt.jl:167-209) / transform_gradients_no_ladj! (:217-251) -> y_grad (f64)."""
+        ys, single = self._rows(ys, np.float64, self.n - 1)
+        xg, _ = self._rows(x_grad, np.float64, self.n)
+        B = ys.shape[0]
+        yg = np.empty((B, self.n - 1), np.float64)
+        check(L.lib().polee_ptt_transform_gradients(self._h, ptr(ys, f64p), ptr(xg, f64p), B, int(with_ladj),
+                                                    ptr(yg, f64p)), self.ctx._h)
+        return yg[0] if single else yg
+
+    def transform_gradients_no_ladj(self, ys, x_grad):
+        return self.transform_gradients(ys, x_grad, with_ladj=False)
+
+    def inverse_transform(self, xs):
+        """inverse_transform! (ptt.jl:257-285) -> (ys, ladj)."""
+        xs, single = self._rows(xs, np.float32, self.n)
+        B = xs.shape[0]
+        ys = np.empty((B, self.n - 1), np.float64)
+        ladj = np.zeros(B, np.float64)
+        check(L.lib().polee_ptt_inverse_transform(self._h, ptr(xs, f32p), B, ptr(ys, f64p), ptr(ladj, f64p)),
+              self.ctx._h)
+        return (ys[0], float(ladj[0])) if single else (ys, ladj)
+
+
+def _tree_for_ops(left_index, right_index, leaf_index, ctx):
+    l = arr(left_index, np.int32)
+    if l.ndim == 2 and l.shape[0] > 1:
+        raise ValueError("per-row trees: build one PolyaTreeTransform per tree (or use RNASeqApproxLikelihood)")
+    return PolyaTreeTransform(ctx=ctx, index=(l, right_index, leaf_index))
+
+
+def hsb(y_logit, left_index, right_index, leaf_index, ctx=None):
+    """TF op HSB (hsb_ops.cpp:17-120)."""
+    t = left_index if isinstance(left_index, PolyaTreeTransform) else _tree_for_ops(left_index, right_index, leaf_index, ctx)
+    y, single = t._rows(y_logit, np.float32, t.n - 1)
+    x = np.empty((y.shape[0], t.n), np.float32)
+    check(L.lib().polee_hsb(t._h, ptr(y, f32p), y.shape[0], ptr(x, f32p)), t.ctx._h)
+    return x
+
+
+def inv_hsb(x, left_index, right_index=None, leaf_index=None, ctx=None):
+    """TF op InvHSB (hsb_ops.cpp:128-249) -> (y f64 [B,n-1], ladj f32 [B,1])."""
+    t = left_index if isinstance(left_index, PolyaTreeTransform) else _tree_for_ops(left_index, right_index, leaf_index, ctx)
+    x, _ = t._rows(x, np.float32, t.n)
+    B = x.shape[0]
+    y = np.empty((B, t.n - 1), np.float64)
+    ladj = np.empty((B, 1), np.float32)
+    check(L.lib().polee_inv_hsb(t._h, ptr(x, f32p), B, ptr(y, f64p), ptr(ladj, f32p)), t.ctx._h)
+    return y, ladj
+
+
+def inv_hsb_grad(y_grad, ladj_grad, y, left_index, right_index=None, leaf_index=None, ctx=None):
+    """TF op InvHSBGrad (hsb_ops.cpp:252-402) -> backprops f32 [B,n]."""
+    t = left_index if isinstance(left_index, PolyaTreeTransform) else _tree_for_ops(left_index, right_index, leaf_index, ctx)
+    yg, _ = t._rows(y_grad, np.float64, t.n - 1)
+    yy, _ = t._rows(y, np.float64, t.n - 1)
+    B = yy.shape[0]
+    lg = arr(np.reshape(ladj_grad, (-1,)), np.float32)
+    bp = np.empty((B, t.n), np.float32)
+    check(L.lib().polee_inv_hsb_grad(t._h, ptr(yg, f64p), ptr(lg, f32p), ptr(yy, f64p), B, ptr(bp, f32p)), t.ctx._h)
+    return bp
+
+
+class RNASeqSample:
+    """The numeric part of RNASeqSample (src/rnaseq_sample.jl:6-23): X (m x n CSC, 1-based
+    colptr/rowval exactly as in the likelihood-matrix HDF5, :505-519) + effective_lengths,
+    resident on the GPU.  `ks` = row multiplicities for the factored likelihood."""
+
+    def __init__(self, m, n, colptr, rowval, nzval, effective_lengths=None, ks=None, ctx=None, xt=None):
+        self.ctx = ctx or default_context()
+        self.m, self.n = int(m), int(n)
+        self.effective_lengths = None if effective_lengths is None else arr(effective_lengths, np.float32)
+        self._h = C.c_void_p()
+        ks_a = None if ks is None else arr(ks, np.int64)
+        if xt is not None:
+            tp, tr, tv = arr(xt[0], np.uint64), arr(xt[1], np.uint32), arr(xt[2], np.float32)
+            check(L.lib().polee_loglik_create_from_xt(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n), ptr(tp, u64p),
+                                                      ptr(tr, u32p), ptr(tv, f32p), ptr(ks_a, i64p),
+                                                      C.byref(self._h)), self.ctx._h)
+        else:
+            colptr = np.ascontiguousarray(colptr)
+            if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
+                colptr = colptr.astype(np.uint64)
+            rowval, nzval = arr(rowval, np.uint32), arr(nzval, np.float32)
+            check(L.lib().polee_loglik_create(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n),
+                                              colptr.ctypes.data_as(C.c_void_p), int(colptr.dtype.itemsize),
+                                              ptr(rowval, u32p), ptr(nzval, f32p), ptr(ks_a, i64p),
+                                              C.byref(self._h)), self.ctx._h)
+        self.has_ks = ks is not None
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_loglik_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        i = L.LoglikInfo()
+        check(L.lib().polee_loglik_get_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
+    def log_likelihood(self, xs, gradonly=False):
+        """log_likelihood (likelihood.jl:36-56) for one vector [n] or K stacked vectors [K, n]
+        -> (lp, x_grad); lp is 0.0 when gradonly."""
+        xs = arr(xs, np.float32)
+        single = xs.ndim == 1
+        xs2 = xs.reshape(1, -1) if single else xs
+        K = xs2.shape[0]
+        if xs2.shape[1] != self.n:
+            raise ValueError("xs must have %d columns" % self.n)
+        g = np.empty((K, self.n), np.float64)
+        lp = None if gradonly else np.zeros(K, np.float64)
+        check(L.lib().polee_loglik_eval(self._h, ptr(xs2, f32p), K, ptr(g, f64p), ptr(lp, f64p)), self.ctx._h)
+        if gradonly:
+            lp = np.zeros(K)
+        return (float(lp[0]), g[0]) if single else (lp, g)
+
+
+def log_likelihood(sample, xs, gradonly=False):
+    return sample.log_likelihood(xs, gradonly)
+
+
+def factored_log_likelihood(sample, xs, gradonly=False):
+    """factored_log_likelihood (likelihood.jl:59-85); the sample must have been built with ks."""
+    if not sample.has_ks:
+        raise ValueError("sample was created without multiplicities ks")
+    return sample.log_likelihood(xs, gradonly)
+
+
+def effective_length_jacobian_adjustment(efflens, xs, x_grad, ctx=None):
+    """effective_length_jacobian_adjustment! (likelihood.jl:93-110) -> (xls, adjusted x_grad)."""
+    ctx = ctx or default_context()
+    efflens, xs = arr(efflens, np.float32), arr(xs, np.float32)
+    single = xs.ndim == 1
+    xs2 = xs.reshape(1, -1) if single else xs
+    K, n = xs2.shape
+    g = arr(x_grad, np.float64).reshape(K, n).copy()
+    xls = np.empty((K, n), np.float32)
+    check(L.lib().polee_efflen_jacobian_adjustment(ctx._h, ptr(efflens, f32p), ptr(xs2, f32p), K, C.c_int64(n),
+                                                   ptr(g, f64p), ptr(xls, f32p)), ctx._h)
+    return (xls[0], g[0]) if single else (xls, g)
+
+
+class LogitSkewNormalPTTApprox:
+    """src/likelihood-approximation.jl:8-16 (treemethod is only a label here: tree construction,
+    hclust, is outside the hot path -- pass the tree explicitly)."""
+
+    def __init__(self, treemethod="cluster"):
+        self.treemethod = treemethod
+
+
+class LikelihoodApproximationFit:
+    """State of one fit (polee_vi): lets callers step the VI loop and inspect it."""
+
+    def __init__(self, sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES,
+                 use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False):
+        self.sample, self.t, self.ctx = sample, t, sample.ctx
+        efflens = sample.effective_lengths if efflens is None else efflens
+        if efflens is None:
+            raise ValueError("effective lengths are required")
+        self.efflens = arr(efflens, np.float32)
+        o = L.ViOpts()
+        L.lib().polee_vi_default_opts(C.byref(o))
+        o.num_steps, o.num_mc_samples = int(num_steps), int(num_mc_samples)
+        o.use_efflen_jacobian, o.gradonly, o.seed, o.profile = int(use_efflen_jacobian), int(gradonly), int(seed), int(profile)
+        self._z0 = None
+        if z0 is not None:
+            self._z0 = arr(z0, np.float32).reshape(-1)
+            if self._z0.size != num_steps * num_mc_samples * (sample.n - 1):
+                raise ValueError("z0 must have num_steps*num_mc_samples*(n-1) elements")
+            o.z0 = ptr(self._z0, f32p)
+        self.opts = o
+        self.n, self.K = sample.n, int(num_mc_samples)
+        self._h = C.c_void_p()
+        check(L.lib().polee_vi_create(sample._h, t._h, ptr(self.efflens, f32p), C.byref(o), C.byref(self._h)),
+              self.ctx._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_vi_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def run(self, nsteps):
+        check(L.lib().polee_vi_run(self._h, int(nsteps)), self.ctx._h)
+
+    def sync(self):
+        check(L.lib().polee_vi_sync(self._h), self.ctx._h)
+
+    def params(self):
+        nm1 = self.n - 1
+        mu, om, al = (np.empty(nm1, np.float32) for _ in range(3))
+        check(L.lib().polee_vi_get_params(self._h, ptr(mu, f32p), ptr(om, f32p), ptr(al, f32p)), self.ctx._h)
+        return mu, om, al
+
+    def set_params(self, mu=None, omega=None, alpha=None):
+        a = [None if v is None else arr(v, np.float32) for v in (mu, omega, alpha)]
+        check(L.lib().polee_vi_set_params(self._h, ptr(a[0], f32p), ptr(a[1], f32p), ptr(a[2], f32p)), self.ctx._h)
+
+    def stats(self):
+        s = L.ViStats()
+        check(L.lib().polee_vi_get_stats(self._h, C.byref(s)), self.ctx._h)
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def trace(self):
+        n = self.stats()["steps_done"]
+        e, l = np.zeros(n), np.zeros(n)
+        check(L.lib().polee_vi_get_trace(self._h, ptr(e, f64p), ptr(l, f64p)), self.ctx._h)
+        return e, l
+
+    def export_noise(self, step):
+        z = np.empty((self.K, self.n - 1), np.float32)
+        check(L.lib().polee_vi_export_noise(self._h, int(step), ptr(z, f32p)), self.ctx._h)
+        return z
+
+    def eval_gradients(self):
+        n, nm1, K = self.n, self.n - 1, self.K
+        out = dict(xs=np.empty((K, n), np.float32), x_grad=np.empty((K, n), np.float64),
+                   y_grad=np.empty((K, nm1), np.float64), mu_grad=np.empty(nm1, np.float32),
+                   omega_grad=np.empty(nm1, np.float32), alpha_grad=np.empty(nm1, np.float32),
+                   lp=np.empty(K, np.float64), ladj=np.empty(K, np.float64))
+        check(L.lib().polee_vi_eval_gradients(
+            self._h, ptr(out["xs"], f32p), ptr(out["x_grad"], f64p), ptr(out["y_grad"], f64p),
+            ptr(out["mu_grad"], f32p), ptr(out["omega_grad"], f32p), ptr(out["alpha_grad"], f32p),
+            ptr(out["lp"], f64p), ptr(out["ladj"], f64p)), self.ctx._h)
+        return out
+
+
+def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, use_efflen_jacobian=True,
+                           num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES, gradonly=True,
+                           seed=123456789, z0=None):
+    """approximate_likelihood(::LogitSkewNormalPTTApprox, sample) (likelihood-approximation.jl:395-624).
+    Returns the params Dict: mu, omega, alpha (+ node_parent_idxs, node_js when the tree carries them)."""
+    if not isinstance(approx, LogitSkewNormalPTTApprox):
+        raise NotImplementedError("only LogitSkewNormalPTTApprox is built (the alt approximations are out of scope)")
+    if gene_noninformative:
+        raise NotImplementedError("gene_noninformative prior (likelihood.jl:114-159) is disabled on the CLI path and not built")
+    if t is None:
+        raise ValueError("a PolyaTreeTransform is required (tree construction, hclust.jl, is outside the hot path)")
+    fit = LikelihoodApproximationFit(sample, t, num_steps=num_steps, num_mc_samples=num_mc_samples,
+                                     use_efflen_jacobian=use_efflen_jacobian, gradonly=gradonly, seed=seed, z0=z0)
+    fit.run(num_steps)
+    fit.sync()
+    mu, omega, alpha = fit.params()
+    params = {"mu": mu, "omega": omega, "alpha": alpha}
+    if t.node_parent_idxs is not None:
+        params["node_parent_idxs"] = t.node_parent_idxs
+        params["node_js"] = t.node_js
+    if not gradonly:
+        params["elbo"], params["lp_mean"] = fit.trace()
+    return params
+
+
+class ApproxLikelihoodSampler:
+    """src/approx-sampler.jl:4-44."""
+
+    def __init__(self):
+        self.t = self.mu = self.sigma = self.alpha = None
+        self._seed = 123456789
+        self._count = 0
+
+    def set_transform(self, t, mu, sigma, alpha):
+        """set_transform! (approx-sampler.jl:19-34)."""
+        self.t = t
+        self.mu, self.sigma, self.alpha = (arr(a, np.float32) for a in (mu, sigma, alpha))
+
+    def seed(self, seed):
+        self._seed, self._count = int(seed), 0
+
+    def rand(self, ndraws=1, z0=None):
+        """rand!(als, xs) (approx-sampler.jl:37-44): ndraws draws -> [ndraws, n] f32."""
+        t = self.t
+        xs = np.empty((ndraws, t.n), np.float32)
+        z = None if z0 is None else arr(z0, np.float32).reshape(ndraws, t.n - 1)
+        seed = (self._seed + 0x632BE59BD9B4E019 * self._count) & 0xFFFFFFFFFFFFFFFF
+        self._count += 1
+        check(L.lib().polee_sampler_draw(t._h, ptr(self.mu, f32p), ptr(self.sigma, f32p), ptr(self.alpha, f32p),
+                                         ptr(z, f32p), int(ndraws), C.c_uint64(seed), ptr(xs, f32p)), t.ctx._h)
+        return xs
+
+
+class RNASeqApproxLikelihood:
+    """RNASeqApproxLikelihoodDist (polee_approx_likelihood.py:326-450) for S samples.
+    `vars` uses the keys of create_tensorflow_variables! (estimate.jl:502-556):
+    efflen [S,n], la_mu/la_sigma/la_alpha [S,n-1], left_index/right_index/leaf_index [S,N]
+    (or [1,N] / [N] for a shared tree)."""
+
+    def __init__(self, vars=None, ctx=None, **kw):
+        v = dict(vars or {})
+        v.update(kw)
+        self.ctx = ctx or default_context()
+        eff = arr(np.atleast_2d(v["efflen"]), np.float32)
+        mu, sg, al = (arr(np.atleast_2d(v[k]), np.float32) for k in ("la_mu", "la_sigma", "la_alpha"))
+        li, ri, fi = (arr(np.atleast_2d(v[k]), np.int32) for k in ("left_index", "right_index", "leaf_index"))
+        self.S, self.n = eff.shape
+        shared = 1 if li.shape[0] == 1 and self.S > 1 else 0
+        if not shared and li.shape[0] != self.S:
+            raise ValueError("index arrays must have S rows or 1 row")
+        self._h = C.c_void_p()
+        check(L.lib().polee_approx_create(self.ctx._h, self.S, self.n, ptr(eff, f32p), ptr(mu, f32p), ptr(sg, f32p),
+                                          ptr(al, f32p), ptr(li, i32p), ptr(ri, i32p), ptr(fi, i32p), shared,
+                                          C.byref(self._h)), self.ctx._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_approx_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def log_prob(self, x, want_grad=False):
+        """_log_prob (polee_approx_likelihood.py:367-450): x [S,n] -> lp [S] (and d lp/d x)."""
+        x = arr(np.atleast_2d(x), np.float32)
+        if x.shape != (self.S, self.n):
+            raise ValueError("x must be [%d, %d]" % (self.S, self.n))
+        lp = np.empty(self.S, np.float32)
+        g = np.empty((self.S, self.n), np.float32) if want_grad else None
+        check(L.lib().polee_approx_logprob(self._h, ptr(x, f32p), ptr(lp, f32p), ptr(g, f32p)), self.ctx._h)
+        return (lp, g) if want_grad else lp
+
+    def sample(self, z0=None, seed=123456789):
+        """rnaseq_approx_likelihood_sampler (polee_approx_likelihood.py:35-59), one draw per sample."""
+        z = None if z0 is None else arr(z0, np.float32).reshape(self.S, self.n - 1)
+        x = np.empty((self.S, self.n), np.float32)
+        check(L.lib().polee_approx_sample(self._h, ptr(z, f32p), C.c_uint64(seed), ptr(x, f32p)), self.ctx._h)
+        return x
+
+
+def rnaseq_approx_likelihood_sampler(vars, z0=None, seed=123456789, ctx=None):
+    return RNASeqApproxLikelihood(vars, ctx=ctx).sample(z0, seed)

@@ -1,0 +1,375 @@
+// Density (and its gradient) of fitted likelihood approximations, batched over samples.
+// Replaces RNASeqApproxLikelihoodDist._log_prob (src/polee_approx_likelihood.py:367-450)
+// with its TF autodiff backward (InvHSB's registered gradient :17-28 -> InvHSBGrad,
+// hsb_ops.cpp:342-391), and rnaseq_approx_likelihood_sampler (:35-59).
+//
+// Per sample s (row of the batch), with p = softmax(x), r = p * efflen, q = r / sum r:
+//   leaf scan  : double-double prefix of q over the sample's DFS leaf order
+//   nodes      : u_l, u_r from prefix differences; y = u_l/u; all per-node ladj / lp terms;
+//                y_grad (for the VJP) and 1/u
+//   (grad) tour scan : InvHSBGrad as an Euler-tour prefix sum of edge terms -> bp (d/dq)
+//   (grad) finish    : chain through q = r/R, r = p*l, p = softmax(x):
+//                      x_grad_j = q_j (bp_j - <bp,q> - 1) + 1 - (n-2) p_j
+#include "ptt_internal.hpp"
+
+#include <cmath>
+
+namespace polee {
+
+struct ApproxView {
+    int32_t S, n;
+    const float *efflens;              // [S][n]
+    const float *mu, *sigma, *alpha;   // [S][n-1]
+};
+
+// per-sample sums: acc[s][0] = sum x, [1] = A = sum exp(x), [2] = Bn = sum exp(x)*efflen
+__global__ void approx_sums_kernel(ApproxView a, const float *x, double *acc)
+{
+    __shared__ double smd[4];
+    const int s = blockIdx.y;
+    double sx = 0.0, A = 0.0, Bn = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.n; j += (int64_t)gridDim.x * blockDim.x) {
+        const float xv = x[(int64_t)s * a.n + j];
+        const double ex = (double)expf(xv);  // tf.math.exp(self.x) in f32 (:379)
+        sx += (double)xv;
+        A += ex;
+        Bn += ex * (double)a.efflens[(int64_t)s * a.n + j];
+    }
+    sx = block_sum_f64(sx, smd);
+    A = block_sum_f64(A, smd);
+    Bn = block_sum_f64(Bn, smd);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[s * 8 + 0], sx);
+        atomicAdd(&acc[s * 8 + 1], A);
+        atomicAdd(&acc[s * 8 + 2], Bn);
+    }
+}
+
+// q (effective-length scaled, renormalised expression) of transcript tid of sample s
+__device__ inline float approx_q(const ApproxView &a, const float *x, const double *acc, int s, int tid)
+{
+    const double ex = (double)expf(x[(int64_t)s * a.n + tid]);
+    return (float)(ex * (double)a.efflens[(int64_t)s * a.n + tid] / acc[s * 8 + 2]);
+}
+
+struct ApproxLeafLoad {
+    PttView v;
+    ApproxView a;
+    const float *x;
+    const double *acc;
+    __device__ dd operator()(int row, int64_t pos) const
+    {
+        const int tid = v.leaf_tid[(int64_t)v.tree(row) * v.n + pos];
+        return dd_make((double)approx_q(a, x, acc, row, tid));
+    }
+};
+
+// acc[s][3] += lp + ladj contributions of the internal nodes
+__global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *acc, double *y_out,
+                                    double *y_grad_out, double *inv_u_out)
+{
+    __shared__ double smd[4];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    const int64_t nm1 = v.n - 1;
+    double contrib = 0.0;
+    if (k < nm1) {
+        const int64_t tb = (int64_t)v.tree(s) * nm1;
+        const int lo = v.lo[tb + k], mid = v.mid[tb + k], hi1 = v.hi1[tb + k];
+        const dd *Cr = C + (int64_t)s * (v.n + 1);
+        const double ur = dd_diff(Cr[mid], Cr[lo]);
+        const double ul = dd_diff(Cr[hi1], Cr[mid]);
+        const double u = ul + ur;
+        const double y = ul / u;                                    // hsb_ops.cpp:230
+        double ladj = -log(u);                                      // hsb_ops.cpp:231
+        const double y_log = log(y), y_1mlog = log1p(-y);           // :418-419
+        const float y_logit = (float)(y_log - y_1mlog);             // :421
+        ladj += (double)(float)(-y_log - y_1mlog);                  // :423-425
+        const float muk = a.mu[(int64_t)s * nm1 + k], sg = a.sigma[(int64_t)s * nm1 + k];
+        const float al = a.alpha[(int64_t)s * nm1 + k];
+        const float z_std = (y_logit - muk) / sg;                   // :430
+        ladj -= (double)logf(sg);                                   // :432
+        const float z_asinh = asinhf(z_std);                        // :437
+        const float z = sinhf(z_asinh - al);                        // :438
+        ladj += (double)(logf(coshf(al - z_asinh)) - 0.5f * log1pf(z_std * z_std));  // :440-443
+        const double lp = (-1.8378770664093453 - (double)(z * z)) / 2.0;              // :448, log(2 pi)
+        contrib = lp + ladj;
+        if (y_out) y_out[(int64_t)s * nm1 + k] = y;
+        if (inv_u_out) inv_u_out[(int64_t)s * nm1 + k] = 1.0 / u;
+        if (y_grad_out) {
+            // d(lp + ladj)/d y_logit, then d y_logit / d y and the -log y - log1p(-y) term
+            const double zs = z_std, c = (double)z_asinh - (double)al;
+            const double rs = 1.0 / sqrt(1.0 + zs * zs);
+            const double d_lp = -sinh(c) * cosh(c) * rs;
+            const double d_la = tanh(c) * rs - zs * rs * rs;
+            const double d_logit = (d_lp + d_la) / (double)sg;
+            y_grad_out[(int64_t)s * nm1 + k] = d_logit / (y * (1 - y)) + (-1 / y + 1 / (1 - y));
+        }
+    }
+    contrib = block_sum_f64(contrib, smd);
+    if (threadIdx.x == 0) atomicAdd(&acc[s * 8 + 3], contrib);
+}
+
+// lp[s] = node terms + sum x - (n-1) log A + sum log efflen - log(R), R = Bn / A   (:384-400)
+__global__ void approx_finish_lp_kernel(ApproxView a, const double *acc, const double *sum_log_l, float *lp)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S) return;
+    const double sx = acc[s * 8 + 0], A = acc[s * 8 + 1], Bn = acc[s * 8 + 2];
+    const double ladj = sx - (double)(a.n - 1) * log(A) + sum_log_l[s] - log(Bn / A);
+    lp[s] = (float)(acc[s * 8 + 3] + ladj);
+}
+
+// InvHSBGrad (hsb_ops.cpp:342-391) with ladj_grad = 1 as an Euler-tour scan; 1/u_j comes
+// straight from the leaf prefix because sum q = 1 (u_root = 1, as the op assumes).
+struct ApproxGradLoad {
+    PttView v;
+    const double *y, *y_grad, *inv_u;  // [S][n-1]
+    __device__ inline double term(int row, uint32_t code) const
+    {
+        if (code & 4u) return 0.0;
+        const int64_t o = (int64_t)row * (v.n - 1) + (code >> 4);
+        const double iu = inv_u[o], yy = y[o];
+        const double w = (code & 8u) ? (1.0 - yy) : -yy;
+        return -iu + w * iu * y_grad[o];
+    }
+    __device__ dd operator()(int row, int64_t e) const
+    {
+        const uint32_t code = v.tour_code[(int64_t)v.tree(row) * v.TL + e];
+        const uint32_t type = code & 3u;
+        if (type == TOUR_LEAF) return dd_make(0.0);
+        const double t = term(row, code);
+        return dd_make(type == TOUR_ENTER ? t : -t);
+    }
+};
+struct ApproxGradEmit {
+    ApproxGradLoad l;
+    ApproxView a;
+    const float *x;
+    const double *acc;
+    float *bp;  // [S][n] by transcript
+    __device__ void operator()(int row, int64_t e, dd /*excl*/, dd incl, double &p0, double &p1) const
+    {
+        p0 = p1 = 0.0;
+        const int64_t tb = (int64_t)l.v.tree(row) * l.v.TL;
+        const uint32_t code = l.v.tour_code[tb + e];
+        if ((code & 3u) != TOUR_LEAF) return;
+        const dd tot = dd_add(incl, dd_make(l.term(row, code)));
+        const int pos = l.v.tour_tgt[tb + e];
+        const int tid = l.v.leaf_tid[(int64_t)l.v.tree(row) * l.v.n + pos];
+        const float b = (float)(tot.hi + tot.lo);  // backprops is float32 (hsb_ops.cpp:260)
+        bp[(int64_t)row * l.v.n + tid] = b;
+        p0 = (double)b * (double)approx_q(a, x, acc, row, tid);  // <bp, q>
+    }
+};
+
+__global__ void approx_finish_grad_kernel(ApproxView a, const float *x, const double *acc, const double *dots,
+                                          const float *bp, float *x_grad)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (j >= a.n) return;
+    const double p = (double)expf(x[(int64_t)s * a.n + j]) / acc[s * 8 + 1];
+    const double q = (double)approx_q(a, x, acc, s, (int)j);
+    const double dot = dots[s * 2];
+    x_grad[(int64_t)s * a.n + j] =
+        (float)(q * ((double)bp[(int64_t)s * a.n + j] - dot - 1.0) + 1.0 - (double)(a.n - 2) * p);
+}
+
+// sampler: z = sinh(asinh(z0) + alpha); y_logit = mu + sigma z; y = logistic (hsb_ops.cpp:103)
+__global__ void approx_sample_y_kernel(ApproxView a, const float *z0, uint64_t seed, double *ys);
+__global__ void approx_sample_finish_kernel(ApproxView a, const double *row_sums, float *x)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (j >= a.n) return;
+    // x_scaled = x_efflen / efflens; x = x_scaled / sum; clip (:54-58)
+    float v = x[(int64_t)s * a.n + j] / a.efflens[(int64_t)s * a.n + j];
+    v = (float)((double)v / row_sums[s * 2]);
+    v = fminf(fmaxf(v, 1e-16f), 0.99999999f);
+    x[(int64_t)s * a.n + j] = v;
+}
+
+__device__ inline float approx_philox_randn(uint64_t seed, uint32_t s, uint32_t k)
+{
+    // Philox4x32-10 as in vi.hip (kept local: separate translation unit)
+    uint32_t c[4] = {k, s, 1u, 0x61707078u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ key[0], n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ key[1], n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        key[0] += 0x9E3779B9u;
+        key[1] += 0xBB67AE85u;
+    }
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ void approx_sample_y_kernel(ApproxView a, const float *z0, uint64_t seed, double *ys)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    const int64_t nm1 = a.n - 1;
+    if (k >= nm1) return;
+    const int64_t o = (int64_t)s * nm1 + k;
+    const float z0v = z0 ? z0[o] : approx_philox_randn(seed, (uint32_t)s, (uint32_t)k);
+    const float z = sinhf(asinhf(z0v) + a.alpha[o]);
+    const float y_logit = a.mu[o] + a.sigma[o] * z;
+    ys[o] = 1.0 / (1.0 + (double)expf(-y_logit));
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+struct polee_approx {
+    polee_ctx *ctx = nullptr;
+    int32_t S = 0, n = 0;
+    polee_ptt *t = nullptr;  // S trees (or 1 shared)
+    DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
+    DevBuf<double> d_sum_log_l, d_acc, d_y, d_ygrad, d_invu, d_dots;
+    DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
+    ApproxView view() const { return ApproxView{S, n, d_efflens.p, d_mu.p, d_sigma.p, d_alpha.p}; }
+};
+
+extern "C" {
+
+polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const float *efflens, const float *la_mu,
+                                 const float *la_sigma, const float *la_alpha, const int32_t *left_index,
+                                 const int32_t *right_index, const int32_t *leaf_index, int shared_tree,
+                                 polee_approx **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!out || !efflens || !la_mu || !la_sigma || !la_alpha || !left_index || !right_index || !leaf_index || S < 1 ||
+        n < 2)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_approx_create: bad argument");
+    polee_approx *ap = new (std::nothrow) polee_approx();
+    if (!ap) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    ap->ctx = ctx;
+    ap->S = S;
+    ap->n = n;
+    const size_t sn = (size_t)S * n, sk = (size_t)S * (n - 1);
+    std::vector<double> sll(S, 0.0);
+    for (int32_t s = 0; s < S; ++s)
+        for (int32_t j = 0; j < n; ++j) sll[s] += (double)logf(efflens[(size_t)s * n + j]);
+    polee_status st = ptt_create_multi(ctx, left_index, right_index, leaf_index, shared_tree ? 1 : S, 2 * n - 1, &ap->t);
+    auto A = [&](polee_status r) {
+        if (st == POLEE_OK) st = r;
+    };
+    A(ap->d_efflens.upload(ctx, efflens, sn));
+    A(ap->d_mu.upload(ctx, la_mu, sk));
+    A(ap->d_sigma.upload(ctx, la_sigma, sk));
+    A(ap->d_alpha.upload(ctx, la_alpha, sk));
+    A(ap->d_sum_log_l.upload(ctx, sll));
+    A(ap->d_acc.alloc(ctx, (size_t)S * 8));
+    A(ap->d_dots.alloc(ctx, (size_t)S * 2));
+    A(ap->d_y.alloc(ctx, sk));
+    A(ap->d_ygrad.alloc(ctx, sk));
+    A(ap->d_invu.alloc(ctx, sk));
+    A(ap->d_bp.alloc(ctx, sn));
+    A(ap->d_x.alloc(ctx, sn));
+    A(ap->d_xgrad.alloc(ctx, sn));
+    A(ap->d_lp.alloc(ctx, S));
+    if (st == POLEE_OK) st = ap->t->reserve(S);
+    if (st != POLEE_OK) {
+        polee_approx_destroy(ap);
+        return st;
+    }
+    *out = ap;
+    return POLEE_OK;
+}
+
+void polee_approx_destroy(polee_approx *ap)
+{
+    if (!ap) return;
+    if (ap->ctx) (void)hipSetDevice(ap->ctx->device);
+    polee_ptt_destroy(ap->t);
+    delete ap;
+}
+
+polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, float *d_lp, float *d_x_grad)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!d_x || !d_lp) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ptt *t = ap->t;
+    hipStream_t st = ctx->stream;
+    const int S = ap->S, n = ap->n;
+    const int64_t nm1 = n - 1;
+    const bool grad = d_x_grad != nullptr;
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(ap->d_acc.p, 0, sizeof(double) * S * 8, st));
+    const unsigned nb = (unsigned)std::min<int64_t>(ceil_div(n, 256), 256);
+    hipLaunchKernelGGL(approx_sums_kernel, dim3(nb, S), dim3(256), 0, st, ap->view(), d_x, ap->d_acc.p);
+    POLEE_KERNEL_CHECK(ctx);
+    ApproxLeafLoad load{t->view(), ap->view(), d_x, ap->d_acc.p};
+    LeafPrefixEmit emit{n, t->d_C.p};
+    hipError_t e = run_scan_partial<dd>(st, S, n, t->d_chunk.p, nullptr, load, emit);
+    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
+                       ap->view(), t->d_C.p, ap->d_acc.p, grad ? ap->d_y.p : nullptr, grad ? ap->d_ygrad.p : nullptr,
+                       grad ? ap->d_invu.p : nullptr);
+    hipLaunchKernelGGL(approx_finish_lp_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, ap->view(),
+                       ap->d_acc.p, ap->d_sum_log_l.p, d_lp);
+    POLEE_KERNEL_CHECK(ctx);
+    if (grad) {
+        ApproxGradLoad gl{t->view(), ap->d_y.p, ap->d_ygrad.p, ap->d_invu.p};
+        ApproxGradEmit ge{gl, ap->view(), d_x, ap->d_acc.p, ap->d_bp.p};
+        e = run_scan_partial<dd>(st, S, t->TL, t->d_chunk.p, t->d_part.p, gl, ge);
+        if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(S), dim3(SCAN_THREADS), 0, st, t->d_part.p,
+                           scan_num_chunks(t->TL), ap->d_dots.p, 2);
+        hipLaunchKernelGGL(approx_finish_grad_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), 0, st,
+                           ap->view(), d_x, ap->d_acc.p, ap->d_dots.p, ap->d_bp.p, d_x_grad);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    return POLEE_OK;
+}
+
+polee_status polee_approx_logprob(polee_approx *ap, const float *x, float *lp, float *x_grad)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!x || !lp) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    const size_t sn = (size_t)ap->S * ap->n;
+    POLEE_TRY(ap->d_x.upload(ctx, x, sn));
+    POLEE_TRY(polee_approx_logprob_device(ap, ap->d_x.p, ap->d_lp.p, x_grad ? ap->d_xgrad.p : nullptr));
+    POLEE_TRY(ap->d_lp.download(ctx, lp, ap->S));
+    if (x_grad) POLEE_TRY(ap->d_xgrad.download(ctx, x_grad, sn));
+    return POLEE_OK;
+}
+
+polee_status polee_approx_sample(polee_approx *ap, const float *z0, uint64_t seed, float *x)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!x) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ptt *t = ap->t;
+    const int S = ap->S, n = ap->n;
+    const size_t sn = (size_t)S * n, sk = (size_t)S * (n - 1);
+    if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0, sk));
+    hipLaunchKernelGGL(approx_sample_y_kernel, dim3((unsigned)ceil_div(n - 1, 256), S), dim3(256), 0, ctx->stream,
+                       ap->view(), z0 ? ap->d_z0.p : nullptr, seed, t->d_ys.p);
+    POLEE_KERNEL_CHECK(ctx);
+    FwdOut o;
+    o.xs = ap->d_x.p;
+    o.xs_rs = n;
+    o.leaf_floor = 0.0;
+    o.efflens = ap->d_efflens.p;
+    o.efflens_rs = n;
+    o.row_sums = ap->d_dots.p;
+    POLEE_TRY(ptt_forward_device(t, t->d_ys.p, S, o));
+    hipLaunchKernelGGL(approx_sample_finish_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), 0, ctx->stream,
+                       ap->view(), ap->d_dots.p, ap->d_x.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return ap->d_x.download(ctx, x, sn);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// Shared host-side plumbing of libpolee_hip: context, error state, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/polee_hip.h"
+
+namespace polee {
+
+std::string &global_error();  // last error raised before / without a context
+
+}  // namespace polee
+
+struct polee_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    int num_cus = 256;
+    size_t lds_per_block = 65536;
+};
+
+namespace polee {
+
+inline polee_status fail(polee_ctx *ctx, polee_status code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    global_error() = buf;
+    return code;
+}
+
+#define POLEE_HIP_TRY(ctx, expr)                                                          \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::polee::fail((ctx), e__ == hipErrorOutOfMemory ? POLEE_ERR_OOM        \
+                                                                  : POLEE_ERR_HIP,       \
+                                 "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                                 __FILE__, __LINE__);                                     \
+    } while (0)
+
+#define POLEE_TRY(expr)                     \
+    do {                                    \
+        polee_status s__ = (expr);          \
+        if (s__ != POLEE_OK) return s__;    \
+    } while (0)
+
+#define POLEE_KERNEL_CHECK(ctx)                                                            \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess)                                                             \
+            return ::polee::fail((ctx), POLEE_ERR_HIP, "kernel launch failed: %s (%s:%d)", \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);              \
+    } while (0)
+
+// Device buffer owned by a handle.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    polee_status alloc(polee_ctx *ctx, size_t count)
+    {
+        if (count <= n && p) return POLEE_OK;
+        release();
+        if (count == 0) return POLEE_OK;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(ctx, POLEE_ERR_OOM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T),
+                        hipGetErrorString(e));
+        }
+        n = count;
+        return POLEE_OK;
+    }
+    polee_status upload(polee_ctx *ctx, const T *host, size_t count)
+    {
+        POLEE_TRY(alloc(ctx, count));
+        if (count)
+            POLEE_HIP_TRY(ctx, hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice,
+                                              ctx->stream));
+        // host memory is borrowed for the call only: make the copy complete before returning
+        POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return POLEE_OK;
+    }
+    polee_status upload(polee_ctx *ctx, const std::vector<T> &v) { return upload(ctx, v.data(), v.size()); }
+    polee_status download(polee_ctx *ctx, T *host, size_t count) const
+    {
+        if (count)
+            POLEE_HIP_TRY(ctx, hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost,
+                                              ctx->stream));
+        POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return POLEE_OK;
+    }
+};
+
+inline polee_status use_device(polee_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, POLEE_ERR_BAD_ARG, "null context");
+    POLEE_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return POLEE_OK;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace polee

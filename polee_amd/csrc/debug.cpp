@@ -1,0 +1,79 @@
+// Host-only introspection entry points (include/polee_hip_debug.h).
+#include <algorithm>
+
+#include "../../include/polee_hip_debug.h"
+#include "loglik_internal.hpp"
+#include "ptt_internal.hpp"
+
+namespace polee {
+std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                       const float *nzval, std::vector<uint64_t> &rowptr, std::vector<uint32_t> &col,
+                       std::vector<float> &val);
+}
+using namespace polee;
+
+struct polee_psell_debug {
+    PsellHost h;
+};
+
+extern "C" {
+
+polee_status polee_debug_ptt_plan(const int32_t *node_parent_idxs, const int32_t *node_js, int32_t N,
+                                  uint32_t *tour_code, int32_t *tour_tgt, int32_t *leaf_tid, int32_t *lo,
+                                  int32_t *mid, int32_t *hi1, int32_t *max_depth)
+{
+    if (!node_parent_idxs || !node_js) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    std::vector<int32_t> l, r, f;
+    std::string err = children_from_parents(node_parent_idxs, node_js, N, l, r, f);
+    PttPlan pl;
+    if (err.empty()) err = build_ptt_plan(l.data(), r.data(), f.data(), N, pl);
+    if (!err.empty()) return fail(nullptr, POLEE_ERR_BAD_ARG, "malformed tree: %s", err.c_str());
+    if (tour_code) std::copy(pl.tour_code.begin(), pl.tour_code.end(), tour_code);
+    if (tour_tgt) std::copy(pl.tour_tgt.begin(), pl.tour_tgt.end(), tour_tgt);
+    if (leaf_tid) std::copy(pl.leaf_tid.begin(), pl.leaf_tid.end(), leaf_tid);
+    if (lo) std::copy(pl.lo.begin(), pl.lo.end(), lo);
+    if (mid) std::copy(pl.mid.begin(), pl.mid.end(), mid);
+    if (hi1) std::copy(pl.hi1.begin(), pl.hi1.end(), hi1);
+    if (max_depth) *max_depth = pl.max_depth;
+    return POLEE_OK;
+}
+
+polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                     const uint32_t *rowval, const float *nzval, const int64_t *ks,
+                                     polee_psell_debug **out)
+{
+    if (!colptr || !out) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    std::vector<uint64_t> rowptr;
+    std::vector<uint32_t> col;
+    std::vector<float> val;
+    std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
+    if (!err.empty()) return fail(nullptr, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());
+    polee_psell_debug *p = new polee_psell_debug();
+    err = build_psell(m, n, rowptr.data(), col.data(), val.data(), ks, p->h);
+    if (!err.empty()) {
+        delete p;
+        return fail(nullptr, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
+                    "likelihood matrix: %s", err.c_str());
+    }
+    *out = p;
+    return POLEE_OK;
+}
+
+polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *v)
+{
+    if (!p || !v) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    const PsellHost &h = p->h;
+    v->m = h.m; v->n = h.n; v->nnz = h.nnz;
+    v->num_slices = h.num_slices; v->num_tiles = h.num_tiles; v->padded_nnz = h.padded_nnz;
+    v->num_empty_rows = h.empty_rows;
+    v->data_bytes = (int64_t)h.data.size(); v->dict_len = (int64_t)h.dict.size();
+    v->max_row_nnz = h.max_row; v->max_tile_cols = h.max_tile_cols;
+    v->data = h.data.data(); v->slice_off = h.slice_off.data(); v->tile_slice = h.tile_slice.data();
+    v->tile_dict = h.tile_dict.data(); v->dict = h.dict.data(); v->row_order = h.row_order.data();
+    v->slice_ks = h.slice_ks.empty() ? nullptr : h.slice_ks.data();
+    return POLEE_OK;
+}
+
+void polee_debug_psell_free(polee_psell_debug *p) { delete p; }
+
+}  // extern "C"

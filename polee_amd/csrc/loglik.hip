@@ -1,0 +1,469 @@
+// Sparse fragment x transcript log-likelihood and gradient on gfx950.
+// Replaces pAt_mul_B!/pAt_mulinv_B! (src/sparse.jl:6-40) and log_likelihood /
+// factored_log_likelihood (src/likelihood.jl:36-85) with ONE pass over X that evaluates
+// K expression vectors at once:
+//     s_i[k] = sum_j X_ij x_j[k]        (row sums, in registers: one lane owns one row)
+//     lp[k] += ks_i log s_i[k]
+//     g_j[k] += X_ij ks_i / s_i[k]      (accumulated per tile in LDS, flushed once)
+// The reference makes two passes (CSR for s, CSC for g) per draw, i.e. 2*K passes per VI
+// step; this kernel makes one.  Roofline: HBM-bound, no MFMA (0.25 flop/B).
+#include "loglik_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace polee {
+
+template <int K>
+__device__ inline void lds_row_load(const float *row, float (&out)[K])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = row[k];
+}
+
+template <int K, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__restrict__ data,
+                                                          const uint32_t *__restrict__ slice_off,
+                                                          const uint32_t *__restrict__ tile_slice,
+                                                          const uint32_t *__restrict__ tile_dict,
+                                                          const uint32_t *__restrict__ dict,
+                                                          const float *__restrict__ slice_ks,
+                                                          const float *__restrict__ x, float *__restrict__ g,
+                                                          double *__restrict__ lp, int lcap)
+{
+    extern __shared__ float lds[];
+    float *xw = lds;                     // [L][K] tile-local copy of x
+    float *gw = lds + (size_t)lcap * K;  // [L][K] tile-local gradient accumulator
+    __shared__ double lp_red[4];
+
+    const int tile = blockIdx.x;
+    const uint32_t d0 = tile_dict[tile];
+    const int L = (int)(tile_dict[tile + 1] - d0);
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int l = i / K, k = i - l * K;
+        xw[i] = x[(size_t)dict[d0 + l] * K + k];
+        gw[i] = 0.0f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t s0 = tile_slice[tile], s1 = tile_slice[tile + 1];
+    double lpacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
+
+    for (uint32_t s = s0 + wave; s < s1; s += 4) {
+        const uint32_t off = slice_off[s];
+        const int w = (int)((slice_off[s + 1] - off) / 3u);
+        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
+        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+
+        float sacc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        int t = 0;
+        for (; t + 4 <= w; t += 4) {
+            float v[4];
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = vals[(t + u) * 64];
+                c[u] = cols[(t + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *xr = xw + c[u] * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sacc[k] = fmaf(v[u], xr[k], sacc[k]);
+            }
+        }
+        for (; t < w; ++t) {
+            const float v = vals[t * 64];
+            const float *xr = xw + (int)cols[t * 64] * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, xr[k], sacc[k]);
+        }
+
+        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
+        float wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool live = sacc[k] > 0.0f;  // padded lanes (and empty rows) have s = 0
+            wk[k] = live ? ksv / sacc[k] : 0.0f;
+            if (WANT_LP && live) lpacc[k] += (double)ksv * log((double)sacc[k]);
+        }
+
+        // second sweep over the slice (L1/L2-resident): scatter X_ij * w_i into the tile window
+        t = 0;
+        for (; t + 4 <= w; t += 4) {
+            float v[4];
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = vals[(t + u) * 64];
+                c[u] = cols[(t + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (v[u] != 0.0f) {
+                    float *gr = gw + c[u] * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) atomicAdd(gr + k, v[u] * wk[k]);
+                }
+            }
+        }
+        for (; t < w; ++t) {
+            const float v = vals[t * 64];
+            if (v != 0.0f) {
+                float *gr = gw + (int)cols[t * 64] * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) atomicAdd(gr + k, v * wk[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int l = i / K, k = i - l * K;
+        const float v = gw[i];
+        if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
+    }
+    if (WANT_LP) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = lpacc[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if (lane == 0) lp_red[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
+            __syncthreads();
+        }
+    }
+}
+
+template <int K>
+static hipError_t launch_k(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
+{
+    const PsellHost &h = ll->host;
+    if (h.num_tiles == 0) return hipSuccess;
+    const int lcap = std::max(h.max_tile_cols, 1);
+    const size_t lds = (size_t)2 * lcap * K * sizeof(float);
+    dim3 grid((unsigned)h.num_tiles), block(256);
+    hipStream_t st = ll->ctx->stream;
+#define POLEE_LAUNCH(LP, KS)                                                                                  \
+    hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), grid, block, lds, st, ll->d_data.p, ll->d_slice_off.p, \
+                       ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap)
+    if (d_lp) {
+        if (ll->has_ks)
+            POLEE_LAUNCH(true, true);
+        else
+            POLEE_LAUNCH(true, false);
+    } else {
+        if (ll->has_ks)
+            POLEE_LAUNCH(false, true);
+        else
+            POLEE_LAUNCH(false, false);
+    }
+#undef POLEE_LAUNCH
+    return hipGetLastError();
+}
+
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp)
+{
+    polee_ctx *ctx = ll->ctx;
+    if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ll->profile) {
+        if (ll->prof_used + 2 > ll->prof_events.size()) {
+            if (ll->prof_events.size() >= 8192) POLEE_TRY(ll->profile_collect());
+            if (ll->prof_used + 2 > ll->prof_events.size()) {
+                hipEvent_t a, b;
+                POLEE_HIP_TRY(ctx, hipEventCreate(&a));
+                POLEE_HIP_TRY(ctx, hipEventCreate(&b));
+                ll->prof_events.push_back(a);
+                ll->prof_events.push_back(b);
+            }
+        }
+        e0 = ll->prof_events[ll->prof_used];
+        e1 = ll->prof_events[ll->prof_used + 1];
+        ll->prof_used += 2;
+        POLEE_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    hipError_t e = hipSuccess;
+    switch (K) {
+        case 1: e = launch_k<1>(ll, d_x, d_g, d_lp); break;
+        case 2: e = launch_k<2>(ll, d_x, d_g, d_lp); break;
+        case 3: e = launch_k<3>(ll, d_x, d_g, d_lp); break;
+        case 4: e = launch_k<4>(ll, d_x, d_g, d_lp); break;
+        case 5: e = launch_k<5>(ll, d_x, d_g, d_lp); break;
+        case 6: e = launch_k<6>(ll, d_x, d_g, d_lp); break;
+        case 7: e = launch_k<7>(ll, d_x, d_g, d_lp); break;
+        case 8: e = launch_k<8>(ll, d_x, d_g, d_lp); break;
+    }
+    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "likelihood kernel launch failed: %s", hipGetErrorString(e));
+    if (e1) POLEE_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    return POLEE_OK;
+}
+
+// [rows][n] <-> [n][rows] re-layout between the host API (one expression vector per row)
+// and the kernel's transcript-major layout.
+__global__ void rows_to_aos_kernel(const float *in, int K, int64_t n, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int64_t j = i / K;
+    const int k = (int)(i - j * K);
+    out[i] = in[(int64_t)k * n + j];
+}
+__global__ void aos_to_rows_f64_kernel(const float *in, int K, int64_t n, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int k = (int)(i / n);
+    const int64_t j = i - (int64_t)k * n;
+    out[i] = (double)in[j * K + k];
+}
+
+// effective_length_jacobian_adjustment! (src/likelihood.jl:93-110), host-pointer form.
+__global__ void efflen_sum_kernel(const float *efflens, const float *xs, int64_t n, double *sums)
+{
+    __shared__ double smd[4];
+    const int row = blockIdx.y;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)(xs[(int64_t)row * n + i] / efflens[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) smd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[row], smd[0] + smd[1] + smd[2] + smd[3]);
+}
+__global__ void efflen_adjust_kernel(const float *efflens, const float *xs, const double *sums, int64_t n,
+                                     double *x_grad, float *xls)
+{
+    const int row = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double c = sums[row];
+    const float inv_l = 1.0f / efflens[i];
+    x_grad[(int64_t)row * n + i] -= (double)((float)n * inv_l) / c;  // n * (1/efflens[i]) is Float32 in the reference
+    if (xls) xls[(int64_t)row * n + i] = (float)((double)(xs[(int64_t)row * n + i] / efflens[i]) / c);
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+polee_status polee_loglik::profile_collect()
+{
+    if (prof_used == 0) return POLEE_OK;
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+        float ms = 0.f;
+        POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
+        prof_ms_total += ms;
+        ++prof_launches;
+    }
+    prof_used = 0;
+    return POLEE_OK;
+}
+
+static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee_loglik **out)
+{
+    PsellHost &h = ll->host;
+    polee_status s;
+    if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
+        (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
+        (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        delete ll;
+        return s;
+    }
+    // keep only metadata on the host
+    std::vector<uint8_t>().swap(h.data);
+    std::vector<uint32_t>().swap(h.slice_off);
+    std::vector<uint32_t>().swap(h.dict);
+    std::vector<float>().swap(h.slice_ks);
+    std::vector<uint32_t>().swap(h.row_order);
+    *out = ll;
+    return POLEE_OK;
+}
+
+namespace polee {
+// CSC (1-based, as in the HDF5) -> CSR (0-based).  Columns stay ascending within a row.
+std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                       const float *nzval, std::vector<uint64_t> &rowptr, std::vector<uint32_t> &col,
+                       std::vector<float> &val)
+{
+    auto cp = [&](int64_t j) -> uint64_t {
+        return colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j]
+                                 : reinterpret_cast<const uint64_t *>(colptr)[j];
+    };
+    if (colptr_bytes != 4 && colptr_bytes != 8) return "colptr_bytes must be 4 or 8";
+    if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
+    const uint64_t nnz = cp(n) - 1;
+    rowptr.assign(m + 1, 0);
+    for (int64_t j = 0; j < n; ++j)
+        if (cp(j + 1) < cp(j)) return "colptr is not monotone";
+    for (uint64_t k = 0; k < nnz; ++k) {
+        const uint32_t r = rowval[k];
+        if (r < 1 || (int64_t)r > m) return "rowval out of range";
+        rowptr[r]++;
+    }
+    for (int64_t i = 0; i < m; ++i) rowptr[i + 1] += rowptr[i];
+    col.resize(nnz);
+    val.resize(nnz);
+    std::vector<uint64_t> cursor(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t j = 0; j < n; ++j)
+        for (uint64_t k = cp(j) - 1; k < cp(j + 1) - 1; ++k) {
+            const uint64_t p = cursor[rowval[k] - 1]++;
+            col[p] = (uint32_t)j;
+            val[p] = nzval[k];
+        }
+    return "";
+}
+}  // namespace polee
+
+extern "C" {
+
+polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
+                                         const uint32_t *trowval, const float *tnzval, const int64_t *ks,
+                                         polee_loglik **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!tcolptr || !out || m < 0 || n < 1 || (tcolptr[m] > 1 && (!trowval || !tnzval)))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_xt: bad argument");
+    if (tcolptr[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "tcolptr[0] must be 1 (1-based)");
+    const uint64_t nnz = tcolptr[m] - 1;
+    std::vector<uint64_t> rowptr(m + 1);
+    for (int64_t i = 0; i <= m; ++i) rowptr[i] = tcolptr[i] - 1;
+    std::vector<uint32_t> col(nnz);
+    for (uint64_t k = 0; k < nnz; ++k) {
+        if (trowval[k] < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "trowval must be 1-based");
+        col[k] = trowval[k] - 1;
+    }
+    polee_loglik *ll = new (std::nothrow) polee_loglik();
+    if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    ll->ctx = ctx;
+    ll->m = m;
+    ll->n = n;
+    ll->nnz = (int64_t)nnz;
+    ll->has_ks = ks != nullptr;
+    std::string err = build_psell(m, n, rowptr.data(), col.data(), tnzval, ks, ll->host);
+    if (!err.empty()) {
+        delete ll;
+        return fail(ctx, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
+                    "likelihood matrix: %s", err.c_str());
+    }
+    return loglik_finish_create(ctx, ll, out);
+}
+
+polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                 const uint32_t *rowval, const float *nzval, const int64_t *ks, polee_loglik **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!colptr || !out || m < 0 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create: bad argument");
+    std::vector<uint64_t> rowptr;
+    std::vector<uint32_t> col;
+    std::vector<float> val;
+    std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
+    if (!err.empty()) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());
+    polee_loglik *ll = new (std::nothrow) polee_loglik();
+    if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    ll->ctx = ctx;
+    ll->m = m;
+    ll->n = n;
+    ll->nnz = (int64_t)col.size();
+    ll->has_ks = ks != nullptr;
+    err = build_psell(m, n, rowptr.data(), col.data(), val.data(), ks, ll->host);
+    if (!err.empty()) {
+        delete ll;
+        return fail(ctx, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
+                    "likelihood matrix: %s", err.c_str());
+    }
+    return loglik_finish_create(ctx, ll, out);
+}
+
+void polee_loglik_destroy(polee_loglik *ll)
+{
+    if (!ll) return;
+    if (ll->ctx) (void)hipSetDevice(ll->ctx->device);
+    for (hipEvent_t e : ll->prof_events) (void)hipEventDestroy(e);
+    delete ll;
+}
+
+polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info)
+{
+    if (!ll || !info) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    const PsellHost &h = ll->host;
+    info->m = ll->m;
+    info->n = ll->n;
+    info->nnz = ll->nnz;
+    info->num_slices = h.num_slices;
+    info->num_tiles = h.num_tiles;
+    info->padded_nnz = h.padded_nnz;
+    info->stream_bytes = (int64_t)(ll->d_data.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
+                                                        ll->d_dict.n + ll->d_slice_ks.n));
+    info->device_bytes = info->stream_bytes;
+    info->num_empty_rows = h.empty_rows;
+    info->max_row_nnz = h.max_row;
+    info->max_tile_cols = h.max_tile_cols;
+    return POLEE_OK;
+}
+
+polee_status polee_loglik_eval(polee_loglik *ll, const float *xs, int32_t K, double *x_grad, double *lp)
+{
+    if (!ll) return fail(nullptr, POLEE_ERR_BAD_ARG, "null likelihood handle");
+    polee_ctx *ctx = ll->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!xs || !x_grad || K < 1 || K > PSELL_MAX_K)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_eval: bad argument (K must be 1..8)");
+    const size_t n = ll->n, tot = n * K;
+    POLEE_TRY(ll->d_x_rows.upload(ctx, xs, tot));
+    POLEE_TRY(ll->d_x_aos.alloc(ctx, tot));
+    POLEE_TRY(ll->d_g_aos.alloc(ctx, tot));
+    POLEE_TRY(ll->d_g_rows.alloc(ctx, tot));
+    POLEE_TRY(ll->d_lp.alloc(ctx, PSELL_MAX_K));
+    const unsigned nb = (unsigned)ceil_div(tot, 256);
+    hipLaunchKernelGGL(rows_to_aos_kernel, dim3(nb), dim3(256), 0, ctx->stream, ll->d_x_rows.p, K, (int64_t)n,
+                       ll->d_x_aos.p);
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(ll->d_g_aos.p, 0, tot * sizeof(float), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(ll->d_lp.p, 0, PSELL_MAX_K * sizeof(double), ctx->stream));
+    POLEE_TRY(loglik_eval_device(ll, ll->d_x_aos.p, K, ll->d_g_aos.p, lp ? ll->d_lp.p : nullptr));
+    hipLaunchKernelGGL(aos_to_rows_f64_kernel, dim3(nb), dim3(256), 0, ctx->stream, ll->d_g_aos.p, K, (int64_t)n,
+                       ll->d_g_rows.p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(ll->d_g_rows.download(ctx, x_grad, tot));
+    if (lp) {
+        POLEE_TRY(ll->d_lp.download(ctx, lp, K));
+        for (int k = 0; k < K; ++k)
+            if (!std::isfinite(lp[k]))
+                return fail(ctx, POLEE_ERR_NONFINITE, "log-likelihood is not finite (likelihood.jl:50)");
+    }
+    return POLEE_OK;
+}
+
+polee_status polee_efflen_jacobian_adjustment(polee_ctx *ctx, const float *efflens, const float *xs, int32_t K,
+                                              int64_t n, double *x_grad, float *xls)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!efflens || !xs || !x_grad || K < 1 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<float> d_l, d_x, d_xls;
+    DevBuf<double> d_g, d_s;
+    const size_t tot = (size_t)n * K;
+    POLEE_TRY(d_l.upload(ctx, efflens, n));
+    POLEE_TRY(d_x.upload(ctx, xs, tot));
+    POLEE_TRY(d_g.upload(ctx, x_grad, tot));
+    POLEE_TRY(d_s.alloc(ctx, K));
+    if (xls) POLEE_TRY(d_xls.alloc(ctx, tot));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_s.p, 0, K * sizeof(double), ctx->stream));
+    const unsigned nb = (unsigned)std::min<int64_t>(ceil_div(n, 256), 1024);
+    hipLaunchKernelGGL(efflen_sum_kernel, dim3(nb, K), dim3(256), 0, ctx->stream, d_l.p, d_x.p, n, d_s.p);
+    hipLaunchKernelGGL(efflen_adjust_kernel, dim3((unsigned)ceil_div(n, 256), K), dim3(256), 0, ctx->stream, d_l.p,
+                       d_x.p, d_s.p, n, d_g.p, xls ? d_xls.p : nullptr);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(d_g.download(ctx, x_grad, tot));
+    if (xls) POLEE_TRY(d_xls.download(ctx, xls, tot));
+    return POLEE_OK;
+}
+
+}  // extern "C"

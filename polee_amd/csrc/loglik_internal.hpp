@@ -1,0 +1,74 @@
+// Sparse fragment x transcript likelihood: device layout ("PSELL") and internal entry points.
+//
+// PSELL = pattern-sorted sliced ELL with tile-local column dictionaries.
+//   * Fragments (rows of X) are reordered: key = (first transcript / 256, row length,
+//     hash of the row's transcript set).  Reordering rows changes no result (the
+//     likelihood is a sum over fragments); it puts fragments with the same compatible
+//     transcript set next to each other and keeps rows of equal length together.
+//   * 64 consecutive rows form a SLICE, one row per lane of a wavefront, stored
+//     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
+//     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
+//     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
+//   * Up to 32 consecutive slices form a TILE, processed by one 256-thread workgroup.
+//     A tile owns a dictionary of the distinct transcripts its rows touch
+//     (dict: local id u16 -> transcript id u32, at most 1024 entries), so an entry
+//     costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
+//   * The kernel stages the tile's x[dict][K] into LDS, accumulates the tile's gradient
+//     contributions in LDS (ds_add_f32) and flushes L*K values to HBM per tile.
+// HBM traffic per likelihood pass ~ 6 B/nnz (+ padding + dictionaries), read once.
+#pragma once
+#include "common.hpp"
+
+namespace polee {
+
+constexpr int PSELL_LANES = 64;
+constexpr int PSELL_MAX_TILE_COLS = 1024;
+constexpr int PSELL_MAX_TILE_SLICES = 32;
+constexpr int PSELL_MAX_K = 8;
+
+struct PsellHost {
+    int64_t m = 0, n = 0, nnz = 0;
+    int64_t num_slices = 0, num_tiles = 0, padded_nnz = 0, empty_rows = 0;
+    int32_t max_row = 0, max_tile_cols = 0;
+    std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
+    std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units
+    std::vector<uint32_t> tile_slice;  // [num_tiles+1]
+    std::vector<uint32_t> tile_dict;   // [num_tiles+1]
+    std::vector<uint32_t> dict;        // transcript ids (0-based)
+    std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
+    std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
+};
+
+// Builds the layout from X in CSR form (0-based): rowptr [m+1], col [nnz], val [nnz].
+// Returns "" or an error message.
+std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                        const int64_t *ks, PsellHost &out);
+
+}  // namespace polee
+
+struct polee_loglik {
+    polee_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0, nnz = 0;
+    bool has_ks = false;
+    polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
+    polee::DevBuf<uint8_t> d_data;
+    polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
+    polee::DevBuf<float> d_slice_ks;
+    // staging for the host-pointer API
+    polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
+    polee::DevBuf<double> d_g_rows, d_lp;
+    // profiling of the sparse kernel
+    bool profile = false;
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms_total = 0.0;
+    polee_status profile_collect();
+};
+
+namespace polee {
+// d_x, d_g: [n][K] f32 (transcript-major, the K draws of one transcript adjacent).
+// d_g must be zeroed by the caller; the kernel adds into it.  d_lp [K] f64 or null
+// (also accumulated into).
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp);
+}  // namespace polee

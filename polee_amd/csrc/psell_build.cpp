@@ -1,0 +1,180 @@
+// Host-side construction of the PSELL device layout (see loglik_internal.hpp).
+// Plays the role of `Xt = SparseMatrixCSC(transpose(X))` in the reference
+// (src/likelihood-approximation.jl:407): a one-off re-layout of X for the hot loop.
+#include <algorithm>
+#include <numeric>
+
+#include "loglik_internal.hpp"
+
+namespace polee {
+
+static inline uint32_t mix32(uint32_t h, uint32_t v)
+{
+    h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    return h;
+}
+
+// LSD radix sort of (key, value) pairs by 64-bit key, 16 bits per pass, skipping
+// passes whose digit is constant.
+static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &vals)
+{
+    const size_t N = keys.size();
+    if (N < 2) return;
+    std::vector<uint64_t> k2(N);
+    std::vector<uint32_t> v2(N);
+    std::vector<size_t> hist(65536);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = pass * 16;
+        std::fill(hist.begin(), hist.end(), 0);
+        for (size_t i = 0; i < N; ++i) hist[(keys[i] >> sh) & 0xffff]++;
+        if (hist[(keys[0] >> sh) & 0xffff] == N) continue;
+        size_t sum = 0;
+        for (size_t d = 0; d < 65536; ++d) {
+            size_t c = hist[d];
+            hist[d] = sum;
+            sum += c;
+        }
+        for (size_t i = 0; i < N; ++i) {
+            size_t p = hist[(keys[i] >> sh) & 0xffff]++;
+            k2[p] = keys[i];
+            v2[p] = vals[i];
+        }
+        keys.swap(k2);
+        vals.swap(v2);
+    }
+}
+
+std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                        const int64_t *ks, PsellHost &out)
+{
+    if (m < 0 || n < 1) return "bad matrix dimensions";
+    if (n > (int64_t)1 << 31) return "more than 2^31 transcripts is not supported";
+    out = PsellHost();
+    out.m = m;
+    out.n = n;
+    out.nnz = (int64_t)rowptr[m];
+
+    int binsh = 8;
+    if (const char *e = getenv("POLEE_PSELL_BINSH")) binsh = std::max(0, std::min(24, atoi(e)));
+
+    // 1. sort keys
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> rows;
+    keys.reserve(m);
+    rows.reserve(m);
+    for (int64_t i = 0; i < m; ++i) {
+        const uint64_t b = rowptr[i], e = rowptr[i + 1];
+        if (e < b) return "row offsets are not monotone";
+        const uint64_t len = e - b;
+        if (len == 0) {
+            ++out.empty_rows;
+            continue;
+        }
+        if (len > (uint64_t)PSELL_MAX_TILE_COLS) return "a fragment is compatible with more than 1024 transcripts";
+        uint32_t h = 0x12345u, first = col[b];
+        for (uint64_t k = b; k < e; ++k) {
+            if (col[k] >= (uint64_t)n) return "transcript index out of range";
+            h = mix32(h, col[k]);
+            first = std::min(first, col[k]);
+        }
+        out.max_row = std::max<int32_t>(out.max_row, (int32_t)len);
+        const uint64_t key = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)std::min<uint64_t>(len, 255) << 32) | h;
+        keys.push_back(key);
+        rows.push_back((uint32_t)i);
+    }
+    radix_sort_pairs(keys, rows);
+    keys.clear();
+    keys.shrink_to_fit();
+
+    // 2. greedy slices and tiles
+    std::vector<uint32_t> col_stamp(n, 0);   // tile id + 1 in which the column was last registered
+    std::vector<uint16_t> col_local(n, 0);
+    out.data.reserve((size_t)((double)out.nnz * 6.6) + 4096);
+    out.slice_off.push_back(0);
+    out.tile_slice.push_back(0);
+    out.tile_dict.push_back(0);
+    if (ks) out.slice_ks.reserve(rows.size() + 64);
+    out.row_order.reserve(rows.size() + 64);
+
+    uint32_t tile_id = 1;        // stamp of the current tile
+    uint32_t tile_cols = 0;      // dictionary size of the current tile
+    uint32_t tile_nslices = 0;
+    std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
+    slice_rows.reserve(PSELL_LANES);
+
+    auto close_slice = [&]() {
+        if (slice_rows.empty()) return;
+        uint32_t w = 0;
+        for (uint32_t r : slice_rows) w = std::max<uint32_t>(w, (uint32_t)(rowptr[r + 1] - rowptr[r]));
+        const size_t base = out.data.size();
+        out.data.resize(base + (size_t)w * 384, 0);
+        float *vals = reinterpret_cast<float *>(out.data.data() + base);
+        uint16_t *lcols = reinterpret_cast<uint16_t *>(out.data.data() + base + (size_t)w * 256);
+        for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
+            const uint32_t r = slice_rows[lane];
+            const uint64_t b = rowptr[r], len = rowptr[r + 1] - b;
+            uint16_t last = 0;
+            for (uint32_t t = 0; t < w; ++t) {
+                if (t < len) {
+                    vals[(size_t)t * 64 + lane] = val[b + t];
+                    last = col_local[col[b + t]];
+                }
+                lcols[(size_t)t * 64 + lane] = last;  // padding repeats the last valid local id
+            }
+        }
+        for (size_t lane = 0; lane < PSELL_LANES; ++lane) {
+            const bool valid = lane < slice_rows.size();
+            out.row_order.push_back(valid ? slice_rows[lane] : 0xffffffffu);
+            if (ks) out.slice_ks.push_back(valid ? (float)ks[slice_rows[lane]] : 0.0f);
+        }
+        out.padded_nnz += (int64_t)w * 64;
+        out.slice_off.push_back((uint32_t)(out.data.size() / 128));
+        ++out.num_slices;
+        ++tile_nslices;
+        slice_rows.clear();
+    };
+    auto close_tile = [&]() {
+        if (tile_nslices == 0) return;
+        out.tile_slice.push_back((uint32_t)out.num_slices);
+        out.tile_dict.push_back((uint32_t)out.dict.size());
+        out.max_tile_cols = std::max<int32_t>(out.max_tile_cols, (int32_t)tile_cols);
+        ++out.num_tiles;
+        ++tile_id;
+        tile_cols = 0;
+        tile_nslices = 0;
+    };
+
+    for (size_t ri = 0; ri < rows.size(); ++ri) {
+        const uint32_t r = rows[ri];
+        const uint64_t b = rowptr[r], e = rowptr[r + 1];
+        for (;;) {
+            uint32_t fresh = 0;
+            for (uint64_t k = b; k < e; ++k) fresh += col_stamp[col[k]] != tile_id;
+            if (tile_cols + fresh <= (uint32_t)PSELL_MAX_TILE_COLS) break;
+            // does not fit into the current tile: finish it (possibly with a partial slice)
+            close_slice();
+            close_tile();
+        }
+        for (uint64_t k = b; k < e; ++k) {
+            const uint32_t c = col[k];
+            if (col_stamp[c] != tile_id) {
+                col_stamp[c] = tile_id;
+                col_local[c] = (uint16_t)tile_cols++;
+                out.dict.push_back(c);
+            }
+        }
+        slice_rows.push_back(r);
+        if (slice_rows.size() == PSELL_LANES) {
+            close_slice();
+            if (tile_nslices >= (uint32_t)PSELL_MAX_TILE_SLICES) close_tile();
+        }
+    }
+    close_slice();
+    close_tile();
+    if (out.data.size() / 128 > 0xffffffffull) return "matrix too large for 32-bit slice offsets";
+    return "";
+}
+
+}  // namespace polee

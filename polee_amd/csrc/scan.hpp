@@ -1,0 +1,203 @@
+// Batched prefix sums for the tree kernels (gfx950, wave64).
+//
+// Every Polya-tree operation of the reference is a serial pointer-chasing walk
+// (src/ptt.jl:134-155,175-207; hsb_ops.cpp:87-109,212-238,342-391).  Because the nodes
+// are in DFS pre-order, those walks are prefix sums over (a) the Euler tour of the tree
+// or (b) the leaves in DFS order, so one three-phase scan serves all of them:
+//   scan_reduce  : one workgroup per 1024-element chunk -> chunk total
+//   scan_spine   : one workgroup per batch row -> exclusive scan of chunk totals
+//   scan_apply   : re-loads the chunk, scans it with the chunk offset, hands every
+//                  element's exclusive/inclusive prefix to an emit functor
+// Element types: double (log-space products) and dd (double-double, ~1e-32 relative)
+// for sums whose differences are taken afterwards -- subtree sums come out with full
+// f64 relative accuracy, as the reference's exact tree recursion gives.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace polee {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
+
+struct dd {
+    double hi, lo;
+};
+
+__host__ __device__ inline dd dd_make(double a) { return dd{a, 0.0}; }
+
+// Error-free transformation based double-double addition (Knuth TwoSum + renormalise).
+__host__ __device__ inline dd dd_add(dd a, dd b)
+{
+    double s = a.hi + b.hi;
+    double bb = s - a.hi;
+    double e = (a.hi - (s - bb)) + (b.hi - bb);
+    e += a.lo + b.lo;
+    double hi = s + e;
+    double lo = e - (hi - s);
+    return dd{hi, lo};
+}
+__host__ __device__ inline dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+// (a - b) rounded to double
+__host__ __device__ inline double dd_diff(dd a, dd b)
+{
+    dd r = dd_add(a, dd_neg(b));
+    return r.hi + r.lo;
+}
+
+template <typename T>
+struct ScanOps;
+template <>
+struct ScanOps<double> {
+    __device__ static double zero() { return 0.0; }
+    __device__ static double add(double a, double b) { return a + b; }
+    __device__ static double shfl_up(double v, int d) { return __shfl_up(v, d, 64); }
+};
+template <>
+struct ScanOps<dd> {
+    __device__ static dd zero() { return dd{0.0, 0.0}; }
+    __device__ static dd add(dd a, dd b) { return dd_add(a, b); }
+    __device__ static dd shfl_up(dd v, int d) { return dd{__shfl_up(v.hi, d, 64), __shfl_up(v.lo, d, 64)}; }
+};
+
+// Inclusive scan across the 64 lanes of a wave.
+template <typename T>
+__device__ inline T wave_inclusive_scan(T v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = ScanOps<T>::shfl_up(v, d);
+        if (lane >= d) v = ScanOps<T>::add(o, v);
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread block; also returns the
+// block total.  `smem` must hold 4 T's.
+template <typename T>
+__device__ inline T block_exclusive_scan(T v, T *smem, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T inc = wave_inclusive_scan<T>(v);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    T woff = ScanOps<T>::zero();
+    T tot = ScanOps<T>::zero();
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        if (w < wave) woff = ScanOps<T>::add(woff, smem[w]);
+        tot = ScanOps<T>::add(tot, smem[w]);
+    }
+    __syncthreads();
+    // exclusive = (wave offset) + (inclusive of previous lane)
+    T prev = ScanOps<T>::shfl_up(inc, 1);
+    if (lane == 0) prev = ScanOps<T>::zero();
+    *total = tot;
+    return ScanOps<T>::add(woff, prev);
+}
+
+// Load functor: T operator()(int row, int64_t idx) -- value of element idx (< len).
+template <typename T, typename Load>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load load, int64_t len, int nchunks,
+                                                                  T *chunk_sums)
+{
+    __shared__ T smem[SCAN_THREADS / 64];
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const int64_t base = (int64_t)chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = ScanOps<T>::zero();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < len) acc = ScanOps<T>::add(acc, load(row, base + j));
+    T tot;
+    (void)block_exclusive_scan<T>(acc, smem, &tot);
+    if (threadIdx.x == 0) chunk_sums[(int64_t)row * nchunks + chunk] = tot;
+}
+
+// In-place exclusive scan of each row's chunk totals; one workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_spine_kernel(T *chunk_sums, int nchunks)
+{
+    __shared__ T smem[SCAN_THREADS / 64];
+    T *row = chunk_sums + (int64_t)blockIdx.x * nchunks;
+    const int per = (nchunks + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int b = threadIdx.x * per, e = min(b + per, nchunks);
+    T acc = ScanOps<T>::zero();
+    for (int i = b; i < e; ++i) acc = ScanOps<T>::add(acc, row[i]);
+    T tot;
+    T off = block_exclusive_scan<T>(acc, smem, &tot);
+    for (int i = b; i < e; ++i) {
+        T v = row[i];
+        row[i] = off;
+        off = ScanOps<T>::add(off, v);
+    }
+}
+
+// Emit functor: void operator()(int row, int64_t idx, T exclusive, T inclusive).
+// `fin` (optional) is called once per row by the thread that owns the last element
+// with the row total: void fin(int row, T total).
+template <typename T, typename Load, typename Emit>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(Load load, Emit emit, int64_t len, int nchunks,
+                                                                 const T *chunk_offsets)
+{
+    __shared__ T smem[SCAN_THREADS / 64];
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const int64_t base = (int64_t)chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T acc = ScanOps<T>::zero();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = (base + j < len) ? load(row, base + j) : ScanOps<T>::zero();
+        acc = ScanOps<T>::add(acc, v[j]);
+    }
+    T tot;
+    T off = block_exclusive_scan<T>(acc, smem, &tot);
+    off = ScanOps<T>::add(chunk_offsets[(int64_t)row * nchunks + chunk], off);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        T inc = ScanOps<T>::add(off, v[j]);
+        if (base + j < len) emit(row, base + j, off, inc);
+        off = inc;
+    }
+}
+
+inline int scan_num_chunks(int64_t len) { return (int)((len + SCAN_CHUNK - 1) / SCAN_CHUNK); }
+
+// Runs the three phases on `stream`.  chunk_buf must hold rows * scan_num_chunks(len) T's.
+template <typename T, typename Load, typename Emit>
+inline hipError_t run_scan(hipStream_t stream, int rows, int64_t len, T *chunk_buf, Load load, Emit emit)
+{
+    if (rows <= 0 || len <= 0) return hipSuccess;
+    const int nchunks = scan_num_chunks(len);
+    dim3 grid(nchunks, rows);
+    if (nchunks > 1) {
+        hipLaunchKernelGGL((scan_reduce_kernel<T, Load>), grid, dim3(SCAN_THREADS), 0, stream, load, len, nchunks,
+                           chunk_buf);
+        hipLaunchKernelGGL((scan_spine_kernel<T>), dim3(rows), dim3(SCAN_THREADS), 0, stream, chunk_buf, nchunks);
+    } else {
+        hipError_t e = hipMemsetAsync(chunk_buf, 0, sizeof(T) * rows, stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((scan_apply_kernel<T, Load, Emit>), grid, dim3(SCAN_THREADS), 0, stream, load, emit, len,
+                       nchunks, chunk_buf);
+    return hipGetLastError();
+}
+
+// Block-wide sum of doubles (256 threads); result valid in thread 0.
+__device__ inline double block_sum_f64(double v, double *smem4)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) smem4[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += smem4[w];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace polee

@@ -1,0 +1,695 @@
+// The likelihood-approximation VI loop, device resident.
+// Replaces approximate_likelihood(::LogitSkewNormalPTTApprox, sample)
+// (src/likelihood-approximation.jl:395-575), ADAM (:107-146), the factored variant
+// (:248-392), and the element-wise reparameterisations (src/logitnormal.jl:8-55,
+// src/sinh_arcsinh.jl:10-38), plus the sampler (src/approx-sampler.jl:37-44).
+//
+// One VI iteration = the K Monte-Carlo draws evaluated TOGETHER (one pass over X):
+//   sample   : z0 -> sinh-arcsinh -> logit-normal -> clamp              -> ys [K][n-1] f64
+//   forward  : Euler-tour scan (ptt_forward_device)                      -> xs [n][K] f32, leaf u
+//   loglik   : loglik_eval_device (PSELL kernel)                         -> g  [n][K] f32
+//   backward : double-double scan of u*(g - efflen term) over leaf order -> C  [K][n+1]
+//   update   : per internal node: y_grad from C, chain rule through both
+//              reparameterisations, mean over K, finiteness flag, ADAM   -> mu, omega, alpha
+// No host synchronisation inside polee_vi_run.
+#include "loglik_internal.hpp"
+#include "ptt_internal.hpp"
+
+#include <cmath>
+
+namespace polee {
+
+// ---- counter-based RNG: Philox4x32-10, one N(0,1) per (seed, step, draw, k) -------------
+__host__ __device__ inline void philox_round(uint32_t (&c)[4], const uint32_t (&k)[2])
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+}
+__device__ inline float philox_randn(uint64_t seed, uint32_t step, uint32_t draw, uint32_t k)
+{
+    uint32_t c[4] = {k, draw, step, 0x706f6c65u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, key);
+        key[0] += 0x9E3779B9u;
+        key[1] += 0xBB67AE85u;
+    }
+    // Box-Muller on two 32-bit uniforms in (0,1)
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+struct NoiseSrc {
+    const float *z0;  // device [steps][K][n-1] or null
+    uint64_t seed;
+    int32_t K;
+    int64_t nm1;
+    __device__ inline float get(int step /*1-based*/, int d, int64_t k) const
+    {
+        if (z0) return z0[((int64_t)(step - 1) * K + d) * nm1 + k];
+        return philox_randn(seed, (uint32_t)step, (uint32_t)d, (uint32_t)k);
+    }
+};
+
+__device__ inline float logistic_f32(float x) { return 1.0f / (1.0f + expf(-x)); }  // logitnormal.jl:2
+
+// sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform!
+// (logitnormal.jl:8-20) -> clamp!(ys, eps, 1-eps) (likelihood-approximation.jl:523).
+// ladj_out [K][2] (skew, logit-normal) accumulated when non-null (unclamped y, as the
+// reference computes them before the clamp).
+__global__ void vi_sample_kernel(const float *mu, const float *omega, const float *alpha, NoiseSrc noise, int step,
+                                 double y_eps, int clamp, double *ys, double *ladj_out)
+{
+    __shared__ double smd[4];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    double l_skew = 0.0, l_ln = 0.0;
+    if (k < noise.nm1) {
+        const float z0 = noise.get(step, d, k);
+        const float c = alpha[k] + asinhf(z0);
+        const float zs = sinhf(c);
+        const float sigma = expf(omega[k]);
+        double y = (double)logistic_f32(mu[k] + zs * sigma);
+        if (ladj_out) {
+            l_skew = (double)logf(coshf(c)) - 0.5 * (double)log1pf(z0 * z0);
+            l_ln = log((double)sigma * y * (1 - y));
+        }
+        if (clamp) y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
+        ys[(int64_t)d * noise.nm1 + k] = y;
+    }
+    if (ladj_out) {
+        l_skew = block_sum_f64(l_skew, smd);
+        l_ln = block_sum_f64(l_ln, smd);
+        if (threadIdx.x == 0) {
+            atomicAdd(&ladj_out[d * 2 + 0], l_skew);
+            atomicAdd(&ladj_out[d * 2 + 1], l_ln);
+        }
+    }
+}
+
+// backward scan summand: a = u_leaf * x_grad with the effective-length Jacobian term
+// (likelihood.jl:93-110) folded in: x_grad[j] -= n (1/efflen_j) / sum_i x_i/efflen_i.
+struct ViLeafLoad {
+    PttView v;
+    const double *uleaf;    // [K][n] leaf order
+    const float *g;         // [n][K]
+    const float *efflens;   // [n] or null
+    const double *row_sums; // [K][2], [0] = sum x/efflen
+    int K;
+    __device__ inline double xgrad(int row, int tid) const
+    {
+        double xg = (double)g[(int64_t)tid * K + row];
+        if (efflens) xg -= (double)((float)v.n * (1.0f / efflens[tid])) / row_sums[row * 2];
+        return xg;
+    }
+    __device__ dd operator()(int row, int64_t pos) const
+    {
+        const int tid = v.leaf_tid[pos];
+        return dd_make(uleaf[(int64_t)row * v.n + pos] * xgrad(row, tid));
+    }
+};
+
+struct AdamConsts {
+    double lr, rm, rv, eps, m_denom, v_denom;
+    double max_mu, max_omega, max_alpha;
+    int first;  // step_num == 1
+};
+
+__device__ inline float adam_one(float &p, float &m, float &v, float grad, const AdamConsts &a, double max_step)
+{
+    // adam_update_mv! (likelihood-approximation.jl:116-130)
+    if (a.first) {
+        m = grad;
+        v = grad * grad;
+    } else {
+        m = (float)(a.rm * (double)m + (1 - a.rm) * (double)grad);
+        v = (float)(a.rv * (double)v + (1 - a.rv) * (double)(grad * grad));
+    }
+    // adam_update_params! (likelihood-approximation.jl:136-146) -- ascent, clamped step
+    const double pm = (double)m / a.m_denom, pv = (double)v / a.v_denom;
+    double delta = a.lr * pm / (sqrt(pv) + a.eps);
+    delta = delta < -max_step ? -max_step : (delta > max_step ? max_step : delta);
+    p = (float)((double)p + delta);
+    return p;
+}
+
+// update: one thread per internal node k, looping over the K draws.
+//   y_grad[k] = H_l / y - H_r / (1 - y)   (closed form of ptt.jl:167-209, see ptt.hip)
+//   logit_normal_transform_gradients! (logitnormal.jl:38-55),
+//   sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38),
+//   omega_grad += sigma * sigma_grad (likelihood-approximation.jl:547-549), / K (:552-557)
+template <int K>
+__global__ void vi_update_kernel(PttView v, const double *ys, const dd *C, NoiseSrc noise, int step, float *mu,
+                                 float *omega, float *alpha, float *m_mu, float *v_mu, float *m_omega, float *v_omega,
+                                 float *m_alpha, float *v_alpha, AdamConsts adam, int apply, int *nonfinite_step,
+                                 double *y_grad_out, float *mu_grad_out, float *omega_grad_out, float *alpha_grad_out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nm1 = v.n - 1;
+    if (k >= nm1) return;
+    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    const double cnt_r = (double)(mid - lo - 1), cnt_l = (double)(hi1 - mid - 1);
+    const float muk = mu[k], omk = omega[k], alk = alpha[k];
+    const float sigma = expf(omk);
+    float mu_g = 0.f, om_g = 0.f, al_g = 0.f;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const dd *Cr = C + (int64_t)d * (v.n + 1);
+        const double Hr = cnt_r + dd_diff(Cr[mid], Cr[lo]);
+        const double Hl = cnt_l + dd_diff(Cr[hi1], Cr[mid]);
+        const double y = ys[(int64_t)d * nm1 + k];
+        const double ygd = Hl / y - Hr / (1.0 - y);
+        if (y_grad_out) y_grad_out[(int64_t)d * nm1 + k] = ygd;
+        const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
+        const float z0 = noise.get(step, d, k);
+        const float c = alk + asinhf(z0);
+        const float zs = sinhf(c);
+        const double dyy = y * (1 - y);
+        // per-draw accumulators start at zero (fill! at :513-516)
+        mu_g = (float)((double)mu_g + dyy * (double)yg);  // mu_grad accumulates across draws in f32
+        mu_g = (float)((double)mu_g + (1 - 2 * y));
+        float sg = (float)(dyy * (double)zs * (double)yg);
+        sg = (float)((double)sg + ((double)(1.0f / sigma) + (double)zs * (1 - 2 * y)));
+        float zg = (float)(dyy * (double)sigma * (double)yg);
+        zg = (float)((double)zg + (double)sigma * (1 - 2 * y));
+        al_g += coshf(c) * zg;
+        al_g += tanhf(c);
+        om_g += sigma * sg;
+    }
+    mu_g /= (float)K;
+    om_g /= (float)K;
+    al_g /= (float)K;
+    if (mu_grad_out) mu_grad_out[k] = mu_g;
+    if (omega_grad_out) omega_grad_out[k] = om_g;
+    if (alpha_grad_out) alpha_grad_out[k] = al_g;
+    if (!(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
+    if (apply) {
+        float p = muk, mm = m_mu[k], vv = v_mu[k];
+        adam_one(p, mm, vv, mu_g, adam, adam.max_mu);
+        mu[k] = p; m_mu[k] = mm; v_mu[k] = vv;
+        p = omk; mm = m_omega[k]; vv = v_omega[k];
+        adam_one(p, mm, vv, om_g, adam, adam.max_omega);
+        omega[k] = p; m_omega[k] = mm; v_omega[k] = vv;
+        p = alk; mm = m_alpha[k]; vv = v_alpha[k];
+        adam_one(p, mm, vv, al_g, adam, adam.max_alpha);
+        alpha[k] = p; m_alpha[k] = mm; v_alpha[k] = vv;
+    }
+}
+
+// elbo bookkeeping of the !gradonly mode: `elbo = lp + skew_ladj + ln_ladj + hsb_ladj` is an
+// ASSIGNMENT inside the draw loop (likelihood-approximation.jl:537) followed by `/= K`
+// (:561), i.e. the last draw's value over K.  lp_mean is the mean log-likelihood over draws.
+__global__ void vi_trace_kernel(const double *lp, const double *ladj_el, const double *row_sums, int K, int idx,
+                                double *elbo_trace, double *lp_trace)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int d = K - 1;
+    elbo_trace[idx] = (lp[d] + ladj_el[d * 2 + 0] + ladj_el[d * 2 + 1] + row_sums[d * 2 + 1]) / K;
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) s += lp[i];
+    lp_trace[idx] = s / K;
+}
+
+__global__ void vi_init_mu_kernel(const double *ys, int64_t nm1, float *mu, float *omega, float *alpha)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nm1) return;
+    const double y = ys[k];
+    mu[k] = (float)log(y / (1 - y));  // logit (logitnormal.jl:4)
+    omega[k] = logf(0.1f);
+    alpha[k] = 0.0f;
+}
+
+__global__ void aos_to_rows_f32_kernel(const float *in, int K, int64_t n, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * K) return;
+    const int k = (int)(i / n);
+    const int64_t j = i - (int64_t)k * n;
+    out[i] = in[j * K + k];
+}
+
+// x_grad after the effective length adjustment, as rows [K][n] f64 (test hook output).
+__global__ void vi_xgrad_rows_kernel(ViLeafLoad l, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)l.v.n * l.K) return;
+    const int k = (int)(i / l.v.n);
+    const int tid = (int)(i - (int64_t)k * l.v.n);
+    out[i] = l.xgrad(k, tid);
+}
+
+// inverse_transform!(t, fill(1.0f0/n, n), ys) (likelihood-approximation.jl:451): every leaf holds 1/n
+struct UniformLeafLoad {
+    double val;
+    __device__ dd operator()(int, int64_t) const { return dd_make(val); }
+};
+__global__ void vi_inverse_nodes_kernel(PttView v, const dd *C, double *ys)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= v.n - 1) return;
+    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    const double ur = dd_diff(C[mid], C[lo]);
+    const double ul = dd_diff(C[hi1], C[mid]);
+    ys[k] = ul / (ul + ur);
+}
+
+// sampler: rand! (approx-sampler.jl:37-44) -- no clamp of ys
+__global__ void sampler_y_kernel(const float *mu, const float *sigma, const float *alpha, NoiseSrc noise, double *ys)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (k >= noise.nm1) return;
+    const float z0 = noise.get(1, d, k);
+    const float zs = sinhf(alpha[k] + asinhf(z0));
+    ys[(int64_t)d * noise.nm1 + k] = (double)logistic_f32(mu[k] + zs * sigma[k]);
+}
+
+__global__ void export_noise_kernel(NoiseSrc noise, int step, float *out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (k < noise.nm1) out[(int64_t)d * noise.nm1 + k] = noise.get(step, d, k);
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+struct polee_vi {
+    polee_ctx *ctx = nullptr;
+    polee_loglik *ll = nullptr;
+    polee_ptt *t = nullptr;
+    polee_vi_opts o;
+    int32_t n = 0, K = 0;
+    int32_t step = 0;  // steps completed
+    int32_t trace_cap = 0;
+    DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
+    DevBuf<double> d_ys, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
+    DevBuf<int> d_flag;
+    // outputs of the test hook
+    DevBuf<double> d_ygrad, d_xgrad_rows;
+    DevBuf<float> d_mug, d_omg, d_alg, d_x_rows;
+
+    NoiseSrc noise() const { return NoiseSrc{d_z0.p, o.seed, K, (int64_t)n - 1}; }
+    polee_status one_step(bool apply, bool want_values, bool hook_outputs);
+};
+
+polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
+{
+    const int64_t nm1 = n - 1;
+    const int step_num = step + 1;
+    hipStream_t st = ctx->stream;
+    POLEE_TRY(t->reserve(K));
+    if (o.z0 && step_num > o.num_steps)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "caller-supplied z0 covers only %d steps", o.num_steps);
+
+    // sample
+    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(d_ladj_el.p, 0, sizeof(double) * K * 2, st));
+    if (nm1 > 0) {
+        dim3 grid((unsigned)ceil_div(nm1, 256), K);
+        hipLaunchKernelGGL(vi_sample_kernel, grid, dim3(256), 0, st, d_mu.p, d_omega.p, d_alpha.p, noise(), step_num,
+                           o.y_eps, 1, d_ys.p, want_values ? d_ladj_el.p : nullptr);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526)
+    FwdOut fo;
+    fo.uleaf = t->d_uleaf.p;
+    fo.xs = d_x.p;
+    fo.xs_rs = 1;
+    fo.xs_es = K;
+    fo.clamp_lo = (float)o.y_eps;
+    fo.clamp_hi = (float)(1.0 - o.y_eps);
+    fo.efflens = o.use_efflen_jacobian ? d_efflens.p : nullptr;
+    fo.row_sums = (o.use_efflen_jacobian || want_values) ? d_rows.p : nullptr;
+    POLEE_TRY(ptt_forward_device(t, d_ys.p, K, fo));
+    // likelihood
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_g.p, 0, sizeof(float) * (size_t)n * K, st));
+    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
+    POLEE_TRY(loglik_eval_device(ll, d_x.p, K, d_g.p, want_values ? d_lp.p : nullptr));
+    // backward scan over leaves
+    ViLeafLoad load{t->view(), t->d_uleaf.p, d_g.p, o.use_efflen_jacobian ? d_efflens.p : nullptr, d_rows.p, K};
+    LeafPrefixEmit emit{n, t->d_C.p};
+    hipError_t e = run_scan_partial<dd>(st, K, n, t->d_chunk.p, nullptr, load, emit);
+    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "backward scan launch failed: %s", hipGetErrorString(e));
+    if (hook_outputs) {
+        hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st, load,
+                           d_xgrad_rows.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    // update
+    if (nm1 > 0) {
+        AdamConsts a;
+        // adam_learning_rate(step_num - 1) (likelihood-approximation.jl:107-110, 497)
+        a.lr = std::max(o.adam_min_learning_rate,
+                        o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));
+        a.rm = o.adam_rm;
+        a.rv = o.adam_rv;
+        a.eps = o.adam_eps;
+        a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
+        a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
+        a.max_mu = o.max_mu_step;
+        a.max_omega = o.max_omega_step;
+        a.max_alpha = o.max_alpha_step;
+        a.first = step_num == 1;
+        dim3 grid((unsigned)ceil_div(nm1, 256));
+#define POLEE_UPD(KK)                                                                                              \
+    hipLaunchKernelGGL((vi_update_kernel<KK>), grid, dim3(256), 0, st, t->view(), d_ys.p, t->d_C.p, noise(),       \
+                       step_num, d_mu.p, d_omega.p, d_alpha.p, d_mm.p, d_vm.p, d_mo.p, d_vo.p, d_ma.p, d_va.p, a,  \
+                       apply ? 1 : 0, d_flag.p, hook_outputs ? d_ygrad.p : nullptr,                                \
+                       hook_outputs ? d_mug.p : nullptr, hook_outputs ? d_omg.p : nullptr,                         \
+                       hook_outputs ? d_alg.p : nullptr)
+        switch (K) {
+            case 1: POLEE_UPD(1); break;
+            case 2: POLEE_UPD(2); break;
+            case 3: POLEE_UPD(3); break;
+            case 4: POLEE_UPD(4); break;
+            case 5: POLEE_UPD(5); break;
+            case 6: POLEE_UPD(6); break;
+            case 7: POLEE_UPD(7); break;
+            case 8: POLEE_UPD(8); break;
+        }
+#undef POLEE_UPD
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    if (want_values && apply && step < trace_cap) {
+        hipLaunchKernelGGL(vi_trace_kernel, dim3(1), dim3(64), 0, st, d_lp.p, d_ladj_el.p, d_rows.p, K, step, d_elbo.p,
+                           d_lptrace.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    if (apply) ++step;
+    return POLEE_OK;
+}
+
+extern "C" {
+
+void polee_vi_default_opts(polee_vi_opts *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->num_steps = 500;           // LIKAP_NUM_STEPS (constants.jl:64)
+    o->num_mc_samples = 6;        // LIKAP_NUM_MC_SAMPLES (constants.jl:65)
+    o->use_efflen_jacobian = 1;
+    o->gradonly = 1;
+    o->seed = 123456789ull;       // main.jl:126
+    o->z0 = nullptr;
+    o->y_eps = 1e-10;             // LIKAP_Y_EPS (constants.jl:48)
+    o->adam_initial_learning_rate = 1.0;
+    o->adam_learning_rate_decay = 2e-2;
+    o->adam_min_learning_rate = 1e-3;
+    o->adam_eps = 1e-8;
+    o->adam_rv = 0.9;
+    o->adam_rm = 0.7;
+    o->max_mu_step = 2e-1;        // likelihood-approximation.jl:421-423
+    o->max_omega_step = 2e-1;
+    o->max_alpha_step = 2e-2;
+    o->profile = 0;
+}
+
+polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflens, const polee_vi_opts *opts,
+                             polee_vi **out)
+{
+    if (!ll || !t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ll->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (t->ctx != ctx) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood and tree belong to different contexts");
+    if (!out || !efflens) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    if (t->T != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "the VI loop needs a single tree");
+    if ((int64_t)t->n != ll->n)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "tree has %d leaves but X has %lld transcripts", t->n, (long long)ll->n);
+    polee_vi_opts o;
+    if (opts)
+        o = *opts;
+    else
+        polee_vi_default_opts(&o);
+    if (o.num_mc_samples < 1 || o.num_mc_samples > PSELL_MAX_K)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "num_mc_samples must be in 1..8");
+    if (o.num_steps < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "num_steps must be >= 0");
+    polee_vi *vi = new (std::nothrow) polee_vi();
+    if (!vi) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    vi->ctx = ctx;
+    vi->ll = ll;
+    vi->t = t;
+    vi->o = o;
+    vi->n = t->n;
+    vi->K = o.num_mc_samples;
+    ll->profile = o.profile != 0;
+    const size_t n = vi->n, nm1 = std::max<size_t>(n - 1, 1), K = vi->K;
+    polee_status s = POLEE_OK;
+    auto A = [&](polee_status r) {
+        if (s == POLEE_OK) s = r;
+    };
+    A(vi->d_efflens.upload(ctx, efflens, n));
+    for (DevBuf<float> *b : {&vi->d_mu, &vi->d_omega, &vi->d_alpha, &vi->d_mm, &vi->d_vm, &vi->d_mo, &vi->d_vo,
+                             &vi->d_ma, &vi->d_va, &vi->d_mug, &vi->d_omg, &vi->d_alg})
+        A(b->alloc(ctx, nm1));
+    A(vi->d_x.alloc(ctx, n * K));
+    A(vi->d_g.alloc(ctx, n * K));
+    A(vi->d_x_rows.alloc(ctx, n * K));
+    A(vi->d_ys.alloc(ctx, nm1 * K));
+    A(vi->d_ygrad.alloc(ctx, nm1 * K));
+    A(vi->d_xgrad_rows.alloc(ctx, n * K));
+    A(vi->d_lp.alloc(ctx, PSELL_MAX_K));
+    A(vi->d_ladj_el.alloc(ctx, PSELL_MAX_K * 2));
+    A(vi->d_rows.alloc(ctx, PSELL_MAX_K * 2));
+    A(vi->d_flag.alloc(ctx, 1));
+    vi->trace_cap = o.gradonly ? 0 : std::max(o.num_steps, 1);
+    if (!o.gradonly) {
+        A(vi->d_elbo.alloc(ctx, vi->trace_cap));
+        A(vi->d_lptrace.alloc(ctx, vi->trace_cap));
+    }
+    if (o.z0 && o.num_steps > 0) A(vi->d_z0.upload(ctx, o.z0, (size_t)o.num_steps * K * (n - 1)));
+    vi->o.z0 = o.z0;  // only its null-ness is used from here on
+    A(t->reserve((int32_t)K));
+    if (s != POLEE_OK) {
+        delete vi;
+        return s;
+    }
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemsetAsync(vi->d_flag.p, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(vi->d_rows.p, 0, sizeof(double) * PSELL_MAX_K * 2, st);
+    for (DevBuf<float> *b : {&vi->d_mm, &vi->d_vm, &vi->d_mo, &vi->d_vo, &vi->d_ma, &vi->d_va})
+        if (e == hipSuccess) e = hipMemsetAsync(b->p, 0, sizeof(float) * nm1, st);
+    if (e != hipSuccess) {
+        delete vi;
+        return fail(ctx, POLEE_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
+    }
+    // initial values (likelihood-approximation.jl:451-456): mu = logit(inverse_transform!(fill(1/n)))
+    if (n > 1) {
+        UniformLeafLoad load{(double)(1.0f / (float)n)};
+        LeafPrefixEmit emit{(int32_t)n, t->d_C.p};
+        e = run_scan_partial<dd>(st, 1, n, t->d_chunk.p, nullptr, load, emit);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(vi_inverse_nodes_kernel, dim3((unsigned)ceil_div(n - 1, 256)), dim3(256), 0, st,
+                               t->view(), t->d_C.p, vi->d_ys.p);
+            hipLaunchKernelGGL(vi_init_mu_kernel, dim3((unsigned)ceil_div(n - 1, 256)), dim3(256), 0, st, vi->d_ys.p,
+                               (int64_t)n - 1, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            delete vi;
+            return fail(ctx, POLEE_ERR_HIP, "initialisation failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = vi;
+    return POLEE_OK;
+}
+
+void polee_vi_destroy(polee_vi *vi)
+{
+    if (!vi) return;
+    if (vi->ctx) {
+        (void)hipSetDevice(vi->ctx->device);
+        (void)hipStreamSynchronize(vi->ctx->stream);
+    }
+    delete vi;
+}
+
+polee_status polee_vi_run(polee_vi *vi, int32_t nsteps)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    POLEE_TRY(use_device(vi->ctx));
+    vi->ll->profile = vi->o.profile != 0;
+    for (int32_t i = 0; i < nsteps; ++i) POLEE_TRY(vi->one_step(true, !vi->o.gradonly, false));
+    return POLEE_OK;
+}
+
+polee_status polee_vi_sync(polee_vi *vi)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    int flag = 0;
+    POLEE_TRY(vi->d_flag.download(ctx, &flag, 1));
+    if (vi->ll->profile) POLEE_TRY(vi->ll->profile_collect());
+    if (flag != 0)
+        return fail(ctx, POLEE_ERR_NONFINITE, "non-finite gradient at VI step %d (likelihood-approximation.jl:559)",
+                    flag);
+    return POLEE_OK;
+}
+
+polee_status polee_vi_get_params(polee_vi *vi, float *mu, float *omega, float *alpha)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    const size_t nm1 = vi->n - 1;
+    if (mu) POLEE_TRY(vi->d_mu.download(ctx, mu, nm1));
+    if (omega) POLEE_TRY(vi->d_omega.download(ctx, omega, nm1));
+    if (alpha) POLEE_TRY(vi->d_alpha.download(ctx, alpha, nm1));
+    return POLEE_OK;
+}
+
+polee_status polee_vi_set_params(polee_vi *vi, const float *mu, const float *omega, const float *alpha)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    const size_t nm1 = vi->n - 1;
+    if (mu) POLEE_TRY(vi->d_mu.upload(ctx, mu, nm1));
+    if (omega) POLEE_TRY(vi->d_omega.upload(ctx, omega, nm1));
+    if (alpha) POLEE_TRY(vi->d_alpha.upload(ctx, alpha, nm1));
+    return POLEE_OK;
+}
+
+polee_status polee_vi_get_stats(polee_vi *vi, polee_vi_stats *stats)
+{
+    if (!vi || !stats) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    memset(stats, 0, sizeof(*stats));
+    stats->steps_done = vi->step;
+    int flag = 0;
+    POLEE_TRY(vi->d_flag.download(ctx, &flag, 1));
+    stats->nonfinite_step = flag;
+    if (vi->ll->profile) POLEE_TRY(vi->ll->profile_collect());
+    stats->loglik_kernel_launches = vi->ll->prof_launches;
+    stats->loglik_kernel_ms_avg = vi->ll->prof_launches ? vi->ll->prof_ms_total / vi->ll->prof_launches : 0.0;
+    if (!vi->o.gradonly && vi->step > 0 && vi->step <= vi->trace_cap) {
+        POLEE_HIP_TRY(ctx, hipMemcpyAsync(&stats->last_elbo, vi->d_elbo.p + (vi->step - 1), sizeof(double),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        POLEE_HIP_TRY(ctx, hipMemcpyAsync(&stats->last_lp_mean, vi->d_lptrace.p + (vi->step - 1), sizeof(double),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return POLEE_OK;
+}
+
+polee_status polee_vi_get_trace(polee_vi *vi, double *elbo, double *lp_mean)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (vi->o.gradonly) return fail(ctx, POLEE_ERR_BAD_ARG, "no trace is recorded in gradonly mode");
+    const size_t cnt = std::min(vi->step, vi->trace_cap);
+    if (elbo) POLEE_TRY(vi->d_elbo.download(ctx, elbo, cnt));
+    if (lp_mean) POLEE_TRY(vi->d_lptrace.download(ctx, lp_mean, cnt));
+    return POLEE_OK;
+}
+
+polee_status polee_vi_export_noise(polee_vi *vi, int32_t step, float *z0)
+{
+    if (!vi || !z0 || step < 1) return fail(nullptr, POLEE_ERR_BAD_ARG, "bad argument");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    const int64_t nm1 = vi->n - 1;
+    if (nm1 < 1) return POLEE_OK;
+    if (vi->o.z0 && step > vi->o.num_steps) return fail(ctx, POLEE_ERR_BAD_ARG, "step beyond the supplied noise");
+    DevBuf<float> tmp;
+    POLEE_TRY(tmp.alloc(ctx, (size_t)vi->K * nm1));
+    hipLaunchKernelGGL(export_noise_kernel, dim3((unsigned)ceil_div(nm1, 256), vi->K), dim3(256), 0, ctx->stream,
+                       vi->noise(), step, tmp.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return tmp.download(ctx, z0, (size_t)vi->K * nm1);
+}
+
+polee_status polee_vi_eval_gradients(polee_vi *vi, float *xs, double *x_grad, double *y_grad, float *mu_grad,
+                                     float *omega_grad, float *alpha_grad, double *lp, double *ladj)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = vi->ctx;
+    POLEE_TRY(use_device(ctx));
+    const size_t n = vi->n, nm1 = n - 1, K = vi->K;
+    POLEE_TRY(vi->one_step(false, true, true));
+    if (xs) {
+        hipLaunchKernelGGL(aos_to_rows_f32_kernel, dim3((unsigned)ceil_div(n * K, 256)), dim3(256), 0, ctx->stream,
+                           vi->d_x.p, (int)K, (int64_t)n, vi->d_x_rows.p);
+        POLEE_KERNEL_CHECK(ctx);
+        POLEE_TRY(vi->d_x_rows.download(ctx, xs, n * K));
+    }
+    if (x_grad) POLEE_TRY(vi->d_xgrad_rows.download(ctx, x_grad, n * K));
+    if (y_grad) POLEE_TRY(vi->d_ygrad.download(ctx, y_grad, nm1 * K));
+    if (mu_grad) POLEE_TRY(vi->d_mug.download(ctx, mu_grad, nm1));
+    if (omega_grad) POLEE_TRY(vi->d_omg.download(ctx, omega_grad, nm1));
+    if (alpha_grad) POLEE_TRY(vi->d_alg.download(ctx, alpha_grad, nm1));
+    if (lp) POLEE_TRY(vi->d_lp.download(ctx, lp, K));
+    if (ladj) {
+        std::vector<double> el(K * 2), rs(K * 2);
+        POLEE_TRY(vi->d_ladj_el.download(ctx, el.data(), K * 2));
+        POLEE_TRY(vi->d_rows.download(ctx, rs.data(), K * 2));
+        for (size_t d = 0; d < K; ++d) ladj[d] = el[d * 2] + el[d * 2 + 1] + rs[d * 2 + 1];
+    }
+    // the hook must not leave a stale flag behind
+    return POLEE_OK;
+}
+
+polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens, const polee_vi_opts *opts, float *mu,
+                          float *omega, float *alpha, polee_vi_stats *stats)
+{
+    polee_vi *vi = nullptr;
+    POLEE_TRY(polee_vi_create(ll, t, efflens, opts, &vi));
+    polee_status s = polee_vi_run(vi, vi->o.num_steps);
+    if (s == POLEE_OK) s = polee_vi_sync(vi);
+    if (s == POLEE_OK) s = polee_vi_get_params(vi, mu, omega, alpha);
+    if (s == POLEE_OK && stats) s = polee_vi_get_stats(vi, stats);
+    polee_vi_destroy(vi);
+    return s;
+}
+
+polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                const float *z0, int32_t ndraws, uint64_t seed, float *xs)
+{
+    if (!t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null tree");
+    polee_ctx *ctx = t->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!mu || !sigma || !alpha || !xs || ndraws < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (t->T != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "the sampler needs a single tree");
+    const size_t n = t->n, nm1 = n - 1;
+    DevBuf<float> d_mu, d_sigma, d_alpha, d_z0, d_x;
+    POLEE_TRY(d_mu.upload(ctx, mu, nm1));
+    POLEE_TRY(d_sigma.upload(ctx, sigma, nm1));
+    POLEE_TRY(d_alpha.upload(ctx, alpha, nm1));
+    POLEE_TRY(d_x.alloc(ctx, n));
+    // draws are processed in batches of 8 rows
+    for (int32_t b0 = 0; b0 < ndraws; b0 += 8) {
+        const int32_t B = std::min(8, ndraws - b0);
+        POLEE_TRY(t->reserve(B));
+        if (z0) POLEE_TRY(d_z0.upload(ctx, z0 + (size_t)b0 * nm1, (size_t)B * nm1));
+        NoiseSrc noise{z0 ? d_z0.p : nullptr, seed + (uint64_t)b0 * 0x9E3779B97F4A7C15ull, B, (int64_t)nm1};
+        if (nm1 > 0) {
+            hipLaunchKernelGGL(sampler_y_kernel, dim3((unsigned)ceil_div(nm1, 256), B), dim3(256), 0, ctx->stream,
+                               d_mu.p, d_sigma.p, d_alpha.p, noise, t->d_ys.p);
+            POLEE_KERNEL_CHECK(ctx);
+        }
+        POLEE_TRY(t->d_f32a.alloc(ctx, (size_t)B * n));
+        FwdOut o;
+        o.xs = t->d_f32a.p;
+        o.xs_rs = n;
+        POLEE_TRY(ptt_forward_device(t, t->d_ys.p, B, o));
+        POLEE_TRY(t->d_f32a.download(ctx, xs + (size_t)b0 * n, (size_t)B * n));
+    }
+    return POLEE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+"""GPU parity tests: the HIP path, called through the C ABI (polee_amd -> libpolee_hip.so),
+against the CPU oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances: the north star asks for 1e-4 relative on log-likelihood and posterior-mean
+effects; integer/index structure is exact.  Tighter bounds are used where the arithmetic
+allows (f64 tree, f32 sparse sums)."""
+import numpy as np
+import pytest
+
+from conftest import random_tree
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import polee_amd
+    return polee_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(P):
+    return P.Context(0)
+
+
+TREES = [("random", 313), ("spine", 40), ("balanced", 1000), ("random", 2), ("random", 3), ("spine", 3000),
+         ("random", 5000)]
+
+
+@pytest.mark.parametrize("kind,n", TREES)
+def test_transform_matches_oracle(P, ctx, kind, n):
+    rng = np.random.default_rng(n)
+    p, js = random_tree(n, rng, kind)
+    t = P.PolyaTreeTransform(p, js, ctx=ctx)
+    to = O.PTT(p, js)
+    lo, hi = (0.3, 0.7) if kind != "spine" or n < 100 else (0.02, 0.98)
+    B = 3
+    ys = rng.uniform(lo, hi, size=(B, n - 1))
+    xs, ladj = t.transform(ys, compute_ladj=True)
+    for b in range(B):
+        xo, lo_ = to.transform(ys[b], True)
+        np.testing.assert_allclose(xs[b], xo, rtol=3e-7, atol=0)
+        if np.isfinite(lo_):
+            assert abs(ladj[b] - lo_) <= 1e-10 * max(1.0, abs(lo_))
+    assert xs.dtype == np.float32 and (xs >= np.float32(1e-16)).all()
+
+
+@pytest.mark.parametrize("kind,n", [("random", 313), ("spine", 40), ("balanced", 1000), ("random", 5000)])
+def test_transform_gradients_match_oracle(P, ctx, kind, n):
+    rng = np.random.default_rng(n + 1)
+    p, js = random_tree(n, rng, kind)
+    t = P.PolyaTreeTransform(p, js, ctx=ctx)
+    to = O.PTT(p, js)
+    ys = rng.uniform(0.3, 0.7, size=(2, n - 1))
+    xg = rng.normal(size=(2, n)) * 10
+    yg = t.transform_gradients(ys, xg)
+    yg0 = t.transform_gradients_no_ladj(ys, xg)
+    for b in range(2):
+        to.transform(ys[b], False)
+        ref = to.transform_gradients(ys[b], xg[b])
+        ref0 = to.transform_gradients_no_ladj(ys[b], xg[b])
+        # the reference keeps f32 intermediates (ptt.jl:62): compare at f32 resolution of the
+        # two cancelling terms
+        us = to.us
+        scale = np.abs(ref) + 1 + np.abs(xg[b]).max() * 64
+        assert (np.abs(yg[b] - ref) <= 2e-6 * scale).all()
+        assert (np.abs(yg0[b] - ref0) <= 2e-6 * scale).all()
+
+
+def test_transform_gradients_f64_reference(P, ctx):
+    """Tight check against an f64 restatement of ptt.jl:167-209 (no f32 intermediates)."""
+    rng = np.random.default_rng(5)
+    n = 400
+    p, js = random_tree(n, rng, "random")
+    t = P.PolyaTreeTransform(p, js, ctx=ctx)
+    to = O.PTT(p, js)
+    ys = rng.uniform(0.05, 0.95, n - 1)
+    xg = rng.normal(size=n) * 100
+    yg = t.transform_gradients(ys, xg)
+    idx = to.index; N = to.N
+    to.transform(ys, False); us = to.us
+    g1 = np.zeros(N); g2 = np.zeros(N); ref = np.zeros(n - 1); k = n - 2
+    for i in range(N - 1, -1, -1):
+        if idx[0][i] > 0:
+            g1[i] = xg[idx[0][i] - 1]
+        else:
+            l, r = idx[1][i] - 1, idx[2][i] - 1
+            ref[k] = us[i] * ((g1[l] + g2[l]) - (g1[r] + g2[r]))
+            g1[i] = ys[k] * g1[l] + (1 - ys[k]) * g1[r]
+            g2[i] = 1 / us[i] + ys[k] * g2[l] + (1 - ys[k]) * g2[r]
+            k -= 1
+    np.testing.assert_allclose(yg, ref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind,n", [("random", 313), ("spine", 30), ("balanced", 1000), ("random", 2)])
+def test_inverse_and_tf_ops_match_oracle(P, ctx, kind, n):
+    rng = np.random.default_rng(n + 2)
+    p, js = random_tree(n, rng, kind)
+    t = P.PolyaTreeTransform(p, js, ctx=ctx)
+    to = O.PTT(p, js)
+    l, r, f = P.make_inverse_ptt_params(p, js)
+    lo_, ro_, fo_ = O.make_inverse_ptt_params(p, js)
+    assert (l == lo_).all() and (r == ro_).all() and (f == fo_).all()
+    B = 2
+    x = rng.dirichlet(np.ones(n) * 0.5, size=B).astype(np.float32)
+    x = np.maximum(x, np.float32(1e-12))
+    ys, ladj = t.inverse_transform(x)
+    for b in range(B):
+        yo, lo2 = to.inverse_transform(x[b])
+        np.testing.assert_allclose(ys[b], yo, rtol=1e-12)
+        assert abs(ladj[b] - lo2) <= 1e-5 * max(1, abs(lo2))
+    t2 = P.PolyaTreeTransform(ctx=ctx, index=(l, r, f))
+    y_tf, ladj_tf = P.inv_hsb(x, t2)
+    yo, lo3 = O.inv_hsb(x, l, r, f)
+    np.testing.assert_allclose(y_tf, yo, rtol=1e-12)
+    np.testing.assert_allclose(ladj_tf, lo3, rtol=2e-5, atol=1e-4)
+    logit = rng.normal(0, 2, size=(B, n - 1)).astype(np.float32)
+    np.testing.assert_allclose(P.hsb(logit, t2), O.hsb(logit, l, r, f), rtol=3e-7, atol=1e-38)
+    yg = rng.normal(size=(B, n - 1))
+    lg = rng.normal(size=B).astype(np.float32)
+    bp = P.inv_hsb_grad(yg, lg, yo, t2)
+    bo = O.inv_hsb_grad(yg, lg, yo, l, r, f)
+    np.testing.assert_allclose(bp, bo, rtol=2e-6, atol=1e-6 * np.abs(bo).max())
+    # round trip: inverse(transform(y)) == y
+    y0 = rng.uniform(0.2, 0.8, n - 1)
+    xr, _ = t.transform(y0)
+    yr, _ = t.inverse_transform(xr)
+    if kind != "spine":
+        np.testing.assert_allclose(yr, y0, rtol=2e-5)
+
+
+def _gpu_sample(P, ctx, f, **kw):
+    return P.RNASeqSample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"], ctx=ctx, **kw)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_loglik_fixture_matches_oracle(P, ctx, lm_fixture, K):
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    rng = np.random.default_rng(K)
+    x = rng.dirichlet(np.ones(f["n"]) * 0.3, size=K).astype(np.float32)
+    x = np.clip(x, np.float32(1e-10), 1)
+    lp, g = s.log_likelihood(x)
+    lp0, g0 = s.log_likelihood(x, gradonly=True)
+    assert (lp0 == 0).all()
+    for k in range(K):
+        lpo, go = so.log_likelihood(x[k])
+        assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo)
+        np.testing.assert_allclose(g[k], go, rtol=2e-5, atol=1e-7 * np.abs(go).max())
+        np.testing.assert_allclose(g0[k], go, rtol=2e-5, atol=1e-7 * np.abs(go).max())
+        # homogeneity: sum_j x_j dlp/dx_j = m
+        assert abs(float(g[k] @ x[k].astype(np.float64)) - f["m"]) < 1e-4 * f["m"]
+    info = s.info
+    assert info["nnz"] == 42775 and info["num_empty_rows"] == 0
+
+
+def _random_matrix(rng, m, n, maxlen=6, empty_every=0, long_row=None):
+    rows, cols = [], []
+    for i in range(m):
+        if empty_every and i % empty_every == 3:
+            continue
+        ln = 1 + int(rng.integers(0, maxlen))
+        if long_row is not None and i == long_row[0]:
+            ln = long_row[1]
+        base = int(rng.integers(0, n))
+        cs = np.unique((base + rng.integers(0, max(8, 2 * ln), size=ln)) % n)
+        rows += [i] * cs.size; cols += cs.tolist()
+    rows, cols = np.array(rows), np.array(cols)
+    vals = np.exp(rng.normal(-9, 1.5, rows.size)).astype(np.float32)
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    colptr = np.zeros(n + 1, np.int64); np.add.at(colptr, cols + 1, 1)
+    colptr = (np.cumsum(colptr) + 1).astype(np.uint32)
+    return colptr, (rows + 1).astype(np.uint32), vals
+
+
+def test_loglik_ragged_empty_rows_long_row_and_ks(P, ctx):
+    rng = np.random.default_rng(11)
+    m, n = 3000, 2500
+    colptr, rowval, nzval = _random_matrix(rng, m, n, empty_every=40, long_row=(5, 700))
+    ks = rng.integers(1, 6, m).astype(np.int64)
+    x = np.clip(rng.dirichlet(np.ones(n), size=2), 1e-10, 1).astype(np.float32)
+    s = P.RNASeqSample(m, n, colptr, rowval, nzval, ctx=ctx)
+    sk = P.RNASeqSample(m, n, colptr.astype(np.uint64), rowval, nzval, ks=ks, ctx=ctx)
+    assert s.info["num_empty_rows"] == 75 and s.info["max_row_nnz"] >= 500
+    rows = rowval.astype(np.int64) - 1
+    cols = np.repeat(np.arange(n), np.diff(colptr.astype(np.int64)))
+    lp, g = s.log_likelihood(x)
+    lpk, gk = P.factored_log_likelihood(sk, x)
+    for k in range(2):
+        sp = np.zeros(m); np.add.at(sp, rows, (nzval * x[k][cols]).astype(np.float64))
+        live = sp > 0
+        assert abs(lp[k] - np.log(sp[live]).sum()) <= 1e-6 * abs(lp[k])
+        assert abs(lpk[k] - (ks[live] * np.log(sp[live])).sum()) <= 1e-6 * abs(lpk[k])
+        gg = np.zeros(n); np.add.at(gg, cols, nzval.astype(np.float64) / sp[rows])
+        ggk = np.zeros(n); np.add.at(ggk, cols, nzval.astype(np.float64) * ks[rows] / sp[rows])
+        np.testing.assert_allclose(g[k], gg, rtol=3e-5, atol=1e-7 * gg.max())
+        np.testing.assert_allclose(gk[k], ggk, rtol=3e-5, atol=1e-7 * ggk.max())
+    # Xt entry point gives identical results
+    so = O.Sample(m, n, colptr, rowval, nzval)
+    s2 = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=so.csr())
+    lp2, g2 = s2.log_likelihood(x)
+    np.testing.assert_allclose(lp2, lp, rtol=1e-12)
+    np.testing.assert_allclose(g2, g, rtol=1e-6)
+
+
+def test_loglik_rejects_bad_input(P, ctx):
+    with pytest.raises(P.PoleeError):
+        P.RNASeqSample(3, 2, np.array([1, 2, 3], np.uint32), np.array([1, 9], np.uint32), np.ones(2, np.float32), ctx=ctx)
+    f_rows = np.ones(1100, np.uint32)  # one fragment compatible with 1100 transcripts: unsupported
+    with pytest.raises(P.PoleeError):
+        P.RNASeqSample(1, 1100, np.arange(1, 1102, dtype=np.uint32), f_rows, np.ones(1100, np.float32), ctx=ctx)
+    with pytest.raises(P.PoleeError):
+        P.PolyaTreeTransform(np.array([0, 1, 1, 2, 2], np.int32), np.array([0, 0, 1, 2, 2], np.int32), ctx=ctx)
+
+
+def test_efflen_jacobian(P, ctx, lm_fixture):
+    rng = np.random.default_rng(5)
+    n = lm_fixture["n"]
+    x = rng.dirichlet(np.ones(n), size=2).astype(np.float32)
+    l = lm_fixture["effective_lengths"]
+    g0 = rng.normal(size=(2, n))
+    xls, g = P.effective_length_jacobian_adjustment(l, x, g0, ctx=ctx)
+    for k in range(2):
+        xo, go = O.effective_length_jacobian_adjustment(l, x[k], g0[k])
+        np.testing.assert_allclose(g[k], go, rtol=1e-9)
+        np.testing.assert_allclose(xls[k], xo, rtol=2e-6)
+
+
+@pytest.mark.parametrize("use_efflen", [True, False])
+def test_vi_single_step_gradients_match_oracle(P, ctx, lm_fixture, prep_fixture, use_efflen):
+    """One VI iteration's K draws at the reference's own fitted parameters, device RNG noise
+    exported and fed to the oracle."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    K = 6
+    fit = P.LikelihoodApproximationFit(s, t, num_steps=2, num_mc_samples=K, use_efflen_jacobian=use_efflen,
+                                       gradonly=False, seed=99)
+    fit.set_params(prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"])
+    z0 = fit.export_noise(1)
+    assert abs(z0.mean()) < 0.1 and abs(z0.std() - 1) < 0.05
+    out = fit.eval_gradients()
+    mu_g = np.zeros(f["n"] - 1); om_g = np.zeros_like(mu_g); al_g = np.zeros_like(mu_g)
+    for d in range(K):
+        r = O.vi_draw_gradients(so, to, f["effective_lengths"], prep_fixture["mu"], prep_fixture["omega"],
+                                prep_fixture["alpha"], z0[d], use_efflen_jacobian=use_efflen)
+        np.testing.assert_allclose(out["xs"][d], r["xs"], rtol=1e-5)
+        assert abs(out["lp"][d] - r["lp"]) <= 1e-6 * abs(r["lp"])
+        assert abs(out["ladj"][d] - r["ladj"]) <= 1e-5 * max(1, abs(r["ladj"]))
+        np.testing.assert_allclose(out["x_grad"][d], r["x_grad"], rtol=1e-4, atol=1e-6 * np.abs(r["x_grad"]).max())
+        scale = np.abs(r["y_grad"]) + 1e-4 * np.abs(r["y_grad"]).max() + 1
+        assert (np.abs(out["y_grad"][d] - r["y_grad"]) <= 1e-4 * scale).all()
+        mu_g += r["mu_grad"]; om_g += r["omega_grad"]; al_g += r["alpha_grad"]
+    for name, acc in (("mu_grad", mu_g), ("omega_grad", om_g), ("alpha_grad", al_g)):
+        ref = acc / K
+        assert (np.abs(out[name] - ref) <= 1e-4 * (np.abs(ref) + 1e-3 * np.abs(ref).max() + 1)).all(), name
+
+
+def test_vi_trajectory_with_supplied_noise(P, ctx, lm_fixture, prep_fixture):
+    """Five full iterations (sampling, likelihood, backward, ADAM) with identical z0 on both sides."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    steps, K = 5, 6
+    z0 = O.randn(steps * K * (f["n"] - 1), 3)
+    ref = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False)
+    # initial values first
+    fit0 = P.LikelihoodApproximationFit(s, t, num_steps=steps, num_mc_samples=K, z0=z0)
+    init = O.approximate_likelihood(so, to, f["effective_lengths"], init_only=True)
+    mu0, om0, al0 = fit0.params()
+    np.testing.assert_allclose(mu0, init["mu"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(om0, init["omega"]); np.testing.assert_array_equal(al0, init["alpha"])
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
+                                   gradonly=False)
+    # ADAM's first steps move every parameter by +-max_step whatever the gradient's size, so a
+    # parameter whose gradient is ~0 is sign-sensitive to rounding: require near-all to agree.
+    for key, tol in (("mu", 2e-4), ("omega", 2e-4), ("alpha", 2e-4)):
+        ok = np.abs(got[key] - ref[key]) <= tol * (1 + np.abs(ref[key]))
+        assert ok.mean() >= 0.99, (key, ok.mean())
+    np.testing.assert_allclose(got["lp_mean"], ref["lp_mean"], rtol=1e-5)
+    np.testing.assert_allclose(got["elbo"], ref["elbo"], rtol=1e-5)
+    assert (got["node_parent_idxs"] == prep_fixture["node_parent_idxs"]).all()
+
+
+def _expected_loglik(so, to, mu, omega, alpha, efflens, ndraws, seed):
+    sigma = np.exp(omega)
+    lps, pm = [], np.zeros(to.n)
+    for d in range(ndraws):
+        z0 = O.randn(to.n - 1, seed + d)
+        x = O.sampler_draw(to, mu, sigma, alpha, z0)
+        lps.append(so.log_likelihood(np.clip(x, np.float32(1e-10), np.float32(1.0)))[0])
+        xe = x.astype(np.float64) / efflens
+        pm += xe / xe.sum()
+    return np.array(lps), pm / ndraws
+
+
+def test_full_fit_matches_reference_fit_statistically(P, ctx, lm_fixture, prep_fixture):
+    """500 x 6 production fit (device RNG, gradonly) vs the reference's own fit of the same X
+    (prep.h5): expected log-likelihood within MC error, posterior means within 1e-4-level
+    agreement of their log-correlation."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t)
+    l = f["effective_lengths"]
+    lp_ref, pm_ref = _expected_loglik(so, to, prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"], l, 200, 1000)
+    lp_fit, pm_fit = _expected_loglik(so, to, got["mu"], got["omega"], got["alpha"], l, 200, 5000)
+    assert abs(lp_fit.mean() - lp_ref.mean()) < 6 * np.hypot(lp_ref.std(), lp_fit.std()) / np.sqrt(200) + 5
+    expressed = pm_ref > 1e-4
+    r = np.corrcoef(np.log(pm_ref[expressed]), np.log(pm_fit[expressed]))[0, 1]
+    assert r > 0.99, r
+
+
+def test_sampler_matches_oracle(P, ctx, prep_fixture):
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    mu, sigma, alpha = prep_fixture["mu"], np.exp(prep_fixture["omega"]), prep_fixture["alpha"]
+    als = P.ApproxLikelihoodSampler()
+    als.set_transform(t, mu, sigma, alpha)
+    z0 = np.stack([O.randn(t.n - 1, 50 + d) for d in range(11)])
+    xs = als.rand(11, z0=z0)
+    for d in range(11):
+        np.testing.assert_allclose(xs[d], O.sampler_draw(to, mu, sigma, alpha, z0[d]), rtol=2e-5, atol=1e-30)
+    # device RNG: draws are on the simplex and differ between calls
+    a, b = als.rand(4), als.rand(4)
+    assert np.allclose(a.sum(axis=1), 1, atol=1e-4) and not np.allclose(a, b)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_approx_logprob_and_gradient_match_oracle(P, ctx, shared):
+    rng = np.random.default_rng(21)
+    n, S = 600, 3
+    trees = [random_tree(n, rng) for _ in range(1 if shared else S)]
+    idx = [O.make_inverse_ptt_params(*tr) for tr in trees]
+    L_, R_, F_ = (np.stack([i[j] for i in idx]) for j in range(3))
+    x = rng.normal(0, 1.5, size=(S, n)).astype(np.float32)
+    eff = rng.uniform(200, 3000, size=(S, n)).astype(np.float32)
+    mu = rng.normal(0, 1, size=(S, n - 1)).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.3, size=(S, n - 1))).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=(S, n - 1)).astype(np.float32)
+    ap = P.RNASeqApproxLikelihood(dict(efflen=eff, la_mu=mu, la_sigma=sigma, la_alpha=alpha, left_index=L_,
+                                       right_index=R_, leaf_index=F_), ctx=ctx)
+    lp, g = ap.log_prob(x, want_grad=True)
+    lpo, go = O.approx_log_prob(x, eff, mu, sigma, alpha, L_, R_, F_, want_grad=True)
+    np.testing.assert_allclose(lp, lpo, rtol=1e-4)
+    np.testing.assert_allclose(g, go, rtol=2e-3, atol=2e-3 * np.abs(go).max())
+    np.testing.assert_allclose(ap.log_prob(x), lp, rtol=1e-6)
+    z0 = rng.normal(size=(S, n - 1)).astype(np.float32)
+    xs = ap.sample(z0)
+    xo = O.tf_sampler(z0, eff, mu, sigma, alpha, L_, R_, F_)
+    np.testing.assert_allclose(xs, xo, rtol=1e-4, atol=1e-16)
