@@ -312,11 +312,12 @@ def vi_draw_gradients(sample, ptt, efflens, mu, omega, alpha, zs0, use_efflen_ja
     x_grad = np.empty(n, np.float64)
     y_grad, mu_g, om_g, al_g = (np.empty(nm1, np.float32) for _ in range(4))
     lp, ladj = C.c_double(), C.c_double()
+    ys = np.empty(nm1, np.float64)
     lib().oracle_vi_draw_gradients(
         sample.h, ptt.h, _p(efflens, c_f32p), int(use_efflen_jacobian), _p(mu, c_f32p), _p(omega, c_f32p),
         _p(alpha, c_f32p), _p(zs0, c_f32p), _p(xs, c_f32p), _p(x_grad, c_f64p), _p(y_grad, c_f32p),
-        _p(mu_g, c_f32p), _p(om_g, c_f32p), _p(al_g, c_f32p), C.byref(lp), C.byref(ladj))
-    return dict(xs=xs, x_grad=x_grad, y_grad=y_grad, mu_grad=mu_g, omega_grad=om_g, alpha_grad=al_g,
+        _p(mu_g, c_f32p), _p(om_g, c_f32p), _p(al_g, c_f32p), C.byref(lp), C.byref(ladj), _p(ys, c_f64p))
+    return dict(ys=ys, xs=xs, x_grad=x_grad, y_grad=y_grad, mu_grad=mu_g, omega_grad=om_g, alpha_grad=al_g,
                 lp=lp.value, ladj=ladj.value)
 
 

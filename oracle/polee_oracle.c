@@ -457,7 +457,7 @@ double oracle_effective_length_jacobian_adjustment(const float *efflens, const f
     }
     for (int64_t i = 0; i < n; ++i) xls[i] = (float)((double)xls[i] / x_scaled_sum);
     for (int64_t i = 0; i < n; ++i)
-        x_grad[i] -= (double)n * (double)(1 / efflens[i]) / x_scaled_sum;
+        x_grad[i] -= (double)((float)n * (1 / efflens[i])) / x_scaled_sum; /* Int64 * Float32 -> Float32 */
     return 0.0;
 }
 
@@ -748,7 +748,7 @@ void oracle_vi_draw_gradients(oracle_sample *s, oracle_ptt *t, const float *effl
                               const float *alpha, const float *zs0, float *xs_out,
                               double *x_grad_out, float *y_grad_out, float *mu_grad,
                               float *omega_grad, float *alpha_grad, double *lp_out,
-                              double *ladj_out)
+                              double *ladj_out, double *ys_out)
 {
     int64_t n = s->n, nm1 = n - 1;
     float *zs = calloc(nm1, 4), *sigma = calloc(nm1, 4), *xls = calloc(n, 4);
@@ -777,6 +777,7 @@ void oracle_vi_draw_gradients(oracle_sample *s, oracle_ptt *t, const float *effl
     for (int64_t i = 0; i < nm1; ++i) omega_grad[i] += sigma[i] * sigma_grad[i];
     if (lp_out) *lp_out = lp;
     if (ladj_out) *ladj_out = (double)skew_ladj + (double)ln_ladj + hsb_ladj;
+    if (ys_out) memcpy(ys_out, ys, nm1 * 8);
     free(zs); free(sigma); free(xls); free(sigma_grad); free(z_grad); free(ys);
 }
 

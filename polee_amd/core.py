@@ -144,7 +144,7 @@ def _tree_for_ops(left_index, right_index, leaf_index, ctx):
     return PolyaTreeTransform(ctx=ctx, index=(l, right_index, leaf_index))
 
 
-def hsb(y_logit, left_index, right_index, leaf_index, ctx=None):
+def hsb(y_logit, left_index, right_index=None, leaf_index=None, ctx=None):
     """TF op HSB (hsb_ops.cpp:17-120)."""
     t = left_index if isinstance(left_index, PolyaTreeTransform) else _tree_for_ops(left_index, right_index, leaf_index, ctx)
     y, single = t._rows(y_logit, np.float32, t.n - 1)

@@ -251,6 +251,7 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
     polee_approx *ap = new (std::nothrow) polee_approx();
     if (!ap) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
     ap->ctx = ctx;
+    ctx_retain(ctx);
     ap->S = S;
     ap->n = n;
     const size_t sn = (size_t)S * n, sk = (size_t)S * (n - 1);
@@ -287,9 +288,11 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
 void polee_approx_destroy(polee_approx *ap)
 {
     if (!ap) return;
-    if (ap->ctx) (void)hipSetDevice(ap->ctx->device);
+    polee_ctx *ctx = ap->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
     polee_ptt_destroy(ap->t);
     delete ap;
+    ctx_release(ctx);
 }
 
 polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, float *d_lp, float *d_x_grad)

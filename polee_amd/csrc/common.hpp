@@ -26,6 +26,7 @@ struct polee_ctx {
     std::string err;
     int num_cus = 256;
     size_t lds_per_block = 65536;
+    int refs = 1;  // the creator's reference + one per live child handle
 };
 
 namespace polee {
@@ -123,6 +124,12 @@ inline polee_status use_device(polee_ctx *ctx)
     POLEE_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return POLEE_OK;
 }
+
+// Handles keep their parents alive: destroying a context (tree, matrix) while a child still
+// exists only drops the caller's reference (garbage-collected host languages finalise in
+// arbitrary order).
+void ctx_retain(polee_ctx *ctx);
+void ctx_release(polee_ctx *ctx);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

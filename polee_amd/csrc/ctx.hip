@@ -7,6 +7,20 @@ std::string &global_error()
     static thread_local std::string e;
     return e;
 }
+void ctx_retain(polee_ctx *ctx)
+{
+    if (ctx) ++ctx->refs;
+}
+void ctx_release(polee_ctx *ctx)
+{
+    if (!ctx || --ctx->refs > 0) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
 }  // namespace polee
 
 using namespace polee;
@@ -50,16 +64,7 @@ polee_status polee_ctx_create(int device, polee_ctx **out)
     return POLEE_OK;
 }
 
-void polee_ctx_destroy(polee_ctx *ctx)
-{
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipEventDestroy(ctx->ev0);
-    (void)hipEventDestroy(ctx->ev1);
-    (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-}
+void polee_ctx_destroy(polee_ctx *ctx) { ctx_release(ctx); }
 
 const char *polee_last_error(const polee_ctx *ctx)
 {

@@ -252,6 +252,22 @@ __global__ void efflen_adjust_kernel(const float *efflens, const float *xs, cons
 
 }  // namespace polee
 
+namespace polee {
+void loglik_retain(polee_loglik *ll)
+{
+    if (ll) ++ll->refs;
+}
+void loglik_release(polee_loglik *ll)
+{
+    if (!ll || --ll->refs > 0) return;
+    polee_ctx *ctx = ll->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (hipEvent_t e : ll->prof_events) (void)hipEventDestroy(e);
+    delete ll;
+    ctx_release(ctx);
+}
+}  // namespace polee
+
 using namespace polee;
 
 polee_status polee_loglik::profile_collect()
@@ -275,7 +291,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
-        delete ll;
+        loglik_release(ll);
         return s;
     }
     // keep only metadata on the host
@@ -344,13 +360,14 @@ polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, c
     polee_loglik *ll = new (std::nothrow) polee_loglik();
     if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
     ll->ctx = ctx;
+    ctx_retain(ctx);
     ll->m = m;
     ll->n = n;
     ll->nnz = (int64_t)nnz;
     ll->has_ks = ks != nullptr;
     std::string err = build_psell(m, n, rowptr.data(), col.data(), tnzval, ks, ll->host);
     if (!err.empty()) {
-        delete ll;
+        loglik_release(ll);
         return fail(ctx, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
                     "likelihood matrix: %s", err.c_str());
     }
@@ -370,26 +387,21 @@ polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const voi
     polee_loglik *ll = new (std::nothrow) polee_loglik();
     if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
     ll->ctx = ctx;
+    ctx_retain(ctx);
     ll->m = m;
     ll->n = n;
     ll->nnz = (int64_t)col.size();
     ll->has_ks = ks != nullptr;
     err = build_psell(m, n, rowptr.data(), col.data(), val.data(), ks, ll->host);
     if (!err.empty()) {
-        delete ll;
+        loglik_release(ll);
         return fail(ctx, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
                     "likelihood matrix: %s", err.c_str());
     }
     return loglik_finish_create(ctx, ll, out);
 }
 
-void polee_loglik_destroy(polee_loglik *ll)
-{
-    if (!ll) return;
-    if (ll->ctx) (void)hipSetDevice(ll->ctx->device);
-    for (hipEvent_t e : ll->prof_events) (void)hipEventDestroy(e);
-    delete ll;
-}
+void polee_loglik_destroy(polee_loglik *ll) { loglik_release(ll); }
 
 polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info)
 {

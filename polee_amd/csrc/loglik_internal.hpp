@@ -48,6 +48,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
 
 struct polee_loglik {
     polee_ctx *ctx = nullptr;
+    int refs = 1;
     int64_t m = 0, n = 0, nnz = 0;
     bool has_ks = false;
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
@@ -70,5 +71,7 @@ namespace polee {
 // d_x, d_g: [n][K] f32 (transcript-major, the K draws of one transcript adjacent).
 // d_g must be zeroed by the caller; the kernel adds into it.  d_lp [K] f64 or null
 // (also accumulated into).
+void loglik_retain(polee_loglik *ll);
+void loglik_release(polee_loglik *ll);
 polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp);
 }  // namespace polee

@@ -317,6 +317,7 @@ static polee_status ptt_create_from_plans(polee_ctx *ctx, std::vector<PttPlan> &
     polee_ptt *t = new (std::nothrow) polee_ptt();
     if (!t) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
     t->ctx = ctx;
+    ctx_retain(ctx);
     t->plans = std::move(plans);
     t->T = (int32_t)t->plans.size();
     t->n = t->plans[0].n;
@@ -341,7 +342,7 @@ static polee_status ptt_create_from_plans(polee_ctx *ctx, std::vector<PttPlan> &
     if ((s = t->d_tour_code.upload(ctx, code)) || (s = t->d_tour_tgt.upload(ctx, tgt)) ||
         (s = t->d_leaf_tid.upload(ctx, ltid)) || (s = t->d_lo.upload(ctx, lo)) || (s = t->d_mid.upload(ctx, mid)) ||
         (s = t->d_hi1.upload(ctx, hi1))) {
-        delete t;
+        ptt_release(t);
         return s;
     }
     *out = t;
@@ -349,6 +350,18 @@ static polee_status ptt_create_from_plans(polee_ctx *ctx, std::vector<PttPlan> &
 }
 
 namespace polee {
+void ptt_retain(polee_ptt *t)
+{
+    if (t) ++t->refs;
+}
+void ptt_release(polee_ptt *t)
+{
+    if (!t || --t->refs > 0) return;
+    polee_ctx *ctx = t->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    delete t;
+    ctx_release(ctx);
+}
 polee_status ptt_create_multi(polee_ctx *ctx, const int32_t *left_index, const int32_t *right_index,
                               const int32_t *leaf_index, int32_t T, int32_t N, polee_ptt **out)
 {
@@ -401,12 +414,7 @@ polee_status polee_ptt_create(polee_ctx *ctx, const int32_t *node_parent_idxs, c
     return polee_ptt_create_from_index(ctx, l.data(), r.data(), f.data(), N, out);
 }
 
-void polee_ptt_destroy(polee_ptt *t)
-{
-    if (!t) return;
-    if (t->ctx) (void)hipSetDevice(t->ctx->device);
-    delete t;
-}
+void polee_ptt_destroy(polee_ptt *t) { ptt_release(t); }
 
 int32_t polee_ptt_n(const polee_ptt *t) { return t ? t->n : 0; }
 

@@ -55,6 +55,7 @@ struct PttView {
 
 struct polee_ptt {
     polee_ctx *ctx = nullptr;
+    int refs = 1;
     int32_t n = 0, N = 0, T = 1;
     int64_t TL = 0;
     std::vector<polee::PttPlan> plans;  // host copies (debug / tests)
@@ -239,6 +240,8 @@ struct FwdOut {
 };
 polee_status ptt_forward_device(polee_ptt *t, const double *d_ys, int32_t B, const FwdOut &out);
 // One handle holding T trees over the same n (row b of a batch uses tree b); index arrays are [T][N].
+void ptt_retain(polee_ptt *t);
+void ptt_release(polee_ptt *t);
 polee_status ptt_create_multi(polee_ctx *ctx, const int32_t *left_index, const int32_t *right_index,
                               const int32_t *leaf_index, int32_t T, int32_t N, polee_ptt **out);
 

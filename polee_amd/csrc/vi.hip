@@ -440,6 +440,9 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     vi->ctx = ctx;
     vi->ll = ll;
     vi->t = t;
+    ctx_retain(ctx);
+    loglik_retain(ll);
+    ptt_retain(t);
     vi->o = o;
     vi->n = t->n;
     vi->K = o.num_mc_samples;
@@ -472,7 +475,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     vi->o.z0 = o.z0;  // only its null-ness is used from here on
     A(t->reserve((int32_t)K));
     if (s != POLEE_OK) {
-        delete vi;
+        polee_vi_destroy(vi);
         return s;
     }
     hipStream_t st = ctx->stream;
@@ -481,7 +484,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     for (DevBuf<float> *b : {&vi->d_mm, &vi->d_vm, &vi->d_mo, &vi->d_vo, &vi->d_ma, &vi->d_va})
         if (e == hipSuccess) e = hipMemsetAsync(b->p, 0, sizeof(float) * nm1, st);
     if (e != hipSuccess) {
-        delete vi;
+        polee_vi_destroy(vi);
         return fail(ctx, POLEE_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
     }
     // initial values (likelihood-approximation.jl:451-456): mu = logit(inverse_transform!(fill(1/n)))
@@ -498,7 +501,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
-            delete vi;
+            polee_vi_destroy(vi);
             return fail(ctx, POLEE_ERR_HIP, "initialisation failed: %s", hipGetErrorString(e));
         }
     }
@@ -509,11 +512,17 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
 void polee_vi_destroy(polee_vi *vi)
 {
     if (!vi) return;
-    if (vi->ctx) {
-        (void)hipSetDevice(vi->ctx->device);
-        (void)hipStreamSynchronize(vi->ctx->stream);
+    polee_ctx *ctx = vi->ctx;
+    polee_loglik *ll = vi->ll;
+    polee_ptt *t = vi->t;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
     }
     delete vi;
+    loglik_release(ll);
+    ptt_release(t);
+    ctx_release(ctx);
 }
 
 polee_status polee_vi_run(polee_vi *vi, int32_t nsteps)
