@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- approx-lik VI iterations/sec on a synthetic RNA-Seq sample (BASELINE.json metric).
+
+One "step" = one VI iteration of approximate_likelihood(::LogitSkewNormalPTTApprox)
+(src/likelihood-approximation.jl:496-572): K=6 Monte-Carlo draws (sampling, Polya tree
+transform, sparse log-likelihood + gradient over X, backward, ADAM).  Inputs (X in its device
+layout, the tree, effective lengths) are resident in HBM before the timed region starts.
+
+N=1 workload: BASELINE.json configs[1] -- one GENCODE-scale sample, n=200 000 transcripts x
+m=30 000 000 fragments (~240 M nnz), on one MI355X.  N>1: one such sample per GPU, fitted
+independently (samples shard one-per-GPU, no data-path collective: "scaling": "weak");
+value = total VI iterations of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (sparse likelihood kernel vs HBM) and, at N=1,
+`cpu_baseline` (the CPU oracle -- a port keeping the reference's loop structure -- timed on
+this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (n, m, mean nnz/fragment)
+    "c1": (1000, 100000, 2.2),
+    "small": (20000, 3000000, 8.0),
+    "c2": (200000, 30000000, 8.0),
+    "c5": (200000, 150000000, 8.0),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_pass(nnz, m, n, K):
+    """nnz*(4 B value + 4 B column) + (m+1)*4 B row offsets + K*n*8 B (read x, write grad)."""
+    return nnz * 8 + (m + 1) * 4 + K * n * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("POLEE_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--draws", type=int, default=6, help="MC draws per VI iteration (LIKAP_NUM_MC_SAMPLES)")
+    ap.add_argument("--tree", default="hclust", choices=["hclust", "balanced", "spine"])
+    ap.add_argument("--cpu-steps", type=int, default=1, help="VI iterations timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=123456789)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import polee_amd as P
+    from tools import synth
+
+    n, m, mean_nnz = WORKLOADS[args.workload]
+    K = args.draws
+    t0 = time.time()
+    # every rank fits its own sample (different seed per rank), as `polee prep` does over a cohort
+    smp = synth.make_sample(n, m, mean_nnz, seed=args.seed + 7919 * rank)
+    parents, js = synth.make_tree(smp["gene"], seed=args.seed, kind=args.tree)
+    t_gen = time.time() - t0
+
+    ctx = P.Context(local_rank if world > 1 else 0)
+    t0 = time.time()
+    sample = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ctx,
+                            xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
+    tree = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    info = sample.info
+    t_build = time.time() - t0
+    total = args.warmup + args.steps
+    fit = P.LikelihoodApproximationFit(sample, tree, num_steps=max(total, 1), num_mc_samples=K, seed=args.seed,
+                                       profile=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    fit.run(args.warmup)
+    fit.sync()
+    st0 = fit.stats()
+    barrier()
+    t_start = time.perf_counter()
+    ctx.timer_start()
+    fit.run(args.steps)
+    ev_ms = ctx.timer_stop()  # HIP events on the library's own stream
+    fit.sync()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    st1 = fit.stats()
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    launches = st1["loglik_kernel_launches"] - st0["loglik_kernel_launches"]
+    kern_ms = ((st1["loglik_kernel_ms_avg"] * st1["loglik_kernel_launches"]
+                - st0["loglik_kernel_ms_avg"] * st0["loglik_kernel_launches"]) / max(launches, 1))
+    bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
+    achieved = bytes_pass / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "approx-lik VI iters/sec",
+        "value": world * args.steps / elapsed,
+        "unit": "VI iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: one sample per GPU, n=%d transcripts x m=%d fragments, nnz=%d (%.2f/fragment), "
+                        "K=%d draws per VI iteration, %s tree" % (args.workload.upper(), n, m, info["nnz"],
+                                                                  info["nnz"] / m, K, args.tree),
+            "samples_per_gpu": 1,
+            "parallelism": "sample-per-GPU x%d, no collective" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "loglik_psell_kernel<K=%d>" % K, "kernel_ms_avg": kern_ms, "launches": int(launches),
+            "algorithmic_bytes_per_launch": bytes_pass, "device_bytes_streamed_per_launch": info["stream_bytes"],
+        },
+        "detail": {
+            "hip_event_ms_per_step": ev_ms / args.steps, "gen_s": t_gen, "device_layout_build_s": t_build,
+            "padded_nnz_ratio": info["padded_nnz"] / max(info["nnz"], 1), "num_tiles": info["num_tiles"],
+            "max_tile_cols": info["max_tile_cols"],
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        # CPU baseline: the oracle (a port that keeps the reference's loop structure: CSR pass
+        # threaded over fragments, CSC pass threaded over transcripts, serial tree walks) on the host cores.
+        from oracle import oracle as O
+        t0 = time.time()
+        colptr, rowval, nzval = synth.to_csc(smp)
+        so = O.Sample(m, n, colptr, rowval, nzval)
+        to = O.PTT(parents, js)
+        t_prep = time.time() - t0
+        t0 = time.time()
+        O.approximate_likelihood(so, to, smp["effective_lengths"], num_steps=args.cpu_steps, num_mc=K,
+                                 seed=args.seed)
+        t_cpu = time.time() - t0
+        out["cpu_baseline"] = {
+            "value": args.cpu_steps / t_cpu, "unit": "VI iters/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d full VI iteration(s) (K=%d draws, %d likelihood passes) of the oracle on the SAME %s sample "
+                      "(%.1f s of CPU work; setup %.1f s not counted)" % (args.cpu_steps, K, 2 * K * args.cpu_steps,
+                                                                          args.workload.upper(), t_cpu, t_prep),
+        }
+        out["detail"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

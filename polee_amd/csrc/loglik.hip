@@ -14,11 +14,73 @@
 
 namespace polee {
 
-template <int K>
-__device__ inline void lds_row_load(const float *row, float (&out)[K])
+// ---- wave-level sum via DPP (gfx9 row_shr / row_bcast), result valid in lane 63 ------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ inline float dpp_add(float v)
 {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
+    return v + __int_as_float(moved);
+}
+__device__ inline float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1   (inclusive scan inside each row of 16 lanes)
+    v = dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row total
+    v = dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_mov0(float v)  // lanes without a source (or in masked-off rows) read 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// Adds q[k] of every lane into gw[c*K + k].  Lanes holding the same column id are contiguous
+// (rows are pattern-sorted), so contributions are first summed per run of equal ids with a
+// segmented DPP scan; only the last lane of each run touches LDS.
+template <int K>
+__device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
+{
+    const int c0 = __builtin_amdgcn_readfirstlane(c);
+    if (__all(c == c0)) {  // one column for the whole wavefront: plain wave sum
+        float *gr = gw + c0 * K;
 #pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = row[k];
+        for (int k = 0; k < K; ++k) {
+            const float r = wave_sum_to_lane63(q[k]);
+            if (lane == 63) atomicAdd(gr + k, r);
+        }
+        return;
+    }
+    const int cprev = __builtin_amdgcn_update_dpp(-1, c, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const unsigned long long heads = __ballot(c != cprev);  // lane 0 compares with -1: always a head
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int dist = lane - (63 - __clzll(heads & upto));  // distance to the head of this lane's run
+    const int rl = lane & 15;
+    const float m1 = dist >= 1 ? 1.f : 0.f, m2 = dist >= 2 ? 1.f : 0.f, m4 = dist >= 4 ? 1.f : 0.f,
+                m8 = dist >= 8 ? 1.f : 0.f;
+    const float mb15 = dist > rl ? 1.f : 0.f;           // run started in an earlier row of 16
+    const float mb31 = dist > (lane & 31) ? 1.f : 0.f;  // run started before lane 32
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float v = q[k];
+        v = fmaf(dpp_mov0<0x111, 0xf>(v), m1, v);
+        v = fmaf(dpp_mov0<0x112, 0xf>(v), m2, v);
+        v = fmaf(dpp_mov0<0x114, 0xf>(v), m4, v);
+        v = fmaf(dpp_mov0<0x118, 0xf>(v), m8, v);
+        v = fmaf(dpp_mov0<0x142, 0xa>(v), mb15, v);  // row_bcast:15 -> rows 1, 3
+        v = fmaf(dpp_mov0<0x143, 0xc>(v), mb31, v);  // row_bcast:31 -> rows 2, 3
+        q[k] = v;
+    }
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (tail) {
+        float *gr = gw + c * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (q[k] != 0.0f) atomicAdd(gr + k, q[k]);
+    }
 }
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -58,6 +120,7 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
         const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
         const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
 
+        // sweep 1: row sums s[k] = sum_t v[t] * x[c[t]][k]
         float sacc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
@@ -93,32 +156,14 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
             if (WANT_LP && live) lpacc[k] += (double)ksv * log((double)sacc[k]);
         }
 
-        // second sweep over the slice (L1/L2-resident): scatter X_ij * w_i into the tile window
-        t = 0;
-        for (; t + 4 <= w; t += 4) {
-            float v[4];
-            int c[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = vals[(t + u) * 64];
-                c[u] = cols[(t + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (v[u] != 0.0f) {
-                    float *gr = gw + c[u] * K;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) atomicAdd(gr + k, v[u] * wk[k]);
-                }
-            }
-        }
-        for (; t < w; ++t) {
+        // sweep 2 (slice is L1/L2 resident): g[c[t]][k] += v[t] * w[k], summed per run of equal ids
+        for (t = 0; t < w; ++t) {
             const float v = vals[t * 64];
-            if (v != 0.0f) {
-                float *gr = gw + (int)cols[t * 64] * K;
+            const int c = cols[t * 64];
+            float q[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) atomicAdd(gr + k, v * wk[k]);
-            }
+            for (int k = 0; k < K; ++k) q[k] = v * wk[k];
+            scatter_runs<K>(c, q, gw, lane);
         }
     }
     __syncthreads();

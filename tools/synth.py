@@ -1,0 +1,102 @@
+"""Synthetic RNA-Seq samples and trees for benchmarks and full-size tests.
+Bench/test support; not part of the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libpolee_synth.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _lib = C.CDLL(_LIB)
+        _lib.synth_create.restype = C.c_void_p
+        _lib.synth_count.restype = C.c_int64
+        _lib.synth_mean_nnz.restype = C.c_double
+        _lib.synth_gamma.restype = C.c_double
+    return _lib
+
+
+def make_sample(n, m, mean_nnz=8.0, seed=123456789):
+    """Returns dict(m, n, nnz, tcolptr u64[m+1], trowval u32, tnzval f32, effective_lengths f32[n], gene i32[n])."""
+    L = lib()
+    h = C.c_void_p(L.synth_create(C.c_int64(n), C.c_int64(m), C.c_double(mean_nnz), C.c_uint64(seed)))
+    tcolptr = np.zeros(m + 1, np.uint64)
+    nnz = L.synth_count(h, tcolptr.ctypes.data_as(C.c_void_p))
+    trowval = np.empty(nnz, np.uint32)
+    tnzval = np.empty(nnz, np.float32)
+    eff = np.empty(n, np.float32)
+    L.synth_fill(h, tcolptr.ctypes.data_as(C.c_void_p), trowval.ctypes.data_as(C.c_void_p),
+                 tnzval.ctypes.data_as(C.c_void_p), eff.ctypes.data_as(C.c_void_p))
+    gene = np.empty(n, np.int32)
+    L.synth_gene_of_transcript(h, gene.ctypes.data_as(C.c_void_p))
+    out = dict(m=m, n=n, nnz=int(nnz), tcolptr=tcolptr, trowval=trowval, tnzval=tnzval, effective_lengths=eff,
+               gene=gene, num_genes=int(L.synth_num_genes(h)), gamma=float(L.synth_gamma(h)))
+    L.synth_free(h)
+    return out
+
+
+def to_csc(s):
+    """Xt (CSR) -> the CSC arrays of the likelihood-matrix HDF5 (colptr u64 1-based, rowval u32 1-based, nzval)."""
+    m, n, nnz = s["m"], s["n"], s["nnz"]
+    colptr = np.zeros(n + 1, np.uint64)
+    rowval = np.empty(nnz, np.uint32)
+    nzval = np.empty(nnz, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().synth_csr_to_csc(C.c_int64(m), C.c_int64(n), p(s["tcolptr"]), p(s["trowval"]), p(s["tnzval"]), p(colptr),
+                           p(rowval), p(nzval))
+    return colptr, rowval, nzval
+
+
+def make_tree(gene, seed=1, kind="hclust"):
+    """Serialised tree (node_parent_idxs, node_js; 1-based, DFS pre-order, right child first).
+    'hclust': isoforms of a gene form a subtree; gene subtrees are joined by a random recursive
+    split that peels single genes off with probability 0.3 (long spines, like hclust output);
+    'balanced': perfectly balanced over transcripts in order; 'spine': caterpillar (the reference's
+    :sequential tree, hclust.jl:477-489)."""
+    rng = np.random.default_rng(seed)
+    gene = np.asarray(gene)
+    n = gene.size
+    parents = np.zeros(2 * n - 1, np.int32)
+    js = np.zeros(2 * n - 1, np.int32)
+    # work items: (lo, hi, parent, level) over an ordering of leaves; level 0 = genes, 1 = within gene
+    if kind == "hclust":
+        starts = np.flatnonzero(np.r_[True, gene[1:] != gene[:-1]])
+        ends = np.r_[starts[1:], n]
+        ng = starts.size
+    idx = 0
+    stack = [("g", 0, (starts.size if kind == "hclust" else n), 0)]
+    while stack:
+        typ, lo, hi, par = stack.pop()
+        me = idx + 1
+        if typ == "g" and kind == "hclust":
+            if hi - lo == 1:
+                stack.append(("t", int(starts[lo]), int(ends[lo]), par))
+                continue
+            parents[idx] = par; idx += 1
+            if rng.random() < 0.3:
+                cut = lo + 1 if rng.random() < 0.5 else hi - 1
+            else:
+                cut = int(rng.integers(lo + 1, hi))
+            stack.append(("g", lo, cut, me)); stack.append(("g", cut, hi, me))
+        else:
+            if hi - lo == 1:
+                parents[idx] = par; js[idx] = lo + 1; idx += 1
+                continue
+            parents[idx] = par; idx += 1
+            if kind == "spine":
+                cut = lo + 1
+            elif kind == "balanced":
+                cut = (lo + hi) // 2
+            else:
+                cut = int(rng.integers(lo + 1, hi))
+            stack.append(("t", lo, cut, me)); stack.append(("t", cut, hi, me))
+    assert idx == 2 * n - 1
+    return parents, js
