@@ -32,6 +32,7 @@ typedef struct {
     const uint32_t *dict;       /* [dict_len] 0-based transcript ids                       */
     const uint32_t *row_order;  /* [num_slices*64] 0-based fragment per lane, ~0 = empty   */
     const float *slice_ks;      /* [num_slices*64] or NULL                                 */
+    const uint8_t *slice_flags; /* [num_slices] bit0 uniform, bit1 continues previous      */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

@@ -71,6 +71,7 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->data = h.data.data(); v->slice_off = h.slice_off.data(); v->tile_slice = h.tile_slice.data();
     v->tile_dict = h.tile_dict.data(); v->dict = h.dict.data(); v->row_order = h.row_order.data();
     v->slice_ks = h.slice_ks.empty() ? nullptr : h.slice_ks.data();
+    v->slice_flags = h.slice_flags.data();
     return POLEE_OK;
 }
 

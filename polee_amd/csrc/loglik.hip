@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace polee {
 
@@ -31,6 +32,23 @@ __device__ inline float wave_sum_to_lane63(float v)
     v = dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
     return v;
 }
+// the same for N values at once, step-major so that the N dependency chains interleave
+template <int N>
+__device__ inline void wave_sum_to_lane63_n(float (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x111, 0xf, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x112, 0xf, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x114, 0xf, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x118, 0xf, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xa, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xc, 0xf>(v[i]);
+}
 
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_mov0(float v)  // lanes without a source (or in masked-off rows) read 0
@@ -47,10 +65,10 @@ __device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
     const int c0 = __builtin_amdgcn_readfirstlane(c);
     if (__all(c == c0)) {  // one column for the whole wavefront: plain wave sum
         float *gr = gw + c0 * K;
+        wave_sum_to_lane63_n<K>(q);
+        if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float r = wave_sum_to_lane63(q[k]);
-            if (lane == 63) atomicAdd(gr + k, r);
+            for (int k = 0; k < K; ++k) atomicAdd(gr + k, q[k]);
         }
         return;
     }
@@ -64,16 +82,17 @@ __device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
     const float mb15 = dist > rl ? 1.f : 0.f;           // run started in an earlier row of 16
     const float mb31 = dist > (lane & 31) ? 1.f : 0.f;  // run started before lane 32
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float v = q[k];
-        v = fmaf(dpp_mov0<0x111, 0xf>(v), m1, v);
-        v = fmaf(dpp_mov0<0x112, 0xf>(v), m2, v);
-        v = fmaf(dpp_mov0<0x114, 0xf>(v), m4, v);
-        v = fmaf(dpp_mov0<0x118, 0xf>(v), m8, v);
-        v = fmaf(dpp_mov0<0x142, 0xa>(v), mb15, v);  // row_bcast:15 -> rows 1, 3
-        v = fmaf(dpp_mov0<0x143, 0xc>(v), mb31, v);  // row_bcast:31 -> rows 2, 3
-        q[k] = v;
-    }
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x111, 0xf>(q[k]), m1, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x112, 0xf>(q[k]), m2, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x114, 0xf>(q[k]), m4, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x118, 0xf>(q[k]), m8, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x142, 0xa>(q[k]), mb15, q[k]);  // row_bcast:15 -> rows 1, 3
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x143, 0xc>(q[k]), mb31, q[k]);  // row_bcast:31 -> rows 2, 3
     const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
     if (tail) {
         float *gr = gw + c * K;
@@ -83,6 +102,18 @@ __device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
     }
 }
 
+constexpr int PSELL_WACC = 16;  // transcripts per row whose contributions are accumulated in registers
+
+__device__ inline float fast_weight(float ksv, float s)
+{
+    // ks / s with v_rcp_f32 (1 ulp): well inside the 1e-4 budget, 10x fewer instructions than a division
+    return s > 0.0f ? ksv * __builtin_amdgcn_rcpf(s) : 0.0f;  // padded lanes (and empty rows) have s = 0
+}
+
+// ---- stream B (and fallback for very wide rows): mixed slices ---------------------------------------
+// Two sweeps over each slice straight from global memory (the second one hits L1/L2); contributions
+// are summed per run of equal transcript ids with DPP before touching LDS.  Few registers -> high
+// occupancy hides the latency.
 template <int K, bool WANT_LP, bool HAS_KS>
 __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__restrict__ data,
                                                           const uint32_t *__restrict__ slice_off,
@@ -91,14 +122,14 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
                                                           const uint32_t *__restrict__ dict,
                                                           const float *__restrict__ slice_ks,
                                                           const float *__restrict__ x, float *__restrict__ g,
-                                                          double *__restrict__ lp, int lcap)
+                                                          double *__restrict__ lp, int lcap, int tile_base)
 {
     extern __shared__ float lds[];
     float *xw = lds;                     // [L][K] tile-local copy of x
     float *gw = lds + (size_t)lcap * K;  // [L][K] tile-local gradient accumulator
     __shared__ double lp_red[4];
 
-    const int tile = blockIdx.x;
+    const int tile = tile_base + blockIdx.x;
     const uint32_t d0 = tile_dict[tile];
     const int L = (int)(tile_dict[tile + 1] - d0);
     for (int i = threadIdx.x; i < L * K; i += 256) {
@@ -146,16 +177,13 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
 #pragma unroll
             for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, xr[k], sacc[k]);
         }
-
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
         float wk[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool live = sacc[k] > 0.0f;  // padded lanes (and empty rows) have s = 0
-            wk[k] = live ? ksv / sacc[k] : 0.0f;
-            if (WANT_LP && live) lpacc[k] += (double)ksv * log((double)sacc[k]);
+            wk[k] = fast_weight(ksv, sacc[k]);
+            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
         }
-
         // sweep 2 (slice is L1/L2 resident): g[c[t]][k] += v[t] * w[k], summed per run of equal ids
         for (t = 0; t < w; ++t) {
             const float v = vals[t * 64];
@@ -186,31 +214,281 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
     }
 }
 
+// ---- stream A: uniform slices, LDS-DMA streamed ------------------------------------------------------
+// Every slice holds 64 fragments with one and the same transcript set.  Each wave owns a contiguous
+// byte range of the slice stream (its quarter of the tile) and pulls it through a private 16 KiB LDS
+// ring with `global_load_lds_dwordx4` (1 KiB per wave-instruction, no VGPR destination), up to 16
+// pieces ahead of the slice being processed, so HBM sees every byte of X exactly once and memory-level
+// parallelism does not depend on occupancy.  x rows are wave-uniform (LDS broadcast reads), a slice's
+// values stay in registers for both sweeps, and gradient contributions accumulate per lane across the
+// whole run of slices sharing the set; lanes are only summed (DPP) when the run ends.
+constexpr int RING_BYTES = 16384;
+constexpr int RING_PIECES = RING_BYTES / 1024;
+
+__device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_lane), "s"(lds_dst)
+        : "memory");
+}
+
+// waits until at most `allowed` of this wave's vector-memory operations are outstanding (rounded down
+// to an encodable step: waiting for fewer outstanding operations is always safe)
+__device__ inline void wait_vm_outstanding(int allowed)
+{
+    if (allowed >= 12)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (allowed >= 8)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (allowed >= 6)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (allowed >= 4)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (allowed >= 3)
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (allowed >= 2)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (allowed >= 1)
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int K, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) void loglik_psell_ring_kernel(const uint8_t *__restrict__ data,
+                                                               const uint32_t *__restrict__ slice_off,
+                                                               const uint8_t *__restrict__ slice_flags,
+                                                               const uint32_t *__restrict__ tile_slice,
+                                                               const uint32_t *__restrict__ tile_dict,
+                                                               const uint32_t *__restrict__ dict,
+                                                               const float *__restrict__ slice_ks,
+                                                               const float *__restrict__ x, float *__restrict__ g,
+                                                               double *__restrict__ lp, int lcap, int dbg)
+{
+    extern __shared__ float lds[];  // [4 rings][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
+    const char *rings = reinterpret_cast<const char *>(lds);
+    float *xw = lds + 4 * RING_BYTES / 4;
+    float *gw = xw + (size_t)lcap * K;
+    double *lp_red = reinterpret_cast<double *>(gw + (size_t)((lcap * K + 1) & ~1));
+
+    const int tile = blockIdx.x;
+    const uint32_t d0 = tile_dict[tile];
+    const int L = (int)(tile_dict[tile + 1] - d0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t s0 = tile_slice[tile], s1 = tile_slice[tile + 1];
+    // each wave takes a contiguous quarter of the tile's slices: runs stay inside one wave
+    const uint32_t per = (s1 - s0 + 3u) >> 2;
+    const uint32_t sb = min(s0 + wave * per, s1), se = min(sb + per, s1);
+
+    // start streaming this wave's byte range before anything else
+    const uint32_t cb = slice_off[sb], ce = slice_off[se];  // 128-byte units
+    const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
+    const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
+    const char *ring = rings + wave * RING_BYTES;
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uintptr_t)(__attribute__((address_space(3))) const char *)ring);
+    int issued = 0;
+    {
+        const int target = min(npieces, RING_PIECES);
+        for (; issued < target; ++issued) dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (uint32_t)issued * 1024u);
+    }
+
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int l = i / K, k = i - l * K;
+        xw[i] = x[(size_t)dict[d0 + l] * K + k];
+        gw[i] = 0.0f;
+    }
+    __syncthreads();
+
+    double lpacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
+    // acc[t][k]: per-lane partial of g[pc[t]][k] for the current run; pc[t] (wave-uniform) = tile-local
+    // id of the run's t-th transcript
+    float acc[PSELL_WACC][K];
+    int pc[PSELL_WACC];
+#pragma unroll
+    for (int t = 0; t < PSELL_WACC; ++t) {
+        pc[t] = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[t][k] = 0.0f;
+    }
+    int pend_w = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int t = 0; t < PSELL_WACC; ++t) {
+            if (t < pend_w) {
+                float *gr = gw + pc[t] * K;
+                if (!(dbg & 16)) {
+                    wave_sum_to_lane63_n<K>(acc[t]);
+                    if (lane == 63) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) atomicAdd(gr + k, acc[t][k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[t][k] = 0.0f;
+            }
+        }
+        pend_w = 0;
+    };
+
+    uint32_t pos = 0;  // byte offset of the current slice inside this wave's range
+    for (uint32_t s = sb; s < se; ++s) {
+        const uint32_t off = slice_off[s];
+        const int w = (int)((slice_off[s + 1] - off) / 3u);
+        const int flags = slice_flags[s];
+        const uint32_t bytes = (uint32_t)w * 384u;
+        // all pieces covering [pos, pos+bytes) must have landed
+        wait_vm_outstanding(issued - (int)((pos + bytes + 1023u) >> 10));
+        const uint32_t vbase = pos + lane * 4u, cbase = pos + (uint32_t)w * 256u + lane * 2u;
+        auto ld_v = [&](int t) -> float {
+            return *reinterpret_cast<const float *>(ring + ((vbase + (uint32_t)t * 256u) & (RING_BYTES - 1)));
+        };
+        auto ld_c = [&](int t) -> int {
+            return *reinterpret_cast<const uint16_t *>(ring + ((cbase + (uint32_t)t * 128u) & (RING_BYTES - 1)));
+        };
+        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
+        float sacc[K], wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+
+        if (pend_w != 0 && !(flags & 2)) flush();
+        const bool fresh = pend_w == 0;
+        const int wa = min(w, PSELL_WACC);
+        auto body = [&](auto wc_tag) {
+            constexpr int WC = decltype(wc_tag)::value;
+            float v[WC];
+#pragma unroll
+            for (int t = 0; t < WC; ++t) v[t] = ld_v(t);
+            if (fresh) {
+                int cc[WC];
+#pragma unroll
+                for (int t = 0; t < WC; ++t) cc[t] = ld_c(t);
+#pragma unroll
+                for (int t = 0; t < WC; ++t) pc[t] = t < wa ? __builtin_amdgcn_readfirstlane(cc[t]) : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < WC; ++t) v[t] = t < wa ? v[t] : 0.0f;
+            if (!(dbg & 4)) {
+#pragma unroll
+                for (int t = 0; t < WC; ++t) {
+                    const float *xr = xw + pc[t] * K;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) sacc[k] = fmaf(v[t], xr[k], sacc[k]);
+                }
+            }
+            for (int t = PSELL_WACC; t < w; ++t) {  // transcripts beyond the register window
+                const float vv = ld_v(t);
+                const float *xr = xw + ld_c(t) * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sacc[k] = fmaf(vv, xr[k], sacc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                wk[k] = fast_weight(ksv, sacc[k]);
+                if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
+            }
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int t = 0; t < WC; ++t) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[t][k] = fmaf(v[t], wk[k], acc[t][k]);
+                }
+            }
+        };
+        if (w <= 4)
+            body(std::integral_constant<int, 4>{});
+        else if (w <= 8)
+            body(std::integral_constant<int, 8>{});
+        else
+            body(std::integral_constant<int, PSELL_WACC>{});
+        pend_w = wa;
+        if (!(dbg & 8))
+            for (int t = PSELL_WACC; t < w; ++t) {  // rare wide sets: immediate wave sums
+                const float v = ld_v(t);
+                const int c = ld_c(t);
+                float q[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) q[k] = v * wk[k];
+                scatter_runs<K>(c, q, gw, lane);
+            }
+
+        // the slice is consumed: refill the ring behind it
+        pos += bytes;
+        {
+            const int target = min(npieces, (int)(pos >> 10) + RING_PIECES);
+            for (; issued < target; ++issued)
+                dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (((uint32_t)issued * 1024u) & (RING_BYTES - 1)));
+        }
+    }
+    if (pend_w != 0) flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!(dbg & 1))
+        for (int i = threadIdx.x; i < L * K; i += 256) {
+            const int l = i / K, k = i - l * K;
+            const float v = gw[i];
+            if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
+        }
+    if (WANT_LP) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = lpacc[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if (lane == 0) lp_red[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
+            __syncthreads();
+        }
+    }
+}
+
+template <int K, bool LP, bool KS>
+static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
+{
+    const PsellHost &h = ll->host;
+    const int lcap = std::max(h.max_tile_cols, 1);
+    hipStream_t st = ll->ctx->stream;
+    static const bool no_ring = getenv("POLEE_NO_RING") != nullptr;
+    static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
+    int tiles_a = (int)h.num_tiles_a;
+    if (no_ring || (size_t)h.max_row * 384 + 1024 > (size_t)RING_BYTES) tiles_a = 0;  // rows too wide for the ring
+    if (tiles_a > 0) {
+        const size_t lds = (size_t)4 * RING_BYTES + ((size_t)2 * lcap * K + 2) * sizeof(float) + 4 * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)loglik_psell_ring_kernel<K, LP, KS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((loglik_psell_ring_kernel<K, LP, KS>), dim3((unsigned)tiles_a), dim3(256), lds, st,
+                           ll->d_data.p, ll->d_slice_off.p, ll->d_slice_flags.p, ll->d_tile_slice.p, ll->d_tile_dict.p,
+                           ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, dbg);
+    }
+    const int tiles_b = (int)h.num_tiles - tiles_a;
+    if (tiles_b > 0 && !(dbg & 32)) {
+        const size_t lds = (size_t)2 * lcap * K * sizeof(float);
+        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds, st, ll->d_data.p,
+                           ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p, ll->d_slice_ks.p,
+                           d_x, d_g, d_lp, lcap, tiles_a);
+    }
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_k(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
-    const PsellHost &h = ll->host;
-    if (h.num_tiles == 0) return hipSuccess;
-    const int lcap = std::max(h.max_tile_cols, 1);
-    const size_t lds = (size_t)2 * lcap * K * sizeof(float);
-    dim3 grid((unsigned)h.num_tiles), block(256);
-    hipStream_t st = ll->ctx->stream;
-#define POLEE_LAUNCH(LP, KS)                                                                                  \
-    hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), grid, block, lds, st, ll->d_data.p, ll->d_slice_off.p, \
-                       ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap)
-    if (d_lp) {
-        if (ll->has_ks)
-            POLEE_LAUNCH(true, true);
-        else
-            POLEE_LAUNCH(true, false);
-    } else {
-        if (ll->has_ks)
-            POLEE_LAUNCH(false, true);
-        else
-            POLEE_LAUNCH(false, false);
-    }
-#undef POLEE_LAUNCH
-    return hipGetLastError();
+    if (ll->host.num_tiles == 0) return hipSuccess;
+    if (d_lp) return ll->has_ks ? launch_variant<K, true, true>(ll, d_x, d_g, d_lp)
+                                : launch_variant<K, true, false>(ll, d_x, d_g, d_lp);
+    return ll->has_ks ? launch_variant<K, false, true>(ll, d_x, d_g, d_lp)
+                      : launch_variant<K, false, false>(ll, d_x, d_g, d_lp);
 }
 
 polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp)
@@ -333,9 +611,10 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
 {
     PsellHost &h = ll->host;
     polee_status s;
+    h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
-        (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_slice_flags.upload(ctx, h.slice_flags)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
         loglik_release(ll);
         return s;
     }
@@ -344,6 +623,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     std::vector<uint32_t>().swap(h.slice_off);
     std::vector<uint32_t>().swap(h.dict);
     std::vector<float>().swap(h.slice_ks);
+    std::vector<uint8_t>().swap(h.slice_flags);
     std::vector<uint32_t>().swap(h.row_order);
     *out = ll;
     return POLEE_OK;
@@ -458,7 +738,7 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_slices = h.num_slices;
     info->num_tiles = h.num_tiles;
     info->padded_nnz = h.padded_nnz;
-    info->stream_bytes = (int64_t)(ll->d_data.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
+    info->stream_bytes = (int64_t)(ll->d_data.n + ll->d_slice_flags.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
                                                         ll->d_dict.n + ll->d_slice_ks.n));
     info->device_bytes = info->stream_bytes;
     info->num_empty_rows = h.empty_rows;

@@ -15,6 +15,14 @@
 //     costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
 //   * The kernel stages the tile's x[dict][K] into LDS, accumulates the tile's gradient
 //     contributions in LDS (ds_add_f32) and flushes L*K values to HBM per tile.
+//   * Rows are split into two streams: A = whole slices of runs of >= 64 fragments with one and the
+//     same transcript set (tiles [0, num_tiles_a)), B = everything else.  A is processed by
+//     loglik_psell_ring_kernel (LDS-DMA streaming, register accumulation, no cross-lane traffic
+//     inside a run), B by loglik_psell_kernel (per-run DPP sums).
+//   * Each slice carries two flag bits: "uniform" (its 64 rows share one transcript set) and
+//     "continues" (the same set as the previous slice).  Runs of such slices -- the bulk of
+//     real and synthetic data, where many fragments fall into the same equivalence class --
+//     accumulate their gradient contributions in registers with no cross-lane traffic.
 // HBM traffic per likelihood pass ~ 6 B/nnz (+ padding + dictionaries), read once.
 #pragma once
 #include "common.hpp"
@@ -29,12 +37,15 @@ constexpr int PSELL_MAX_K = 8;
 struct PsellHost {
     int64_t m = 0, n = 0, nnz = 0;
     int64_t num_slices = 0, num_tiles = 0, padded_nnz = 0, empty_rows = 0;
+    // stream A (tiles [0, num_tiles_a)): only slices whose 64 rows share one transcript set
+    int64_t rows_a = 0, num_tiles_a = 0, num_slices_a = 0;
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units
     std::vector<uint32_t> tile_slice;  // [num_tiles+1]
     std::vector<uint32_t> tile_dict;   // [num_tiles+1]
     std::vector<uint32_t> dict;        // transcript ids (0-based)
+    std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
 };
@@ -55,6 +66,7 @@ struct polee_loglik {
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
     polee::DevBuf<float> d_slice_ks;
+    polee::DevBuf<uint8_t> d_slice_flags;
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;

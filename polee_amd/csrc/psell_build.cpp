@@ -88,6 +88,31 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     keys.clear();
     keys.shrink_to_fit();
 
+    // 1b. runs of rows with the same transcript set.  Stream A = the first 64*floor(r/64) rows of every
+    // run with r >= 64 (whole "uniform" slices); stream B = run remainders and short runs.  The two
+    // streams occupy disjoint tile ranges [0, num_tiles_a) and [num_tiles_a, num_tiles) and are
+    // processed by differently specialised kernels.
+    {
+        auto same_set = [&](uint32_t r1, uint32_t r2) {
+            const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
+            return l1 == l2 && std::equal(col + rowptr[r1], col + rowptr[r1] + l1, col + rowptr[r2]);
+        };
+        std::vector<uint32_t> ra, rb;
+        ra.reserve(rows.size());
+        size_t i = 0;
+        while (i < rows.size()) {
+            size_t j = i + 1;
+            while (j < rows.size() && same_set(rows[i], rows[j])) ++j;
+            const size_t r = j - i, whole = (r / PSELL_LANES) * PSELL_LANES;
+            ra.insert(ra.end(), rows.begin() + i, rows.begin() + i + whole);
+            rb.insert(rb.end(), rows.begin() + i + whole, rows.begin() + j);
+            i = j;
+        }
+        out.rows_a = (int64_t)ra.size();
+        rows.swap(ra);
+        rows.insert(rows.end(), rb.begin(), rb.end());
+    }
+
     // 2. greedy slices and tiles
     std::vector<uint32_t> col_stamp(n, 0);   // tile id + 1 in which the column was last registered
     std::vector<uint16_t> col_local(n, 0);
@@ -103,6 +128,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     uint32_t tile_nslices = 0;
     std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
     slice_rows.reserve(PSELL_LANES);
+    std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
+    bool prev_uniform = false;
 
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
@@ -129,6 +156,28 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.row_order.push_back(valid ? slice_rows[lane] : 0xffffffffu);
             if (ks) out.slice_ks.push_back(valid ? (float)ks[slice_rows[lane]] : 0.0f);
         }
+        // flags: bit0 = all 64 lanes hold rows with one and the same transcript set ("uniform"),
+        //        bit1 = uniform and the same set as the previous slice of this tile ("continues")
+        uint8_t flags = 0;
+        {
+            const uint32_t r0 = slice_rows[0];
+            const uint64_t b0 = rowptr[r0], len0 = rowptr[r0 + 1] - b0;
+            bool uni = slice_rows.size() == (size_t)PSELL_LANES;
+            for (size_t lane = 1; uni && lane < slice_rows.size(); ++lane) {
+                const uint32_t r = slice_rows[lane];
+                uni = (rowptr[r + 1] - rowptr[r] == len0) &&
+                      std::equal(col + b0, col + b0 + len0, col + rowptr[r]);
+            }
+            if (uni) {
+                flags |= 1;
+                if (prev_uniform && tile_nslices > 0 && prev_pattern.size() == len0 &&
+                    std::equal(prev_pattern.begin(), prev_pattern.end(), col + b0))
+                    flags |= 2;
+                prev_pattern.assign(col + b0, col + b0 + len0);
+            }
+            prev_uniform = uni;
+        }
+        out.slice_flags.push_back(flags);
         out.padded_nnz += (int64_t)w * 64;
         out.slice_off.push_back((uint32_t)(out.data.size() / 128));
         ++out.num_slices;
@@ -147,6 +196,13 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     };
 
     for (size_t ri = 0; ri < rows.size(); ++ri) {
+        if ((int64_t)ri == out.rows_a) {  // stream A ends here: start stream B on a fresh tile
+            close_slice();
+            close_tile();
+            out.num_tiles_a = out.num_tiles;
+            out.num_slices_a = out.num_slices;
+            prev_uniform = false;
+        }
         const uint32_t r = rows[ri];
         const uint64_t b = rowptr[r], e = rowptr[r + 1];
         for (;;) {
@@ -173,6 +229,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     }
     close_slice();
     close_tile();
+    if ((int64_t)rows.size() == out.rows_a) {
+        out.num_tiles_a = out.num_tiles;
+        out.num_slices_a = out.num_slices;
+    }
+    for (int64_t s = 0; s < out.num_slices_a; ++s)
+        if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
     if (out.data.size() / 128 > 0xffffffffull) return "matrix too large for 32-bit slice offsets";
     return "";
 }
