@@ -102,8 +102,6 @@ __device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
     }
 }
 
-constexpr int PSELL_WACC = 16;  // transcripts per row whose contributions are accumulated in registers
-
 __device__ inline float fast_weight(float ksv, float s)
 {
     // ks / s with v_rcp_f32 (1 ulp): well inside the 1e-4 budget, 10x fewer instructions than a division
@@ -214,22 +212,28 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
     }
 }
 
-// ---- stream A: uniform slices, LDS-DMA streamed ------------------------------------------------------
-// Every slice holds 64 fragments with one and the same transcript set.  Each wave owns a contiguous
-// byte range of the slice stream (its quarter of the tile) and pulls it through a private 16 KiB LDS
-// ring with `global_load_lds_dwordx4` (1 KiB per wave-instruction, no VGPR destination), up to 16
-// pieces ahead of the slice being processed, so HBM sees every byte of X exactly once and memory-level
-// parallelism does not depend on occupancy.  x rows are wave-uniform (LDS broadcast reads), a slice's
-// values stay in registers for both sweeps, and gradient contributions accumulate per lane across the
-// whole run of slices sharing the set; lanes are only summed (DPP) when the run ends.
-constexpr int RING_BYTES = 16384;
-constexpr int RING_PIECES = RING_BYTES / 1024;
-
+// ---- stream A: uniform slices, LDS-DMA streamed, transposed accumulation --------------------------------
+// Every slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs
+// of consecutive slices with the same set are marked by the builder.  For such a slice
+//     s[r][k]  = sum_t V[r][t] x[c_t][k]          (phase 1, lane = fragment r; x rows are LDS broadcasts)
+//     G[t][k] += sum_r V[r][t] ks_r / s[r][k]     (phase 2, lane = one (t, k) pair)
+// Phase 2 is the transpose of phase 1.  Instead of summing 64 lanes with DPP, the weights W[k][r] are
+// written to LDS and every lane walks the 64 fragments for its own (t, k) with 16-byte LDS reads of
+// V[t][.] (already in the ring) and W[k][.]; the partial G stays in ONE register per lane for the whole
+// run and is added to the tile window once, by its owner, when the run ends.  No cross-lane reduction,
+// ~60 VGPRs, so occupancy is set by LDS (ring size), not registers.
+//
+// Streaming: each wave owns a contiguous byte range of the slice stream (its quarter of the tile) and
+// pulls it through a private LDS ring of RP KiB with `global_load_lds_dwordx4` (1 KiB per
+// wave-instruction, no VGPR destination), RP pieces ahead; HBM sees every byte of X exactly once.
+#ifndef POLEE_DMA_POLICY
+#define POLEE_DMA_POLICY " nt"  // X is read once per pass: non-temporal keeps it from evicting x / g lines
+#endif
 __device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst)
 {
     unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" POLEE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc_lane), "s"(lds_dst)
         : "memory");
@@ -239,12 +243,14 @@ __device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst)
 // to an encodable step: waiting for fewer outstanding operations is always safe)
 __device__ inline void wait_vm_outstanding(int allowed)
 {
-    if (allowed >= 12)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (allowed >= 10)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if (allowed >= 8)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (allowed >= 6)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (allowed >= 5)
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (allowed >= 4)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (allowed >= 3)
@@ -257,24 +263,28 @@ __device__ inline void wait_vm_outstanding(int allowed)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int K, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) void loglik_psell_ring_kernel(const uint8_t *__restrict__ data,
-                                                               const uint32_t *__restrict__ slice_off,
-                                                               const uint8_t *__restrict__ slice_flags,
-                                                               const uint32_t *__restrict__ tile_slice,
-                                                               const uint32_t *__restrict__ tile_dict,
-                                                               const uint32_t *__restrict__ dict,
-                                                               const float *__restrict__ slice_ks,
-                                                               const float *__restrict__ x, float *__restrict__ g,
-                                                               double *__restrict__ lp, int lcap, int dbg)
+template <int K, int RP, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__restrict__ data,
+                                                            const uint32_t *__restrict__ slice_off,
+                                                            const uint8_t *__restrict__ slice_flags,
+                                                            const uint32_t *__restrict__ tile_slice,
+                                                            const uint32_t *__restrict__ tile_dict,
+                                                            const uint32_t *__restrict__ dict,
+                                                            const float *__restrict__ slice_ks,
+                                                            const float *__restrict__ x, float *__restrict__ g,
+                                                            double *__restrict__ lp, int lcap, int tile_base, int dbg)
 {
-    extern __shared__ float lds[];  // [4 rings][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
+    constexpr uint32_t RB = RP * 1024u;   // ring bytes per wave
+    constexpr int WMAXR = RP >= 12 ? PSELL_WIDE_MAX : PSELL_NARROW_MAX;  // widest set this instantiation sees
+    constexpr int NSET = (WMAXR * K + 63) / 64;                          // (t, k) pairs per lane
+    extern __shared__ float lds[];  // [4 rings][4 W buffers: K*64 floats][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
     const char *rings = reinterpret_cast<const char *>(lds);
-    float *xw = lds + 4 * RING_BYTES / 4;
+    float *wbufs = lds + 4 * RB / 4;
+    float *xw = wbufs + 4 * K * 64;
     float *gw = xw + (size_t)lcap * K;
     double *lp_red = reinterpret_cast<double *>(gw + (size_t)((lcap * K + 1) & ~1));
 
-    const int tile = blockIdx.x;
+    const int tile = tile_base + blockIdx.x;
     const uint32_t d0 = tile_dict[tile];
     const int L = (int)(tile_dict[tile + 1] - d0);
     const int lane = threadIdx.x & 63;
@@ -288,14 +298,18 @@ __global__ __launch_bounds__(256) void loglik_psell_ring_kernel(const uint8_t *_
     const uint32_t cb = slice_off[sb], ce = slice_off[se];  // 128-byte units
     const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
     const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
-    const char *ring = rings + wave * RING_BYTES;
+    const char *ring = rings + wave * RB;
+    float *wbuf = wbufs + wave * K * 64;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(uintptr_t)(__attribute__((address_space(3))) const char *)ring);
-    int issued = 0;
-    {
-        const int target = min(npieces, RING_PIECES);
-        for (; issued < target; ++issued) dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (uint32_t)issued * 1024u);
-    }
+    int issued = 0, islot = 0;
+    auto refill = [&](int target) {
+        for (; issued < target; ++issued) {
+            dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (uint32_t)islot * 1024u);
+            islot = islot + 1 == RP ? 0 : islot + 1;
+        }
+    };
+    refill(min(npieces, RP));
 
     for (int i = threadIdx.x; i < L * K; i += 256) {
         const int l = i / K, k = i - l * K;
@@ -307,126 +321,121 @@ __global__ __launch_bounds__(256) void loglik_psell_ring_kernel(const uint8_t *_
     double lpacc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
-    // acc[t][k]: per-lane partial of g[pc[t]][k] for the current run; pc[t] (wave-uniform) = tile-local
-    // id of the run's t-th transcript
-    float acc[PSELL_WACC][K];
-    int pc[PSELL_WACC];
+
+    // this lane's (t, k) pairs: pair p = lane + 64*j  ->  t = p / K, k = p % K
+    int pt[NSET], pk[NSET], mycol[NSET];
+    int pc[WMAXR];  // wave-uniform tile-local transcript ids of the current run
+    float acc[NSET];
 #pragma unroll
-    for (int t = 0; t < PSELL_WACC; ++t) {
-        pc[t] = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[t][k] = 0.0f;
+    for (int j = 0; j < NSET; ++j) {
+        const int p = lane + 64 * j;
+        pt[j] = p / K;
+        pk[j] = p - pt[j] * K;
+        mycol[j] = 0;
+        acc[j] = 0.0f;
     }
-    int pend_w = 0;
+    int pend_pairs = 0;  // w * K of the current run (0: no run open)
     auto flush = [&]() {
 #pragma unroll
-        for (int t = 0; t < PSELL_WACC; ++t) {
-            if (t < pend_w) {
-                float *gr = gw + pc[t] * K;
-                if (!(dbg & 16)) {
-                    wave_sum_to_lane63_n<K>(acc[t]);
-                    if (lane == 63) {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) atomicAdd(gr + k, acc[t][k]);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc[t][k] = 0.0f;
+        for (int j = 0; j < NSET; ++j) {
+            if (64 * j < pend_pairs) {
+                if (lane + 64 * j < pend_pairs && acc[j] != 0.0f) atomicAdd(gw + mycol[j] * K + pk[j], acc[j]);
+                acc[j] = 0.0f;
             }
         }
-        pend_w = 0;
+        pend_pairs = 0;
     };
 
-    uint32_t pos = 0;  // byte offset of the current slice inside this wave's range
+    uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
+    uint32_t pos_r = 0;  // pos modulo the ring size
     for (uint32_t s = sb; s < se; ++s) {
         const uint32_t off = slice_off[s];
-        const int w = (int)((slice_off[s + 1] - off) / 3u);
+        const uint32_t units = slice_off[s + 1] - off;
+        const int w = (int)(units / 3u);
         const int flags = slice_flags[s];
-        const uint32_t bytes = (uint32_t)w * 384u;
+        const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
         wait_vm_outstanding(issued - (int)((pos + bytes + 1023u) >> 10));
-        const uint32_t vbase = pos + lane * 4u, cbase = pos + (uint32_t)w * 256u + lane * 2u;
-        auto ld_v = [&](int t) -> float {
-            return *reinterpret_cast<const float *>(ring + ((vbase + (uint32_t)t * 256u) & (RING_BYTES - 1)));
+        auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
+            uint32_t a = pos_r + rel;
+            if ((RB & (RB - 1)) == 0)
+                a &= RB - 1;
+            else
+                a = a >= RB ? a - RB : a;
+            return ring + a;
         };
-        auto ld_c = [&](int t) -> int {
-            return *reinterpret_cast<const uint16_t *>(ring + ((cbase + (uint32_t)t * 128u) & (RING_BYTES - 1)));
-        };
-        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
-        float sacc[K], wk[K];
+        const int npairs = w * K;
+        if (pend_pairs != 0 && !(flags & 2)) flush();
+        if (pend_pairs == 0) {  // a new run: look up the tile-local ids of its transcripts
+#pragma unroll
+            for (int j = 0; j < NSET; ++j)
+                if (lane + 64 * j < npairs)
+                    mycol[j] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)pt[j] * 128u));
+#pragma unroll
+            for (int t = 0; t < WMAXR; ++t) {
+                pc[t] = 0;
+                if (t < w)
+                    pc[t] = __builtin_amdgcn_readfirstlane(
+                        (int)*reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)t * 128u)));
+            }
+        }
+
+        // phase 1 (lane = fragment): row sums s[k] = sum_t V[lane][t] x[c_t][k] (x rows: uniform LDS reads)
+        float sacc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
-
-        if (pend_w != 0 && !(flags & 2)) flush();
-        const bool fresh = pend_w == 0;
-        const int wa = min(w, PSELL_WACC);
-        auto body = [&](auto wc_tag) {
-            constexpr int WC = decltype(wc_tag)::value;
-            float v[WC];
+        if (!(dbg & 4)) {
 #pragma unroll
-            for (int t = 0; t < WC; ++t) v[t] = ld_v(t);
-            if (fresh) {
-                int cc[WC];
-#pragma unroll
-                for (int t = 0; t < WC; ++t) cc[t] = ld_c(t);
-#pragma unroll
-                for (int t = 0; t < WC; ++t) pc[t] = t < wa ? __builtin_amdgcn_readfirstlane(cc[t]) : 0;
-            }
-#pragma unroll
-            for (int t = 0; t < WC; ++t) v[t] = t < wa ? v[t] : 0.0f;
-            if (!(dbg & 4)) {
-#pragma unroll
-                for (int t = 0; t < WC; ++t) {
+            for (int t = 0; t < WMAXR; ++t) {
+                if (t < w) {
+                    const float v = *reinterpret_cast<const float *>(ring_at((uint32_t)t * 256u + lane * 4u));
                     const float *xr = xw + pc[t] * K;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) sacc[k] = fmaf(v[t], xr[k], sacc[k]);
+                    for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, xr[k], sacc[k]);
                 }
             }
-            for (int t = PSELL_WACC; t < w; ++t) {  // transcripts beyond the register window
-                const float vv = ld_v(t);
-                const float *xr = xw + ld_c(t) * K;
+        }
+        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) sacc[k] = fmaf(vv, xr[k], sacc[k]);
-            }
+        for (int k = 0; k < K; ++k) {
+            wbuf[k * 64 + lane] = fast_weight(ksv, sacc[k]);
+            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
+        }
+
+        // phase 2 (lane = (t, k) pair): G[t][k] += sum_r V[t][r] W[k][r], 4 fragments per LDS read; lanes start
+        // at different 16-byte slots so that the 16 lanes of an LDS read group hit 16 different bank groups
+        if (!(dbg & 2)) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                wk[k] = fast_weight(ksv, sacc[k]);
-                if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
-            }
-            if (!(dbg & 2)) {
+            for (int j = 0; j < NSET; ++j) {
+                if (64 * j < npairs) {
+                    if (lane + 64 * j < npairs) {
+                        const char *vrow = ring_at((uint32_t)pt[j] * 256u);
+                        const char *wrow = reinterpret_cast<const char *>(wbuf + pk[j] * 64);
+                        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int t = 0; t < WC; ++t) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) acc[t][k] = fmaf(v[t], wk[k], acc[t][k]);
+                        for (int it = 0; it < 16; ++it) {
+                            const int slot = ((it + lane) & 15) * 16;
+                            const float4 a = *reinterpret_cast<const float4 *>(vrow + slot);
+                            const float4 b = *reinterpret_cast<const float4 *>(wrow + slot);
+                            a0 = fmaf(a.x, b.x, a0);
+                            a1 = fmaf(a.y, b.y, a1);
+                            a0 = fmaf(a.z, b.z, a0);
+                            a1 = fmaf(a.w, b.w, a1);
+                        }
+                        acc[j] += a0 + a1;
+                    }
                 }
             }
-        };
-        if (w <= 4)
-            body(std::integral_constant<int, 4>{});
-        else if (w <= 8)
-            body(std::integral_constant<int, 8>{});
-        else
-            body(std::integral_constant<int, PSELL_WACC>{});
-        pend_w = wa;
-        if (!(dbg & 8))
-            for (int t = PSELL_WACC; t < w; ++t) {  // rare wide sets: immediate wave sums
-                const float v = ld_v(t);
-                const int c = ld_c(t);
-                float q[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) q[k] = v * wk[k];
-                scatter_runs<K>(c, q, gw, lane);
-            }
+        }
+        pend_pairs = npairs;
 
         // the slice is consumed: refill the ring behind it
         pos += bytes;
-        {
-            const int target = min(npieces, (int)(pos >> 10) + RING_PIECES);
-            for (; issued < target; ++issued)
-                dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (((uint32_t)issued * 1024u) & (RING_BYTES - 1)));
-        }
+        pos_r += bytes;
+        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+        refill(min(npieces, (int)(pos >> 10) + RP));
     }
-    if (pend_w != 0) flush();
+    if (pend_pairs != 0) flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!(dbg & 1))
@@ -449,6 +458,23 @@ __global__ __launch_bounds__(256) void loglik_psell_ring_kernel(const uint8_t *_
     }
 }
 
+template <int K, int RP, bool LP, bool KS>
+static void launch_uniform(polee_loglik *ll, hipStream_t st, const float *d_x, float *d_g, double *d_lp, int tile_base,
+                           int ntiles, int lcap, int dbg)
+{
+    const size_t lds = (size_t)4 * RP * 1024 + (size_t)4 * K * 64 * sizeof(float) +
+                       ((size_t)2 * lcap * K + 2) * sizeof(float) + 4 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)loglik_uniform_kernel<K, RP, LP, KS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((loglik_uniform_kernel<K, RP, LP, KS>), dim3((unsigned)ntiles), dim3(256), lds, st,
+                       ll->d_data.p, ll->d_slice_off.p, ll->d_slice_flags.p, ll->d_tile_slice.p, ll->d_tile_dict.p,
+                       ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, tile_base, dbg);
+}
+
 template <int K, bool LP, bool KS>
 static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
@@ -457,26 +483,40 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     hipStream_t st = ll->ctx->stream;
     static const bool no_ring = getenv("POLEE_NO_RING") != nullptr;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
-    int tiles_a = (int)h.num_tiles_a;
-    if (no_ring || (size_t)h.max_row * 384 + 1024 > (size_t)RING_BYTES) tiles_a = 0;  // rows too wide for the ring
-    if (tiles_a > 0) {
-        const size_t lds = (size_t)4 * RING_BYTES + ((size_t)2 * lcap * K + 2) * sizeof(float) + 4 * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)loglik_psell_ring_kernel<K, LP, KS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((loglik_psell_ring_kernel<K, LP, KS>), dim3((unsigned)tiles_a), dim3(256), lds, st,
-                           ll->d_data.p, ll->d_slice_off.p, ll->d_slice_flags.p, ll->d_tile_slice.p, ll->d_tile_dict.p,
-                           ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, dbg);
-    }
+    int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a;
+    if (no_ring) tiles_a1 = tiles_a = 0;
+    // ring sizes: a slice of w transcripts occupies ceil(w*384/256)*256 bytes and may start 896 bytes into a piece
+    static_assert(PSELL_NARROW_MAX * 384 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
+    static_assert(((PSELL_WIDE_MAX * 384 + 255) / 256) * 256 + 1024 <= 12 * 1024, "A2 slices must fit a 12 KiB ring");
+    static const int rp_a1 = getenv("POLEE_RP_A1") ? atoi(getenv("POLEE_RP_A1")) : 8;
     const int tiles_b = (int)h.num_tiles - tiles_a;
+    // the three streams of X only meet in the atomics on g: run A2 and B beside A1 on side streams
+    const bool fork = ll->side[0] && (tiles_a - tiles_a1 > 0 || tiles_b > 0) && tiles_a1 > 0 && !(dbg & 256);
+    hipStream_t st_a2 = fork ? ll->side[0] : st, st_b = fork ? ll->side[1] : st;
+    if (fork) {
+        (void)hipEventRecord(ll->ev_fork, st);
+        (void)hipStreamWaitEvent(st_a2, ll->ev_fork, 0);
+        (void)hipStreamWaitEvent(st_b, ll->ev_fork, 0);
+    }
+    if (tiles_a1 > 0 && !(dbg & 64)) {
+        if (rp_a1 == 12)
+            launch_uniform<K, 12, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
+        else
+            launch_uniform<K, 8, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
+    }
+    if (tiles_a - tiles_a1 > 0 && !(dbg & 128))
+        launch_uniform<K, 12, LP, KS>(ll, st_a2, d_x, d_g, d_lp, tiles_a1, tiles_a - tiles_a1, lcap, dbg);
     if (tiles_b > 0 && !(dbg & 32)) {
         const size_t lds = (size_t)2 * lcap * K * sizeof(float);
-        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds, st, ll->d_data.p,
+        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds, st_b, ll->d_data.p,
                            ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p, ll->d_slice_ks.p,
                            d_x, d_g, d_lp, lcap, tiles_a);
+    }
+    if (fork) {
+        (void)hipEventRecord(ll->ev_join[0], st_a2);
+        (void)hipEventRecord(ll->ev_join[1], st_b);
+        (void)hipStreamWaitEvent(st, ll->ev_join[0], 0);
+        (void)hipStreamWaitEvent(st, ll->ev_join[1], 0);
     }
     return hipGetLastError();
 }
@@ -586,6 +626,11 @@ void loglik_release(polee_loglik *ll)
     polee_ctx *ctx = ll->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
     for (hipEvent_t e : ll->prof_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ll->side[i]) (void)hipStreamDestroy(ll->side[i]);
+        if (ll->ev_join[i]) (void)hipEventDestroy(ll->ev_join[i]);
+    }
+    if (ll->ev_fork) (void)hipEventDestroy(ll->ev_fork);
     delete ll;
     ctx_release(ctx);
 }
@@ -612,6 +657,11 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     PsellHost &h = ll->host;
     polee_status s;
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
+    for (int i = 0; i < 2; ++i) {
+        if (hipStreamCreateWithFlags(&ll->side[i], hipStreamNonBlocking) != hipSuccess) ll->side[i] = nullptr;
+        if (hipEventCreateWithFlags(&ll->ev_join[i], hipEventDisableTiming) != hipSuccess) ll->side[0] = nullptr;
+    }
+    if (hipEventCreateWithFlags(&ll->ev_fork, hipEventDisableTiming) != hipSuccess) ll->side[0] = nullptr;
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_slice_flags.upload(ctx, h.slice_flags)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {

@@ -30,15 +30,22 @@
 namespace polee {
 
 constexpr int PSELL_LANES = 64;
-constexpr int PSELL_MAX_TILE_COLS = 1024;
-constexpr int PSELL_MAX_TILE_SLICES = 32;
+constexpr int PSELL_MAX_TILE_COLS = 1024;     // hard limit = longest supported row
+constexpr int PSELL_TILE_COLS_TARGET = 256;   // a tile is closed when its dictionary would grow past this
+constexpr int PSELL_TILE_SLICES_A1 = 64;      // slices per tile (= per workgroup) in each stream
+constexpr int PSELL_TILE_SLICES_A2 = 8;
+constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
+constexpr int PSELL_NARROW_MAX = 18;        // widest transcript set of stream A1 (8 KiB LDS ring)
+constexpr int PSELL_WIDE_MAX = 28;          // widest transcript set of stream A2 (12 KiB LDS ring)
+constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 
 struct PsellHost {
     int64_t m = 0, n = 0, nnz = 0;
     int64_t num_slices = 0, num_tiles = 0, padded_nnz = 0, empty_rows = 0;
     // stream A (tiles [0, num_tiles_a)): only slices whose 64 rows share one transcript set
     int64_t rows_a = 0, num_tiles_a = 0, num_slices_a = 0;
+    int64_t rows_a1 = 0, num_tiles_a1 = 0;  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units
@@ -71,6 +78,8 @@ struct polee_loglik {
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;
     // profiling of the sparse kernel
+    hipStream_t side[2] = {nullptr, nullptr};  // streams A2 and B run beside A1
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool profile = false;
     std::vector<hipEvent_t> prof_events;
     size_t prof_used = 0;

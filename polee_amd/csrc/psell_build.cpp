@@ -88,29 +88,46 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     keys.clear();
     keys.shrink_to_fit();
 
-    // 1b. runs of rows with the same transcript set.  Stream A = the first 64*floor(r/64) rows of every
-    // run with r >= 64 (whole "uniform" slices); stream B = run remainders and short runs.  The two
-    // streams occupy disjoint tile ranges [0, num_tiles_a) and [num_tiles_a, num_tiles) and are
-    // processed by differently specialised kernels.
+    // 1b. runs of rows with the same transcript set.  Rows are split into three streams, each a
+    // contiguous tile range processed by a differently specialised kernel launch:
+    //   A1: uniform slices (every valid row of a slice has the same transcript set), set size <= 18
+    //   A2: uniform slices, set size 19..28
+    //   B : everything else (short runs, small run remainders, very wide rows)
+    // A run of r rows contributes floor(r/64) whole slices to A, and its remainder as one more
+    // (zero-padded) uniform slice when the remainder is at least 32 rows.
+    std::vector<uint32_t> run_end;  // for stream A rows: index (in `rows`) one past the row's slice
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
             return l1 == l2 && std::equal(col + rowptr[r1], col + rowptr[r1] + l1, col + rowptr[r2]);
         };
-        std::vector<uint32_t> ra, rb;
-        ra.reserve(rows.size());
+        std::vector<uint32_t> ra1, ra2, rb, e1, e2;
         size_t i = 0;
         while (i < rows.size()) {
             size_t j = i + 1;
             while (j < rows.size() && same_set(rows[i], rows[j])) ++j;
-            const size_t r = j - i, whole = (r / PSELL_LANES) * PSELL_LANES;
-            ra.insert(ra.end(), rows.begin() + i, rows.begin() + i + whole);
-            rb.insert(rb.end(), rows.begin() + i + whole, rows.begin() + j);
+            const size_t r = j - i;
+            const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
+            size_t take = (r / PSELL_LANES) * PSELL_LANES;
+            if (r - take >= (size_t)PSELL_MIN_UNIFORM_ROWS) take = r;
+            if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
+            std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? ra1 : ra2;
+            std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? e1 : e2;
+            for (size_t q = 0; q < take; ++q) {
+                dst.push_back(rows[i + q]);
+                // slice boundary inside the run: after every 64 rows, and at the end of the taken part
+                de.push_back((q + 1) % PSELL_LANES == 0 || q + 1 == take ? 1u : 0u);
+            }
+            rb.insert(rb.end(), rows.begin() + i + take, rows.begin() + j);
             i = j;
         }
-        out.rows_a = (int64_t)ra.size();
-        rows.swap(ra);
+        out.rows_a1 = (int64_t)ra1.size();
+        out.rows_a = (int64_t)(ra1.size() + ra2.size());
+        rows.swap(ra1);
+        rows.insert(rows.end(), ra2.begin(), ra2.end());
         rows.insert(rows.end(), rb.begin(), rb.end());
+        run_end.swap(e1);
+        run_end.insert(run_end.end(), e2.begin(), e2.end());
     }
 
     // 2. greedy slices and tiles
@@ -136,7 +153,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         uint32_t w = 0;
         for (uint32_t r : slice_rows) w = std::max<uint32_t>(w, (uint32_t)(rowptr[r + 1] - rowptr[r]));
         const size_t base = out.data.size();
-        out.data.resize(base + (size_t)w * 384, 0);
+        // blocks are padded to a multiple of 256 bytes so that no 256-byte value row wraps in the LDS ring
+        out.data.resize(base + (((size_t)w * 384 + 255) & ~(size_t)255), 0);
         float *vals = reinterpret_cast<float *>(out.data.data() + base);
         uint16_t *lcols = reinterpret_cast<uint16_t *>(out.data.data() + base + (size_t)w * 256);
         for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
@@ -162,7 +180,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         {
             const uint32_t r0 = slice_rows[0];
             const uint64_t b0 = rowptr[r0], len0 = rowptr[r0 + 1] - b0;
-            bool uni = slice_rows.size() == (size_t)PSELL_LANES;
+            bool uni = true;
             for (size_t lane = 1; uni && lane < slice_rows.size(); ++lane) {
                 const uint32_t r = slice_rows[lane];
                 uni = (rowptr[r + 1] - rowptr[r] == len0) &&
@@ -196,6 +214,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     };
 
     for (size_t ri = 0; ri < rows.size(); ++ri) {
+        if ((int64_t)ri == out.rows_a1) {  // stream A1 ends here: start A2 on a fresh tile
+            close_slice();
+            close_tile();
+            out.num_tiles_a1 = out.num_tiles;
+            prev_uniform = false;
+        }
         if ((int64_t)ri == out.rows_a) {  // stream A ends here: start stream B on a fresh tile
             close_slice();
             close_tile();
@@ -208,7 +232,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         for (;;) {
             uint32_t fresh = 0;
             for (uint64_t k = b; k < e; ++k) fresh += col_stamp[col[k]] != tile_id;
-            if (tile_cols + fresh <= (uint32_t)PSELL_MAX_TILE_COLS) break;
+            if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && slice_rows.empty())) break;
             // does not fit into the current tile: finish it (possibly with a partial slice)
             close_slice();
             close_tile();
@@ -222,17 +246,23 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
         slice_rows.push_back(r);
-        if (slice_rows.size() == PSELL_LANES) {
+        const bool boundary = (int64_t)ri < out.rows_a ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
+        if (boundary) {
             close_slice();
-            if (tile_nslices >= (uint32_t)PSELL_MAX_TILE_SLICES) close_tile();
+            // small tiles for the two small streams (more workgroups, shorter tails)
+            const uint32_t cap = (int64_t)ri < out.rows_a1 ? PSELL_TILE_SLICES_A1
+                                 : (int64_t)ri < out.rows_a ? PSELL_TILE_SLICES_A2 : PSELL_TILE_SLICES_B;
+            if (tile_nslices >= cap) close_tile();
         }
     }
     close_slice();
     close_tile();
+    if ((int64_t)rows.size() == out.rows_a1) out.num_tiles_a1 = out.num_tiles;
     if ((int64_t)rows.size() == out.rows_a) {
         out.num_tiles_a = out.num_tiles;
         out.num_slices_a = out.num_slices;
     }
+    if (out.rows_a1 == out.rows_a) out.num_tiles_a1 = std::min(out.num_tiles_a1, out.num_tiles_a);
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
     if (out.data.size() / 128 > 0xffffffffull) return "matrix too large for 32-bit slice offsets";
