@@ -135,6 +135,12 @@ typedef struct {
     int64_t num_empty_rows;  /* fragments with no compatible transcript (skipped)       */
     int32_t max_row_nnz;
     int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
+    /* the three row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):   */
+    /* [0] uniform slices, sets of <= 18 transcripts; [1] uniform, 19..28; [2] everything else */
+    int64_t stream_rows[3];  /* fragments                                               */
+    int64_t stream_nnz[3];   /* non-zeros of X                                          */
+    int64_t stream_tiles[3]; /* workgroups per launch                                   */
+    int64_t stream_bytes_hbm[3]; /* bytes of the slice stream each launch reads          */
 } polee_loglik_info;
 polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info);
 
@@ -179,10 +185,13 @@ void polee_vi_default_opts(polee_vi_opts *opts);
 typedef struct {
     int32_t steps_done;
     int32_t nonfinite_step;        /* first step with a non-finite gradient, 0 if none    */
-    double loglik_kernel_ms_avg;   /* profile=1: mean duration of the sparse kernel       */
+    double loglik_kernel_ms_avg;   /* profile=1: mean duration of the dominant sparse     */
+                                   /* kernel (uniform stream A1; the whole pass if none)  */
     int64_t loglik_kernel_launches;
     double last_elbo;              /* !gradonly: reference-style elbo of the last step    */
     double last_lp_mean;           /* !gradonly: mean log-likelihood over the K draws     */
+    double loglik_pass_ms_avg;     /* profile=1: mean duration of one whole likelihood    */
+                                   /* pass (all three concurrent launches)                */
 } polee_vi_stats;
 
 /* Builds the state and the initial values mu = logit(inverse_transform(1/n)),

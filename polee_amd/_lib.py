@@ -46,14 +46,15 @@ class ViOpts(C.Structure):
 
 class ViStats(C.Structure):
     _fields_ = [("steps_done", C.c_int32), ("nonfinite_step", C.c_int32), ("loglik_kernel_ms_avg", C.c_double),
-                ("loglik_kernel_launches", C.c_int64), ("last_elbo", C.c_double), ("last_lp_mean", C.c_double)]
+                ("loglik_kernel_launches", C.c_int64), ("last_elbo", C.c_double), ("last_lp_mean", C.c_double), ("loglik_pass_ms_avg", C.c_double)]
 
 
 class LoglikInfo(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int64), ("nnz", C.c_int64), ("num_slices", C.c_int64),
                 ("num_tiles", C.c_int64), ("padded_nnz", C.c_int64), ("device_bytes", C.c_int64),
                 ("stream_bytes", C.c_int64), ("num_empty_rows", C.c_int64), ("max_row_nnz", C.c_int32),
-                ("max_tile_cols", C.c_int32)]
+                ("max_tile_cols", C.c_int32), ("stream_rows", C.c_int64 * 3), ("stream_nnz", C.c_int64 * 3),
+                ("stream_tiles", C.c_int64 * 3), ("stream_bytes_hbm", C.c_int64 * 3)]
 
 
 class PsellView(C.Structure):

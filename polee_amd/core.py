@@ -215,7 +215,7 @@ class RNASeqSample:
     def info(self):
         i = L.LoglikInfo()
         check(L.lib().polee_loglik_get_info(self._h, C.byref(i)))
-        return {k: getattr(i, k) for k, _ in i._fields_}
+        return {k: (list(getattr(i, k)) if hasattr(getattr(i, k), "__len__") else getattr(i, k)) for k, _ in i._fields_}
 
     def log_likelihood(self, xs, gradonly=False):
         """log_likelihood (likelihood.jl:36-56) for one vector [n] or K stacked vectors [K, n]

@@ -498,11 +498,16 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
         (void)hipStreamWaitEvent(st_a2, ll->ev_fork, 0);
         (void)hipStreamWaitEvent(st_b, ll->ev_fork, 0);
     }
-    if (tiles_a1 > 0 && !(dbg & 64)) {
+    // profiling events bracket the dominant launch (stream A1) alone; without one, the whole pass
+    const bool ev_a1 = tiles_a1 > 0 && !(dbg & 64);
+    if (ll->cur_e0 && !ev_a1) (void)hipEventRecord(ll->cur_e0, st);
+    if (ev_a1) {
+        if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
         if (rp_a1 == 12)
             launch_uniform<K, 12, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
         else
             launch_uniform<K, 8, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
+        if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     }
     if (tiles_a - tiles_a1 > 0 && !(dbg & 128))
         launch_uniform<K, 12, LP, KS>(ll, st_a2, d_x, d_g, d_lp, tiles_a1, tiles_a - tiles_a1, lcap, dbg);
@@ -518,6 +523,7 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
         (void)hipStreamWaitEvent(st, ll->ev_join[0], 0);
         (void)hipStreamWaitEvent(st, ll->ev_join[1], 0);
     }
+    if (ll->cur_e1 && !ev_a1) (void)hipEventRecord(ll->cur_e1, st);
     return hipGetLastError();
 }
 
@@ -535,23 +541,25 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
 {
     polee_ctx *ctx = ll->ctx;
     if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, p0 = nullptr, p1 = nullptr;
     if (ll->profile) {
-        if (ll->prof_used + 2 > ll->prof_events.size()) {
+        if (ll->prof_used + 4 > ll->prof_events.size()) {
             if (ll->prof_events.size() >= 8192) POLEE_TRY(ll->profile_collect());
-            if (ll->prof_used + 2 > ll->prof_events.size()) {
-                hipEvent_t a, b;
+            while (ll->prof_used + 4 > ll->prof_events.size()) {
+                hipEvent_t a;
                 POLEE_HIP_TRY(ctx, hipEventCreate(&a));
-                POLEE_HIP_TRY(ctx, hipEventCreate(&b));
                 ll->prof_events.push_back(a);
-                ll->prof_events.push_back(b);
             }
         }
         e0 = ll->prof_events[ll->prof_used];
         e1 = ll->prof_events[ll->prof_used + 1];
-        ll->prof_used += 2;
-        POLEE_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        p0 = ll->prof_events[ll->prof_used + 2];
+        p1 = ll->prof_events[ll->prof_used + 3];
+        ll->prof_used += 4;
+        POLEE_HIP_TRY(ctx, hipEventRecord(p0, ctx->stream));
     }
+    ll->cur_e0 = e0;
+    ll->cur_e1 = e1;
     hipError_t e = hipSuccess;
     switch (K) {
         case 1: e = launch_k<1>(ll, d_x, d_g, d_lp); break;
@@ -564,7 +572,7 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         case 8: e = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
     if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "likelihood kernel launch failed: %s", hipGetErrorString(e));
-    if (e1) POLEE_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    if (p1) POLEE_HIP_TRY(ctx, hipEventRecord(p1, ctx->stream));
     return POLEE_OK;
 }
 
@@ -642,10 +650,12 @@ polee_status polee_loglik::profile_collect()
 {
     if (prof_used == 0) return POLEE_OK;
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+    for (size_t i = 0; i + 3 < prof_used; i += 4) {
         float ms = 0.f;
         POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
         prof_ms_total += ms;
+        POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i + 2], prof_events[i + 3]));
+        prof_pass_ms_total += ms;
         ++prof_launches;
     }
     prof_used = 0;
@@ -794,6 +804,13 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_empty_rows = h.empty_rows;
     info->max_row_nnz = h.max_row;
     info->max_tile_cols = h.max_tile_cols;
+    const int64_t tiles[3] = {h.num_tiles_a1, h.num_tiles_a - h.num_tiles_a1, h.num_tiles - h.num_tiles_a};
+    for (int i = 0; i < 3; ++i) {
+        info->stream_rows[i] = h.stream_rows[i];
+        info->stream_nnz[i] = h.stream_nnz[i];
+        info->stream_tiles[i] = tiles[i];
+        info->stream_bytes_hbm[i] = h.stream_bytes[i];
+    }
     return POLEE_OK;
 }
 

@@ -45,7 +45,8 @@ struct PsellHost {
     int64_t num_slices = 0, num_tiles = 0, padded_nnz = 0, empty_rows = 0;
     // stream A (tiles [0, num_tiles_a)): only slices whose 64 rows share one transcript set
     int64_t rows_a = 0, num_tiles_a = 0, num_slices_a = 0;
-    int64_t rows_a1 = 0, num_tiles_a1 = 0;  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
+    int64_t rows_a1 = 0, num_tiles_a1 = 0;
+    int64_t stream_rows[3] = {0, 0, 0}, stream_nnz[3] = {0, 0, 0}, stream_bytes[3] = {0, 0, 0};  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units
@@ -81,10 +82,12 @@ struct polee_loglik {
     hipStream_t side[2] = {nullptr, nullptr};  // streams A2 and B run beside A1
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool profile = false;
+    hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;  // bracket the dominant launch of the current pass
+    hipEvent_t cur_p0 = nullptr, cur_p1 = nullptr;  // bracket the whole pass
     std::vector<hipEvent_t> prof_events;
     size_t prof_used = 0;
     int64_t prof_launches = 0;
-    double prof_ms_total = 0.0;
+    double prof_ms_total = 0.0, prof_pass_ms_total = 0.0;
     polee_status profile_collect();
 };
 

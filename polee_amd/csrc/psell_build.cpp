@@ -147,6 +147,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     slice_rows.reserve(PSELL_LANES);
     std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
     bool prev_uniform = false;
+    int cur_stream = 0;  // 0 = A1, 1 = A2, 2 = B
 
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
@@ -196,6 +197,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             prev_uniform = uni;
         }
         out.slice_flags.push_back(flags);
+        {
+            const int st = cur_stream;
+            out.stream_rows[st] += (int64_t)slice_rows.size();
+            for (uint32_t r : slice_rows) out.stream_nnz[st] += (int64_t)(rowptr[r + 1] - rowptr[r]);
+            out.stream_bytes[st] += (int64_t)(out.data.size() - base);
+        }
         out.padded_nnz += (int64_t)w * 64;
         out.slice_off.push_back((uint32_t)(out.data.size() / 128));
         ++out.num_slices;
@@ -219,6 +226,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             close_tile();
             out.num_tiles_a1 = out.num_tiles;
             prev_uniform = false;
+            cur_stream = 1;
         }
         if ((int64_t)ri == out.rows_a) {  // stream A ends here: start stream B on a fresh tile
             close_slice();
@@ -226,6 +234,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.num_tiles_a = out.num_tiles;
             out.num_slices_a = out.num_slices;
             prev_uniform = false;
+            cur_stream = 2;
         }
         const uint32_t r = rows[ri];
         const uint64_t b = rowptr[r], e = rowptr[r + 1];

@@ -149,8 +149,9 @@ polee_status ptt_forward_device(polee_ptt *t, const double *d_ys, int32_t B, con
 {
     polee_ctx *ctx = t->ctx;
     POLEE_TRY(t->reserve(B));
-    FwdLoad load{t->view(), d_ys};
-    FwdEmit emit{t->view(), d_ys,       o.uleaf,    o.logu,     o.xs,     o.xs_rs,
+    const EdgeLogs el{d_ys, o.ly, o.l1y, (int64_t)t->n - 1};
+    FwdLoad load{t->view(), el};
+    FwdEmit emit{t->view(), el,         o.uleaf,    o.logu,     o.xs,     o.xs_rs,
                  o.xs_es,   o.leaf_floor, o.clamp_lo, o.clamp_hi, o.efflens, o.efflens_rs};
     double *partials = o.row_sums ? t->d_part.p : nullptr;
     hipError_t e = run_scan_partial<double>(ctx->stream, B, t->TL, (double *)t->d_chunk.p, partials, load, emit);

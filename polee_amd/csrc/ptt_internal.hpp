@@ -85,32 +85,42 @@ namespace polee {
 // ---- device functors ------------------------------------------------------------------
 
 // log of the edge factor of a tour entry: log y (left) or log(1-y) (right); 0 for the root.
-__device__ inline double edge_log(uint32_t code, const double *ys_row)
-{
-    if (code & 4u) return 0.0;
-    const double y = ys_row[code >> 4];
-    return (code & 8u) ? log(y) : log1p(-y);
-}
+// logs (optional): precomputed [2][B][n-1] = {log y, log1p(-y)}; every internal node's logs are needed
+// by four tour entries in each scan phase, so callers on the hot path compute them once.
+struct EdgeLogs {
+    const double *ys;     // [B][n-1]
+    const double *ly;     // [B][n-1] log y, or null
+    const double *l1y;    // [B][n-1] log1p(-y), or null
+    int64_t nm1;
+    __device__ inline double operator()(uint32_t code, int row) const
+    {
+        if (code & 4u) return 0.0;
+        const int64_t o = (int64_t)row * nm1 + (code >> 4);
+        if (ly) return (code & 8u) ? ly[o] : l1y[o];
+        const double y = ys[o];
+        return (code & 8u) ? log(y) : log1p(-y);
+    }
+};
 
 // Forward (transform!, src/ptt.jl:125-160; HSB op hsb_ops.cpp:87-109): Euler-tour scan
 // of signed edge logs.  log u(node) = inclusive prefix at its ENTER; leaves add their
 // own edge.
 struct FwdLoad {
     PttView v;
-    const double *ys;  // [B][n-1]
+    EdgeLogs el;
     __device__ double operator()(int row, int64_t e) const
     {
         const uint32_t code = v.tour_code[(int64_t)v.tree(row) * v.TL + e];
         const uint32_t type = code & 3u;
         if (type == TOUR_LEAF) return 0.0;
-        const double lf = edge_log(code, ys + (int64_t)row * (v.n - 1));
+        const double lf = el(code, row);
         return type == TOUR_ENTER ? lf : -lf;
     }
 };
 
 struct FwdEmit {
     PttView v;
-    const double *ys;
+    EdgeLogs el;
     double *uleaf;         // [B][n] leaf order, or null
     double *logu;          // [B][n-1] by k, or null
     float *xs;             // transcript order, element (row, tid) at xs[row*xs_rs + tid*xs_es]; or null
@@ -128,7 +138,7 @@ struct FwdEmit {
         p0 = 0.0;
         p1 = 0.0;
         if (type == TOUR_LEAF) {
-            const double lu = incl + edge_log(code, ys + (int64_t)row * (v.n - 1));
+            const double lu = incl + el(code, row);
             const double u = exp(lu);
             const int pos = v.tour_tgt[tb + e];
             if (uleaf) uleaf[(int64_t)row * v.n + pos] = u;
@@ -236,6 +246,7 @@ struct FwdOut {
     float clamp_lo = 0.0f, clamp_hi = 1.0f;
     const float *efflens = nullptr;
     int64_t efflens_rs = 0;
+    const double *ly = nullptr, *l1y = nullptr;  // optional precomputed log y / log1p(-y), [B][n-1]
     double *row_sums = nullptr;  // [B][2]: {sum x/efflen, ladj}; needs partial reduction
 };
 polee_status ptt_forward_device(polee_ptt *t, const double *d_ys, int32_t B, const FwdOut &out);

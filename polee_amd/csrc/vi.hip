@@ -68,7 +68,7 @@ __device__ inline float logistic_f32(float x) { return 1.0f / (1.0f + expf(-x));
 // ladj_out [K][2] (skew, logit-normal) accumulated when non-null (unclamped y, as the
 // reference computes them before the clamp).
 __global__ void vi_sample_kernel(const float *mu, const float *omega, const float *alpha, NoiseSrc noise, int step,
-                                 double y_eps, int clamp, double *ys, double *ladj_out)
+                                 double y_eps, int clamp, double *ys, double *ly, double *l1y, double *ladj_out)
 {
     __shared__ double smd[4];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,6 +86,9 @@ __global__ void vi_sample_kernel(const float *mu, const float *omega, const floa
         }
         if (clamp) y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
         ys[(int64_t)d * noise.nm1 + k] = y;
+        // logs of the two edge factors, once per node (the tree scans read them four times each)
+        ly[(int64_t)d * noise.nm1 + k] = log(y);
+        l1y[(int64_t)d * noise.nm1 + k] = log1p(-y);
     }
     if (ladj_out) {
         l_skew = block_sum_f64(l_skew, smd);
@@ -295,7 +298,7 @@ struct polee_vi {
     int32_t step = 0;  // steps completed
     int32_t trace_cap = 0;
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
-    DevBuf<double> d_ys, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
+    DevBuf<double> d_ys, d_ly, d_l1y, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<int> d_flag;
     // outputs of the test hook
     DevBuf<double> d_ygrad, d_xgrad_rows;
@@ -319,7 +322,7 @@ polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
     if (nm1 > 0) {
         dim3 grid((unsigned)ceil_div(nm1, 256), K);
         hipLaunchKernelGGL(vi_sample_kernel, grid, dim3(256), 0, st, d_mu.p, d_omega.p, d_alpha.p, noise(), step_num,
-                           o.y_eps, 1, d_ys.p, want_values ? d_ladj_el.p : nullptr);
+                           o.y_eps, 1, d_ys.p, d_ly.p, d_l1y.p, want_values ? d_ladj_el.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
     }
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526)
@@ -332,6 +335,8 @@ polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
     fo.clamp_hi = (float)(1.0 - o.y_eps);
     fo.efflens = o.use_efflen_jacobian ? d_efflens.p : nullptr;
     fo.row_sums = (o.use_efflen_jacobian || want_values) ? d_rows.p : nullptr;
+    fo.ly = d_ly.p;
+    fo.l1y = d_l1y.p;
     POLEE_TRY(ptt_forward_device(t, d_ys.p, K, fo));
     // likelihood
     POLEE_HIP_TRY(ctx, hipMemsetAsync(d_g.p, 0, sizeof(float) * (size_t)n * K, st));
@@ -460,6 +465,8 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     A(vi->d_g.alloc(ctx, n * K));
     A(vi->d_x_rows.alloc(ctx, n * K));
     A(vi->d_ys.alloc(ctx, nm1 * K));
+    A(vi->d_ly.alloc(ctx, nm1 * K));
+    A(vi->d_l1y.alloc(ctx, nm1 * K));
     A(vi->d_ygrad.alloc(ctx, nm1 * K));
     A(vi->d_xgrad_rows.alloc(ctx, n * K));
     A(vi->d_lp.alloc(ctx, PSELL_MAX_K));
@@ -585,6 +592,7 @@ polee_status polee_vi_get_stats(polee_vi *vi, polee_vi_stats *stats)
     if (vi->ll->profile) POLEE_TRY(vi->ll->profile_collect());
     stats->loglik_kernel_launches = vi->ll->prof_launches;
     stats->loglik_kernel_ms_avg = vi->ll->prof_launches ? vi->ll->prof_ms_total / vi->ll->prof_launches : 0.0;
+    stats->loglik_pass_ms_avg = vi->ll->prof_launches ? vi->ll->prof_pass_ms_total / vi->ll->prof_launches : 0.0;
     if (!vi->o.gradonly && vi->step > 0 && vi->step <= vi->trace_cap) {
         POLEE_HIP_TRY(ctx, hipMemcpyAsync(&stats->last_elbo, vi->d_elbo.p + (vi->step - 1), sizeof(double),
                                           hipMemcpyDeviceToHost, ctx->stream));
