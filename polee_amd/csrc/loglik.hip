@@ -102,6 +102,24 @@ __device__ inline void scatter_runs(int c, float (&q)[K], float *gw, int lane)
     }
 }
 
+// sacc[k] += v * row[k]; rows of K floats start 8-byte aligned when K is even -> 8-byte LDS reads
+template <int K>
+__device__ inline void fma_row(float v, const float *row, float (&sacc)[K])
+{
+    if constexpr (K % 2 == 0) {
+        const float2 *r2 = reinterpret_cast<const float2 *>(row);
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            const float2 x = r2[k];
+            sacc[2 * k] = fmaf(v, x.x, sacc[2 * k]);
+            sacc[2 * k + 1] = fmaf(v, x.y, sacc[2 * k + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, row[k], sacc[k]);
+    }
+}
+
 __device__ inline float fast_weight(float ksv, float s)
 {
     // ks / s with v_rcp_f32 (1 ulp): well inside the 1e-4 budget, 10x fewer instructions than a division
@@ -144,8 +162,8 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
 
     for (uint32_t s = s0 + wave; s < s1; s += 4) {
-        const uint32_t off = slice_off[s];
-        const int w = (int)((slice_off[s + 1] - off) / 3u);
+        const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
+        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
         const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
         const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
 
@@ -163,18 +181,9 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
                 c[u] = cols[(t + u) * 64];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float *xr = xw + c[u] * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) sacc[k] = fmaf(v[u], xr[k], sacc[k]);
-            }
+            for (int u = 0; u < 4; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
         }
-        for (; t < w; ++t) {
-            const float v = vals[t * 64];
-            const float *xr = xw + (int)cols[t * 64] * K;
-#pragma unroll
-            for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, xr[k], sacc[k]);
-        }
+        for (; t < w; ++t) fma_row<K>(vals[t * 64], xw + (int)cols[t * 64] * K, sacc);
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
         float wk[K];
 #pragma unroll
@@ -263,10 +272,25 @@ __device__ inline void wait_vm_outstanding(int allowed)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef POLEE_STAMPS
+// diagnostic build only: where does a wave of the uniform kernel spend its cycles?
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                          \
+    do {                                                                  \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();    \
+        st_acc[i] += now__ - st_last;                                     \
+        st_last = now__;                                                  \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// LDS (not registers) sets the occupancy of this kernel: 3 workgroups per CU with the 8 KiB ring, 2 with the
+// 12 KiB ring.  Telling the backend so lets it keep many LDS reads in flight instead of minimising VGPRs.
 template <int K, int RP, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__restrict__ data,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 8 ? 3 : 2, RP <= 8 ? 3 : 2)))
+void loglik_uniform_kernel(const uint8_t *__restrict__ data,
                                                             const uint32_t *__restrict__ slice_off,
-                                                            const uint8_t *__restrict__ slice_flags,
                                                             const uint32_t *__restrict__ tile_slice,
                                                             const uint32_t *__restrict__ tile_dict,
                                                             const uint32_t *__restrict__ dict,
@@ -284,6 +308,10 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
     float *gw = xw + (size_t)lcap * K;
     double *lp_red = reinterpret_cast<double *>(gw + (size_t)((lcap * K + 1) & ~1));
 
+#ifdef POLEE_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     const int tile = tile_base + blockIdx.x;
     const uint32_t d0 = tile_dict[tile];
     const int L = (int)(tile_dict[tile + 1] - d0);
@@ -294,8 +322,14 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
     const uint32_t per = (s1 - s0 + 3u) >> 2;
     const uint32_t sb = min(s0 + wave * per, s1), se = min(sb + per, s1);
 
+    // slice offsets (+ flags in the top bits) of this wave's range, one per lane: a wave owns at most 63
+    // slices (tiles hold <= 64).  They are read with v_readlane inside the loop, so that the loop contains
+    // no compiler-visible memory load: a compiler-inserted s_waitcnt vmcnt(0) there would drain the
+    // LDS-DMA prefetch queue on every slice.
+    const uint32_t ent = slice_off[min(sb + (uint32_t)lane, se)];
     // start streaming this wave's byte range before anything else
-    const uint32_t cb = slice_off[sb], ce = slice_off[se];  // 128-byte units
+    const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ent, 0) & PSELL_OFF_MASK;
+    const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)(se - sb)) & PSELL_OFF_MASK;  // 128-byte units
     const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
     const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
     const char *ring = rings + wave * RB;
@@ -311,12 +345,38 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
     };
     refill(min(npieces, RP));
 
-    for (int i = threadIdx.x; i < L * K; i += 256) {
-        const int l = i / K, k = i - l * K;
-        xw[i] = x[(size_t)dict[d0 + l] * K + k];
-        gw[i] = 0.0f;
+    // stage the tile window: x[dict[l]][k] -> LDS, zero the accumulators.  Loads are issued for the whole
+    // window before any is consumed (two dependent HBM/L2 latencies per tile instead of 2 per 256 entries)
+    {
+        constexpr int NB = (PSELL_TILE_COLS_TARGET * K + 255) / 256;  // covers every tile built with the soft cap
+        float xv[NB];
+        uint32_t dv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = threadIdx.x + 256 * b;
+            dv[b] = i < L * K ? dict[d0 + i / K] : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = threadIdx.x + 256 * b;
+            xv[b] = i < L * K ? x[(size_t)dv[b] * K + (i - (i / K) * K)] : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = threadIdx.x + 256 * b;
+            if (i < L * K) {
+                xw[i] = xv[b];
+                gw[i] = 0.0f;
+            }
+        }
+        for (int i = threadIdx.x + 256 * NB; i < L * K; i += 256) {  // tiles with a larger dictionary (very long rows)
+            const int l = i / K, k = i - l * K;
+            xw[i] = x[(size_t)dict[d0 + l] * K + k];
+            gw[i] = 0.0f;
+        }
     }
     __syncthreads();
+    STAMP(0);  // prologue: first DMAs, window staging, barrier
 
     double lpacc[K];
 #pragma unroll
@@ -349,13 +409,18 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
     uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
     uint32_t pos_r = 0;  // pos modulo the ring size
     for (uint32_t s = sb; s < se; ++s) {
-        const uint32_t off = slice_off[s];
-        const uint32_t units = slice_off[s + 1] - off;
+        const int si = (int)(s - sb);
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent, si);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ent, si + 1);
+        const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
+        const int flags = (int)(e0 >> 30);
+        const uint32_t units = off_next - off;
         const int w = (int)(units / 3u);
-        const int flags = slice_flags[s];
         const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
+        STAMP(1);  // slice bookkeeping
         wait_vm_outstanding(issued - (int)((pos + bytes + 1023u) >> 10));
+        STAMP(2);  // waiting for the DMA
         auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
             uint32_t a = pos_r + rel;
             if ((RB & (RB - 1)) == 0)
@@ -366,35 +431,47 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
         };
         const int npairs = w * K;
         if (pend_pairs != 0 && !(flags & 2)) flush();
-        if (pend_pairs == 0) {  // a new run: look up the tile-local ids of its transcripts
+        if (pend_pairs == 0) {  // a new run: look up the tile-local ids of its transcripts (loads batched)
 #pragma unroll
             for (int j = 0; j < NSET; ++j)
                 if (lane + 64 * j < npairs)
                     mycol[j] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)pt[j] * 128u));
+            int cc[WMAXR];
 #pragma unroll
-            for (int t = 0; t < WMAXR; ++t) {
-                pc[t] = 0;
-                if (t < w)
-                    pc[t] = __builtin_amdgcn_readfirstlane(
-                        (int)*reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)t * 128u)));
-            }
+            for (int t = 0; t < WMAXR; ++t)
+                cc[t] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)min(t, w - 1) * 128u));
+#pragma unroll
+            for (int t = 0; t < WMAXR; ++t) pc[t] = t < w ? __builtin_amdgcn_readfirstlane(cc[t]) : 0;
         }
 
-        // phase 1 (lane = fragment): row sums s[k] = sum_t V[lane][t] x[c_t][k] (x rows: uniform LDS reads)
+        STAMP(3);  // run change: flush + column lookup
+        // phase 1 (lane = fragment): row sums s[k] = sum_t V[lane][t] x[c_t][k] (x rows: uniform LDS reads),
+        // four transcripts per step so that the LDS reads of a step are in flight together
         float sacc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
         if (!(dbg & 4)) {
 #pragma unroll
-            for (int t = 0; t < WMAXR; ++t) {
-                if (t < w) {
-                    const float v = *reinterpret_cast<const float *>(ring_at((uint32_t)t * 256u + lane * 4u));
-                    const float *xr = xw + pc[t] * K;
+            for (int t0 = 0; t0 < WMAXR; t0 += 4) {
+                if (t0 < w) {
+                    float v[4];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, xr[k], sacc[k]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u;
+                        v[u] = 0.0f;
+                        if (t < WMAXR) {
+                            const float vv = *reinterpret_cast<const float *>(ring_at((uint32_t)min(t, w - 1) * 256u + lane * 4u));
+                            v[u] = t < w ? vv : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + u < WMAXR) fma_row<K>(v[u], xw + pc[t0 + u] * K, sacc);
                 }
             }
         }
+        // (with multiplicities this is the one compiler-visible load of the loop: the factored likelihood
+        // pays a vmcnt(0) per slice -- acceptable for the secondary variant)
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -402,6 +479,7 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
             if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
         }
 
+        STAMP(4);  // phase 1
         // phase 2 (lane = (t, k) pair): G[t][k] += sum_r V[t][r] W[k][r], 4 fragments per LDS read; lanes start
         // at different 16-byte slots so that the 16 lanes of an LDS read group hit 16 different bank groups
         if (!(dbg & 2)) {
@@ -412,15 +490,26 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
                         const char *vrow = ring_at((uint32_t)pt[j] * 256u);
                         const char *wrow = reinterpret_cast<const char *>(wbuf + pk[j] * 64);
                         float a0 = 0.f, a1 = 0.f;
+                        // 16 steps of 4 fragments; the LDS reads of 8 steps are issued together (LDS latency is the
+                        // cost of this loop, not its bandwidth)
 #pragma unroll
-                        for (int it = 0; it < 16; ++it) {
-                            const int slot = ((it + lane) & 15) * 16;
-                            const float4 a = *reinterpret_cast<const float4 *>(vrow + slot);
-                            const float4 b = *reinterpret_cast<const float4 *>(wrow + slot);
-                            a0 = fmaf(a.x, b.x, a0);
-                            a1 = fmaf(a.y, b.y, a1);
-                            a0 = fmaf(a.z, b.z, a0);
-                            a1 = fmaf(a.w, b.w, a1);
+                        for (int half = 0; half < 2; ++half) {
+                            float4 a[8], b[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int slot = ((half * 8 + u + lane) & 15) * 16;
+                                a[u] = *reinterpret_cast<const float4 *>(vrow + slot);
+                                b[u] = *reinterpret_cast<const float4 *>(wrow + slot);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                a0 = fmaf(a[u].x, b[u].x, a0);
+                                a1 = fmaf(a[u].y, b[u].y, a1);
+                                a0 = fmaf(a[u].z, b[u].z, a0);
+                                a1 = fmaf(a[u].w, b[u].w, a1);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // 16 DS reads ...
+                            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // ... then their 16 packed FMAs
                         }
                         acc[j] += a0 + a1;
                     }
@@ -428,16 +517,20 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
             }
         }
         pend_pairs = npairs;
+        STAMP(5);  // phase 2
 
         // the slice is consumed: refill the ring behind it
         pos += bytes;
         pos_r += bytes;
         pos_r = pos_r >= RB ? pos_r - RB : pos_r;
         refill(min(npieces, (int)(pos >> 10) + RP));
+        STAMP(6);  // refill
     }
     if (pend_pairs != 0) flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);  // final flush
     __syncthreads();
+    STAMP(8);  // waiting for the other waves of the workgroup
     if (!(dbg & 1))
         for (int i = threadIdx.x; i < L * K; i += 256) {
             const int l = i / K, k = i - l * K;
@@ -456,7 +549,24 @@ __global__ __launch_bounds__(256) void loglik_uniform_kernel(const uint8_t *__re
             __syncthreads();
         }
     }
+#ifdef POLEE_STAMPS
+    STAMP(9);  // global flush
+    if (lane == 0) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+        atomicAdd(&g_stamps[10], (unsigned long long)(se - sb));
+        atomicAdd(&g_stamps[11], 1ull);
+    }
+#endif
 }
+
+#ifdef POLEE_STAMPS
+extern "C" int polee_debug_read_stamps(unsigned long long *out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) == hipSuccess ? 0 : 1;
+}
+#endif
 
 template <int K, int RP, bool LP, bool KS>
 static void launch_uniform(polee_loglik *ll, hipStream_t st, const float *d_x, float *d_g, double *d_lp, int tile_base,
@@ -471,8 +581,8 @@ static void launch_uniform(polee_loglik *ll, hipStream_t st, const float *d_x, f
         attr_set = true;
     }
     hipLaunchKernelGGL((loglik_uniform_kernel<K, RP, LP, KS>), dim3((unsigned)ntiles), dim3(256), lds, st,
-                       ll->d_data.p, ll->d_slice_off.p, ll->d_slice_flags.p, ll->d_tile_slice.p, ll->d_tile_dict.p,
-                       ll->d_dict.p, ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, tile_base, dbg);
+                       ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
+                       ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, tile_base, dbg);
 }
 
 template <int K, bool LP, bool KS>
@@ -674,7 +784,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     if (hipEventCreateWithFlags(&ll->ev_fork, hipEventDisableTiming) != hipSuccess) ll->side[0] = nullptr;
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
-        (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_slice_flags.upload(ctx, h.slice_flags)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
         loglik_release(ll);
         return s;
     }
@@ -798,7 +908,7 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_slices = h.num_slices;
     info->num_tiles = h.num_tiles;
     info->padded_nnz = h.padded_nnz;
-    info->stream_bytes = (int64_t)(ll->d_data.n + ll->d_slice_flags.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
+    info->stream_bytes = (int64_t)(ll->d_data.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
                                                         ll->d_dict.n + ll->d_slice_ks.n));
     info->device_bytes = info->stream_bytes;
     info->num_empty_rows = h.empty_rows;

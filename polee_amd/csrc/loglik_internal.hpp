@@ -36,6 +36,7 @@ constexpr int PSELL_TILE_SLICES_A1 = 64;      // slices per tile (= per workgrou
 constexpr int PSELL_TILE_SLICES_A2 = 8;
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
+constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
 constexpr int PSELL_NARROW_MAX = 18;        // widest transcript set of stream A1 (8 KiB LDS ring)
 constexpr int PSELL_WIDE_MAX = 28;          // widest transcript set of stream A2 (12 KiB LDS ring)
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
@@ -49,7 +50,7 @@ struct PsellHost {
     int64_t stream_rows[3] = {0, 0, 0}, stream_nnz[3] = {0, 0, 0}, stream_bytes[3] = {0, 0, 0};  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
-    std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units
+    std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units in bits 0..29, slice flags in bits 30..31
     std::vector<uint32_t> tile_slice;  // [num_tiles+1]
     std::vector<uint32_t> tile_dict;   // [num_tiles+1]
     std::vector<uint32_t> dict;        // transcript ids (0-based)
@@ -74,7 +75,6 @@ struct polee_loglik {
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
     polee::DevBuf<float> d_slice_ks;
-    polee::DevBuf<uint8_t> d_slice_flags;
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;

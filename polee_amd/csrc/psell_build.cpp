@@ -259,7 +259,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (boundary) {
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
-            const uint32_t cap = (int64_t)ri < out.rows_a1 ? PSELL_TILE_SLICES_A1
+            static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
+            const uint32_t cap = (int64_t)ri < out.rows_a1 ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
                                  : (int64_t)ri < out.rows_a ? PSELL_TILE_SLICES_A2 : PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }
@@ -274,7 +275,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     if (out.rows_a1 == out.rows_a) out.num_tiles_a1 = std::min(out.num_tiles_a1, out.num_tiles_a);
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
-    if (out.data.size() / 128 > 0xffffffffull) return "matrix too large for 32-bit slice offsets";
+    if (out.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
+    // the two flag bits of slice s ride in the top bits of slice_off[s] (one scalar/lane load per slice)
+    for (int64_t s = 0; s < out.num_slices; ++s) out.slice_off[s] |= (uint32_t)(out.slice_flags[s] & 3u) << 30;
     return "";
 }
 

@@ -142,7 +142,9 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     out = dict(num_slices=v.num_slices, num_tiles=v.num_tiles, padded_nnz=v.padded_nnz, nnz=v.nnz,
                empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz)
     out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
-    out["slice_off"] = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
+    raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
+    out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
+    out["slice_flags"] = (raw >> np.uint32(30))[:-1]
     out["tile_slice"] = np.ctypeslib.as_array(v.tile_slice, shape=(v.num_tiles + 1,)).copy()
     out["tile_dict"] = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).copy()
     out["dict"] = np.ctypeslib.as_array(v.dict, shape=(v.dict_len,)).copy()
