@@ -118,10 +118,8 @@ def main():
 
     kern_ms, pass_ms = avg("loglik_kernel_ms_avg"), avg("loglik_pass_ms_avg")
     bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
-    # the dominant kernel processes the uniform stream A1 (most of X); price it with the same per-unit figures
-    dom = 0 if info["stream_tiles"][0] > 0 else 2
-    bytes_dom = (algorithmic_bytes_per_pass(info["stream_nnz"][0], info["stream_rows"][0] - 1, n, K)
-                 if dom == 0 else bytes_pass)
+    # the whole pass is one launch (loglik_fused_kernel: three kinds of workgroups, one per row stream)
+    bytes_dom = bytes_pass
     achieved = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -154,16 +152,11 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": ("loglik_uniform_kernel<%d, 8, false, false>" % K) if dom == 0 else
-                      ("loglik_psell_kernel<%d, false, false>" % K),
+            "kernel": "loglik_fused_kernel<%d, false, false>" % K,
             "kernel_ms_avg": kern_ms, "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_dom,
-            "kernel_share_of_nnz": info["stream_nnz"][dom] / max(info["nnz"], 1),
-            "slice_stream_bytes_per_launch": info["stream_bytes_hbm"][dom],
-            "whole_pass": {"ms_avg": pass_ms, "algorithmic_bytes": bytes_pass,
-                           "achieved": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
-                           "frac": bytes_pass / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pass_ms > 0 else 0.0,
-                           "launches": "uniform<RP=8> || uniform<RP=12> || psell (three concurrent streams)"},
+            "slice_stream_bytes_per_launch": sum(info["stream_bytes_hbm"]),
+            "stream_share_of_nnz": [v / max(info["nnz"], 1) for v in info["stream_nnz"]],
         },
         "detail": {
             "hip_event_ms_per_step": ev_ms / args.steps, "gen_s": t_gen, "device_layout_build_s": t_build,

@@ -130,22 +130,29 @@ __device__ inline float fast_weight(float ksv, float s)
 // Two sweeps over each slice straight from global memory (the second one hits L1/L2); contributions
 // are summed per run of equal transcript ids with DPP before touching LDS.  Few registers -> high
 // occupancy hides the latency.
-template <int K, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__restrict__ data,
-                                                          const uint32_t *__restrict__ slice_off,
-                                                          const uint32_t *__restrict__ tile_slice,
-                                                          const uint32_t *__restrict__ tile_dict,
-                                                          const uint32_t *__restrict__ dict,
-                                                          const float *__restrict__ slice_ks,
-                                                          const float *__restrict__ x, float *__restrict__ g,
-                                                          double *__restrict__ lp, int lcap, int tile_base)
-{
-    extern __shared__ float lds[];
-    float *xw = lds;                     // [L][K] tile-local copy of x
-    float *gw = lds + (size_t)lcap * K;  // [L][K] tile-local gradient accumulator
-    __shared__ double lp_red[4];
+struct PsellArgs {
+    const uint8_t *data;
+    const uint32_t *slice_off, *tile_slice, *tile_dict, *dict;
+    const float *slice_ks;
+    const float *x;
+    float *g;
+    double *lp;
+    int lcap;
+};
 
-    const int tile = tile_base + blockIdx.x;
+template <int K, bool WANT_LP, bool HAS_KS>
+__device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, float *gw, double *lp_red)
+{
+    const uint8_t *__restrict__ data = A.data;
+    const uint32_t *__restrict__ slice_off = A.slice_off;
+    const uint32_t *__restrict__ tile_slice = A.tile_slice;
+    const uint32_t *__restrict__ tile_dict = A.tile_dict;
+    const uint32_t *__restrict__ dict = A.dict;
+    const float *__restrict__ slice_ks = A.slice_ks;
+    const float *__restrict__ x = A.x;
+    float *__restrict__ g = A.g;
+    double *__restrict__ lp = A.lp;
+
     const uint32_t d0 = tile_dict[tile];
     const int L = (int)(tile_dict[tile + 1] - d0);
     for (int i = threadIdx.x; i < L * K; i += 256) {
@@ -221,6 +228,14 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(const uint8_t *__rest
     }
 }
 
+template <int K, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile_base)
+{
+    extern __shared__ float lds[];
+    __shared__ double lp_red[4];
+    psell_tile_body<K, WANT_LP, HAS_KS>(A, tile_base + (int)blockIdx.x, lds, lds + (size_t)A.lcap * K, lp_red);
+}
+
 // ---- stream A: uniform slices, LDS-DMA streamed, transposed accumulation --------------------------------
 // Every slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs
 // of consecutive slices with the same set are marked by the builder.  For such a slice
@@ -285,42 +300,37 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { } while (0)
 #endif
 
-// LDS (not registers) sets the occupancy of this kernel: 3 workgroups per CU with the 8 KiB ring, 2 with the
-// 12 KiB ring.  Telling the backend so lets it keep many LDS reads in flight instead of minimising VGPRs.
-template <int K, int RP, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RP <= 8 ? 3 : 2, RP <= 8 ? 3 : 2)))
-void loglik_uniform_kernel(const uint8_t *__restrict__ data,
-                                                            const uint32_t *__restrict__ slice_off,
-                                                            const uint32_t *__restrict__ tile_slice,
-                                                            const uint32_t *__restrict__ tile_dict,
-                                                            const uint32_t *__restrict__ dict,
-                                                            const float *__restrict__ slice_ks,
-                                                            const float *__restrict__ x, float *__restrict__ g,
-                                                            double *__restrict__ lp, int lcap, int tile_base, int dbg)
+// One tile of a uniform stream.  RB = ring bytes per active wave, NW = waves that own slices (the others only
+// take part in the staging and the barriers), WMAXR = widest transcript set of the stream.
+template <int K, uint32_t RB, int NW, int WMAXR, bool WANT_LP, bool HAS_KS>
+__device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, const char *rings, float *wbufs,
+                                         float *xw, float *gw, double *lp_red)
 {
-    constexpr uint32_t RB = RP * 1024u;   // ring bytes per wave
-    constexpr int WMAXR = RP >= 12 ? PSELL_WIDE_MAX : PSELL_NARROW_MAX;  // widest set this instantiation sees
-    constexpr int NSET = (WMAXR * K + 63) / 64;                          // (t, k) pairs per lane
-    extern __shared__ float lds[];  // [4 rings][4 W buffers: K*64 floats][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
-    const char *rings = reinterpret_cast<const char *>(lds);
-    float *wbufs = lds + 4 * RB / 4;
-    float *xw = wbufs + 4 * K * 64;
-    float *gw = xw + (size_t)lcap * K;
-    double *lp_red = reinterpret_cast<double *>(gw + (size_t)((lcap * K + 1) & ~1));
+    constexpr int RP = (int)(RB / 1024u);
+    constexpr int NSET = (WMAXR * K + 63) / 64;  // (t, k) pairs per lane
+    const uint8_t *__restrict__ data = A.data;
+    const uint32_t *__restrict__ slice_off = A.slice_off;
+    const uint32_t *__restrict__ tile_slice = A.tile_slice;
+    const uint32_t *__restrict__ tile_dict = A.tile_dict;
+    const uint32_t *__restrict__ dict = A.dict;
+    const float *__restrict__ slice_ks = A.slice_ks;
+    const float *__restrict__ x = A.x;
+    float *__restrict__ g = A.g;
+    double *__restrict__ lp = A.lp;
 
 #ifdef POLEE_STAMPS
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-    const int tile = tile_base + blockIdx.x;
     const uint32_t d0 = tile_dict[tile];
     const int L = (int)(tile_dict[tile + 1] - d0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t s0 = tile_slice[tile], s1 = tile_slice[tile + 1];
-    // each wave takes a contiguous quarter of the tile's slices: runs stay inside one wave
-    const uint32_t per = (s1 - s0 + 3u) >> 2;
-    const uint32_t sb = min(s0 + wave * per, s1), se = min(sb + per, s1);
+    // each active wave takes a contiguous share of the tile's slices: runs stay inside one wave
+    const uint32_t per = (s1 - s0 + (uint32_t)NW - 1u) / (uint32_t)NW;
+    const uint32_t sb = wave < NW ? min(s0 + (uint32_t)wave * per, s1) : s1;
+    const uint32_t se = wave < NW ? min(sb + per, s1) : s1;
 
     // slice offsets (+ flags in the top bits) of this wave's range, one per lane: a wave owns at most 63
     // slices (tiles hold <= 64).  They are read with v_readlane inside the loop, so that the loop contains
@@ -332,7 +342,7 @@ void loglik_uniform_kernel(const uint8_t *__restrict__ data,
     const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)(se - sb)) & PSELL_OFF_MASK;  // 128-byte units
     const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
     const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
-    const char *ring = rings + wave * RB;
+    const char *ring = rings + (wave < NW ? wave : 0) * RB;
     float *wbuf = wbufs + wave * K * 64;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(uintptr_t)(__attribute__((address_space(3))) const char *)ring);
@@ -568,21 +578,36 @@ extern "C" int polee_debug_read_stamps(unsigned long long *out)
 }
 #endif
 
-template <int K, int RP, bool LP, bool KS>
-static void launch_uniform(polee_loglik *ll, hipStream_t st, const float *d_x, float *d_g, double *d_lp, int tile_base,
-                           int ntiles, int lcap, int dbg)
+// LDS layout of the fused kernel: [32 KiB rings][4 W buffers: K*64 floats][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
+constexpr uint32_t FUSED_RING_TOTAL = 32768u;
+
+// The whole likelihood pass as ONE launch with three kinds of workgroups (block index ranges), so that the
+// three streams of X share the machine without cross-stream events:
+//   [0, nb_b)              stream B  (mixed slices; compute heavy, dispatched first)
+//   [nb_b, nb_b + nb_a2)   stream A2 (uniform, sets of 19..28 transcripts): 2 active waves x 16 KiB ring
+//   the rest               stream A1 (uniform, sets of <= 18 transcripts):   4 waves x 8 KiB ring
+// LDS (53 KiB) lets 3 workgroups share a CU; the backend is told so that it can keep LDS reads in flight
+// rather than minimise VGPRs.
+template <int K, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int nb_a2, int dbg)
 {
-    const size_t lds = (size_t)4 * RP * 1024 + (size_t)4 * K * 64 * sizeof(float) +
-                       ((size_t)2 * lcap * K + 2) * sizeof(float) + 4 * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)loglik_uniform_kernel<K, RP, LP, KS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    extern __shared__ float lds[];
+    const char *rings = reinterpret_cast<const char *>(lds);
+    float *wbufs = lds + FUSED_RING_TOTAL / 4;
+    float *xw = wbufs + 4 * K * 64;
+    float *gw = xw + (size_t)A.lcap * K;
+    double *lp_red = reinterpret_cast<double *>(gw + (size_t)((A.lcap * K + 1) & ~1));
+    const int b = blockIdx.x;
+    if (b < nb_b) {
+        psell_tile_body<K, WANT_LP, HAS_KS>(A, tiles_a + b, xw, gw, lp_red);
+    } else if (b < nb_b + nb_a2) {
+        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + (b - nb_b), dbg, rings, wbufs, xw,
+                                                                         gw, lp_red);
+    } else {
+        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, b - nb_b - nb_a2, dbg, rings, wbufs, xw, gw,
+                                                                          lp_red);
     }
-    hipLaunchKernelGGL((loglik_uniform_kernel<K, RP, LP, KS>), dim3((unsigned)ntiles), dim3(256), lds, st,
-                       ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
-                       ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, tile_base, dbg);
 }
 
 template <int K, bool LP, bool KS>
@@ -593,47 +618,33 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     hipStream_t st = ll->ctx->stream;
     static const bool no_ring = getenv("POLEE_NO_RING") != nullptr;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
-    int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a;
-    if (no_ring) tiles_a1 = tiles_a = 0;
-    // ring sizes: a slice of w transcripts occupies ceil(w*384/256)*256 bytes and may start 896 bytes into a piece
+    const PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
+                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap};
+    // a slice of w transcripts occupies ceil(w*384/256)*256 bytes and may start 896 bytes into a 1 KiB piece
     static_assert(PSELL_NARROW_MAX * 384 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
-    static_assert(((PSELL_WIDE_MAX * 384 + 255) / 256) * 256 + 1024 <= 12 * 1024, "A2 slices must fit a 12 KiB ring");
-    static const int rp_a1 = getenv("POLEE_RP_A1") ? atoi(getenv("POLEE_RP_A1")) : 8;
-    const int tiles_b = (int)h.num_tiles - tiles_a;
-    // the three streams of X only meet in the atomics on g: run A2 and B beside A1 on side streams
-    const bool fork = ll->side[0] && (tiles_a - tiles_a1 > 0 || tiles_b > 0) && tiles_a1 > 0 && !(dbg & 256);
-    hipStream_t st_a2 = fork ? ll->side[0] : st, st_b = fork ? ll->side[1] : st;
-    if (fork) {
-        (void)hipEventRecord(ll->ev_fork, st);
-        (void)hipStreamWaitEvent(st_a2, ll->ev_fork, 0);
-        (void)hipStreamWaitEvent(st_b, ll->ev_fork, 0);
+    static_assert(((PSELL_WIDE_MAX * 384 + 255) / 256) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
+    const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)4 * K * 64 + (size_t)2 * lcap * K + 2) * sizeof(float) +
+                       4 * sizeof(double);
+    const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
+    if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
+    if (!no_ring && tiles_a > 0 && lds <= 64 * 1024) {
+        int nb_b = tiles - tiles_a, nb_a2 = tiles_a - tiles_a1, nb_a1 = tiles_a1;
+        if (dbg & 32) nb_b = 0;
+        if (dbg & 128) nb_a2 = 0;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)loglik_fused_kernel<K, LP, KS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((loglik_fused_kernel<K, LP, KS>), dim3((unsigned)(nb_b + nb_a2 + nb_a1)), dim3(256), lds, st,
+                           A, tiles_a1, tiles_a, nb_b, nb_a2, dbg);
+    } else {
+        // no uniform stream (or a tile dictionary too large for the fused LDS budget): everything as mixed slices
+        const size_t lds_b = (size_t)2 * lcap * K * sizeof(float);
+        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles), dim3(256), lds_b, st, A, 0);
     }
-    // profiling events bracket the dominant launch (stream A1) alone; without one, the whole pass
-    const bool ev_a1 = tiles_a1 > 0 && !(dbg & 64);
-    if (ll->cur_e0 && !ev_a1) (void)hipEventRecord(ll->cur_e0, st);
-    if (ev_a1) {
-        if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
-        if (rp_a1 == 12)
-            launch_uniform<K, 12, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
-        else
-            launch_uniform<K, 8, LP, KS>(ll, st, d_x, d_g, d_lp, 0, tiles_a1, lcap, dbg);
-        if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
-    }
-    if (tiles_a - tiles_a1 > 0 && !(dbg & 128))
-        launch_uniform<K, 12, LP, KS>(ll, st_a2, d_x, d_g, d_lp, tiles_a1, tiles_a - tiles_a1, lcap, dbg);
-    if (tiles_b > 0 && !(dbg & 32)) {
-        const size_t lds = (size_t)2 * lcap * K * sizeof(float);
-        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds, st_b, ll->d_data.p,
-                           ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p, ll->d_slice_ks.p,
-                           d_x, d_g, d_lp, lcap, tiles_a);
-    }
-    if (fork) {
-        (void)hipEventRecord(ll->ev_join[0], st_a2);
-        (void)hipEventRecord(ll->ev_join[1], st_b);
-        (void)hipStreamWaitEvent(st, ll->ev_join[0], 0);
-        (void)hipStreamWaitEvent(st, ll->ev_join[1], 0);
-    }
-    if (ll->cur_e1 && !ev_a1) (void)hipEventRecord(ll->cur_e1, st);
+    if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 // No host synchronisation inside polee_vi_run.
 #include "loglik_internal.hpp"
 #include "ptt_internal.hpp"
+#include "vi_fused.hpp"
 
 #include <cmath>
 
@@ -63,152 +64,6 @@ struct NoiseSrc {
 
 __device__ inline float logistic_f32(float x) { return 1.0f / (1.0f + expf(-x)); }  // logitnormal.jl:2
 
-// sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform!
-// (logitnormal.jl:8-20) -> clamp!(ys, eps, 1-eps) (likelihood-approximation.jl:523).
-// ladj_out [K][2] (skew, logit-normal) accumulated when non-null (unclamped y, as the
-// reference computes them before the clamp).
-__global__ void vi_sample_kernel(const float *mu, const float *omega, const float *alpha, NoiseSrc noise, int step,
-                                 double y_eps, int clamp, double *ys, double *ly, double *l1y, double *ladj_out)
-{
-    __shared__ double smd[4];
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int d = blockIdx.y;
-    double l_skew = 0.0, l_ln = 0.0;
-    if (k < noise.nm1) {
-        const float z0 = noise.get(step, d, k);
-        const float c = alpha[k] + asinhf(z0);
-        const float zs = sinhf(c);
-        const float sigma = expf(omega[k]);
-        double y = (double)logistic_f32(mu[k] + zs * sigma);
-        if (ladj_out) {
-            l_skew = (double)logf(coshf(c)) - 0.5 * (double)log1pf(z0 * z0);
-            l_ln = log((double)sigma * y * (1 - y));
-        }
-        if (clamp) y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
-        ys[(int64_t)d * noise.nm1 + k] = y;
-        // logs of the two edge factors, once per node (the tree scans read them four times each)
-        ly[(int64_t)d * noise.nm1 + k] = log(y);
-        l1y[(int64_t)d * noise.nm1 + k] = log1p(-y);
-    }
-    if (ladj_out) {
-        l_skew = block_sum_f64(l_skew, smd);
-        l_ln = block_sum_f64(l_ln, smd);
-        if (threadIdx.x == 0) {
-            atomicAdd(&ladj_out[d * 2 + 0], l_skew);
-            atomicAdd(&ladj_out[d * 2 + 1], l_ln);
-        }
-    }
-}
-
-// backward scan summand: a = u_leaf * x_grad with the effective-length Jacobian term
-// (likelihood.jl:93-110) folded in: x_grad[j] -= n (1/efflen_j) / sum_i x_i/efflen_i.
-struct ViLeafLoad {
-    PttView v;
-    const double *uleaf;    // [K][n] leaf order
-    const float *g;         // [n][K]
-    const float *efflens;   // [n] or null
-    const double *row_sums; // [K][2], [0] = sum x/efflen
-    int K;
-    __device__ inline double xgrad(int row, int tid) const
-    {
-        double xg = (double)g[(int64_t)tid * K + row];
-        if (efflens) xg -= (double)((float)v.n * (1.0f / efflens[tid])) / row_sums[row * 2];
-        return xg;
-    }
-    __device__ dd operator()(int row, int64_t pos) const
-    {
-        const int tid = v.leaf_tid[pos];
-        return dd_make(uleaf[(int64_t)row * v.n + pos] * xgrad(row, tid));
-    }
-};
-
-struct AdamConsts {
-    double lr, rm, rv, eps, m_denom, v_denom;
-    double max_mu, max_omega, max_alpha;
-    int first;  // step_num == 1
-};
-
-__device__ inline float adam_one(float &p, float &m, float &v, float grad, const AdamConsts &a, double max_step)
-{
-    // adam_update_mv! (likelihood-approximation.jl:116-130)
-    if (a.first) {
-        m = grad;
-        v = grad * grad;
-    } else {
-        m = (float)(a.rm * (double)m + (1 - a.rm) * (double)grad);
-        v = (float)(a.rv * (double)v + (1 - a.rv) * (double)(grad * grad));
-    }
-    // adam_update_params! (likelihood-approximation.jl:136-146) -- ascent, clamped step
-    const double pm = (double)m / a.m_denom, pv = (double)v / a.v_denom;
-    double delta = a.lr * pm / (sqrt(pv) + a.eps);
-    delta = delta < -max_step ? -max_step : (delta > max_step ? max_step : delta);
-    p = (float)((double)p + delta);
-    return p;
-}
-
-// update: one thread per internal node k, looping over the K draws.
-//   y_grad[k] = H_l / y - H_r / (1 - y)   (closed form of ptt.jl:167-209, see ptt.hip)
-//   logit_normal_transform_gradients! (logitnormal.jl:38-55),
-//   sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38),
-//   omega_grad += sigma * sigma_grad (likelihood-approximation.jl:547-549), / K (:552-557)
-template <int K>
-__global__ void vi_update_kernel(PttView v, const double *ys, const dd *C, NoiseSrc noise, int step, float *mu,
-                                 float *omega, float *alpha, float *m_mu, float *v_mu, float *m_omega, float *v_omega,
-                                 float *m_alpha, float *v_alpha, AdamConsts adam, int apply, int *nonfinite_step,
-                                 double *y_grad_out, float *mu_grad_out, float *omega_grad_out, float *alpha_grad_out)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nm1 = v.n - 1;
-    if (k >= nm1) return;
-    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
-    const double cnt_r = (double)(mid - lo - 1), cnt_l = (double)(hi1 - mid - 1);
-    const float muk = mu[k], omk = omega[k], alk = alpha[k];
-    const float sigma = expf(omk);
-    float mu_g = 0.f, om_g = 0.f, al_g = 0.f;
-#pragma unroll
-    for (int d = 0; d < K; ++d) {
-        const dd *Cr = C + (int64_t)d * (v.n + 1);
-        const double Hr = cnt_r + dd_diff(Cr[mid], Cr[lo]);
-        const double Hl = cnt_l + dd_diff(Cr[hi1], Cr[mid]);
-        const double y = ys[(int64_t)d * nm1 + k];
-        const double ygd = Hl / y - Hr / (1.0 - y);
-        if (y_grad_out) y_grad_out[(int64_t)d * nm1 + k] = ygd;
-        const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
-        const float z0 = noise.get(step, d, k);
-        const float c = alk + asinhf(z0);
-        const float zs = sinhf(c);
-        const double dyy = y * (1 - y);
-        // per-draw accumulators start at zero (fill! at :513-516)
-        mu_g = (float)((double)mu_g + dyy * (double)yg);  // mu_grad accumulates across draws in f32
-        mu_g = (float)((double)mu_g + (1 - 2 * y));
-        float sg = (float)(dyy * (double)zs * (double)yg);
-        sg = (float)((double)sg + ((double)(1.0f / sigma) + (double)zs * (1 - 2 * y)));
-        float zg = (float)(dyy * (double)sigma * (double)yg);
-        zg = (float)((double)zg + (double)sigma * (1 - 2 * y));
-        al_g += coshf(c) * zg;
-        al_g += tanhf(c);
-        om_g += sigma * sg;
-    }
-    mu_g /= (float)K;
-    om_g /= (float)K;
-    al_g /= (float)K;
-    if (mu_grad_out) mu_grad_out[k] = mu_g;
-    if (omega_grad_out) omega_grad_out[k] = om_g;
-    if (alpha_grad_out) alpha_grad_out[k] = al_g;
-    if (!(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
-    if (apply) {
-        float p = muk, mm = m_mu[k], vv = v_mu[k];
-        adam_one(p, mm, vv, mu_g, adam, adam.max_mu);
-        mu[k] = p; m_mu[k] = mm; v_mu[k] = vv;
-        p = omk; mm = m_omega[k]; vv = v_omega[k];
-        adam_one(p, mm, vv, om_g, adam, adam.max_omega);
-        omega[k] = p; m_omega[k] = mm; v_omega[k] = vv;
-        p = alk; mm = m_alpha[k]; vv = v_alpha[k];
-        adam_one(p, mm, vv, al_g, adam, adam.max_alpha);
-        alpha[k] = p; m_alpha[k] = mm; v_alpha[k] = vv;
-    }
-}
-
 // elbo bookkeeping of the !gradonly mode: `elbo = lp + skew_ladj + ln_ladj + hsb_ladj` is an
 // ASSIGNMENT inside the draw loop (likelihood-approximation.jl:537) followed by `/= K`
 // (:561), i.e. the last draw's value over K.  lp_mean is the mean log-likelihood over draws.
@@ -243,13 +98,16 @@ __global__ void aos_to_rows_f32_kernel(const float *in, int K, int64_t n, float 
 }
 
 // x_grad after the effective length adjustment, as rows [K][n] f64 (test hook output).
-__global__ void vi_xgrad_rows_kernel(ViLeafLoad l, double *out)
+__global__ void vi_xgrad_rows_kernel(const float *g, const float *efflens, const double *csum, int K, int64_t n,
+                                     double *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)l.v.n * l.K) return;
-    const int k = (int)(i / l.v.n);
-    const int tid = (int)(i - (int64_t)k * l.v.n);
-    out[i] = l.xgrad(k, tid);
+    if (i >= n * K) return;
+    const int k = (int)(i / n);
+    const int64_t tid = i - (int64_t)k * n;
+    double xg = (double)g[tid * K + k];
+    if (efflens) xg -= (double)((float)n * (1.0f / efflens[tid])) / csum[k];
+    out[i] = xg;
 }
 
 // inverse_transform!(t, fill(1.0f0/n, n), ys) (likelihood-approximation.jl:451): every leaf holds 1/n
@@ -298,7 +156,8 @@ struct polee_vi {
     int32_t step = 0;  // steps completed
     int32_t trace_cap = 0;
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
-    DevBuf<double> d_ys, d_ly, d_l1y, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
+    DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
+    DevBuf<dd> d_C;
     DevBuf<int> d_flag;
     // outputs of the test hook
     DevBuf<double> d_ygrad, d_xgrad_rows;
@@ -308,48 +167,60 @@ struct polee_vi {
     polee_status one_step(bool apply, bool want_values, bool hook_outputs);
 };
 
-polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
+template <int K>
+static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool hook_outputs)
 {
+    polee_ctx *ctx = vi->ctx;
+    polee_ptt *t = vi->t;
+    const polee_vi_opts &o = vi->o;
+    const int32_t n = vi->n;
     const int64_t nm1 = n - 1;
-    const int step_num = step + 1;
+    const int step_num = vi->step + 1;
     hipStream_t st = ctx->stream;
-    POLEE_TRY(t->reserve(K));
-    if (o.z0 && step_num > o.num_steps)
-        return fail(ctx, POLEE_ERR_BAD_ARG, "caller-supplied z0 covers only %d steps", o.num_steps);
+    const PttView view = t->view();
+    const int nch_f = scan_num_chunks(t->TL), nch_b = scan_num_chunks(n);
+    const float *eff = o.use_efflen_jacobian ? vi->d_efflens.p : nullptr;
+    VK<K> *chunk_f = reinterpret_cast<VK<K> *>(t->d_chunk.p);
+    VD<K> *chunk_b = reinterpret_cast<VD<K> *>(t->d_chunk.p);
+    const NoiseSrc noise = vi->noise();
 
     // sample
-    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(d_ladj_el.p, 0, sizeof(double) * K * 2, st));
+    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_ladj_el.p, 0, sizeof(double) * K * 2, st));
     if (nm1 > 0) {
-        dim3 grid((unsigned)ceil_div(nm1, 256), K);
-        hipLaunchKernelGGL(vi_sample_kernel, grid, dim3(256), 0, st, d_mu.p, d_omega.p, d_alpha.p, noise(), step_num,
-                           o.y_eps, 1, d_ys.p, d_ly.p, d_l1y.p, want_values ? d_ladj_el.p : nullptr);
+        hipLaunchKernelGGL((vi_sample_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st,
+                           vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, noise, step_num, o.y_eps, vi->d_ys.p, vi->d_lyy.p,
+                           want_values ? vi->d_ladj_el.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
     }
-    // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526)
-    FwdOut fo;
-    fo.uleaf = t->d_uleaf.p;
-    fo.xs = d_x.p;
-    fo.xs_rs = 1;
-    fo.xs_es = K;
-    fo.clamp_lo = (float)o.y_eps;
-    fo.clamp_hi = (float)(1.0 - o.y_eps);
-    fo.efflens = o.use_efflen_jacobian ? d_efflens.p : nullptr;
-    fo.row_sums = (o.use_efflen_jacobian || want_values) ? d_rows.p : nullptr;
-    fo.ly = d_ly.p;
-    fo.l1y = d_l1y.p;
-    POLEE_TRY(ptt_forward_device(t, d_ys.p, K, fo));
+    // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
+    if (nch_f > 1) {
+        hipLaunchKernelGGL((vi_fwd_reduce_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
+        hipLaunchKernelGGL((scan_spine_kernel<VK<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
+    } else {
+        POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
+    }
+    hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
+                       vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
+                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr);
+    POLEE_KERNEL_CHECK(ctx);
     // likelihood
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_g.p, 0, sizeof(float) * (size_t)n * K, st));
-    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
-    POLEE_TRY(loglik_eval_device(ll, d_x.p, K, d_g.p, want_values ? d_lp.p : nullptr));
-    // backward scan over leaves
-    ViLeafLoad load{t->view(), t->d_uleaf.p, d_g.p, o.use_efflen_jacobian ? d_efflens.p : nullptr, d_rows.p, K};
-    LeafPrefixEmit emit{n, t->d_C.p};
-    hipError_t e = run_scan_partial<dd>(st, K, n, t->d_chunk.p, nullptr, load, emit);
-    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "backward scan launch failed: %s", hipGetErrorString(e));
+    if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
+    POLEE_TRY(loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr));
+    // backward: double-double prefix over leaves of u * (g - efflen term)
+    hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
+                       eff, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
+    hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
+    hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
+                       eff, vi->d_csum.p, chunk_b, vi->d_C.p);
+    POLEE_KERNEL_CHECK(ctx);
+    if (want_values) {
+        hipLaunchKernelGGL((vi_values_finish_kernel<K>), dim3(1), dim3(256), 0, st, vi->d_part_ladj.p, nch_f,
+                           eff ? vi->d_csum.p : nullptr, vi->d_rows.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
     if (hook_outputs) {
-        hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st, load,
-                           d_xgrad_rows.p);
+        hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st,
+                           vi->d_g.p, eff, vi->d_csum.p, K, (int64_t)n, vi->d_xgrad_rows.p);
         POLEE_KERNEL_CHECK(ctx);
     }
     // update
@@ -367,33 +238,38 @@ polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
         a.max_omega = o.max_omega_step;
         a.max_alpha = o.max_alpha_step;
         a.first = step_num == 1;
-        dim3 grid((unsigned)ceil_div(nm1, 256));
-#define POLEE_UPD(KK)                                                                                              \
-    hipLaunchKernelGGL((vi_update_kernel<KK>), grid, dim3(256), 0, st, t->view(), d_ys.p, t->d_C.p, noise(),       \
-                       step_num, d_mu.p, d_omega.p, d_alpha.p, d_mm.p, d_vm.p, d_mo.p, d_vo.p, d_ma.p, d_va.p, a,  \
-                       apply ? 1 : 0, d_flag.p, hook_outputs ? d_ygrad.p : nullptr,                                \
-                       hook_outputs ? d_mug.p : nullptr, hook_outputs ? d_omg.p : nullptr,                         \
-                       hook_outputs ? d_alg.p : nullptr)
-        switch (K) {
-            case 1: POLEE_UPD(1); break;
-            case 2: POLEE_UPD(2); break;
-            case 3: POLEE_UPD(3); break;
-            case 4: POLEE_UPD(4); break;
-            case 5: POLEE_UPD(5); break;
-            case 6: POLEE_UPD(6); break;
-            case 7: POLEE_UPD(7); break;
-            case 8: POLEE_UPD(8); break;
-        }
-#undef POLEE_UPD
+        hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
+                           vi->d_ys.p, vi->d_C.p, noise, step_num, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p,
+                           vi->d_vm.p, vi->d_mo.p, vi->d_vo.p, vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p,
+                           hook_outputs ? vi->d_ygrad.p : nullptr, hook_outputs ? vi->d_mug.p : nullptr,
+                           hook_outputs ? vi->d_omg.p : nullptr, hook_outputs ? vi->d_alg.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
     }
-    if (want_values && apply && step < trace_cap) {
-        hipLaunchKernelGGL(vi_trace_kernel, dim3(1), dim3(64), 0, st, d_lp.p, d_ladj_el.p, d_rows.p, K, step, d_elbo.p,
-                           d_lptrace.p);
+    if (want_values && apply && vi->step < vi->trace_cap) {
+        hipLaunchKernelGGL(vi_trace_kernel, dim3(1), dim3(64), 0, st, vi->d_lp.p, vi->d_ladj_el.p, vi->d_rows.p, K,
+                           vi->step, vi->d_elbo.p, vi->d_lptrace.p);
         POLEE_KERNEL_CHECK(ctx);
     }
-    if (apply) ++step;
+    if (apply) ++vi->step;
     return POLEE_OK;
+}
+
+polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
+{
+    POLEE_TRY(t->reserve(K));
+    if (o.z0 && step + 1 > o.num_steps)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "caller-supplied z0 covers only %d steps", o.num_steps);
+    switch (K) {
+        case 1: return vi_step_k<1>(this, apply, want_values, hook_outputs);
+        case 2: return vi_step_k<2>(this, apply, want_values, hook_outputs);
+        case 3: return vi_step_k<3>(this, apply, want_values, hook_outputs);
+        case 4: return vi_step_k<4>(this, apply, want_values, hook_outputs);
+        case 5: return vi_step_k<5>(this, apply, want_values, hook_outputs);
+        case 6: return vi_step_k<6>(this, apply, want_values, hook_outputs);
+        case 7: return vi_step_k<7>(this, apply, want_values, hook_outputs);
+        case 8: return vi_step_k<8>(this, apply, want_values, hook_outputs);
+    }
+    return fail(ctx, POLEE_ERR_BAD_ARG, "num_mc_samples must be in 1..8");
 }
 
 extern "C" {
@@ -465,8 +341,15 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     A(vi->d_g.alloc(ctx, n * K));
     A(vi->d_x_rows.alloc(ctx, n * K));
     A(vi->d_ys.alloc(ctx, nm1 * K));
-    A(vi->d_ly.alloc(ctx, nm1 * K));
-    A(vi->d_l1y.alloc(ctx, nm1 * K));
+    A(vi->d_lyy.alloc(ctx, nm1 * 2 * K));
+    A(vi->d_uleaf.alloc(ctx, n * K));
+    A(vi->d_C.alloc(ctx, (n + 1) * K));
+    {
+        const size_t nch = (size_t)std::max(scan_num_chunks(3 * (int64_t)n - 2), 1);
+        A(vi->d_part_c.alloc(ctx, nch * K));
+        A(vi->d_part_ladj.alloc(ctx, nch * K));
+        A(vi->d_csum.alloc(ctx, PSELL_MAX_K));
+    }
     A(vi->d_ygrad.alloc(ctx, nm1 * K));
     A(vi->d_xgrad_rows.alloc(ctx, n * K));
     A(vi->d_lp.alloc(ctx, PSELL_MAX_K));

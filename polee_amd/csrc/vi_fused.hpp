@@ -1,0 +1,456 @@
+// The K-vectorised tree pipeline of the VI loop.
+//
+// The generic tree kernels (ptt.hip) treat the K Monte-Carlo draws as K independent batch rows.  Inside the
+// VI loop all K draws walk the SAME tree, so here one thread owns a tour entry / leaf / node for all K draws
+// at once: the index arrays are read once instead of K times, the per-draw values sit next to each other
+// ([...][K] layouts: one 48-byte access instead of six scattered 8-byte ones), and the K scan chains give
+// each thread K-fold instruction-level parallelism.  Per VI iteration:
+//   vi_sample      : z0 -> zs -> y, log y, log(1-y)                          (thread = node, K draws)
+//   vi_fwd_reduce / scan_spine / vi_fwd_apply : Euler-tour scan -> leaf u, clamped x, zeroed g, sum x/efflen
+//   [sparse likelihood pass]
+//   vi_bwd_reduce / scan_spine / vi_bwd_apply : double-double leaf-order prefix of u*(g - efflen term)
+//   vi_update      : y_grad, chain rule, mean over K, finiteness flag, ADAM  (thread = node)
+#pragma once
+#include "ptt_internal.hpp"
+
+namespace polee {
+
+template <int K>
+struct VK {
+    double v[K];
+};
+template <int K>
+struct VD {
+    dd v[K];
+};
+template <int K>
+struct ScanOps<VK<K>> {
+    __device__ static VK<K> zero()
+    {
+        VK<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = 0.0;
+        return r;
+    }
+    __device__ static VK<K> add(const VK<K> &a, const VK<K> &b)
+    {
+        VK<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = a.v[d] + b.v[d];
+        return r;
+    }
+    __device__ static VK<K> shfl_up(const VK<K> &a, int dist)
+    {
+        VK<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = __shfl_up(a.v[d], dist, 64);
+        return r;
+    }
+};
+template <int K>
+struct ScanOps<VD<K>> {
+    __device__ static VD<K> zero()
+    {
+        VD<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = dd{0.0, 0.0};
+        return r;
+    }
+    __device__ static VD<K> add(const VD<K> &a, const VD<K> &b)
+    {
+        VD<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = dd_add(a.v[d], b.v[d]);
+        return r;
+    }
+    __device__ static VD<K> shfl_up(const VD<K> &a, int dist)
+    {
+        VD<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = dd{__shfl_up(a.v[d].hi, dist, 64), __shfl_up(a.v[d].lo, dist, 64)};
+        return r;
+    }
+};
+
+// Block-wide sums of K doubles per thread (256 threads).  smem must hold 4*K doubles; results valid in
+// threads 0..K-1 as out (and for every thread after the trailing barrier through smem[0..K-1]).
+template <int K>
+__device__ inline void block_sum_vec(double (&v)[K], double *smem)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        double s = v[d];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) smem[wave * K + d] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const double s = smem[threadIdx.x] + smem[K + threadIdx.x] + smem[2 * K + threadIdx.x] + smem[3 * K + threadIdx.x];
+        smem[threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < K; ++d) v[d] = smem[d];
+    __syncthreads();
+}
+
+// thread d stores v[d] to out[d] (no runtime-indexed register array)
+template <int K>
+__device__ inline void store_vec_by_thread(const double (&v)[K], double *out)
+{
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+        if (threadIdx.x == d) out[d] = v[d];
+}
+
+// sinh(a + asinh(z)) = sinh(a) sqrt(1+z^2) + cosh(a) z : one sinh/cosh pair per node instead of an
+// asinh + sinh per draw (src/sinh_arcsinh.jl:14-15)
+__device__ inline float sinh_asinh(float sa, float ca, float z0) { return fmaf(sa, sqrtf(fmaf(z0, z0, 1.0f)), ca * z0); }
+
+// sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform! (logitnormal.jl:8-20) ->
+// clamp!(ys, eps, 1-eps) (likelihood-approximation.jl:523).  ys [n-1][K]; lyy [n-1][2][K]: [0] = log(1-y)
+// (right edge), [1] = log y (left edge).  ladj_out [K][2] = (skew, logit-normal) sums when non-null.
+template <int K, typename Noise>
+__global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restrict__ mu, const float *__restrict__ omega,
+                                                         const float *__restrict__ alpha, Noise noise, int step,
+                                                         double y_eps, double *__restrict__ ys,
+                                                         double *__restrict__ lyy, double *__restrict__ ladj_out)
+{
+    __shared__ double smem[4 * 2 * K];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double lsum[2 * K];
+#pragma unroll
+    for (int d = 0; d < 2 * K; ++d) lsum[d] = 0.0;
+    if (k < noise.nm1) {
+        const float al = alpha[k], sigma = expf(omega[k]), m = mu[k];
+        const float sa = sinhf(al), ca = coshf(al);
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const float z0 = noise.get(step, d, k);
+            const float zs = sinh_asinh(sa, ca, z0);
+            double y = (double)(1.0f / (1.0f + expf(-(m + zs * sigma))));
+            if (ladj_out) {
+                // log cosh(c) - 0.5 log1p(z0^2) with cosh(c) = sqrt(1 + sinh(c)^2)
+                lsum[d] = 0.5 * (double)log1pf(zs * zs) - 0.5 * (double)log1pf(z0 * z0);
+                lsum[K + d] = log((double)sigma * y * (1 - y));
+            }
+            y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
+            ys[k * K + d] = y;
+            lyy[(k * 2 + 0) * K + d] = log1p(-y);
+            lyy[(k * 2 + 1) * K + d] = log(y);
+        }
+    }
+    if (ladj_out) {
+        block_sum_vec<2 * K>(lsum, smem);
+#pragma unroll
+        for (int i = 0; i < 2 * K; ++i)
+            if (threadIdx.x == i) atomicAdd(&ladj_out[(i % K) * 2 + i / K], lsum[i]);
+    }
+}
+
+template <int K>
+__device__ inline VK<K> tour_value(uint32_t code, const double *__restrict__ lyy, VK<K> &edge)
+{
+    // edge = log of this entry's edge factor (0 for the root); value = +edge on ENTER, -edge on EXIT, 0 on LEAF
+    VK<K> val;
+    const uint32_t type = code & 3u;
+    if (code & 4u) {
+#pragma unroll
+        for (int d = 0; d < K; ++d) edge.v[d] = 0.0;
+    } else {
+        const double *p = lyy + ((size_t)(code >> 4) * 2 + ((code >> 3) & 1u)) * K;
+#pragma unroll
+        for (int d = 0; d < K; ++d) edge.v[d] = p[d];
+    }
+#pragma unroll
+    for (int d = 0; d < K; ++d) val.v[d] = type == TOUR_ENTER ? edge.v[d] : (type == TOUR_EXIT ? -edge.v[d] : 0.0);
+    return val;
+}
+
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, const double *__restrict__ lyy,
+                                                                    VK<K> *__restrict__ chunk_sums)
+{
+    __shared__ VK<K> smem[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    VK<K> acc = ScanOps<VK<K>>::zero(), edge;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < v.TL) acc = ScanOps<VK<K>>::add(acc, tour_value<K>(v.tour_code[base + j], lyy, edge));
+    VK<K> tot;
+    (void)block_exclusive_scan<VK<K>>(acc, smem, &tot);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+}
+
+// forward apply: leaves get u = exp(prefix + own edge); x = clamp(max(f32(u), 1e-16)) (ptt.jl:138-139,
+// likelihood-approximation.jl:526) written to xs[tid][K]; g[tid][K] is zeroed for the likelihood pass;
+// per-chunk partial sums of x/efflen (likelihood.jl:97-100) and, if wanted, of log u over internal nodes.
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, const double *__restrict__ lyy,
+                                                                   const VK<K> *__restrict__ chunk_offsets,
+                                                                   double *__restrict__ uleaf, float *__restrict__ xs,
+                                                                   float *__restrict__ g,
+                                                                   const float *__restrict__ efflens, float clamp_lo,
+                                                                   float clamp_hi, double *__restrict__ part_c,
+                                                                   double *__restrict__ part_ladj)
+{
+    __shared__ VK<K> smem[SCAN_THREADS / 64];
+    __shared__ double smd[4 * K];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    VK<K> val[SCAN_ITEMS], edge[SCAN_ITEMS];
+    uint32_t code[SCAN_ITEMS];
+    VK<K> acc = ScanOps<VK<K>>::zero();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        code[j] = base + j < v.TL ? v.tour_code[base + j] : (4u | TOUR_LEAF);
+        val[j] = tour_value<K>(code[j], lyy, edge[j]);
+        if (base + j >= v.TL) val[j] = ScanOps<VK<K>>::zero();
+        acc = ScanOps<VK<K>>::add(acc, val[j]);
+    }
+    VK<K> tot;
+    VK<K> off = block_exclusive_scan<VK<K>>(acc, smem, &tot);
+    off = ScanOps<VK<K>>::add(chunk_offsets[blockIdx.x], off);
+    double pc[K], pl[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) pc[d] = pl[d] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const VK<K> inc = ScanOps<VK<K>>::add(off, val[j]);
+        if (base + j < v.TL) {
+            const uint32_t type = code[j] & 3u;
+            if (type == TOUR_LEAF) {
+                const int pos = v.tour_tgt[base + j];
+                const int tid = v.leaf_tid[pos];
+                const float inv_l = efflens ? 1.0f / efflens[tid] : 0.0f;
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    const double u = exp(inc.v[d] + edge[j].v[d]);
+                    uleaf[(size_t)pos * K + d] = u;
+                    float x = (float)u;
+                    x = (float)fmax((double)x, 1e-16);
+                    x = fminf(fmaxf(x, clamp_lo), clamp_hi);
+                    xs[(size_t)tid * K + d] = x;
+                    g[(size_t)tid * K + d] = 0.0f;
+                    pc[d] += (double)(x * inv_l);  // xls[i] = xs[i] / efflens[i] in f32 (likelihood.jl:97)
+                }
+            } else if (type == TOUR_ENTER && part_ladj) {
+#pragma unroll
+                for (int d = 0; d < K; ++d) pl[d] += inc.v[d];
+            }
+        }
+        off = inc;
+    }
+    if (part_c) {
+        block_sum_vec<K>(pc, smd);
+        store_vec_by_thread<K>(pc, part_c + (size_t)blockIdx.x * K);
+    }
+    if (part_ladj) {
+        block_sum_vec<K>(pl, smd);
+        store_vec_by_thread<K>(pl, part_ladj + (size_t)blockIdx.x * K);
+    }
+}
+
+// summand of the backward scan at leaf position pos: a = u * x_grad, with the effective-length Jacobian
+// term folded in (likelihood.jl:102-104): x_grad[j] -= n * (1/efflen_j) / sum_i x_i/efflen_i
+template <int K>
+__device__ inline void bwd_values(const PttView &v, int64_t pos, const double *__restrict__ uleaf,
+                                  const float *__restrict__ g, const float *__restrict__ efflens,
+                                  const double *csum, VD<K> &a)
+{
+    const int tid = v.leaf_tid[pos];
+    const float nl = efflens ? (float)v.n * (1.0f / efflens[tid]) : 0.0f;  // Int * Float32 -> Float32 in the reference
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        double xg = (double)g[(size_t)tid * K + d];
+        if (efflens) xg -= (double)nl / csum[d];
+        a.v[d] = dd_make(uleaf[(size_t)pos * K + d] * xg);
+    }
+}
+
+// backward reduce; its prologue also finishes sum x/efflen from the forward pass's per-chunk partials
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_reduce_kernel(PttView v, const double *__restrict__ uleaf,
+                                                                    const float *__restrict__ g,
+                                                                    const float *__restrict__ efflens,
+                                                                    const double *__restrict__ part_c, int nchunks_fwd,
+                                                                    double *__restrict__ csum_out,
+                                                                    VD<K> *__restrict__ chunk_sums)
+{
+    __shared__ VD<K> smem[SCAN_THREADS / 64];
+    __shared__ double smd[4 * K];
+    double c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) c[d] = 0.0;
+    if (efflens) {
+        for (int ch = threadIdx.x; ch < nchunks_fwd; ch += SCAN_THREADS)
+#pragma unroll
+            for (int d = 0; d < K; ++d) c[d] += part_c[(size_t)ch * K + d];
+        block_sum_vec<K>(c, smd);
+        if (blockIdx.x == 0) store_vec_by_thread<K>(c, csum_out);
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    VD<K> acc = ScanOps<VD<K>>::zero(), a;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < v.n) {
+            bwd_values<K>(v, base + j, uleaf, g, efflens, c, a);
+            acc = ScanOps<VD<K>>::add(acc, a);
+        }
+    VD<K> tot;
+    (void)block_exclusive_scan<VD<K>>(acc, smem, &tot);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+}
+
+// backward apply: C[pos][K] = exclusive double-double prefix over leaf order, C[n] = total
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, const double *__restrict__ uleaf,
+                                                                   const float *__restrict__ g,
+                                                                   const float *__restrict__ efflens,
+                                                                   const double *__restrict__ csum,
+                                                                   const VD<K> *__restrict__ chunk_offsets,
+                                                                   dd *__restrict__ C)
+{
+    __shared__ VD<K> smem[SCAN_THREADS / 64];
+    double c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) c[d] = efflens ? csum[d] : 1.0;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    VD<K> val[SCAN_ITEMS];
+    VD<K> acc = ScanOps<VD<K>>::zero();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < v.n)
+            bwd_values<K>(v, base + j, uleaf, g, efflens, c, val[j]);
+        else
+            val[j] = ScanOps<VD<K>>::zero();
+        acc = ScanOps<VD<K>>::add(acc, val[j]);
+    }
+    VD<K> tot;
+    VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
+    off = ScanOps<VD<K>>::add(chunk_offsets[blockIdx.x], off);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < v.n) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) C[(size_t)(base + j) * K + d] = off.v[d];
+        }
+        off = ScanOps<VD<K>>::add(off, val[j]);
+        if (base + j == v.n - 1) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) C[(size_t)v.n * K + d] = off.v[d];
+        }
+    }
+}
+
+struct AdamConsts {
+    double lr, rm, rv, eps, m_denom, v_denom;
+    double max_mu, max_omega, max_alpha;
+    int first;  // step_num == 1
+};
+
+__device__ inline void adam_one(float &p, float &m, float &v, float grad, const AdamConsts &a, double max_step)
+{
+    // adam_update_mv! (likelihood-approximation.jl:116-130)
+    if (a.first) {
+        m = grad;
+        v = grad * grad;
+    } else {
+        m = (float)(a.rm * (double)m + (1 - a.rm) * (double)grad);
+        v = (float)(a.rv * (double)v + (1 - a.rv) * (double)(grad * grad));
+    }
+    // adam_update_params! (likelihood-approximation.jl:136-146) -- ascent, clamped step
+    const double pm = (double)m / a.m_denom, pv = (double)v / a.v_denom;
+    double delta = a.lr * pm / (sqrt(pv) + a.eps);
+    delta = delta < -max_step ? -max_step : (delta > max_step ? max_step : delta);
+    p = (float)((double)p + delta);
+}
+
+// update: one thread per internal node k, all K draws.
+//   y_grad[k] = H_l / y - H_r / (1 - y)   (closed form of ptt.jl:167-209, see ptt.hip)
+//   logit_normal_transform_gradients! (logitnormal.jl:38-55),
+//   sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38) with cosh(c) = sqrt(1+zs^2), tanh(c) = zs/cosh(c),
+//   omega_grad += sigma * sigma_grad (likelihood-approximation.jl:547-549), / K (:552-557), ADAM.
+template <int K, typename Noise>
+__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const double *__restrict__ ys,
+                                                         const dd *__restrict__ C, Noise noise, int step,
+                                                         float *mu, float *omega, float *alpha, float *m_mu, float *v_mu,
+                                                         float *m_omega, float *v_omega, float *m_alpha, float *v_alpha,
+                                                         AdamConsts adam, int apply, int *nonfinite_step,
+                                                         double *y_grad_out, float *mu_grad_out, float *omega_grad_out,
+                                                         float *alpha_grad_out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nm1 = v.n - 1;
+    if (k >= nm1) return;
+    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    const double cnt_r = (double)(mid - lo - 1), cnt_l = (double)(hi1 - mid - 1);
+    const float muk = mu[k], omk = omega[k], alk = alpha[k];
+    const float sigma = expf(omk), sa = sinhf(alk), ca = coshf(alk);
+    const dd *Clo = C + (size_t)lo * K, *Cmid = C + (size_t)mid * K, *Chi = C + (size_t)hi1 * K;
+    float mu_g = 0.f, om_g = 0.f, al_g = 0.f;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const dd cm = Cmid[d];
+        const double Hr = cnt_r + dd_diff(cm, Clo[d]);
+        const double Hl = cnt_l + dd_diff(Chi[d], cm);
+        const double y = ys[k * K + d];
+        const double ygd = Hl / y - Hr / (1.0 - y);
+        if (y_grad_out) y_grad_out[(int64_t)d * nm1 + k] = ygd;
+        const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
+        const float z0 = noise.get(step, d, k);
+        const float zs = sinh_asinh(sa, ca, z0);
+        const float cc = sqrtf(fmaf(zs, zs, 1.0f));  // cosh(alpha + asinh z0)
+        const double dyy = y * (1 - y);
+        mu_g = (float)((double)mu_g + dyy * (double)yg);  // mu_grad accumulates across draws in f32
+        mu_g = (float)((double)mu_g + (1 - 2 * y));
+        float sg = (float)(dyy * (double)zs * (double)yg);
+        sg = (float)((double)sg + ((double)(1.0f / sigma) + (double)zs * (1 - 2 * y)));
+        float zg = (float)(dyy * (double)sigma * (double)yg);
+        zg = (float)((double)zg + (double)sigma * (1 - 2 * y));
+        al_g += cc * zg;
+        al_g += zs / cc;
+        om_g += sigma * sg;
+    }
+    mu_g /= (float)K;
+    om_g /= (float)K;
+    al_g /= (float)K;
+    if (mu_grad_out) mu_grad_out[k] = mu_g;
+    if (omega_grad_out) omega_grad_out[k] = om_g;
+    if (alpha_grad_out) alpha_grad_out[k] = al_g;
+    if (!(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
+    if (apply) {
+        float p = muk, mm = m_mu[k], vv = v_mu[k];
+        adam_one(p, mm, vv, mu_g, adam, adam.max_mu);
+        mu[k] = p; m_mu[k] = mm; v_mu[k] = vv;
+        p = omk; mm = m_omega[k]; vv = v_omega[k];
+        adam_one(p, mm, vv, om_g, adam, adam.max_omega);
+        omega[k] = p; m_omega[k] = mm; v_omega[k] = vv;
+        p = alk; mm = m_alpha[k]; vv = v_alpha[k];
+        adam_one(p, mm, vv, al_g, adam, adam.max_alpha);
+        alpha[k] = p; m_alpha[k] = mm; v_alpha[k] = vv;
+    }
+}
+
+// sum of the per-chunk log-u partials -> row_sums[d*2+1] (hsb ladj), and csum -> row_sums[d*2+0]
+template <int K>
+__global__ void vi_values_finish_kernel(const double *part_ladj, int nchunks, const double *csum, double *row_sums)
+{
+    __shared__ double smd[4 * K];
+    double s[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) s[d] = 0.0;
+    for (int ch = threadIdx.x; ch < nchunks; ch += blockDim.x)
+#pragma unroll
+        for (int d = 0; d < K; ++d) s[d] += part_ladj[(size_t)ch * K + d];
+    block_sum_vec<K>(s, smd);
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+        if (threadIdx.x == d) {
+            row_sums[d * 2 + 1] = s[d];
+            row_sums[d * 2 + 0] = csum ? csum[d] : 0.0;
+        }
+}
+
+}  // namespace polee
