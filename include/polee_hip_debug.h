@@ -41,6 +41,10 @@ polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, i
 polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *view);
 void polee_debug_psell_free(polee_psell_debug *p);
 
+/* Process every slice with the mixed-slice kernel (the uniform streams' LDS-DMA kernel is bypassed): two
+ * different algorithms over the same layout, used by the full-size cross-check test. */
+polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on);
+
 #ifdef __cplusplus
 }
 #endif

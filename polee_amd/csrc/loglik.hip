@@ -616,7 +616,8 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     const PsellHost &h = ll->host;
     const int lcap = std::max(h.max_tile_cols, 1);
     hipStream_t st = ll->ctx->stream;
-    static const bool no_ring = getenv("POLEE_NO_RING") != nullptr;
+    static const bool no_ring_env = getenv("POLEE_NO_RING") != nullptr;
+    const bool no_ring = no_ring_env || ll->force_mixed;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     const PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                       ll->d_slice_ks.p, d_x, d_g, d_lp, lcap};
@@ -846,6 +847,13 @@ std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_byte
 }  // namespace polee
 
 extern "C" {
+
+polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on)
+{
+    if (!ll) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    ll->force_mixed = on != 0;
+    return POLEE_OK;
+}
 
 polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
                                          const uint32_t *trowval, const float *tnzval, const int64_t *ks,

@@ -71,6 +71,7 @@ struct polee_loglik {
     int refs = 1;
     int64_t m = 0, n = 0, nnz = 0;
     bool has_ks = false;
+    bool force_mixed = false;  // debug: process every slice with the mixed-slice kernel
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;

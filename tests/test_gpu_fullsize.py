@@ -1,0 +1,106 @@
+"""Full-size (BASELINE.json configs[1]: n=200 000 x m=30 000 000, ~240 M nnz) checks on the GPU through
+size-independent properties -- the oracle cannot visit this size in seconds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, M, NNZ_PER_FRAG = 200_000, 30_000_000, 8.0
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import polee_amd as P
+    from tools import synth
+    smp = synth.make_sample(N, M, NNZ_PER_FRAG, seed=123456789)
+    ctx = P.Context(0)
+    s = P.RNASeqSample(M, N, None, None, None, smp["effective_lengths"], ctx=ctx,
+                       xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
+    return P, ctx, smp, s
+
+
+def test_c2_layout_accounts_for_every_nonzero(c2):
+    P, ctx, smp, s = c2
+    info = s.info
+    assert info["nnz"] == smp["nnz"] and info["num_empty_rows"] == 0
+    assert sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == M
+    assert info["padded_nnz"] < 1.1 * info["nnz"]
+    assert info["stream_nnz"][0] > 0.5 * info["nnz"]  # most of X is in uniform slices
+
+
+def test_c2_homogeneity_and_kernel_cross_check(c2):
+    """sum_j x_j dlp/dx_j = m for every draw (Euler's theorem: lp is a sum of logs of linear forms), and the
+    LDS-DMA uniform-stream kernel agrees with the mixed-slice kernel run over the same slices."""
+    P, ctx, smp, s = c2
+    from polee_amd import _lib as L
+    rng = np.random.default_rng(0)
+    K = 6
+    x = rng.gamma(0.3, size=(K, N)).astype(np.float32) + np.float32(1e-7)
+    x /= x.sum(axis=1, keepdims=True)
+    x = np.clip(x, np.float32(1e-10), 1)
+    lp, g = s.log_likelihood(x)
+    assert np.isfinite(lp).all() and (lp < 0).all()
+    for k in range(K):
+        assert abs(float(g[k] @ x[k].astype(np.float64)) - M) < 2e-5 * M
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 1))
+    lp2, g2 = s.log_likelihood(x)
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 0))
+    np.testing.assert_allclose(lp2, lp, rtol=1e-7)
+    np.testing.assert_allclose(g2, g, rtol=2e-4, atol=1e-6 * np.abs(g).max())
+    # one draw at a time equals the batched pass
+    lp1, g1 = s.log_likelihood(x[2])
+    assert abs(lp1 - lp[2]) <= 1e-9 * abs(lp[2])
+    np.testing.assert_allclose(g1, g[2], rtol=2e-4, atol=1e-6 * np.abs(g).max())
+    # scaling x by c shifts lp by m log c and scales the gradient by 1/c
+    lp3, g3 = s.log_likelihood((x[0] * np.float32(0.5)))
+    assert abs((lp3 - lp[0]) - M * np.log(0.5)) < 1e-6 * abs(lp[0])
+    np.testing.assert_allclose(g3, 2 * g[0], rtol=2e-4, atol=1e-6 * np.abs(g).max())
+
+
+@pytest.mark.parametrize("kind", ["hclust", "spine"])
+def test_c2_tree_roundtrip_any_depth(c2, kind):
+    """transform / inverse round trip on 200 000 leaves, also for a spine (depth n-1, the reference's
+    :sequential tree): the scan formulation does not depend on depth."""
+    P, ctx, smp, s = c2
+    from tools import synth
+    parents, js = synth.make_tree(smp["gene"], seed=3, kind=kind)
+    t = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    rng = np.random.default_rng(1)
+    if kind == "spine":  # keep every leaf above the 1e-16 floor: stick fractions ~ 1/(remaining leaves)
+        k = np.arange(N - 1)
+        ys = 1.0 - 1.0 / (N - k) * rng.uniform(0.5, 1.5, N - 1)
+        ys = np.clip(ys, 1e-6, 1 - 1e-6)
+        idx = None
+    else:
+        ys = rng.uniform(0.3, 0.7, N - 1)
+    xs, ladj = t.transform(ys, compute_ladj=True)
+    assert abs(xs.astype(np.float64).sum() - 1) < 1e-4 and np.isfinite(ladj)
+    yr, ladj_inv = t.inverse_transform(xs)
+    ok = xs.min() > 1e-15
+    if ok:
+        np.testing.assert_allclose(yr, ys, rtol=1e-4, atol=1e-7)
+    # gradient of sum(c*x) + ladj: finite and consistent with a directional finite difference
+    c = rng.normal(size=N)
+    yg = t.transform_gradients(ys, c)
+    assert np.isfinite(yg).all()
+    d = rng.normal(size=N - 1) * 1e-7
+    f = lambda y: float(c @ t.transform(y, True)[0].astype(np.float64)) + t.transform(y, True)[1]
+    if kind == "hclust":
+        fd = (f(ys + d) - f(ys - d)) / 2
+        assert abs(fd - float(yg @ d)) < 5e-3 * max(1.0, abs(fd)) + 1e-4
+
+
+def test_c2_vi_steps_are_finite_and_move_uphill(c2):
+    P, ctx, smp, s = c2
+    from tools import synth
+    parents, js = synth.make_tree(smp["gene"], seed=3, kind="hclust")
+    t = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    fit = P.LikelihoodApproximationFit(s, t, num_steps=12, num_mc_samples=6, gradonly=False)
+    fit.run(12)
+    fit.sync()  # raises on a non-finite gradient
+    elbo, lp_mean = fit.trace()
+    assert np.isfinite(lp_mean).all() and lp_mean[-1] > lp_mean[0]  # ADAM ascent on the likelihood
+    mu, om, al = fit.params()
+    assert np.isfinite(mu).all() and np.isfinite(om).all() and np.isfinite(al).all()
