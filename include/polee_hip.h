@@ -155,6 +155,26 @@ polee_status polee_efflen_jacobian_adjustment(polee_ctx *ctx, const float *effle
                                               int32_t K, int64_t n, double *x_grad,
                                               float *xls_or_null);
 
+/* ---- element-wise reparameterisations (standalone forms) --------------------------------
+ * The Julia functions of src/logitnormal.jl:8-55, src/sinh_arcsinh.jl:10-38 and
+ * src/kumaraswamy.jl:27-78 (inside the VI loop the first two are fused into the tree kernels).
+ * Gradient entry points ACCUMULATE into *_grad like the reference's `+=`.  ladj pointers may be
+ * NULL (= Val(false)). */
+polee_status polee_logit_normal_transform(polee_ctx *ctx, const float *mu, const float *sigma,
+                                          const float *zs, int64_t len, double *ys, double *ladj_or_null);
+polee_status polee_logit_normal_transform_gradients(polee_ctx *ctx, const float *zs, const double *ys,
+                                                    const float *sigma, const float *y_grad, int64_t len,
+                                                    float *z_grad_or_null, float *mu_grad, float *sigma_grad);
+polee_status polee_sinh_asinh_transform(polee_ctx *ctx, const float *alpha, const float *zs0, int64_t len,
+                                        float *zs, double *ladj_or_null);
+polee_status polee_sinh_asinh_transform_gradients(polee_ctx *ctx, const float *zs0, const float *alpha,
+                                                  const float *z_grad, int64_t len, float *alpha_grad);
+polee_status polee_kumaraswamy_transform(polee_ctx *ctx, const float *as, const float *bs, const float *zs,
+                                         int64_t len, double *ys, double *ladj_or_null);
+polee_status polee_kumaraswamy_transform_gradients(polee_ctx *ctx, const float *zs, const float *as,
+                                                   const float *bs, const float *y_grad, int64_t len,
+                                                   float *a_grad, float *b_grad);
+
 /* ---- likelihood approximation (the VI loop) ----------------------------------------
  * Replaces approximate_likelihood(::LogitSkewNormalPTTApprox, sample)
  * (src/likelihood-approximation.jl:395-575), its factored variant (:248-392), ADAM

@@ -259,6 +259,85 @@ def effective_length_jacobian_adjustment(efflens, xs, x_grad, ctx=None):
     return (xls[0], g[0]) if single else (xls, g)
 
 
+def _vecs(dtype, *arrs):
+    out = [arr(a, dtype).reshape(-1) for a in arrs]
+    if len({a.size for a in out}) != 1:
+        raise ValueError("arguments differ in length")
+    return out
+
+
+def logit_normal_transform(mu, sigma, zs, compute_ladj=False, ctx=None):
+    """logit_normal_transform! (logitnormal.jl:8-20) -> (ys f64, ladj)."""
+    ctx = ctx or default_context()
+    mu, sigma, zs = _vecs(np.float32, mu, sigma, zs)
+    ys = np.empty(mu.size, np.float64)
+    ladj = C.c_double(0.0)
+    check(L.lib().polee_logit_normal_transform(ctx._h, ptr(mu, f32p), ptr(sigma, f32p), ptr(zs, f32p),
+                                               C.c_int64(mu.size), ptr(ys, f64p),
+                                               C.byref(ladj) if compute_ladj else None), ctx._h)
+    return ys, ladj.value
+
+
+def logit_normal_transform_gradients(zs, ys, mu, sigma, y_grad, z_grad=None, mu_grad=None, sigma_grad=None, ctx=None):
+    """logit_normal_transform_gradients! (logitnormal.jl:23-55): returns (z_grad, mu_grad, sigma_grad), each the
+    given array (or zeros) plus this call's contribution."""
+    ctx = ctx or default_context()
+    zs, sigma, y_grad = _vecs(np.float32, zs, sigma, y_grad)
+    ys = arr(ys, np.float64).reshape(-1)
+    n = zs.size
+    zg = np.zeros(n, np.float32) if z_grad is None else arr(z_grad, np.float32).copy()
+    mg = np.zeros(n, np.float32) if mu_grad is None else arr(mu_grad, np.float32).copy()
+    sg = np.zeros(n, np.float32) if sigma_grad is None else arr(sigma_grad, np.float32).copy()
+    check(L.lib().polee_logit_normal_transform_gradients(ctx._h, ptr(zs, f32p), ptr(ys, f64p), ptr(sigma, f32p),
+                                                         ptr(y_grad, f32p), C.c_int64(n), ptr(zg, f32p),
+                                                         ptr(mg, f32p), ptr(sg, f32p)), ctx._h)
+    return zg, mg, sg
+
+
+def sinh_asinh_transform(alpha, zs0, compute_ladj=False, ctx=None):
+    """sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> (zs, ladj)."""
+    ctx = ctx or default_context()
+    alpha, zs0 = _vecs(np.float32, alpha, zs0)
+    zs = np.empty(alpha.size, np.float32)
+    ladj = C.c_double(0.0)
+    check(L.lib().polee_sinh_asinh_transform(ctx._h, ptr(alpha, f32p), ptr(zs0, f32p), C.c_int64(alpha.size),
+                                             ptr(zs, f32p), C.byref(ladj) if compute_ladj else None), ctx._h)
+    return zs, ladj.value
+
+
+def sinh_asinh_transform_gradients(zs0, alpha, z_grad, alpha_grad=None, ctx=None):
+    """sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38)."""
+    ctx = ctx or default_context()
+    zs0, alpha, z_grad = _vecs(np.float32, zs0, alpha, z_grad)
+    ag = np.zeros(zs0.size, np.float32) if alpha_grad is None else arr(alpha_grad, np.float32).copy()
+    check(L.lib().polee_sinh_asinh_transform_gradients(ctx._h, ptr(zs0, f32p), ptr(alpha, f32p), ptr(z_grad, f32p),
+                                                       C.c_int64(zs0.size), ptr(ag, f32p)), ctx._h)
+    return ag
+
+
+def kumaraswamy_transform(as_, bs, zs, compute_ladj=True, ctx=None):
+    """kumaraswamy_transform! (kumaraswamy.jl:27-51) -> (ys, ladj)."""
+    ctx = ctx or default_context()
+    as_, bs, zs = _vecs(np.float32, as_, bs, zs)
+    ys = np.empty(zs.size, np.float64)
+    ladj = C.c_double(0.0)
+    check(L.lib().polee_kumaraswamy_transform(ctx._h, ptr(as_, f32p), ptr(bs, f32p), ptr(zs, f32p), C.c_int64(zs.size),
+                                              ptr(ys, f64p), C.byref(ladj) if compute_ladj else None), ctx._h)
+    return ys, ladj.value
+
+
+def kumaraswamy_transform_gradients(zs, as_, bs, y_grad, a_grad=None, b_grad=None, ctx=None):
+    """kumaraswamy_transform_gradients! (kumaraswamy.jl:54-78)."""
+    ctx = ctx or default_context()
+    zs, as_, bs, y_grad = _vecs(np.float32, zs, as_, bs, y_grad)
+    ag = np.zeros(zs.size, np.float32) if a_grad is None else arr(a_grad, np.float32).copy()
+    bg = np.zeros(zs.size, np.float32) if b_grad is None else arr(b_grad, np.float32).copy()
+    check(L.lib().polee_kumaraswamy_transform_gradients(ctx._h, ptr(zs, f32p), ptr(as_, f32p), ptr(bs, f32p),
+                                                        ptr(y_grad, f32p), C.c_int64(zs.size), ptr(ag, f32p),
+                                                        ptr(bg, f32p)), ctx._h)
+    return ag, bg
+
+
 class LogitSkewNormalPTTApprox:
     """src/likelihood-approximation.jl:8-16 (treemethod is only a label here: tree construction,
     hclust, is outside the hot path -- pass the tree explicitly)."""

@@ -1,0 +1,256 @@
+// Element-wise reparameterisations as standalone entry points (host-pointer API): the Julia functions of
+// src/logitnormal.jl:8-55, src/sinh_arcsinh.jl:10-38 and src/kumaraswamy.jl:27-78.  Inside the VI loop the first
+// two are fused into vi_sample / vi_update (vi_fused.hpp); these exist so that callers of the individual
+// reference functions (alt approximations, tests) find them behind the same C ABI.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace polee {
+
+// ---- logit-normal --------------------------------------------------------------------------------------
+__global__ void logit_normal_kernel(const float *mu, const float *sigma, const float *zs, int64_t len, double *ys,
+                                    double *ladj)
+{
+    __shared__ double smd[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double l = 0.0;
+    if (i < len) {
+        const double y = (double)(1.0f / (1.0f + expf(-(mu[i] + zs[i] * sigma[i]))));  // logitnormal.jl:2,12
+        ys[i] = y;
+        if (ladj) l = log((double)sigma[i] * y * (1 - y));  // :15
+    }
+    if (ladj) {
+        l = block_sum_f64(l, smd);
+        if (threadIdx.x == 0) atomicAdd(ladj, l);
+    }
+}
+
+// logit_normal_transform_gradients! (8-argument form, logitnormal.jl:38-55); z_grad may be null (7-argument form)
+__global__ void logit_normal_grad_kernel(const float *zs, const double *ys, const float *sigma, const float *y_grad,
+                                         int64_t len, float *z_grad, float *mu_grad, float *sigma_grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const double y = ys[i], d = y * (1 - y);
+    float mg = mu_grad[i], sg = sigma_grad[i];
+    mg = (float)((double)mg + d * (double)y_grad[i]);
+    sg = (float)((double)sg + d * (double)zs[i] * (double)y_grad[i]);
+    mg = (float)((double)mg + (1 - 2 * y));
+    sg = (float)((double)sg + ((double)(1.0f / sigma[i]) + (double)zs[i] * (1 - 2 * y)));
+    mu_grad[i] = mg;
+    sigma_grad[i] = sg;
+    if (z_grad) {
+        float zg = z_grad[i];
+        zg = (float)((double)zg + d * (double)sigma[i] * (double)y_grad[i]);
+        zg = (float)((double)zg + (double)sigma[i] * (1 - 2 * y));
+        z_grad[i] = zg;
+    }
+}
+
+// ---- sinh-arcsinh ----------------------------------------------------------------------------------------
+__global__ void sinh_asinh_kernel(const float *alpha, const float *zs0, int64_t len, float *zs, double *ladj)
+{
+    __shared__ double smd[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double l = 0.0;
+    if (i < len) {
+        const float c = alpha[i] + asinhf(zs0[i]);
+        zs[i] = sinhf(c);
+        if (ladj) l = (double)logf(coshf(c)) - 0.5 * (double)log1pf(zs0[i] * zs0[i]);  // sinh_arcsinh.jl:18
+    }
+    if (ladj) {  // a proper reduction (the reference's threaded += is a data race)
+        l = block_sum_f64(l, smd);
+        if (threadIdx.x == 0) atomicAdd(ladj, l);
+    }
+}
+__global__ void sinh_asinh_grad_kernel(const float *zs0, const float *alpha, const float *z_grad, int64_t len,
+                                       float *alpha_grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float c = alpha[i] + asinhf(zs0[i]);
+    float ag = alpha_grad[i];
+    ag += coshf(c) * z_grad[i];  // sinh_arcsinh.jl:32-33
+    ag += tanhf(c);              // :36
+    alpha_grad[i] = ag;
+}
+
+// ---- Kumaraswamy -----------------------------------------------------------------------------------------
+__global__ void kumaraswamy_kernel(const float *as, const float *bs, const float *zs, int64_t len, double *ys,
+                                   double *ladj)
+{
+    __shared__ double smd[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double l = 0.0;
+    if (i < len) {
+        const double a = as[i], b = bs[i], z = zs[i];
+        const double ia = 1 / a, ib = 1 / b;
+        const double c = 1 - pow(1 - z, ib);  // kumaraswamy.jl:39
+        ys[i] = pow(c, ia);
+        if (ladj) l = (ib - 1) * log(1 - z) + (ia - 1) * log(c) - log(a * b);  // :44
+    }
+    if (ladj) {
+        l = block_sum_f64(l, smd);
+        if (threadIdx.x == 0) atomicAdd(ladj, l);
+    }
+}
+__global__ void kumaraswamy_grad_kernel(const float *zs, const float *as, const float *bs, const float *y_grad,
+                                        int64_t len, float *a_grad, float *b_grad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const double a = as[i], b = bs[i], z = zs[i];
+    const double ia = 1 / a, ib = 1 / b;
+    const double omz_ib = pow(1 - z, ib);
+    const double c = 1 - omz_ib, log_c = log(c), log_omz = log(1 - z);
+    float ag = a_grad[i], bg = b_grad[i];
+    ag = (float)((double)ag + (-log_c / (a * a) - ia));                                                    // :66
+    bg = (float)((double)bg + (-log_omz / (b * b) + (ia - 1) * (1 / c) * omz_ib * log_omz / (b * b) - ib));  // :67-69
+    ag = (float)((double)ag + (-pow(c, ia) * log_c / (a * a)) * (double)y_grad[i]);                          // :72-73
+    bg = (float)((double)bg + (pow(c, ia - 1) * omz_ib * log_omz / (a * b * b)) * (double)y_grad[i]);        // :75-76
+    a_grad[i] = ag;
+    b_grad[i] = bg;
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+namespace {
+struct Scratch {
+    DevBuf<float> f[6];
+    DevBuf<double> d[2];
+};
+inline unsigned blocks(int64_t len) { return (unsigned)ceil_div(len, 256); }
+}  // namespace
+
+extern "C" {
+
+polee_status polee_logit_normal_transform(polee_ctx *ctx, const float *mu, const float *sigma, const float *zs,
+                                          int64_t len, double *ys, double *ladj)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!mu || !sigma || !zs || !ys || len < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, mu, len));
+    POLEE_TRY(s.f[1].upload(ctx, sigma, len));
+    POLEE_TRY(s.f[2].upload(ctx, zs, len));
+    POLEE_TRY(s.d[0].alloc(ctx, len));
+    POLEE_TRY(s.d[1].alloc(ctx, 1));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(s.d[1].p, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(logit_normal_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.f[1].p, s.f[2].p,
+                       len, s.d[0].p, ladj ? s.d[1].p : nullptr);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(s.d[0].download(ctx, ys, len));
+    if (ladj) POLEE_TRY(s.d[1].download(ctx, ladj, 1));
+    return POLEE_OK;
+}
+
+polee_status polee_logit_normal_transform_gradients(polee_ctx *ctx, const float *zs, const double *ys,
+                                                    const float *sigma, const float *y_grad, int64_t len,
+                                                    float *z_grad_or_null, float *mu_grad, float *sigma_grad)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!zs || !ys || !sigma || !y_grad || !mu_grad || !sigma_grad || len < 0)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, zs, len));
+    POLEE_TRY(s.d[0].upload(ctx, ys, len));
+    POLEE_TRY(s.f[1].upload(ctx, sigma, len));
+    POLEE_TRY(s.f[2].upload(ctx, y_grad, len));
+    POLEE_TRY(s.f[3].upload(ctx, mu_grad, len));
+    POLEE_TRY(s.f[4].upload(ctx, sigma_grad, len));
+    if (z_grad_or_null) POLEE_TRY(s.f[5].upload(ctx, z_grad_or_null, len));
+    hipLaunchKernelGGL(logit_normal_grad_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.d[0].p,
+                       s.f[1].p, s.f[2].p, len, z_grad_or_null ? s.f[5].p : nullptr, s.f[3].p, s.f[4].p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(s.f[3].download(ctx, mu_grad, len));
+    POLEE_TRY(s.f[4].download(ctx, sigma_grad, len));
+    if (z_grad_or_null) POLEE_TRY(s.f[5].download(ctx, z_grad_or_null, len));
+    return POLEE_OK;
+}
+
+polee_status polee_sinh_asinh_transform(polee_ctx *ctx, const float *alpha, const float *zs0, int64_t len, float *zs,
+                                        double *ladj)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!alpha || !zs0 || !zs || len < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, alpha, len));
+    POLEE_TRY(s.f[1].upload(ctx, zs0, len));
+    POLEE_TRY(s.f[2].alloc(ctx, len));
+    POLEE_TRY(s.d[1].alloc(ctx, 1));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(s.d[1].p, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(sinh_asinh_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.f[1].p, len,
+                       s.f[2].p, ladj ? s.d[1].p : nullptr);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(s.f[2].download(ctx, zs, len));
+    if (ladj) POLEE_TRY(s.d[1].download(ctx, ladj, 1));
+    return POLEE_OK;
+}
+
+polee_status polee_sinh_asinh_transform_gradients(polee_ctx *ctx, const float *zs0, const float *alpha,
+                                                  const float *z_grad, int64_t len, float *alpha_grad)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!zs0 || !alpha || !z_grad || !alpha_grad || len < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, zs0, len));
+    POLEE_TRY(s.f[1].upload(ctx, alpha, len));
+    POLEE_TRY(s.f[2].upload(ctx, z_grad, len));
+    POLEE_TRY(s.f[3].upload(ctx, alpha_grad, len));
+    hipLaunchKernelGGL(sinh_asinh_grad_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.f[1].p,
+                       s.f[2].p, len, s.f[3].p);
+    POLEE_KERNEL_CHECK(ctx);
+    return s.f[3].download(ctx, alpha_grad, len);
+}
+
+polee_status polee_kumaraswamy_transform(polee_ctx *ctx, const float *as, const float *bs, const float *zs, int64_t len,
+                                         double *ys, double *ladj)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!as || !bs || !zs || !ys || len < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, as, len));
+    POLEE_TRY(s.f[1].upload(ctx, bs, len));
+    POLEE_TRY(s.f[2].upload(ctx, zs, len));
+    POLEE_TRY(s.d[0].alloc(ctx, len));
+    POLEE_TRY(s.d[1].alloc(ctx, 1));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(s.d[1].p, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(kumaraswamy_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.f[1].p, s.f[2].p,
+                       len, s.d[0].p, ladj ? s.d[1].p : nullptr);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(s.d[0].download(ctx, ys, len));
+    if (ladj) {
+        POLEE_TRY(s.d[1].download(ctx, ladj, 1));
+        if (!std::isfinite(*ladj)) return fail(ctx, POLEE_ERR_NONFINITE, "kumaraswamy ladj is not finite (kumaraswamy.jl:49)");
+    }
+    return POLEE_OK;
+}
+
+polee_status polee_kumaraswamy_transform_gradients(polee_ctx *ctx, const float *zs, const float *as, const float *bs,
+                                                   const float *y_grad, int64_t len, float *a_grad, float *b_grad)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!zs || !as || !bs || !y_grad || !a_grad || !b_grad || len < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (len == 0) return POLEE_OK;
+    Scratch s;
+    POLEE_TRY(s.f[0].upload(ctx, zs, len));
+    POLEE_TRY(s.f[1].upload(ctx, as, len));
+    POLEE_TRY(s.f[2].upload(ctx, bs, len));
+    POLEE_TRY(s.f[3].upload(ctx, y_grad, len));
+    POLEE_TRY(s.f[4].upload(ctx, a_grad, len));
+    POLEE_TRY(s.f[5].upload(ctx, b_grad, len));
+    hipLaunchKernelGGL(kumaraswamy_grad_kernel, dim3(blocks(len)), dim3(256), 0, ctx->stream, s.f[0].p, s.f[1].p,
+                       s.f[2].p, s.f[3].p, len, s.f[4].p, s.f[5].p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(s.f[4].download(ctx, a_grad, len));
+    return s.f[5].download(ctx, b_grad, len);
+}
+
+}  // extern "C"

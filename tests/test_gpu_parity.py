@@ -396,3 +396,39 @@ def test_approx_logprob_and_gradient_match_oracle(P, ctx, shared):
     xs = ap.sample(z0)
     xo = O.tf_sampler(z0, eff, mu, sigma, alpha, L_, R_, F_)
     np.testing.assert_allclose(xs, xo, rtol=1e-4, atol=1e-16)
+
+
+def test_elementwise_reparameterisations_match_oracle(P, ctx):
+    """Standalone logit-normal / sinh-arcsinh / Kumaraswamy transforms and their gradients."""
+    rng = np.random.default_rng(31)
+    k = 5000
+    mu = rng.normal(size=k).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.5, size=k)).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=k).astype(np.float32)
+    z0 = rng.normal(size=k).astype(np.float32)
+    yg = rng.normal(size=k).astype(np.float32)
+    zs, skew = P.sinh_asinh_transform(alpha, z0, True, ctx=ctx)
+    zo, skew_o = O.sinh_asinh_transform(alpha, z0, True)
+    np.testing.assert_allclose(zs, zo, rtol=2e-6, atol=1e-7)
+    assert abs(skew - skew_o) <= 1e-4 * max(1, abs(skew_o))  # the reference accumulates this ladj in f32
+    ys, ln = P.logit_normal_transform(mu, sigma, zo, True, ctx=ctx)
+    yo, ln_o = O.logit_normal_transform(mu, sigma, zo, True)
+    np.testing.assert_allclose(ys, yo, rtol=5e-7)
+    assert abs(ln - ln_o) <= 1e-4 * max(1, abs(ln_o))
+    zg, mg, sg = P.logit_normal_transform_gradients(zo, yo, mu, sigma, yg, ctx=ctx)
+    zgo, mgo, sgo = O.logit_normal_transform_gradients(zo, yo, mu, sigma, yg)
+    for a, b in ((zg, zgo), (mg, mgo), (sg, sgo)):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+    ag = P.sinh_asinh_transform_gradients(z0, alpha, zgo, ctx=ctx)
+    np.testing.assert_allclose(ag, O.sinh_asinh_transform_gradients(z0, alpha, zgo), rtol=5e-6, atol=1e-6)
+    a = rng.uniform(0.5, 3, k).astype(np.float32)
+    b = rng.uniform(0.5, 3, k).astype(np.float32)
+    z = rng.uniform(0.02, 0.98, k).astype(np.float32)
+    yk, lk = P.kumaraswamy_transform(a, b, z, True, ctx=ctx)
+    yko, lko = O.kumaraswamy_transform(a, b, z, True)
+    np.testing.assert_allclose(yk, yko, rtol=1e-12)
+    assert abs(lk - lko) <= 1e-10 * max(1, abs(lko))
+    ka, kb = P.kumaraswamy_transform_gradients(z, a, b, yg, ctx=ctx)
+    kao, kbo = O.kumaraswamy_transform_gradients(z, a, b, yg)
+    np.testing.assert_allclose(ka, kao, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(kb, kbo, rtol=1e-6, atol=1e-6)
