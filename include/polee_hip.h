@@ -247,6 +247,13 @@ polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens,
                           const polee_vi_opts *opts, float *mu, float *omega, float *alpha,
                           polee_vi_stats *stats_or_null);
 
+/* approximate_likelihood(::OptimizePTTApprox, sample) (src/likelihood-approximation.jl:149-242): point
+ * optimisation of the expression vector by ADAM ascent on z (ys = logistic(z)), used by the reference to
+ * assign reads while fitting bias models (src/rnaseq_sample.jl:343).  The reference builds a :sequential
+ * tree itself; here the tree is the caller's.  xs f32 [n] (clamped to [1e-10, 1]); zs optional f32 [n-1]. */
+polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *efflens, int32_t num_steps,
+                                float *xs, float *zs_or_null);
+
 /* ---- sampler ------------------------------------------------------------------------
  * rand!(::ApproxLikelihoodSampler) (src/approx-sampler.jl:37-44): draws x f32
  * [ndraws][n] from a fitted approximation.  z0 (optional host [ndraws][n-1]) replaces

@@ -305,6 +305,35 @@ def approximate_likelihood(sample, ptt, efflens, num_steps=500, num_mc=6, use_ef
     return dict(mu=mu, omega=omega, alpha=alpha, elbo=elbo, lp_mean=lpm)
 
 
+def optimize_ptt(sample, ptt, efflens, num_steps=500):
+    """approximate_likelihood(::OptimizePTTApprox, sample) (likelihood-approximation.jl:149-242) -> (xs, zs)."""
+    efflens = _f32(efflens)
+    xs = np.empty(sample.n, np.float32)
+    zs = np.empty(sample.n - 1, np.float32)
+    lib().oracle_optimize_ptt(sample.h, ptt.h, _p(efflens, c_f32p), int(num_steps), _p(zs, c_f32p), _p(xs, c_f32p))
+    return xs, zs
+
+
+def list_nodes(n):
+    """The :sequential tree (hclust.jl:477-489 list_nodes + order_nodes :361-389), serialised."""
+    stack = list(range(1, n + 1))
+    while len(stack) > 1:
+        a = stack.pop(); b = stack.pop()
+        stack.append((a, b))  # HClustNode(a, b): left = a, right = b
+    parents, js = [], []
+    st = [(stack[0], 0)]
+    while st:
+        node, par = st.pop()
+        idx = len(parents) + 1
+        parents.append(par)
+        if isinstance(node, tuple):
+            js.append(0)
+            st.append((node[0], idx)); st.append((node[1], idx))  # right is popped (visited) first
+        else:
+            js.append(int(node))
+    return np.array(parents, np.int32), np.array(js, np.int32)
+
+
 def vi_draw_gradients(sample, ptt, efflens, mu, omega, alpha, zs0, use_efflen_jacobian=True):
     efflens, mu, omega, alpha, zs0 = map(_f32, (efflens, mu, omega, alpha, zs0))
     n, nm1 = sample.n, sample.n - 1

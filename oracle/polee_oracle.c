@@ -739,6 +739,61 @@ done:
     return rc;
 }
 
+/* src/likelihood-approximation.jl:149-242 approximate_likelihood(::OptimizePTTApprox, sample): point
+ * optimisation of z (ys = logistic(z), no clamp of ys, no ladj terms), ADAM with max step 0.1.  The
+ * reference builds a :sequential tree itself (:160); here the tree is an argument.  xs_out f32[n]. */
+int oracle_optimize_ptt(oracle_sample *s, oracle_ptt *t, const float *efflens, int num_steps, float *zs_out,
+                        float *xs_out)
+{
+    int64_t n = s->n, nm1 = n - 1;
+    float *m_z = calloc(nm1, 4), *v_z = calloc(nm1, 4), *zs = calloc(nm1, 4), *xls = calloc(n, 4);
+    double *ys = calloc(nm1, 8), *z_grad = calloc(nm1, 8), *y_grad = calloc(nm1, 8), *x_grad = calloc(n, 8);
+    float *zg32 = calloc(nm1, 4);
+    const double eps = 1e-10, ss_max_z_step = 1e-1;
+    for (int64_t j = 0; j < n; ++j) xs_out[j] = 1.0f / (float)n;
+    oracle_ptt_inverse_transform(t, xs_out, ys);
+    for (int64_t i = 0; i < nm1; ++i) zs[i] = (float)logit_f64(ys[i]);
+    for (int step_num = 1; step_num <= num_steps; ++step_num) {
+        double learning_rate = oracle_adam_learning_rate((double)(step_num - 1));
+        for (int64_t i = 0; i < nm1; ++i) ys[i] = (double)logistic_f32(zs[i]);
+        memset(x_grad, 0, n * 8);
+        memset(y_grad, 0, nm1 * 8);
+        oracle_ptt_transform(t, ys, xs_out, 0);
+        for (int64_t j = 0; j < n; ++j) {
+            double x = xs_out[j];
+            x = x < eps ? eps : (x > 1 - eps ? 1 - eps : x);
+            xs_out[j] = (float)x;
+        }
+        oracle_log_likelihood(s, xs_out, x_grad, 1);
+        oracle_effective_length_jacobian_adjustment(efflens, xs_out, xls, x_grad, n);
+        oracle_ptt_transform_gradients_no_ladj(t, ys, y_grad, x_grad);
+        for (int64_t i = 0; i < nm1; ++i) {
+            z_grad[i] = ys[i] * (1 - ys[i]) * y_grad[i];
+            zg32[i] = (float)z_grad[i]; /* ms[i] = grad[i] stores into Float32 arrays (:116-130) */
+        }
+        /* adam_update_mv! with a Float64 grad: ms/vs are Float32, grad^2 in f64 */
+        if (step_num == 1) {
+            for (int64_t i = 0; i < nm1; ++i) { m_z[i] = (float)z_grad[i]; v_z[i] = (float)(z_grad[i] * z_grad[i]); }
+        } else {
+            for (int64_t i = 0; i < nm1; ++i) {
+                m_z[i] = (float)(ADAM_RM * (double)m_z[i] + (1 - ADAM_RM) * z_grad[i]);
+                v_z[i] = (float)(ADAM_RV * (double)v_z[i] + (1 - ADAM_RV) * (z_grad[i] * z_grad[i]));
+            }
+        }
+        oracle_adam_update_params(zs, m_z, v_z, learning_rate, step_num, ss_max_z_step, nm1);
+    }
+    for (int64_t i = 0; i < nm1; ++i) ys[i] = (double)logistic_f32(zs[i]);
+    oracle_ptt_transform(t, ys, xs_out, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        double x = xs_out[j];
+        x = x < eps ? eps : (x > 1 - eps ? 1 - eps : x);
+        xs_out[j] = (float)x;
+    }
+    if (zs_out) memcpy(zs_out, zs, nm1 * 4);
+    free(m_z); free(v_z); free(zs); free(xls); free(ys); free(z_grad); free(y_grad); free(x_grad); free(zg32);
+    return 0;
+}
+
 /* One gradient evaluation of the loop body above for a given (mu, omega, alpha,
  * zs0): returns the per-draw contributions before the /num_mc (i.e. what one
  * pass of :513-549 adds to mu_grad/omega_grad/alpha_grad), plus xs and lp.

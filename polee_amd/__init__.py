@@ -21,7 +21,8 @@ from .core import (Context, PolyaTreeTransform, make_inverse_ptt_params, hsb, in
                    LikelihoodApproximationFit, ApproxLikelihoodSampler, RNASeqApproxLikelihood,
                    rnaseq_approx_likelihood_sampler, LIKAP_NUM_STEPS, LIKAP_NUM_MC_SAMPLES,
                    logit_normal_transform, logit_normal_transform_gradients, sinh_asinh_transform,
-                   sinh_asinh_transform_gradients, kumaraswamy_transform, kumaraswamy_transform_gradients)
+                   sinh_asinh_transform_gradients, kumaraswamy_transform, kumaraswamy_transform_gradients,
+                   OptimizePTTApprox, optimize_likelihood, list_nodes)
 
 from . import h5io, estimate  # noqa: F401,E402
 from .estimate import LoadedSamples, load_samples_from_specification, load_samples_hdf5, read_specification  # noqa: F401,E402

@@ -450,6 +450,45 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
     return params
 
 
+class OptimizePTTApprox:
+    """src/likelihood-approximation.jl:4-7."""
+
+
+def list_nodes(n):
+    """Serialised :sequential tree (hclust.jl:477-489 + order_nodes :361-389) -> (node_parent_idxs, node_js).
+    It is a caterpillar: leaf n-? ... the k-th merge joins the running subtree (left) with the next leaf (right)."""
+    N = 2 * n - 1
+    parents = np.zeros(N, np.int32)
+    js = np.zeros(N, np.int32)
+    # DFS pre-order, right child first: root, its right leaf (transcript 1), then the left subtree, recursively
+    idx = 0
+    par = 0
+    for leaf in range(1, n):  # internal node whose right child is `leaf`
+        parents[idx] = par
+        me = idx + 1
+        idx += 1
+        parents[idx] = me
+        js[idx] = leaf
+        idx += 1
+        par = me
+    parents[idx] = par
+    js[idx] = n
+    return parents, js
+
+
+def optimize_likelihood(sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS):
+    """optimize_likelihood / approximate_likelihood(::OptimizePTTApprox, sample)
+    (likelihood-approximation.jl:21-23, 149-242) -> {"x": xs}.  `t` is the tree to optimise over (the
+    reference uses PolyaTreeTransform(X, :sequential); see list_nodes)."""
+    efflens = sample.effective_lengths if efflens is None else efflens
+    efflens = arr(efflens, np.float32)
+    xs = np.empty(sample.n, np.float32)
+    zs = np.empty(sample.n - 1, np.float32)
+    check(L.lib().polee_optimize_ptt(sample._h, t._h, ptr(efflens, f32p), int(num_steps), ptr(xs, f32p), ptr(zs, f32p)),
+          sample.ctx._h)
+    return {"x": xs, "z": zs}
+
+
 class ApproxLikelihoodSampler:
     """src/approx-sampler.jl:4-44."""
 

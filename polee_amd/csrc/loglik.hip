@@ -6,7 +6,9 @@
 //     lp[k] += ks_i log s_i[k]
 //     g_j[k] += X_ij ks_i / s_i[k]      (accumulated per tile in LDS, flushed once)
 // The reference makes two passes (CSR for s, CSC for g) per draw, i.e. 2*K passes per VI
-// step; this kernel makes one.  Roofline: HBM-bound, no MFMA (0.25 flop/B).
+// step; this file makes one, as a single launch (loglik_fused_kernel) whose workgroups are of
+// three kinds, one per row stream of the PSELL layout (loglik_internal.hpp).
+// Roofline: HBM-bound, no MFMA (0.25 flop/B).
 #include "loglik_internal.hpp"
 
 #include <algorithm>
@@ -756,11 +758,6 @@ void loglik_release(polee_loglik *ll)
     polee_ctx *ctx = ll->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
     for (hipEvent_t e : ll->prof_events) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) {
-        if (ll->side[i]) (void)hipStreamDestroy(ll->side[i]);
-        if (ll->ev_join[i]) (void)hipEventDestroy(ll->ev_join[i]);
-    }
-    if (ll->ev_fork) (void)hipEventDestroy(ll->ev_fork);
     delete ll;
     ctx_release(ctx);
 }
@@ -789,11 +786,6 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     PsellHost &h = ll->host;
     polee_status s;
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
-    for (int i = 0; i < 2; ++i) {
-        if (hipStreamCreateWithFlags(&ll->side[i], hipStreamNonBlocking) != hipSuccess) ll->side[i] = nullptr;
-        if (hipEventCreateWithFlags(&ll->ev_join[i], hipEventDisableTiming) != hipSuccess) ll->side[0] = nullptr;
-    }
-    if (hipEventCreateWithFlags(&ll->ev_fork, hipEventDisableTiming) != hipSuccess) ll->side[0] = nullptr;
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {

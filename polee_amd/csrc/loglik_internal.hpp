@@ -9,20 +9,23 @@
 //     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
 //     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
 //     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
-//   * Up to 32 consecutive slices form a TILE, processed by one 256-thread workgroup.
-//     A tile owns a dictionary of the distinct transcripts its rows touch
-//     (dict: local id u16 -> transcript id u32, at most 1024 entries), so an entry
-//     costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
+//   * Consecutive slices form a TILE (64 / 8 / 16 slices in streams A1 / A2 / B), processed by one
+//     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
+//     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
+//     pass 256 entries), so an entry costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
 //   * The kernel stages the tile's x[dict][K] into LDS, accumulates the tile's gradient
 //     contributions in LDS (ds_add_f32) and flushes L*K values to HBM per tile.
-//   * Rows are split into two streams: A = whole slices of runs of >= 64 fragments with one and the
-//     same transcript set (tiles [0, num_tiles_a)), B = everything else.  A is processed by
-//     loglik_psell_ring_kernel (LDS-DMA streaming, register accumulation, no cross-lane traffic
-//     inside a run), B by loglik_psell_kernel (per-run DPP sums).
-//   * Each slice carries two flag bits: "uniform" (its 64 rows share one transcript set) and
-//     "continues" (the same set as the previous slice).  Runs of such slices -- the bulk of
-//     real and synthetic data, where many fragments fall into the same equivalence class --
-//     accumulate their gradient contributions in registers with no cross-lane traffic.
+//   * Rows are split into three streams: A = slices whose rows all share one transcript set (whole
+//     64-row slices of every run of identical rows, plus run remainders of >= 32 rows, zero padded;
+//     A1 = sets of <= 18 transcripts, A2 = 19..28), B = everything else.  Tiles [0, num_tiles_a1)
+//     are A1, [num_tiles_a1, num_tiles_a) A2, the rest B.  One launch (loglik_fused_kernel)
+//     processes all three with differently specialised workgroups: A by uniform_tile_body (LDS-DMA
+//     streaming, transposed accumulation through LDS, no cross-lane traffic), B by psell_tile_body
+//     (per-run DPP sums).
+//   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
+//     share one transcript set) and "continues" (the same set as the previous slice).  Runs of such
+//     slices -- the bulk of real and synthetic data, where many fragments fall into the same
+//     equivalence class -- keep their gradient contributions in one register per lane.
 // HBM traffic per likelihood pass ~ 6 B/nnz (+ padding + dictionaries), read once.
 #pragma once
 #include "common.hpp"
@@ -80,8 +83,6 @@ struct polee_loglik {
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;
     // profiling of the sparse kernel
-    hipStream_t side[2] = {nullptr, nullptr};  // streams A2 and B run beside A1
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool profile = false;
     hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;  // bracket the dominant launch of the current pass
     hipEvent_t cur_p0 = nullptr, cur_p1 = nullptr;  // bracket the whole pass

@@ -557,6 +557,74 @@ polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens, 
     return s;
 }
 
+polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *efflens, int32_t num_steps, float *xs,
+                                float *zs_out)
+{
+    if (!ll || !t || !efflens || !xs || num_steps < 0) return fail(nullptr, POLEE_ERR_BAD_ARG, "bad argument");
+    polee_vi_opts o;
+    polee_vi_default_opts(&o);
+    o.num_steps = num_steps;
+    o.num_mc_samples = 1;
+    polee_vi *vi = nullptr;
+    POLEE_TRY(polee_vi_create(ll, t, efflens, &o, &vi));  // initial z = logit(inverse_transform(1/n)) lands in d_mu
+    polee_ctx *ctx = vi->ctx;
+    hipStream_t st = ctx->stream;
+    const int32_t n = vi->n;
+    const int64_t nm1 = n - 1;
+    const PttView view = t->view();
+    const int nch_f = scan_num_chunks(t->TL), nch_b = scan_num_chunks(n);
+    VK<1> *chunk_f = reinterpret_cast<VK<1> *>(t->d_chunk.p);
+    VD<1> *chunk_b = reinterpret_cast<VD<1> *>(t->d_chunk.p);
+    polee_status rc = POLEE_OK;
+    auto forward = [&]() -> polee_status {
+        hipLaunchKernelGGL(point_sample_kernel, dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, vi->d_mu.p, nm1,
+                           vi->d_ys.p, vi->d_lyy.p);
+        if (nch_f > 1) {
+            hipLaunchKernelGGL((vi_fwd_reduce_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
+            hipLaunchKernelGGL((scan_spine_kernel<VK<1>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
+        } else {
+            POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<1>), st));
+        }
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
+                           vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
+                           vi->d_part_c.p, (double *)nullptr);
+        POLEE_KERNEL_CHECK(ctx);
+        return POLEE_OK;
+    };
+    for (int step_num = 1; step_num <= num_steps && rc == POLEE_OK && nm1 > 0; ++step_num) {
+        rc = forward();
+        if (rc != POLEE_OK) break;
+        rc = loglik_eval_device(ll, vi->d_x.p, 1, vi->d_g.p, nullptr);
+        if (rc != POLEE_OK) break;
+        hipLaunchKernelGGL((vi_bwd_reduce_kernel<1>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p,
+                           vi->d_g.p, vi->d_efflens.p, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
+        hipLaunchKernelGGL((scan_spine_kernel<VD<1>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
+        hipLaunchKernelGGL((vi_bwd_apply_kernel<1>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p,
+                           vi->d_g.p, vi->d_efflens.p, vi->d_csum.p, chunk_b, vi->d_C.p);
+        AdamConsts a;
+        a.lr = std::max(o.adam_min_learning_rate,
+                        o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));
+        a.rm = o.adam_rm;
+        a.rv = o.adam_rv;
+        a.eps = o.adam_eps;
+        a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
+        a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
+        a.max_mu = 1e-1;  // ss_max_z_step (likelihood-approximation.jl:166)
+        a.max_omega = a.max_alpha = 0.0;
+        a.first = step_num == 1;
+        hipLaunchKernelGGL(point_update_kernel, dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view, vi->d_ys.p,
+                           vi->d_C.p, vi->d_mu.p, vi->d_mm.p, vi->d_vm.p, a, vi->d_flag.p, step_num);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(ctx, POLEE_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    }
+    if (rc == POLEE_OK) rc = forward();  // final xs = clamp(transform(logistic(zs))) (:235-241)
+    if (rc == POLEE_OK) rc = polee_vi_sync(vi);
+    if (rc == POLEE_OK) rc = vi->d_x.download(ctx, xs, n);  // K = 1: [n][1] is [n]
+    if (rc == POLEE_OK && zs_out) rc = vi->d_mu.download(ctx, zs_out, nm1);
+    polee_vi_destroy(vi);
+    return rc;
+}
+
 polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
                                 const float *z0, int32_t ndraws, uint64_t seed, float *xs)
 {

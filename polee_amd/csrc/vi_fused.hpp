@@ -433,6 +433,49 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
     }
 }
 
+// ---- point optimisation (OptimizePTTApprox, likelihood-approximation.jl:149-242), K = 1 ------------------
+// ys = logistic(zs) without clamp (:196-198)
+__global__ void point_sample_kernel(const float *__restrict__ zs, int64_t nm1, double *__restrict__ ys,
+                                    double *__restrict__ lyy)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nm1) return;
+    double y = (double)(1.0f / (1.0f + expf(-zs[k])));
+    // the f32 logistic saturates at exactly 0 or 1 (the reference does not clamp here); its tree recursion
+    // stays finite there, the closed form H_l/y - H_r/(1-y) needs the limit: keep y one ulp inside (0, 1) --
+    // with the double-double leaf prefix the subtree sums stay exact at that scale
+    y = y < 0x1p-52 ? 0x1p-52 : (y > 1 - 0x1p-52 ? 1 - 0x1p-52 : y);
+    ys[k] = y;
+    lyy[k * 2 + 0] = log1p(-y);
+    lyy[k * 2 + 1] = log(y);
+}
+// z_grad = y (1-y) y_grad with transform_gradients_no_ladj! (ptt.jl:217-251; :208-213), ADAM on z (:226-227)
+__global__ void point_update_kernel(PttView v, const double *__restrict__ ys, const dd *__restrict__ C, float *zs,
+                                    float *m_z, float *v_z, AdamConsts adam, int *nonfinite_step, int step)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= v.n - 1) return;
+    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    const double Hr = dd_diff(C[mid], C[lo]), Hl = dd_diff(C[hi1], C[mid]);
+    const double y = ys[k];
+    const double zg = y * (1 - y) * (Hl / y - Hr / (1.0 - y));
+    if (!isfinite(zg)) atomicCAS(nonfinite_step, 0, step);
+    float m = m_z[k], vv = v_z[k], p = zs[k];
+    if (adam.first) {
+        m = (float)zg;
+        vv = (float)(zg * zg);
+    } else {
+        m = (float)(adam.rm * (double)m + (1 - adam.rm) * zg);
+        vv = (float)(adam.rv * (double)vv + (1 - adam.rv) * (zg * zg));
+    }
+    const double pm = (double)m / adam.m_denom, pv = (double)vv / adam.v_denom;
+    double delta = adam.lr * pm / (sqrt(pv) + adam.eps);
+    delta = delta < -adam.max_mu ? -adam.max_mu : (delta > adam.max_mu ? adam.max_mu : delta);
+    zs[k] = (float)((double)p + delta);
+    m_z[k] = m;
+    v_z[k] = vv;
+}
+
 // sum of the per-chunk log-u partials -> row_sums[d*2+1] (hsb ladj), and csum -> row_sums[d*2+0]
 template <int K>
 __global__ void vi_values_finish_kernel(const double *part_ladj, int nchunks, const double *csum, double *row_sums)

@@ -369,3 +369,15 @@ def test_tf_sampler_matches_julia_sampler(prep_fixture, lm_fixture):
     np.testing.assert_allclose(xt[big], xj[big], rtol=3e-4)
     x0 = O.x0_draw(t, mu, sigma, alpha, eff, z0)
     np.testing.assert_allclose(x0[big], xj[big], rtol=3e-4)
+
+
+def test_optimize_ptt_climbs_the_likelihood(lm_fixture):
+    """OptimizePTTApprox (likelihood-approximation.jl:149-242) on the :sequential tree: the point estimate's
+    log-likelihood approaches the EM maximum (-326 994.4) from the uniform start (-364 724.4)."""
+    f = lm_fixture
+    s = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    t = O.PTT(*O.list_nodes(f["n"]))
+    xs, zs = O.optimize_ptt(s, t, f["effective_lengths"], num_steps=500)
+    assert abs(xs.astype(np.float64).sum() - 1) < 1e-3
+    lp, _ = s.log_likelihood(xs)
+    assert -327600 < lp < -326990, lp
