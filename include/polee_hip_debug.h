@@ -25,7 +25,7 @@ typedef struct {
     int64_t m, n, nnz, num_slices, num_tiles, padded_nnz, num_empty_rows;
     int64_t data_bytes, dict_len;
     int32_t max_row_nnz, max_tile_cols;
-    const uint8_t *data;        /* slice blocks: float val[w][64]; uint16 lcol[w][64]      */
+    const uint8_t *data;        /* mixed slice blocks: float val[w][64]; uint16 lcol[w][64] */
     const uint32_t *slice_off;  /* [num_slices+1], 128-byte units                          */
     const uint32_t *tile_slice; /* [num_tiles+1]                                           */
     const uint32_t *tile_dict;  /* [num_tiles+1]                                           */
@@ -33,6 +33,9 @@ typedef struct {
     const uint32_t *row_order;  /* [num_slices*64] 0-based fragment per lane, ~0 = empty   */
     const float *slice_ks;      /* [num_slices*64] or NULL                                 */
     const uint8_t *slice_flags; /* [num_slices] bit0 uniform, bit1 continues previous      */
+    int64_t num_tiles_a;        /* tiles [0, num_tiles_a) hold COMPACT slices:             */
+                                /*   uint16 lcol[128] (w used); float val[w][64]           */
+    int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): transcript sets of <= 18        */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

@@ -72,6 +72,8 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->tile_dict = h.tile_dict.data(); v->dict = h.dict.data(); v->row_order = h.row_order.data();
     v->slice_ks = h.slice_ks.empty() ? nullptr : h.slice_ks.data();
     v->slice_flags = h.slice_flags.data();
+    v->num_tiles_a = h.num_tiles_a;
+    v->num_tiles_a1 = h.num_tiles_a1;
     return POLEE_OK;
 }
 

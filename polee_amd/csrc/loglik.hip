@@ -140,6 +140,7 @@ struct PsellArgs {
     float *g;
     double *lp;
     int lcap;
+    int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layout
 };
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -166,15 +167,21 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t s0 = tile_slice[tile], s1 = tile_slice[tile + 1];
+    const bool compact = tile < A.tiles_a;
     double lpacc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
 
     for (uint32_t s = s0 + wave; s < s1; s += 4) {
         const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
-        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
-        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
-        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+        const uint32_t units = (slice_off[s + 1] & PSELL_OFF_MASK) - off;
+        // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
+        // mixed slices: float val[w][64]; uint16 lcol[w][64]
+        const int w = compact ? (int)(units / 2u) - 1 : (int)(units / 3u);
+        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0)) + lane;
+        const uint16_t *cols = compact ? reinterpret_cast<const uint16_t *>(data + (size_t)off * 128)
+                                       : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+        const int cstride = compact ? 1 : 64;
 
         // sweep 1: row sums s[k] = sum_t v[t] * x[c[t]][k]
         float sacc[K];
@@ -187,12 +194,12 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = vals[(t + u) * 64];
-                c[u] = cols[(t + u) * 64];
+                c[u] = cols[(t + u) * cstride];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
         }
-        for (; t < w; ++t) fma_row<K>(vals[t * 64], xw + (int)cols[t * 64] * K, sacc);
+        for (; t < w; ++t) fma_row<K>(vals[t * 64], xw + (int)cols[t * cstride] * K, sacc);
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
         float wk[K];
 #pragma unroll
@@ -203,7 +210,7 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         // sweep 2 (slice is L1/L2 resident): g[c[t]][k] += v[t] * w[k], summed per run of equal ids
         for (t = 0; t < w; ++t) {
             const float v = vals[t * 64];
-            const int c = cols[t * 64];
+            const int c = cols[t * cstride];
             float q[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) q[k] = v * wk[k];
@@ -427,7 +434,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
         const uint32_t units = off_next - off;
-        const int w = (int)(units / 3u);
+        const int w = (int)(units / 2u) - 1;  // 256-byte header (column ids) + w rows of 64 values
         const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
         STAMP(1);  // slice bookkeeping
@@ -447,13 +454,14 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
 #pragma unroll
             for (int j = 0; j < NSET; ++j)
                 if (lane + 64 * j < npairs)
-                    mycol[j] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)pt[j] * 128u));
-            int cc[WMAXR];
+                    mycol[j] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)pt[j] * 2u));
+            // the header as one dword per lane (two ids each); the wave-uniform copies come out with v_readlane
+            const int hd = *reinterpret_cast<const int *>(ring_at((uint32_t)(lane & 63) * 4u));
 #pragma unroll
-            for (int t = 0; t < WMAXR; ++t)
-                cc[t] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)w * 256u + (uint32_t)min(t, w - 1) * 128u));
-#pragma unroll
-            for (int t = 0; t < WMAXR; ++t) pc[t] = t < w ? __builtin_amdgcn_readfirstlane(cc[t]) : 0;
+            for (int t = 0; t < WMAXR; ++t) {
+                const int two = __builtin_amdgcn_readlane(hd, t >> 1);
+                pc[t] = t < w ? ((t & 1) ? (int)((unsigned)two >> 16) : (two & 0xffff)) : 0;
+            }
         }
 
         STAMP(3);  // run change: flush + column lookup
@@ -472,7 +480,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
                         const int t = t0 + u;
                         v[u] = 0.0f;
                         if (t < WMAXR) {
-                            const float vv = *reinterpret_cast<const float *>(ring_at((uint32_t)min(t, w - 1) * 256u + lane * 4u));
+                            const float vv = *reinterpret_cast<const float *>(ring_at(256u + (uint32_t)min(t, w - 1) * 256u + lane * 4u));
                             v[u] = t < w ? vv : 0.0f;
                         }
                     }
@@ -499,7 +507,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
             for (int j = 0; j < NSET; ++j) {
                 if (64 * j < npairs) {
                     if (lane + 64 * j < npairs) {
-                        const char *vrow = ring_at((uint32_t)pt[j] * 256u);
+                        const char *vrow = ring_at(256u + (uint32_t)pt[j] * 256u);
                         const char *wrow = reinterpret_cast<const char *>(wbuf + pk[j] * 64);
                         float a0 = 0.f, a1 = 0.f;
                         // 16 steps of 4 fragments; the LDS reads of 8 steps are issued together (LDS latency is the
@@ -622,10 +630,10 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     const bool no_ring = no_ring_env || ll->force_mixed;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     const PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
-                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap};
-    // a slice of w transcripts occupies ceil(w*384/256)*256 bytes and may start 896 bytes into a 1 KiB piece
-    static_assert(PSELL_NARROW_MAX * 384 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
-    static_assert(((PSELL_WIDE_MAX * 384 + 255) / 256) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
+                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a};
+    // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
+    static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
+    static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
     const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)4 * K * 64 + (size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;

@@ -154,20 +154,34 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         uint32_t w = 0;
         for (uint32_t r : slice_rows) w = std::max<uint32_t>(w, (uint32_t)(rowptr[r + 1] - rowptr[r]));
         const size_t base = out.data.size();
-        // blocks are padded to a multiple of 256 bytes so that no 256-byte value row wraps in the LDS ring
-        out.data.resize(base + (((size_t)w * 384 + 255) & ~(size_t)255), 0);
-        float *vals = reinterpret_cast<float *>(out.data.data() + base);
-        uint16_t *lcols = reinterpret_cast<uint16_t *>(out.data.data() + base + (size_t)w * 256);
-        for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
-            const uint32_t r = slice_rows[lane];
-            const uint64_t b = rowptr[r], len = rowptr[r + 1] - b;
-            uint16_t last = 0;
-            for (uint32_t t = 0; t < w; ++t) {
-                if (t < len) {
-                    vals[(size_t)t * 64 + lane] = val[b + t];
-                    last = col_local[col[b + t]];
+        if (cur_stream < 2) {
+            // uniform streams: the 64 fragments share one transcript set, so the column ids are stored once:
+            //   uint16 lcol[128] (256-byte header, w used) ; float val[w][64]
+            out.data.resize(base + 256 + (size_t)w * 256, 0);
+            uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
+            float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
+            const uint64_t b0 = rowptr[slice_rows[0]];
+            for (uint32_t t = 0; t < w; ++t) hdr[t] = col_local[col[b0 + t]];
+            for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
+                const uint64_t b = rowptr[slice_rows[lane]];
+                for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + lane] = val[b + t];
+            }
+        } else {
+            // mixed stream: float val[w][64]; uint16 lcol[w][64], padded to a multiple of 256 bytes
+            out.data.resize(base + (((size_t)w * 384 + 255) & ~(size_t)255), 0);
+            float *vals = reinterpret_cast<float *>(out.data.data() + base);
+            uint16_t *lcols = reinterpret_cast<uint16_t *>(out.data.data() + base + (size_t)w * 256);
+            for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
+                const uint32_t r = slice_rows[lane];
+                const uint64_t b = rowptr[r], len = rowptr[r + 1] - b;
+                uint16_t last = 0;
+                for (uint32_t t = 0; t < w; ++t) {
+                    if (t < len) {
+                        vals[(size_t)t * 64 + lane] = val[b + t];
+                        last = col_local[col[b + t]];
+                    }
+                    lcols[(size_t)t * 64 + lane] = last;  // padding repeats the last valid local id
                 }
-                lcols[(size_t)t * 64 + lane] = last;  // padding repeats the last valid local id
             }
         }
         for (size_t lane = 0; lane < PSELL_LANES; ++lane) {

@@ -140,7 +140,8 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     v = L.PsellView()
     L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
     out = dict(num_slices=v.num_slices, num_tiles=v.num_tiles, padded_nnz=v.padded_nnz, nnz=v.nnz,
-               empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz)
+               empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz,
+               num_tiles_a=v.num_tiles_a)
     out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
     raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
     out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
@@ -166,9 +167,17 @@ def _emulate_psell(ps, x, n):
         gw = np.zeros((K, d1 - d0))
         for s in range(ps["tile_slice"][t], ps["tile_slice"][t + 1]):
             off = int(ps["slice_off"][s]) * 128
-            w = (int(ps["slice_off"][s + 1]) * 128 - off) // 384
-            vals = data[off:off + w * 256].view(np.float32).reshape(w, 64)
-            cols = data[off + w * 256:off + w * 384].view(np.uint16).reshape(w, 64).astype(np.int64)
+            nbytes = int(ps["slice_off"][s + 1]) * 128 - off
+            if t < ps["num_tiles_a"]:  # compact uniform slice: one column-id header, then the values
+                w = nbytes // 256 - 1
+                assert ps["slice_flags"][s] & 1
+                hdr = data[off:off + 256].view(np.uint16)[:w].astype(np.int64)
+                cols = np.repeat(hdr[:, None], 64, axis=1)
+                vals = data[off + 256:off + 256 + w * 256].view(np.float32).reshape(w, 64)
+            else:
+                w = nbytes // 384
+                vals = data[off:off + w * 256].view(np.float32).reshape(w, 64)
+                cols = data[off + w * 256:off + w * 384].view(np.uint16).reshape(w, 64).astype(np.int64)
             assert cols.max(initial=0) < d1 - d0
             ksv = np.ones(64) if ps["ks"] is None else ps["ks"][s * 64:(s + 1) * 64].astype(np.float64)
             for k in range(K):
