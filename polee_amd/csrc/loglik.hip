@@ -141,6 +141,9 @@ struct PsellArgs {
     double *lp;
     int lcap;
     int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layout
+    // transposed copy of the mixed tiles (PsellHost::tdata)
+    const uint8_t *tdata;
+    const uint32_t *tgroup_off, *ttile_group;
 };
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -243,6 +246,138 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile
     extern __shared__ float lds[];
     __shared__ double lp_red[4];
     psell_tile_body<K, WANT_LP, HAS_KS>(A, tile_base + (int)blockIdx.x, lds, lds + (size_t)A.lcap * K, lp_red);
+}
+
+// ---- stream B inside the fused launch: row sweep, then column sweep ---------------------------------------
+// Sweep 1 (lane = fragment, row-major slices) leaves the weights W[row][k] = ks / s of the tile's <= 1024
+// fragments in LDS.  Sweep 2 walks the tile's TRANSPOSED copy: every lane owns a piece (<= 32 entries) of one
+// transcript's entries and gathers the weights of their fragments, G[c][k] = sum_e v_e W[row_e][k] -- no
+// cross-lane sums, one LDS add per (piece, k).
+template <int K, bool WANT_LP, bool HAS_KS>
+__device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrows, float *xw, float *gw, double *lp_red)
+{
+    const uint8_t *__restrict__ data = A.data;
+    const uint32_t *__restrict__ slice_off = A.slice_off;
+    const uint32_t *__restrict__ dict = A.dict;
+    const float *__restrict__ slice_ks = A.slice_ks;
+    const float *__restrict__ x = A.x;
+    float *__restrict__ g = A.g;
+
+    const uint32_t d0 = A.tile_dict[tile];
+    const int L = (int)(A.tile_dict[tile + 1] - d0);
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int l = i / K, k = i - l * K;
+        xw[i] = x[(size_t)dict[d0 + l] * K + k];
+        gw[i] = 0.0f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t s0 = A.tile_slice[tile], s1 = A.tile_slice[tile + 1];
+    double lpacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
+
+    for (uint32_t s = s0 + wave; s < s1; s += 4) {
+        const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
+        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
+        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
+        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+        float sacc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        int t = 0;
+        for (; t + 8 <= w; t += 8) {
+            float v[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = vals[(t + u) * 64];
+                c[u] = cols[(t + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
+        }
+        {  // remainder (< 8): loads predicated, all in flight together
+            float v[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = t + u < w;
+                v[u] = live ? vals[(t + u) * 64] : 0.0f;
+                c[u] = live ? (int)cols[(t + u) * 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
+        }
+        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
+        float *wr = wrows + ((size_t)(s - s0) * 64 + lane) * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wr[k] = fast_weight(ksv, sacc[k]);
+            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
+        }
+    }
+    __syncthreads();
+
+    const int tb = tile - A.tiles_a;
+    const uint32_t g0 = A.ttile_group[tb], g1 = A.ttile_group[tb + 1];
+    for (uint32_t gi = g0 + wave; gi < g1; gi += 4) {
+        const uint32_t off = A.tgroup_off[gi];
+        const int width = (int)((A.tgroup_off[gi + 1] - off - 1u) / 3u);
+        const uint8_t *base = A.tdata + (size_t)off * 128;
+        const int vc = reinterpret_cast<const uint16_t *>(base)[lane];
+        const float *vval = reinterpret_cast<const float *>(base + 128) + lane;
+        const uint16_t *vrow = reinterpret_cast<const uint16_t *>(base + 128 + (size_t)width * 256) + lane;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+        int e = 0;
+        for (; e + 8 <= width; e += 8) {
+            float v[8];
+            int r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = vval[(e + u) * 64];
+                r[u] = vrow[(e + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
+        }
+        {
+            float v[8];
+            int r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = e + u < width;
+                v[u] = live ? vval[(e + u) * 64] : 0.0f;
+                r[u] = live ? (int)vrow[(e + u) * 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (acc[k] != 0.0f) atomicAdd(gw + vc * K + k, acc[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int l = i / K, k = i - l * K;
+        const float v = gw[i];
+        if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
+    }
+    if (WANT_LP) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = lpacc[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if (lane == 0) lp_red[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(A.lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
+            __syncthreads();
+        }
+    }
 }
 
 // ---- stream A: uniform slices, LDS-DMA streamed, transposed accumulation --------------------------------
@@ -608,15 +743,28 @@ void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int n
     float *xw = wbufs + 4 * K * 64;
     float *gw = xw + (size_t)A.lcap * K;
     double *lp_red = reinterpret_cast<double *>(gw + (size_t)((A.lcap * K + 1) & ~1));
+    // The three kinds are interleaved over the grid (stream B and A2 workgroups are latency-bound chains of
+    // dependent loads; spread among the A1 workgroups their stalls are covered by A1's streaming).  They
+    // are spread over the first 7/8 of the grid so that the launch does not end on a slow workgroup.
     const int b = blockIdx.x;
-    if (b < nb_b) {
-        psell_tile_body<K, WANT_LP, HAS_KS>(A, tiles_a + b, xw, gw, lp_red);
-    } else if (b < nb_b + nb_a2) {
-        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + (b - nb_b), dbg, rings, wbufs, xw,
-                                                                         gw, lp_red);
+    const int total = (int)gridDim.x;
+    const int span = max(max(total - total / 8, nb_b), 1);
+    auto before = [](int i, int count, int span_) -> int {  // how many of `count` blocks precede position i
+        return (int)min((long long)count, (long long)i * count / span_);
+    };
+    const int nbb = before(b, nb_b, span);
+    if (before(b + 1, nb_b, span) > nbb) {
+        mixed_tile_body<K, WANT_LP, HAS_KS>(A, tiles_a + nbb, lds, xw, gw, lp_red);  // W rows live in the ring area
+        return;
+    }
+    const int r = b - nbb, rest = total - nb_b;
+    const int span2 = max(max(rest - rest / 8, nb_a2), 1);
+    const int na2 = before(r, nb_a2, span2);
+    if (before(r + 1, nb_a2, span2) > na2) {
+        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, wbufs, xw, gw,
+                                                                         lp_red);
     } else {
-        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, b - nb_b - nb_a2, dbg, rings, wbufs, xw, gw,
-                                                                          lp_red);
+        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, wbufs, xw, gw, lp_red);
     }
 }
 
@@ -630,9 +778,11 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     const bool no_ring = no_ring_env || ll->force_mixed;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     const PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
-                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a};
+                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a,
+                      ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p};
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
     static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
+    static_assert(PSELL_TILE_SLICES_B * 64 * PSELL_MAX_K * 4 <= (int)FUSED_RING_TOTAL, "stream-B weight rows must fit the ring area");
     static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
     const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)4 * K * 64 + (size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
@@ -796,7 +946,8 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
-        (s = ll->d_dict.upload(ctx, h.dict)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_tdata.upload(ctx, h.tdata)) ||
+        (s = ll->d_tgroup_off.upload(ctx, h.tgroup_off)) || (s = ll->d_ttile_group.upload(ctx, h.ttile_group)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
         loglik_release(ll);
         return s;
     }
@@ -804,6 +955,8 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     std::vector<uint8_t>().swap(h.data);
     std::vector<uint32_t>().swap(h.slice_off);
     std::vector<uint32_t>().swap(h.dict);
+    std::vector<uint8_t>().swap(h.tdata);
+    std::vector<uint32_t>().swap(h.tgroup_off);
     std::vector<float>().swap(h.slice_ks);
     std::vector<uint8_t>().swap(h.slice_flags);
     std::vector<uint32_t>().swap(h.row_order);

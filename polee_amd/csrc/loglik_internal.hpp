@@ -42,6 +42,7 @@ constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
 constexpr int PSELL_NARROW_MAX = 18;        // widest transcript set of stream A1 (8 KiB LDS ring)
 constexpr int PSELL_WIDE_MAX = 28;          // widest transcript set of stream A2 (12 KiB LDS ring)
+constexpr int PSELL_VCOL_CAP = 32;         // stream B: entries per virtual column (lane) of the transposed copy
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 
 struct PsellHost {
@@ -59,6 +60,15 @@ struct PsellHost {
     std::vector<uint32_t> dict;        // transcript ids (0-based)
     std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
+    // stream B only: the tile's entries a second time, grouped by transcript ("virtual columns": a transcript
+    // of the tile with many entries is cut into pieces of <= PSELL_VCOL_CAP entries; pieces are sorted by
+    // length and packed 64 to a GROUP, one per lane).  Group block:
+    //   uint16 vcol[64] (tile-local transcript id per lane); float vval[width][64]; uint16 vrow[width][64]
+    // (vrow = fragment index inside the tile, slice*64 + lane; padding has vval = 0, vrow = 0).
+    std::vector<uint8_t> tdata;
+    std::vector<uint32_t> tgroup_off;   // [num_groups+1], 128-byte units into tdata
+    std::vector<uint32_t> ttile_group;  // [num_tiles - num_tiles_a + 1] group range of each stream-B tile
+    int64_t num_groups = 0;
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
 };
 
@@ -78,6 +88,8 @@ struct polee_loglik {
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
+    polee::DevBuf<uint8_t> d_tdata;
+    polee::DevBuf<uint32_t> d_tgroup_off, d_ttile_group;
     polee::DevBuf<float> d_slice_ks;
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
