@@ -181,7 +181,9 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
         const int w = compact ? (int)(units / 2u) - 1 : (int)(units / 3u);
-        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0)) + lane;
+        // (compact slices store element r of row t at position (r + 4 t) & 63, see uniform_tile_body)
+        const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0));
+        auto vat = [&](int t) -> float { return vbase[t * 64 + (compact ? ((lane + 4 * t) & 63) : lane)]; };
         const uint16_t *cols = compact ? reinterpret_cast<const uint16_t *>(data + (size_t)off * 128)
                                        : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
         const int cstride = compact ? 1 : 64;
@@ -196,13 +198,13 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
             int c[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[u] = vals[(t + u) * 64];
+                v[u] = vat(t + u);
                 c[u] = cols[(t + u) * cstride];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
         }
-        for (; t < w; ++t) fma_row<K>(vals[t * 64], xw + (int)cols[t * cstride] * K, sacc);
+        for (; t < w; ++t) fma_row<K>(vat(t), xw + (int)cols[t * cstride] * K, sacc);
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
         float wk[K];
 #pragma unroll
@@ -212,7 +214,7 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         }
         // sweep 2 (slice is L1/L2 resident): g[c[t]][k] += v[t] * w[k], summed per run of equal ids
         for (t = 0; t < w; ++t) {
-            const float v = vals[t * 64];
+            const float v = vat(t);
             const int c = cols[t * cstride];
             float q[K];
 #pragma unroll
@@ -447,11 +449,10 @@ __device__ unsigned long long g_stamps[16];
 // One tile of a uniform stream.  RB = ring bytes per active wave, NW = waves that own slices (the others only
 // take part in the staging and the barriers), WMAXR = widest transcript set of the stream.
 template <int K, uint32_t RB, int NW, int WMAXR, bool WANT_LP, bool HAS_KS>
-__device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, const char *rings, float *wbufs,
+__device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, const char *rings,
                                          float *xw, float *gw, double *lp_red)
 {
     constexpr int RP = (int)(RB / 1024u);
-    constexpr int NSET = (WMAXR * K + 63) / 64;  // (t, k) pairs per lane
     const uint8_t *__restrict__ data = A.data;
     const uint32_t *__restrict__ slice_off = A.slice_off;
     const uint32_t *__restrict__ tile_slice = A.tile_slice;
@@ -487,7 +488,6 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
     const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
     const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
     const char *ring = rings + (wave < NW ? wave : 0) * RB;
-    float *wbuf = wbufs + wave * K * 64;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(uintptr_t)(__attribute__((address_space(3))) const char *)ring);
     int issued = 0, islot = 0;
@@ -532,32 +532,51 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
     __syncthreads();
     STAMP(0);  // prologue: first DMAs, window staging, barrier
 
-    double lpacc[K];
+    // Both phases run on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate -- bit-for-bit an
+    // fmaf chain); lane l = (tt = l & 15, q = l >> 4).  A slice is a (w x 64) block V[t][r]:
+    //   phase 1   S[r][k] = sum_t V[t][r] x[c_t][k]      M = r (4 tiles: tile e holds rows 4 i + e), N = k, inner = t
+    //       A[i][kk=q] = V[4 step + q][4 i + e]  -- one 16-byte LDS read per step feeds the 4 row tiles
+    //       B[kk=q][tt] = x[c_{4 step + q}][tt]  -- constant over a run, kept in registers (xq)
+    //       D1[e]: lane (tt, q), register v  =  S[16 q + 4 v + e][tt]
+    //   weights   W = ks / S, in place (v_rcp_f32)
+    //   phase 2   G[t][k] += sum_r V[t][r] W[k][r]      M = t, N = k, inner = r = 16 q + (0..15)
+    //       A[tt][kk=q] = V[tt][16 q + 4 j + e]   -- four 16-byte LDS reads
+    //       B[kk=q][tt] = W[tt][16 q + 4 j + e]   = D1[e][j] of THIS lane: the weights never leave the registers
+    //       D2 (rows 4 q + v, column tt) stays in registers for the whole run of slices sharing the set.
+    // Rows are stored ROTATED (element r of row t at position (r + 4 t) & 63) so that the 16 lanes of every
+    // 16-byte read hit 16 different bank groups.  Columns tt >= K are padding (B = 0 there).
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = (WMAXR + 15) / 16;  // 16-row tiles of transcripts (phase 2)
+    constexpr int NS = (WMAXR + 3) / 4;    // steps of 4 transcripts (phase 1)
+    const int tt = lane & 15, q = lane >> 4;
+    double lpacc = 0.0;        // draw tt, fragments 16 q .. 16 q + 15 of every slice
+    f32x4 acc0[NT], acc1[NT];  // two accumulation chains per tile (dependent MFMA latency 40 > issue 32)
+    uint2 colq[NT];            // tile-local ids of transcripts 16 mt + 4 q + (0..3) of the current run, 16 bit each
+    float xq[NS];              // x[c_{4 step + q}][tt] of the current run
 #pragma unroll
-    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
-
-    // this lane's (t, k) pairs: pair p = lane + 64*j  ->  t = p / K, k = p % K
-    int pt[NSET], pk[NSET], mycol[NSET];
-    int pc[WMAXR];  // wave-uniform tile-local transcript ids of the current run
-    float acc[NSET];
-#pragma unroll
-    for (int j = 0; j < NSET; ++j) {
-        const int p = lane + 64 * j;
-        pt[j] = p / K;
-        pk[j] = p - pt[j] * K;
-        mycol[j] = 0;
-        acc[j] = 0.0f;
+    for (int mt = 0; mt < NT; ++mt) {
+        acc0[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        colq[mt] = make_uint2(0u, 0u);
     }
-    int pend_pairs = 0;  // w * K of the current run (0: no run open)
+#pragma unroll
+    for (int st = 0; st < NS; ++st) xq[st] = 0.0f;
+    int pend_w = 0;  // transcripts of the current run (0: no run open)
     auto flush = [&]() {
 #pragma unroll
-        for (int j = 0; j < NSET; ++j) {
-            if (64 * j < pend_pairs) {
-                if (lane + 64 * j < pend_pairs && acc[j] != 0.0f) atomicAdd(gw + mycol[j] * K + pk[j], acc[j]);
-                acc[j] = 0.0f;
+        for (int mt = 0; mt < NT; ++mt) {
+            if (16 * mt < pend_w) {
+                const f32x4 sum = acc0[mt] + acc1[mt];
+                const unsigned cid[4] = {colq[mt].x & 0xffffu, colq[mt].x >> 16, colq[mt].y & 0xffffu, colq[mt].y >> 16};
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (tt < K && 16 * mt + 4 * q + v < pend_w && sum[v] != 0.0f)
+                        atomicAdd(gw + cid[v] * K + tt, sum[v]);
+                acc0[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        pend_pairs = 0;
+        pend_w = 0;
     };
 
     uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
@@ -583,95 +602,97 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
                 a = a >= RB ? a - RB : a;
             return ring + a;
         };
-        const int npairs = w * K;
-        if (pend_pairs != 0 && !(flags & 2)) flush();
-        if (pend_pairs == 0) {  // a new run: look up the tile-local ids of its transcripts (loads batched)
+        if (pend_w != 0 && !(flags & 2)) flush();
+        if (pend_w == 0) {  // a new run: the tile-local ids of its transcripts and their x rows
 #pragma unroll
-            for (int j = 0; j < NSET; ++j)
-                if (lane + 64 * j < npairs)
-                    mycol[j] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)pt[j] * 2u));
-            // the header as one dword per lane (two ids each); the wave-uniform copies come out with v_readlane
-            const int hd = *reinterpret_cast<const int *>(ring_at((uint32_t)(lane & 63) * 4u));
+            for (int mt = 0; mt < NT; ++mt)
+                colq[mt] = *reinterpret_cast<const uint2 *>(ring_at((uint32_t)(32 * mt + 8 * q)));
+            int cl[NS];
 #pragma unroll
-            for (int t = 0; t < WMAXR; ++t) {
-                const int two = __builtin_amdgcn_readlane(hd, t >> 1);
-                pc[t] = t < w ? ((t & 1) ? (int)((unsigned)two >> 16) : (two & 0xffff)) : 0;
+            for (int st = 0; st < NS; ++st)
+                cl[st] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)(2 * min(4 * st + q, w - 1))));
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const float xv = xw[cl[st] * K + min(tt, K - 1)];
+                xq[st] = (tt < K && 4 * st + q < w) ? xv : 0.0f;
             }
         }
 
         STAMP(3);  // run change: flush + column lookup
-        // phase 1 (lane = fragment): row sums s[k] = sum_t V[lane][t] x[c_t][k] (x rows: uniform LDS reads),
-        // four transcripts per step so that the LDS reads of a step are in flight together
-        float sacc[K];
+        // operand reads of both phases, issued together
+        f32x4 av1[NS], av2[NT][4];
 #pragma unroll
-        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        for (int st = 0; st < NS; ++st) {
+            if (4 * st < w) {
+                const int t = min(4 * st + q, w - 1);  // rows >= w: B is 0 there, A only has to be finite
+                av1[st] = *reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)t * 256u) + ((tt + t) & 15) * 16);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            if (16 * mt < w) {
+                const int t = 16 * mt + tt;  // rows t >= w read whatever follows in the ring: their D2 rows are never used
+                const char *vrow = ring_at(256u + (uint32_t)t * 256u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av2[mt][j] = *reinterpret_cast<const f32x4 *>(vrow + ((4 * q + j + t) & 15) * 16);
+            }
+        }
+        // phase 1
+        f32x4 d1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(dbg & 4)) {
 #pragma unroll
-            for (int t0 = 0; t0 < WMAXR; t0 += 4) {
-                if (t0 < w) {
-                    float v[4];
+            for (int st = 0; st < NS; ++st) {
+                if (4 * st < w) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int t = t0 + u;
-                        v[u] = 0.0f;
-                        if (t < WMAXR) {
-                            const float vv = *reinterpret_cast<const float *>(ring_at(256u + (uint32_t)min(t, w - 1) * 256u + lane * 4u));
-                            v[u] = t < w ? vv : 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (t0 + u < WMAXR) fma_row<K>(v[u], xw + pc[t0 + u] * K, sacc);
+                    for (int e = 0; e < 4; ++e)
+                        d1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[st][e], xq[st], d1[e], 0, 0, 0);
                 }
             }
         }
-        // (with multiplicities this is the one compiler-visible load of the loop: the factored likelihood
-        // pays a vmcnt(0) per slice -- acceptable for the secondary variant)
-        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
+        // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt
+        if (HAS_KS) {
+            // (with multiplicities these are the compiler-visible loads of the loop: the factored likelihood pays a
+            // vmcnt(0) per slice -- acceptable for the secondary variant)
+            const f32x4 *kp = reinterpret_cast<const f32x4 *>(slice_ks + (size_t)s * 64 + 16 * q);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            wbuf[k * 64 + lane] = fast_weight(ksv, sacc[k]);
-            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 kv = kp[v];  // ks of fragments 16 q + 4 v + (0..3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sv = d1[e][v];
+                    if (WANT_LP && sv > 0.0f) lpacc += (double)kv[e] * log((double)sv);
+                    d1[e][v] = fast_weight(kv[e], sv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float sv = d1[e][v];
+                    if (WANT_LP && sv > 0.0f) lpacc += log((double)sv);
+                    d1[e][v] = fast_weight(1.0f, sv);
+                }
         }
 
         STAMP(4);  // phase 1
-        // phase 2 (lane = (t, k) pair): G[t][k] += sum_r V[t][r] W[k][r], 4 fragments per LDS read; lanes start
-        // at different 16-byte slots so that the 16 lanes of an LDS read group hit 16 different bank groups
         if (!(dbg & 2)) {
 #pragma unroll
-            for (int j = 0; j < NSET; ++j) {
-                if (64 * j < npairs) {
-                    if (lane + 64 * j < npairs) {
-                        const char *vrow = ring_at(256u + (uint32_t)pt[j] * 256u);
-                        const char *wrow = reinterpret_cast<const char *>(wbuf + pk[j] * 64);
-                        float a0 = 0.f, a1 = 0.f;
-                        // 16 steps of 4 fragments; the LDS reads of 8 steps are issued together (LDS latency is the
-                        // cost of this loop, not its bandwidth)
+            for (int mt = 0; mt < NT; ++mt) {
+                if (16 * mt < w) {
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            float4 a[8], b[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const int slot = ((half * 8 + u + lane) & 15) * 16;
-                                a[u] = *reinterpret_cast<const float4 *>(vrow + slot);
-                                b[u] = *reinterpret_cast<const float4 *>(wrow + slot);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                a0 = fmaf(a[u].x, b[u].x, a0);
-                                a1 = fmaf(a[u].y, b[u].y, a1);
-                                a0 = fmaf(a[u].z, b[u].z, a0);
-                                a1 = fmaf(a[u].w, b[u].w, a1);
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // 16 DS reads ...
-                            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // ... then their 16 packed FMAs
-                        }
-                        acc[j] += a0 + a1;
+                    for (int j = 0; j < 4; ++j) {
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][0], d1[0][j], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][1], d1[1][j], acc1[mt], 0, 0, 0);
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][2], d1[2][j], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][3], d1[3][j], acc1[mt], 0, 0, 0);
                     }
                 }
             }
         }
-        pend_pairs = npairs;
+        pend_w = w;
         STAMP(5);  // phase 2
 
         // the slice is consumed: refill the ring behind it
@@ -681,7 +702,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         refill(min(npieces, (int)(pos >> 10) + RP));
         STAMP(6);  // refill
     }
-    if (pend_pairs != 0) flush();
+    if (pend_w != 0) flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(7);  // final flush
     __syncthreads();
@@ -693,16 +714,11 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
             if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
         }
     if (WANT_LP) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double v = lpacc[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-            if (lane == 0) lp_red[wave] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) atomicAdd(lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
-            __syncthreads();
-        }
+        // lane (tt, q) holds the share of draw tt: sum the four q, then one f64 atomic per wave and draw
+        double v = lpacc;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < K) atomicAdd(lp + lane, v);
     }
 #ifdef POLEE_STAMPS
     STAMP(9);  // global flush
@@ -723,7 +739,7 @@ extern "C" int polee_debug_read_stamps(unsigned long long *out)
 }
 #endif
 
-// LDS layout of the fused kernel: [32 KiB rings][4 W buffers: K*64 floats][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
+// LDS layout of the fused kernel: [32 KiB rings][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
 constexpr uint32_t FUSED_RING_TOTAL = 32768u;
 
 // The whole likelihood pass as ONE launch with three kinds of workgroups (block index ranges), so that the
@@ -739,8 +755,7 @@ void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int n
 {
     extern __shared__ float lds[];
     const char *rings = reinterpret_cast<const char *>(lds);
-    float *wbufs = lds + FUSED_RING_TOTAL / 4;
-    float *xw = wbufs + 4 * K * 64;
+    float *xw = lds + FUSED_RING_TOTAL / 4;
     float *gw = xw + (size_t)A.lcap * K;
     double *lp_red = reinterpret_cast<double *>(gw + (size_t)((A.lcap * K + 1) & ~1));
     // The three kinds are interleaved over the grid (stream B and A2 workgroups are latency-bound chains of
@@ -761,10 +776,10 @@ void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int n
     const int span2 = max(max(rest - rest / 8, nb_a2), 1);
     const int na2 = before(r, nb_a2, span2);
     if (before(r + 1, nb_a2, span2) > na2) {
-        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, wbufs, xw, gw,
+        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, xw, gw,
                                                                          lp_red);
     } else {
-        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, wbufs, xw, gw, lp_red);
+        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, xw, gw, lp_red);
     }
 }
 
@@ -784,7 +799,7 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
     static_assert(PSELL_TILE_SLICES_B * 64 * PSELL_MAX_K * 4 <= (int)FUSED_RING_TOTAL, "stream-B weight rows must fit the ring area");
     static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
-    const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)4 * K * 64 + (size_t)2 * lcap * K + 2) * sizeof(float) +
+    const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);

@@ -40,8 +40,8 @@ constexpr int PSELL_TILE_SLICES_A2 = 8;
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
-constexpr int PSELL_NARROW_MAX = 18;        // widest transcript set of stream A1 (8 KiB LDS ring)
-constexpr int PSELL_WIDE_MAX = 28;          // widest transcript set of stream A2 (12 KiB LDS ring)
+constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (8 KiB LDS ring, one 16-row MFMA tile)
+constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (16 KiB LDS ring, two MFMA tiles)
 constexpr int PSELL_VCOL_CAP = 32;         // stream B: entries per virtual column (lane) of the transposed copy
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 

@@ -156,7 +156,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         const size_t base = out.data.size();
         if (cur_stream < 2) {
             // uniform streams: the 64 fragments share one transcript set, so the column ids are stored once:
-            //   uint16 lcol[128] (256-byte header, w used) ; float val[w][64]
+            //   uint16 lcol[128] (256-byte header, w used) ; float val[w][64] (rows rotated, see below)
             out.data.resize(base + 256 + (size_t)w * 256, 0);
             uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
             float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
@@ -164,7 +164,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (uint32_t t = 0; t < w; ++t) hdr[t] = col_local[col[b0 + t]];
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
                 const uint64_t b = rowptr[slice_rows[lane]];
-                for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + lane] = val[b + t];
+                // element r of row t sits at position (r + 4 t) & 63: bank-conflict-free operand reads for the MFMA phase
+                for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[b + t];
             }
         } else {
             // mixed stream: float val[w][64]; uint16 lcol[w][64], padded to a multiple of 256 bytes

@@ -179,7 +179,9 @@ def _emulate_psell(ps, x, n):
                 assert ps["slice_flags"][s] & 1
                 hdr = data[off:off + 256].view(np.uint16)[:w].astype(np.int64)
                 cols = np.repeat(hdr[:, None], 64, axis=1)
-                vals = data[off + 256:off + 256 + w * 256].view(np.float32).reshape(w, 64)
+                rot = data[off + 256:off + 256 + w * 256].view(np.float32).reshape(w, 64)
+                # element r of row t is stored at position (r + 4 t) & 63
+                vals = np.stack([rot[tt][(np.arange(64) + 4 * tt) & 63] for tt in range(w)]) if w else rot
             else:
                 w = nbytes // 384
                 vals = data[off:off + w * 256].view(np.float32).reshape(w, 64)
