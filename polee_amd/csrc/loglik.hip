@@ -740,7 +740,13 @@ extern "C" int polee_debug_read_stamps(unsigned long long *out)
 #endif
 
 // LDS layout of the fused kernel: [32 KiB rings][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
-constexpr uint32_t FUSED_RING_TOTAL = 32768u;
+constexpr uint32_t FUSED_RINGS = 24576u;  // 4 x 6 KiB (A1) or 2 x 12 KiB (A2)
+// the ring area also holds stream B's weight rows (16 slices x 64 fragments x K draws)
+template <int K>
+constexpr uint32_t fused_ring_total()
+{
+    return PSELL_TILE_SLICES_B * 64 * K * 4 > (int)FUSED_RINGS ? (uint32_t)(PSELL_TILE_SLICES_B * 64 * K * 4) : FUSED_RINGS;
+}
 
 // The whole likelihood pass as ONE launch with three kinds of workgroups (block index ranges), so that the
 // three streams of X share the machine without cross-stream events:
@@ -750,12 +756,12 @@ constexpr uint32_t FUSED_RING_TOTAL = 32768u;
 // LDS (53 KiB) lets 3 workgroups share a CU; the backend is told so that it can keep LDS reads in flight
 // rather than minimise VGPRs.
 template <int K, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int nb_a2, int dbg)
 {
     extern __shared__ float lds[];
     const char *rings = reinterpret_cast<const char *>(lds);
-    float *xw = lds + FUSED_RING_TOTAL / 4;
+    float *xw = lds + fused_ring_total<K>() / 4;
     float *gw = xw + (size_t)A.lcap * K;
     double *lp_red = reinterpret_cast<double *>(gw + (size_t)((A.lcap * K + 1) & ~1));
     // The three kinds are interleaved over the grid (stream B and A2 workgroups are latency-bound chains of
@@ -776,10 +782,10 @@ void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int n
     const int span2 = max(max(rest - rest / 8, nb_a2), 1);
     const int na2 = before(r, nb_a2, span2);
     if (before(r + 1, nb_a2, span2) > na2) {
-        uniform_tile_body<K, 16384u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, xw, gw,
+        uniform_tile_body<K, 12288u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, xw, gw,
                                                                          lp_red);
     } else {
-        uniform_tile_body<K, 8192u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, xw, gw, lp_red);
+        uniform_tile_body<K, 6144u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, xw, gw, lp_red);
     }
 }
 
@@ -796,10 +802,9 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
                       ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a,
                       ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p};
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
-    static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 8 * 1024, "A1 slices must fit an 8 KiB ring");
-    static_assert(PSELL_TILE_SLICES_B * 64 * PSELL_MAX_K * 4 <= (int)FUSED_RING_TOTAL, "stream-B weight rows must fit the ring area");
-    static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 16 * 1024, "A2 slices must fit a 16 KiB ring");
-    const size_t lds = (size_t)FUSED_RING_TOTAL + ((size_t)2 * lcap * K + 2) * sizeof(float) +
+    static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 6 * 1024, "A1 slices must fit a 6 KiB ring");
+    static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 12 * 1024, "A2 slices must fit a 12 KiB ring");
+    const size_t lds = (size_t)fused_ring_total<K>() + ((size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
