@@ -843,11 +843,12 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
 {
     polee_ctx *ctx = ll->ctx;
     if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
-    hipEvent_t e0 = nullptr, e1 = nullptr, p0 = nullptr, p1 = nullptr;
+    // (the pass is a single launch: one pair of events brackets both the kernel and the pass)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ll->profile) {
-        if (ll->prof_used + 4 > ll->prof_events.size()) {
+        if (ll->prof_used + 2 > ll->prof_events.size()) {
             if (ll->prof_events.size() >= 8192) POLEE_TRY(ll->profile_collect());
-            while (ll->prof_used + 4 > ll->prof_events.size()) {
+            while (ll->prof_used + 2 > ll->prof_events.size()) {
                 hipEvent_t a;
                 POLEE_HIP_TRY(ctx, hipEventCreate(&a));
                 ll->prof_events.push_back(a);
@@ -855,10 +856,7 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         }
         e0 = ll->prof_events[ll->prof_used];
         e1 = ll->prof_events[ll->prof_used + 1];
-        p0 = ll->prof_events[ll->prof_used + 2];
-        p1 = ll->prof_events[ll->prof_used + 3];
-        ll->prof_used += 4;
-        POLEE_HIP_TRY(ctx, hipEventRecord(p0, ctx->stream));
+        ll->prof_used += 2;
     }
     ll->cur_e0 = e0;
     ll->cur_e1 = e1;
@@ -874,7 +872,6 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         case 8: e = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
     if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "likelihood kernel launch failed: %s", hipGetErrorString(e));
-    if (p1) POLEE_HIP_TRY(ctx, hipEventRecord(p1, ctx->stream));
     return POLEE_OK;
 }
 
@@ -947,11 +944,10 @@ polee_status polee_loglik::profile_collect()
 {
     if (prof_used == 0) return POLEE_OK;
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i + 3 < prof_used; i += 4) {
+    for (size_t i = 0; i + 1 < prof_used; i += 2) {
         float ms = 0.f;
         POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
         prof_ms_total += ms;
-        POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i + 2], prof_events[i + 3]));
         prof_pass_ms_total += ms;
         ++prof_launches;
     }

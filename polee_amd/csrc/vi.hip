@@ -154,6 +154,7 @@ struct polee_vi {
     polee_vi_opts o;
     int32_t n = 0, K = 0;
     int32_t step = 0;  // steps completed
+    int32_t ahead_step = 0;  // iteration whose draws (ys, lyy) are already on the device; 0 = none
     int32_t trace_cap = 0;
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
@@ -186,7 +187,8 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
 
     // sample
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_ladj_el.p, 0, sizeof(double) * K * 2, st));
-    if (nm1 > 0) {
+    // (skipped when the previous update already drew this step's samples, see below)
+    if (nm1 > 0 && (vi->ahead_step != step_num || want_values)) {
         hipLaunchKernelGGL((vi_sample_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st,
                            vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, noise, step_num, o.y_eps, vi->d_ys.p, vi->d_lyy.p,
                            want_values ? vi->d_ladj_el.p : nullptr);
@@ -238,12 +240,17 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         a.max_omega = o.max_omega_step;
         a.max_alpha = o.max_alpha_step;
         a.first = step_num == 1;
+        // the update also draws the next iteration's samples (one launch and one pass over the parameters less),
+        // unless the caller's noise table ends here
+        const bool sample_next = apply && !(o.z0 && step_num + 1 > o.num_steps);
         hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
                            vi->d_ys.p, vi->d_C.p, noise, step_num, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p,
                            vi->d_vm.p, vi->d_mo.p, vi->d_vo.p, vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p,
                            hook_outputs ? vi->d_ygrad.p : nullptr, hook_outputs ? vi->d_mug.p : nullptr,
-                           hook_outputs ? vi->d_omg.p : nullptr, hook_outputs ? vi->d_alg.p : nullptr);
+                           hook_outputs ? vi->d_omg.p : nullptr, hook_outputs ? vi->d_alg.p : nullptr,
+                           sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p);
         POLEE_KERNEL_CHECK(ctx);
+        vi->ahead_step = apply ? (sample_next ? step_num + 1 : 0) : step_num;
     }
     if (want_values && apply && vi->step < vi->trace_cap) {
         hipLaunchKernelGGL(vi_trace_kernel, dim3(1), dim3(64), 0, st, vi->d_lp.p, vi->d_ladj_el.p, vi->d_rows.p, K,
@@ -459,6 +466,7 @@ polee_status polee_vi_set_params(polee_vi *vi, const float *mu, const float *ome
     if (mu) POLEE_TRY(vi->d_mu.upload(ctx, mu, nm1));
     if (omega) POLEE_TRY(vi->d_omega.upload(ctx, omega, nm1));
     if (alpha) POLEE_TRY(vi->d_alpha.upload(ctx, alpha, nm1));
+    vi->ahead_step = 0;  // draws made from the old parameters are stale
     return POLEE_OK;
 }
 

@@ -112,6 +112,30 @@ __device__ inline float sinh_asinh(float sa, float ca, float z0) { return fmaf(s
 // sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform! (logitnormal.jl:8-20) ->
 // clamp!(ys, eps, 1-eps) (likelihood-approximation.jl:523).  ys [n-1][K]; lyy [n-1][2][K]: [0] = log(1-y)
 // (right edge), [1] = log y (left edge).  ladj_out [K][2] = (skew, logit-normal) sums when non-null.
+// one node's K draws (shared by the sample kernel and the update kernel's look-ahead)
+template <int K, typename Noise>
+__device__ inline void sample_node(float m, float om, float al, const Noise &noise, int step, int64_t k, double y_eps,
+                                   double *__restrict__ ys, double *__restrict__ lyy, double *lsum)
+{
+    const float sigma = expf(om);
+    const float sa = sinhf(al), ca = coshf(al);
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const float z0 = noise.get(step, d, k);
+        const float zs = sinh_asinh(sa, ca, z0);
+        double y = (double)(1.0f / (1.0f + expf(-(m + zs * sigma))));
+        if (lsum) {
+            // log cosh(c) - 0.5 log1p(z0^2) with cosh(c) = sqrt(1 + sinh(c)^2)
+            lsum[d] = 0.5 * (double)log1pf(zs * zs) - 0.5 * (double)log1pf(z0 * z0);
+            lsum[K + d] = log((double)sigma * y * (1 - y));
+        }
+        y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
+        ys[k * K + d] = y;
+        lyy[(k * 2 + 0) * K + d] = log1p(-y);
+        lyy[(k * 2 + 1) * K + d] = log(y);
+    }
+}
+
 template <int K, typename Noise>
 __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restrict__ mu, const float *__restrict__ omega,
                                                          const float *__restrict__ alpha, Noise noise, int step,
@@ -123,25 +147,8 @@ __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restric
     double lsum[2 * K];
 #pragma unroll
     for (int d = 0; d < 2 * K; ++d) lsum[d] = 0.0;
-    if (k < noise.nm1) {
-        const float al = alpha[k], sigma = expf(omega[k]), m = mu[k];
-        const float sa = sinhf(al), ca = coshf(al);
-#pragma unroll
-        for (int d = 0; d < K; ++d) {
-            const float z0 = noise.get(step, d, k);
-            const float zs = sinh_asinh(sa, ca, z0);
-            double y = (double)(1.0f / (1.0f + expf(-(m + zs * sigma))));
-            if (ladj_out) {
-                // log cosh(c) - 0.5 log1p(z0^2) with cosh(c) = sqrt(1 + sinh(c)^2)
-                lsum[d] = 0.5 * (double)log1pf(zs * zs) - 0.5 * (double)log1pf(z0 * z0);
-                lsum[K + d] = log((double)sigma * y * (1 - y));
-            }
-            y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
-            ys[k * K + d] = y;
-            lyy[(k * 2 + 0) * K + d] = log1p(-y);
-            lyy[(k * 2 + 1) * K + d] = log(y);
-        }
-    }
+    if (k < noise.nm1)
+        sample_node<K, Noise>(mu[k], omega[k], alpha[k], noise, step, k, y_eps, ys, lyy, ladj_out ? lsum : nullptr);
     if (ladj_out) {
         block_sum_vec<2 * K>(lsum, smem);
 #pragma unroll
@@ -373,13 +380,13 @@ __device__ inline void adam_one(float &p, float &m, float &v, float grad, const 
 //   sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38) with cosh(c) = sqrt(1+zs^2), tanh(c) = zs/cosh(c),
 //   omega_grad += sigma * sigma_grad (likelihood-approximation.jl:547-549), / K (:552-557), ADAM.
 template <int K, typename Noise>
-__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const double *__restrict__ ys,
-                                                         const dd *__restrict__ C, Noise noise, int step,
+__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys, const dd *__restrict__ C, Noise noise,
+                                                         int step,
                                                          float *mu, float *omega, float *alpha, float *m_mu, float *v_mu,
                                                          float *m_omega, float *v_omega, float *m_alpha, float *v_alpha,
                                                          AdamConsts adam, int apply, int *nonfinite_step,
                                                          double *y_grad_out, float *mu_grad_out, float *omega_grad_out,
-                                                         float *alpha_grad_out)
+                                                         float *alpha_grad_out, int sample_next, double y_eps, double *lyy)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nm1 = v.n - 1;
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
     const float sigma = expf(omk), sa = sinhf(alk), ca = coshf(alk);
     const dd *Clo = C + (size_t)lo * K, *Cmid = C + (size_t)mid * K, *Chi = C + (size_t)hi1 * K;
     float mu_g = 0.f, om_g = 0.f, al_g = 0.f;
+    float p_mu = muk, p_om = omk, p_al = alk;
 #pragma unroll
     for (int d = 0; d < K; ++d) {
         const dd cm = Cmid[d];
@@ -424,13 +432,19 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
         float p = muk, mm = m_mu[k], vv = v_mu[k];
         adam_one(p, mm, vv, mu_g, adam, adam.max_mu);
         mu[k] = p; m_mu[k] = mm; v_mu[k] = vv;
+        p_mu = p;
         p = omk; mm = m_omega[k]; vv = v_omega[k];
         adam_one(p, mm, vv, om_g, adam, adam.max_omega);
         omega[k] = p; m_omega[k] = mm; v_omega[k] = vv;
+        p_om = p;
         p = alk; mm = m_alpha[k]; vv = v_alpha[k];
         adam_one(p, mm, vv, al_g, adam, adam.max_alpha);
         alpha[k] = p; m_alpha[k] = mm; v_alpha[k] = vv;
+        p_al = p;
     }
+    // look-ahead: the next iteration's draws from the parameters just written (this thread is the only one that
+    // touches node k's ys / lyy, and its reads of ys[k] are done)
+    if (sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, step + 1, k, y_eps, ys, lyy, nullptr);
 }
 
 // ---- point optimisation (OptimizePTTApprox, likelihood-approximation.jl:149-242), K = 1 ------------------
