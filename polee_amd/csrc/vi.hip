@@ -195,15 +195,17 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         POLEE_KERNEL_CHECK(ctx);
     }
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
+    // (up to 2048 chunks every apply workgroup sums the totals of the chunks before it itself: no spine launch)
+    const int own_f = nch_f <= 2048, own_b = nch_b <= 2048;
     if (nch_f > 1) {
         hipLaunchKernelGGL((vi_fwd_reduce_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
-        hipLaunchKernelGGL((scan_spine_kernel<VK<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
+        if (!own_f) hipLaunchKernelGGL((scan_spine_kernel<VK<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
     } else {
         POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
     }
     hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                        vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr);
+                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
@@ -211,9 +213,9 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // backward: double-double prefix over leaves of u * (g - efflen term)
     hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
                        eff, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
-    hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
+    if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
     hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
-                       eff, vi->d_csum.p, chunk_b, vi->d_C.p);
+                       eff, vi->d_csum.p, chunk_b, vi->d_C.p, own_b);
     POLEE_KERNEL_CHECK(ctx);
     if (want_values) {
         hipLaunchKernelGGL((vi_values_finish_kernel<K>), dim3(1), dim3(256), 0, st, vi->d_part_ladj.p, nch_f,
@@ -595,7 +597,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         }
         hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                           vi->d_part_c.p, (double *)nullptr);
+                           vi->d_part_c.p, (double *)nullptr, 0);
         POLEE_KERNEL_CHECK(ctx);
         return POLEE_OK;
     };
@@ -608,7 +610,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
                            vi->d_g.p, vi->d_efflens.p, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
         hipLaunchKernelGGL((scan_spine_kernel<VD<1>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
         hipLaunchKernelGGL((vi_bwd_apply_kernel<1>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p,
-                           vi->d_g.p, vi->d_efflens.p, vi->d_csum.p, chunk_b, vi->d_C.p);
+                           vi->d_g.p, vi->d_efflens.p, vi->d_csum.p, chunk_b, vi->d_C.p, 0);
         AdamConsts a;
         a.lr = std::max(o.adam_min_learning_rate,
                         o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));

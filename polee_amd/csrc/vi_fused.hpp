@@ -176,6 +176,18 @@ __device__ inline VK<K> tour_value(uint32_t code, const double *__restrict__ lyy
     return val;
 }
 
+// Sum of the totals of the chunks before `chunk` (its exclusive offset), computed by the workgroup itself: with a
+// few hundred chunks this is cheaper than a separate single-workgroup spine launch between reduce and apply.
+template <typename T>
+__device__ inline T chunk_prefix(const T *__restrict__ chunk_sums, int chunk, T *smem)
+{
+    T acc = ScanOps<T>::zero();
+    for (int i = threadIdx.x; i < chunk; i += SCAN_THREADS) acc = ScanOps<T>::add(acc, chunk_sums[i]);
+    T tot;
+    (void)block_exclusive_scan<T>(acc, smem, &tot);
+    return tot;
+}
+
 template <int K>
 __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, const double *__restrict__ lyy,
                                                                     VK<K> *__restrict__ chunk_sums)
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                                                                    float *__restrict__ g,
                                                                    const float *__restrict__ efflens, float clamp_lo,
                                                                    float clamp_hi, double *__restrict__ part_c,
-                                                                   double *__restrict__ part_ladj)
+                                                                   double *__restrict__ part_ladj, int own_prefix)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
@@ -218,7 +230,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
     }
     VK<K> tot;
     VK<K> off = block_exclusive_scan<VK<K>>(acc, smem, &tot);
-    off = ScanOps<VK<K>>::add(chunk_offsets[blockIdx.x], off);
+    // chunk_offsets holds the chunks' exclusive offsets (after a spine pass) or, with own_prefix, their totals
+    off = ScanOps<VK<K>>::add(own_prefix ? chunk_prefix<VK<K>>(chunk_offsets, blockIdx.x, smem) : chunk_offsets[blockIdx.x], off);
     double pc[K], pl[K];
 #pragma unroll
     for (int d = 0; d < K; ++d) pc[d] = pl[d] = 0.0;
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
                                                                    const float *__restrict__ efflens,
                                                                    const double *__restrict__ csum,
                                                                    const VD<K> *__restrict__ chunk_offsets,
-                                                                   dd *__restrict__ C)
+                                                                   dd *__restrict__ C, int own_prefix)
 {
     __shared__ VD<K> smem[SCAN_THREADS / 64];
     double c[K];
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
     }
     VD<K> tot;
     VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
-    off = ScanOps<VD<K>>::add(chunk_offsets[blockIdx.x], off);
+    off = ScanOps<VD<K>>::add(own_prefix ? chunk_prefix<VD<K>>(chunk_offsets, blockIdx.x, smem) : chunk_offsets[blockIdx.x], off);
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         if (base + j < v.n) {

@@ -22,10 +22,10 @@ try:
     json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
 except Exception:
     pass
-dom = [k for k in s.get("pmc", {}) if "loglik_uniform_kernel<6, 8" in k or "loglik_uniform_kernel<6,8" in k]
+dom = [k for k in s.get("pmc", {}) if "loglik_fused_kernel<6" in k]
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), "",
          "Command: `tools/profile.sh %s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-steps 0`" % tag,
-         "plus separate `--pmc` passes (SQ / LDS / FETCH_SIZE / WRITE_SIZE).", "",
+         "plus separate `--pmc` passes (SQ / LDS / MFMA / FETCH_SIZE / WRITE_SIZE).", "",
          "| kernel | calls | avg µs | % of GPU time |", "|---|---|---|---|"]
 for r in s.get("kernel_stats", []):
     lines.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
@@ -43,6 +43,8 @@ if dom:
               "* LDS busy: %.0f %% (SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs)); bank-conflict cycles %.2f %% of LDS cycles" % (
                   100 * c.get("SQ_LDS_IDX_ACTIVE", 0) / max(cyc * 256, 1), 100 * c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1)),
               "* waves waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES): %.0f %%" % (100 * c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1)),
+              "* matrix-core busy: %.0f %% (SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)); %.1f M MFMA instructions" % (
+                  100 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(cyc * 1024, 1), c.get("SQ_INSTS_MFMA", 0) / 1e6),
               "* wave-level instructions: VALU %.1f M, LDS %.1f M, SALU %.1f M" % (c.get("SQ_INSTS_VALU", 0) / 1e6, c.get("SQ_INSTS_LDS", 0) / 1e6, c.get("SQ_INSTS_SALU", 0) / 1e6)]
 if bench:
     lines += ["", "bench.py line under the profiler (slower than an unprofiled run): `value` %.1f VI iters/s, dominant kernel %.3f ms" % (bench["value"], bench["roofline"]["kernel_ms_avg"])]
