@@ -619,35 +619,43 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         }
 
         STAMP(3);  // run change: flush + column lookup
-        // operand reads of both phases, issued together
-        f32x4 av1[NS], av2[NT][4];
+        // operand reads: for the narrow stream (one 16-row tile) both phases' reads are issued together up front;
+        // the wide stream reads per group of 4 steps / per tile, to stay inside the register budget
+        constexpr bool WIDE = NT > 1;
+        auto read_tile = [&](int mt, f32x4 (&dst)[4]) {
+            const int t = 16 * mt + tt;  // rows t >= w read whatever follows in the ring: their D2 rows are never used
+            const char *vrow = ring_at(256u + (uint32_t)t * 256u);
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            if (4 * st < w) {
-                const int t = min(4 * st + q, w - 1);  // rows >= w: B is 0 there, A only has to be finite
-                av1[st] = *reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)t * 256u) + ((tt + t) & 15) * 16);
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            if (16 * mt < w) {
-                const int t = 16 * mt + tt;  // rows t >= w read whatever follows in the ring: their D2 rows are never used
-                const char *vrow = ring_at(256u + (uint32_t)t * 256u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) av2[mt][j] = *reinterpret_cast<const f32x4 *>(vrow + ((4 * q + j + t) & 15) * 16);
-            }
-        }
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4 *>(vrow + ((4 * q + j + t) & 15) * 16);
+        };
+        f32x4 av2[4];
+        if (!WIDE) read_tile(0, av2);
         // phase 1
         f32x4 d1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) d1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(dbg & 4)) {
 #pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                if (4 * st < w) {
+            for (int g0 = 0; g0 < NS; g0 += 4) {
+                if (4 * g0 < w) {
+                    f32x4 av1[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        d1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[st][e], xq[st], d1[e], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = g0 + u;
+                        if (st < NS && 4 * st < w) {
+                            const int t = min(4 * st + q, w - 1);  // rows >= w: B is 0 there, A only has to be finite
+                            av1[u] = *reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)t * 256u) + ((tt + t) & 15) * 16);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = g0 + u;
+                        if (st < NS && 4 * st < w) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                d1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[u][e], xq[st], d1[e], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -682,12 +690,13 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
                 if (16 * mt < w) {
+                    if (WIDE) read_tile(mt, av2);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][0], d1[0][j], acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][1], d1[1][j], acc1[mt], 0, 0, 0);
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][2], d1[2][j], acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[mt][j][3], d1[3][j], acc1[mt], 0, 0, 0);
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][0], d1[0][j], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][1], d1[1][j], acc1[mt], 0, 0, 0);
+                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][2], d1[2][j], acc0[mt], 0, 0, 0);
+                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][3], d1[3][j], acc1[mt], 0, 0, 0);
                     }
                 }
             }
