@@ -155,6 +155,14 @@ polee_status polee_efflen_jacobian_adjustment(polee_ctx *ctx, const float *effle
                                               int32_t K, int64_t n, double *x_grad,
                                               float *xls_or_null);
 
+/* gene_noninformative_prior! (src/likelihood.jl:114-159), batched over K draws: gradient of the
+ * non-informative prior over gene-level expression.  gene_of int32[n] = gene index of each transcript
+ * (0-based, -1 = no gene known): the reference's Dict{gene id -> transcript indexes} as an array.
+ * xls f32 [K][n] is the output of polee_efflen_jacobian_adjustment; x_grad f64 [K][n] is updated. */
+polee_status polee_gene_noninformative_prior(polee_ctx *ctx, const float *efflens, const float *xls,
+                                             const float *xs, int32_t K, int64_t n, const int32_t *gene_of,
+                                             double *x_grad);
+
 /* ---- element-wise reparameterisations (standalone forms) --------------------------------
  * The Julia functions of src/logitnormal.jl:8-55, src/sinh_arcsinh.jl:10-38 and
  * src/kumaraswamy.jl:27-78 (inside the VI loop the first two are fused into the tree kernels).

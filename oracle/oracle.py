@@ -223,6 +223,18 @@ def effective_length_jacobian_adjustment(efflens, xs, x_grad):
     return xls, x_grad
 
 
+def gene_noninformative_prior(efflens, xls, xs, x_grad, gene_of):
+    """likelihood.jl:114-159; gene_of int32[n], -1 = no gene.  Returns the adjusted x_grad."""
+    efflens, xls, xs = _f32(efflens), _f32(xls), _f32(xs)
+    gene_of = np.ascontiguousarray(gene_of, np.int32)
+    x_grad = _f64(x_grad).copy()
+    f = lib().oracle_gene_noninformative_prior
+    f.restype = C.c_double
+    f(_p(efflens, c_f32p), _p(xls, c_f32p), _p(xs, c_f32p), _p(x_grad, c_f64p),
+      gene_of.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(xs.size), C.c_int64(int(gene_of.max(initial=-1)) + 1))
+    return x_grad
+
+
 def sinh_asinh_transform(alpha, zs0, compute_ladj=False):
     alpha, zs0 = _f32(alpha), _f32(zs0)
     zs = np.empty_like(zs0)

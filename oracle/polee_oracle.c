@@ -461,6 +461,38 @@ double oracle_effective_length_jacobian_adjustment(const float *efflens, const f
     return 0.0;
 }
 
+/* src/likelihood.jl:114-159 gene_noninformative_prior!: gradient only, returns 0.
+ * gene_of[i] = gene index of transcript i (0..num_genes-1) or -1 (no gene known); the reference's
+ * Dict{gene -> transcript indexes} in array form.  xls f32 (from the effective-length adjustment),
+ * xl_grad and x_grad f64 (likelihood-approximation.jl:449,468). */
+double oracle_gene_noninformative_prior(const float *efflens, const float *xls, const float *xs, double *x_grad,
+                                        const int32_t *gene_of, int64_t n, int64_t num_genes)
+{
+    double *c = (double *)calloc((size_t)(num_genes > 0 ? num_genes : 1), sizeof(double));
+    int64_t *k = (int64_t *)calloc((size_t)(num_genes > 0 ? num_genes : 1), sizeof(int64_t));
+    double *xl_grad = (double *)calloc((size_t)n, sizeof(double));
+    for (int64_t i = 0; i < n; ++i)
+        if (gene_of[i] >= 0) {
+            c[gene_of[i]] += (double)xls[i]; /* :126-128 */
+            k[gene_of[i]] += 1;
+        }
+    for (int64_t i = 0; i < n; ++i)
+        if (gene_of[i] >= 0 && k[gene_of[i]] > 1) xl_grad[i] = -(double)(k[gene_of[i]] - 1) / c[gene_of[i]]; /* :130-132 */
+    double x_scaled_sum = 0.0;
+    for (int64_t i = 0; i < n; ++i) x_scaled_sum += (double)(xs[i] / efflens[i]); /* :139-141, f32 quotient */
+    const double x_scaled_sum_sq = x_scaled_sum * x_scaled_sum;
+    double offdiag = 0.0;
+    for (int64_t i = 0; i < n; ++i) offdiag += -xl_grad[i] * (double)xls[i]; /* :145-147 */
+    offdiag /= x_scaled_sum_sq;
+    for (int64_t i = 0; i < n; ++i) {
+        const double grad_a = xl_grad[i] * ((double)(1 / efflens[i]) / x_scaled_sum); /* :151 */
+        const double grad_b = (double)(1 / efflens[i]) * offdiag;                      /* :152 */
+        x_grad[i] += grad_a + grad_b;
+    }
+    free(c); free(k); free(xl_grad);
+    return 0.0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* src/logitnormal.jl:2,4 */
 static inline float logistic_f32(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -259,6 +259,34 @@ def effective_length_jacobian_adjustment(efflens, xs, x_grad, ctx=None):
     return (xls[0], g[0]) if single else (xls, g)
 
 
+def gene_noninformative_prior(efflens, xls, xs, x_grad, gene_transcripts, ctx=None):
+    """gene_noninformative_prior! (likelihood.jl:114-159) -> adjusted x_grad.
+
+    `gene_transcripts` is the reference's Dict{gene id -> 1-based transcript indexes}
+    (likelihood-approximation.jl:476-487) or an int array gene_of[n] (0-based gene index, -1 = none)."""
+    ctx = ctx or default_context()
+    efflens, xs, xls = arr(efflens, np.float32), arr(xs, np.float32), arr(xls, np.float32)
+    single = xs.ndim == 1
+    xs2 = xs.reshape(1, -1) if single else xs
+    K, n = xs2.shape
+    if isinstance(gene_transcripts, dict):
+        gene_of = np.full(n, -1, np.int32)
+        for gi, idxs in enumerate(gene_transcripts.values()):
+            for i in idxs:
+                if not 1 <= i <= n:
+                    raise ValueError("transcript index %d out of range" % i)
+                gene_of[i - 1] = gi
+    else:
+        gene_of = arr(gene_transcripts, np.int32).reshape(-1)
+        if gene_of.size != n:
+            raise ValueError("gene_of must have one entry per transcript")
+    g = arr(x_grad, np.float64).reshape(K, n).copy()
+    check(L.lib().polee_gene_noninformative_prior(ctx._h, ptr(efflens, f32p), ptr(xls.reshape(K, n), f32p),
+                                                  ptr(xs2, f32p), K, C.c_int64(n), ptr(gene_of, L.i32p), ptr(g, f64p)),
+          ctx._h)
+    return g[0] if single else g
+
+
 def _vecs(dtype, *arrs):
     out = [arr(a, dtype).reshape(-1) for a in arrs]
     if len({a.size for a in out}) != 1:

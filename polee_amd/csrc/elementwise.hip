@@ -112,6 +112,56 @@ __global__ void kumaraswamy_grad_kernel(const float *zs, const float *as, const 
     b_grad[i] = bg;
 }
 
+// ---- gene-level non-informative prior (likelihood.jl:114-159), K draws at once -----------------------------
+// pass 1: per-gene sums c[g][k] = sum_{i in g} xls[k][i] and member counts; sum_i xs/efflen per draw
+__global__ void gene_prior_sums_kernel(const float *efflens, const float *xls, const float *xs, const int32_t *gene_of,
+                                       int64_t n, int K, double *gene_c, int *gene_k, double *xsum)
+{
+    __shared__ double smd[4];
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double q = 0.0;
+    if (i < n) {
+        const int g = gene_of[i];
+        if (g >= 0) {
+            atomicAdd(&gene_c[(size_t)g * K + k], (double)xls[(size_t)k * n + i]);
+            if (k == 0) atomicAdd(&gene_k[g], 1);
+        }
+        q = (double)(xs[(size_t)k * n + i] / efflens[i]);  // f32 quotient (:140)
+    }
+    q = block_sum_f64(q, smd);
+    if (threadIdx.x == 0) atomicAdd(&xsum[k], q);
+}
+// pass 2: offdiag[k] = sum_i -xl_grad_i * xls_i with xl_grad_i = -(k_g - 1) / c_g (:130-147)
+__global__ void gene_prior_offdiag_kernel(const float *xls, const int32_t *gene_of, int64_t n, int K,
+                                          const double *gene_c, const int *gene_k, double *offdiag)
+{
+    __shared__ double smd[4];
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double q = 0.0;
+    if (i < n) {
+        const int g = gene_of[i];
+        if (g >= 0 && gene_k[g] > 1) q = (double)(gene_k[g] - 1) / gene_c[(size_t)g * K + k] * (double)xls[(size_t)k * n + i];
+    }
+    q = block_sum_f64(q, smd);
+    if (threadIdx.x == 0) atomicAdd(&offdiag[k], q);
+}
+// pass 3: x_grad_i += xl_grad_i * (1/efflen_i) / xsum + (1/efflen_i) * offdiag / xsum^2 (:149-155)
+__global__ void gene_prior_apply_kernel(const float *efflens, const int32_t *gene_of, int64_t n, int K,
+                                        const double *gene_c, const int *gene_k, const double *xsum,
+                                        const double *offdiag, double *x_grad)
+{
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = gene_of[i];
+    const double xlg = (g >= 0 && gene_k[g] > 1) ? -(double)(gene_k[g] - 1) / gene_c[(size_t)g * K + k] : 0.0;
+    const double inv_l = (double)(1.0f / efflens[i]);
+    const double s = xsum[k];
+    x_grad[(size_t)k * n + i] += xlg * (inv_l / s) + inv_l * (offdiag[k] / (s * s));
+}
+
 }  // namespace polee
 
 using namespace polee;
@@ -251,6 +301,44 @@ polee_status polee_kumaraswamy_transform_gradients(polee_ctx *ctx, const float *
     POLEE_KERNEL_CHECK(ctx);
     POLEE_TRY(s.f[4].download(ctx, a_grad, len));
     return s.f[5].download(ctx, b_grad, len);
+}
+
+polee_status polee_gene_noninformative_prior(polee_ctx *ctx, const float *efflens, const float *xls, const float *xs,
+                                             int32_t K, int64_t n, const int32_t *gene_of, double *x_grad)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!efflens || !xls || !xs || !gene_of || !x_grad || K < 1 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    int32_t num_genes = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (gene_of[i] < -1) return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of[%lld] = %d", (long long)i, gene_of[i]);
+        num_genes = std::max(num_genes, gene_of[i] + 1);
+    }
+    if (num_genes == 0) return POLEE_OK;  // no gene information: nothing to add (likelihood-approximation.jl:489-492)
+    const size_t tot = (size_t)n * K;
+    DevBuf<float> d_l, d_xls, d_xs;
+    DevBuf<int32_t> d_gene;
+    DevBuf<int> d_k;
+    DevBuf<double> d_c, d_sums, d_g;
+    POLEE_TRY(d_l.upload(ctx, efflens, n));
+    POLEE_TRY(d_xls.upload(ctx, xls, tot));
+    POLEE_TRY(d_xs.upload(ctx, xs, tot));
+    POLEE_TRY(d_gene.upload(ctx, gene_of, n));
+    POLEE_TRY(d_g.upload(ctx, x_grad, tot));
+    POLEE_TRY(d_c.alloc(ctx, (size_t)num_genes * K));
+    POLEE_TRY(d_k.alloc(ctx, num_genes));
+    POLEE_TRY(d_sums.alloc(ctx, 2 * (size_t)K));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_c.p, 0, sizeof(double) * num_genes * K, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_k.p, 0, sizeof(int) * num_genes, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_sums.p, 0, sizeof(double) * 2 * K, ctx->stream));
+    const dim3 grid(blocks(n), (unsigned)K);
+    hipLaunchKernelGGL(gene_prior_sums_kernel, grid, dim3(256), 0, ctx->stream, d_l.p, d_xls.p, d_xs.p, d_gene.p, n, K,
+                       d_c.p, d_k.p, d_sums.p);
+    hipLaunchKernelGGL(gene_prior_offdiag_kernel, grid, dim3(256), 0, ctx->stream, d_xls.p, d_gene.p, n, K, d_c.p, d_k.p,
+                       d_sums.p + K);
+    hipLaunchKernelGGL(gene_prior_apply_kernel, grid, dim3(256), 0, ctx->stream, d_l.p, d_gene.p, n, K, d_c.p, d_k.p,
+                       d_sums.p, d_sums.p + K, d_g.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return d_g.download(ctx, x_grad, tot);
 }
 
 }  // extern "C"

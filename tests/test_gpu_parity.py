@@ -248,6 +248,33 @@ def test_efflen_jacobian(P, ctx, lm_fixture):
         np.testing.assert_allclose(xls[k], xo, rtol=2e-6)
 
 
+def test_gene_noninformative_prior(P, ctx, lm_fixture):
+    """gene_noninformative_prior! (likelihood.jl:114-159) on top of the effective-length adjustment."""
+    rng = np.random.default_rng(6)
+    n = lm_fixture["n"]
+    x = rng.dirichlet(np.ones(n), size=3).astype(np.float32)
+    l = lm_fixture["effective_lengths"]
+    g0 = rng.normal(size=(3, n))
+    gene_of = rng.integers(0, n // 3, size=n).astype(np.int32)
+    gene_of[rng.random(n) < 0.1] = -1  # transcripts without a known gene
+    xls, g1 = P.effective_length_jacobian_adjustment(l, x, g0, ctx=ctx)
+    g2 = P.gene_noninformative_prior(l, xls, x, g1, gene_of, ctx=ctx)
+    for k in range(3):
+        go = O.gene_noninformative_prior(l, xls[k], x[k], g1[k], gene_of)
+        np.testing.assert_allclose(g2[k], go, rtol=1e-9, atol=1e-9 * np.abs(go).max())
+        assert np.abs(g2[k] - g1[k]).max() > 0  # the prior does contribute
+    # the reference's Dict form (1-based transcript indexes), single vector
+    d = {}
+    for i, gi in enumerate(gene_of):
+        if gi >= 0:
+            d.setdefault("g%d" % gi, []).append(i + 1)
+    g3 = P.gene_noninformative_prior(l, xls[0], x[0], g1[0], d, ctx=ctx)
+    np.testing.assert_allclose(g3, g2[0], rtol=1e-12)
+    # no gene information at all: unchanged
+    g4 = P.gene_noninformative_prior(l, xls[0], x[0], g1[0], np.full(n, -1, np.int32), ctx=ctx)
+    np.testing.assert_array_equal(g4, g1[0])
+
+
 @pytest.mark.parametrize("use_efflen", [True, False])
 def test_vi_single_step_gradients_match_oracle(P, ctx, lm_fixture, prep_fixture, use_efflen):
     """One VI iteration's K draws at the reference's own fitted parameters, device RNG noise

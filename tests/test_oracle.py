@@ -381,3 +381,31 @@ def test_optimize_ptt_climbs_the_likelihood(lm_fixture):
     assert abs(xs.astype(np.float64).sum() - 1) < 1e-3
     lp, _ = s.log_likelihood(xs)
     assert -327600 < lp < -326990, lp
+
+
+def test_gene_noninformative_prior_follows_the_reference_lines():
+    """likelihood.jl:114-159 restated in NumPy f64.  Note the reference's chain rule uses the NORMALISED xls in the
+    off-diagonal sum (:146), i.e. that term is 1/sum(x/l) times the exact derivative of
+    -sum_g (k_g - 1) log(sum_{i in g} xl_i); the oracle keeps what the reference computes."""
+    rng = np.random.default_rng(3)
+    n = 40
+    l = rng.uniform(200, 3000, n).astype(np.float32)
+    x = rng.dirichlet(np.ones(n)).astype(np.float32)
+    gene_of = rng.integers(0, 9, n).astype(np.int32)
+    gene_of[:3] = -1
+    xls, _ = O.effective_length_jacobian_adjustment(l, x, np.zeros(n))
+    g0 = rng.normal(size=n)
+    got = O.gene_noninformative_prior(l, xls, x, g0, gene_of)
+    xl_grad = np.zeros(n)
+    for g in range(9):
+        idx = np.flatnonzero(gene_of == g)
+        if len(idx) > 1:
+            xl_grad[idx] = -(len(idx) - 1) / xls[idx].astype(np.float64).sum()
+    S = (x / l).astype(np.float64).sum()
+    offdiag = (-xl_grad * xls).sum() / S ** 2
+    inv_l = (np.float32(1) / l).astype(np.float64)
+    want = g0 + xl_grad * (inv_l / S) + inv_l * offdiag
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    # the diagonal term alone is the exact derivative at fixed normalisation: d/dx_j of -(k-1) log c_g with xl = (x/l)/S
+    j = int(np.flatnonzero(xl_grad != 0)[0])
+    assert np.isclose(xl_grad[j] * inv_l[j] / S, -(np.sum(gene_of == gene_of[j]) - 1) / xls[gene_of == gene_of[j]].sum() * inv_l[j] / S)
