@@ -104,3 +104,33 @@ def test_c2_vi_steps_are_finite_and_move_uphill(c2):
     assert np.isfinite(lp_mean).all() and lp_mean[-1] > lp_mean[0]  # ADAM ascent on the likelihood
     mu, om, al = fit.params()
     assert np.isfinite(mu).all() and np.isfinite(om).all() and np.isfinite(al).all()
+
+
+def test_c5_maximum_size_properties():
+    """BASELINE.json configs[4] (n=200 000 x m=150 000 000, ~1.2 G nnz: the largest single-GPU sample): every
+    non-zero is accounted for, Euler homogeneity holds for each draw, and the two independent kernels agree."""
+    import polee_amd as P
+    from polee_amd import _lib as L
+    from tools import synth
+    m5 = 150_000_000
+    smp = synth.make_sample(N, m5, NNZ_PER_FRAG, seed=987654321)
+    ctx = P.Context(0)
+    s = P.RNASeqSample(m5, N, None, None, None, smp["effective_lengths"], ctx=ctx,
+                       xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
+    info = s.info
+    assert info["nnz"] == smp["nnz"] and sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == m5
+    del smp
+    rng = np.random.default_rng(1)
+    K = 2
+    x = rng.gamma(0.3, size=(K, N)).astype(np.float32) + np.float32(1e-7)
+    x /= x.sum(axis=1, keepdims=True)
+    x = np.clip(x, np.float32(1e-10), 1)
+    lp, g = s.log_likelihood(x)
+    assert np.isfinite(lp).all() and (lp < 0).all()
+    for k in range(K):
+        assert abs(float(g[k] @ x[k].astype(np.float64)) - m5) < 2e-5 * m5
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 1))
+    lp2, g2 = s.log_likelihood(x)
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 0))
+    np.testing.assert_allclose(lp2, lp, rtol=1e-7)
+    np.testing.assert_allclose(g2, g, rtol=2e-4, atol=1e-6 * np.abs(g).max())
