@@ -262,6 +262,25 @@ polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens,
 polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *efflens, int32_t num_steps,
                                 float *xs, float *zs_or_null);
 
+/* ---- one sample over several GPUs -----------------------------------
+ * X's rows (fragments) are sharded over the ranks in contiguous blocks; every rank creates its
+ * polee_loglik from its block and runs the same polee_vi (same seed => identical state); per
+ * likelihood pass the partial gradients (K*n f32) and log-likelihoods are summed with one
+ * all-reduce over RCCL (bound at run time).  One rank calls polee_comm_unique_id and the caller
+ * distributes the 128 bytes (MPI, torch.distributed, a file ...). */
+typedef struct polee_comm polee_comm;
+#define POLEE_COMM_ID_BYTES 128
+polee_status polee_comm_unique_id(uint8_t id[POLEE_COMM_ID_BYTES]);
+polee_status polee_comm_create(polee_ctx *ctx, int32_t nranks, int32_t rank,
+                               const uint8_t id[POLEE_COMM_ID_BYTES], polee_comm **out);
+void polee_comm_destroy(polee_comm *comm);
+int32_t polee_comm_rank(const polee_comm *comm);
+int32_t polee_comm_size(const polee_comm *comm);
+/* sum over ranks of a host buffer (convenience; the VI loop reduces device buffers in place) */
+polee_status polee_allreduce_sum_f32(polee_comm *comm, float *buf, int64_t count);
+/* make `vi` a row-sharded fit: its likelihood handle holds this rank's block of rows */
+polee_status polee_vi_set_comm(polee_vi *vi, polee_comm *comm_or_null);
+
 /* ---- sampler ------------------------------------------------------------------------
  * rand!(::ApproxLikelihoodSampler) (src/approx-sampler.jl:37-44): draws x f32
  * [ndraws][n] from a fitted approximation.  z0 (optional host [ndraws][n-1]) replaces

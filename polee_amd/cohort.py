@@ -16,6 +16,34 @@ def shard_samples(num_samples, world_size, rank):
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
+def shard_rows(tcolptr, world_size, rank):
+    """Contiguous block [r0, r1) of fragments (rows of X) owned by `rank` when ONE sample is spread over
+    `world_size` GPUs, balanced on the number of non-zeros.  `tcolptr` = offsets of X in CSR form
+    (the `xt=` input of RNASeqSample), 0- or 1-based.  Rows are locus-sorted, so a block touches a compact
+    set of transcripts.  The likelihood and its gradient are sums over fragments: each rank evaluates its block
+    and ONE all-reduce per pass (polee_comm) completes them."""
+    import numpy as np
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    p = np.asarray(tcolptr).astype(np.int64)
+    p = p - p[0]
+    m, nnz = len(p) - 1, int(p[-1])
+    cuts = [int(np.searchsorted(p, (nnz * r) // world_size, side="left")) for r in range(world_size + 1)]
+    cuts[0], cuts[-1] = 0, m
+    for r in range(1, world_size + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def take_rows(tcolptr, trowval, tnzval, r0, r1):
+    """The CSR arrays of rows [r0, r1) with offsets rebased (same base as the input)."""
+    import numpy as np
+    p = np.asarray(tcolptr)
+    base = p[0]
+    lo, hi = int(p[r0] - base), int(p[r1] - base)
+    return (p[r0:r1 + 1] - p[r0] + base).astype(p.dtype), np.asarray(trowval)[lo:hi], np.asarray(tnzval)[lo:hi]
+
+
 def sample_seed(base_seed, sample_index):
     """Per-sample seed of the synthetic generator / device RNG: distinct streams per sample."""
     return (int(base_seed) + 7919 * int(sample_index)) & 0xFFFFFFFFFFFFFFFF

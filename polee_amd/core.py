@@ -374,12 +374,48 @@ class LogitSkewNormalPTTApprox:
         self.treemethod = treemethod
 
 
+class Comm:
+    """RCCL communicator over the GPUs that share ONE sample by rows (polee_comm).
+
+    `broadcast` distributes rank 0's 128-byte id: a callable bytes -> bytes (e.g. built on
+    torch.distributed.broadcast_object_list or MPI); it may be None for a single rank."""
+
+    def __init__(self, ctx, world_size=1, rank=0, broadcast=None):
+        self.ctx, self.world_size, self.rank = ctx, int(world_size), int(rank)
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(L.lib().polee_comm_unique_id(uid))
+        raw = bytes(uid)
+        if self.world_size > 1:
+            if broadcast is None:
+                raise ValueError("a broadcast function is required for more than one rank")
+            raw = broadcast(raw)
+        uid = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self._h = C.c_void_p()
+        check(L.lib().polee_comm_create(ctx._h, self.world_size, self.rank, uid, C.byref(self._h)), ctx._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_comm_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def allreduce_sum(self, values):
+        """Sum of a float32 array over the ranks (polee_allreduce_sum_f32)."""
+        v = arr(values, np.float32).copy()
+        check(L.lib().polee_allreduce_sum_f32(self._h, ptr(v, f32p), C.c_int64(v.size)), self.ctx._h)
+        return v
+
+
 class LikelihoodApproximationFit:
     """State of one fit (polee_vi): lets callers step the VI loop and inspect it."""
 
     def __init__(self, sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES,
-                 use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False):
+                 use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False, comm=None):
         self.sample, self.t, self.ctx = sample, t, sample.ctx
+        self.comm = comm
         efflens = sample.effective_lengths if efflens is None else efflens
         if efflens is None:
             raise ValueError("effective lengths are required")
@@ -399,6 +435,8 @@ class LikelihoodApproximationFit:
         self._h = C.c_void_p()
         check(L.lib().polee_vi_create(sample._h, t._h, ptr(self.efflens, f32p), C.byref(o), C.byref(self._h)),
               self.ctx._h)
+        if comm is not None:  # `sample` holds this rank's block of fragments (cohort.shard_rows)
+            check(L.lib().polee_vi_set_comm(self._h, comm._h), self.ctx._h)
 
     def __del__(self):
         try:

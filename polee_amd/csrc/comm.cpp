@@ -1,0 +1,142 @@
+// Collective for a sample whose fragments are sharded over the GPUs of a node: every rank
+// holds a contiguous block of X's rows and the full O(n) state; per likelihood pass the partial gradients
+// (K*n f32) and log-likelihoods are summed over ranks with ONE all-reduce; everything else is replicated.
+// RCCL is bound at run time (dlopen) so that single-GPU users need not have it.
+#include <dlfcn.h>
+
+#include "comm_internal.hpp"
+
+namespace polee {
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl(std::string &err)
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        // a copy that is already in the process (e.g. PyTorch's) wins; otherwise the ROCm one
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (r.lib) break;
+        }
+        if (!r.lib)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
+        if (r.lib) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+            r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        }
+    }
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
+        err = "librccl.so could not be loaded (needed only for row-sharded fits)";
+        return nullptr;
+    }
+    return &r;
+}
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values (rccl.h)
+}  // namespace
+
+polee_status comm_allreduce_device(polee_comm *c, void *buf, size_t count, bool f64)
+{
+    std::string err;
+    Rccl *r = rccl(err);
+    if (!r) return fail(c->ctx, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
+    const int rc = r->AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, c->comm, c->ctx->stream);
+    if (rc != 0)
+        return fail(c->ctx, POLEE_ERR_HIP, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+    return POLEE_OK;
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+extern "C" {
+
+polee_status polee_comm_unique_id(uint8_t id[POLEE_COMM_ID_BYTES])
+{
+    if (!id) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    std::string err;
+    Rccl *r = rccl(err);
+    if (!r) return fail(nullptr, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
+    static_assert(sizeof(RcclUniqueId) == POLEE_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    const int rc = r->GetUniqueId(id);
+    if (rc != 0) return fail(nullptr, POLEE_ERR_HIP, "ncclGetUniqueId failed (%d)", rc);
+    return POLEE_OK;
+}
+
+polee_status polee_comm_create(polee_ctx *ctx, int32_t nranks, int32_t rank, const uint8_t id[POLEE_COMM_ID_BYTES],
+                               polee_comm **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_comm_create: bad argument (rank %d of %d)", rank, nranks);
+    std::string err;
+    Rccl *r = rccl(err);
+    if (!r) return fail(ctx, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
+    RcclUniqueId uid;
+    memcpy(uid.bytes, id, POLEE_COMM_ID_BYTES);
+    void *comm = nullptr;
+    const int rc = r->CommInitRank(&comm, nranks, uid, rank);
+    if (rc != 0 || !comm)
+        return fail(ctx, POLEE_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+    polee_comm *c = new (std::nothrow) polee_comm();
+    if (!c) {
+        r->CommDestroy(comm);
+        return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    }
+    c->ctx = ctx;
+    c->comm = comm;
+    c->nranks = nranks;
+    c->rank = rank;
+    ctx_retain(ctx);
+    *out = c;
+    return POLEE_OK;
+}
+
+void polee_comm_destroy(polee_comm *c)
+{
+    if (!c) return;
+    if (--c->refs > 0) return;
+    std::string err;
+    if (Rccl *r = rccl(err)) {
+        (void)hipStreamSynchronize(c->ctx->stream);
+        r->CommDestroy(c->comm);
+    }
+    polee_ctx *ctx = c->ctx;
+    delete c;
+    ctx_release(ctx);
+}
+
+polee_status polee_allreduce_sum_f32(polee_comm *c, float *buf, int64_t count)
+{
+    if (!c) return fail(nullptr, POLEE_ERR_BAD_ARG, "null communicator");
+    polee_ctx *ctx = c->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!buf || count < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (count == 0) return POLEE_OK;
+    DevBuf<float> d;
+    POLEE_TRY(d.upload(ctx, buf, (size_t)count));
+    POLEE_TRY(comm_allreduce_device(c, d.p, (size_t)count, false));
+    return d.download(ctx, buf, (size_t)count);
+}
+
+int32_t polee_comm_rank(const polee_comm *c) { return c ? c->rank : -1; }
+int32_t polee_comm_size(const polee_comm *c) { return c ? c->nranks : 0; }
+
+}  // extern "C"

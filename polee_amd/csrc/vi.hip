@@ -15,6 +15,7 @@
 #include "loglik_internal.hpp"
 #include "ptt_internal.hpp"
 #include "vi_fused.hpp"
+#include "comm_internal.hpp"
 
 #include <cmath>
 
@@ -156,6 +157,7 @@ struct polee_vi {
     int32_t step = 0;  // steps completed
     int32_t ahead_step = 0;  // iteration whose draws (ys, lyy) are already on the device; 0 = none
     int32_t trace_cap = 0;
+    polee_comm *comm = nullptr;  // row-sharded fit: sum the likelihood gradient (and lp) over ranks each pass
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
@@ -210,6 +212,10 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
     POLEE_TRY(loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr));
+    if (vi->comm) {  // this rank saw only its block of fragments: x_grad and lp are sums over fragments
+        POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_g.p, (size_t)n * K, false));
+        if (want_values) POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_lp.p, (size_t)K, true));
+    }
     // backward: double-double prefix over leaves of u * (g - efflen term)
     hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
                        eff, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
@@ -414,14 +420,27 @@ void polee_vi_destroy(polee_vi *vi)
     polee_ctx *ctx = vi->ctx;
     polee_loglik *ll = vi->ll;
     polee_ptt *t = vi->t;
+    polee_comm *comm = vi->comm;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
     delete vi;
+    polee_comm_destroy(comm);  // drops this handle's reference
     loglik_release(ll);
     ptt_release(t);
     ctx_release(ctx);
+}
+
+polee_status polee_vi_set_comm(polee_vi *vi, polee_comm *comm)
+{
+    if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    if (comm && comm->ctx != vi->ctx)
+        return fail(vi->ctx, POLEE_ERR_BAD_ARG, "communicator and fit belong to different contexts");
+    if (comm) ++comm->refs;
+    polee_comm_destroy(vi->comm);
+    vi->comm = comm;
+    return POLEE_OK;
 }
 
 polee_status polee_vi_run(polee_vi *vi, int32_t nsteps)

@@ -483,3 +483,24 @@ def test_optimize_ptt_matches_oracle(P, ctx, lm_fixture):
     full = P.optimize_likelihood(s, t)  # 500 steps
     lp_full, _ = so.log_likelihood(full["x"])
     assert -327600 < lp_full < -326990, lp_full
+
+
+def test_row_sharded_fit_with_one_rank_equals_the_plain_fit(P, ctx, lm_fixture, prep_fixture):
+    """polee_comm (RCCL) with a single rank: the all-reduce is the identity, so the fit must not change; the
+    host-buffer all-reduce returns its input."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    comm = P.Comm(ctx, 1, 0)
+    v = np.arange(10, dtype=np.float32)
+    np.testing.assert_array_equal(comm.allreduce_sum(v), v)
+    out = []
+    for c in (None, comm):
+        fit = P.LikelihoodApproximationFit(s, t, num_steps=8, num_mc_samples=3, seed=5, comm=c, gradonly=False)
+        fit.run(8)
+        fit.sync()
+        out.append((fit.params(), fit.trace()))
+    # (two runs of the same fit differ in the last bits: the gradient is accumulated with f32 atomics)
+    for a, b in zip(out[0][0], out[1][0]):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out[0][1][1], out[1][1][1], rtol=1e-6)  # expected log-likelihood trace

@@ -52,3 +52,73 @@ def test_two_rank_gloo_aggregation(tmp_path):
     # 5 samples over 2 ranks: 3 + 2; whole-job rate = all units / slowest rank's time (2.0 s)
     assert d["world"] == 2 and d["total"] == 5 and d["mine"] == [0, 1, 2]
     assert abs(d["rate"] - 50 / 2.0) < 1e-9
+
+
+ROW_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["POLEE_ROOT"])
+import numpy as np, scipy.sparse as sp, torch
+import torch.distributed as dist
+from polee_amd.cohort import shard_rows, take_rows
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = np.load(os.path.join(os.environ["POLEE_ROOT"], "tests", "golden", "mBr_M_6w_1.likelihood-matrix.npz"))
+m, n = int(d["m"]), int(d["n"])
+X = sp.csc_matrix((d["nzval"], d["rowval"].astype(np.int64) - 1, d["colptr"].astype(np.int64) - 1), shape=(m, n))
+Xr = X.tocsr(); Xr.sort_indices()
+tcolptr = (Xr.indptr + 1).astype(np.uint64); trowval = (Xr.indices + 1).astype(np.uint32); tnzval = Xr.data.astype(np.float32)
+r0, r1 = shard_rows(tcolptr, world, rank)
+bp, br, bv = take_rows(tcolptr, trowval, tnzval, r0, r1)
+blk = sp.csr_matrix((bv, br.astype(np.int64) - 1, bp.astype(np.int64) - 1), shape=(r1 - r0, n)).tocsc()
+blk.sort_indices()
+so = O.Sample(r1 - r0, n, (blk.indptr + 1).astype(np.uint32), (blk.indices + 1).astype(np.uint32), blk.data.astype(np.float32))
+x = np.random.default_rng(0).dirichlet(np.ones(n)).astype(np.float32)
+lp, g = so.log_likelihood(x)
+t = torch.tensor(np.concatenate([g, [lp, r1 - r0, blk.nnz]]))
+dist.all_reduce(t)
+if rank == 0:
+    full = O.Sample(m, n, d["colptr"], d["rowval"], d["nzval"])
+    lp_f, g_f = full.log_likelihood(x)
+    tot = t.numpy()
+    print(json.dumps({"rows": int(tot[-2]), "nnz": int(tot[-1]), "m": m, "nnz_full": int(X.nnz),
+                      "lp_err": abs(tot[-3] - lp_f) / abs(lp_f), "g_err": float(np.abs(tot[:n] - g_f).max() / np.abs(g_f).max()),
+                      "r": [int(r0), int(r1)]}))
+dist.destroy_process_group()
+'''
+
+
+def test_shard_rows_is_a_balanced_partition():
+    import numpy as np
+    from polee_amd.cohort import shard_rows, take_rows
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 30, size=1000)
+    p = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.uint64)  # 1-based offsets
+    for W in (1, 2, 3, 8):
+        cuts = [shard_rows(p, W, r) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == 1000
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(W - 1))
+        nnz = [int(p[b] - p[a]) for a, b in cuts]
+        assert max(nnz) - min(nnz) <= 2 * 30  # balanced on non-zeros up to one row
+    idx = np.arange(int(p[-1] - 1), dtype=np.uint32)
+    bp, br, bv = take_rows(p, idx, idx.astype(np.float32), 10, 20)
+    assert bp[0] == 1 and len(bp) == 11 and len(br) == int(p[20] - p[10]) and br[0] == int(p[10] - 1)
+
+
+def test_two_rank_row_sharded_likelihood_sums_to_the_whole(tmp_path):
+    """SURVEY.md 8(e)(1): each rank evaluates its block of fragments (oracle on CPU here), one all-reduce of
+    x_grad and lp gives the whole sample's values."""
+    script = tmp_path / "row_worker.py"
+    script.write_text(ROW_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, POLEE_ROOT=ROOT, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rows"] == d["m"] and d["nnz"] == d["nnz_full"]
+    assert d["lp_err"] < 1e-12 and d["g_err"] < 1e-12
