@@ -148,4 +148,50 @@ function rand_draws!(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{F
     return xs
 end
 
+"effective_length_jacobian_adjustment!(efflens, xs, xls, x_grad) -- src/likelihood.jl:93-110"
+function effective_length_jacobian_adjustment!(ctx::Context, efflens::Vector{Float32}, xs::Vector{Float32},
+                                               xls::Vector{Float32}, x_grad::Vector{Float64})
+    GC.@preserve efflens xs xls x_grad check(
+        ccall((:polee_efflen_jacobian_adjustment, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Int64, Ptr{Float64}, Ptr{Float32}),
+              ctx.h, efflens, xs, 1, length(xs), x_grad, xls), ctx.h)
+    return 0.0
+end
+
+"gene_noninformative_prior!(efflens, xls, xl_grad, xs, x_grad, gene_transcripts) -- src/likelihood.jl:114-159"
+function gene_noninformative_prior!(ctx::Context, efflens::Vector{Float32}, xls::Vector{Float32}, xs::Vector{Float32},
+                                    x_grad::Vector{Float64}, gene_transcripts::Dict{String, Vector{Int}})
+    gene_of = fill(Int32(-1), length(xs))
+    for (gi, idxs) in enumerate(values(gene_transcripts)), i in idxs
+        gene_of[i] = Int32(gi - 1)
+    end
+    GC.@preserve efflens xls xs x_grad gene_of check(
+        ccall((:polee_gene_noninformative_prior, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, Int64, Ptr{Int32}, Ptr{Float64}),
+              ctx.h, efflens, xls, xs, 1, length(xs), gene_of, x_grad), ctx.h)
+    return 0.0
+end
+
+# ---- one sample over several GPUs (one Julia process per GPU) -------------------------
+"128-byte id for polee_comm_create; rank 0 creates it and the caller broadcasts it (MPI.jl, a file, ...)"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id check(ccall((:polee_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+
+mutable struct Comm
+    h::Ptr{Cvoid}
+    ctx::Context
+    function Comm(ctx::Context, nranks::Integer, rank::Integer, id::Vector{UInt8})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve id check(ccall((:polee_comm_create, LIB), Cint,
+                                    (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+                                    ctx.h, nranks, rank, id, out), ctx.h)
+        c = new(out[], ctx)
+        finalizer(x -> ccall((:polee_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+        return c
+    end
+end
+
 end # module
