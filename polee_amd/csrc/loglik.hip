@@ -243,11 +243,12 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 }
 
 template <int K, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile_base)
+__global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile_base, const uint32_t *tile_ids)
 {
     extern __shared__ float lds[];
     __shared__ double lp_red[4];
-    psell_tile_body<K, WANT_LP, HAS_KS>(A, tile_base + (int)blockIdx.x, lds, lds + (size_t)A.lcap * K, lp_red);
+    const int tile = tile_ids ? (int)tile_ids[blockIdx.x] : tile_base + (int)blockIdx.x;
+    psell_tile_body<K, WANT_LP, HAS_KS>(A, tile, lds, lds + (size_t)A.lcap * K, lp_red);
 }
 
 // ---- stream B inside the fused launch: row sweep, then column sweep ---------------------------------------
@@ -267,6 +268,7 @@ __device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrow
 
     const uint32_t d0 = A.tile_dict[tile];
     const int L = (int)(A.tile_dict[tile + 1] - d0);
+    if (L > A.lcap) return;  // a tile around a fragment with > 256 transcripts: left to loglik_psell_kernel
     for (int i = threadIdx.x; i < L * K; i += 256) {
         const int l = i / K, k = i - l * K;
         xw[i] = x[(size_t)dict[d0 + l] * K + k];
@@ -802,7 +804,11 @@ template <int K, bool LP, bool KS>
 static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
     const PsellHost &h = ll->host;
-    const int lcap = std::max(h.max_tile_cols, 1);
+    const int lcap_all = std::max(h.max_tile_cols, 1);
+    // tiles around a fragment with > 256 transcripts (rare, a few rows each) do not fit the fused kernel's LDS
+    // windows: it skips them and loglik_psell_kernel takes them in a second, small launch
+    const bool fusable = !h.big_tiles.empty() || lcap_all <= PSELL_TILE_COLS_TARGET;
+    const int lcap = fusable ? std::min(lcap_all, (int)PSELL_TILE_COLS_TARGET) : lcap_all;
     hipStream_t st = ll->ctx->stream;
     static const bool no_ring_env = getenv("POLEE_NO_RING") != nullptr;
     const bool no_ring = no_ring_env || ll->force_mixed;
@@ -816,23 +822,37 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     const size_t lds = (size_t)fused_ring_total<K>() + ((size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
+    static bool attr_set = false;
+    if (!attr_set) {  // (a 1024-transcript dictionary at K = 8 needs 64 KiB of windows)
+        (void)hipFuncSetAttribute((const void *)loglik_fused_kernel<K, LP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  128 * 1024);  // (this kernel also has a little static LDS)
+        (void)hipGetLastError();
+        attr_set = true;
+    }
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     if (!no_ring && tiles_a > 0 && lds <= 64 * 1024) {
         int nb_b = tiles - tiles_a, nb_a2 = tiles_a - tiles_a1, nb_a1 = tiles_a1;
         if (dbg & 32) nb_b = 0;
         if (dbg & 128) nb_a2 = 0;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)loglik_fused_kernel<K, LP, KS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+
         hipLaunchKernelGGL((loglik_fused_kernel<K, LP, KS>), dim3((unsigned)(nb_b + nb_a2 + nb_a1)), dim3(256), lds, st,
                            A, tiles_a1, tiles_a, nb_b, nb_a2, dbg);
+        if (!h.big_tiles.empty()) {
+            PsellArgs Ab = A;
+            Ab.lcap = lcap_all;
+            const size_t lds_b = (size_t)2 * lcap_all * K * sizeof(float);
+            hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.big_tiles.size()), dim3(256), lds_b, st,
+                               Ab, 0, ll->d_big_tiles.p);
+        }
     } else {
-        // no uniform stream (or a tile dictionary too large for the fused LDS budget): everything as mixed slices
-        const size_t lds_b = (size_t)2 * lcap * K * sizeof(float);
-        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles), dim3(256), lds_b, st, A, 0);
+        // no uniform stream, or the cross-check switch: every tile as mixed slices with the per-run DPP kernel
+        PsellArgs Ab = A;
+        Ab.lcap = lcap_all;
+        const size_t lds_b = (size_t)2 * lcap_all * K * sizeof(float);
+        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles), dim3(256), lds_b, st, Ab, 0,
+                           (const uint32_t *)nullptr);
     }
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     return hipGetLastError();
@@ -972,7 +992,8 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_tdata.upload(ctx, h.tdata)) ||
-        (s = ll->d_tgroup_off.upload(ctx, h.tgroup_off)) || (s = ll->d_ttile_group.upload(ctx, h.ttile_group)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (s = ll->d_tgroup_off.upload(ctx, h.tgroup_off)) || (s = ll->d_ttile_group.upload(ctx, h.ttile_group)) ||
+        (s = ll->d_big_tiles.upload(ctx, h.big_tiles)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
         loglik_release(ll);
         return s;
     }

@@ -58,6 +58,7 @@ struct PsellHost {
     std::vector<uint32_t> tile_slice;  // [num_tiles+1]
     std::vector<uint32_t> tile_dict;   // [num_tiles+1]
     std::vector<uint32_t> dict;        // transcript ids (0-based)
+    std::vector<uint32_t> big_tiles;   // tiles whose dictionary exceeds PSELL_TILE_COLS_TARGET (a fragment with > 256 transcripts)
     std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
     // stream B only: the tile's entries a second time, grouped by transcript ("virtual columns": a transcript
@@ -89,7 +90,7 @@ struct polee_loglik {
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
     polee::DevBuf<uint8_t> d_tdata;
-    polee::DevBuf<uint32_t> d_tgroup_off, d_ttile_group;
+    polee::DevBuf<uint32_t> d_tgroup_off, d_ttile_group, d_big_tiles;
     polee::DevBuf<float> d_slice_ks;
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;

@@ -229,6 +229,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.tile_slice.push_back((uint32_t)out.num_slices);
         out.tile_dict.push_back((uint32_t)out.dict.size());
         out.max_tile_cols = std::max<int32_t>(out.max_tile_cols, (int32_t)tile_cols);
+        if (tile_cols > (uint32_t)PSELL_TILE_COLS_TARGET) out.big_tiles.push_back((uint32_t)out.num_tiles);
         ++out.num_tiles;
         ++tile_id;
         tile_cols = 0;

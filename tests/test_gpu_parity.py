@@ -217,6 +217,14 @@ def test_loglik_ragged_empty_rows_long_row_and_ks(P, ctx):
         ggk = np.zeros(n); np.add.at(ggk, cols, nzval.astype(np.float64) * ks[rows] / sp[rows])
         np.testing.assert_allclose(g[k], gg, rtol=3e-5, atol=1e-7 * gg.max())
         np.testing.assert_allclose(gk[k], ggk, rtol=3e-5, atol=1e-7 * ggk.max())
+    # the 700-transcript fragments form their own oversized tiles (second small launch); all K up to 8 work there
+    x8 = np.clip(rng.dirichlet(np.ones(n), size=8), 1e-10, 1).astype(np.float32)
+    lp8, g8 = s.log_likelihood(x8)
+    for k in (0, 7):
+        sp = np.zeros(m); np.add.at(sp, rows, (nzval * x8[k][cols]).astype(np.float64))
+        gg = np.zeros(n); np.add.at(gg, cols, nzval.astype(np.float64) / sp[rows])
+        assert abs(lp8[k] - np.log(sp[sp > 0]).sum()) <= 1e-6 * abs(lp8[k])
+        np.testing.assert_allclose(g8[k], gg, rtol=3e-5, atol=1e-7 * gg.max())
     # Xt entry point gives identical results
     so = O.Sample(m, n, colptr, rowval, nzval)
     s2 = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=so.csr())
