@@ -62,17 +62,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (a box with fewer GPUs than ranks): POLEE_BENCH_BACKEND=gloo keeps the bookkeeping collectives on the
+    # CPU, POLEE_BENCH_FORCE_DEVICE=<id> puts every rank on that GPU
+    backend = os.environ.get("POLEE_BENCH_BACKEND", "nccl")
+    if "POLEE_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["POLEE_BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
 
     import polee_amd as P
     from polee_amd.cohort import Ranks, sample_seed
     from tools import synth
-    ranks = Ranks(dist, "cuda" if dist is not None else None)
+    ranks = Ranks(dist, "cuda" if dist is not None and backend == "nccl" else None)
 
     n, m, mean_nnz = WORKLOADS[args.workload]
     K = args.draws
