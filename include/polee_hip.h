@@ -307,6 +307,14 @@ polee_status polee_approx_logprob(polee_approx *ap, const float *x, float *lp,
 /* Same on device buffers, enqueued on the context's stream (no host sync). */
 polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, float *d_lp,
                                          float *d_x_grad_or_null);
+/* RNASeqGeneApproxLikelihoodDist (src/polee_gene_expression.py:14-90): the same density reached through
+ * gene-level expression.  x[s][i] = x_gene[s][g(i)] + x_isoform[s][i] - logsumexp_{i' in g(i)} x_isoform[s][i']
+ * (the reference's exp / blockwise sparse matmul / log), then _log_prob of the transcript approximation.
+ * gene_of int32 [n]: 0-based gene of every transcript (each transcript in exactly one gene, every gene
+ * non-empty).  lp f32 [S]; gradients (optional) d lp[s] / d x_gene [S][G] and / d x_isoform [S][n]. */
+polee_status polee_approx_gene_logprob(polee_approx *ap, const float *x_gene, const float *x_isoform,
+                                       const int32_t *gene_of, int32_t num_genes, float *lp,
+                                       float *gene_grad_or_null, float *isoform_grad_or_null);
 /* rnaseq_approx_likelihood_sampler (src/polee_approx_likelihood.py:35-59): one draw per
  * sample, divided by efflens, renormalised and clipped to [1e-16, 0.99999999].
  * z0 optional host [S][n-1]. */

@@ -402,5 +402,23 @@ def approx_log_prob(x, efflens, mu, sigma, alpha, left, right, leaf, want_grad=F
     return (lp, g) if want_grad else lp
 
 
+def approx_gene_log_prob(x_gene, x_iso, gene_of, efflens, mu, sigma, alpha, left, right, leaf, want_grad=False):
+    """polee_gene_expression.py:14-90 around approx_log_prob; x_gene [S, G], x_iso [S, n]."""
+    x_gene, x_iso, efflens, mu, sigma, alpha = (_f32(np.atleast_2d(a)) for a in (x_gene, x_iso, efflens, mu, sigma, alpha))
+    S, n = x_iso.shape
+    G = x_gene.shape[1]
+    gene_of = np.ascontiguousarray(gene_of, np.int32)
+    left, right, leaf, shared = _tree_args(left, right, leaf)
+    lp = np.empty(S, np.float32)
+    gg = np.empty((S, G), np.float32) if want_grad else None
+    gi = np.empty((S, n), np.float32) if want_grad else None
+    f = lib().oracle_approx_gene_log_prob
+    f.restype = None
+    f(_p(x_gene, c_f32p), _p(x_iso, c_f32p), _p(gene_of, c_i32p), C.c_int64(G), _p(efflens, c_f32p), _p(mu, c_f32p),
+      _p(sigma, c_f32p), _p(alpha, c_f32p), _p(left, c_i32p), _p(right, c_i32p), _p(leaf, c_i32p), C.c_int64(S),
+      C.c_int64(n), shared, _p(lp, c_f32p), _p(gg, c_f32p), _p(gi, c_f32p))
+    return (lp, gg, gi) if want_grad else lp
+
+
 def num_threads():
     return lib().oracle_num_threads()

@@ -1036,3 +1036,39 @@ int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* src/polee_gene_expression.py:14-90 RNASeqGeneApproxLikelihoodDist: transcript log-expression from gene-level
+ * and within-gene isoform log-expression, as the reference composes it (f32, no max shift: :30-60):
+ *   x_exp[i] = exp(x_iso[i]) * (exp(x_gene[g]) / sum_{i' in g} exp(x_iso[i']));  x = log(x_exp)
+ * then the transcript density (oracle_approx_log_prob).  Gradients: what TF autodiff yields, by hand:
+ *   d/dx_gene[g] = sum_{i in g} gx_i;   d/dx_iso[i] = gx_i - p_i * sum_{i' in g} gx_i',  p = softmax within the gene. */
+void oracle_approx_gene_log_prob(const float *x_gene, const float *x_iso, const int32_t *gene_of, int64_t G,
+                                 const float *efflens, const float *mu, const float *sigma, const float *alpha,
+                                 const int32_t *left_index, const int32_t *right_index,
+                                 const int32_t *leaf_index, int64_t S, int64_t n, int shared_tree, float *lp_out,
+                                 float *gene_grad, float *iso_grad)
+{
+    float *x = malloc(sizeof(float) * S * n), *gx = malloc(sizeof(float) * S * n);
+    float *norm = malloc(sizeof(float) * G), *tot = malloc(sizeof(float) * G);
+    for (int64_t s = 0; s < S; ++s) {
+        for (int64_t g = 0; g < G; ++g) norm[g] = 0.0f;
+        for (int64_t i = 0; i < n; ++i) norm[gene_of[i]] += expf(x_iso[s * n + i]); /* :48-51 */
+        for (int64_t i = 0; i < n; ++i)
+            x[s * n + i] = logf(expf(x_iso[s * n + i]) * (expf(x_gene[s * G + gene_of[i]]) / norm[gene_of[i]])); /* :53-56 */
+    }
+    oracle_approx_log_prob(x, efflens, mu, sigma, alpha, left_index, right_index, leaf_index, S, n, shared_tree,
+                           lp_out, gene_grad ? gx : NULL);
+    if (gene_grad) {
+        for (int64_t s = 0; s < S; ++s) {
+            for (int64_t g = 0; g < G; ++g) norm[g] = tot[g] = 0.0f;
+            for (int64_t i = 0; i < n; ++i) {
+                norm[gene_of[i]] += expf(x_iso[s * n + i]);
+                tot[gene_of[i]] += gx[s * n + i];
+            }
+            for (int64_t g = 0; g < G; ++g) gene_grad[s * G + g] = tot[g];
+            for (int64_t i = 0; i < n; ++i)
+                iso_grad[s * n + i] = gx[s * n + i] - expf(x_iso[s * n + i]) / norm[gene_of[i]] * tot[gene_of[i]];
+        }
+    }
+    free(x); free(gx); free(norm); free(tot);
+}

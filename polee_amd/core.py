@@ -623,6 +623,23 @@ class RNASeqApproxLikelihood:
         check(L.lib().polee_approx_logprob(self._h, ptr(x, f32p), ptr(lp, f32p), ptr(g, f32p)), self.ctx._h)
         return (lp, g) if want_grad else lp
 
+    def gene_log_prob(self, x_gene, x_isoform, feature_idxs, want_grad=False):
+        """RNASeqGeneApproxLikelihoodDist._log_prob (polee_gene_expression.py:14-90): the density reached through
+        gene-level expression x_gene [S,G] and within-gene isoform log-expression x_isoform [S,n].
+        `feature_idxs` [n]: 1-based gene of every transcript, as the reference passes it (transcript_idxs = 1..n).
+        Returns lp [S] (and d lp / d x_gene, d lp / d x_isoform)."""
+        xg, xi = arr(np.atleast_2d(x_gene), np.float32), arr(np.atleast_2d(x_isoform), np.float32)
+        gene_of = (arr(feature_idxs, np.int64).reshape(-1) - 1).astype(np.int32)
+        G = xg.shape[1]
+        if xi.shape != (self.S, self.n) or xg.shape[0] != self.S or gene_of.size != self.n:
+            raise ValueError("shapes must be x_gene [S,G], x_isoform [S,n], feature_idxs [n]")
+        lp = np.empty(self.S, np.float32)
+        gg = np.empty((self.S, G), np.float32) if want_grad else None
+        gi = np.empty((self.S, self.n), np.float32) if want_grad else None
+        check(L.lib().polee_approx_gene_logprob(self._h, ptr(xg, f32p), ptr(xi, f32p), ptr(gene_of, i32p), G,
+                                                ptr(lp, f32p), ptr(gg, f32p), ptr(gi, f32p)), self.ctx._h)
+        return (lp, gg, gi) if want_grad else lp
+
     def sample(self, z0=None, seed=123456789):
         """rnaseq_approx_likelihood_sampler (polee_approx_likelihood.py:35-59), one draw per sample."""
         z = None if z0 is None else arr(z0, np.float32).reshape(self.S, self.n - 1)

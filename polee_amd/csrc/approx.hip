@@ -223,6 +223,43 @@ __global__ void approx_sample_y_kernel(ApproxView a, const float *z0, uint64_t s
     ys[o] = 1.0 / (1.0 + (double)expf(-y_logit));
 }
 
+// ---- gene-level wrapper (polee_gene_expression.py:14-90) -------------------------------------------------
+// x[s][i] = x_gene[s][g] + x_iso[s][i] - logsumexp_{i' in g} x_iso[s][i']; one thread per (sample, gene)
+__global__ void gene_compose_kernel(const int32_t *gptr, const int32_t *gidx, int G, int n, const float *x_gene,
+                                    const float *x_iso, float *x)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (g >= G) return;
+    const float *xi = x_iso + (size_t)s * n;
+    float mx = -INFINITY;
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) mx = fmaxf(mx, xi[gidx[e]]);
+    float sum = 0.0f;
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) sum += expf(xi[gidx[e]] - mx);
+    const float shift = x_gene[(size_t)s * G + g] - (mx + logf(sum));
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) x[(size_t)s * n + gidx[e]] = xi[gidx[e]] + shift;
+}
+// VJP: gene_grad[g] = sum_{i in g} gx_i;  iso_grad[i] = gx_i - softmax_i * gene_grad[g]  (written over x_iso)
+__global__ void gene_compose_grad_kernel(const int32_t *gptr, const int32_t *gidx, int G, int n, float *x_iso,
+                                         const float *gx, float *gene_grad)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (g >= G) return;
+    float *xi = x_iso + (size_t)s * n;
+    const float *gxs = gx + (size_t)s * n;
+    float mx = -INFINITY;
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) mx = fmaxf(mx, xi[gidx[e]]);
+    float sum = 0.0f, tot = 0.0f;
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) {
+        sum += expf(xi[gidx[e]] - mx);
+        tot += gxs[gidx[e]];
+    }
+    gene_grad[(size_t)s * G + g] = tot;
+    for (int e = gptr[g]; e < gptr[g + 1]; ++e) {
+        const int i = gidx[e];
+        xi[i] = gxs[i] - expf(xi[i] - mx) / sum * tot;
+    }
+}
+
 }  // namespace polee
 
 using namespace polee;
@@ -345,6 +382,56 @@ polee_status polee_approx_logprob(polee_approx *ap, const float *x, float *lp, f
     POLEE_TRY(polee_approx_logprob_device(ap, ap->d_x.p, ap->d_lp.p, x_grad ? ap->d_xgrad.p : nullptr));
     POLEE_TRY(ap->d_lp.download(ctx, lp, ap->S));
     if (x_grad) POLEE_TRY(ap->d_xgrad.download(ctx, x_grad, sn));
+    return POLEE_OK;
+}
+
+polee_status polee_approx_gene_logprob(polee_approx *ap, const float *x_gene, const float *x_isoform,
+                                       const int32_t *gene_of, int32_t G, float *lp, float *gene_grad,
+                                       float *isoform_grad)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    const int S = ap->S, n = ap->n;
+    if (!x_gene || !x_isoform || !gene_of || !lp || G < 1 || G > n) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if ((gene_grad == nullptr) != (isoform_grad == nullptr))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "ask for both gradients or for none");
+    // genes as CSR (transcripts of gene g: gidx[gptr[g] .. gptr[g+1]))
+    std::vector<int32_t> gptr((size_t)G + 1, 0), gidx((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (gene_of[i] < 0 || gene_of[i] >= G) return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of[%d] = %d outside 0..%d", i, gene_of[i], G - 1);
+        ++gptr[(size_t)gene_of[i] + 1];
+    }
+    for (int g = 0; g < G; ++g) {
+        if (gptr[(size_t)g + 1] == 0) return fail(ctx, POLEE_ERR_BAD_ARG, "gene %d has no transcript", g);
+        gptr[(size_t)g + 1] += gptr[g];
+    }
+    {
+        std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
+        for (int i = 0; i < n; ++i) gidx[(size_t)fill[gene_of[i]]++] = i;
+    }
+    DevBuf<int32_t> d_gptr, d_gidx;
+    DevBuf<float> d_xg, d_xi, d_gg;
+    const size_t sn = (size_t)S * n, sg = (size_t)S * G;
+    POLEE_TRY(d_gptr.upload(ctx, gptr));
+    POLEE_TRY(d_gidx.upload(ctx, gidx));
+    POLEE_TRY(d_xg.upload(ctx, x_gene, sg));
+    POLEE_TRY(d_xi.upload(ctx, x_isoform, sn));
+    const dim3 grid((unsigned)ceil_div(G, 256), (unsigned)S);
+    hipLaunchKernelGGL(gene_compose_kernel, grid, dim3(256), 0, ctx->stream, d_gptr.p, d_gidx.p, G, n, d_xg.p, d_xi.p,
+                       ap->d_x.p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(polee_approx_logprob_device(ap, ap->d_x.p, ap->d_lp.p, gene_grad ? ap->d_xgrad.p : nullptr));
+    POLEE_TRY(ap->d_lp.download(ctx, lp, S));
+    if (gene_grad) {
+        POLEE_TRY(d_gg.alloc(ctx, sg));
+        // (d_xi is overwritten with the isoform gradient)
+        hipLaunchKernelGGL(gene_compose_grad_kernel, grid, dim3(256), 0, ctx->stream, d_gptr.p, d_gidx.p, G, n, d_xi.p,
+                           ap->d_xgrad.p, d_gg.p);
+        POLEE_KERNEL_CHECK(ctx);
+        POLEE_TRY(d_gg.download(ctx, gene_grad, sg));
+        POLEE_TRY(d_xi.download(ctx, isoform_grad, sn));
+    }
     return POLEE_OK;
 }
 

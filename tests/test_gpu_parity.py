@@ -433,6 +433,36 @@ def test_approx_logprob_and_gradient_match_oracle(P, ctx, shared):
     np.testing.assert_allclose(xs, xo, rtol=1e-4, atol=1e-16)
 
 
+def test_gene_level_logprob_and_gradients_match_oracle(P, ctx):
+    """RNASeqGeneApproxLikelihoodDist (polee_gene_expression.py:14-90) around the transcript density."""
+    rng = np.random.default_rng(22)
+    n, S, G = 500, 2, 140
+    trees = [random_tree(n, rng) for _ in range(S)]
+    idx = [O.make_inverse_ptt_params(*tr) for tr in trees]
+    L_, R_, F_ = (np.stack([i[j] for i in idx]) for j in range(3))
+    eff = rng.uniform(200, 3000, size=(S, n)).astype(np.float32)
+    mu = rng.normal(0, 1, size=(S, n - 1)).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.3, size=(S, n - 1))).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=(S, n - 1)).astype(np.float32)
+    gene_of = np.concatenate([np.arange(G), rng.integers(0, G, n - G)]).astype(np.int32)  # every gene non-empty
+    rng.shuffle(gene_of)
+    x_gene = rng.normal(0, 1.5, size=(S, G)).astype(np.float32)
+    x_iso = rng.normal(0, 1.0, size=(S, n)).astype(np.float32)
+    ap = P.RNASeqApproxLikelihood(dict(efflen=eff, la_mu=mu, la_sigma=sigma, la_alpha=alpha, left_index=L_,
+                                       right_index=R_, leaf_index=F_), ctx=ctx)
+    lp, gg, gi = ap.gene_log_prob(x_gene, x_iso, gene_of + 1, want_grad=True)
+    lpo, ggo, gio = O.approx_gene_log_prob(x_gene, x_iso, gene_of, eff, mu, sigma, alpha, L_, R_, F_, want_grad=True)
+    np.testing.assert_allclose(lp, lpo, rtol=1e-4)
+    np.testing.assert_allclose(gg, ggo, rtol=3e-3, atol=3e-3 * np.abs(ggo).max())
+    np.testing.assert_allclose(gi, gio, rtol=3e-3, atol=3e-3 * np.abs(gio).max())
+    np.testing.assert_allclose(ap.gene_log_prob(x_gene, x_iso, gene_of + 1), lp, rtol=1e-6)
+    # the within-gene parametrisation is shift invariant: adding a constant to a gene's isoforms changes nothing
+    x_iso2 = x_iso + rng.normal(size=(S, G)).astype(np.float32)[:, gene_of]
+    np.testing.assert_allclose(ap.gene_log_prob(x_gene, x_iso2, gene_of + 1), lp, rtol=2e-5)
+    with pytest.raises(P.PoleeError):
+        ap.gene_log_prob(x_gene, x_iso, np.full(n, G + 5, np.int32))
+
+
 def test_elementwise_reparameterisations_match_oracle(P, ctx):
     """Standalone logit-normal / sinh-arcsinh / Kumaraswamy transforms and their gradients."""
     rng = np.random.default_rng(31)

@@ -409,3 +409,27 @@ def test_gene_noninformative_prior_follows_the_reference_lines():
     # the diagonal term alone is the exact derivative at fixed normalisation: d/dx_j of -(k-1) log c_g with xl = (x/l)/S
     j = int(np.flatnonzero(xl_grad != 0)[0])
     assert np.isclose(xl_grad[j] * inv_l[j] / S, -(np.sum(gene_of == gene_of[j]) - 1) / xls[gene_of == gene_of[j]].sum() * inv_l[j] / S)
+
+
+def test_gene_level_composition_gradient_matches_finite_differences():
+    """polee_gene_expression.py:14-90: the hand-written VJP of the gene / isoform composition in the oracle."""
+    rng = np.random.default_rng(4)
+    n, G = 30, 7
+    parents, js = random_tree(n, rng)
+    L_, R_, F_ = O.make_inverse_ptt_params(parents, js)
+    eff = rng.uniform(200, 3000, size=n).astype(np.float32)
+    mu = rng.normal(0, 1, size=n - 1).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.3, size=n - 1)).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=n - 1).astype(np.float32)
+    gene_of = np.concatenate([np.arange(G), rng.integers(0, G, n - G)]).astype(np.int32)
+    xg = rng.normal(0, 1, size=G).astype(np.float32)
+    xi = rng.normal(0, 1, size=n).astype(np.float32)
+    lp, gg, gi = O.approx_gene_log_prob(xg, xi, gene_of, eff, mu, sigma, alpha, L_, R_, F_, want_grad=True)
+    # the composed x and the chain rule, checked against the transcript-level gradient
+    xn = xg[gene_of] + xi - np.log(np.bincount(gene_of, np.exp(xi.astype(np.float64)), G))[gene_of]
+    lp_t, gx = O.approx_log_prob(xn.astype(np.float32), eff, mu, sigma, alpha, L_, R_, F_, want_grad=True)
+    assert abs(lp[0] - lp_t[0]) <= 2e-4 * abs(lp_t[0])
+    tot = np.bincount(gene_of, gx[0].astype(np.float64), G)
+    p = np.exp(xi.astype(np.float64)) / np.bincount(gene_of, np.exp(xi.astype(np.float64)), G)[gene_of]
+    np.testing.assert_allclose(gg[0], tot, rtol=2e-3, atol=2e-3 * np.abs(tot).max())
+    np.testing.assert_allclose(gi[0], gx[0] - p * tot[gene_of], rtol=2e-3, atol=2e-3 * np.abs(gx).max())
