@@ -262,6 +262,16 @@ polee_status polee_vi_fit(polee_loglik *ll, polee_ptt *t, const float *efflens,
 polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *efflens, int32_t num_steps,
                                 float *xs, float *zs_or_null);
 
+/* ---- tree construction (host side) --------------------------------------------------------
+ * hclust + order_nodes (src/hclust.jl:193-319, 361-389), the heuristic behind
+ * PolyaTreeTransform(X, :cluster) (src/ptt.jl:35-52): greedy joining of the transcripts / subtrees that share
+ * the most reads (Jaccard similarity of read sets among 25 neighbours in median-read order), remaining
+ * components smallest first, nodes in DFS pre-order, right child first.  X in CSC, 1-based, as in the
+ * likelihood-matrix HDF5.  Outputs int32 [2n-1] each: exactly the arrays polee_ptt_create takes and the prep
+ * HDF5 stores.  Runs on the CPU (as the reference's does); no context needed. */
+polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                          int32_t *node_parent_idxs, int32_t *node_js);
+
 /* ---- one sample over several GPUs -----------------------------------
  * X's rows (fragments) are sharded over the ranks in contiguous blocks; every rank creates its
  * polee_loglik from its block and runs the same polee_vi (same seed => identical state); per

@@ -186,6 +186,7 @@ class RNASeqSample:
         self.m, self.n = int(m), int(n)
         self.effective_lengths = None if effective_lengths is None else arr(effective_lengths, np.float32)
         self._h = C.c_void_p()
+        self._csc = None
         ks_a = None if ks is None else arr(ks, np.int64)
         if xt is not None:
             tp, tr, tv = arr(xt[0], np.uint64), arr(xt[1], np.uint32), arr(xt[2], np.float32)
@@ -197,6 +198,7 @@ class RNASeqSample:
             if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
                 colptr = colptr.astype(np.uint64)
             rowval, nzval = arr(rowval, np.uint32), arr(nzval, np.float32)
+            self._csc = (colptr, rowval)  # kept for tree construction (hclust)
             check(L.lib().polee_loglik_create(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n),
                                               colptr.ctypes.data_as(C.c_void_p), int(colptr.dtype.itemsize),
                                               ptr(rowval, u32p), ptr(nzval, f32p), ptr(ks_a, i64p),
@@ -366,9 +368,23 @@ def kumaraswamy_transform_gradients(zs, as_, bs, y_grad, a_grad=None, b_grad=Non
     return ag, bg
 
 
+def hclust(m, n, colptr, rowval):
+    """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
+    (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],
+    i.e. what the prep HDF5 stores and PolyaTreeTransform(...) takes.  Runs on the host, as in the reference."""
+    colptr = np.ascontiguousarray(colptr)
+    if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
+        colptr = colptr.astype(np.uint64)
+    rowval = arr(rowval, np.uint32)
+    parents, js = np.empty(2 * int(n) - 1, np.int32), np.empty(2 * int(n) - 1, np.int32)
+    check(L.lib().polee_hclust(C.c_int64(int(m)), C.c_int64(int(n)), colptr.ctypes.data_as(C.c_void_p),
+                               int(colptr.dtype.itemsize), ptr(rowval, u32p), ptr(parents, L.i32p), ptr(js, L.i32p)))
+    return parents, js
+
+
 class LogitSkewNormalPTTApprox:
-    """src/likelihood-approximation.jl:8-16 (treemethod is only a label here: tree construction,
-    hclust, is outside the hot path -- pass the tree explicitly)."""
+    """src/likelihood-approximation.jl:8-16.  treemethod "cluster" (hclust.jl) or "sequential" (list tree) is used
+    by approximate_likelihood when no tree is passed (ptt.jl:35-52)."""
 
     def __init__(self, treemethod="cluster"):
         self.treemethod = treemethod
@@ -500,8 +516,17 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
         raise NotImplementedError("only LogitSkewNormalPTTApprox is built (the alt approximations are out of scope)")
     if gene_noninformative:
         raise NotImplementedError("gene_noninformative prior (likelihood.jl:114-159) is disabled on the CLI path and not built")
-    if t is None:
-        raise ValueError("a PolyaTreeTransform is required (tree construction, hclust.jl, is outside the hot path)")
+    if t is None:  # PolyaTreeTransform(X, approx.treemethod) (ptt.jl:35-52, likelihood-approximation.jl:425-440)
+        if approx.treemethod == "cluster":
+            if getattr(sample, "_csc", None) is None:
+                raise ValueError("tree construction needs the sample's CSC arrays (create it from colptr/rowval/nzval) "
+                                 "or pass a PolyaTreeTransform")
+            parents, js = hclust(sample.m, sample.n, *sample._csc)
+        elif approx.treemethod == "sequential":
+            parents, js = list_nodes(sample.n)
+        else:
+            raise ValueError("%r is not a supported Polya tree transform heuristic" % (approx.treemethod,))
+        t = PolyaTreeTransform(parents, js, ctx=sample.ctx)
     fit = LikelihoodApproximationFit(sample, t, num_steps=num_steps, num_mc_samples=num_mc_samples,
                                      use_efflen_jacobian=use_efflen_jacobian, gradonly=gradonly, seed=seed, z0=z0)
     fit.run(num_steps)

@@ -1,0 +1,246 @@
+// Tree construction for the Polya tree transform: the reference's greedy read-set clustering
+// (src/hclust.jl:193-319) and DFS node ordering (src/hclust.jl:361-389), host side (the reference runs it on the
+// CPU too).  Output = the two arrays the prep HDF5 stores (node_parent_idxs, node_js), i.e.
+// exactly what polee_ptt_create takes.
+//
+// Determinism: the reference's result depends on tie-breaking inside DataStructures.jl's binary heaps, on the
+// stability of sortperm and on Dict iteration order (remaining components).  This restatement uses the same
+// heap algorithm (push = append + percolate up, pop = move last to root + percolate down, strict comparisons),
+// a stable sort, neighbour lists in insertion order, and visits the remaining components in ascending node id
+// (the one place where Julia's hash order cannot be followed).
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "common.hpp"
+
+namespace polee {
+namespace {
+
+struct Edge {
+    uint32_t j1, j2;
+    float similarity;
+};
+struct NodeWithSize {
+    uint32_t j, size;
+};
+
+// DataStructures.jl BinaryHeap: `before(a, b)` = a must be nearer the root than b (strict)
+template <class T, class Before>
+struct BinHeap {
+    std::vector<T> xs;
+    Before before;
+    bool empty() const { return xs.empty(); }
+    size_t size() const { return xs.size(); }
+    void push(const T &x)
+    {
+        xs.push_back(x);
+        size_t i = xs.size();  // 1-based position
+        while (i > 1) {
+            const size_t j = i / 2;
+            if (before(x, xs[j - 1])) {
+                xs[i - 1] = xs[j - 1];
+                i = j;
+            } else
+                break;
+        }
+        xs[i - 1] = x;
+    }
+    T pop()
+    {
+        T top = xs[0];
+        T y = xs.back();
+        xs.pop_back();
+        const size_t len = xs.size();
+        if (len > 0) {
+            size_t i = 1;
+            for (;;) {
+                const size_t l = 2 * i, r = l + 1;
+                if (l > len) break;
+                const size_t j = (r > len || before(xs[l - 1], xs[r - 1])) ? l : r;
+                if (before(xs[j - 1], y)) {
+                    xs[i - 1] = xs[j - 1];
+                    i = j;
+                } else
+                    break;
+            }
+            xs[i - 1] = y;
+        }
+        return top;
+    }
+};
+struct EdgeBefore {
+    bool operator()(const Edge &a, const Edge &b) const { return a.similarity > b.similarity; }  // max-heap
+};
+struct SizeBefore {
+    bool operator()(const NodeWithSize &a, const NodeWithSize &b) const { return a.size < b.size; }  // min-heap
+};
+
+typedef std::vector<uint32_t> ReadSet;
+
+// hclust.jl:116-135
+size_t intersection_size(const ReadSet &a, const ReadSet &b)
+{
+    if (a.empty() || b.empty() || a.front() > b.back() || a.back() < b.front()) return 0;
+    size_t i = 0, j = 0, c = 0;
+    while (i < a.size() && j < b.size()) {
+        if (a[i] < b[j])
+            ++i;
+        else if (a[i] > b[j])
+            ++j;
+        else {
+            ++i;
+            ++j;
+            ++c;
+        }
+    }
+    return c;
+}
+// hclust.jl:143-152 (Float64 quotient, stored as Float32 in the edge)
+double relative_intersection(const ReadSet &a, const ReadSet &b)
+{
+    if (a.empty() && b.empty()) return 0.0;
+    const size_t is = intersection_size(a, b);
+    return (double)is / (double)(a.size() + b.size() - is);
+}
+// hclust.jl:150-190
+ReadSet merge_sets(const ReadSet &a, const ReadSet &b)
+{
+    ReadSet out;
+    out.reserve(a.size() + b.size());
+    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
+    return out;
+}
+
+struct TreeNode {
+    uint32_t j = 0;           // transcript (1-based), 0 = internal
+    int32_t left = -1, right = -1;
+};
+
+}  // namespace
+
+// Returns "" or an error message.  colptr/rowval: X in CSC, 1-based, rows ascending within a column.
+std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                         int32_t *node_parent_idxs, int32_t *node_js)
+{
+    if (n < 1 || m < 0 || !colptr || !node_parent_idxs || !node_js) return "bad argument";
+    if (colptr_bytes != 4 && colptr_bytes != 8) return "colptr_bytes must be 4 or 8";
+    auto cp = [&](int64_t j) -> uint64_t {
+        return colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j]
+                                 : reinterpret_cast<const uint64_t *>(colptr)[j];
+    };
+    if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
+    const int K = 25;  // neighbours compared left and right (:200)
+
+    // order transcripts by the median compatible read (:204-212); sortperm is stable
+    std::vector<uint32_t> med((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        if (cp(j + 1) < cp(j)) return "colptr is not monotone";
+        if (cp(j) == cp(j + 1))
+            med[(size_t)j] = 0;
+        else
+            med[(size_t)j] = rowval[(cp(j) + cp(j + 1)) / 2 - 1];  // 1-based position div(a + b, 2)
+    }
+    std::vector<uint32_t> idxs((size_t)n);
+    for (int64_t j = 0; j < n; ++j) idxs[(size_t)j] = (uint32_t)j;
+    std::stable_sort(idxs.begin(), idxs.end(), [&](uint32_t a, uint32_t b) { return med[a] < med[b]; });
+
+    // nodes 1..n are the leaves in that order; internal nodes are appended (:215-222)
+    std::vector<TreeNode> nodes((size_t)n + 1);  // [0] unused: ids are 1-based like the reference's keys
+    std::vector<ReadSet> read_sets((size_t)n + 1);
+    std::vector<char> alive((size_t)n + 1, 1), deleted((size_t)n + 1, 0);
+    nodes.reserve(2 * (size_t)n);
+    read_sets.reserve(2 * (size_t)n);
+    for (int64_t j = 1; j <= n; ++j) {
+        const uint32_t t = idxs[(size_t)j - 1];
+        nodes[(size_t)j].j = t + 1;
+        read_sets[(size_t)j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
+        for (size_t e = 1; e < read_sets[(size_t)j].size(); ++e)
+            if (read_sets[(size_t)j][e] <= read_sets[(size_t)j][e - 1]) return "row indexes of a column are not ascending";
+    }
+
+    // initial edges (:225-236)
+    BinHeap<Edge, EdgeBefore> queue;
+    std::vector<std::vector<uint32_t>> neighbors((size_t)n + 1);
+    neighbors.reserve(2 * (size_t)n);
+    for (int64_t j1 = 1; j1 <= n; ++j1)
+        for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
+            const double sim = relative_intersection(read_sets[(size_t)j1], read_sets[(size_t)j2]);
+            if (sim > 0) queue.push(Edge{(uint32_t)j1, (uint32_t)j2, (float)sim});
+            neighbors[(size_t)j1].push_back((uint32_t)j2);
+            neighbors[(size_t)j2].push_back((uint32_t)j1);
+        }
+
+    // greedy joining (:262-308)
+    while (!queue.empty()) {
+        const Edge e = queue.pop();
+        if (deleted[e.j1] || deleted[e.j2]) continue;  // stale edge
+        const uint32_t k = (uint32_t)nodes.size();
+        nodes.push_back(TreeNode{0, (int32_t)e.j1, (int32_t)e.j2});
+        read_sets.push_back(merge_sets(read_sets[e.j1], read_sets[e.j2]));
+        neighbors.emplace_back();
+        alive.push_back(1);
+        deleted.push_back(0);
+        ReadSet().swap(read_sets[e.j1]);
+        ReadSet().swap(read_sets[e.j2]);
+        alive[e.j1] = alive[e.j2] = 0;
+        deleted[e.j1] = deleted[e.j2] = 1;
+        const uint32_t pair[2][2] = {{e.j1, e.j2}, {e.j2, e.j1}};
+        for (const auto &ab : pair) {
+            const std::vector<uint32_t> list = neighbors[ab[0]];  // (copy: neighbors may reallocate)
+            for (uint32_t l : list) {
+                if (l == ab[1] || deleted[l]) continue;
+                const double sim = relative_intersection(read_sets[l], read_sets[k]);
+                if (sim != 0) queue.push(Edge{l, k, (float)sim});
+                neighbors[l].push_back(k);
+                neighbors[k].push_back(l);
+            }
+        }
+    }
+
+    // remaining components: smallest first (:244-258)
+    BinHeap<NodeWithSize, SizeBefore> rest;
+    for (uint32_t j = 1; j < nodes.size(); ++j)
+        if (alive[j]) rest.push(NodeWithSize{j, (uint32_t)(1 + read_sets[j].size())});
+    while (rest.size() > 1) {
+        const NodeWithSize a = rest.pop(), b = rest.pop();
+        const uint32_t k = (uint32_t)nodes.size();
+        nodes.push_back(TreeNode{0, (int32_t)a.j, (int32_t)b.j});
+        rest.push(NodeWithSize{k, a.size + b.size});
+    }
+    if (rest.size() != 1) return "internal error: no root";
+    const uint32_t root = rest.pop().j;
+    if (nodes.size() != 2 * (size_t)n) return "internal error: node count";
+
+    // order_nodes (:361-389): DFS, left pushed first so that the right child is visited first
+    std::vector<uint32_t> stack{root};
+    std::vector<int32_t> parent_of(nodes.size(), 0);
+    int64_t pos = 0;
+    while (!stack.empty()) {
+        const uint32_t v = stack.back();
+        stack.pop_back();
+        node_parent_idxs[pos] = parent_of[v];
+        node_js[pos] = (int32_t)nodes[v].j;
+        ++pos;
+        if (nodes[v].j == 0) {
+            parent_of[(size_t)nodes[v].left] = (int32_t)pos;
+            parent_of[(size_t)nodes[v].right] = (int32_t)pos;
+            stack.push_back((uint32_t)nodes[v].left);
+            stack.push_back((uint32_t)nodes[v].right);
+        }
+    }
+    if (pos != 2 * n - 1) return "internal error: tree size";
+    return "";
+}
+
+}  // namespace polee
+
+extern "C" polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                     int32_t *node_parent_idxs, int32_t *node_js)
+{
+    const std::string err = polee::hclust_build(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js);
+    if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
+    return POLEE_OK;
+}

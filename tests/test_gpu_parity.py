@@ -393,6 +393,30 @@ def test_full_fit_matches_reference_fit_statistically(P, ctx, lm_fixture, prep_f
     assert r > 0.99, r
 
 
+def test_fit_with_own_tree_is_as_good_as_the_reference_fit(P, ctx, lm_fixture, prep_fixture):
+    """approximate_likelihood(approx, sample) with NO tree given: the tree comes from polee_hclust
+    (PolyaTreeTransform(X, :cluster), ptt.jl:35-52).  The fitted approximation must explain the data as well as
+    the reference's own fit (which used its stored tree): expected log-likelihood within MC error + a small
+    margin, posterior means strongly correlated."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox("cluster"), s)
+    assert len(got["node_js"]) == 2 * f["n"] - 1
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to_ref = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    to_own = O.PTT(got["node_parent_idxs"], got["node_js"])
+    l = f["effective_lengths"]
+    lp_ref, pm_ref = _expected_loglik(so, to_ref, prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"], l, 100, 1000)
+    lp_fit, pm_fit = _expected_loglik(so, to_own, got["mu"], got["omega"], got["alpha"], l, 100, 7000)
+    assert lp_fit.mean() > lp_ref.mean() - (6 * np.hypot(lp_ref.std(), lp_fit.std()) / np.sqrt(100) + 10)
+    expressed = pm_ref > 1e-4
+    r = np.corrcoef(np.log(pm_ref[expressed]), np.log(pm_fit[expressed]))[0, 1]
+    assert r > 0.98, r
+    # the sequential (list) tree is accepted as well
+    got2 = P.approximate_likelihood(P.LogitSkewNormalPTTApprox("sequential"), s, num_steps=20)
+    assert np.isfinite(got2["mu"]).all()
+
+
 def test_sampler_matches_oracle(P, ctx, prep_fixture):
     t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
     to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])

@@ -267,3 +267,64 @@ def test_psell_rejects_bad_input():
         _psell(3, 2, np.array([1, 2, 3], np.uint32), np.array([1, 9], np.uint32), np.ones(2, np.float32))
     with pytest.raises(L.PoleeError):
         _psell(3, 2, np.array([0, 1, 2], np.uint32), np.array([1, 2], np.uint32), np.ones(2, np.float32))
+
+
+def _valid_tree(parents, js, n):
+    assert len(parents) == len(js) == 2 * n - 1 and parents[0] == 0
+    assert sorted(js[js > 0].tolist()) == list(range(1, n + 1))  # every transcript is a leaf exactly once
+    kids = np.bincount(parents[1:], minlength=2 * n)
+    internal = np.flatnonzero(js == 0) + 1
+    assert (kids[internal] == 2).all() and kids.sum() == 2 * n - 2
+    assert (parents[1:] < np.arange(2, 2 * n)).all()  # parents precede children (DFS pre-order)
+
+
+def test_hclust_matches_the_python_restatement_and_builds_valid_trees():
+    """polee_hclust (C++) against oracle/hclust_ref.py (plain Python restatement of hclust.jl:193-319,361-389)."""
+    from oracle import hclust_ref
+    import polee_amd as P
+    rng = np.random.default_rng(8)
+    for trial, (m, n) in enumerate([(60, 9), (300, 40), (500, 80), (40, 30)]):
+        import scipy.sparse as sp
+        dens = [0.3, 0.08, 0.05, 0.02][trial]  # the last one leaves many disconnected components (and an empty column)
+        X = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        X.sort_indices()
+        colptr, rowval = (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32)
+        pc, jc = P.hclust(m, n, colptr, rowval)
+        pr, jr = hclust_ref.hclust(m, n, colptr, rowval)
+        _valid_tree(pc, jc, n)
+        np.testing.assert_array_equal(pc, pr)
+        np.testing.assert_array_equal(jc, jr)
+
+
+def test_hclust_on_the_reference_fixture(lm_fixture, prep_fixture):
+    """Our tree for the fixture's X next to the tree the reference stored for it (prep fixture).  The stored tree is
+    NOT reproduced by hclust.jl as it stands -- in 83 of its 105 sibling-leaf pairs the two transcripts share no
+    read at all (an older heuristic or read order) -- so there is no exact pin for this row ("parity unpinned").
+    What is checked: both are valid trees over the same leaves, and ours does what the heuristic promises:
+    sibling leaves share reads."""
+    import polee_amd as P
+    f = lm_fixture
+    n = f["n"]
+    p, j = P.hclust(f["m"], n, f["colptr"], f["rowval"])
+    _valid_tree(p, j, n)
+    pf, jf = np.asarray(prep_fixture["node_parent_idxs"]), np.asarray(prep_fixture["node_js"])
+    _valid_tree(pf, jf, n)
+    colptr, rowval = f["colptr"].astype(np.int64), f["rowval"].astype(np.int64)
+    rs = [set(rowval[colptr[t] - 1:colptr[t + 1] - 1].tolist()) for t in range(n)]
+
+    def sibling_similarity(parents, js):
+        kids = [[] for _ in range(len(js))]
+        for i in range(1, len(js)):
+            kids[parents[i] - 1].append(i)
+        sims = []
+        for i in range(len(js)):
+            if js[i] == 0 and js[kids[i][0]] > 0 and js[kids[i][1]] > 0:
+                a, b = rs[js[kids[i][0]] - 1], rs[js[kids[i][1]] - 1]
+                sims.append(len(a & b) / max(len(a | b), 1))
+        return float(np.mean(sims))
+    ours, ref = sibling_similarity(p, j), sibling_similarity(pf, jf)
+    assert ours > 0.4 and ours > ref, (ours, ref)
+    # deterministic
+    p2, j2 = P.hclust(f["m"], n, f["colptr"], f["rowval"])
+    np.testing.assert_array_equal(p, p2)
+    np.testing.assert_array_equal(j, j2)
