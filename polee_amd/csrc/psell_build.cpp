@@ -2,6 +2,8 @@
 // Plays the role of `Xt = SparseMatrixCSC(transpose(X))` in the reference
 // (src/likelihood-approximation.jl:407): a one-off re-layout of X for the hot loop.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <numeric>
 
 #include "loglik_internal.hpp"
@@ -59,6 +61,13 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     int binsh = 8;
     if (const char *e = getenv("POLEE_PSELL_BINSH")) binsh = std::max(0, std::min(24, atoi(e)));
 
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[psell build] %-28s %.3f s\n", what, now() - t_prev);
+        t_prev = now();
+    };
     // 1. sort keys
     std::vector<uint64_t> keys;
     std::vector<uint32_t> rows;
@@ -84,7 +93,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         keys.push_back(key);
         rows.push_back((uint32_t)i);
     }
+    lap("keys");
     radix_sort_pairs(keys, rows);
+    lap("radix sort");
     keys.clear();
     keys.shrink_to_fit();
 
@@ -130,6 +141,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         run_end.insert(run_end.end(), e2.begin(), e2.end());
     }
 
+    lap("runs / stream split");
     // 2. greedy slices and tiles
     std::vector<uint32_t> col_stamp(n, 0);   // tile id + 1 in which the column was last registered
     std::vector<uint16_t> col_local(n, 0);
@@ -289,6 +301,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.num_slices_a = out.num_slices;
     }
     if (out.rows_a1 == out.rows_a) out.num_tiles_a1 = std::min(out.num_tiles_a1, out.num_tiles_a);
+    lap("slices and tiles");
     // 3. stream B: transposed copy of every tile (see PsellHost::tdata)
     {
         const int64_t ntb = out.num_tiles - out.num_tiles_a;
@@ -362,6 +375,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     }
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
+    lap("transposed copy (B)");
     if (out.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
     // the two flag bits of slice s ride in the top bits of slice_off[s] (one scalar/lane load per slice)
     for (int64_t s = 0; s < out.num_slices; ++s) out.slice_off[s] |= (uint32_t)(out.slice_flags[s] & 3u) << 30;
