@@ -180,7 +180,7 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         const uint32_t units = (slice_off[s + 1] & PSELL_OFF_MASK) - off;
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
-        const int w = compact ? (int)(units / 2u) - 1 : (int)(units / 3u);
+        const int w = compact ? (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0) : (int)(units / 3u);  // (+ a ks row when factored)
         // (compact slices store element r of row t at position (r + 4 t) & 63, see uniform_tile_body)
         const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0));
         auto vat = [&](int t) -> float { return vbase[t * 64 + (compact ? ((lane + 4 * t) & 63) : lane)]; };
@@ -460,7 +460,6 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
     const uint32_t *__restrict__ tile_slice = A.tile_slice;
     const uint32_t *__restrict__ tile_dict = A.tile_dict;
     const uint32_t *__restrict__ dict = A.dict;
-    const float *__restrict__ slice_ks = A.slice_ks;
     const float *__restrict__ x = A.x;
     float *__restrict__ g = A.g;
     double *__restrict__ lp = A.lp;
@@ -590,7 +589,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
         const uint32_t units = off_next - off;
-        const int w = (int)(units / 2u) - 1;  // 256-byte header (column ids) + w rows of 64 values
+        const int w = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // 256-byte header (column ids) + w rows of 64 values (+ ks row)
         const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
         STAMP(1);  // slice bookkeeping
@@ -663,9 +662,8 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         }
         // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt
         if (HAS_KS) {
-            // (with multiplicities these are the compiler-visible loads of the loop: the factored likelihood pays a
-            // vmcnt(0) per slice -- acceptable for the secondary variant)
-            const f32x4 *kp = reinterpret_cast<const f32x4 *>(slice_ks + (size_t)s * 64 + 16 * q);
+            // the multiplicities travel with the slice (its last row): no global load in this loop
+            const f32x4 *kp = reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)w * 256u) + 64 * q);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const f32x4 kv = kp[v];  // ks of fragments 16 q + 4 v + (0..3)
@@ -817,8 +815,8 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
                       ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a,
                       ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p};
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
-    static_assert((PSELL_NARROW_MAX + 1) * 256 + 1024 <= 6 * 1024, "A1 slices must fit a 6 KiB ring");
-    static_assert((PSELL_WIDE_MAX + 1) * 256 + 1024 <= 12 * 1024, "A2 slices must fit a 12 KiB ring");
+    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= 6 * 1024, "A1 slices (+ ks row) must fit a 6 KiB ring");
+    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= 12 * 1024, "A2 slices (+ ks row) must fit a 12 KiB ring");
     const size_t lds = (size_t)fused_ring_total<K>() + ((size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;

@@ -169,7 +169,13 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (cur_stream < 2) {
             // uniform streams: the 64 fragments share one transcript set, so the column ids are stored once:
             //   uint16 lcol[128] (256-byte header, w used) ; float val[w][64] (rows rotated, see below)
-            out.data.resize(base + 256 + (size_t)w * 256, 0);
+            // with row multiplicities (factored likelihood) a last row float ks[64] follows, so that they reach the
+            // kernel through the same stream as the values
+            out.data.resize(base + 256 + (size_t)w * 256 + (ks ? 256 : 0), 0);
+            if (ks) {
+                float *kr = reinterpret_cast<float *>(out.data.data() + base + 256 + (size_t)w * 256);
+                for (size_t lane = 0; lane < slice_rows.size(); ++lane) kr[lane] = (float)ks[slice_rows[lane]];
+            }
             uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
             float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
             const uint64_t b0 = rowptr[slice_rows[0]];

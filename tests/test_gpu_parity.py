@@ -233,6 +233,43 @@ def test_loglik_ragged_empty_rows_long_row_and_ks(P, ctx):
     np.testing.assert_allclose(g2, g, rtol=1e-6)
 
 
+def _equivalence_class_matrix(rng, n=300, classes=40, copies=200):
+    """Fragments in equivalence classes: `copies` rows per transcript set, as salmon's eq-classes / real data."""
+    import scipy.sparse as sp
+    rows, cols, vals = [], [], []
+    r = 0
+    for c in range(classes):
+        w = int(rng.integers(1, 30))
+        ts = np.sort(rng.choice(n, size=w, replace=False))
+        for _ in range(copies + int(rng.integers(0, 70))):
+            rows += [r] * w
+            cols += ts.tolist()
+            vals += rng.uniform(1e-6, 1e-3, w).tolist()
+            r += 1
+    X = sp.csc_matrix((np.array(vals, np.float32), (rows, cols)), shape=(r, n))
+    X.sort_indices()
+    return r, n, (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32), X.data.astype(np.float32)
+
+
+def test_factored_loglik_on_equivalence_classes(P, ctx):
+    """factored_log_likelihood (likelihood.jl:59-85) where almost every slice is uniform: the multiplicities reach
+    the matrix-core kernel through the slice stream."""
+    rng = np.random.default_rng(12)
+    m, n, colptr, rowval, nzval = _equivalence_class_matrix(rng)
+    ks = rng.integers(1, 50, m).astype(np.int64)
+    sk = P.RNASeqSample(m, n, colptr, rowval, nzval, ks=ks, ctx=ctx)
+    assert sk.info["stream_nnz"][0] + sk.info["stream_nnz"][1] > 0.8 * sk.info["nnz"]
+    x = np.clip(rng.dirichlet(np.ones(n), size=3), 1e-10, 1).astype(np.float32)
+    lpk, gk = P.factored_log_likelihood(sk, x)
+    rows = rowval.astype(np.int64) - 1
+    cols = np.repeat(np.arange(n), np.diff(colptr.astype(np.int64)))
+    for k in range(3):
+        sp_ = np.zeros(m); np.add.at(sp_, rows, (nzval * x[k][cols]).astype(np.float64))
+        assert abs(lpk[k] - (ks * np.log(sp_)).sum()) <= 1e-6 * abs(lpk[k])
+        gg = np.zeros(n); np.add.at(gg, cols, nzval.astype(np.float64) * ks[rows] / sp_[rows])
+        np.testing.assert_allclose(gk[k], gg, rtol=3e-5, atol=1e-7 * gg.max())
+
+
 def test_loglik_rejects_bad_input(P, ctx):
     with pytest.raises(P.PoleeError):
         P.RNASeqSample(3, 2, np.array([1, 2, 3], np.uint32), np.array([1, 9], np.uint32), np.ones(2, np.float32), ctx=ctx)

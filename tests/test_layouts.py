@@ -175,8 +175,11 @@ def _emulate_psell(ps, x, n):
             off = int(ps["slice_off"][s]) * 128
             nbytes = int(ps["slice_off"][s + 1]) * 128 - off
             if t < ps["num_tiles_a"]:  # compact uniform slice: one column-id header, then the values
-                w = nbytes // 256 - 1
+                w = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
                 assert ps["slice_flags"][s] & 1
+                if ps["ks"] is not None:  # the multiplicities also travel as the slice's last row
+                    np.testing.assert_array_equal(data[off + 256 + w * 256:off + 512 + w * 256].view(np.float32),
+                                                  ps["ks"][s * 64:(s + 1) * 64])
                 hdr = data[off:off + 256].view(np.uint16)[:w].astype(np.int64)
                 cols = np.repeat(hdr[:, None], 64, axis=1)
                 rot = data[off + 256:off + 256 + w * 256].view(np.float32).reshape(w, 64)
@@ -328,3 +331,27 @@ def test_hclust_on_the_reference_fixture(lm_fixture, prep_fixture):
     p2, j2 = P.hclust(f["m"], n, f["colptr"], f["rowval"])
     np.testing.assert_array_equal(p, p2)
     np.testing.assert_array_equal(j, j2)
+
+
+def test_psell_layout_with_multiplicities_on_equivalence_classes():
+    """Uniform slices carry the row multiplicities as their last row; the emulated pass equals the factored oracle."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(13)
+    n, rows, cols, vals, r = 120, [], [], [], 0
+    for c in range(12):
+        w = int(rng.integers(1, 30))
+        ts = np.sort(rng.choice(n, size=w, replace=False))
+        for _ in range(150 + int(rng.integers(0, 40))):
+            rows += [r] * w; cols += ts.tolist(); vals += rng.uniform(1e-6, 1e-3, w).tolist(); r += 1
+    X = sp.csc_matrix((np.array(vals, np.float32), (rows, cols)), shape=(r, n)); X.sort_indices()
+    colptr, rowval, nzval = (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32), X.data.astype(np.float32)
+    ks = rng.integers(1, 9, r).astype(np.int64)
+    ps = _psell(r, n, colptr, rowval, nzval, ks=ks)
+    assert ps["num_tiles_a"] > 0
+    x = rng.dirichlet(np.ones(n), size=2).astype(np.float32)
+    lp, g = _emulate_psell(ps, x, n)
+    so = O.Sample(r, n, colptr, rowval, nzval)
+    for k in range(2):
+        lp_o, g_o = so.factored_log_likelihood(ks, x[k])
+        assert abs(lp[k] - lp_o) < 1e-6 * abs(lp_o)
+        np.testing.assert_allclose(g[k], g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
