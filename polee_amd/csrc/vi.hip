@@ -35,9 +35,10 @@ __host__ __device__ inline void philox_round(uint32_t (&c)[4], const uint32_t (&
     c[2] = n2;
     c[3] = n3;
 }
-__device__ inline float philox_randn(uint64_t seed, uint32_t step, uint32_t draw, uint32_t k)
+// Four N(0,1) per Philox block: counter (k, draw / 4, step), two Box-Muller pairs.
+__device__ inline void philox_randn4(uint64_t seed, uint32_t step, uint32_t group, uint32_t k, float (&z)[4])
 {
-    uint32_t c[4] = {k, draw, step, 0x706f6c65u};
+    uint32_t c[4] = {k, group, step, 0x706f6c65u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -45,10 +46,23 @@ __device__ inline float philox_randn(uint64_t seed, uint32_t step, uint32_t draw
         key[0] += 0x9E3779B9u;
         key[1] += 0xBB67AE85u;
     }
-    // Box-Muller on two 32-bit uniforms in (0,1)
-    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // Box-Muller on two 24-bit uniforms in (0,1)
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * h] = r * cs;
+        z[2 * h + 1] = r * sn;
+    }
+}
+__device__ inline float philox_randn(uint64_t seed, uint32_t step, uint32_t draw, uint32_t k)
+{
+    float z[4];
+    philox_randn4(seed, step, draw >> 2, k, z);
+    return z[draw & 3];
 }
 
 struct NoiseSrc {
@@ -60,6 +74,24 @@ struct NoiseSrc {
     {
         if (z0) return z0[((int64_t)(step - 1) * K + d) * nm1 + k];
         return philox_randn(seed, (uint32_t)step, (uint32_t)d, (uint32_t)k);
+    }
+    // all KK draws of node k at once (one Philox block per four draws)
+    template <int KK>
+    __device__ inline void get_all(int step, int64_t k, float (&z)[KK]) const
+    {
+        if (z0) {
+#pragma unroll
+            for (int d = 0; d < KK; ++d) z[d] = z0[((int64_t)(step - 1) * K + d) * nm1 + k];
+            return;
+        }
+#pragma unroll
+        for (int g = 0; g < (KK + 3) / 4; ++g) {
+            float q[4];
+            philox_randn4(seed, (uint32_t)step, (uint32_t)g, (uint32_t)k, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < KK) z[4 * g + e] = q[e];
+        }
     }
 };
 
@@ -159,6 +191,7 @@ struct polee_vi {
     int32_t trace_cap = 0;
     polee_comm *comm = nullptr;  // row-sharded fit: sum the likelihood gradient (and lp) over ranks each pass
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
+    DevBuf<float> d_zcur;  // [n-1][K] the current iteration's N(0,1) draws
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
     DevBuf<int> d_flag;
@@ -193,7 +226,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     if (nm1 > 0 && (vi->ahead_step != step_num || want_values)) {
         hipLaunchKernelGGL((vi_sample_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st,
                            vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, noise, step_num, o.y_eps, vi->d_ys.p, vi->d_lyy.p,
-                           want_values ? vi->d_ladj_el.p : nullptr);
+                           vi->d_zcur.p, want_values ? vi->d_ladj_el.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
     }
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
@@ -256,7 +289,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
                            vi->d_vm.p, vi->d_mo.p, vi->d_vo.p, vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p,
                            hook_outputs ? vi->d_ygrad.p : nullptr, hook_outputs ? vi->d_mug.p : nullptr,
                            hook_outputs ? vi->d_omg.p : nullptr, hook_outputs ? vi->d_alg.p : nullptr,
-                           sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p);
+                           sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p, vi->d_zcur.p);
         POLEE_KERNEL_CHECK(ctx);
         vi->ahead_step = apply ? (sample_next ? step_num + 1 : 0) : step_num;
     }
@@ -353,6 +386,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
                              &vi->d_ma, &vi->d_va, &vi->d_mug, &vi->d_omg, &vi->d_alg})
         A(b->alloc(ctx, nm1));
     A(vi->d_x.alloc(ctx, n * K));
+    A(vi->d_zcur.alloc(ctx, nm1 * K));
     A(vi->d_g.alloc(ctx, n * K));
     A(vi->d_x_rows.alloc(ctx, n * K));
     A(vi->d_ys.alloc(ctx, nm1 * K));

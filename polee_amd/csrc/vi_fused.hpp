@@ -115,13 +115,17 @@ __device__ inline float sinh_asinh(float sa, float ca, float z0) { return fmaf(s
 // one node's K draws (shared by the sample kernel and the update kernel's look-ahead)
 template <int K, typename Noise>
 __device__ inline void sample_node(float m, float om, float al, const Noise &noise, int step, int64_t k, double y_eps,
-                                   double *__restrict__ ys, double *__restrict__ lyy, double *lsum)
+                                   double *__restrict__ ys, double *__restrict__ lyy, float *__restrict__ zcur,
+                                   double *lsum)
 {
     const float sigma = expf(om);
     const float sa = sinhf(al), ca = coshf(al);
+    float zall[K];
+    noise.template get_all<K>(step, k, zall);
 #pragma unroll
     for (int d = 0; d < K; ++d) {
-        const float z0 = noise.get(step, d, k);
+        const float z0 = zall[d];
+        zcur[k * K + d] = z0;  // kept for this iteration's update (no second pass through the generator)
         const float zs = sinh_asinh(sa, ca, z0);
         double y = (double)(1.0f / (1.0f + expf(-(m + zs * sigma))));
         if (lsum) {
@@ -140,7 +144,8 @@ template <int K, typename Noise>
 __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restrict__ mu, const float *__restrict__ omega,
                                                          const float *__restrict__ alpha, Noise noise, int step,
                                                          double y_eps, double *__restrict__ ys,
-                                                         double *__restrict__ lyy, double *__restrict__ ladj_out)
+                                                         double *__restrict__ lyy, float *__restrict__ zcur,
+                                                         double *__restrict__ ladj_out)
 {
     __shared__ double smem[4 * 2 * K];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restric
 #pragma unroll
     for (int d = 0; d < 2 * K; ++d) lsum[d] = 0.0;
     if (k < noise.nm1)
-        sample_node<K, Noise>(mu[k], omega[k], alpha[k], noise, step, k, y_eps, ys, lyy, ladj_out ? lsum : nullptr);
+        sample_node<K, Noise>(mu[k], omega[k], alpha[k], noise, step, k, y_eps, ys, lyy, zcur, ladj_out ? lsum : nullptr);
     if (ladj_out) {
         block_sum_vec<2 * K>(lsum, smem);
 #pragma unroll
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys,
                                                          float *m_omega, float *v_omega, float *m_alpha, float *v_alpha,
                                                          AdamConsts adam, int apply, int *nonfinite_step,
                                                          double *y_grad_out, float *mu_grad_out, float *omega_grad_out,
-                                                         float *alpha_grad_out, int sample_next, double y_eps, double *lyy)
+                                                         float *alpha_grad_out, int sample_next, double y_eps, double *lyy,
+                                                         float *zcur)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nm1 = v.n - 1;
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys,
         const double ygd = Hl / y - Hr / (1.0 - y);
         if (y_grad_out) y_grad_out[(int64_t)d * nm1 + k] = ygd;
         const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
-        const float z0 = noise.get(step, d, k);
+        const float z0 = zcur[k * K + d];  // this iteration's draw, left by the sampling step
         const float zs = sinh_asinh(sa, ca, z0);
         const float cc = sqrtf(fmaf(zs, zs, 1.0f));  // cosh(alpha + asinh z0)
         const double dyy = y * (1 - y);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys,
     }
     // look-ahead: the next iteration's draws from the parameters just written (this thread is the only one that
     // touches node k's ys / lyy, and its reads of ys[k] are done)
-    if (sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, step + 1, k, y_eps, ys, lyy, nullptr);
+    if (sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, step + 1, k, y_eps, ys, lyy, zcur, nullptr);
 }
 
 // ---- point optimisation (OptimizePTTApprox, likelihood-approximation.jl:149-242), K = 1 ------------------
