@@ -9,7 +9,11 @@
 // a stable sort, neighbour lists in insertion order, and visits the remaining components in ascending node id
 // (the one place where Julia's hash order cannot be followed).
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -133,6 +137,13 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     };
     if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
     const int K = 25;  // neighbours compared left and right (:200)
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[hclust] %-24s %.3f s\n", what, now() - t_prev);
+        t_prev = now();
+    };
 
     // order transcripts by the median compatible read (:204-212); sortperm is stable
     std::vector<uint32_t> med((size_t)n);
@@ -165,13 +176,31 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     BinHeap<Edge, EdgeBefore> queue;
     std::vector<std::vector<uint32_t>> neighbors((size_t)n + 1);
     neighbors.reserve(2 * (size_t)n);
+    lap("read sets");
+    // (the n x 25 similarities are independent: computed by a few threads, then pushed in the reference's order)
+    std::vector<float> sims((size_t)n * K, 0.0f);
+    {
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned th = 0; th < hw; ++th)
+            pool.emplace_back([&, th]() {
+                for (int64_t j1 = 1 + th; j1 <= n; j1 += hw)
+                    for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2)
+                        sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)] =
+                            (float)relative_intersection(read_sets[(size_t)j1], read_sets[(size_t)j2]);
+            });
+        for (auto &t : pool) t.join();
+    }
+    lap("initial similarities");
     for (int64_t j1 = 1; j1 <= n; ++j1)
         for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
-            const double sim = relative_intersection(read_sets[(size_t)j1], read_sets[(size_t)j2]);
-            if (sim > 0) queue.push(Edge{(uint32_t)j1, (uint32_t)j2, (float)sim});
+            const float sim = sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)];
+            if (sim > 0) queue.push(Edge{(uint32_t)j1, (uint32_t)j2, sim});
             neighbors[(size_t)j1].push_back((uint32_t)j2);
             neighbors[(size_t)j2].push_back((uint32_t)j1);
         }
+    std::vector<float>().swap(sims);
+    lap("initial edges");
 
     // greedy joining (:262-308)
     while (!queue.empty()) {
@@ -200,6 +229,7 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         }
     }
 
+    lap("greedy joining");
     // remaining components: smallest first (:244-258)
     BinHeap<NodeWithSize, SizeBefore> rest;
     for (uint32_t j = 1; j < nodes.size(); ++j)
