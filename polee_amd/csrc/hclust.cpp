@@ -203,6 +203,9 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     lap("initial edges");
 
     // greedy joining (:262-308)
+    std::vector<uint32_t> cand;
+    std::vector<double> csim;
+    const unsigned hw_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     while (!queue.empty()) {
         const Edge e = queue.pop();
         if (deleted[e.j1] || deleted[e.j2]) continue;  // stale edge
@@ -216,16 +219,33 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         ReadSet().swap(read_sets[e.j2]);
         alive[e.j1] = alive[e.j2] = 0;
         deleted[e.j1] = deleted[e.j2] = 1;
+        // candidates in the reference's order (:291-305): live neighbours of j1 then of j2, duplicates included
+        cand.clear();
         const uint32_t pair[2][2] = {{e.j1, e.j2}, {e.j2, e.j1}};
-        for (const auto &ab : pair) {
-            const std::vector<uint32_t> list = neighbors[ab[0]];  // (copy: neighbors may reallocate)
-            for (uint32_t l : list) {
-                if (l == ab[1] || deleted[l]) continue;
-                const double sim = relative_intersection(read_sets[l], read_sets[k]);
-                if (sim != 0) queue.push(Edge{l, k, (float)sim});
-                neighbors[l].push_back(k);
-                neighbors[k].push_back(l);
-            }
+        for (const auto &ab : pair)
+            for (uint32_t l : neighbors[ab[0]])
+                if (l != ab[1] && !deleted[l]) cand.push_back(l);
+        csim.resize(cand.size());
+        size_t work = 0;
+        for (uint32_t l : cand) work += read_sets[l].size() + read_sets[k].size();
+        auto eval = [&](size_t lo, size_t hi) {
+            for (size_t c = lo; c < hi; ++c) csim[c] = relative_intersection(read_sets[cand[c]], read_sets[k]);
+        };
+        if (work > (size_t)4000000 && cand.size() >= 8 && hw_threads > 1) {  // a heavy merge: share it out
+            const unsigned nt = (unsigned)std::min<size_t>(hw_threads, cand.size() / 4);
+            std::vector<std::thread> pool;
+            for (unsigned th = 1; th < nt; ++th)
+                pool.emplace_back(eval, cand.size() * th / nt, cand.size() * (th + 1) / nt);
+            eval(0, cand.size() / nt);
+            for (auto &t : pool) t.join();
+        } else {
+            eval(0, cand.size());
+        }
+        for (size_t c = 0; c < cand.size(); ++c) {
+            const uint32_t l = cand[c];
+            if (csim[c] != 0) queue.push(Edge{l, k, (float)csim[c]});
+            neighbors[l].push_back(k);
+            neighbors[k].push_back(l);
         }
     }
 
