@@ -59,6 +59,26 @@ def test_c2_homogeneity_and_kernel_cross_check(c2):
     np.testing.assert_allclose(g3, 2 * g[0], rtol=2e-4, atol=1e-6 * np.abs(g).max())
 
 
+@pytest.mark.parametrize("K", [3, 8])
+def test_c2_other_draw_counts(c2, K):
+    """The fused kernel is specialised per K (K = 7, 8 run with fewer workgroups per CU): homogeneity and agreement
+    with the second algorithm at full size for draw counts other than the production 6."""
+    P, ctx, smp, s = c2
+    from polee_amd import _lib as L
+    rng = np.random.default_rng(K)
+    x = rng.gamma(0.3, size=(K, N)).astype(np.float32) + np.float32(1e-7)
+    x /= x.sum(axis=1, keepdims=True)
+    x = np.clip(x, np.float32(1e-10), 1)
+    lp, g = s.log_likelihood(x)
+    for k in range(K):
+        assert abs(float(g[k] @ x[k].astype(np.float64)) - M) < 2e-5 * M
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 1))
+    lp2, g2 = s.log_likelihood(x)
+    L.check(L.lib().polee_debug_loglik_force_mixed(s._h, 0))
+    np.testing.assert_allclose(lp2, lp, rtol=1e-7)
+    np.testing.assert_allclose(g2, g, rtol=2e-4, atol=1e-6 * np.abs(g).max())
+
+
 @pytest.mark.parametrize("kind", ["hclust", "spine"])
 def test_c2_tree_roundtrip_any_depth(c2, kind):
     """transform / inverse round trip on 200 000 leaves, also for a spine (depth n-1, the reference's

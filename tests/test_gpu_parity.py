@@ -603,3 +603,38 @@ def test_row_sharded_fit_with_one_rank_equals_the_plain_fit(P, ctx, lm_fixture, 
     for a, b in zip(out[0][0], out[1][0]):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(out[0][1][1], out[1][1][1], rtol=1e-6)  # expected log-likelihood trace
+
+
+def test_handles_release_device_memory(P, lm_fixture, prep_fixture):
+    """create / destroy cycles of every handle type (in arbitrary finaliser order) give the device memory back."""
+    import gc
+    import torch
+    f = lm_fixture
+    torch.cuda.init()
+
+    def free_bytes():
+        gc.collect()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    def cycle():
+        ctx = P.Context(0)
+        s = P.RNASeqSample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"], ctx=ctx)
+        t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+        fit = P.LikelihoodApproximationFit(s, t, num_steps=3, num_mc_samples=6)
+        fit.run(3)
+        fit.sync()
+        comm = P.Comm(ctx, 1, 0)
+        fit2 = P.LikelihoodApproximationFit(s, t, num_steps=2, num_mc_samples=2, comm=comm)
+        fit2.run(2)
+        fit2.sync()
+        # drop in an order that differs from creation order: parents before children
+        del ctx, s, t
+        del comm
+        del fit, fit2
+
+    cycle()  # first cycle pays one-off allocations (module load, RCCL)
+    base = free_bytes()
+    for _ in range(5):
+        cycle()
+    assert base - free_bytes() < 8 << 20, (base, free_bytes())
