@@ -631,9 +631,10 @@ def test_handles_release_device_memory(P, lm_fixture, prep_fixture):
         # drop in an order that differs from creation order: parents before children
         del ctx, s, t
         del comm
-        del fit, fit2
+        del fit2, fit
 
-    cycle()  # first cycle pays one-off allocations (module load, RCCL)
+    cycle()
+    cycle()  # the first cycles pay one-off allocations (code objects, RCCL and allocator pools: ~56 MB, then flat)
     base = free_bytes()
     for _ in range(5):
         cycle()
