@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "loglik_internal.hpp"
 
@@ -48,6 +50,25 @@ static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> 
     }
 }
 
+// f(i) for i in [0, count) on a few host threads (dynamic chunks of `grain`)
+template <class F>
+static void parallel_chunks(size_t count, size_t grain, F &&f)
+{
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nchunks = (count + grain - 1) / grain;
+    if (hw == 1 || nchunks <= 1) {
+        for (size_t c = 0; c < nchunks; ++c) f(c * grain, std::min(count, (c + 1) * grain), 0u);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned th = 0; th < std::min<size_t>(hw, nchunks); ++th)
+        pool.emplace_back([&, th]() {
+            for (size_t c = next++; c < nchunks; c = next++) f(c * grain, std::min(count, (c + 1) * grain), th);
+        });
+    for (auto &t : pool) t.join();
+}
+
 std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
                         const int64_t *ks, PsellHost &out)
 {
@@ -68,30 +89,52 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (timing) fprintf(stderr, "[psell build] %-28s %.3f s\n", what, now() - t_prev);
         t_prev = now();
     };
-    // 1. sort keys
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> rows;
-    keys.reserve(m);
-    rows.reserve(m);
-    for (int64_t i = 0; i < m; ++i) {
-        const uint64_t b = rowptr[i], e = rowptr[i + 1];
-        if (e < b) return "row offsets are not monotone";
-        const uint64_t len = e - b;
-        if (len == 0) {
-            ++out.empty_rows;
-            continue;
+    // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards)
+    std::vector<uint64_t> keys((size_t)m);
+    std::vector<uint32_t> rows((size_t)m);
+    {
+        std::atomic<int> err{0};
+        std::atomic<int64_t> empties{0};
+        std::atomic<int32_t> max_row{0};
+        parallel_chunks((size_t)m, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
+            int64_t em = 0;
+            int32_t mr = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                const uint64_t b = rowptr[i], e = rowptr[i + 1];
+                rows[i] = (uint32_t)i;
+                if (e < b) { err = 1; keys[i] = ~0ull; continue; }
+                const uint64_t len = e - b;
+                if (len == 0) { ++em; keys[i] = ~0ull; continue; }
+                if (len > (uint64_t)PSELL_MAX_TILE_COLS) { err = 2; keys[i] = ~0ull; continue; }
+                uint32_t h = 0x12345u, first = col[b];
+                for (uint64_t k = b; k < e; ++k) {
+                    if (col[k] >= (uint64_t)n) err = 3;
+                    h = mix32(h, col[k]);
+                    first = std::min(first, col[k]);
+                }
+                mr = std::max(mr, (int32_t)len);
+                keys[i] = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)std::min<uint64_t>(len, 255) << 32) | h;
+            }
+            empties += em;
+            int32_t cur = max_row.load();
+            while (mr > cur && !max_row.compare_exchange_weak(cur, mr)) {}
+        });
+        if (err == 1) return "row offsets are not monotone";
+        if (err == 2) return "a fragment is compatible with more than 1024 transcripts";
+        if (err == 3) return "transcript index out of range";
+        out.empty_rows = empties;
+        out.max_row = max_row;
+        if (out.empty_rows > 0) {  // drop the empty rows (stable)
+            size_t w = 0;
+            for (size_t i = 0; i < (size_t)m; ++i)
+                if (keys[i] != ~0ull) {
+                    keys[w] = keys[i];
+                    rows[w] = rows[i];
+                    ++w;
+                }
+            keys.resize(w);
+            rows.resize(w);
         }
-        if (len > (uint64_t)PSELL_MAX_TILE_COLS) return "a fragment is compatible with more than 1024 transcripts";
-        uint32_t h = 0x12345u, first = col[b];
-        for (uint64_t k = b; k < e; ++k) {
-            if (col[k] >= (uint64_t)n) return "transcript index out of range";
-            h = mix32(h, col[k]);
-            first = std::min(first, col[k]);
-        }
-        out.max_row = std::max<int32_t>(out.max_row, (int32_t)len);
-        const uint64_t key = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)std::min<uint64_t>(len, 255) << 32) | h;
-        keys.push_back(key);
-        rows.push_back((uint32_t)i);
     }
     lap("keys");
     radix_sort_pairs(keys, rows);
@@ -112,11 +155,16 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
             return l1 == l2 && std::equal(col + rowptr[r1], col + rowptr[r1] + l1, col + rowptr[r2]);
         };
+        // head[i]: row i starts a new run (comparisons in parallel)
+        std::vector<uint8_t> head(rows.size() + 1, 1);
+        parallel_chunks(rows.size(), (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
+        });
         std::vector<uint32_t> ra1, ra2, rb, e1, e2;
         size_t i = 0;
         while (i < rows.size()) {
             size_t j = i + 1;
-            while (j < rows.size() && same_set(rows[i], rows[j])) ++j;
+            while (j < rows.size() && !head[j]) ++j;
             const size_t r = j - i;
             const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
             size_t take = (r / PSELL_LANES) * PSELL_LANES;
@@ -142,25 +190,64 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     }
 
     lap("runs / stream split");
-    // 2. greedy slices and tiles
-    std::vector<uint32_t> col_stamp(n, 0);   // tile id + 1 in which the column was last registered
-    std::vector<uint16_t> col_local(n, 0);
-    out.data.reserve((size_t)((double)out.nnz * 6.6) + 4096);
+    // 2. greedy slices and tiles.  The three streams are cut into SEGMENTS of about a million rows (at slice
+    // boundaries; every segment starts a fresh tile) which are laid out independently, on several host threads, and
+    // concatenated afterwards.  The cut points depend on the data only, not on the number of threads.
+    struct Segment {
+        size_t ra, rb;  // rows[ra, rb)
+        int stream;     // 0 = A1, 1 = A2, 2 = B
+        PsellHost frag;
+    };
+    std::vector<Segment> segs;
+    {
+        static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
+        const size_t SEG_ROWS = seg_env >= 64 ? seg_env : (size_t)1 << 20;
+        const size_t bounds[4] = {0, (size_t)out.rows_a1, (size_t)out.rows_a, rows.size()};
+        for (int st = 0; st < 3; ++st) {
+            size_t a = bounds[st];
+            while (a < bounds[st + 1]) {
+                size_t e = std::min(bounds[st + 1], a + SEG_ROWS);
+                if (e < bounds[st + 1]) {
+                    if (st < 2) {
+                        while (e < bounds[st + 1] && !run_end[e - 1]) ++e;  // uniform streams: end on a closed slice
+                    } else {  // mixed stream: whole tiles of 16 slices
+                        const size_t tile_rows = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
+                        e = std::min(bounds[st + 1], a + ((e - a + tile_rows - 1) / tile_rows) * tile_rows);
+                    }
+                }
+                segs.push_back(Segment{a, e, st, PsellHost()});
+                a = e;
+            }
+        }
+    }
+    static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
+    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<uint32_t>> stamps(nthreads);
+    std::vector<std::vector<uint16_t>> locals(nthreads);
+    std::vector<uint32_t> next_tile_id(nthreads, 1);
+    auto emit_segment = [&](Segment &sg, unsigned th) {
+    PsellHost &out = sg.frag;  // (shadows the result: a segment fills its own fragment)
+    if (stamps[th].empty()) {
+        stamps[th].assign((size_t)n, 0);
+        locals[th].assign((size_t)n, 0);
+    }
+    std::vector<uint32_t> &col_stamp = stamps[th];   // tile id in which the column was last registered
+    std::vector<uint16_t> &col_local = locals[th];
+    const int cur_stream = sg.stream;
+    out.data.reserve((size_t)((double)(rowptr[m] / std::max<size_t>(rows.size(), 1)) * 6.6 * (double)(sg.rb - sg.ra)) + 4096);
     out.slice_off.push_back(0);
     out.tile_slice.push_back(0);
     out.tile_dict.push_back(0);
-    if (ks) out.slice_ks.reserve(rows.size() + 64);
-    out.row_order.reserve(rows.size() + 64);
+    if (ks) out.slice_ks.reserve(sg.rb - sg.ra + 64);
+    out.row_order.reserve(sg.rb - sg.ra + 64);
 
-    uint32_t tile_id = 1;        // stamp of the current tile
+    uint32_t &tile_id = next_tile_id[th];  // stamp of the current tile (unique per thread)
     uint32_t tile_cols = 0;      // dictionary size of the current tile
     uint32_t tile_nslices = 0;
     std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
     slice_rows.reserve(PSELL_LANES);
     std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
     bool prev_uniform = false;
-    int cur_stream = 0;  // 0 = A1, 1 = A2, 2 = B
-
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
         uint32_t w = 0;
@@ -254,22 +341,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         tile_nslices = 0;
     };
 
-    for (size_t ri = 0; ri < rows.size(); ++ri) {
-        if ((int64_t)ri == out.rows_a1) {  // stream A1 ends here: start A2 on a fresh tile
-            close_slice();
-            close_tile();
-            out.num_tiles_a1 = out.num_tiles;
-            prev_uniform = false;
-            cur_stream = 1;
-        }
-        if ((int64_t)ri == out.rows_a) {  // stream A ends here: start stream B on a fresh tile
-            close_slice();
-            close_tile();
-            out.num_tiles_a = out.num_tiles;
-            out.num_slices_a = out.num_slices;
-            prev_uniform = false;
-            cur_stream = 2;
-        }
+    for (size_t ri = sg.ra; ri < sg.rb; ++ri) {
         const uint32_t r = rows[ri];
         const uint64_t b = rowptr[r], e = rowptr[r + 1];
         for (;;) {
@@ -289,24 +361,105 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
         slice_rows.push_back(r);
-        const bool boundary = (int64_t)ri < out.rows_a ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
+        const bool boundary = cur_stream < 2 ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
         if (boundary) {
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
-            static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
-            const uint32_t cap = (int64_t)ri < out.rows_a1 ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
-                                 : (int64_t)ri < out.rows_a ? PSELL_TILE_SLICES_A2 : PSELL_TILE_SLICES_B;
+            const uint32_t cap = cur_stream == 0 ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
+                                 : cur_stream == 1 ? PSELL_TILE_SLICES_A2 : PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }
     }
     close_slice();
     close_tile();
-    if ((int64_t)rows.size() == out.rows_a1) out.num_tiles_a1 = out.num_tiles;
-    if ((int64_t)rows.size() == out.rows_a) {
-        out.num_tiles_a = out.num_tiles;
-        out.num_slices_a = out.num_slices;
+    };  // emit_segment
+    {
+        std::atomic<size_t> next{0};
+        auto worker = [&](unsigned th) {
+            for (size_t i = next++; i < segs.size(); i = next++) emit_segment(segs[i], th);
+        };
+        std::vector<std::thread> pool;
+        const unsigned nt = (unsigned)std::min<size_t>(nthreads, std::max<size_t>(segs.size(), 1));
+        for (unsigned th = 1; th < nt; ++th) pool.emplace_back(worker, th);
+        worker(0);
+        for (auto &t : pool) t.join();
     }
-    if (out.rows_a1 == out.rows_a) out.num_tiles_a1 = std::min(out.num_tiles_a1, out.num_tiles_a);
+    lap("slices and tiles (segments)");
+    // concatenate the fragments
+    {
+        size_t tot_data = 0, tot_slices = 0, tot_tiles = 0, tot_dict = 0;
+        for (const Segment &sg : segs) {
+            tot_data += sg.frag.data.size();
+            tot_slices += (size_t)sg.frag.num_slices;
+            tot_tiles += (size_t)sg.frag.num_tiles;
+            tot_dict += sg.frag.dict.size();
+        }
+        out.data.resize(tot_data);
+        out.slice_off.assign(1, 0);
+        out.tile_slice.assign(1, 0);
+        out.tile_dict.assign(1, 0);
+        out.slice_off.reserve(tot_slices + 1);
+        out.tile_slice.reserve(tot_tiles + 1);
+        out.tile_dict.reserve(tot_tiles + 1);
+        out.dict.reserve(tot_dict);
+        out.slice_flags.reserve(tot_slices);
+        out.row_order.reserve(tot_slices * 64);
+        if (ks) out.slice_ks.reserve(tot_slices * 64);
+        std::vector<size_t> data_base(segs.size());
+        size_t dbase = 0;
+        int last_stream = 0;
+        for (size_t si = 0; si < segs.size(); ++si) {
+            Segment &sg = segs[si];
+            PsellHost &f = sg.frag;
+            // stream boundaries in tile / slice numbering
+            for (; last_stream < sg.stream; ++last_stream) {
+                if (last_stream == 0) out.num_tiles_a1 = out.num_tiles;
+                if (last_stream == 1) {
+                    out.num_tiles_a = out.num_tiles;
+                    out.num_slices_a = out.num_slices;
+                }
+            }
+            data_base[si] = dbase;
+            const uint32_t unit_base = (uint32_t)(dbase / 128), slice_base = (uint32_t)out.num_slices,
+                           dict_base = (uint32_t)out.dict.size(), tile_base = (uint32_t)out.num_tiles;
+            if (dbase / 128 + f.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
+            for (size_t q = 1; q < f.slice_off.size(); ++q) out.slice_off.push_back(f.slice_off[q] + unit_base);
+            for (size_t q = 1; q < f.tile_slice.size(); ++q) out.tile_slice.push_back(f.tile_slice[q] + slice_base);
+            for (size_t q = 1; q < f.tile_dict.size(); ++q) out.tile_dict.push_back(f.tile_dict[q] + dict_base);
+            out.dict.insert(out.dict.end(), f.dict.begin(), f.dict.end());
+            out.slice_flags.insert(out.slice_flags.end(), f.slice_flags.begin(), f.slice_flags.end());
+            out.row_order.insert(out.row_order.end(), f.row_order.begin(), f.row_order.end());
+            if (ks) out.slice_ks.insert(out.slice_ks.end(), f.slice_ks.begin(), f.slice_ks.end());
+            for (uint32_t bt : f.big_tiles) out.big_tiles.push_back(bt + tile_base);
+            for (int q = 0; q < 3; ++q) {
+                out.stream_rows[q] += f.stream_rows[q];
+                out.stream_nnz[q] += f.stream_nnz[q];
+                out.stream_bytes[q] += f.stream_bytes[q];
+            }
+            out.padded_nnz += f.padded_nnz;
+            out.max_tile_cols = std::max(out.max_tile_cols, f.max_tile_cols);
+            out.num_slices += f.num_slices;
+            out.num_tiles += f.num_tiles;
+            dbase += f.data.size();
+        }
+        for (; last_stream < 2; ++last_stream) {
+            if (last_stream == 0) out.num_tiles_a1 = out.num_tiles;
+            if (last_stream == 1) {
+                out.num_tiles_a = out.num_tiles;
+                out.num_slices_a = out.num_slices;
+            }
+        }
+        // the bulk copy in parallel
+        parallel_chunks(segs.size(), 1, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t si = lo; si < hi; ++si) {
+                const std::vector<uint8_t> &d = segs[si].frag.data;
+                if (!d.empty()) memcpy(out.data.data() + data_base[si], d.data(), d.size());
+                std::vector<uint8_t>().swap(segs[si].frag.data);
+            }
+        });
+        segs.clear();
+    }
+    std::vector<uint16_t> col_local((size_t)n, 0);  // (scratch of the transposed-copy pass below)
     lap("slices and tiles");
     // 3. stream B: transposed copy of every tile (see PsellHost::tdata)
     {

@@ -355,3 +355,32 @@ def test_psell_layout_with_multiplicities_on_equivalence_classes():
         lp_o, g_o = so.factored_log_likelihood(ks, x[k])
         assert abs(lp[k] - lp_o) < 1e-6 * abs(lp_o)
         np.testing.assert_allclose(g[k], g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
+
+
+def test_psell_layout_built_in_many_segments(lm_fixture):
+    """The builder lays out segments of rows independently (in parallel) and concatenates them; with tiny segments
+    the fixture is cut into dozens of them and must still reproduce the oracle."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        from test_layouts import _psell, _emulate_psell
+        from oracle import oracle as O
+        d = np.load(%r)
+        m, n = int(d["m"].item()), int(d["n"].item())
+        ps = _psell(m, n, d["colptr"], d["rowval"], d["nzval"])
+        ro = ps["row_order"]
+        assert sorted(ro[ro != 0xFFFFFFFF].tolist()) == list(range(m))
+        assert ps["num_tiles"] > 20, ps["num_tiles"]
+        x = np.random.default_rng(0).dirichlet(np.ones(n), size=2).astype(np.float32)
+        lp, g = _emulate_psell(ps, x, n)
+        s = O.Sample(m, n, d["colptr"], d["rowval"], d["nzval"])
+        for k in range(2):
+            lp_o, g_o = s.log_likelihood(x[k])
+            assert abs(lp[k] - lp_o) < 1e-6 * abs(lp_o)
+            np.testing.assert_allclose(g[k], g_o, rtol=1e-6, atol=1e-9)
+        print("ok")
+    """) % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "mBr_M_6w_1.likelihood-matrix.npz"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POLEE_PSELL_SEG_ROWS="512"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
