@@ -8,7 +8,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
+#include <vector>
 #include <vector>
 
 #include "../../include/polee_hip.h"
@@ -117,6 +121,26 @@ struct DevBuf {
         return POLEE_OK;
     }
 };
+
+// f(lo, hi, thread) over [0, count) in chunks of `grain` on a few host threads (dynamic assignment)
+template <class F>
+inline void parallel_chunks(size_t count, size_t grain, F &&f)
+{
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nchunks = (count + grain - 1) / grain;
+    if (hw == 1 || nchunks <= 1) {
+        for (size_t c = 0; c < nchunks; ++c) f(c * grain, std::min(count, (c + 1) * grain), 0u);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned th = 0; th < std::min<size_t>(hw, nchunks); ++th)
+        pool.emplace_back([&, th]() {
+            for (size_t c = next++; c < nchunks; c = next++) f(c * grain, std::min(count, (c + 1) * grain), th);
+        });
+    for (auto &t : pool) t.join();
+}
+
 
 inline polee_status use_device(polee_ctx *ctx)
 {

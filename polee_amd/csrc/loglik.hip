@@ -1024,21 +1024,51 @@ std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_byte
     rowptr.assign(m + 1, 0);
     for (int64_t j = 0; j < n; ++j)
         if (cp(j + 1) < cp(j)) return "colptr is not monotone";
-    for (uint64_t k = 0; k < nnz; ++k) {
-        const uint32_t r = rowval[k];
-        if (r < 1 || (int64_t)r > m) return "rowval out of range";
-        rowptr[r]++;
-    }
+    // On several host threads: count per row (atomic increments), prefix sum, scatter through atomic cursors
+    // (arbitrary order inside a row), then sort every row by transcript -- the result is the same as a
+    // sequential transposition because a row holds every transcript at most once.
+    std::atomic<int> err{0};
+    parallel_chunks((size_t)nnz, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t k = lo; k < hi; ++k) {
+            const uint32_t r = rowval[k];
+            if (r < 1 || (int64_t)r > m) {
+                err = 1;
+                continue;
+            }
+            __atomic_fetch_add(&rowptr[r], (uint64_t)1, __ATOMIC_RELAXED);
+        }
+    });
+    if (err) return "rowval out of range";
     for (int64_t i = 0; i < m; ++i) rowptr[i + 1] += rowptr[i];
     col.resize(nnz);
     val.resize(nnz);
     std::vector<uint64_t> cursor(rowptr.begin(), rowptr.end() - 1);
-    for (int64_t j = 0; j < n; ++j)
-        for (uint64_t k = cp(j) - 1; k < cp(j + 1) - 1; ++k) {
-            const uint64_t p = cursor[rowval[k] - 1]++;
-            col[p] = (uint32_t)j;
-            val[p] = nzval[k];
+    parallel_chunks((size_t)n, 1024, [&](size_t jlo, size_t jhi, unsigned) {
+        for (size_t j = jlo; j < jhi; ++j)
+            for (uint64_t k = cp((int64_t)j) - 1; k < cp((int64_t)j + 1) - 1; ++k) {
+                const uint64_t p = __atomic_fetch_add(&cursor[rowval[k] - 1], (uint64_t)1, __ATOMIC_RELAXED);
+                col[p] = (uint32_t)j;
+                val[p] = nzval[k];
+            }
+    });
+    std::vector<uint64_t>().swap(cursor);
+    parallel_chunks((size_t)m, (size_t)1 << 16, [&](size_t ilo, size_t ihi, unsigned) {
+        for (size_t i = ilo; i < ihi; ++i) {
+            const uint64_t b = rowptr[i], e = rowptr[i + 1];
+            for (uint64_t p = b + 1; p < e; ++p) {  // insertion sort: rows are short
+                const uint32_t c = col[p];
+                const float v = val[p];
+                uint64_t q = p;
+                while (q > b && col[q - 1] > c) {
+                    col[q] = col[q - 1];
+                    val[q] = val[q - 1];
+                    --q;
+                }
+                col[q] = c;
+                val[q] = v;
+            }
         }
+    });
     return "";
 }
 }  // namespace polee
@@ -1064,9 +1094,15 @@ polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, c
     std::vector<uint64_t> rowptr(m + 1);
     for (int64_t i = 0; i <= m; ++i) rowptr[i] = tcolptr[i] - 1;
     std::vector<uint32_t> col(nnz);
-    for (uint64_t k = 0; k < nnz; ++k) {
-        if (trowval[k] < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "trowval must be 1-based");
-        col[k] = trowval[k] - 1;
+    {
+        std::atomic<int> bad{0};
+        parallel_chunks((size_t)nnz, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t k = lo; k < hi; ++k) {
+                if (trowval[k] < 1) bad = 1;
+                col[k] = trowval[k] - 1;
+            }
+        });
+        if (bad) return fail(ctx, POLEE_ERR_BAD_ARG, "trowval must be 1-based");
     }
     polee_loglik *ll = new (std::nothrow) polee_loglik();
     if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");

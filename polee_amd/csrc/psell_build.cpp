@@ -20,53 +20,55 @@ static inline uint32_t mix32(uint32_t h, uint32_t v)
     return h;
 }
 
-// LSD radix sort of (key, value) pairs by 64-bit key, 16 bits per pass, skipping
-// passes whose digit is constant.
+// LSD radix sort of (key, value) pairs by 64-bit key, 16 bits per pass, skipping passes whose digit is
+// constant; stable; histogram and scatter run on several host threads (fixed contiguous chunk per thread).
 static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &vals)
 {
     const size_t N = keys.size();
     if (N < 2) return;
     std::vector<uint64_t> k2(N);
     std::vector<uint32_t> v2(N);
-    std::vector<size_t> hist(65536);
+    const unsigned T = N < ((size_t)1 << 16) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<size_t>> hist(T, std::vector<size_t>(65536));
+    auto run = [&](auto &&f) {
+        if (T == 1) {
+            f(0u);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(f, t);
+        f(0u);
+        for (auto &th : pool) th.join();
+    };
     for (int pass = 0; pass < 4; ++pass) {
         const int sh = pass * 16;
-        std::fill(hist.begin(), hist.end(), 0);
-        for (size_t i = 0; i < N; ++i) hist[(keys[i] >> sh) & 0xffff]++;
-        if (hist[(keys[0] >> sh) & 0xffff] == N) continue;
+        run([&](unsigned t) {
+            std::vector<size_t> &h = hist[t];
+            std::fill(h.begin(), h.end(), 0);
+            for (size_t i = N * t / T, e = N * (t + 1) / T; i < e; ++i) h[(keys[i] >> sh) & 0xffff]++;
+        });
+        size_t first_digit_count = 0;
+        const size_t d0 = (keys[0] >> sh) & 0xffff;
+        for (unsigned t = 0; t < T; ++t) first_digit_count += hist[t][d0];
+        if (first_digit_count == N) continue;  // constant digit
         size_t sum = 0;
-        for (size_t d = 0; d < 65536; ++d) {
-            size_t c = hist[d];
-            hist[d] = sum;
-            sum += c;
-        }
-        for (size_t i = 0; i < N; ++i) {
-            size_t p = hist[(keys[i] >> sh) & 0xffff]++;
-            k2[p] = keys[i];
-            v2[p] = vals[i];
-        }
+        for (size_t d = 0; d < 65536; ++d)
+            for (unsigned t = 0; t < T; ++t) {
+                const size_t c = hist[t][d];
+                hist[t][d] = sum;
+                sum += c;
+            }
+        run([&](unsigned t) {
+            std::vector<size_t> &h = hist[t];
+            for (size_t i = N * t / T, e = N * (t + 1) / T; i < e; ++i) {
+                const size_t p = h[(keys[i] >> sh) & 0xffff]++;
+                k2[p] = keys[i];
+                v2[p] = vals[i];
+            }
+        });
         keys.swap(k2);
         vals.swap(v2);
     }
-}
-
-// f(i) for i in [0, count) on a few host threads (dynamic chunks of `grain`)
-template <class F>
-static void parallel_chunks(size_t count, size_t grain, F &&f)
-{
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const size_t nchunks = (count + grain - 1) / grain;
-    if (hw == 1 || nchunks <= 1) {
-        for (size_t c = 0; c < nchunks; ++c) f(c * grain, std::min(count, (c + 1) * grain), 0u);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> pool;
-    for (unsigned th = 0; th < std::min<size_t>(hw, nchunks); ++th)
-        pool.emplace_back([&, th]() {
-            for (size_t c = next++; c < nchunks; c = next++) f(c * grain, std::min(count, (c + 1) * grain), th);
-        });
-    for (auto &t : pool) t.join();
 }
 
 std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
