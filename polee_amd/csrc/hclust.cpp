@@ -88,6 +88,18 @@ typedef std::vector<uint32_t> ReadSet;
 size_t intersection_size(const ReadSet &a, const ReadSet &b)
 {
     if (a.empty() || b.empty() || a.front() > b.back() || a.back() < b.front()) return 0;
+    // one set much smaller than the other: look its elements up (galloping) instead of walking both
+    const ReadSet &sm = a.size() <= b.size() ? a : b, &lg = a.size() <= b.size() ? b : a;
+    if (sm.size() * 24 < lg.size()) {
+        size_t c = 0;
+        auto from = lg.begin();
+        for (uint32_t v : sm) {
+            from = std::lower_bound(from, lg.end(), v);
+            if (from == lg.end()) break;
+            if (*from == v) ++c;
+        }
+        return c;
+    }
     size_t i = 0, j = 0, c = 0;
     while (i < a.size() && j < b.size()) {
         if (a[i] < b[j])
@@ -203,8 +215,8 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     lap("initial edges");
 
     // greedy joining (:262-308)
-    std::vector<uint32_t> cand;
-    std::vector<double> csim;
+    std::vector<uint32_t> cand, uniq;
+    std::vector<double> csim, usim;
     const unsigned hw_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     while (!queue.empty()) {
         const Edge e = queue.pop();
@@ -225,22 +237,29 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         for (const auto &ab : pair)
             for (uint32_t l : neighbors[ab[0]])
                 if (l != ab[1] && !deleted[l]) cand.push_back(l);
-        csim.resize(cand.size());
+        // every distinct neighbour is evaluated once (the two lists overlap and contain repeats)
+        uniq.assign(cand.begin(), cand.end());
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        usim.resize(uniq.size());
         size_t work = 0;
-        for (uint32_t l : cand) work += read_sets[l].size() + read_sets[k].size();
+        for (uint32_t l : uniq) work += read_sets[l].size() + read_sets[k].size();
         auto eval = [&](size_t lo, size_t hi) {
-            for (size_t c = lo; c < hi; ++c) csim[c] = relative_intersection(read_sets[cand[c]], read_sets[k]);
+            for (size_t c = lo; c < hi; ++c) usim[c] = relative_intersection(read_sets[uniq[c]], read_sets[k]);
         };
-        if (work > (size_t)4000000 && cand.size() >= 8 && hw_threads > 1) {  // a heavy merge: share it out
-            const unsigned nt = (unsigned)std::min<size_t>(hw_threads, cand.size() / 4);
+        if (work > (size_t)4000000 && uniq.size() >= 8 && hw_threads > 1) {  // a heavy merge: share it out
+            const unsigned nt = (unsigned)std::min<size_t>(hw_threads, uniq.size() / 4);
             std::vector<std::thread> pool;
             for (unsigned th = 1; th < nt; ++th)
-                pool.emplace_back(eval, cand.size() * th / nt, cand.size() * (th + 1) / nt);
-            eval(0, cand.size() / nt);
+                pool.emplace_back(eval, uniq.size() * th / nt, uniq.size() * (th + 1) / nt);
+            eval(0, uniq.size() / nt);
             for (auto &t : pool) t.join();
         } else {
-            eval(0, cand.size());
+            eval(0, uniq.size());
         }
+        csim.resize(cand.size());
+        for (size_t c = 0; c < cand.size(); ++c)
+            csim[c] = usim[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), cand[c]) - uniq.begin())];
         for (size_t c = 0; c < cand.size(); ++c) {
             const uint32_t l = cand[c];
             if (csim[c] != 0) queue.push(Edge{l, k, (float)csim[c]});
