@@ -1,0 +1,65 @@
+"""The second half of `polee prep-sample` on the GPU: likelihood matrix in, prepared sample out.
+
+Mirrors approximate_likelihood(approximation, sample, output_filename; use_efflen_jacobian,
+tree_topology_input_filename) (src/likelihood-approximation.jl:32-60) for a sample whose likelihood matrix was
+written with `--likelihood-matrix` (src/rnaseq_sample.jl:505-519): read X and the effective lengths, build the
+Polya tree (hclust, or read it from a `--ptt-tree` file, :428-436), fit the approximation on the GPU
+(polee_vi_*), write the prepared-sample HDF5 (write_approximation, :61-87) that `polee model ...` /
+load_samples_from_specification read.  The ingest that produces X (BAM -> fragments -> X, bias models) stays with
+the reference.
+
+    python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method cluster|sequential]
+        [--ptt-tree tree.h5] [--no-efflen-jacobian] [--seed N] [--device D]
+"""
+import argparse
+import sys
+import time
+
+from . import h5io
+from .core import (Context, LogitSkewNormalPTTApprox, PolyaTreeTransform, RNASeqSample, approximate_likelihood)
+
+
+def approximate_likelihood_to_file(approx, likelihood_matrix_filename, output_filename, use_efflen_jacobian=True,
+                                   tree_topology_input_filename=None, seed=123456789, ctx=None, args=""):
+    """Returns the params dict that was written (mu, omega, alpha, node_parent_idxs, node_js) plus timings."""
+    ctx = ctx or Context(0)
+    t0 = time.time()
+    lm = h5io.read_likelihood_matrix(likelihood_matrix_filename)
+    t_read = time.time() - t0
+    t0 = time.time()
+    sample = RNASeqSample(lm["m"], lm["n"], lm["colptr"], lm["rowval"], lm["nzval"], lm["effective_lengths"], ctx=ctx)
+    t_layout = time.time() - t0
+    tree = None
+    if tree_topology_input_filename is not None:  # likelihood-approximation.jl:428-433
+        parents, js = h5io.read_transformation(tree_topology_input_filename)
+        tree = PolyaTreeTransform(parents, js, ctx=ctx)
+    t0 = time.time()
+    params = approximate_likelihood(approx, sample, tree, use_efflen_jacobian=use_efflen_jacobian, seed=seed)
+    t_fit = time.time() - t0
+    h5io.write_approximation(output_filename, lm["m"], lm["n"], lm["effective_lengths"], params, args=args)
+    params["timings"] = {"read_s": t_read, "device_layout_s": t_layout, "tree_and_fit_s": t_fit}
+    return params
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m polee_amd.prep", description=__doc__.split("\n\n")[0])
+    ap.add_argument("likelihood_matrix", metavar="likelihood-matrix.h5")
+    ap.add_argument("-o", "--output", default="prepared-sample.h5", metavar="prepared-sample.h5")
+    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "sequential"])
+    ap.add_argument("--ptt-tree", default=None, metavar="tree.h5", help="use this tree topology (polee fit-tree output)")
+    ap.add_argument("--no-efflen-jacobian", action="store_true")
+    ap.add_argument("--seed", type=int, default=123456789)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    params = approximate_likelihood_to_file(LogitSkewNormalPTTApprox(a.tree_method), a.likelihood_matrix, a.output,
+                                            use_efflen_jacobian=not a.no_efflen_jacobian,
+                                            tree_topology_input_filename=a.ptt_tree, seed=a.seed,
+                                            ctx=Context(a.device), args=" ".join(argv or sys.argv[1:]))
+    t = params["timings"]
+    print("wrote %s (n=%d): read %.2f s, device layout %.2f s, tree + fit %.2f s"
+          % (a.output, len(params["mu"]) + 1, t["read_s"], t["device_layout_s"], t["tree_and_fit_s"]))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

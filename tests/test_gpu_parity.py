@@ -639,3 +639,31 @@ def test_handles_release_device_memory(P, lm_fixture, prep_fixture):
     for _ in range(5):
         cycle()
     assert base - free_bytes() < 8 << 20, (base, free_bytes())
+
+
+def test_prep_from_likelihood_matrix_file_to_prepared_sample_file(P, ctx, lm_fixture, prep_fixture, tmp_path):
+    """`python -m polee_amd.prep`: likelihood-matrix HDF5 -> (hclust, fit on the GPU) -> prepared-sample HDF5 that the
+    model-entry loader reads back; the written approximation explains the data like the reference's own file."""
+    from polee_amd import h5io, prep
+    f = lm_fixture
+    lm_file, out_file = str(tmp_path / "lm.h5"), str(tmp_path / "prep.h5")
+    h5io.write_likelihood_matrix(lm_file, f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"])
+    assert prep.main([lm_file, "-o", out_file, "--seed", "7"]) == 0
+    got = h5io.read_prepared_sample(out_file)  # (checks the format version)
+    assert got["n"] == f["n"] and got["m"] == f["m"] and len(got["node_js"]) == 2 * f["n"] - 1
+    np.testing.assert_array_equal(got["effective_lengths"], f["effective_lengths"])
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    l = f["effective_lengths"]
+    lp_ref, _ = _expected_loglik(so, O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"]),
+                                 prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"], l, 60, 1000)
+    lp_fit, _ = _expected_loglik(so, O.PTT(got["node_parent_idxs"], got["node_js"]), got["mu"], got["omega"],
+                                 got["alpha"], l, 60, 9000)
+    assert lp_fit.mean() > lp_ref.mean() - (6 * np.hypot(lp_ref.std(), lp_fit.std()) / np.sqrt(60) + 10)
+    # with the reference's tree given as a --ptt-tree file
+    tree_file = str(tmp_path / "tree.h5")
+    with h5io.File(tree_file, "w") as h:
+        h.write("node_parent_idxs", np.ascontiguousarray(prep_fixture["node_parent_idxs"], np.int32))
+        h.write("node_js", np.ascontiguousarray(prep_fixture["node_js"], np.int32))
+    assert prep.main([lm_file, "-o", out_file, "--ptt-tree", tree_file]) == 0
+    got2 = h5io.read_prepared_sample(out_file)
+    np.testing.assert_array_equal(got2["node_js"], prep_fixture["node_js"])
