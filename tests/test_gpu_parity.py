@@ -667,3 +667,39 @@ def test_prep_from_likelihood_matrix_file_to_prepared_sample_file(P, ctx, lm_fix
     assert prep.main([lm_file, "-o", out_file, "--ptt-tree", tree_file]) == 0
     got2 = h5io.read_prepared_sample(out_file)
     np.testing.assert_array_equal(got2["node_js"], prep_fixture["node_js"])
+
+
+def test_degenerate_sizes(P, ctx):
+    """Smallest problems through the whole C ABI: two transcripts (one internal node), a sample without fragments,
+    a single fragment; nothing may crash and everything stays finite."""
+    rng = np.random.default_rng(41)
+    # n = 2: the tree is one internal node with two leaves
+    parents, js = np.array([0, 1, 1], np.int32), np.array([0, 1, 2], np.int32)
+    t = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    x, ladj = t.transform(np.array([0.25]), compute_ladj=True)
+    np.testing.assert_allclose(np.sort(x), [0.25, 0.75], rtol=1e-6)
+    m, n = 7, 2
+    import scipy.sparse as sp
+    D = np.where(rng.random((m, n)) < 0.7, rng.uniform(1e-5, 1e-3, (m, n)), 0).astype(np.float32)
+    D[D.sum(axis=1) == 0, 0] = 1e-4  # every fragment is compatible with something (compact_indexes!, rnaseq_sample.jl:126)
+    X = sp.csc_matrix(D); X.sort_indices(); X.eliminate_zeros()
+    colptr, rowval, nzval = (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32), X.data.astype(np.float32)
+    eff = np.array([500.0, 900.0], np.float32)
+    s = P.RNASeqSample(m, n, colptr, rowval, nzval, eff, ctx=ctx)
+    so = O.Sample(m, n, colptr, rowval, nzval)
+    xv = np.array([0.3, 0.7], np.float32)
+    lp, g = s.log_likelihood(xv)
+    lpo, go = so.log_likelihood(xv)
+    assert abs(lp - lpo) < 1e-6 * abs(lpo)
+    np.testing.assert_allclose(g, go, rtol=3e-5)
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=30)
+    assert all(np.isfinite(got[k]).all() and got[k].shape == (1,) for k in ("mu", "omega", "alpha"))
+    # a sample without any fragment: the likelihood is constant
+    s0 = P.RNASeqSample(0, 2, np.array([1, 1, 1], np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), eff, ctx=ctx)
+    lp0, g0 = s0.log_likelihood(xv)
+    assert lp0 == 0 and not g0.any()
+    got0 = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s0, t, num_steps=5)
+    assert np.isfinite(got0["mu"]).all()
+    # hclust on two transcripts, one of them without reads
+    p2, j2 = P.hclust(3, 2, np.array([1, 3, 3], np.uint32), np.array([1, 2], np.uint32))
+    assert sorted(j2.tolist()) == [0, 1, 2] and p2.tolist() == [0, 1, 1]
