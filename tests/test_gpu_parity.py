@@ -703,3 +703,27 @@ def test_degenerate_sizes(P, ctx):
     # hclust on two transcripts, one of them without reads
     p2, j2 = P.hclust(3, 2, np.array([1, 3, 3], np.uint32), np.array([1, 2], np.uint32))
     assert sorted(j2.tolist()) == [0, 1, 2] and p2.tolist() == [0, 1, 1]
+
+
+def test_factored_vi_trajectory_with_supplied_noise(P, ctx, lm_fixture, prep_fixture):
+    """The factored variant of the fit (likelihood-approximation.jl:248-392: X with row multiplicities ks, a given
+    tree): four iterations with identical noise on both sides."""
+    f = lm_fixture
+    rng = np.random.default_rng(17)
+    ks = rng.integers(1, 6, f["m"]).astype(np.int64)
+    s = P.RNASeqSample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"], ks=ks, ctx=ctx)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    steps, K = 4, 6
+    z0 = O.randn(steps * K * (f["n"] - 1), 5)
+    ref = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False, ks=ks)
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
+                                   gradonly=False)
+    for key in ("mu", "omega", "alpha"):
+        ok = np.abs(got[key] - ref[key]) <= 2e-4 * (1 + np.abs(ref[key]))
+        assert ok.mean() >= 0.99, (key, ok.mean())
+    np.testing.assert_allclose(got["lp_mean"], ref["lp_mean"], rtol=1e-5)
+    # the multiplicities matter: the unweighted fit sees a different likelihood
+    ref1 = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=1, num_mc=K, z0=z0[:K * (f["n"] - 1)], gradonly=False)
+    assert abs(ref1["lp_mean"][0] - ref["lp_mean"][0]) > 0.1 * abs(ref1["lp_mean"][0])
