@@ -428,6 +428,16 @@ def test_full_fit_matches_reference_fit_statistically(P, ctx, lm_fixture, prep_f
     expressed = pm_ref > 1e-4
     r = np.corrcoef(np.log(pm_ref[expressed]), np.log(pm_fit[expressed]))[0, 1]
     assert r > 0.99, r
+    # node by node against the reference's OWN fitted parameters (same tree, different RNG): the agreement is at
+    # the level of our own seed-to-seed variation (measured: r = 0.9994 / 0.9995 / 0.979 vs 0.9995 / 0.9995 / 0.981)
+    other = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, seed=2)
+    for key, rmin in (("mu", 0.998), ("omega", 0.998), ("alpha", 0.95)):
+        r_ref = np.corrcoef(got[key], prep_fixture[key])[0, 1]
+        r_self = np.corrcoef(got[key], other[key])[0, 1]
+        assert r_ref > rmin and r_ref > r_self - 0.01, (key, r_ref, r_self)
+        d_ref = np.median(np.abs(got[key] - prep_fixture[key]))
+        d_self = np.median(np.abs(got[key] - other[key]))
+        assert d_ref < 2.0 * d_self + 1e-3, (key, d_ref, d_self)
 
 
 def test_fit_with_own_tree_is_as_good_as_the_reference_fit(P, ctx, lm_fixture, prep_fixture):
