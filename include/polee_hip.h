@@ -331,6 +331,17 @@ polee_status polee_approx_gene_logprob(polee_approx *ap, const float *x_gene, co
 polee_status polee_approx_sample(polee_approx *ap, const float *z0_or_null, uint64_t seed,
                                  float *x);
 
+/* approximate_feature_likelihood (src/polee_gene_expression.py:191-222): a normal approximation of the log
+ * expression of FEATURES (sets of transcripts, typically genes), by moments of sampler draws: loc = mean over
+ * num_mean_draws draws of log sum_{t in feature} x_t (x from polee_approx_sample's sampler), scale = sqrt of the mean
+ * squared deviation from loc over a further num_var_draws draws.  The feature / transcript incidence comes as
+ * num_pairs (feature, transcript) pairs, 1-based (transcript_expression_to_feature_expression, :163-173).
+ * z0 (optional, tests) = noise of all draws, host [(num_mean_draws + num_var_draws)][S][n-1].
+ * loc, scale: f32 [S][F].  (The reference runs 1000 + 1000 draws.) */
+polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *feature_idxs, const int32_t *transcript_idxs,
+                                          int64_t num_pairs, int32_t F, int32_t num_mean_draws, int32_t num_var_draws,
+                                          uint64_t seed, const float *z0_or_null, float *loc, float *scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -665,6 +665,26 @@ class RNASeqApproxLikelihood:
                                                 ptr(lp, f32p), ptr(gg, f32p), ptr(gi, f32p)), self.ctx._h)
         return (lp, gg, gi) if want_grad else lp
 
+    def approximate_feature_likelihood(self, num_features, feature_idxs, transcript_idxs, num_mean_draws=1000,
+                                       num_var_draws=1000, seed=123456789, z0=None):
+        """approximate_feature_likelihood (polee_gene_expression.py:191-222): normal approximation (loc, scale), each
+        [S, num_features], of the log expression of features (sets of transcripts) from sampler draws.
+        `feature_idxs`, `transcript_idxs`: equal-length 1-based incidence pairs, as in the reference."""
+        fi, ti = arr(feature_idxs, np.int32).reshape(-1), arr(transcript_idxs, np.int32).reshape(-1)
+        if fi.size != ti.size:
+            raise ValueError("feature_idxs and transcript_idxs must have the same length")
+        F = int(num_features)
+        z = None
+        if z0 is not None:
+            z = arr(z0, np.float32).reshape(-1)
+            if z.size != (num_mean_draws + num_var_draws) * self.S * (self.n - 1):
+                raise ValueError("z0 must hold (num_mean_draws + num_var_draws) x S x (n-1) values")
+        loc, scale = np.empty((self.S, F), np.float32), np.empty((self.S, F), np.float32)
+        check(L.lib().polee_approx_feature_moments(self._h, ptr(fi, i32p), ptr(ti, i32p), C.c_int64(fi.size), F,
+                                                   int(num_mean_draws), int(num_var_draws), C.c_uint64(seed),
+                                                   ptr(z, f32p), ptr(loc, f32p), ptr(scale, f32p)), self.ctx._h)
+        return loc, scale
+
     def sample(self, z0=None, seed=123456789):
         """rnaseq_approx_likelihood_sampler (polee_approx_likelihood.py:35-59), one draw per sample."""
         z = None if z0 is None else arr(z0, np.float32).reshape(self.S, self.n - 1)

@@ -435,18 +435,14 @@ polee_status polee_approx_gene_logprob(polee_approx *ap, const float *x_gene, co
     return POLEE_OK;
 }
 
-polee_status polee_approx_sample(polee_approx *ap, const float *z0, uint64_t seed, float *x)
+// one draw per sample into ap->d_x (device side of polee_approx_sample); d_z0 [S][n-1] or null
+static polee_status approx_sample_device(polee_approx *ap, const float *d_z0, uint64_t seed)
 {
-    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
     polee_ctx *ctx = ap->ctx;
-    POLEE_TRY(use_device(ctx));
-    if (!x) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
     polee_ptt *t = ap->t;
     const int S = ap->S, n = ap->n;
-    const size_t sn = (size_t)S * n, sk = (size_t)S * (n - 1);
-    if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0, sk));
     hipLaunchKernelGGL(approx_sample_y_kernel, dim3((unsigned)ceil_div(n - 1, 256), S), dim3(256), 0, ctx->stream,
-                       ap->view(), z0 ? ap->d_z0.p : nullptr, seed, t->d_ys.p);
+                       ap->view(), d_z0, seed, t->d_ys.p);
     POLEE_KERNEL_CHECK(ctx);
     FwdOut o;
     o.xs = ap->d_x.p;
@@ -459,7 +455,101 @@ polee_status polee_approx_sample(polee_approx *ap, const float *z0, uint64_t see
     hipLaunchKernelGGL(approx_sample_finish_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), 0, ctx->stream,
                        ap->view(), ap->d_dots.p, ap->d_x.p);
     POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+polee_status polee_approx_sample(polee_approx *ap, const float *z0, uint64_t seed, float *x)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!x) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    const size_t sn = (size_t)ap->S * ap->n, sk = (size_t)ap->S * (ap->n - 1);
+    if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0, sk));
+    POLEE_TRY(approx_sample_device(ap, z0 ? ap->d_z0.p : nullptr, seed));
     return ap->d_x.download(ctx, x, sn);
+}
+
+// ---- feature (gene) expression approximated by a normal, from sampler draws (polee_gene_expression.py:157-222)
+__global__ void feature_sum_kernel(const int32_t *fidx, const int32_t *tidx, int64_t P, int n, int F, const float *x,
+                                   float *fx)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (p >= P) return;
+    atomicAdd(&fx[(size_t)s * F + fidx[p]], x[(size_t)s * n + tidx[p]]);
+}
+// mode 0: acc += log fx;  mode 1: acc += (loc - log fx)^2;  fx is reset for the next draw
+__global__ void feature_accum_kernel(int64_t SF, float *fx, const float *loc, double *acc, int mode)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SF) return;
+    const float v = logf(fx[i]);
+    fx[i] = 0.0f;
+    if (mode == 0) {
+        acc[i] += (double)v;
+    } else {
+        const float d = loc[i] - v;
+        acc[i] += (double)(d * d);
+    }
+}
+__global__ void feature_finish_kernel(int64_t SF, double *acc, double denom, int mode, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SF) return;
+    out[i] = mode == 0 ? (float)(acc[i] / denom) : sqrtf((float)(acc[i] / denom));
+    acc[i] = 0.0;
+}
+
+polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *feature_idxs, const int32_t *transcript_idxs,
+                                          int64_t num_pairs, int32_t F, int32_t num_mean_draws, int32_t num_var_draws,
+                                          uint64_t seed, const float *z0, float *loc, float *scale)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    const int S = ap->S, n = ap->n;
+    if (!feature_idxs || !transcript_idxs || !loc || !scale || num_pairs < 1 || F < 1 || num_mean_draws < 1 ||
+        num_var_draws < 1)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    std::vector<int32_t> fi((size_t)num_pairs), ti((size_t)num_pairs);
+    for (int64_t p = 0; p < num_pairs; ++p) {  // 1-based, as the reference passes them
+        if (feature_idxs[p] < 1 || feature_idxs[p] > F || transcript_idxs[p] < 1 || transcript_idxs[p] > n)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "pair %lld (%d, %d) out of range", (long long)p, feature_idxs[p],
+                        transcript_idxs[p]);
+        fi[(size_t)p] = feature_idxs[p] - 1;
+        ti[(size_t)p] = transcript_idxs[p] - 1;
+    }
+    DevBuf<int32_t> d_fi, d_ti;
+    DevBuf<float> d_fx, d_loc, d_out;
+    DevBuf<double> d_acc;
+    const size_t SF = (size_t)S * F, sk = (size_t)S * (n - 1);
+    POLEE_TRY(d_fi.upload(ctx, fi));
+    POLEE_TRY(d_ti.upload(ctx, ti));
+    POLEE_TRY(d_fx.alloc(ctx, SF));
+    POLEE_TRY(d_loc.alloc(ctx, SF));
+    POLEE_TRY(d_out.alloc(ctx, SF));
+    POLEE_TRY(d_acc.alloc(ctx, SF));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_fx.p, 0, SF * sizeof(float), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_acc.p, 0, SF * sizeof(double), ctx->stream));
+    const dim3 gp((unsigned)ceil_div(num_pairs, 256), (unsigned)S), gf((unsigned)ceil_div((int64_t)SF, 256));
+    int64_t draw = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        const int nd = mode == 0 ? num_mean_draws : num_var_draws;
+        for (int d = 0; d < nd; ++d, ++draw) {
+            if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0 + (size_t)draw * sk, sk));
+            POLEE_TRY(approx_sample_device(ap, z0 ? ap->d_z0.p : nullptr, seed + 0x9E3779B97F4A7C15ull * (uint64_t)draw));
+            hipLaunchKernelGGL(feature_sum_kernel, gp, dim3(256), 0, ctx->stream, d_fi.p, d_ti.p, num_pairs, n, F,
+                               ap->d_x.p, d_fx.p);
+            hipLaunchKernelGGL(feature_accum_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_fx.p, d_loc.p, d_acc.p,
+                               mode);
+        }
+        hipLaunchKernelGGL(feature_finish_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_acc.p, (double)nd, mode,
+                           mode == 0 ? d_loc.p : d_out.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    POLEE_TRY(d_loc.download(ctx, loc, SF));
+    return d_out.download(ctx, scale, SF);
 }
 
 }  // extern "C"

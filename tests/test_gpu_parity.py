@@ -534,6 +534,41 @@ def test_gene_level_logprob_and_gradients_match_oracle(P, ctx):
         ap.gene_log_prob(x_gene, x_iso, np.full(n, G + 5, np.int32))
 
 
+def test_feature_moments_match_sampler_draws(P, ctx):
+    """approximate_feature_likelihood (polee_gene_expression.py:191-222) with supplied noise against the oracle's
+    sampler (tf_sampler) and NumPy moments; then with the device RNG the two estimates agree within MC error."""
+    rng = np.random.default_rng(23)
+    n, S, F, D1, D2 = 300, 2, 40, 6, 5
+    trees = [random_tree(n, rng) for _ in range(S)]
+    idx = [O.make_inverse_ptt_params(*tr) for tr in trees]
+    L_, R_, F_ = (np.stack([i[j] for i in idx]) for j in range(3))
+    eff = rng.uniform(200, 3000, size=(S, n)).astype(np.float32)
+    mu = rng.normal(0, 1, size=(S, n - 1)).astype(np.float32)
+    sigma = np.exp(rng.normal(-1, 0.3, size=(S, n - 1))).astype(np.float32)
+    alpha = rng.normal(0, 0.3, size=(S, n - 1)).astype(np.float32)
+    ap = P.RNASeqApproxLikelihood(dict(efflen=eff, la_mu=mu, la_sigma=sigma, la_alpha=alpha, left_index=L_,
+                                       right_index=R_, leaf_index=F_), ctx=ctx)
+    gene_of = np.concatenate([np.arange(F), rng.integers(0, F, n - F)])
+    fi, ti = gene_of + 1, np.arange(1, n + 1)
+    z0 = rng.normal(size=(D1 + D2, S, n - 1)).astype(np.float32)
+    loc, scale = ap.approximate_feature_likelihood(F, fi, ti, D1, D2, z0=z0)
+    logs = []
+    for d in range(D1 + D2):
+        x = O.tf_sampler(z0[d], eff, mu, sigma, alpha, L_, R_, F_).astype(np.float64)
+        fx = np.stack([np.bincount(gene_of, x[s_], F) for s_ in range(S)])
+        logs.append(np.log(fx))
+    logs = np.array(logs)
+    loc_o = logs[:D1].mean(axis=0)
+    scale_o = np.sqrt(((loc_o[None] - logs[D1:]) ** 2).mean(axis=0))
+    np.testing.assert_allclose(loc, loc_o, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(scale, scale_o, rtol=5e-3, atol=1e-4)
+    # device RNG, more draws: consistent with a second, independent estimate
+    a1, b1 = ap.approximate_feature_likelihood(F, fi, ti, 300, 300, seed=1)
+    a2, b2 = ap.approximate_feature_likelihood(F, fi, ti, 300, 300, seed=2)
+    assert (np.abs(a1 - a2) < 6 * np.maximum(b1, b2) / np.sqrt(300) + 1e-3).all()
+    assert np.median(np.abs(b1 - b2) / b1) < 0.15
+
+
 def test_elementwise_reparameterisations_match_oracle(P, ctx):
     """Standalone logit-normal / sinh-arcsinh / Kumaraswamy transforms and their gradients."""
     rng = np.random.default_rng(31)
