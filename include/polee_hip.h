@@ -342,6 +342,14 @@ polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *featu
                                           int64_t num_pairs, int32_t F, int32_t num_mean_draws, int32_t num_var_draws,
                                           uint64_t seed, const float *z0_or_null, float *loc, float *scale);
 
+/* approximate_splicing_likelihood (src/polee_splicing.py:47-113): the same moments for splicing log-ratios,
+ * log sum_{t in feature} x_t - log sum_{t in antifeature} x_t.  feature_indices / antifeature_indices: int32 [P][2] /
+ * [Q][2] rows (feature, transcript), 0-based, as the reference's NumPy arrays. */
+polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feature_indices, int64_t num_feature_pairs,
+                                           const int32_t *antifeature_indices, int64_t num_antifeature_pairs, int32_t F,
+                                           int32_t num_mean_draws, int32_t num_var_draws, uint64_t seed,
+                                           const float *z0_or_null, float *loc, float *scale);
+
 #ifdef __cplusplus
 }
 #endif

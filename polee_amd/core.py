@@ -685,6 +685,22 @@ class RNASeqApproxLikelihood:
                                                    ptr(z, f32p), ptr(loc, f32p), ptr(scale, f32p)), self.ctx._h)
         return loc, scale
 
+    def approximate_splicing_likelihood(self, num_features, feature_indices, antifeature_indices, num_mean_draws=1000,
+                                        num_var_draws=1000, seed=123456789, z0=None):
+        """approximate_splicing_likelihood (polee_splicing.py:62-113): normal approximation (loc, scale) of the splicing
+        log-ratios log(feature) - log(antifeature); index arrays [P,2] / [Q,2] of (feature, transcript), 0-based."""
+        fi, afi = arr(feature_indices, np.int32).reshape(-1, 2), arr(antifeature_indices, np.int32).reshape(-1, 2)
+        F = int(num_features)
+        z = None if z0 is None else arr(z0, np.float32).reshape(-1)
+        if z is not None and z.size != (num_mean_draws + num_var_draws) * self.S * (self.n - 1):
+            raise ValueError("z0 must hold (num_mean_draws + num_var_draws) x S x (n-1) values")
+        loc, scale = np.empty((self.S, F), np.float32), np.empty((self.S, F), np.float32)
+        check(L.lib().polee_approx_splicing_moments(self._h, ptr(fi, i32p), C.c_int64(fi.shape[0]), ptr(afi, i32p),
+                                                    C.c_int64(afi.shape[0]), F, int(num_mean_draws), int(num_var_draws),
+                                                    C.c_uint64(seed), ptr(z, f32p), ptr(loc, f32p), ptr(scale, f32p)),
+              self.ctx._h)
+        return loc, scale
+
     def sample(self, z0=None, seed=123456789):
         """rnaseq_approx_likelihood_sampler (polee_approx_likelihood.py:35-59), one draw per sample."""
         z = None if z0 is None else arr(z0, np.float32).reshape(self.S, self.n - 1)

@@ -480,12 +480,16 @@ __global__ void feature_sum_kernel(const int32_t *fidx, const int32_t *tidx, int
     atomicAdd(&fx[(size_t)s * F + fidx[p]], x[(size_t)s * n + tidx[p]]);
 }
 // mode 0: acc += log fx;  mode 1: acc += (loc - log fx)^2;  fx is reset for the next draw
-__global__ void feature_accum_kernel(int64_t SF, float *fx, const float *loc, double *acc, int mode)
+__global__ void feature_accum_kernel(int64_t SF, float *fx, float *afx, const float *loc, double *acc, int mode)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= SF) return;
-    const float v = logf(fx[i]);
+    float v = logf(fx[i]);
     fx[i] = 0.0f;
+    if (afx) {  // splicing log-ratio: log(feature) - log(antifeature) (polee_splicing.py:38-39)
+        v -= logf(afx[i]);
+        afx[i] = 0.0f;
+    }
     if (mode == 0) {
         acc[i] += (double)v;
     } else {
@@ -501,6 +505,58 @@ __global__ void feature_finish_kernel(int64_t SF, double *acc, double denom, int
     acc[i] = 0.0;
 }
 
+// shared driver: fi/ti (and optionally afi/ati) are 0-based device-ready pairs
+static polee_status feature_moments_impl(polee_approx *ap, const std::vector<int32_t> &fi, const std::vector<int32_t> &ti,
+                                         const std::vector<int32_t> &afi, const std::vector<int32_t> &ati, int32_t F,
+                                         int32_t num_mean_draws, int32_t num_var_draws, uint64_t seed, const float *z0,
+                                         float *loc, float *scale)
+{
+    polee_ctx *ctx = ap->ctx;
+    const int S = ap->S, n = ap->n;
+    const bool anti = !afi.empty();
+    DevBuf<int32_t> d_fi, d_ti, d_afi, d_ati;
+    DevBuf<float> d_fx, d_afx, d_loc, d_out;
+    DevBuf<double> d_acc;
+    const size_t SF = (size_t)S * F, sk = (size_t)S * (n - 1);
+    POLEE_TRY(d_fi.upload(ctx, fi));
+    POLEE_TRY(d_ti.upload(ctx, ti));
+    POLEE_TRY(d_fx.alloc(ctx, SF));
+    POLEE_TRY(d_loc.alloc(ctx, SF));
+    POLEE_TRY(d_out.alloc(ctx, SF));
+    POLEE_TRY(d_acc.alloc(ctx, SF));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_fx.p, 0, SF * sizeof(float), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_acc.p, 0, SF * sizeof(double), ctx->stream));
+    if (anti) {
+        POLEE_TRY(d_afi.upload(ctx, afi));
+        POLEE_TRY(d_ati.upload(ctx, ati));
+        POLEE_TRY(d_afx.alloc(ctx, SF));
+        POLEE_HIP_TRY(ctx, hipMemsetAsync(d_afx.p, 0, SF * sizeof(float), ctx->stream));
+    }
+    const int64_t P = (int64_t)fi.size(), Q = (int64_t)afi.size();
+    const dim3 gp((unsigned)ceil_div(P, 256), (unsigned)S), gq((unsigned)ceil_div(std::max<int64_t>(Q, 1), 256), (unsigned)S),
+        gf((unsigned)ceil_div((int64_t)SF, 256));
+    int64_t draw = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        const int nd = mode == 0 ? num_mean_draws : num_var_draws;
+        for (int d = 0; d < nd; ++d, ++draw) {
+            if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0 + (size_t)draw * sk, sk));
+            POLEE_TRY(approx_sample_device(ap, z0 ? ap->d_z0.p : nullptr, seed + 0x9E3779B97F4A7C15ull * (uint64_t)draw));
+            hipLaunchKernelGGL(feature_sum_kernel, gp, dim3(256), 0, ctx->stream, d_fi.p, d_ti.p, P, n, F, ap->d_x.p,
+                               d_fx.p);
+            if (anti)
+                hipLaunchKernelGGL(feature_sum_kernel, gq, dim3(256), 0, ctx->stream, d_afi.p, d_ati.p, Q, n, F,
+                                   ap->d_x.p, d_afx.p);
+            hipLaunchKernelGGL(feature_accum_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_fx.p,
+                               anti ? d_afx.p : nullptr, d_loc.p, d_acc.p, mode);
+        }
+        hipLaunchKernelGGL(feature_finish_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_acc.p, (double)nd, mode,
+                           mode == 0 ? d_loc.p : d_out.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    POLEE_TRY(d_loc.download(ctx, loc, SF));
+    return d_out.download(ctx, scale, SF);
+}
+
 polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *feature_idxs, const int32_t *transcript_idxs,
                                           int64_t num_pairs, int32_t F, int32_t num_mean_draws, int32_t num_var_draws,
                                           uint64_t seed, const float *z0, float *loc, float *scale)
@@ -508,7 +564,7 @@ polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *featu
     if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
     polee_ctx *ctx = ap->ctx;
     POLEE_TRY(use_device(ctx));
-    const int S = ap->S, n = ap->n;
+    const int n = ap->n;
     if (!feature_idxs || !transcript_idxs || !loc || !scale || num_pairs < 1 || F < 1 || num_mean_draws < 1 ||
         num_var_draws < 1)
         return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
@@ -520,36 +576,35 @@ polee_status polee_approx_feature_moments(polee_approx *ap, const int32_t *featu
         fi[(size_t)p] = feature_idxs[p] - 1;
         ti[(size_t)p] = transcript_idxs[p] - 1;
     }
-    DevBuf<int32_t> d_fi, d_ti;
-    DevBuf<float> d_fx, d_loc, d_out;
-    DevBuf<double> d_acc;
-    const size_t SF = (size_t)S * F, sk = (size_t)S * (n - 1);
-    POLEE_TRY(d_fi.upload(ctx, fi));
-    POLEE_TRY(d_ti.upload(ctx, ti));
-    POLEE_TRY(d_fx.alloc(ctx, SF));
-    POLEE_TRY(d_loc.alloc(ctx, SF));
-    POLEE_TRY(d_out.alloc(ctx, SF));
-    POLEE_TRY(d_acc.alloc(ctx, SF));
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_fx.p, 0, SF * sizeof(float), ctx->stream));
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_acc.p, 0, SF * sizeof(double), ctx->stream));
-    const dim3 gp((unsigned)ceil_div(num_pairs, 256), (unsigned)S), gf((unsigned)ceil_div((int64_t)SF, 256));
-    int64_t draw = 0;
-    for (int mode = 0; mode < 2; ++mode) {
-        const int nd = mode == 0 ? num_mean_draws : num_var_draws;
-        for (int d = 0; d < nd; ++d, ++draw) {
-            if (z0) POLEE_TRY(ap->d_z0.upload(ctx, z0 + (size_t)draw * sk, sk));
-            POLEE_TRY(approx_sample_device(ap, z0 ? ap->d_z0.p : nullptr, seed + 0x9E3779B97F4A7C15ull * (uint64_t)draw));
-            hipLaunchKernelGGL(feature_sum_kernel, gp, dim3(256), 0, ctx->stream, d_fi.p, d_ti.p, num_pairs, n, F,
-                               ap->d_x.p, d_fx.p);
-            hipLaunchKernelGGL(feature_accum_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_fx.p, d_loc.p, d_acc.p,
-                               mode);
+    return feature_moments_impl(ap, fi, ti, {}, {}, F, num_mean_draws, num_var_draws, seed, z0, loc, scale);
+}
+
+polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feature_indices, int64_t num_feature_pairs,
+                                           const int32_t *antifeature_indices, int64_t num_antifeature_pairs, int32_t F,
+                                           int32_t num_mean_draws, int32_t num_var_draws, uint64_t seed, const float *z0,
+                                           float *loc, float *scale)
+{
+    if (!ap) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = ap->ctx;
+    POLEE_TRY(use_device(ctx));
+    const int n = ap->n;
+    if (!feature_indices || !antifeature_indices || !loc || !scale || num_feature_pairs < 1 || num_antifeature_pairs < 1 ||
+        F < 1 || num_mean_draws < 1 || num_var_draws < 1)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    auto unpack = [&](const int32_t *pairs, int64_t cnt, std::vector<int32_t> &f, std::vector<int32_t> &t) -> bool {
+        f.resize((size_t)cnt);
+        t.resize((size_t)cnt);
+        for (int64_t p = 0; p < cnt; ++p) {  // rows (feature, transcript), 0-based (polee_splicing.py:69-80)
+            f[(size_t)p] = pairs[2 * p];
+            t[(size_t)p] = pairs[2 * p + 1];
+            if (f[(size_t)p] < 0 || f[(size_t)p] >= F || t[(size_t)p] < 0 || t[(size_t)p] >= n) return false;
         }
-        hipLaunchKernelGGL(feature_finish_kernel, gf, dim3(256), 0, ctx->stream, (int64_t)SF, d_acc.p, (double)nd, mode,
-                           mode == 0 ? d_loc.p : d_out.p);
-        POLEE_KERNEL_CHECK(ctx);
-    }
-    POLEE_TRY(d_loc.download(ctx, loc, SF));
-    return d_out.download(ctx, scale, SF);
+        return true;
+    };
+    std::vector<int32_t> fi, ti, afi, ati;
+    if (!unpack(feature_indices, num_feature_pairs, fi, ti) || !unpack(antifeature_indices, num_antifeature_pairs, afi, ati))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "feature / antifeature index out of range");
+    return feature_moments_impl(ap, fi, ti, afi, ati, F, num_mean_draws, num_var_draws, seed, z0, loc, scale);
 }
 
 }  // extern "C"

@@ -562,6 +562,27 @@ def test_feature_moments_match_sampler_draws(P, ctx):
     scale_o = np.sqrt(((loc_o[None] - logs[D1:]) ** 2).mean(axis=0))
     np.testing.assert_allclose(loc, loc_o, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(scale, scale_o, rtol=5e-3, atol=1e-4)
+    # splicing log-ratios (polee_splicing.py:14-113): feature = the gene's first transcripts, antifeature = the rest
+    fpairs, apairs = [], []
+    for gidx in range(F):
+        ts = np.flatnonzero(gene_of == gidx)
+        if len(ts) >= 2:
+            fpairs += [(gidx, int(t_)) for t_ in ts[:len(ts) // 2]]
+            apairs += [(gidx, int(t_)) for t_ in ts[len(ts) // 2:]]
+    has = np.unique([p_[0] for p_ in fpairs])
+    sl, ss = ap.approximate_splicing_likelihood(F, np.array(fpairs), np.array(apairs), D1, D2, z0=z0)
+    lr = []
+    for d in range(D1 + D2):
+        x = O.tf_sampler(z0[d], eff, mu, sigma, alpha, L_, R_, F_).astype(np.float64)
+        fa = np.zeros((S, F)); an = np.zeros((S, F))
+        for (gq, tq) in fpairs: fa[:, gq] += x[:, tq]
+        for (gq, tq) in apairs: an[:, gq] += x[:, tq]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lr.append(np.log(fa) - np.log(an))
+    lr = np.array(lr)
+    sl_o = lr[:D1].mean(axis=0); ss_o = np.sqrt(((sl_o[None] - lr[D1:]) ** 2).mean(axis=0))
+    np.testing.assert_allclose(sl[:, has], sl_o[:, has], rtol=2e-4, atol=3e-4)
+    np.testing.assert_allclose(ss[:, has], ss_o[:, has], rtol=5e-3, atol=2e-4)
     # device RNG, more draws: consistent with a second, independent estimate
     a1, b1 = ap.approximate_feature_likelihood(F, fi, ti, 300, 300, seed=1)
     a2, b2 = ap.approximate_feature_likelihood(F, fi, ti, 300, 300, seed=2)
