@@ -51,6 +51,7 @@ typedef struct polee_ptt polee_ptt;       /* one Polya tree transform (device re
 typedef struct polee_loglik polee_loglik; /* one sample's X, device resident             */
 typedef struct polee_vi polee_vi;         /* state of one likelihood-approximation fit   */
 typedef struct polee_approx polee_approx; /* S fitted approximations (regression input)  */
+typedef struct polee_regression polee_regression; /* regression model + surrogate posterior */
 
 /* ---- context -------------------------------------------------------------------- */
 polee_status polee_ctx_create(int device, polee_ctx **out);
@@ -349,6 +350,49 @@ polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feat
                                            const int32_t *antifeature_indices, int64_t num_antifeature_pairs, int32_t F,
                                            int32_t num_mean_draws, int32_t num_var_draws, uint64_t seed,
                                            const float *z0_or_null, float *loc, float *scale);
+
+/* ---- regression model ---------------------------------------------
+ * Replaces RNASeqLinearRegression.__init__ / model_fn / variational_model_fn / fit
+ * (models/polee_regression.py:18-340): the horseshoe+ linear model of log expression with kernel-regression
+ * mean-variance and distortion terms, its mean-field surrogate posterior, and
+ * tfp.vi.fit_surrogate_posterior(sample_size = 1, Adam(2e-3)) as hand-derived gradients of
+ * loss = log q(z) - log p(z) at one reparameterised draw z per step.
+ *   ap            fitted approximations of the S samples (the likelihood term, polee_approx_likelihood.py:367-450);
+ *                 NULL or use_point_estimates != 0: no likelihood term, x fixed at x_init (qx_loc not trained)
+ *   design        f32 [S][F] factor matrix;  x_init f32 [S][n] log expression;  sample_scales f32 [S]
+ *   hinges        f32 [degree] kernel-regression knots, or NULL for choose_knots(min, max of the column means of
+ *                 x_init) as RNASeqTranscriptLinearRegression does (models/polee_regression.py:436-440)
+ *   x_bias_loc0 / x_bias_scale0   prior of x_bias (log(1/n) and 12 in the reference's subclasses)
+ * Flat parameter (and gradient) vector, each array row-major, in this order (the reference's variable names
+ * without "_var"):  qw_global_scale_variance_loc, .._softplus_scale, qw_global_scale_noncentered_loc,
+ * .._softplus_scale (4 scalars); qw_distortion_c_loc [F][degree]; qx_scale_concentration_c_loc [degree];
+ * qx_scale_scale_c_loc [degree]; then [F][n] each: qw_local1_scale_variance_{loc,softplus_scale},
+ * qw_local1_scale_noncentered_{..}, qw_local2_scale_variance_{..}, qw_local2_scale_noncentered_{..}, qw_loc,
+ * qw_softplus_scale; then [n] each: qx_bias_loc, qx_bias_softplus_scale, qx_scale_loc, qx_scale_softplus_scale;
+ * then [S][n] each: qx_loc, qx_softplus_scale.
+ * Noise vector (standard normals of the draw): w_global_scale_variance, w_global_scale_noncentered (2 scalars);
+ * [F][n] each: w_local1_scale_variance, w_local1_scale_noncentered, w_local2_.., w_local2_.., w; x_bias [n];
+ * x_scale [n]; x [S][n]. */
+polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap_or_null, int32_t S, int32_t F, int32_t n,
+                                     const float *design, const float *x_init, const float *sample_scales,
+                                     const float *hinges_or_null, int32_t degree, float bandwidth, float x_bias_loc0,
+                                     float x_bias_scale0, int use_distortion, float scale_penalty,
+                                     int use_point_estimates, polee_regression **out);
+void polee_regression_destroy(polee_regression *reg);
+int64_t polee_regression_num_params(const polee_regression *reg);
+int64_t polee_regression_num_noise(const polee_regression *reg);
+polee_status polee_regression_get_params(polee_regression *reg, float *params);
+polee_status polee_regression_set_params(polee_regression *reg, const float *params);
+/* kernel_regression_weights (src/polee.py:36-47) as the model uses them: f32 [degree][n] */
+polee_status polee_regression_weights(polee_regression *reg, float *weights);
+/* loss and (optionally) its gradient w.r.t. the flat parameter vector at the current parameters, for the draw
+ * defined by `noise` (host, num_noise values) or, when NULL, by the device RNG with `seed`; no update. */
+polee_status polee_regression_eval(polee_regression *reg, const float *noise_or_null, uint64_t seed, float *loss,
+                                   float *grad_or_null);
+/* niter steps of fit() (models/polee_regression.py:303-340): draw, loss + gradient, Adam(2e-3, 0.9, 0.999, 1e-7).
+ * noise (optional, tests): host [niter][num_noise].  loss_trace (optional): f32 [niter]. */
+polee_status polee_regression_fit(polee_regression *reg, int32_t niter, uint64_t seed, const float *noise_or_null,
+                                  float *loss_trace_or_null);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,196 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (NumPy, float64) restatement of the regression model's variational loss.
+
+Follows `models/polee_regression.py:18-340` (RNASeqLinearRegression.model_fn / variational_model_fn / fit) and the
+helpers in `src/polee.py:14-76`.  The loss is tfp.vi.fit_surrogate_posterior's reverse-KL Monte-Carlo estimate at
+sample_size = 1:   loss = log q(z) - log p(z),  z one reparameterised draw of the surrogate posterior.
+
+PARITY UNPINNED: TensorFlow / TensorFlow-Probability are not available in this image and the reference pins no
+version of either (README.md:74 asks only for "the tensorflow python library").  The log-densities below are TFP's
+published definitions:
+  Normal(l, s).log_prob(x)        = -0.5 ((x-l)/s)^2 - log s - 0.5 log 2pi
+  HalfNormal(s).log_prob(x)       = 0.5 log(2/pi) - log s - 0.5 (x/s)^2
+  InverseGamma(a, b).log_prob(x)  = a log b - lgamma(a) - (a+1) log x - b/x
+  Cauchy(l, s).log_prob(x)        = -log(pi s) - log1p(((x-l)/s)^2)
+  HalfCauchy(0, s).log_prob(x)    = log 2 - log(pi s) - log1p((x/s)^2)
+  Deterministic.log_prob          = 0 at its own sample
+  TransformedDistribution(Normal, Softplus).log_prob(y) = Normal.log_prob(u) - log sigmoid(u),  y = softplus(u)
+Only tests may import this module.
+"""
+import numpy as np
+from scipy.special import gammaln
+
+LOG2PI = np.log(2.0 * np.pi)
+
+# (name, shape-code) in the order of the flat parameter vector shared with the device code
+# shape codes: '1' scalar, 'Fd' [F,deg], 'd' [deg], 'Fn' [F,n], 'n' [n], 'Sn' [S,n]
+PARAMS = [
+    ("qw_global_scale_variance_loc", "1"), ("qw_global_scale_variance_softplus_scale", "1"),
+    ("qw_global_scale_noncentered_loc", "1"), ("qw_global_scale_noncentered_softplus_scale", "1"),
+    ("qw_distortion_c_loc", "Fd"), ("qx_scale_concentration_c_loc", "d"), ("qx_scale_scale_c_loc", "d"),
+    ("qw_local1_scale_variance_loc", "Fn"), ("qw_local1_scale_variance_softplus_scale", "Fn"),
+    ("qw_local1_scale_noncentered_loc", "Fn"), ("qw_local1_scale_noncentered_softplus_scale", "Fn"),
+    ("qw_local2_scale_variance_loc", "Fn"), ("qw_local2_scale_variance_softplus_scale", "Fn"),
+    ("qw_local2_scale_noncentered_loc", "Fn"), ("qw_local2_scale_noncentered_softplus_scale", "Fn"),
+    ("qw_loc", "Fn"), ("qw_softplus_scale", "Fn"),
+    ("qx_bias_loc", "n"), ("qx_bias_softplus_scale", "n"),
+    ("qx_scale_loc", "n"), ("qx_scale_softplus_scale", "n"),
+    ("qx_loc", "Sn"), ("qx_softplus_scale", "Sn"),
+]
+# noise of the reparameterised draws, same convention
+NOISE = [
+    ("w_global_scale_variance", "1"), ("w_global_scale_noncentered", "1"),
+    ("w_local1_scale_variance", "Fn"), ("w_local1_scale_noncentered", "Fn"),
+    ("w_local2_scale_variance", "Fn"), ("w_local2_scale_noncentered", "Fn"),
+    ("w", "Fn"), ("x_bias", "n"), ("x_scale", "n"), ("x", "Sn"),
+]
+
+
+def shape_of(code, S, F, n, deg):
+    return {"1": (1,), "Fd": (F, deg), "d": (deg,), "Fn": (F, n), "n": (n,), "Sn": (S, n)}[code]
+
+
+def unflatten(vec, table, S, F, n, deg):
+    out, o = {}, 0
+    for name, code in table:
+        shp = shape_of(code, S, F, n, deg)
+        k = int(np.prod(shp))
+        out[name] = np.asarray(vec[o:o + k], np.float64).reshape(shp)
+        o += k
+    assert o == len(vec)
+    return out
+
+
+def flatten(d, table):
+    return np.concatenate([np.asarray(d[name], np.float64).reshape(-1) for name, _ in table])
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def log_sigmoid(x):
+    return -np.logaddexp(0.0, -x)
+
+
+def choose_knots(low, high, degree):
+    """src/polee.py:69-76"""
+    d = (high - low) / (degree + 1)
+    return np.array([low + (i + 1) * d for i in range(degree)])
+
+
+def kernel_regression_weights(bandwidth, mean, hinges):
+    """src/polee.py:36-47 -> [deg, n]"""
+    diffs = mean[None, :] - hinges[:, None]
+    w = np.clip(np.exp(-np.square(diffs / bandwidth)), 1e-10, 1.0)
+    return w / w.sum(axis=0, keepdims=True)
+
+
+def initial_params(x_init, F, deg):
+    """RNASeqLinearRegression.__init__ (models/polee_regression.py:49-119)"""
+    S, n = x_init.shape
+    p = {}
+    for name, code in PARAMS:
+        shp = shape_of(code, S, F, n, deg)
+        if name.endswith("softplus_scale"):
+            p[name] = np.full(shp, -1.0)
+        else:
+            p[name] = np.zeros(shp)
+    p["qw_softplus_scale"][:] = 0.0
+    p["qx_bias_loc"] = x_init.mean(axis=0).astype(np.float64)
+    p["qx_scale_concentration_c_loc"][:] = 1.0
+    p["qx_scale_scale_c_loc"][:] = 1.0
+    p["qx_scale_loc"][:] = -0.5
+    p["qx_loc"] = x_init.astype(np.float64).copy()
+    return p
+
+
+def _normal_lp(x, loc, scale):
+    return -0.5 * np.square((x - loc) / scale) - np.log(scale) - 0.5 * LOG2PI
+
+
+def _invgamma_lp(x, a, b):
+    return a * np.log(b) - gammaln(a) - (a + 1.0) * np.log(x) - b / x
+
+
+def _halfnormal_lp(x):
+    return 0.5 * np.log(2.0 / np.pi) - 0.5 * np.square(x)
+
+
+def regression_loss(p, eps, design, W, sample_scales, x_bias_loc0, x_bias_scale0, use_distortion, scale_penalty,
+                    use_point_estimates, lik=None):
+    """loss = log q - log p at the draw defined by `eps`.  `lik(x) -> lp [S]` is the approximate likelihood
+    (polee_approx_likelihood.py:367-450); ignored with point estimates.  Returns (loss, draws)."""
+    logq = 0.0
+    z = {}
+
+    def sp_normal(name_loc, name_s, e):
+        nonlocal logq
+        s = softplus(p[name_s])
+        u = p[name_loc] + s * e
+        logq += np.sum(_normal_lp(u, p[name_loc], s) - log_sigmoid(u))
+        return softplus(u)
+
+    def normal(name_loc, name_s, e):
+        nonlocal logq
+        s = softplus(p[name_s])
+        v = p[name_loc] + s * e
+        logq += np.sum(_normal_lp(v, p[name_loc], s))
+        return v
+
+    gv = sp_normal("qw_global_scale_variance_loc", "qw_global_scale_variance_softplus_scale",
+                   eps["w_global_scale_variance"])
+    gn = sp_normal("qw_global_scale_noncentered_loc", "qw_global_scale_noncentered_softplus_scale",
+                   eps["w_global_scale_noncentered"])
+    l1v = sp_normal("qw_local1_scale_variance_loc", "qw_local1_scale_variance_softplus_scale",
+                    eps["w_local1_scale_variance"])
+    l1n = sp_normal("qw_local1_scale_noncentered_loc", "qw_local1_scale_noncentered_softplus_scale",
+                    eps["w_local1_scale_noncentered"])
+    l2v = sp_normal("qw_local2_scale_variance_loc", "qw_local2_scale_variance_softplus_scale",
+                    eps["w_local2_scale_variance"])
+    l2n = sp_normal("qw_local2_scale_noncentered_loc", "qw_local2_scale_noncentered_softplus_scale",
+                    eps["w_local2_scale_noncentered"])
+    w = normal("qw_loc", "qw_softplus_scale", eps["w"])
+    x_bias = normal("qx_bias_loc", "qx_bias_softplus_scale", eps["x_bias"])
+    dist_c = p["qw_distortion_c_loc"]
+    conc_c = softplus(p["qx_scale_concentration_c_loc"])
+    scale_c = softplus(p["qx_scale_scale_c_loc"])
+    x_scale = sp_normal("qx_scale_loc", "qx_scale_softplus_scale", eps["x_scale"])
+    if use_point_estimates:
+        x = p["qx_loc"]
+    else:
+        x = normal("qx_loc", "qx_softplus_scale", eps["x"])
+
+    # ---- log p (model_fn, models/polee_regression.py:124-256)
+    logp = 0.0
+    logp += np.sum(_invgamma_lp(gv, 0.5, 0.5)) + np.sum(_halfnormal_lp(gn))
+    logp += np.sum(_invgamma_lp(l1v, 0.5, 0.5)) + np.sum(_halfnormal_lp(l1n))
+    logp += np.sum(_invgamma_lp(l2v, 0.5, 0.5)) + np.sum(_halfnormal_lp(l2n))
+    w_scale = (l1n * np.sqrt(l1v)) * (l2n * np.sqrt(l2v)) * (gn * np.sqrt(gv))
+    logp += np.sum(_normal_lp(w, 0.0, w_scale))
+    logp += np.sum(_normal_lp(x_bias, x_bias_loc0, x_bias_scale0))
+    if use_distortion:
+        logp += np.sum(-np.log(np.pi * 0.1) - np.log1p(np.square(dist_c / 0.1)))
+        x_loc = design @ (w + dist_c @ W) + x_bias
+    else:
+        x_loc = design @ w + x_bias
+    logp += np.sum(np.log(2.0) - np.log(np.pi) - np.log1p(np.square(conc_c)))
+    logp += np.sum(np.log(2.0) - np.log(np.pi) - np.log1p(np.square(scale_c)))
+    conc = (conc_c[:, None] * W).sum(axis=0)
+    scale = (scale_c[:, None] * W).sum(axis=0)
+    logp += np.sum(_invgamma_lp(x_scale, conc, scale))
+    logp += np.sum(_normal_lp(x, x_loc - np.asarray(sample_scales, np.float64).reshape(-1, 1), x_scale))
+    if not use_point_estimates:
+        m = p["qx_loc"].max(axis=1)
+        t = m + np.log(np.exp(p["qx_loc"] - m[:, None]).sum(axis=1))
+        logp += np.sum(_normal_lp(t, 0.0, scale_penalty))
+        if lik is not None:
+            logp += float(np.sum(lik(x)))
+    z.update(x=x, w=w, x_bias=x_bias, x_scale=x_scale, x_loc=x_loc, w_scale=w_scale)
+    return float(logq - logp), z
+
+
+def adam_step(theta, g, m, v, t, lr=2e-3, b1=0.9, b2=0.999, eps=1e-7):
+    """tf.optimizers.Adam (Keras): theta -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps), t = 1, 2, ..."""
+    m[:] = b1 * m + (1 - b1) * g
+    v[:] = b2 * v + (1 - b2) * g * g
+    theta -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)

@@ -11,6 +11,7 @@ would use).  Names, argument meaning and error behaviour follow the reference:
   approximate_likelihood(LogitSkewNormalPTTApprox(), sample)                 src/likelihood-approximation.jl
   ApproxLikelihoodSampler / rand!                                            src/approx-sampler.jl
   RNASeqApproxLikelihood(...).log_prob, rnaseq_approx_likelihood_sampler     src/polee_approx_likelihood.py
+  RNASeqLinearRegression / RNASeqTranscriptLinearRegression(...).fit         models/polee_regression.py
 
 All numerics run in libpolee_hip.so on the GPU; nothing here computes on the CPU.
 """
@@ -26,3 +27,5 @@ from .core import (Context, Comm, hclust, PolyaTreeTransform, make_inverse_ptt_p
 
 from . import h5io, estimate  # noqa: F401,E402
 from .estimate import LoadedSamples, load_samples_from_specification, load_samples_hdf5, read_specification  # noqa: F401,E402
+from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegression, estimate_sample_scales,  # noqa: F401,E402
+                         find_minimum_effect_size, write_regression_effects)

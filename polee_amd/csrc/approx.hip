@@ -274,6 +274,15 @@ struct polee_approx {
     ApproxView view() const { return ApproxView{S, n, d_efflens.p, d_mu.p, d_sigma.p, d_alpha.p}; }
 };
 
+namespace polee {
+polee_ctx *approx_ctx(const polee_approx *ap) { return ap->ctx; }
+void approx_dims(const polee_approx *ap, int32_t *S, int32_t *n)
+{
+    *S = ap->S;
+    *n = ap->n;
+}
+}  // namespace polee
+
 extern "C" {
 
 polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const float *efflens, const float *la_mu,

@@ -157,4 +157,8 @@ void ctx_release(polee_ctx *ctx);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// accessors of the approximation handle (approx.hip) for its consumers
+polee_ctx *approx_ctx(const polee_approx *ap);
+void approx_dims(const polee_approx *ap, int32_t *S, int32_t *n);
+
 }  // namespace polee

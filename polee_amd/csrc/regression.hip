@@ -1,0 +1,569 @@
+// The regression model's variational step, device resident.
+// Replaces RNASeqLinearRegression.model_fn / variational_model_fn / fit (models/polee_regression.py:18-340):
+// TensorFlow-Probability's JointDistributionCoroutine pair + tfp.vi.fit_surrogate_posterior(sample_size = 1,
+// Adam(2e-3)) become hand-derived gradients of
+//     loss = log q(z) - log p(z),   z one reparameterised draw of the surrogate posterior,
+// with the approximate likelihood term supplied by polee_approx_logprob_device (approx.hip).
+//
+// One step:
+//   noise    : Philox normals for every latent (or host-provided noise)           -> eps   [num_noise]
+//   lse      : t_s = logsumexp_j qx_loc[s][j] (the scale-drift penalty's value)   -> lse   [S]
+//   sample x : x = qx_loc + softplus(qx_softplus_scale) eps                       -> x     [S][n]
+//   lik      : approximate likelihood of x with d/dx                              -> lp [S], glik [S][n]
+//   columns  : one thread per feature j: draws the horseshoe+ scales, w, x_bias, x_scale of its column,
+//              evaluates its share of log q - log p and all per-column gradients; block-reduces the
+//              pieces shared by columns (global scale, distortion, mean-variance coefficients)
+//   finish   : the few global parameters
+//   adam     : Keras Adam over the flat parameter vector
+// Everything is O((F + S) n) bytes per step (cache / latency bound): no roofline claim.
+#include "common.hpp"
+#include "rng.hpp"
+
+#include <cmath>
+
+namespace polee {
+
+constexpr int REG_MAXF = 16;    // factors (design-matrix columns)
+constexpr int REG_MAXDEG = 32;  // kernel-regression hinges
+constexpr int REG_BLOCK = 128;
+constexpr float HALF_LOG2PI = 0.91893853320467274178f;
+
+// Layout of the flat parameter / gradient vector and of the noise vector (include/polee_hip.h documents the order).
+struct RegView {
+    int32_t S, F, n, deg;
+    int32_t use_distortion, point;
+    float bias_loc0, bias_scale0, penalty;
+    __host__ __device__ int64_t Fn() const { return (int64_t)F * n; }
+    __host__ __device__ int64_t o_dist() const { return 4; }
+    __host__ __device__ int64_t o_conc() const { return 4 + (int64_t)F * deg; }
+    __host__ __device__ int64_t o_scc() const { return o_conc() + deg; }
+    __host__ __device__ int64_t o_cols() const { return o_scc() + deg; }  // 10 arrays [F][n]
+    __host__ __device__ int64_t o_bias_loc() const { return o_cols() + 10 * Fn(); }
+    __host__ __device__ int64_t o_bias_s() const { return o_bias_loc() + n; }
+    __host__ __device__ int64_t o_xs_loc() const { return o_bias_loc() + 2 * (int64_t)n; }
+    __host__ __device__ int64_t o_xs_s() const { return o_bias_loc() + 3 * (int64_t)n; }
+    __host__ __device__ int64_t o_qx_loc() const { return o_bias_loc() + 4 * (int64_t)n; }
+    __host__ __device__ int64_t o_qx_s() const { return o_qx_loc() + (int64_t)S * n; }
+    __host__ __device__ int64_t num_params() const { return o_qx_s() + (int64_t)S * n; }
+    // noise: 2 global, 5 arrays [F][n], x_bias [n], x_scale [n], x [S][n]
+    __host__ __device__ int64_t e_cols() const { return 2; }
+    __host__ __device__ int64_t e_bias() const { return 2 + 5 * Fn(); }
+    __host__ __device__ int64_t e_xs() const { return e_bias() + n; }
+    __host__ __device__ int64_t e_x() const { return e_bias() + 2 * (int64_t)n; }
+    __host__ __device__ int64_t num_noise() const { return e_x() + (int64_t)S * n; }
+    __host__ __device__ int num_red() const { return 1 + F * deg + 2 * deg; }
+};
+
+__device__ inline float softplusf(float x) { return x > 15.0f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// psi(x), x > 0: recurrence up to x >= 6, then the asymptotic series
+__device__ inline float digammaf(float x)
+{
+    float r = 0.0f;
+    while (x < 6.0f) {
+        r -= 1.0f / x;
+        x += 1.0f;
+    }
+    const float i = 1.0f / x, i2 = i * i;
+    return r + logf(x) - 0.5f * i - i2 * (1.0f / 12.0f - i2 * (1.0f / 120.0f - i2 * (1.0f / 252.0f)));
+}
+
+// one draw of SoftplusNormal(loc, softplus(sraw)) (src/polee.py:24-33) and its share of log q
+struct SpDraw {
+    float z, sg, eps, s, sgs, logq;
+};
+__device__ inline SpDraw sp_draw(float loc, float sraw, float eps)
+{
+    SpDraw d;
+    d.eps = eps;
+    d.s = softplusf(sraw);
+    d.sgs = sigmoidf(sraw);
+    const float u = loc + d.s * eps;
+    d.z = softplusf(u);
+    d.sg = sigmoidf(u);
+    d.logq = -0.5f * eps * eps - logf(d.s) - HALF_LOG2PI + softplusf(-u);  // - log sigmoid(u)
+    return d;
+}
+// G = d(-log p)/dz  ->  d loss / d loc, d loss / d sraw
+__device__ inline void sp_grad(const SpDraw &d, float G, float &gloc, float &gs)
+{
+    const float a = G * d.sg - (1.0f - d.sg);
+    gloc = a;
+    gs = (a * d.eps - 1.0f / d.s) * d.sgs;
+}
+// -log InverseGamma(0.5, 0.5)(z), -log HalfNormal(1)(z)
+__device__ inline float nlp_ig_half(float z)
+{
+    return -(0.5f * -0.69314718055994530942f - 0.57236494292470008707f - 1.5f * logf(z) - 0.5f / z);
+}
+__device__ inline float nlp_halfnormal(float z) { return 0.22579135264472743236f + 0.5f * z * z; }  // -0.5 log(2/pi)
+
+__device__ inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void reg_noise_kernel(int64_t count, uint64_t seed, uint32_t step, float *eps)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= count) return;
+    float z[4];
+    philox_randn4(seed ^ 0x7265677265737369ull, step, (uint32_t)(q >> 32), (uint32_t)q, z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (q * 4 + i < count) eps[q * 4 + i] = z[i];
+}
+
+// t_s = logsumexp_j qx_loc[s][j]   (qx_sample_scale, models/polee_regression.py:300-301)
+__global__ __launch_bounds__(1024) void reg_lse_kernel(RegView v, const float *p, float *lse)
+{
+    __shared__ float red[16];
+    const float *row = p + v.o_qx_loc() + (int64_t)blockIdx.x * v.n;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < v.n; j += 1024) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < v.n; j += 1024) s += expf(row[j] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        lse[blockIdx.x] = m + logf(t);
+    }
+}
+
+__global__ void reg_sample_x_kernel(RegView v, const float *p, const float *eps, float *x)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)v.S * v.n) return;
+    x[i] = p[v.o_qx_loc() + i] + softplusf(p[v.o_qx_s() + i]) * eps[v.e_x() + i];
+}
+
+// acc: [0] loss (double); small: [0] sum (1 - r^2), then d/d(distortion_c) [F][deg], then the sums feeding
+// d/d(concentration_c) [deg] and d/d(scale_c) [deg]
+__global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const float *__restrict__ p,
+                                                             const float *__restrict__ eps,
+                                                             const float *__restrict__ design,
+                                                             const float *__restrict__ W, const float *__restrict__ ss,
+                                                             const float *__restrict__ x, const float *__restrict__ glik,
+                                                             const float *__restrict__ lse, float *__restrict__ g,
+                                                             double *loss_acc, float *small)
+{
+    __shared__ float s_weff[REG_MAXF][REG_BLOCK], s_gacc[REG_MAXF][REG_BLOCK], s_wpr[REG_MAXF][REG_BLOCK];
+    __shared__ float s_red[1 + REG_MAXF * REG_MAXDEG + 2 * REG_MAXDEG];
+    __shared__ float s_cc[REG_MAXDEG], s_sc[REG_MAXDEG];
+    const int tid = threadIdx.x;
+    const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
+    const bool live = jj < v.n;
+    const int64_t j = live ? jj : v.n - 1;  // dead lanes recompute the last column and contribute nothing
+    const int F = v.F, deg = v.deg, n = v.n;
+    const int64_t Fn = v.Fn();
+    const int nred = v.num_red();
+    for (int i = tid; i < nred; i += REG_BLOCK) s_red[i] = 0.0f;
+    if (tid < deg) {
+        s_cc[tid] = softplusf(p[v.o_conc() + tid]);
+        s_sc[tid] = softplusf(p[v.o_scc() + tid]);
+    }
+    __syncthreads();
+
+    float loss = 0.0f, S1 = 0.0f;
+    // global horseshoe scale (every thread recomputes the two scalars)
+    const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
+    const float gscale = gn.z * sqrtf(gv.z);
+
+    // ---- phase A: horseshoe+ scales and w of every factor
+    for (int f = 0; f < F; ++f) {
+        const int64_t idx = (int64_t)f * n + j;
+        const float *pc = p + v.o_cols() + idx;
+        const float *ec = eps + v.e_cols() + idx;
+        float *gc = g + v.o_cols() + idx;
+        const SpDraw l1v = sp_draw(pc[0 * Fn], pc[1 * Fn], ec[0 * Fn]);
+        const SpDraw l1n = sp_draw(pc[2 * Fn], pc[3 * Fn], ec[1 * Fn]);
+        const SpDraw l2v = sp_draw(pc[4 * Fn], pc[5 * Fn], ec[2 * Fn]);
+        const SpDraw l2n = sp_draw(pc[6 * Fn], pc[7 * Fn], ec[3 * Fn]);
+        const float s_w = softplusf(pc[9 * Fn]), e_w = ec[4 * Fn];
+        const float w = pc[8 * Fn] + s_w * e_w;
+        const float sw = (l1n.z * sqrtf(l1v.z)) * (l2n.z * sqrtf(l2v.z)) * gscale;
+        const float r = w / sw, q = 1.0f - r * r;
+        S1 += q;
+        loss += l1v.logq + l1n.logq + l2v.logq + l2n.logq + (-0.5f * e_w * e_w - logf(s_w) - HALF_LOG2PI);
+        loss += nlp_ig_half(l1v.z) + nlp_halfnormal(l1n.z) + nlp_ig_half(l2v.z) + nlp_halfnormal(l2n.z);
+        loss += 0.5f * r * r + logf(sw) + HALF_LOG2PI;
+        float a, b;
+        sp_grad(l1v, 1.5f / l1v.z - 0.5f / (l1v.z * l1v.z) + 0.5f * q / l1v.z, a, b);
+        if (live) gc[0 * Fn] = a, gc[1 * Fn] = b;
+        sp_grad(l1n, l1n.z + q / l1n.z, a, b);
+        if (live) gc[2 * Fn] = a, gc[3 * Fn] = b;
+        sp_grad(l2v, 1.5f / l2v.z - 0.5f / (l2v.z * l2v.z) + 0.5f * q / l2v.z, a, b);
+        if (live) gc[4 * Fn] = a, gc[5 * Fn] = b;
+        sp_grad(l2n, l2n.z + q / l2n.z, a, b);
+        if (live) gc[6 * Fn] = a, gc[7 * Fn] = b;
+        float wd = 0.0f;
+        if (v.use_distortion)
+            for (int d = 0; d < deg; ++d) wd += p[v.o_dist() + f * deg + d] * W[(int64_t)d * n + j];
+        s_weff[f][tid] = w + wd;
+        s_wpr[f][tid] = r / sw;
+        s_gacc[f][tid] = 0.0f;
+    }
+
+    // ---- phase B: x_bias, x_scale and the S observations of this column
+    const float s_b = softplusf(p[v.o_bias_s() + j]), e_b = eps[v.e_bias() + j];
+    const float b = p[v.o_bias_loc() + j] + s_b * e_b;
+    loss += -0.5f * e_b * e_b - logf(s_b) - HALF_LOG2PI;
+    const SpDraw xs = sp_draw(p[v.o_xs_loc() + j], p[v.o_xs_s() + j], eps[v.e_xs() + j]);
+    loss += xs.logq;
+    float alpha = 0.0f, beta = 0.0f;
+    for (int d = 0; d < deg; ++d) {
+        const float wdj = W[(int64_t)d * n + j];
+        alpha += s_cc[d] * wdj;
+        beta += s_sc[d] * wdj;
+    }
+    const float inv = 1.0f / xs.z, inv2 = inv * inv, lxs = logf(xs.z);
+    float Gxs = (alpha + 1.0f) * inv - beta * inv2;
+    const float db = (b - v.bias_loc0) / v.bias_scale0;
+    float Gb = db / v.bias_scale0;
+    loss += 0.5f * db * db + logf(v.bias_scale0) + HALF_LOG2PI;
+    loss += -(alpha * logf(beta) - lgammaf(alpha) - (alpha + 1.0f) * lxs - beta * inv);
+    const float g_alpha = -logf(beta) + digammaf(alpha) + lxs, g_beta = -alpha / beta + inv;
+    const float ipen2 = 1.0f / (v.penalty * v.penalty);
+    for (int s = 0; s < v.S; ++s) {
+        float xl = b;
+        for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
+        const int64_t sj = (int64_t)s * n + j;
+        const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
+        const float d = xv - (xl - ss[s]);
+        const float a = d * inv2;
+        loss += 0.5f * d * a + lxs + HALF_LOG2PI;
+        Gxs += inv - d * a * inv;
+        Gb -= a;
+        for (int f = 0; f < F; ++f) s_gacc[f][tid] -= design[s * F + f] * a;
+        float gl = 0.0f, gs = 0.0f;
+        if (!v.point) {
+            const float sraw = p[v.o_qx_s() + sj], sx = softplusf(sraw), e = eps[v.e_x() + sj];
+            const float Gx = a - glik[sj];
+            gl = Gx + lse[s] * ipen2 * expf(p[v.o_qx_loc() + sj] - lse[s]);
+            gs = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
+            loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;
+        }
+        if (live) g[v.o_qx_loc() + sj] = gl, g[v.o_qx_s() + sj] = gs;
+    }
+    if (live) {
+        g[v.o_bias_loc() + j] = Gb;
+        g[v.o_bias_s() + j] = (Gb * e_b - 1.0f / s_b) * sigmoidf(p[v.o_bias_s() + j]);
+        float a, c;
+        sp_grad(xs, Gxs, a, c);
+        g[v.o_xs_loc() + j] = a;
+        g[v.o_xs_s() + j] = c;
+    }
+
+    // ---- phase C: w's gradient, block sums of what the columns share
+    const float lv = live ? 1.0f : 0.0f;
+    const int lane = tid & 63;
+    for (int f = 0; f < F; ++f) {
+        const int64_t idx = (int64_t)f * n + j;
+        const float Gw = s_wpr[f][tid] + s_gacc[f][tid];
+        const float sraw = p[v.o_cols() + 9 * Fn + idx], e_w = eps[v.e_cols() + 4 * Fn + idx];
+        if (live) {
+            g[v.o_cols() + 8 * Fn + idx] = Gw;
+            g[v.o_cols() + 9 * Fn + idx] = (Gw * e_w - 1.0f / softplusf(sraw)) * sigmoidf(sraw);
+        }
+        if (v.use_distortion)
+            for (int d = 0; d < deg; ++d) {
+                const float t = wave_sum(lv * W[(int64_t)d * n + j] * s_gacc[f][tid]);
+                if (lane == 0) atomicAdd(&s_red[1 + f * deg + d], t);
+            }
+    }
+    for (int d = 0; d < deg; ++d) {
+        const float wdj = lv * W[(int64_t)d * n + j];
+        const float ta = wave_sum(wdj * g_alpha), tb = wave_sum(wdj * g_beta);
+        if (lane == 0) {
+            atomicAdd(&s_red[1 + F * deg + d], ta);
+            atomicAdd(&s_red[1 + F * deg + deg + d], tb);
+        }
+    }
+    S1 = wave_sum(lv * S1);
+    loss = wave_sum(lv * loss);
+    if (lane == 0) {
+        atomicAdd(&s_red[0], S1);
+        atomicAdd(loss_acc, (double)loss);
+    }
+    __syncthreads();
+    for (int i = tid; i < nred; i += REG_BLOCK) atomicAdd(&small[i], s_red[i]);
+}
+
+// the global horseshoe scale, the distortion / mean-variance coefficients, the per-sample terms
+__global__ void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small, const float *lse,
+                                  const float *lp, const double *loss_acc, float *g, float *loss_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double loss = loss_acc[0];
+    const float S1 = small[0];
+    {
+        const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
+        loss += gv.logq + gn.logq + nlp_ig_half(gv.z) + nlp_halfnormal(gn.z);
+        sp_grad(gv, 1.5f / gv.z - 0.5f / (gv.z * gv.z) + 0.5f * S1 / gv.z, g[0], g[1]);
+        sp_grad(gn, gn.z + S1 / gn.z, g[2], g[3]);
+    }
+    for (int i = 0; i < v.F * v.deg; ++i) {
+        const float c = p[v.o_dist() + i];
+        if (v.use_distortion) {
+            g[v.o_dist() + i] = 2.0f * c / (0.01f + c * c) + small[1 + i];
+            loss += logf(3.14159265358979323846f * 0.1f) + log1pf(100.0f * c * c);
+        } else
+            g[v.o_dist() + i] = 0.0f;
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int d = 0; d < v.deg; ++d) {
+            const int64_t o = (h == 0 ? v.o_conc() : v.o_scc()) + d;
+            const float c = softplusf(p[o]);
+            g[o] = (2.0f * c / (1.0f + c * c) + small[1 + v.F * v.deg + h * v.deg + d]) * sigmoidf(p[o]);
+            loss += 0.45158270528945486473f + log1pf(c * c);  // -log(2/pi)
+        }
+    if (!v.point)
+        for (int s = 0; s < v.S; ++s) {
+            const float t = lse[s] / v.penalty;
+            loss += 0.5f * t * t + logf(v.penalty) + HALF_LOG2PI;
+            if (lp) loss -= lp[s];
+        }
+    loss_out[0] = (float)loss;
+}
+
+// tf.optimizers.Adam: theta -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps)
+__global__ void reg_adam_kernel(int64_t count, float *p, const float *g, float *m, float *vv, float lr_t)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float gi = g[i];
+    const float mi = 0.9f * m[i] + 0.1f * gi;
+    const float vi = 0.999f * vv[i] + 0.001f * gi * gi;
+    m[i] = mi;
+    vv[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + 1e-7f);
+}
+
+}  // namespace polee
+
+using namespace polee;
+
+struct polee_regression {
+    polee_ctx *ctx = nullptr;
+    polee_approx *ap = nullptr;
+    RegView v{};
+    float lr = 2e-3f;
+    int64_t step = 0;  // ADAM steps taken
+    DevBuf<float> d_p, d_g, d_m, d_v, d_eps, d_design, d_W, d_ss, d_x, d_glik, d_lp, d_lse, d_small, d_loss;
+    DevBuf<double> d_acc;
+};
+
+namespace {
+
+// loss and gradient at the current parameters for the noise in d_eps
+polee_status reg_eval_device(polee_regression *r)
+{
+    polee_ctx *ctx = r->ctx;
+    const RegView &v = r->v;
+    hipStream_t st = ctx->stream;
+    const int64_t sn = (int64_t)v.S * v.n;
+    if (!v.point) {
+        hipLaunchKernelGGL(reg_lse_kernel, dim3(v.S), dim3(1024), 0, st, v, r->d_p.p, r->d_lse.p);
+        hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
+                           r->d_eps.p, r->d_x.p);
+        POLEE_KERNEL_CHECK(ctx);
+        if (r->ap) POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
+    }
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double), st));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * v.num_red(), st));
+    hipLaunchKernelGGL(reg_cols_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
+                       r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p, r->d_g.p,
+                       r->d_acc.p, r->d_small.p);
+    hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p, r->d_lse.p,
+                       (!v.point && r->ap) ? r->d_lp.p : nullptr, r->d_acc.p, r->d_g.p, r->d_loss.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t seed, uint32_t step)
+{
+    polee_ctx *ctx = r->ctx;
+    const int64_t ne = r->v.num_noise();
+    if (noise) return r->d_eps.upload(ctx, noise, (size_t)ne);
+    hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(ne, 4), 256)), dim3(256), 0, ctx->stream, ne,
+                       seed, step, r->d_eps.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S, int32_t F, int32_t n,
+                                     const float *design, const float *x_init, const float *sample_scales,
+                                     const float *hinges, int32_t degree, float bandwidth, float x_bias_loc0,
+                                     float x_bias_scale0, int use_distortion, float scale_penalty,
+                                     int use_point_estimates, polee_regression **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!out || !design || !x_init || !sample_scales || S < 1 || F < 1 || n < 1 || degree < 1)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_regression_create: bad argument");
+    if (F > REG_MAXF || degree > REG_MAXDEG)
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "at most %d factors and %d hinges (got %d, %d)", REG_MAXF, REG_MAXDEG, F,
+                    degree);
+    if (!(bandwidth > 0.0f) || !(x_bias_scale0 > 0.0f) || (!use_point_estimates && !(scale_penalty > 0.0f)))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "bandwidth, x_bias_scale0 and scale_penalty must be positive");
+    if (ap) {
+        int32_t aS, an;
+        approx_dims(ap, &aS, &an);
+        if (approx_ctx(ap) != ctx || aS != S || an != n)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "the approximation handle holds %d x %d, the model %d x %d", aS, an, S, n);
+    }
+    polee_regression *r = new (std::nothrow) polee_regression();
+    if (!r) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    r->ctx = ctx;
+    ctx_retain(ctx);
+    r->ap = use_point_estimates ? nullptr : ap;
+    RegView &v = r->v;
+    v = RegView{S, F, n, degree, use_distortion ? 1 : 0, use_point_estimates ? 1 : 0, x_bias_loc0, x_bias_scale0,
+                use_point_estimates ? 1.0f : scale_penalty};
+    const int64_t P = v.num_params(), sn = (int64_t)S * n, Fn = v.Fn();
+    // initial values (models/polee_regression.py:49-119)
+    std::vector<float> p((size_t)P, 0.0f);
+    std::vector<double> mean((size_t)n, 0.0);
+    for (int s = 0; s < S; ++s)
+        for (int j = 0; j < n; ++j) mean[(size_t)j] += x_init[(size_t)s * n + j];
+    for (auto &m : mean) m /= S;
+    p[1] = p[3] = -1.0f;
+    for (int d = 0; d < degree; ++d) p[(size_t)(v.o_conc() + d)] = p[(size_t)(v.o_scc() + d)] = 1.0f;
+    for (int a = 1; a < 8; a += 2) std::fill_n(p.begin() + v.o_cols() + a * Fn, Fn, -1.0f);
+    for (int j = 0; j < n; ++j) {
+        p[(size_t)(v.o_bias_loc() + j)] = (float)mean[(size_t)j];
+        p[(size_t)(v.o_bias_s() + j)] = -1.0f;
+        p[(size_t)(v.o_xs_loc() + j)] = -0.5f;
+        p[(size_t)(v.o_xs_s() + j)] = -1.0f;
+    }
+    std::copy_n(x_init, sn, p.begin() + v.o_qx_loc());
+    std::fill_n(p.begin() + v.o_qx_s(), sn, -1.0f);
+    // hinges (choose_knots, src/polee.py:69-76) and kernel-regression weights (:36-47)
+    std::vector<double> hg((size_t)degree);
+    if (hinges)
+        for (int d = 0; d < degree; ++d) hg[(size_t)d] = hinges[d];
+    else {
+        const double lo = *std::min_element(mean.begin(), mean.end()), hi = *std::max_element(mean.begin(), mean.end());
+        const double step = (hi - lo) / (degree + 1);
+        for (int d = 0; d < degree; ++d) hg[(size_t)d] = lo + (d + 1) * step;
+    }
+    std::vector<float> W((size_t)degree * n);
+    for (int j = 0; j < n; ++j) {
+        double tot = 0.0, col[REG_MAXDEG];
+        for (int d = 0; d < degree; ++d) {
+            const double u = ((double)(float)mean[(size_t)j] - hg[(size_t)d]) / bandwidth;
+            col[d] = std::min(std::max(std::exp(-u * u), 1e-10), 1.0);
+            tot += col[d];
+        }
+        for (int d = 0; d < degree; ++d) W[(size_t)d * n + j] = (float)(col[d] / tot);
+    }
+    polee_status st = POLEE_OK;
+    auto ok = [&](polee_status s) { return st == POLEE_OK ? (st = s) == POLEE_OK : false; };
+    if (ok(r->d_p.upload(ctx, p)) && ok(r->d_W.upload(ctx, W)) && ok(r->d_design.upload(ctx, design, (size_t)S * F)) &&
+        ok(r->d_ss.upload(ctx, sample_scales, (size_t)S)) && ok(r->d_g.alloc(ctx, (size_t)P)) &&
+        ok(r->d_m.alloc(ctx, (size_t)P)) && ok(r->d_v.alloc(ctx, (size_t)P)) &&
+        ok(r->d_eps.alloc(ctx, (size_t)v.num_noise())) && ok(r->d_x.alloc(ctx, (size_t)sn)) &&
+        ok(r->d_glik.alloc(ctx, (size_t)sn)) && ok(r->d_lp.alloc(ctx, (size_t)S)) && ok(r->d_lse.alloc(ctx, (size_t)S)) &&
+        ok(r->d_small.alloc(ctx, (size_t)v.num_red())) && ok(r->d_loss.alloc(ctx, 1)) && ok(r->d_acc.alloc(ctx, 1))) {
+        hipError_t e = hipMemsetAsync(r->d_m.p, 0, sizeof(float) * P, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_v.p, 0, sizeof(float) * P, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_glik.p, 0, sizeof(float) * sn, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_lse.p, 0, sizeof(float) * S, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = fail(ctx, POLEE_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
+    }
+    if (st != POLEE_OK) {
+        polee_regression_destroy(r);
+        return st;
+    }
+    *out = r;
+    return POLEE_OK;
+}
+
+void polee_regression_destroy(polee_regression *r)
+{
+    if (!r) return;
+    polee_ctx *ctx = r->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    delete r;
+    ctx_release(ctx);
+}
+
+int64_t polee_regression_num_params(const polee_regression *r) { return r ? r->v.num_params() : 0; }
+int64_t polee_regression_num_noise(const polee_regression *r) { return r ? r->v.num_noise() : 0; }
+
+polee_status polee_regression_get_params(polee_regression *r, float *params)
+{
+    if (!r || !params) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_p.download(r->ctx, params, (size_t)r->v.num_params());
+}
+
+polee_status polee_regression_set_params(polee_regression *r, const float *params)
+{
+    if (!r || !params) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_p.upload(r->ctx, params, (size_t)r->v.num_params());
+}
+
+polee_status polee_regression_weights(polee_regression *r, float *weights)
+{
+    if (!r || !weights) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_W.download(r->ctx, weights, (size_t)r->v.deg * r->v.n);
+}
+
+polee_status polee_regression_eval(polee_regression *r, const float *noise, uint64_t seed, float *loss, float *grad)
+{
+    if (!r || !loss) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    POLEE_TRY(reg_fill_noise(r, noise, seed, (uint32_t)(r->step + 1)));
+    POLEE_TRY(reg_eval_device(r));
+    POLEE_TRY(r->d_loss.download(ctx, loss, 1));
+    if (grad) POLEE_TRY(r->d_g.download(ctx, grad, (size_t)r->v.num_params()));
+    return POLEE_OK;
+}
+
+polee_status polee_regression_fit(polee_regression *r, int32_t niter, uint64_t seed, const float *noise,
+                                  float *loss_trace)
+{
+    if (!r || niter < 0) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "bad argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    const int64_t P = r->v.num_params(), ne = r->v.num_noise();
+    DevBuf<float> d_trace;
+    if (loss_trace && niter) POLEE_TRY(d_trace.alloc(ctx, (size_t)niter));
+    for (int32_t it = 0; it < niter; ++it) {
+        const int64_t t = ++r->step;
+        POLEE_TRY(reg_fill_noise(r, noise ? noise + (size_t)it * ne : nullptr, seed, (uint32_t)t));
+        POLEE_TRY(reg_eval_device(r));
+        if (loss_trace)
+            POLEE_HIP_TRY(ctx, hipMemcpyAsync(d_trace.p + it, r->d_loss.p, sizeof(float), hipMemcpyDeviceToDevice,
+                                              ctx->stream));
+        const double lr_t = (double)r->lr * std::sqrt(1.0 - std::pow(0.999, (double)t)) / (1.0 - std::pow(0.9, (double)t));
+        hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, P, r->d_p.p,
+                           r->d_g.p, r->d_m.p, r->d_v.p, (float)lr_t);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    if (loss_trace && niter) POLEE_TRY(d_trace.download(ctx, loss_trace, (size_t)niter));
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return POLEE_OK;
+}
+
+}  // extern "C"

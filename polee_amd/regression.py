@@ -1,0 +1,223 @@
+"""Host-side mirror of the regression model (models/polee_regression.py) over libpolee_hip's polee_regression_*.
+
+Same class names, constructor arguments and return values as the reference; the TensorFlow-Probability
+joint distributions and fit_surrogate_posterior are replaced by the device step in csrc/regression.hip.
+Also: estimate_sample_scales (src/PoleeModel.jl:82-89) and the effect-size output semantics
+(src/regression.jl:604-685).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import arr, check, f32p, ptr
+from .core import RNASeqApproxLikelihood, default_context
+
+# (name, shape code) of the flat parameter vector, in include/polee_hip.h's order
+PARAM_TABLE = [
+    ("qw_global_scale_variance_loc", "1"), ("qw_global_scale_variance_softplus_scale", "1"),
+    ("qw_global_scale_noncentered_loc", "1"), ("qw_global_scale_noncentered_softplus_scale", "1"),
+    ("qw_distortion_c_loc", "Fd"), ("qx_scale_concentration_c_loc", "d"), ("qx_scale_scale_c_loc", "d"),
+    ("qw_local1_scale_variance_loc", "Fn"), ("qw_local1_scale_variance_softplus_scale", "Fn"),
+    ("qw_local1_scale_noncentered_loc", "Fn"), ("qw_local1_scale_noncentered_softplus_scale", "Fn"),
+    ("qw_local2_scale_variance_loc", "Fn"), ("qw_local2_scale_variance_softplus_scale", "Fn"),
+    ("qw_local2_scale_noncentered_loc", "Fn"), ("qw_local2_scale_noncentered_softplus_scale", "Fn"),
+    ("qw_loc", "Fn"), ("qw_softplus_scale", "Fn"),
+    ("qx_bias_loc", "n"), ("qx_bias_softplus_scale", "n"),
+    ("qx_scale_loc", "n"), ("qx_scale_softplus_scale", "n"),
+    ("qx_loc", "Sn"), ("qx_softplus_scale", "Sn"),
+]
+
+
+def _softplus(x):
+    return np.logaddexp(0.0, x).astype(np.float32)
+
+
+def estimate_sample_scales(x, upper_quantile=0.95):
+    """src/PoleeModel.jl:82-89: per-sample offsets from the highly expressed features; x [S, n] log expression.
+    Returns [S, 1] like the reference."""
+    x = np.asarray(x, np.float64)
+    x_mean = np.median(x, axis=0)
+    high = x_mean > np.quantile(x_mean, upper_quantile)
+    return np.median(x_mean[high][None, :] - x[:, high], axis=1, keepdims=True).astype(np.float32)
+
+
+class RNASeqLinearRegression:
+    """RNASeqLinearRegression (models/polee_regression.py:18-340).  `likelihood_model` is an
+    RNASeqApproxLikelihood (or None with point estimates) instead of a TFP coroutine."""
+
+    def __init__(self, F, x_init, likelihood_model, x_bias_loc0, x_bias_scale0, x_scale_hinges, sample_scales,
+                 use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
+                 kernel_regression_bandwidth, ctx=None):
+        Fm = arr(np.atleast_2d(F), np.float32)
+        x0 = arr(np.atleast_2d(x_init), np.float32)
+        ss = arr(np.asarray(sample_scales).reshape(-1), np.float32)
+        self.num_samples, self.num_factors = Fm.shape
+        self.num_features = x0.shape[1]
+        if x0.shape[0] != self.num_samples or ss.size != self.num_samples:
+            raise ValueError("F [S,F], x_init [S,n] and sample_scales [S] disagree on S")
+        self.kernel_regression_degree = int(kernel_regression_degree)
+        hg = None if x_scale_hinges is None else arr(np.asarray(x_scale_hinges).reshape(-1), np.float32)
+        if hg is not None and hg.size != self.kernel_regression_degree:
+            raise ValueError("x_scale_hinges must hold kernel_regression_degree values")
+        self.use_point_estimates = bool(use_point_estimates)
+        self.likelihood_model = likelihood_model
+        if not self.use_point_estimates and likelihood_model is None:
+            raise ValueError("a likelihood model is needed unless use_point_estimates")
+        self.ctx = ctx or (likelihood_model.ctx if likelihood_model is not None else default_context())
+        self._h = C.c_void_p()
+        ap = likelihood_model._h if (likelihood_model is not None and not self.use_point_estimates) else None
+        check(L.lib().polee_regression_create(
+            self.ctx._h, ap, self.num_samples, self.num_factors, self.num_features, ptr(Fm, f32p), ptr(x0, f32p),
+            ptr(ss, f32p), ptr(hg, f32p), self.kernel_regression_degree, C.c_float(kernel_regression_bandwidth),
+            C.c_float(x_bias_loc0), C.c_float(x_bias_scale0), int(bool(use_distortion)), C.c_float(scale_penalty),
+            int(self.use_point_estimates), C.byref(self._h)), self.ctx._h)
+        lib = L.lib()
+        lib.polee_regression_num_params.restype = C.c_int64
+        lib.polee_regression_num_noise.restype = C.c_int64
+        lib.polee_regression_num_params.argtypes = [C.c_void_p]
+        lib.polee_regression_num_noise.argtypes = [C.c_void_p]
+        self.num_params = int(lib.polee_regression_num_params(self._h))
+        self.num_noise = int(lib.polee_regression_num_noise(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                f = L.lib().polee_regression_destroy
+                f.restype = None
+                f.argtypes = [C.c_void_p]
+                f(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- parameters by the reference's variable names
+    def _shape(self, code):
+        S, F, n, d = self.num_samples, self.num_factors, self.num_features, self.kernel_regression_degree
+        return {"1": (), "Fd": (F, d), "d": (d,), "Fn": (F, n), "n": (n,), "Sn": (S, n)}[code]
+
+    def get_flat_params(self):
+        p = np.empty(self.num_params, np.float32)
+        check(L.lib().polee_regression_get_params(self._h, ptr(p, f32p)), self.ctx._h)
+        return p
+
+    def set_flat_params(self, p):
+        p = arr(p, np.float32).reshape(-1)
+        if p.size != self.num_params:
+            raise ValueError("expected %d parameters" % self.num_params)
+        check(L.lib().polee_regression_set_params(self._h, ptr(p, f32p)), self.ctx._h)
+
+    def unflatten(self, vec):
+        out, o = {}, 0
+        for name, code in PARAM_TABLE:
+            shp = self._shape(code)
+            k = int(np.prod(shp)) if shp else 1
+            out[name] = vec[o:o + k].reshape(shp)
+            o += k
+        return out
+
+    def variables(self):
+        """All surrogate-posterior variables (the reference's `<name>_var`) as a dict of arrays."""
+        return self.unflatten(self.get_flat_params())
+
+    def kernel_regression_weights(self):
+        w = np.empty((self.kernel_regression_degree, self.num_features), np.float32)
+        check(L.lib().polee_regression_weights(self._h, ptr(w, f32p)), self.ctx._h)
+        return w
+
+    def get_x_posterior_params(self):
+        """models/polee_regression.py:121-122"""
+        v = self.variables()
+        return v["qx_loc"], _softplus(v["qx_softplus_scale"])
+
+    def loss_and_gradients(self, noise=None, seed=123456789):
+        """One evaluation of the variational loss and its gradient (flat), no update."""
+        z = None if noise is None else arr(noise, np.float32).reshape(-1)
+        if z is not None and z.size != self.num_noise:
+            raise ValueError("expected %d noise values" % self.num_noise)
+        loss = np.empty(1, np.float32)
+        g = np.empty(self.num_params, np.float32)
+        check(L.lib().polee_regression_eval(self._h, ptr(z, f32p), C.c_uint64(seed), ptr(loss, f32p), ptr(g, f32p)),
+              self.ctx._h)
+        return float(loss[0]), g
+
+    def fit(self, niter, seed=123456789, noise=None, return_trace=False):
+        """fit (models/polee_regression.py:303-340): returns (qx_loc, qw_loc, qw_scale, qx_bias_loc, qx_scale)."""
+        z = None if noise is None else arr(noise, np.float32).reshape(-1)
+        if z is not None and z.size != int(niter) * self.num_noise:
+            raise ValueError("noise must hold niter x num_noise values")
+        trace = np.empty(int(niter), np.float32)
+        check(L.lib().polee_regression_fit(self._h, int(niter), C.c_uint64(seed), ptr(z, f32p), ptr(trace, f32p)),
+              self.ctx._h)
+        v = self.variables()
+        out = (v["qx_loc"], v["qw_loc"], _softplus(v["qw_softplus_scale"]), v["qx_bias_loc"],
+               _softplus(v["qx_scale_loc"]))
+        return out + (trace,) if return_trace else out
+
+
+class RNASeqTranscriptLinearRegression(RNASeqLinearRegression):
+    """RNASeqTranscriptLinearRegression (models/polee_regression.py:422-460).  `vars`: the dict of
+    create_tensorflow_variables! (estimate.jl:502-556) or an RNASeqApproxLikelihood."""
+
+    def __init__(self, vars, x_init, F_arr, sample_scales, use_distortion, scale_penalty, use_point_estimates,
+                 kernel_regression_degree=15, kernel_regression_bandwidth=1.0, ctx=None):
+        x_init = np.asarray(x_init, np.float32)
+        num_features = x_init.shape[1]
+        lik = None
+        if not use_point_estimates:
+            lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=ctx)
+        super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, None, sample_scales, use_distortion,
+                         scale_penalty, use_point_estimates, kernel_regression_degree, kernel_regression_bandwidth,
+                         ctx=ctx)
+
+
+# ---- output semantics (src/regression.jl:604-685)
+def find_minimum_effect_size(mu, sigma, target_coverage):
+    """Bisection of src/regression.jl:604-622 on P(|w| < delta) under Normal(mu, sigma)."""
+    from scipy.stats import norm
+    lo, hi, coverage = 0.0, 20.0, 1.0
+    while abs(coverage - target_coverage) / target_coverage > 0.001:
+        d = (hi + lo) / 2
+        coverage = norm.cdf(d, mu, sigma) - norm.cdf(-d, mu, sigma)
+        if coverage > target_coverage:
+            hi = d
+        else:
+            lo = d
+        if hi - lo < 1e-15:
+            break
+    return (hi + lo) / 2
+
+
+def write_regression_effects(output_filename, factor_names, feature_names_label, feature_names, qx_bias, qx_scale,
+                             qw_loc, qw_scale, q0, q1, effect_size, mes_target_coverage,
+                             write_variational_posterior_params=False):
+    """write_regression_effects (src/regression.jl:625-685): CSV of effect sizes in log2 units with t_10 credible
+    intervals and the minimum effect size."""
+    from scipy.stats import t as tdist
+    qw_loc, qw_scale = np.asarray(qw_loc), np.asarray(qw_scale)
+    assert qw_loc.shape == qw_scale.shape
+    num_factors, num_features = qw_loc.shape
+    ln2 = math.log(2.0)
+    tq0, tq1 = tdist.ppf(q0, 10.0), tdist.ppf(q1, 10.0)
+    es = None if effect_size is None else math.log(abs(effect_size))
+    with open(output_filename, "w") as out:
+        out.write("factor,%s,min_effect_size,mean_effect_size,lower_credible,upper_credible" % feature_names_label)
+        if es is not None:
+            out.write(",prob_de,prob_down_de,prob_up_de")
+        if write_variational_posterior_params:
+            out.write(",qx_bias_loc,qx_scale,qw_loc,qw_scale")
+        out.write("\n")
+        for i in range(num_factors):
+            for j in range(num_features):
+                loc, sc = float(qw_loc[i, j]), float(qw_scale[i, j])
+                mes = find_minimum_effect_size(loc, sc, mes_target_coverage)
+                out.write("%s,%s,%f,%f,%f,%f" % (factor_names[i], feature_names[j], mes / ln2, loc / ln2,
+                                                 (tq0 * sc + loc) / ln2, (tq1 * sc + loc) / ln2))
+                if es is not None:
+                    down = tdist.cdf((-es - loc) / sc, 10.0)
+                    up = tdist.sf((es - loc) / sc, 10.0)
+                    out.write(",%f,%f,%f" % (max(down, up), down, up))
+                if write_variational_posterior_params:
+                    out.write(",%f,%f,%f,%f" % (qx_bias[j], qx_scale[j], loc, sc))
+                out.write("\n")
