@@ -1,0 +1,86 @@
+"""CPU: host-side pieces of the regression mirror (no device calls) and the float64 restatement's internal consistency."""
+import math
+
+import numpy as np
+from scipy.stats import norm, t as tdist
+
+from oracle import regression_ref as RR
+from polee_amd import regression as R
+
+
+def test_estimate_sample_scales_is_the_reference_formula():
+    """src/PoleeModel.jl:82-89: median over the features whose median expression exceeds the upper quantile of
+    (median profile - sample)."""
+    rng = np.random.default_rng(0)
+    base = rng.normal(-8, 2, size=500)
+    shifts = np.array([0.0, 0.7, -0.4, 1.5])
+    x = base[None, :] - shifts[:, None] + rng.normal(0, 0.01, size=(4, 500))
+    ss = R.estimate_sample_scales(x)
+    assert ss.shape == (4, 1)
+    # the scale of a sample is its offset from the median profile, up to the noise
+    np.testing.assert_allclose(ss[:, 0] - ss[0, 0], shifts - shifts[0], atol=0.02)
+    xm = np.median(x, axis=0)
+    hi = xm > np.quantile(xm, 0.95)
+    np.testing.assert_allclose(ss[:, 0], np.median(xm[hi][None] - x[:, hi], axis=1), rtol=1e-6)
+
+
+def test_minimum_effect_size_bisection():
+    """src/regression.jl:604-622: bisection until P(|w| < delta) is within 0.1 % of the target; like the reference the
+    value returned is the midpoint of the FINAL bracket (one halving past the accepted delta), so its own coverage
+    is only close to the target."""
+    for mu, sigma, target in [(0.0, 1.0, 0.9), (2.5, 0.3, 0.9), (-1.0, 2.0, 0.5)]:
+        d = R.find_minimum_effect_size(mu, sigma, target)
+        cov = norm.cdf(d, mu, sigma) - norm.cdf(-d, mu, sigma)
+        assert abs(cov - target) / target <= 0.02
+    assert abs(R.find_minimum_effect_size(0.0, 1.0, 0.9) - 1.6449) < 5e-2
+
+
+def test_write_regression_effects_format(tmp_path):
+    """src/regression.jl:625-685: log2 units, t_10 credible interval, probabilities of a minimum effect."""
+    qw_loc = np.array([[0.5, -2.0], [0.0, 1.0]])
+    qw_scale = np.array([[0.1, 0.5], [1.0, 0.2]])
+    out = tmp_path / "effects.csv"
+    R.write_regression_effects(str(out), ["a", "b"], "transcript_id", ["t1", "t2"], np.zeros(2), np.ones(2), qw_loc,
+                               qw_scale, 0.05, 0.95, 1.5, 0.9, write_variational_posterior_params=True)
+    lines = out.read_text().strip().split("\n")
+    assert lines[0] == ("factor,transcript_id,min_effect_size,mean_effect_size,lower_credible,upper_credible,"
+                        "prob_de,prob_down_de,prob_up_de,qx_bias_loc,qx_scale,qw_loc,qw_scale")
+    assert len(lines) == 5
+    row = lines[2].split(",")  # factor a, feature t2
+    assert row[:2] == ["a", "t2"]
+    ln2 = math.log(2)
+    assert abs(float(row[3]) - (-2.0 / ln2)) < 1e-5
+    assert abs(float(row[4]) - (tdist.ppf(0.05, 10) * 0.5 - 2.0) / ln2) < 1e-5
+    down = tdist.cdf((-math.log(1.5) + 2.0) / 0.5, 10)
+    assert abs(float(row[7]) - down) < 1e-5 and abs(float(row[6]) - down) < 1e-5
+
+
+def test_parameter_tables_agree_and_restatement_is_smooth():
+    assert R.PARAM_TABLE == RR.PARAMS
+    rng = np.random.default_rng(1)
+    S, F, n, deg = 3, 2, 11, 4
+    x_init = rng.normal(-3, 1, size=(S, n))
+    p = RR.initial_params(x_init, F, deg)
+    assert p["qw_softplus_scale"].max() == 0.0 and p["qx_scale_loc"].min() == -0.5
+    vec = RR.flatten(p, RR.PARAMS) + rng.normal(0, 0.2, size=4 + F * deg + 2 * deg + 10 * F * n + 4 * n + 2 * S * n)
+    eps = RR.unflatten(rng.normal(size=2 + 5 * F * n + 2 * n + S * n), RR.NOISE, S, F, n, deg)
+    mean = x_init.mean(axis=0)
+    W = RR.kernel_regression_weights(1.0, mean, RR.choose_knots(mean.min(), mean.max(), deg))
+    np.testing.assert_allclose(W.sum(axis=0), 1.0, rtol=1e-12)
+    kw = dict(design=np.eye(S, F), W=W, sample_scales=np.zeros(S), x_bias_loc0=-2.0, x_bias_scale0=12.0,
+              use_distortion=True, scale_penalty=1.0, use_point_estimates=False)
+    l0, z = RR.regression_loss(RR.unflatten(vec, RR.PARAMS, S, F, n, deg), eps, **kw)
+    assert np.isfinite(l0) and z["x"].shape == (S, n)
+    # the scale-drift penalty is the only term that sees qx_loc other than through x: shifting qx_loc by c and x_bias
+    # by the same c leaves the x ~ Normal(x_loc, x_scale) term unchanged
+    pp = RR.unflatten(vec.copy(), RR.PARAMS, S, F, n, deg)
+    pp["qx_loc"] = pp["qx_loc"] + 0.3
+    pp["qx_bias_loc"] = pp["qx_bias_loc"] + 0.3
+    l1, _ = RR.regression_loss(pp, eps, **kw)
+    m = RR.unflatten(vec, RR.PARAMS, S, F, n, deg)["qx_loc"]
+    t0 = np.log(np.exp(m).sum(axis=1))
+    b0 = RR.unflatten(vec, RR.PARAMS, S, F, n, deg)["qx_bias_loc"] + \
+        RR.softplus(RR.unflatten(vec, RR.PARAMS, S, F, n, deg)["qx_bias_softplus_scale"]) * eps["x_bias"]
+    expected = 0.5 * (((t0 + 0.3) ** 2).sum() - (t0 ** 2).sum()) + \
+        0.5 * ((((b0 + 0.3) + 2.0) / 12.0) ** 2 - ((b0 + 2.0) / 12.0) ** 2).sum()
+    np.testing.assert_allclose(l1 - l0, expected, rtol=1e-8, atol=1e-8)
