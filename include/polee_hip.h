@@ -360,6 +360,8 @@ polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feat
  *   ap            fitted approximations of the S samples (the likelihood term, polee_approx_likelihood.py:367-450);
  *                 NULL or use_point_estimates != 0: no likelihood term, x fixed at x_init (qx_loc not trained)
  *   design        f32 [S][F] factor matrix;  x_init f32 [S][n] log expression;  sample_scales f32 [S]
+ *   x_init_mean   f32 [n] column means of x_init over ALL samples, or NULL to take them from x_init (needed when
+ *                 this handle holds one rank's shard of the samples, see polee_regression_set_comm)
  *   hinges        f32 [degree] kernel-regression knots, or NULL for choose_knots(min, max of the column means of
  *                 x_init) as RNASeqTranscriptLinearRegression does (models/polee_regression.py:436-440)
  *   x_bias_loc0 / x_bias_scale0   prior of x_bias (log(1/n) and 12 in the reference's subclasses)
@@ -374,8 +376,8 @@ polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feat
  * [F][n] each: w_local1_scale_variance, w_local1_scale_noncentered, w_local2_.., w_local2_.., w; x_bias [n];
  * x_scale [n]; x [S][n]. */
 polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap_or_null, int32_t S, int32_t F, int32_t n,
-                                     const float *design, const float *x_init, const float *sample_scales,
-                                     const float *hinges_or_null, int32_t degree, float bandwidth, float x_bias_loc0,
+                                     const float *design, const float *x_init, const float *x_init_mean_or_null,
+                                     const float *sample_scales, const float *hinges_or_null, int32_t degree, float bandwidth, float x_bias_loc0,
                                      float x_bias_scale0, int use_distortion, float scale_penalty,
                                      int use_point_estimates, polee_regression **out);
 void polee_regression_destroy(polee_regression *reg);
@@ -383,6 +385,10 @@ int64_t polee_regression_num_params(const polee_regression *reg);
 int64_t polee_regression_num_noise(const polee_regression *reg);
 polee_status polee_regression_get_params(polee_regression *reg, float *params);
 polee_status polee_regression_set_params(polee_regression *reg, const float *params);
+/* Samples sharded over ranks: every rank creates the model over ITS samples (S = local count, the
+ * same F, n, hinges, x_init_mean and seed everywhere), so the shared parameters are replicas and qx_* are local.
+ * Per step one sum all-reduce of (F+2) n + 1 f32 observation-model statistics is the only exchange. */
+polee_status polee_regression_set_comm(polee_regression *reg, polee_comm *comm_or_null);
 /* kernel_regression_weights (src/polee.py:36-47) as the model uses them: f32 [degree][n] */
 polee_status polee_regression_weights(polee_regression *reg, float *weights);
 /* loss and (optionally) its gradient w.r.t. the flat parameter vector at the current parameters, for the draw

@@ -78,3 +78,22 @@ class Ranks:
     def aggregate_throughput(self, local_units, local_seconds):
         """Whole-job rate = units of all ranks / slowest rank's time."""
         return self.sum(local_units) / self.max(local_seconds)
+
+
+def shard_regression_inputs(vars, x_init, F_arr, sample_scales, world_size, rank):
+    """Inputs of RNASeqTranscriptLinearRegression for `rank` when the SAMPLES of the regression are sharded over the
+    ranks (polee_regression_set_comm): this rank's rows of every per-sample array, and the column
+    means of x_init over all samples (the shared parameters' initial values and the kernel-regression knots must be
+    the same everywhere).  Per-sample arrays of `vars` are those with a leading dimension of S; a shared tree
+    ([1, N] index arrays) is passed through.  Returns a dict of keyword arguments."""
+    import numpy as np
+    x_init = np.asarray(x_init)
+    S = x_init.shape[0]
+    rows = shard_samples(S, world_size, rank)
+    if not rows:
+        raise ValueError("rank %d would hold no sample (%d samples over %d ranks)" % (rank, S, world_size))
+    sl = slice(rows[0], rows[-1] + 1)
+    v = {k: (np.asarray(a)[sl] if np.ndim(a) >= 1 and np.shape(a)[0] == S and S > 1 else a) for k, a in vars.items()}
+    return dict(vars=v, x_init=x_init[sl], F_arr=np.asarray(F_arr)[sl],
+                sample_scales=np.asarray(sample_scales).reshape(S, -1)[sl],
+                x_init_mean=x_init.astype(np.float64).mean(axis=0).astype(np.float32))

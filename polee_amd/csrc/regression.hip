@@ -10,13 +10,17 @@
 //   lse      : t_s = logsumexp_j qx_loc[s][j] (the scale-drift penalty's value)   -> lse   [S]
 //   sample x : x = qx_loc + softplus(qx_softplus_scale) eps                       -> x     [S][n]
 //   lik      : approximate likelihood of x with d/dx                              -> lp [S], glik [S][n]
+//   data     : one thread per feature j over this rank's samples: observation-model sums (F+2 per column),
+//              gradients of qx_loc / qx_softplus_scale, the samples' loss terms           -> stats [(F+2) n + 1]
+//   (samples sharded over ranks: ONE all-reduce of stats, polee_regression_set_comm)
 //   columns  : one thread per feature j: draws the horseshoe+ scales, w, x_bias, x_scale of its column,
-//              evaluates its share of log q - log p and all per-column gradients; block-reduces the
-//              pieces shared by columns (global scale, distortion, mean-variance coefficients)
+//              evaluates its share of log q - log p and all per-column gradients from stats; block-reduces
+//              the pieces shared by columns (global scale, distortion, mean-variance coefficients)
 //   finish   : the few global parameters
 //   adam     : Keras Adam over the flat parameter vector
 // Everything is O((F + S) n) bytes per step (cache / latency bound): no roofline claim.
 #include "common.hpp"
+#include "comm_internal.hpp"
 #include "rng.hpp"
 
 #include <cmath>
@@ -149,26 +153,95 @@ __global__ void reg_sample_x_kernel(RegView v, const float *p, const float *eps,
     x[i] = p[v.o_qx_loc() + i] + softplusf(p[v.o_qx_s() + i]) * eps[v.e_x() + i];
 }
 
-// acc: [0] loss (double); small: [0] sum (1 - r^2), then d/d(distortion_c) [F][deg], then the sums feeding
-// d/d(concentration_c) [deg] and d/d(scale_c) [deg]
-__global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const float *__restrict__ p,
+// ---- data pass: what the S (local) samples say about each column ------------------------------------------
+// stats [F+2][n] + 1:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
+// row F+1  sum_s d(-log p_x)/d x_scale;  last value  loss terms of the samples (observation model, log q of x,
+// scale-drift penalty, -likelihood).  These are sums over samples: with the samples sharded over ranks ONE all-reduce
+// of this buffer is the only exchange of a step.  Also writes d loss / d qx_loc, qx_softplus_scale.
+__global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const float *__restrict__ p,
                                                              const float *__restrict__ eps,
                                                              const float *__restrict__ design,
                                                              const float *__restrict__ W, const float *__restrict__ ss,
                                                              const float *__restrict__ x, const float *__restrict__ glik,
-                                                             const float *__restrict__ lse, float *__restrict__ g,
-                                                             double *loss_acc, float *small)
+                                                             const float *__restrict__ lse, const float *__restrict__ lp,
+                                                             float *__restrict__ g, float *__restrict__ stats)
 {
-    __shared__ float s_weff[REG_MAXF][REG_BLOCK], s_gacc[REG_MAXF][REG_BLOCK], s_wpr[REG_MAXF][REG_BLOCK];
-    __shared__ float s_red[1 + REG_MAXF * REG_MAXDEG + 2 * REG_MAXDEG];
-    __shared__ float s_cc[REG_MAXDEG], s_sc[REG_MAXDEG];
+    __shared__ float s_weff[REG_MAXF][REG_BLOCK], s_gacc[REG_MAXF][REG_BLOCK];
     const int tid = threadIdx.x;
     const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
     const bool live = jj < v.n;
     const int64_t j = live ? jj : v.n - 1;  // dead lanes recompute the last column and contribute nothing
     const int F = v.F, deg = v.deg, n = v.n;
     const int64_t Fn = v.Fn();
+    for (int f = 0; f < F; ++f) {
+        const int64_t idx = (int64_t)f * n + j;
+        const float w = p[v.o_cols() + 8 * Fn + idx] + softplusf(p[v.o_cols() + 9 * Fn + idx]) * eps[v.e_cols() + 4 * Fn + idx];
+        float wd = 0.0f;
+        if (v.use_distortion)
+            for (int d = 0; d < deg; ++d) wd += p[v.o_dist() + f * deg + d] * W[(int64_t)d * n + j];
+        s_weff[f][tid] = w + wd;
+        s_gacc[f][tid] = 0.0f;
+    }
+    const float b = p[v.o_bias_loc() + j] + softplusf(p[v.o_bias_s() + j]) * eps[v.e_bias() + j];
+    const float xsz = softplusf(p[v.o_xs_loc() + j] + softplusf(p[v.o_xs_s() + j]) * eps[v.e_xs() + j]);
+    const float inv = 1.0f / xsz, inv2 = inv * inv, lxs = logf(xsz);
+    const float ipen2 = 1.0f / (v.penalty * v.penalty);
+    float loss = 0.0f, sum_a = 0.0f, sum_xs = 0.0f;
+    for (int s = 0; s < v.S; ++s) {
+        float xl = b;
+        for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
+        const int64_t sj = (int64_t)s * n + j;
+        const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
+        const float d = xv - (xl - ss[s]);
+        const float a = d * inv2;
+        loss += 0.5f * d * a + lxs + HALF_LOG2PI;
+        sum_xs += inv - d * a * inv;
+        sum_a += a;
+        for (int f = 0; f < F; ++f) s_gacc[f][tid] -= design[s * F + f] * a;
+        float gl = 0.0f, gs = 0.0f;
+        if (!v.point) {
+            const float sraw = p[v.o_qx_s() + sj], sx = softplusf(sraw), e = eps[v.e_x() + sj];
+            const float Gx = a - glik[sj];
+            gl = Gx + lse[s] * ipen2 * expf(p[v.o_qx_loc() + sj] - lse[s]);
+            gs = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
+            loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;
+        }
+        if (live) g[v.o_qx_loc() + sj] = gl, g[v.o_qx_s() + sj] = gs;
+    }
+    if (live) {
+        for (int f = 0; f < F; ++f) stats[(int64_t)f * n + j] = s_gacc[f][tid];
+        stats[(int64_t)F * n + j] = sum_a;
+        stats[(int64_t)(F + 1) * n + j] = sum_xs;
+    }
+    loss = wave_sum(live ? loss : 0.0f);
+    if (blockIdx.x == 0 && tid == 0 && !v.point)
+        for (int s = 0; s < v.S; ++s) {  // per-sample terms: scale-drift penalty, approximate likelihood
+            const float t = lse[s] / v.penalty;
+            loss += 0.5f * t * t + logf(v.penalty) + HALF_LOG2PI - (lp ? lp[s] : 0.0f);
+        }
+    if ((tid & 63) == 0) atomicAdd(&stats[(int64_t)(F + 2) * n], loss);
+}
+
+// ---- prior pass: everything that does not depend on which samples a rank holds, combined with the (summed) stats
+// acc: [0] loss (double); small: [0] sum (1 - r^2), then d/d(distortion_c) [F][deg], then the sums feeding
+// d/d(concentration_c) [deg] and d/d(scale_c) [deg]
+__global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const float *__restrict__ p,
+                                                             const float *__restrict__ eps,
+                                                             const float *__restrict__ W,
+                                                             const float *__restrict__ stats, float *__restrict__ g,
+                                                             double *loss_acc, float *small)
+{
+    __shared__ float s_red[1 + REG_MAXF * REG_MAXDEG + 2 * REG_MAXDEG];
+    __shared__ float s_cc[REG_MAXDEG], s_sc[REG_MAXDEG];
+    const int tid = threadIdx.x;
+    const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
+    const bool live = jj < v.n;
+    const int64_t j = live ? jj : v.n - 1;
+    const int F = v.F, deg = v.deg, n = v.n;
+    const int64_t Fn = v.Fn();
     const int nred = v.num_red();
+    const float lv = live ? 1.0f : 0.0f;
+    const int lane = tid & 63;
     for (int i = tid; i < nred; i += REG_BLOCK) s_red[i] = 0.0f;
     if (tid < deg) {
         s_cc[tid] = softplusf(p[v.o_conc() + tid]);
@@ -181,7 +254,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
     const float gscale = gn.z * sqrtf(gv.z);
 
-    // ---- phase A: horseshoe+ scales and w of every factor
+    // ---- horseshoe+ scales and w of every factor
     for (int f = 0; f < F; ++f) {
         const int64_t idx = (int64_t)f * n + j;
         const float *pc = p + v.o_cols() + idx;
@@ -191,7 +264,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         const SpDraw l1n = sp_draw(pc[2 * Fn], pc[3 * Fn], ec[1 * Fn]);
         const SpDraw l2v = sp_draw(pc[4 * Fn], pc[5 * Fn], ec[2 * Fn]);
         const SpDraw l2n = sp_draw(pc[6 * Fn], pc[7 * Fn], ec[3 * Fn]);
-        const float s_w = softplusf(pc[9 * Fn]), e_w = ec[4 * Fn];
+        const float sraw_w = pc[9 * Fn], s_w = softplusf(sraw_w), e_w = ec[4 * Fn];
         const float w = pc[8 * Fn] + s_w * e_w;
         const float sw = (l1n.z * sqrtf(l1v.z)) * (l2n.z * sqrtf(l2v.z)) * gscale;
         const float r = w / sw, q = 1.0f - r * r;
@@ -208,15 +281,20 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         if (live) gc[4 * Fn] = a, gc[5 * Fn] = b;
         sp_grad(l2n, l2n.z + q / l2n.z, a, b);
         if (live) gc[6 * Fn] = a, gc[7 * Fn] = b;
-        float wd = 0.0f;
+        const float gacc = stats[idx];
+        const float Gw = r / sw + gacc;
+        if (live) {
+            gc[8 * Fn] = Gw;
+            gc[9 * Fn] = (Gw * e_w - 1.0f / s_w) * sigmoidf(sraw_w);
+        }
         if (v.use_distortion)
-            for (int d = 0; d < deg; ++d) wd += p[v.o_dist() + f * deg + d] * W[(int64_t)d * n + j];
-        s_weff[f][tid] = w + wd;
-        s_wpr[f][tid] = r / sw;
-        s_gacc[f][tid] = 0.0f;
+            for (int d = 0; d < deg; ++d) {
+                const float t = wave_sum(lv * W[(int64_t)d * n + j] * gacc);
+                if (lane == 0) atomicAdd(&s_red[1 + f * deg + d], t);
+            }
     }
 
-    // ---- phase B: x_bias, x_scale and the S observations of this column
+    // ---- x_bias, x_scale
     const float s_b = softplusf(p[v.o_bias_s() + j]), e_b = eps[v.e_bias() + j];
     const float b = p[v.o_bias_loc() + j] + s_b * e_b;
     loss += -0.5f * e_b * e_b - logf(s_b) - HALF_LOG2PI;
@@ -229,34 +307,12 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         beta += s_sc[d] * wdj;
     }
     const float inv = 1.0f / xs.z, inv2 = inv * inv, lxs = logf(xs.z);
-    float Gxs = (alpha + 1.0f) * inv - beta * inv2;
+    const float Gxs = (alpha + 1.0f) * inv - beta * inv2 + stats[(int64_t)(F + 1) * n + j];
     const float db = (b - v.bias_loc0) / v.bias_scale0;
-    float Gb = db / v.bias_scale0;
+    const float Gb = db / v.bias_scale0 - stats[(int64_t)F * n + j];
     loss += 0.5f * db * db + logf(v.bias_scale0) + HALF_LOG2PI;
     loss += -(alpha * logf(beta) - lgammaf(alpha) - (alpha + 1.0f) * lxs - beta * inv);
     const float g_alpha = -logf(beta) + digammaf(alpha) + lxs, g_beta = -alpha / beta + inv;
-    const float ipen2 = 1.0f / (v.penalty * v.penalty);
-    for (int s = 0; s < v.S; ++s) {
-        float xl = b;
-        for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
-        const int64_t sj = (int64_t)s * n + j;
-        const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
-        const float d = xv - (xl - ss[s]);
-        const float a = d * inv2;
-        loss += 0.5f * d * a + lxs + HALF_LOG2PI;
-        Gxs += inv - d * a * inv;
-        Gb -= a;
-        for (int f = 0; f < F; ++f) s_gacc[f][tid] -= design[s * F + f] * a;
-        float gl = 0.0f, gs = 0.0f;
-        if (!v.point) {
-            const float sraw = p[v.o_qx_s() + sj], sx = softplusf(sraw), e = eps[v.e_x() + sj];
-            const float Gx = a - glik[sj];
-            gl = Gx + lse[s] * ipen2 * expf(p[v.o_qx_loc() + sj] - lse[s]);
-            gs = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
-            loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;
-        }
-        if (live) g[v.o_qx_loc() + sj] = gl, g[v.o_qx_s() + sj] = gs;
-    }
     if (live) {
         g[v.o_bias_loc() + j] = Gb;
         g[v.o_bias_s() + j] = (Gb * e_b - 1.0f / s_b) * sigmoidf(p[v.o_bias_s() + j]);
@@ -266,23 +322,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         g[v.o_xs_s() + j] = c;
     }
 
-    // ---- phase C: w's gradient, block sums of what the columns share
-    const float lv = live ? 1.0f : 0.0f;
-    const int lane = tid & 63;
-    for (int f = 0; f < F; ++f) {
-        const int64_t idx = (int64_t)f * n + j;
-        const float Gw = s_wpr[f][tid] + s_gacc[f][tid];
-        const float sraw = p[v.o_cols() + 9 * Fn + idx], e_w = eps[v.e_cols() + 4 * Fn + idx];
-        if (live) {
-            g[v.o_cols() + 8 * Fn + idx] = Gw;
-            g[v.o_cols() + 9 * Fn + idx] = (Gw * e_w - 1.0f / softplusf(sraw)) * sigmoidf(sraw);
-        }
-        if (v.use_distortion)
-            for (int d = 0; d < deg; ++d) {
-                const float t = wave_sum(lv * W[(int64_t)d * n + j] * s_gacc[f][tid]);
-                if (lane == 0) atomicAdd(&s_red[1 + f * deg + d], t);
-            }
-    }
+    // ---- block sums of what the columns share
     for (int d = 0; d < deg; ++d) {
         const float wdj = lv * W[(int64_t)d * n + j];
         const float ta = wave_sum(wdj * g_alpha), tb = wave_sum(wdj * g_beta);
@@ -302,8 +342,8 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
 }
 
 // the global horseshoe scale, the distortion / mean-variance coefficients, the per-sample terms
-__global__ void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small, const float *lse,
-                                  const float *lp, const double *loss_acc, float *g, float *loss_out)
+__global__ void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small,
+                                  const float *stats, const double *loss_acc, float *g, float *loss_out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double loss = loss_acc[0];
@@ -329,12 +369,7 @@ __global__ void reg_finish_kernel(RegView v, const float *p, const float *eps, c
             g[o] = (2.0f * c / (1.0f + c * c) + small[1 + v.F * v.deg + h * v.deg + d]) * sigmoidf(p[o]);
             loss += 0.45158270528945486473f + log1pf(c * c);  // -log(2/pi)
         }
-    if (!v.point)
-        for (int s = 0; s < v.S; ++s) {
-            const float t = lse[s] / v.penalty;
-            loss += 0.5f * t * t + logf(v.penalty) + HALF_LOG2PI;
-            if (lp) loss -= lp[s];
-        }
+    loss += stats[(int64_t)(v.F + 2) * v.n];  // the samples' terms (summed over ranks)
     loss_out[0] = (float)loss;
 }
 
@@ -361,14 +396,16 @@ struct polee_regression {
     RegView v{};
     float lr = 2e-3f;
     int64_t step = 0;  // ADAM steps taken
-    DevBuf<float> d_p, d_g, d_m, d_v, d_eps, d_design, d_W, d_ss, d_x, d_glik, d_lp, d_lse, d_small, d_loss;
+    DevBuf<float> d_p, d_g, d_m, d_v, d_eps, d_design, d_W, d_ss, d_x, d_glik, d_lp, d_lse, d_small, d_loss, d_stats;
     DevBuf<double> d_acc;
+    polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
+    int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + 1; }
 };
 
 namespace {
 
-// loss and gradient at the current parameters for the noise in d_eps
-polee_status reg_eval_device(polee_regression *r)
+// data pass for the noise in d_eps: d_stats (this rank's samples) and the gradients of qx_*
+polee_status reg_data_pass(polee_regression *r)
 {
     polee_ctx *ctx = r->ctx;
     const RegView &v = r->v;
@@ -381,24 +418,51 @@ polee_status reg_eval_device(polee_regression *r)
         POLEE_KERNEL_CHECK(ctx);
         if (r->ap) POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
     }
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double), st));
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * v.num_red(), st));
-    hipLaunchKernelGGL(reg_cols_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
-                       r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p, r->d_g.p,
-                       r->d_acc.p, r->d_small.p);
-    hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p, r->d_lse.p,
-                       (!v.point && r->ap) ? r->d_lp.p : nullptr, r->d_acc.p, r->d_g.p, r->d_loss.p);
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - 1, 0, sizeof(float), st));
+    hipLaunchKernelGGL(reg_data_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
+                       r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p,
+                       (!v.point && r->ap) ? r->d_lp.p : nullptr, r->d_g.p, r->d_stats.p);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
 
+// prior pass: d_stats (summed over ranks) -> loss and the gradients of everything the ranks share
+polee_status reg_prior_pass(polee_regression *r)
+{
+    polee_ctx *ctx = r->ctx;
+    const RegView &v = r->v;
+    hipStream_t st = ctx->stream;
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double), st));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * v.num_red(), st));
+    hipLaunchKernelGGL(reg_cols_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
+                       r->d_eps.p, r->d_W.p, r->d_stats.p, r->d_g.p, r->d_acc.p, r->d_small.p);
+    hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p,
+                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+// loss and gradient at the current parameters for the noise in d_eps
+polee_status reg_eval_device(polee_regression *r)
+{
+    POLEE_TRY(reg_data_pass(r));
+    if (r->comm && r->comm->nranks > 1)
+        POLEE_TRY(comm_allreduce_device(r->comm, r->d_stats.p, (size_t)r->num_stats(), false));
+    return reg_prior_pass(r);
+}
+
+// The latents every rank shares are drawn from (seed, step) alone, so that replicas stay identical; the noise of
+// x belongs to a rank's own samples and is salted with the rank.
 polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t seed, uint32_t step)
 {
     polee_ctx *ctx = r->ctx;
-    const int64_t ne = r->v.num_noise();
+    const int64_t ne = r->v.num_noise(), shared = r->v.e_x(), own = ne - shared;
     if (noise) return r->d_eps.upload(ctx, noise, (size_t)ne);
-    hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(ne, 4), 256)), dim3(256), 0, ctx->stream, ne,
-                       seed, step, r->d_eps.p);
+    const uint64_t salt = 0xD1B54A32D192ED03ull * (uint64_t)(r->comm ? r->comm->rank + 1 : 1);
+    hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(shared, 4), 256)), dim3(256), 0, ctx->stream,
+                       shared, seed, step, r->d_eps.p);
+    hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(own, 4), 256)), dim3(256), 0, ctx->stream, own,
+                       seed ^ salt, step, r->d_eps.p + shared);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -408,8 +472,8 @@ polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t se
 extern "C" {
 
 polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S, int32_t F, int32_t n,
-                                     const float *design, const float *x_init, const float *sample_scales,
-                                     const float *hinges, int32_t degree, float bandwidth, float x_bias_loc0,
+                                     const float *design, const float *x_init, const float *x_init_mean,
+                                     const float *sample_scales, const float *hinges, int32_t degree, float bandwidth, float x_bias_loc0,
                                      float x_bias_scale0, int use_distortion, float scale_penalty,
                                      int use_point_estimates, polee_regression **out)
 {
@@ -439,9 +503,13 @@ polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S
     // initial values (models/polee_regression.py:49-119)
     std::vector<float> p((size_t)P, 0.0f);
     std::vector<double> mean((size_t)n, 0.0);
-    for (int s = 0; s < S; ++s)
-        for (int j = 0; j < n; ++j) mean[(size_t)j] += x_init[(size_t)s * n + j];
-    for (auto &m : mean) m /= S;
+    if (x_init_mean)  // the column means over ALL samples when this handle holds a shard of them
+        for (int j = 0; j < n; ++j) mean[(size_t)j] = x_init_mean[j];
+    else {
+        for (int s = 0; s < S; ++s)
+            for (int j = 0; j < n; ++j) mean[(size_t)j] += x_init[(size_t)s * n + j];
+        for (auto &m : mean) m /= S;
+    }
     p[1] = p[3] = -1.0f;
     for (int d = 0; d < degree; ++d) p[(size_t)(v.o_conc() + d)] = p[(size_t)(v.o_scc() + d)] = 1.0f;
     for (int a = 1; a < 8; a += 2) std::fill_n(p.begin() + v.o_cols() + a * Fn, Fn, -1.0f);
@@ -479,7 +547,7 @@ polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S
         ok(r->d_m.alloc(ctx, (size_t)P)) && ok(r->d_v.alloc(ctx, (size_t)P)) &&
         ok(r->d_eps.alloc(ctx, (size_t)v.num_noise())) && ok(r->d_x.alloc(ctx, (size_t)sn)) &&
         ok(r->d_glik.alloc(ctx, (size_t)sn)) && ok(r->d_lp.alloc(ctx, (size_t)S)) && ok(r->d_lse.alloc(ctx, (size_t)S)) &&
-        ok(r->d_small.alloc(ctx, (size_t)v.num_red())) && ok(r->d_loss.alloc(ctx, 1)) && ok(r->d_acc.alloc(ctx, 1))) {
+        ok(r->d_small.alloc(ctx, (size_t)v.num_red())) && ok(r->d_stats.alloc(ctx, (size_t)r->num_stats())) && ok(r->d_loss.alloc(ctx, 1)) && ok(r->d_acc.alloc(ctx, 1))) {
         hipError_t e = hipMemsetAsync(r->d_m.p, 0, sizeof(float) * P, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_v.p, 0, sizeof(float) * P, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_glik.p, 0, sizeof(float) * sn, ctx->stream);
@@ -500,6 +568,7 @@ void polee_regression_destroy(polee_regression *r)
     if (!r) return;
     polee_ctx *ctx = r->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
+    polee_comm_destroy(r->comm);
     delete r;
     ctx_release(ctx);
 }
@@ -526,6 +595,38 @@ polee_status polee_regression_weights(polee_regression *r, float *weights)
     if (!r || !weights) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(r->ctx));
     return r->d_W.download(r->ctx, weights, (size_t)r->v.deg * r->v.n);
+}
+
+polee_status polee_regression_set_comm(polee_regression *r, polee_comm *comm)
+{
+    if (!r) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    if (comm && comm->ctx != r->ctx)
+        return fail(r->ctx, POLEE_ERR_BAD_ARG, "communicator and model belong to different contexts");
+    if (comm) ++comm->refs;
+    polee_comm_destroy(r->comm);
+    r->comm = comm;
+    return POLEE_OK;
+}
+
+// test hooks (include/polee_hip_debug.h): the two halves of a step, with the exchange left to the caller
+polee_status polee_debug_regression_data_pass(polee_regression *r, const float *noise, float *stats)
+{
+    if (!r || !noise || !stats) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(r->ctx));
+    POLEE_TRY(r->d_eps.upload(r->ctx, noise, (size_t)r->v.num_noise()));
+    POLEE_TRY(reg_data_pass(r));
+    return r->d_stats.download(r->ctx, stats, (size_t)r->num_stats());
+}
+
+polee_status polee_debug_regression_prior_pass(polee_regression *r, const float *stats, float *loss, float *grad)
+{
+    if (!r || !stats || !loss) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(r->ctx));
+    POLEE_TRY(r->d_stats.upload(r->ctx, stats, (size_t)r->num_stats()));
+    POLEE_TRY(reg_prior_pass(r));
+    POLEE_TRY(r->d_loss.download(r->ctx, loss, 1));
+    if (grad) POLEE_TRY(r->d_g.download(r->ctx, grad, (size_t)r->v.num_params()));
+    return POLEE_OK;
 }
 
 polee_status polee_regression_eval(polee_regression *r, const float *noise, uint64_t seed, float *loss, float *grad)

@@ -49,7 +49,9 @@ class RNASeqLinearRegression:
 
     def __init__(self, F, x_init, likelihood_model, x_bias_loc0, x_bias_scale0, x_scale_hinges, sample_scales,
                  use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
-                 kernel_regression_bandwidth, ctx=None):
+                 kernel_regression_bandwidth, ctx=None, comm=None, x_init_mean=None):
+        """comm / x_init_mean: samples sharded over ranks (polee_regression_set_comm) -- F, x_init, sample_scales are
+        this rank's rows, x_init_mean the column means of x_init over all samples."""
         Fm = arr(np.atleast_2d(F), np.float32)
         x0 = arr(np.atleast_2d(x_init), np.float32)
         ss = arr(np.asarray(sample_scales).reshape(-1), np.float32)
@@ -68,9 +70,12 @@ class RNASeqLinearRegression:
         self.ctx = ctx or (likelihood_model.ctx if likelihood_model is not None else default_context())
         self._h = C.c_void_p()
         ap = likelihood_model._h if (likelihood_model is not None and not self.use_point_estimates) else None
+        xm = None if x_init_mean is None else arr(np.asarray(x_init_mean).reshape(-1), np.float32)
+        if xm is not None and xm.size != self.num_features:
+            raise ValueError("x_init_mean must hold one value per feature")
         check(L.lib().polee_regression_create(
             self.ctx._h, ap, self.num_samples, self.num_factors, self.num_features, ptr(Fm, f32p), ptr(x0, f32p),
-            ptr(ss, f32p), ptr(hg, f32p), self.kernel_regression_degree, C.c_float(kernel_regression_bandwidth),
+            ptr(xm, f32p), ptr(ss, f32p), ptr(hg, f32p), self.kernel_regression_degree, C.c_float(kernel_regression_bandwidth),
             C.c_float(x_bias_loc0), C.c_float(x_bias_scale0), int(bool(use_distortion)), C.c_float(scale_penalty),
             int(self.use_point_estimates), C.byref(self._h)), self.ctx._h)
         lib = L.lib()
@@ -80,6 +85,9 @@ class RNASeqLinearRegression:
         lib.polee_regression_num_noise.argtypes = [C.c_void_p]
         self.num_params = int(lib.polee_regression_num_params(self._h))
         self.num_noise = int(lib.polee_regression_num_noise(self._h))
+        self.comm = comm
+        if comm is not None:
+            check(lib.polee_regression_set_comm(self._h, comm._h), self.ctx._h)
 
     def __del__(self):
         try:
@@ -142,6 +150,20 @@ class RNASeqLinearRegression:
               self.ctx._h)
         return float(loss[0]), g
 
+    # test hooks: the two halves of a step (include/polee_hip_debug.h)
+    def _data_pass(self, noise):
+        z = arr(noise, np.float32).reshape(-1)
+        stats = np.empty((self.num_factors + 2) * self.num_features + 1, np.float32)
+        check(L.lib().polee_debug_regression_data_pass(self._h, ptr(z, f32p), ptr(stats, f32p)), self.ctx._h)
+        return stats
+
+    def _prior_pass(self, stats):
+        st = arr(stats, np.float32).reshape(-1)
+        loss, g = np.empty(1, np.float32), np.empty(self.num_params, np.float32)
+        check(L.lib().polee_debug_regression_prior_pass(self._h, ptr(st, f32p), ptr(loss, f32p), ptr(g, f32p)),
+              self.ctx._h)
+        return float(loss[0]), g
+
     def fit(self, niter, seed=123456789, noise=None, return_trace=False):
         """fit (models/polee_regression.py:303-340): returns (qx_loc, qw_loc, qw_scale, qx_bias_loc, qx_scale)."""
         z = None if noise is None else arr(noise, np.float32).reshape(-1)
@@ -161,15 +183,16 @@ class RNASeqTranscriptLinearRegression(RNASeqLinearRegression):
     create_tensorflow_variables! (estimate.jl:502-556) or an RNASeqApproxLikelihood."""
 
     def __init__(self, vars, x_init, F_arr, sample_scales, use_distortion, scale_penalty, use_point_estimates,
-                 kernel_regression_degree=15, kernel_regression_bandwidth=1.0, ctx=None):
+                 kernel_regression_degree=15, kernel_regression_bandwidth=1.0, ctx=None, comm=None, x_init_mean=None,
+                 x_scale_hinges=None):
         x_init = np.asarray(x_init, np.float32)
         num_features = x_init.shape[1]
         lik = None
         if not use_point_estimates:
             lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=ctx)
-        super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, None, sample_scales, use_distortion,
-                         scale_penalty, use_point_estimates, kernel_regression_degree, kernel_regression_bandwidth,
-                         ctx=ctx)
+        super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, x_scale_hinges, sample_scales,
+                         use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
+                         kernel_regression_bandwidth, ctx=ctx, comm=comm, x_init_mean=x_init_mean)
 
 
 # ---- output semantics (src/regression.jl:604-685)

@@ -203,3 +203,62 @@ def test_regression_argument_errors(P, ctx):
     reg = P.RNASeqTranscriptLinearRegression(None, x_init, design, np.zeros(2), True, 1.0, True, ctx=ctx)
     with pytest.raises(ValueError):
         reg.loss_and_gradients(noise=np.zeros(3, np.float32))
+
+
+def test_sample_sharding_statistics_reproduce_the_whole_model(P, ctx):
+    """SURVEY 8(e) for the regression: samples sharded over ranks, one all-reduce of (F+2) n + 1 statistics.  Emulated
+    on one GPU with the debug hooks: two handles holding half the samples each; their data-pass statistics summed on
+    the host and fed to the prior pass give the loss and shared-parameter gradients of the whole model, and each
+    shard's qx gradients are the whole model's rows."""
+    rng = np.random.default_rng(35)
+    S, F, n, deg = 4, 2, 200, 6
+    vars_, design, x_init = _problem(rng, S, F, n)
+    ss = P.estimate_sample_scales(x_init, upper_quantile=0.8)
+    kw = dict(kernel_regression_degree=deg, ctx=ctx)
+    whole = P.RNASeqTranscriptLinearRegression(vars_, x_init, design, ss, True, 0.8, False, **kw)
+    theta = whole.get_flat_params()
+    theta = (theta + rng.normal(0, 0.2, size=theta.size)).astype(np.float32)
+    whole.set_flat_params(theta)
+    eps = rng.normal(size=whole.num_noise).astype(np.float32)
+    loss, g = whole.loss_and_gradients(noise=eps)
+    shared_n = whole.num_params - 2 * S * n
+    e_shared = whole.num_noise - S * n
+    mean = x_init.astype(np.float64).mean(axis=0)
+    tw = whole.unflatten(theta)
+    stats, shards = 0.0, []
+    for rows in (slice(0, 2), slice(2, 4)):
+        v = {k: (a[rows] if a.shape[0] == S else a) for k, a in vars_.items()}
+        sh = P.RNASeqTranscriptLinearRegression(v, x_init[rows], design[rows], ss[rows], True, 0.8, False,
+                                                x_init_mean=mean, **kw)
+        np.testing.assert_allclose(sh.kernel_regression_weights(), whole.kernel_regression_weights(), rtol=1e-6)
+        th = np.concatenate([theta[:shared_n], tw["qx_loc"][rows].reshape(-1), tw["qx_softplus_scale"][rows].reshape(-1)])
+        sh.set_flat_params(th)
+        ez = np.concatenate([eps[:e_shared], eps[e_shared:].reshape(S, n)[rows].reshape(-1)])
+        st = sh._data_pass(ez)
+        stats = stats + st.astype(np.float64)
+        shards.append((sh, rows))
+    gs = np.abs(g).max()
+    for sh, rows in shards:
+        l, gg = sh._prior_pass(stats.astype(np.float32))
+        assert abs(l - loss) <= 2e-5 * abs(loss)
+        np.testing.assert_allclose(gg[:shared_n], g[:shared_n], rtol=2e-4, atol=2e-5 * gs)
+        k = 2 * n  # rows held by the shard
+        whole_qx = whole.unflatten(g)
+        np.testing.assert_allclose(gg[shared_n:shared_n + k].reshape(2, n), whole_qx["qx_loc"][rows], rtol=1e-5,
+                                   atol=1e-6 * gs)
+        np.testing.assert_allclose(gg[shared_n + k:].reshape(2, n), whole_qx["qx_softplus_scale"][rows], rtol=1e-5,
+                                   atol=1e-6 * gs)
+
+
+def test_regression_with_one_rank_communicator(P, ctx):
+    """RCCL communicator of one rank: the all-reduce is skipped / identity and the fit is unchanged."""
+    rng = np.random.default_rng(36)
+    S, F, n = 3, 2, 90
+    vars_, design, x_init = _problem(rng, S, F, n)
+    ss = np.zeros(S, np.float32)
+    comm = P.Comm(ctx, 1, 0)
+    a = P.RNASeqTranscriptLinearRegression(vars_, x_init, design, ss, True, 1.0, False, ctx=ctx, comm=comm)
+    b = P.RNASeqTranscriptLinearRegression(vars_, x_init, design, ss, True, 1.0, False, ctx=ctx)
+    oa, ob = a.fit(25, seed=9, return_trace=True), b.fit(25, seed=9, return_trace=True)
+    np.testing.assert_allclose(oa[-1], ob[-1], rtol=1e-5)
+    np.testing.assert_allclose(oa[1], ob[1], rtol=1e-3, atol=1e-5)

@@ -4,6 +4,9 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
+import pytest
+
 from conftest import ROOT
 from polee_amd.cohort import shard_samples, sample_seed
 
@@ -122,3 +125,22 @@ def test_two_rank_row_sharded_likelihood_sums_to_the_whole(tmp_path):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["rows"] == d["m"] and d["nnz"] == d["nnz_full"]
     assert d["lp_err"] < 1e-12 and d["g_err"] < 1e-12
+
+
+def test_shard_regression_inputs_partitions_the_samples():
+    from polee_amd.cohort import shard_regression_inputs
+    rng = np.random.default_rng(5)
+    S, n, F = 5, 7, 2
+    x_init = rng.normal(size=(S, n)).astype(np.float32)
+    vars_ = dict(efflen=rng.normal(size=(S, n)), la_mu=rng.normal(size=(S, n - 1)), left_index=np.zeros((1, 13), np.int32))
+    design, ss = rng.normal(size=(S, F)), rng.normal(size=(S, 1))
+    parts = [shard_regression_inputs(vars_, x_init, design, ss, 3, r) for r in range(3)]
+    np.testing.assert_array_equal(np.concatenate([p["x_init"] for p in parts]), x_init)
+    np.testing.assert_array_equal(np.concatenate([p["F_arr"] for p in parts]), design)
+    np.testing.assert_array_equal(np.concatenate([p["vars"]["la_mu"] for p in parts]), vars_["la_mu"])
+    np.testing.assert_array_equal(np.concatenate([p["sample_scales"] for p in parts]), ss)
+    for p in parts:
+        assert p["vars"]["left_index"].shape == (1, 13)  # a shared tree is not cut
+        np.testing.assert_allclose(p["x_init_mean"], x_init.mean(axis=0), rtol=1e-6)
+    with pytest.raises(ValueError):
+        shard_regression_inputs(vars_, x_init, design, ss, 8, 7)
