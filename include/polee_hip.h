@@ -385,6 +385,9 @@ int64_t polee_regression_num_params(const polee_regression *reg);
 int64_t polee_regression_num_noise(const polee_regression *reg);
 polee_status polee_regression_get_params(polee_regression *reg, float *params);
 polee_status polee_regression_set_params(polee_regression *reg, const float *params);
+/* RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): replace the likelihood term by
+ * point estimates with a scale, loc[s][j] ~ Normal(log softmax(x[s])[j], scale[s][j]); loc, scale f32 [S][n]. */
+polee_status polee_regression_set_normal_likelihood(polee_regression *reg, const float *loc, const float *scale);
 /* Samples sharded over ranks: every rank creates the model over ITS samples (S = local count, the
  * same F, n, hinges, x_init_mean and seed everywhere), so the shared parameters are replicas and qx_* are local.
  * Per step one sum all-reduce of (F+2) n + 1 f32 observation-model statistics is the only exchange. */

@@ -153,6 +153,53 @@ __global__ void reg_sample_x_kernel(RegView v, const float *p, const float *eps,
     x[i] = p[v.o_qx_loc() + i] + softplusf(p[v.o_qx_s() + i]) * eps[v.e_x() + i];
 }
 
+// Likelihood of RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): the point estimates
+// v [S][n] ~ Normal(log softmax(x), sigma).  One block per sample: lp[s] and glik = d lp / d x.
+__global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float *__restrict__ x,
+                                                               const float *__restrict__ v,
+                                                               const float *__restrict__ sigma, float *lp, float *glik)
+{
+    __shared__ float red[16];
+    __shared__ float bc[2];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float *xr = x + (int64_t)s * n, *vr = v + (int64_t)s * n, *sr = sigma + (int64_t)s * n;
+    float *gr = glik + (int64_t)s * n;
+    auto block_sum = [&](float val) {
+        val = wave_sum(val);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = val;
+        __syncthreads();
+        float t = 0.0f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        return t;
+    };
+    float m = -INFINITY;
+    for (int j = tid; j < n; j += 1024) m = fmaxf(m, xr[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    float se = 0.0f;
+    for (int j = tid; j < n; j += 1024) se += expf(xr[j] - m);
+    const float lse = m + logf(block_sum(se));
+    float sr_sum = 0.0f, l = 0.0f;
+    for (int j = tid; j < n; j += 1024) {
+        const float is = 1.0f / sr[j], d = (vr[j] - (xr[j] - lse)) * is;
+        sr_sum += d * is;
+        l += -0.5f * d * d - logf(sr[j]) - HALF_LOG2PI;
+    }
+    const float R = block_sum(sr_sum);
+    const float L = block_sum(l);
+    if (tid == 0) lp[s] = L;
+    for (int j = tid; j < n; j += 1024) {
+        const float is = 1.0f / sr[j];
+        gr[j] = (vr[j] - (xr[j] - lse)) * is * is - expf(xr[j] - lse) * R;
+    }
+    (void)bc;
+}
+
 // ---- data pass: what the S (local) samples say about each column ------------------------------------------
 // stats [F+2][n] + 1:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
 // row F+1  sum_s d(-log p_x)/d x_scale;  last value  loss terms of the samples (observation model, log q of x,
@@ -397,6 +444,7 @@ struct polee_regression {
     float lr = 2e-3f;
     int64_t step = 0;  // ADAM steps taken
     DevBuf<float> d_p, d_g, d_m, d_v, d_eps, d_design, d_W, d_ss, d_x, d_glik, d_lp, d_lse, d_small, d_loss, d_stats;
+    DevBuf<float> d_lik_loc, d_lik_scale;  // point estimates + their scale: the Normal likelihood variant
     DevBuf<double> d_acc;
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
     int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + 1; }
@@ -416,12 +464,17 @@ polee_status reg_data_pass(polee_regression *r)
         hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
                            r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
-        if (r->ap) POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
+        if (r->d_lik_loc.p) {
+            hipLaunchKernelGGL(reg_normal_lik_kernel, dim3(v.S), dim3(1024), 0, st, v.n, r->d_x.p, r->d_lik_loc.p,
+                               r->d_lik_scale.p, r->d_lp.p, r->d_glik.p);
+            POLEE_KERNEL_CHECK(ctx);
+        } else if (r->ap)
+            POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
     }
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - 1, 0, sizeof(float), st));
     hipLaunchKernelGGL(reg_data_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
                        r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p,
-                       (!v.point && r->ap) ? r->d_lp.p : nullptr, r->d_g.p, r->d_stats.p);
+                       (!v.point && (r->ap || r->d_lik_loc.p)) ? r->d_lp.p : nullptr, r->d_g.p, r->d_stats.p);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -595,6 +648,19 @@ polee_status polee_regression_weights(polee_regression *r, float *weights)
     if (!r || !weights) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(r->ctx));
     return r->d_W.download(r->ctx, weights, (size_t)r->v.deg * r->v.n);
+}
+
+polee_status polee_regression_set_normal_likelihood(polee_regression *r, const float *loc, const float *scale)
+{
+    if (!r || !loc || !scale) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (r->v.point) return fail(ctx, POLEE_ERR_BAD_ARG, "a model with point estimates has no likelihood term");
+    const size_t sn = (size_t)r->v.S * r->v.n;
+    for (size_t i = 0; i < sn; ++i)
+        if (!(scale[i] > 0.0f)) return fail(ctx, POLEE_ERR_BAD_ARG, "scale[%zu] = %g is not positive", i, (double)scale[i]);
+    POLEE_TRY(r->d_lik_loc.upload(ctx, loc, sn));
+    return r->d_lik_scale.upload(ctx, scale, sn);
 }
 
 polee_status polee_regression_set_comm(polee_regression *r, polee_comm *comm)

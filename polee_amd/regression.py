@@ -49,7 +49,7 @@ class RNASeqLinearRegression:
 
     def __init__(self, F, x_init, likelihood_model, x_bias_loc0, x_bias_scale0, x_scale_hinges, sample_scales,
                  use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
-                 kernel_regression_bandwidth, ctx=None, comm=None, x_init_mean=None):
+                 kernel_regression_bandwidth, ctx=None, comm=None, x_init_mean=None, normal_likelihood=None):
         """comm / x_init_mean: samples sharded over ranks (polee_regression_set_comm) -- F, x_init, sample_scales are
         this rank's rows, x_init_mean the column means of x_init over all samples."""
         Fm = arr(np.atleast_2d(F), np.float32)
@@ -65,7 +65,7 @@ class RNASeqLinearRegression:
             raise ValueError("x_scale_hinges must hold kernel_regression_degree values")
         self.use_point_estimates = bool(use_point_estimates)
         self.likelihood_model = likelihood_model
-        if not self.use_point_estimates and likelihood_model is None:
+        if not self.use_point_estimates and likelihood_model is None and normal_likelihood is None:
             raise ValueError("a likelihood model is needed unless use_point_estimates")
         self.ctx = ctx or (likelihood_model.ctx if likelihood_model is not None else default_context())
         self._h = C.c_void_p()
@@ -85,6 +85,11 @@ class RNASeqLinearRegression:
         lib.polee_regression_num_noise.argtypes = [C.c_void_p]
         self.num_params = int(lib.polee_regression_num_params(self._h))
         self.num_noise = int(lib.polee_regression_num_noise(self._h))
+        if normal_likelihood is not None:
+            loc, scale = (arr(np.atleast_2d(a), np.float32) for a in normal_likelihood)
+            if loc.shape != x0.shape or scale.shape != x0.shape:
+                raise ValueError("the Normal likelihood's loc and scale must be [S, n]")
+            check(lib.polee_regression_set_normal_likelihood(self._h, ptr(loc, f32p), ptr(scale, f32p)), self.ctx._h)
         self.comm = comm
         if comm is not None:
             check(lib.polee_regression_set_comm(self._h, comm._h), self.ctx._h)
@@ -193,6 +198,18 @@ class RNASeqTranscriptLinearRegression(RNASeqLinearRegression):
         super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, x_scale_hinges, sample_scales,
                          use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
                          kernel_regression_bandwidth, ctx=ctx, comm=comm, x_init_mean=x_init_mean)
+
+
+class RNASeqNormalTranscriptLinearRegression(RNASeqLinearRegression):
+    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): point estimates and their standard
+    deviation in place of the approximate likelihood.  `vars` is unused, as in the reference."""
+
+    def __init__(self, vars, x_likelihood_loc, x_likelihood_scale, F_arr, sample_scales, use_distortion, scale_penalty,
+                 kernel_regression_degree=15, kernel_regression_bandwidth=1.0, ctx=None, comm=None, x_init_mean=None):
+        loc = np.asarray(x_likelihood_loc, np.float32)
+        super().__init__(F_arr, loc, None, math.log(1.0 / loc.shape[1]), 12.0, None, sample_scales, use_distortion,
+                         scale_penalty, False, kernel_regression_degree, kernel_regression_bandwidth, ctx=ctx, comm=comm,
+                         x_init_mean=x_init_mean, normal_likelihood=(loc, x_likelihood_scale))
 
 
 # ---- output semantics (src/regression.jl:604-685)

@@ -262,3 +262,51 @@ def test_regression_with_one_rank_communicator(P, ctx):
     oa, ob = a.fit(25, seed=9, return_trace=True), b.fit(25, seed=9, return_trace=True)
     np.testing.assert_allclose(oa[-1], ob[-1], rtol=1e-5)
     np.testing.assert_allclose(oa[1], ob[1], rtol=1e-3, atol=1e-5)
+
+
+def test_normal_likelihood_variant_matches_restatement(P, ctx):
+    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): loss and gradient against the
+    float64 restatement with its Normal(log softmax(x), scale) likelihood, by central differences of the whole loss."""
+    rng = np.random.default_rng(37)
+    S, F, n, deg, pen = 3, 2, 130, 5, 0.9
+    _, design, x_loc = _problem(rng, S, F, n)
+    x_scale = np.exp(rng.normal(-1.0, 0.5, size=(S, n))).astype(np.float32)
+    ss = P.estimate_sample_scales(x_loc, upper_quantile=0.8)
+    reg = P.RNASeqNormalTranscriptLinearRegression(None, x_loc, x_scale, design, ss, True, pen,
+                                                   kernel_regression_degree=deg, ctx=ctx)
+    W = _oracle_setup(reg, design, x_loc, ss, deg, 1.0)
+    p0 = reg.get_flat_params()
+    theta = (p0 + rng.normal(0, 0.3, size=p0.size)).astype(np.float32)
+    reg.set_flat_params(theta)
+    eps = rng.normal(size=reg.num_noise).astype(np.float32)
+    loss, g = reg.loss_and_gradients(noise=eps)
+    e = RR.unflatten(eps.astype(np.float64), RR.NOISE, S, F, n, deg)
+    v64, s64 = x_loc.astype(np.float64), x_scale.astype(np.float64)
+
+    def lik(x):
+        m = x.max(axis=1, keepdims=True)
+        ls = x - (m + np.log(np.exp(x - m).sum(axis=1, keepdims=True)))
+        return (-0.5 * np.square((v64 - ls) / s64) - np.log(s64) - 0.5 * RR.LOG2PI).sum(axis=1)
+
+    def Lf(vec):
+        return RR.regression_loss(RR.unflatten(vec, RR.PARAMS, S, F, n, deg), e, design=design.astype(np.float64), W=W,
+                                  sample_scales=ss, x_bias_loc0=np.log(1.0 / n), x_bias_scale0=12.0, use_distortion=True,
+                                  scale_penalty=pen, use_point_estimates=False, lik=lik)[0]
+
+    t64 = theta.astype(np.float64)
+    lo = Lf(t64)
+    assert abs(loss - lo) <= 1e-4 * abs(lo) + 1e-2
+    table = RR.unflatten(np.arange(t64.size), RR.PARAMS, S, F, n, deg)
+    gscale = np.abs(g).max()
+    for name in ("qx_loc", "qx_softplus_scale", "qw_loc", "qx_bias_loc"):
+        for i in rng.choice(table[name].reshape(-1).astype(int), size=10, replace=False):
+            h = 1e-4 * max(1.0, abs(t64[i]))
+            tp, tm = t64.copy(), t64.copy()
+            tp[i] += h
+            tm[i] -= h
+            fd = (Lf(tp) - Lf(tm)) / (2 * h)
+            assert abs(g[i] - fd) / (abs(fd) + 2e-3 * gscale) < 1e-2, (name, i, g[i], fd)
+    out = reg.fit(50, seed=3, return_trace=True)
+    assert np.all(np.isfinite(out[-1]))
+    with pytest.raises(P.PoleeError):
+        P.RNASeqNormalTranscriptLinearRegression(None, x_loc, -x_scale, design, ss, True, pen, ctx=ctx)
