@@ -390,7 +390,7 @@ polee_status polee_regression_set_params(polee_regression *reg, const float *par
 polee_status polee_regression_set_normal_likelihood(polee_regression *reg, const float *loc, const float *scale);
 /* Samples sharded over ranks: every rank creates the model over ITS samples (S = local count, the
  * same F, n, hinges, x_init_mean and seed everywhere), so the shared parameters are replicas and qx_* are local.
- * Per step one sum all-reduce of (F+2) n + 1 f32 observation-model statistics is the only exchange. */
+ * Per step one sum all-reduce of (F+2) n + 32 f32 observation-model statistics is the only exchange. */
 polee_status polee_regression_set_comm(polee_regression *reg, polee_comm *comm_or_null);
 /* kernel_regression_weights (src/polee.py:36-47) as the model uses them: f32 [degree][n] */
 polee_status polee_regression_weights(polee_regression *reg, float *weights);

@@ -54,7 +54,8 @@ void polee_debug_psell_free(polee_psell_debug *p);
 polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on);
 
 /* The two halves of polee_regression_eval with the exchange left to the caller (tests emulate sample sharding on one
- * GPU): data pass -> stats f32 [(F+2) n + 1] of this handle's samples; prior pass <- stats summed over the shards. */
+ * GPU): data pass -> stats f32 [num_stats] ((F+2) n sums + a few loss slots) of this handle's samples; prior pass <- stats summed over the shards. */
+int64_t polee_debug_regression_num_stats(const polee_regression *reg);
 polee_status polee_debug_regression_data_pass(polee_regression *reg, const float *noise, float *stats);
 polee_status polee_debug_regression_prior_pass(polee_regression *reg, const float *stats, float *loss,
                                                float *grad_or_null);

@@ -64,8 +64,9 @@ struct ApproxLeafLoad {
     }
 };
 
-// acc[s][3] += lp + ladj contributions of the internal nodes
-__global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *acc, double *y_out,
+// npart[s][block] = lp + ladj contributions of the block's internal nodes (summed by approx_finish_lp_kernel: one
+// same-address atomic per block serialised ~800 deep per sample and dominated this kernel)
+__global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *npart, double *y_out,
                                     double *y_grad_out, double *inv_u_out)
 {
     __shared__ double smd[4];
@@ -107,17 +108,22 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
         }
     }
     contrib = block_sum_f64(contrib, smd);
-    if (threadIdx.x == 0) atomicAdd(&acc[s * 8 + 3], contrib);
+    if (threadIdx.x == 0) npart[(int64_t)s * gridDim.x + blockIdx.x] = contrib;
 }
 
 // lp[s] = node terms + sum x - (n-1) log A + sum log efflen - log(R), R = Bn / A   (:384-400)
-__global__ void approx_finish_lp_kernel(ApproxView a, const double *acc, const double *sum_log_l, float *lp)
+__global__ __launch_bounds__(256) void approx_finish_lp_kernel(ApproxView a, const double *acc, const double *npart,
+                                                               int nblk, const double *sum_log_l, float *lp)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.S) return;
+    __shared__ double smd[4];
+    const int s = blockIdx.x;
+    double nodes = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) nodes += npart[(int64_t)s * nblk + b];
+    nodes = block_sum_f64(nodes, smd);
+    if (threadIdx.x != 0) return;
     const double sx = acc[s * 8 + 0], A = acc[s * 8 + 1], Bn = acc[s * 8 + 2];
     const double ladj = sx - (double)(a.n - 1) * log(A) + sum_log_l[s] - log(Bn / A);
-    lp[s] = (float)(acc[s * 8 + 3] + ladj);
+    lp[s] = (float)(nodes + ladj);
 }
 
 // InvHSBGrad (hsb_ops.cpp:342-391) with ladj_grad = 1 as an Euler-tour scan; 1/u_j comes
@@ -269,7 +275,7 @@ struct polee_approx {
     int32_t S = 0, n = 0;
     polee_ptt *t = nullptr;  // S trees (or 1 shared)
     DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
-    DevBuf<double> d_sum_log_l, d_acc, d_y, d_ygrad, d_invu, d_dots;
+    DevBuf<double> d_sum_log_l, d_acc, d_npart, d_y, d_ygrad, d_invu, d_dots;
     DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
     ApproxView view() const { return ApproxView{S, n, d_efflens.p, d_mu.p, d_sigma.p, d_alpha.p}; }
 };
@@ -314,6 +320,7 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
     A(ap->d_alpha.upload(ctx, la_alpha, sk));
     A(ap->d_sum_log_l.upload(ctx, sll));
     A(ap->d_acc.alloc(ctx, (size_t)S * 8));
+    A(ap->d_npart.alloc(ctx, (size_t)S * (size_t)ceil_div(n - 1, 256)));
     A(ap->d_dots.alloc(ctx, (size_t)S * 2));
     A(ap->d_y.alloc(ctx, sk));
     A(ap->d_ygrad.alloc(ctx, sk));
@@ -361,10 +368,10 @@ polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, flo
     hipError_t e = run_scan_partial<dd>(st, S, n, t->d_chunk.p, nullptr, load, emit);
     if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
-                       ap->view(), t->d_C.p, ap->d_acc.p, grad ? ap->d_y.p : nullptr, grad ? ap->d_ygrad.p : nullptr,
+                       ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_y.p : nullptr, grad ? ap->d_ygrad.p : nullptr,
                        grad ? ap->d_invu.p : nullptr);
-    hipLaunchKernelGGL(approx_finish_lp_kernel, dim3((unsigned)ceil_div(S, 64)), dim3(64), 0, st, ap->view(),
-                       ap->d_acc.p, ap->d_sum_log_l.p, d_lp);
+    hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
+                       (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp);
     POLEE_KERNEL_CHECK(ctx);
     if (grad) {
         ApproxGradLoad gl{t->view(), ap->d_y.p, ap->d_ygrad.p, ap->d_invu.p};

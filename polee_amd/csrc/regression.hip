@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "comm_internal.hpp"
 #include "rng.hpp"
+#include "wave.hpp"
 
 #include <cmath>
 
@@ -30,6 +31,8 @@ namespace polee {
 constexpr int REG_MAXF = 16;    // factors (design-matrix columns)
 constexpr int REG_MAXDEG = 32;  // kernel-regression hinges
 constexpr int REG_BLOCK = 128;
+constexpr int REG_SLOTS = 32;  // copies of every grid-wide accumulator (block b adds into copy b % 32): same-address
+                               // float atomics from ~1.5 k blocks serialise, 32-way spreading removes that
 constexpr float HALF_LOG2PI = 0.91893853320467274178f;
 
 // Layout of the flat parameter / gradient vector and of the noise vector (include/polee_hip.h documents the order).
@@ -109,10 +112,25 @@ __device__ inline float wave_sum(float v)
     return v;
 }
 
-__global__ void reg_noise_kernel(int64_t count, uint64_t seed, uint32_t step, float *eps)
+// Device-side clock of the fit, so that a whole step is one replayable hipGraph: tick[0] = Adam step t, tick[1] =
+// slot of the loss trace; seed_dev[0] = seed of the fit, lr_t[0] = Adam's step size at t.
+__global__ void reg_tick_kernel(uint32_t *tick, float *lr_t, float lr)
+{
+    const double t = (double)(++tick[0]);
+    lr_t[0] = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+}
+
+// seed / step: immediates, or (tick != nullptr) read from the device clock
+__global__ void reg_noise_kernel(int64_t count, uint64_t seed, uint32_t step, const uint64_t *seed_dev,
+                                 const uint32_t *tick, uint64_t salt, float *eps)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q * 4 >= count) return;
+    if (tick) {
+        seed = seed_dev[0];
+        step = tick[0];
+    }
+    seed ^= salt;
     float z[4];
     philox_randn4(seed ^ 0x7265677265737369ull, step, (uint32_t)(q >> 32), (uint32_t)q, z);
 #pragma unroll
@@ -144,6 +162,30 @@ __global__ __launch_bounds__(1024) void reg_lse_kernel(RegView v, const float *p
         for (int i = 0; i < 16; ++i) t += red[i];
         lse[blockIdx.x] = m + logf(t);
     }
+}
+
+// The same once a nearby shift is known (the previous step's value: Adam moves qx_loc by ~lr per step), so that the
+// row can be spread over many blocks: acc[s] += sum exp(qx_loc - lse_prev[s]); then lse = lse_prev + log acc.
+__global__ __launch_bounds__(256) void reg_lse_accum_kernel(RegView v, const float *p, const float *lse, float *acc)
+{
+    __shared__ float red[4];
+    const int s = blockIdx.y;
+    const float *row = p + v.o_qx_loc() + (int64_t)s * v.n;
+    const float c = lse[s];
+    float t = 0.0f;
+    const int64_t j0 = (int64_t)blockIdx.x * 4096, j1 = j0 + 4096 < v.n ? j0 + 4096 : v.n;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) t += expf(row[j] - c);
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&acc[s], red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void reg_lse_finish_kernel(int S, float *lse, float *acc)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    lse[s] += logf(acc[s]);
+    acc[s] = 0.0f;
 }
 
 __global__ void reg_sample_x_kernel(RegView v, const float *p, const float *eps, float *x)
@@ -201,10 +243,12 @@ __global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float
 }
 
 // ---- data pass: what the S (local) samples say about each column ------------------------------------------
-// stats [F+2][n] + 1:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
-// row F+1  sum_s d(-log p_x)/d x_scale;  last value  loss terms of the samples (observation model, log q of x,
+// stats [F+2][n] + REG_SLOTS:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
+// row F+1  sum_s d(-log p_x)/d x_scale;  last REG_SLOTS values (summed by the reader)  loss terms of the samples (observation model, log q of x,
 // scale-drift penalty, -likelihood).  These are sums over samples: with the samples sharded over ranks ONE all-reduce
 // of this buffer is the only exchange of a step.  Also writes d loss / d qx_loc, qx_softplus_scale.
+// (FT, DT: compile-time F and degree, 0 = run-time; fixed trip counts let the compiler issue a column's loads together)
+template <int FT, int DT>
 __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const float *__restrict__ p,
                                                              const float *__restrict__ eps,
                                                              const float *__restrict__ design,
@@ -213,19 +257,23 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
                                                              const float *__restrict__ lse, const float *__restrict__ lp,
                                                              float *__restrict__ g, float *__restrict__ stats)
 {
-    __shared__ float s_weff[REG_MAXF][REG_BLOCK], s_gacc[REG_MAXF][REG_BLOCK];
+    __shared__ float s_weff[FT ? FT : REG_MAXF][REG_BLOCK], s_gacc[FT ? FT : REG_MAXF][REG_BLOCK];
     const int tid = threadIdx.x;
     const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
     const bool live = jj < v.n;
     const int64_t j = live ? jj : v.n - 1;  // dead lanes recompute the last column and contribute nothing
-    const int F = v.F, deg = v.deg, n = v.n;
+    constexpr int UF = FT ? FT : 1, UD = DT ? DT : 1;  // unroll counts
+    const int F = FT ? FT : v.F, deg = DT ? DT : v.deg, n = v.n;
     const int64_t Fn = v.Fn();
+#pragma unroll UF
     for (int f = 0; f < F; ++f) {
         const int64_t idx = (int64_t)f * n + j;
         const float w = p[v.o_cols() + 8 * Fn + idx] + softplusf(p[v.o_cols() + 9 * Fn + idx]) * eps[v.e_cols() + 4 * Fn + idx];
         float wd = 0.0f;
-        if (v.use_distortion)
+        if (v.use_distortion) {
+#pragma unroll UD
             for (int d = 0; d < deg; ++d) wd += p[v.o_dist() + f * deg + d] * W[(int64_t)d * n + j];
+        }
         s_weff[f][tid] = w + wd;
         s_gacc[f][tid] = 0.0f;
     }
@@ -236,6 +284,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
     float loss = 0.0f, sum_a = 0.0f, sum_xs = 0.0f;
     for (int s = 0; s < v.S; ++s) {
         float xl = b;
+#pragma unroll UF
         for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
         const int64_t sj = (int64_t)s * n + j;
         const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
@@ -244,6 +293,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
         loss += 0.5f * d * a + lxs + HALF_LOG2PI;
         sum_xs += inv - d * a * inv;
         sum_a += a;
+#pragma unroll UF
         for (int f = 0; f < F; ++f) s_gacc[f][tid] -= design[s * F + f] * a;
         float gl = 0.0f, gs = 0.0f;
         if (!v.point) {
@@ -256,6 +306,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
         if (live) g[v.o_qx_loc() + sj] = gl, g[v.o_qx_s() + sj] = gs;
     }
     if (live) {
+#pragma unroll UF
         for (int f = 0; f < F; ++f) stats[(int64_t)f * n + j] = s_gacc[f][tid];
         stats[(int64_t)F * n + j] = sum_a;
         stats[(int64_t)(F + 1) * n + j] = sum_xs;
@@ -266,12 +317,13 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
             const float t = lse[s] / v.penalty;
             loss += 0.5f * t * t + logf(v.penalty) + HALF_LOG2PI - (lp ? lp[s] : 0.0f);
         }
-    if ((tid & 63) == 0) atomicAdd(&stats[(int64_t)(F + 2) * n], loss);
+    if ((tid & 63) == 0) atomicAdd(&stats[(int64_t)(F + 2) * n + (blockIdx.x % REG_SLOTS)], loss);
 }
 
 // ---- prior pass: everything that does not depend on which samples a rank holds, combined with the (summed) stats
-// acc: [0] loss (double); small: [0] sum (1 - r^2), then d/d(distortion_c) [F][deg], then the sums feeding
+// acc: loss (double [REG_SLOTS]); small [REG_SLOTS][num_red]: [0] sum (1 - r^2), then d/d(distortion_c) [F][deg], then the sums feeding
 // d/d(concentration_c) [deg] and d/d(scale_c) [deg]
+template <int FT, int DT>
 __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const float *__restrict__ p,
                                                              const float *__restrict__ eps,
                                                              const float *__restrict__ W,
@@ -284,7 +336,8 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
     const bool live = jj < v.n;
     const int64_t j = live ? jj : v.n - 1;
-    const int F = v.F, deg = v.deg, n = v.n;
+    constexpr int UF = FT ? FT : 1, UD = DT ? DT : 1;  // unroll counts
+    const int F = FT ? FT : v.F, deg = DT ? DT : v.deg, n = v.n;
     const int64_t Fn = v.Fn();
     const int nred = v.num_red();
     const float lv = live ? 1.0f : 0.0f;
@@ -302,6 +355,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     const float gscale = gn.z * sqrtf(gv.z);
 
     // ---- horseshoe+ scales and w of every factor
+#pragma unroll UF
     for (int f = 0; f < F; ++f) {
         const int64_t idx = (int64_t)f * n + j;
         const float *pc = p + v.o_cols() + idx;
@@ -334,11 +388,13 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
             gc[8 * Fn] = Gw;
             gc[9 * Fn] = (Gw * e_w - 1.0f / s_w) * sigmoidf(sraw_w);
         }
-        if (v.use_distortion)
+        if (v.use_distortion) {
+#pragma unroll UD
             for (int d = 0; d < deg; ++d) {
-                const float t = wave_sum(lv * W[(int64_t)d * n + j] * gacc);
-                if (lane == 0) atomicAdd(&s_red[1 + f * deg + d], t);
+                const float t = wave_sum_to_lane63(lv * W[(int64_t)d * n + j] * gacc);
+                if (lane == 63) atomicAdd(&s_red[1 + f * deg + d], t);
             }
+        }
     }
 
     // ---- x_bias, x_scale
@@ -348,6 +404,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     const SpDraw xs = sp_draw(p[v.o_xs_loc() + j], p[v.o_xs_s() + j], eps[v.e_xs() + j]);
     loss += xs.logq;
     float alpha = 0.0f, beta = 0.0f;
+#pragma unroll UD
     for (int d = 0; d < deg; ++d) {
         const float wdj = W[(int64_t)d * n + j];
         alpha += s_cc[d] * wdj;
@@ -370,61 +427,74 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     }
 
     // ---- block sums of what the columns share
+#pragma unroll UD
     for (int d = 0; d < deg; ++d) {
         const float wdj = lv * W[(int64_t)d * n + j];
-        const float ta = wave_sum(wdj * g_alpha), tb = wave_sum(wdj * g_beta);
-        if (lane == 0) {
+        const float ta = wave_sum_to_lane63(wdj * g_alpha), tb = wave_sum_to_lane63(wdj * g_beta);
+        if (lane == 63) {
             atomicAdd(&s_red[1 + F * deg + d], ta);
             atomicAdd(&s_red[1 + F * deg + deg + d], tb);
         }
     }
-    S1 = wave_sum(lv * S1);
-    loss = wave_sum(lv * loss);
-    if (lane == 0) {
+    S1 = wave_sum_to_lane63(lv * S1);
+    loss = wave_sum_to_lane63(lv * loss);
+    const int slot = blockIdx.x % REG_SLOTS;
+    if (lane == 63) {
         atomicAdd(&s_red[0], S1);
-        atomicAdd(loss_acc, (double)loss);
+        atomicAdd(&loss_acc[slot], (double)loss);
     }
     __syncthreads();
-    for (int i = tid; i < nred; i += REG_BLOCK) atomicAdd(&small[i], s_red[i]);
+    for (int i = tid; i < nred; i += REG_BLOCK) atomicAdd(&small[(int64_t)slot * nred + i], s_red[i]);
 }
 
-// the global horseshoe scale, the distortion / mean-variance coefficients, the per-sample terms
-__global__ void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small,
-                                  const float *stats, const double *loss_acc, float *g, float *loss_out)
+// the global horseshoe scale and the distortion / mean-variance coefficients (one wave; lane i takes coefficient i)
+__global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small,
+                                                        const float *stats, const double *loss_acc, float *g,
+                                                        float *loss_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double loss = loss_acc[0];
-    const float S1 = small[0];
-    {
+    const int lane = threadIdx.x, nred = v.num_red();
+    auto slots = [&](int i) {  // sum of accumulator i over its copies
+        float t = 0.0f;
+        for (int k = 0; k < REG_SLOTS; ++k) t += small[(int64_t)k * nred + i];
+        return t;
+    };
+    double loss = 0.0;
+    if (lane < REG_SLOTS)  // the columns' terms + the samples' terms (summed over ranks)
+        loss = loss_acc[lane] + (double)stats[(int64_t)(v.F + 2) * v.n + lane];
+    if (lane == 0) {
+        const float S1 = slots(0);
         const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
         loss += gv.logq + gn.logq + nlp_ig_half(gv.z) + nlp_halfnormal(gn.z);
         sp_grad(gv, 1.5f / gv.z - 0.5f / (gv.z * gv.z) + 0.5f * S1 / gv.z, g[0], g[1]);
         sp_grad(gn, gn.z + S1 / gn.z, g[2], g[3]);
     }
-    for (int i = 0; i < v.F * v.deg; ++i) {
+    for (int i = lane; i < v.F * v.deg; i += 64) {
         const float c = p[v.o_dist() + i];
         if (v.use_distortion) {
-            g[v.o_dist() + i] = 2.0f * c / (0.01f + c * c) + small[1 + i];
+            g[v.o_dist() + i] = 2.0f * c / (0.01f + c * c) + slots(1 + i);
             loss += logf(3.14159265358979323846f * 0.1f) + log1pf(100.0f * c * c);
         } else
             g[v.o_dist() + i] = 0.0f;
     }
-    for (int h = 0; h < 2; ++h)
-        for (int d = 0; d < v.deg; ++d) {
-            const int64_t o = (h == 0 ? v.o_conc() : v.o_scc()) + d;
-            const float c = softplusf(p[o]);
-            g[o] = (2.0f * c / (1.0f + c * c) + small[1 + v.F * v.deg + h * v.deg + d]) * sigmoidf(p[o]);
-            loss += 0.45158270528945486473f + log1pf(c * c);  // -log(2/pi)
-        }
-    loss += stats[(int64_t)(v.F + 2) * v.n];  // the samples' terms (summed over ranks)
-    loss_out[0] = (float)loss;
+    for (int i = lane; i < 2 * v.deg; i += 64) {  // concentration_c then scale_c (adjacent in the vector)
+        const int64_t o = v.o_conc() + i;
+        const float c = softplusf(p[o]);
+        g[o] = (2.0f * c / (1.0f + c * c) + slots(1 + v.F * v.deg + i)) * sigmoidf(p[o]);
+        loss += 0.45158270528945486473f + log1pf(c * c);  // -log(2/pi)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, 64);
+    if (lane == 0) loss_out[0] = (float)loss;
 }
 
 // tf.optimizers.Adam: theta -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps)
-__global__ void reg_adam_kernel(int64_t count, float *p, const float *g, float *m, float *vv, float lr_t)
+__global__ void reg_adam_kernel(int64_t count, float *p, const float *g, float *m, float *vv, const float *lr_dev,
+                                const float *loss, float *trace, uint32_t *tick)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    if (i == 0 && trace) trace[tick[1]++] = loss[0];
+    const float lr_t = lr_dev[0];
     const float gi = g[i];
     const float mi = 0.9f * m[i] + 0.1f * gi;
     const float vi = 0.999f * vv[i] + 0.001f * gi * gi;
@@ -444,10 +514,20 @@ struct polee_regression {
     float lr = 2e-3f;
     int64_t step = 0;  // ADAM steps taken
     DevBuf<float> d_p, d_g, d_m, d_v, d_eps, d_design, d_W, d_ss, d_x, d_glik, d_lp, d_lse, d_small, d_loss, d_stats;
+    DevBuf<float> d_lse_acc, d_lr, d_trace;
+    DevBuf<uint32_t> d_tick;
+    DevBuf<uint64_t> d_seed;
+    hipGraphExec_t graph = nullptr;  // one step (device RNG), replayed by polee_regression_fit
+    void drop_graph()
+    {
+        if (graph) (void)hipGraphExecDestroy(graph);
+        graph = nullptr;
+    }
+    bool lse_valid = false;  // d_lse holds the log-sum-exp of a nearby qx_loc (shift of the multi-block kernel)
     DevBuf<float> d_lik_loc, d_lik_scale;  // point estimates + their scale: the Normal likelihood variant
     DevBuf<double> d_acc;
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
-    int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + 1; }
+    int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + REG_SLOTS; }
 };
 
 namespace {
@@ -460,7 +540,14 @@ polee_status reg_data_pass(polee_regression *r)
     hipStream_t st = ctx->stream;
     const int64_t sn = (int64_t)v.S * v.n;
     if (!v.point) {
-        hipLaunchKernelGGL(reg_lse_kernel, dim3(v.S), dim3(1024), 0, st, v, r->d_p.p, r->d_lse.p);
+        if (r->lse_valid) {
+            hipLaunchKernelGGL(reg_lse_accum_kernel, dim3((unsigned)ceil_div(v.n, 4096), v.S), dim3(256), 0, st, v,
+                               r->d_p.p, r->d_lse.p, r->d_lse_acc.p);
+            hipLaunchKernelGGL(reg_lse_finish_kernel, dim3((unsigned)ceil_div(v.S, 64)), dim3(64), 0, st, v.S,
+                               r->d_lse.p, r->d_lse_acc.p);
+        } else
+            hipLaunchKernelGGL(reg_lse_kernel, dim3(v.S), dim3(1024), 0, st, v, r->d_p.p, r->d_lse.p);
+        r->lse_valid = true;
         hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
                            r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
@@ -471,10 +558,19 @@ polee_status reg_data_pass(polee_regression *r)
         } else if (r->ap)
             POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
     }
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - 1, 0, sizeof(float), st));
-    hipLaunchKernelGGL(reg_data_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
-                       r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p,
-                       (!v.point && (r->ap || r->d_lik_loc.p)) ? r->d_lp.p : nullptr, r->d_g.p, r->d_stats.p);
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - REG_SLOTS, 0, sizeof(float) * REG_SLOTS, st));
+    const float *lp = (!v.point && (r->ap || r->d_lik_loc.p)) ? r->d_lp.p : nullptr;
+    const dim3 grid((unsigned)ceil_div(v.n, REG_BLOCK));
+#define POLEE_REG_DATA(FT, DT)                                                                                          \
+    hipLaunchKernelGGL((reg_data_kernel<FT, DT>), grid, dim3(REG_BLOCK), 0, st, v, r->d_p.p, r->d_eps.p, r->d_design.p, \
+                       r->d_W.p, r->d_ss.p, r->d_x.p, r->d_glik.p, r->d_lse.p, lp, r->d_g.p, r->d_stats.p)
+    // the reference's default degree (15) with up to four factors runs with fixed trip counts
+    if (v.deg == 15 && v.F == 1) POLEE_REG_DATA(1, 15);
+    else if (v.deg == 15 && v.F == 2) POLEE_REG_DATA(2, 15);
+    else if (v.deg == 15 && v.F == 3) POLEE_REG_DATA(3, 15);
+    else if (v.deg == 15 && v.F == 4) POLEE_REG_DATA(4, 15);
+    else POLEE_REG_DATA(0, 0);
+#undef POLEE_REG_DATA
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -485,10 +581,18 @@ polee_status reg_prior_pass(polee_regression *r)
     polee_ctx *ctx = r->ctx;
     const RegView &v = r->v;
     hipStream_t st = ctx->stream;
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double), st));
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * v.num_red(), st));
-    hipLaunchKernelGGL(reg_cols_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st, v, r->d_p.p,
-                       r->d_eps.p, r->d_W.p, r->d_stats.p, r->d_g.p, r->d_acc.p, r->d_small.p);
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double) * REG_SLOTS, st));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * REG_SLOTS * v.num_red(), st));
+    const dim3 grid((unsigned)ceil_div(v.n, REG_BLOCK));
+#define POLEE_REG_COLS(FT, DT)                                                                                     \
+    hipLaunchKernelGGL((reg_cols_kernel<FT, DT>), grid, dim3(REG_BLOCK), 0, st, v, r->d_p.p, r->d_eps.p, r->d_W.p, \
+                       r->d_stats.p, r->d_g.p, r->d_acc.p, r->d_small.p)
+    if (v.deg == 15 && v.F == 1) POLEE_REG_COLS(1, 15);
+    else if (v.deg == 15 && v.F == 2) POLEE_REG_COLS(2, 15);
+    else if (v.deg == 15 && v.F == 3) POLEE_REG_COLS(3, 15);
+    else if (v.deg == 15 && v.F == 4) POLEE_REG_COLS(4, 15);
+    else POLEE_REG_COLS(0, 0);
+#undef POLEE_REG_COLS
     hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p,
                        r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p);
     POLEE_KERNEL_CHECK(ctx);
@@ -506,16 +610,33 @@ polee_status reg_eval_device(polee_regression *r)
 
 // The latents every rank shares are drawn from (seed, step) alone, so that replicas stay identical; the noise of
 // x belongs to a rank's own samples and is salted with the rank.
-polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t seed, uint32_t step)
+polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t seed, uint32_t step, bool device_clock)
 {
     polee_ctx *ctx = r->ctx;
     const int64_t ne = r->v.num_noise(), shared = r->v.e_x(), own = ne - shared;
     if (noise) return r->d_eps.upload(ctx, noise, (size_t)ne);
     const uint64_t salt = 0xD1B54A32D192ED03ull * (uint64_t)(r->comm ? r->comm->rank + 1 : 1);
+    const uint64_t *sd = device_clock ? r->d_seed.p : nullptr;
+    const uint32_t *tk = device_clock ? r->d_tick.p : nullptr;
     hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(shared, 4), 256)), dim3(256), 0, ctx->stream,
-                       shared, seed, step, r->d_eps.p);
+                       shared, seed, step, sd, tk, (uint64_t)0, r->d_eps.p);
     hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(own, 4), 256)), dim3(256), 0, ctx->stream, own,
-                       seed ^ salt, step, r->d_eps.p + shared);
+                       seed, step, sd, tk, salt, r->d_eps.p + shared);
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+// one step of fit() on the device clock: tick, draw, loss + gradient, Adam (+ the loss into the trace)
+polee_status reg_enqueue_step(polee_regression *r, const float *noise, bool want_trace)
+{
+    polee_ctx *ctx = r->ctx;
+    const int64_t P = r->v.num_params();
+    hipLaunchKernelGGL(reg_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, r->d_tick.p, r->d_lr.p, r->lr);
+    POLEE_TRY(reg_fill_noise(r, noise, 0, 0, true));
+    POLEE_TRY(reg_eval_device(r));
+    hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, P, r->d_p.p,
+                       r->d_g.p, r->d_m.p, r->d_v.p, r->d_lr.p, r->d_loss.p, want_trace ? r->d_trace.p : nullptr,
+                       r->d_tick.p);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -599,12 +720,13 @@ polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S
         ok(r->d_ss.upload(ctx, sample_scales, (size_t)S)) && ok(r->d_g.alloc(ctx, (size_t)P)) &&
         ok(r->d_m.alloc(ctx, (size_t)P)) && ok(r->d_v.alloc(ctx, (size_t)P)) &&
         ok(r->d_eps.alloc(ctx, (size_t)v.num_noise())) && ok(r->d_x.alloc(ctx, (size_t)sn)) &&
-        ok(r->d_glik.alloc(ctx, (size_t)sn)) && ok(r->d_lp.alloc(ctx, (size_t)S)) && ok(r->d_lse.alloc(ctx, (size_t)S)) &&
-        ok(r->d_small.alloc(ctx, (size_t)v.num_red())) && ok(r->d_stats.alloc(ctx, (size_t)r->num_stats())) && ok(r->d_loss.alloc(ctx, 1)) && ok(r->d_acc.alloc(ctx, 1))) {
+        ok(r->d_glik.alloc(ctx, (size_t)sn)) && ok(r->d_lp.alloc(ctx, (size_t)S)) && ok(r->d_lse.alloc(ctx, (size_t)S)) && ok(r->d_lse_acc.alloc(ctx, (size_t)S)) && ok(r->d_lr.alloc(ctx, 1)) && ok(r->d_tick.alloc(ctx, 2)) && ok(r->d_seed.alloc(ctx, 1)) &&
+        ok(r->d_small.alloc(ctx, (size_t)REG_SLOTS * v.num_red())) && ok(r->d_stats.alloc(ctx, (size_t)r->num_stats())) && ok(r->d_loss.alloc(ctx, 1)) && ok(r->d_acc.alloc(ctx, REG_SLOTS))) {
         hipError_t e = hipMemsetAsync(r->d_m.p, 0, sizeof(float) * P, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_v.p, 0, sizeof(float) * P, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_glik.p, 0, sizeof(float) * sn, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_lse.p, 0, sizeof(float) * S, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_lse_acc.p, 0, sizeof(float) * S, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = fail(ctx, POLEE_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
     }
@@ -622,12 +744,14 @@ void polee_regression_destroy(polee_regression *r)
     polee_ctx *ctx = r->ctx;
     if (ctx) (void)hipSetDevice(ctx->device);
     polee_comm_destroy(r->comm);
+    r->drop_graph();
     delete r;
     ctx_release(ctx);
 }
 
 int64_t polee_regression_num_params(const polee_regression *r) { return r ? r->v.num_params() : 0; }
 int64_t polee_regression_num_noise(const polee_regression *r) { return r ? r->v.num_noise() : 0; }
+int64_t polee_debug_regression_num_stats(const polee_regression *r) { return r ? r->num_stats() : 0; }
 
 polee_status polee_regression_get_params(polee_regression *r, float *params)
 {
@@ -640,6 +764,7 @@ polee_status polee_regression_set_params(polee_regression *r, const float *param
 {
     if (!r || !params) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(r->ctx));
+    r->lse_valid = false;
     return r->d_p.upload(r->ctx, params, (size_t)r->v.num_params());
 }
 
@@ -659,6 +784,7 @@ polee_status polee_regression_set_normal_likelihood(polee_regression *r, const f
     const size_t sn = (size_t)r->v.S * r->v.n;
     for (size_t i = 0; i < sn; ++i)
         if (!(scale[i] > 0.0f)) return fail(ctx, POLEE_ERR_BAD_ARG, "scale[%zu] = %g is not positive", i, (double)scale[i]);
+    r->drop_graph();
     POLEE_TRY(r->d_lik_loc.upload(ctx, loc, sn));
     return r->d_lik_scale.upload(ctx, scale, sn);
 }
@@ -671,6 +797,7 @@ polee_status polee_regression_set_comm(polee_regression *r, polee_comm *comm)
     if (comm) ++comm->refs;
     polee_comm_destroy(r->comm);
     r->comm = comm;
+    r->drop_graph();
     return POLEE_OK;
 }
 
@@ -700,7 +827,7 @@ polee_status polee_regression_eval(polee_regression *r, const float *noise, uint
     if (!r || !loss) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     polee_ctx *ctx = r->ctx;
     POLEE_TRY(use_device(ctx));
-    POLEE_TRY(reg_fill_noise(r, noise, seed, (uint32_t)(r->step + 1)));
+    POLEE_TRY(reg_fill_noise(r, noise, seed, (uint32_t)(r->step + 1), false));
     POLEE_TRY(reg_eval_device(r));
     POLEE_TRY(r->d_loss.download(ctx, loss, 1));
     if (grad) POLEE_TRY(r->d_g.download(ctx, grad, (size_t)r->v.num_params()));
@@ -713,23 +840,50 @@ polee_status polee_regression_fit(polee_regression *r, int32_t niter, uint64_t s
     if (!r || niter < 0) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "bad argument");
     polee_ctx *ctx = r->ctx;
     POLEE_TRY(use_device(ctx));
-    const int64_t P = r->v.num_params(), ne = r->v.num_noise();
-    DevBuf<float> d_trace;
-    if (loss_trace && niter) POLEE_TRY(d_trace.alloc(ctx, (size_t)niter));
-    for (int32_t it = 0; it < niter; ++it) {
-        const int64_t t = ++r->step;
-        POLEE_TRY(reg_fill_noise(r, noise ? noise + (size_t)it * ne : nullptr, seed, (uint32_t)t));
-        POLEE_TRY(reg_eval_device(r));
-        if (loss_trace)
-            POLEE_HIP_TRY(ctx, hipMemcpyAsync(d_trace.p + it, r->d_loss.p, sizeof(float), hipMemcpyDeviceToDevice,
-                                              ctx->stream));
-        const double lr_t = (double)r->lr * std::sqrt(1.0 - std::pow(0.999, (double)t)) / (1.0 - std::pow(0.9, (double)t));
-        hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, P, r->d_p.p,
-                           r->d_g.p, r->d_m.p, r->d_v.p, (float)lr_t);
-        POLEE_KERNEL_CHECK(ctx);
+    if (niter == 0) return POLEE_OK;
+    hipStream_t st = ctx->stream;
+    const int64_t ne = r->v.num_noise();
+    if (r->d_trace.n < (size_t)niter) {  // (the trace's address is part of the captured step)
+        r->drop_graph();
+        POLEE_TRY(r->d_trace.alloc(ctx, std::max<size_t>((size_t)niter, 8192)));
     }
-    if (loss_trace && niter) POLEE_TRY(d_trace.download(ctx, loss_trace, (size_t)niter));
-    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t clock[2] = {(uint32_t)r->step, 0u};
+    POLEE_TRY(r->d_tick.upload(ctx, clock, 2));
+    POLEE_TRY(r->d_seed.upload(ctx, &seed, 1));
+    // Steps with the device RNG are replayed from a hipGraph (about 25 launches per step otherwise bound the step on
+    // the host); supplied noise, a multi-rank communicator (RCCL inside a capture) or POLEE_REG_NO_GRAPH=1 enqueue
+    // directly.  The first step always runs directly: it computes the exact log-sum-exp the later ones start from.
+    const bool use_graph = !noise && !(r->comm && r->comm->nranks > 1) && !std::getenv("POLEE_REG_NO_GRAPH");
+    int32_t it = 0;
+    if (!use_graph || !r->lse_valid) {
+        POLEE_TRY(reg_enqueue_step(r, noise, true));
+        it = 1;
+    }
+    if (use_graph && it < niter && !r->graph) {
+        hipGraph_t g = nullptr;
+        POLEE_HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const polee_status cs = reg_enqueue_step(r, nullptr, true);
+        const hipError_t ce = hipStreamEndCapture(st, &g);
+        if (cs != POLEE_OK || ce != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            return cs != POLEE_OK ? cs : fail(ctx, POLEE_ERR_HIP, "graph capture failed: %s", hipGetErrorString(ce));
+        }
+        const hipError_t ie = hipGraphInstantiate(&r->graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) {
+            r->graph = nullptr;
+            return fail(ctx, POLEE_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        }
+    }
+    for (; it < niter; ++it) {
+        if (use_graph)
+            POLEE_HIP_TRY(ctx, hipGraphLaunch(r->graph, st));
+        else
+            POLEE_TRY(reg_enqueue_step(r, noise ? noise + (size_t)it * ne : nullptr, true));
+    }
+    r->step += niter;
+    if (loss_trace) POLEE_TRY(r->d_trace.download(ctx, loss_trace, (size_t)niter));
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(st));
     return POLEE_OK;
 }
 

@@ -158,7 +158,9 @@ class RNASeqLinearRegression:
     # test hooks: the two halves of a step (include/polee_hip_debug.h)
     def _data_pass(self, noise):
         z = arr(noise, np.float32).reshape(-1)
-        stats = np.empty((self.num_factors + 2) * self.num_features + 1, np.float32)
+        f = L.lib().polee_debug_regression_num_stats
+        f.restype, f.argtypes = C.c_int64, [C.c_void_p]
+        stats = np.empty(int(f(self._h)), np.float32)
         check(L.lib().polee_debug_regression_data_pass(self._h, ptr(z, f32p), ptr(stats, f32p)), self.ctx._h)
         return stats
 

@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import torch
 torch.cuda.init()  # (torch's HIP runtime must come up before libpolee_hip's in a shared process)

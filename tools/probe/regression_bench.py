@@ -1,6 +1,6 @@
 """Regression steps/s (SURVEY.md 8(d) secondary metric, configs C3 / C4 per-GPU share): S samples, F=2 factors,
 n=200k transcripts, synthetic approximation parameters.  usage: regression_bench.py [S] [steps]"""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import polee_amd as P
 from oracle import oracle as O  # only make_inverse_ptt_params (index arrays of a tree), not timed
