@@ -388,6 +388,20 @@ polee_status polee_regression_set_params(polee_regression *reg, const float *par
 /* RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): replace the likelihood term by
  * point estimates with a scale, loc[s][j] ~ Normal(log softmax(x[s])[j], scale[s][j]); loc, scale f32 [S][n]. */
 polee_status polee_regression_set_normal_likelihood(polee_regression *reg, const float *loc, const float *scale);
+/* RNASeqGeneLinearRegression (models/polee_regression.py:533-600): the model's n features are GENES and the
+ * likelihood is RNASeqGeneApproxLikelihoodDist (polee_approx_gene_logprob) of (x_gene, x_isoform), with
+ * x_isoform_mean ~ Normal(0, 2) [nt], x_isoform ~ Normal(x_isoform_mean, 1) [S][nt] and Normal surrogates for both.
+ * Create the model with ap = NULL over the genes, then attach: ap over the nt transcripts, gene_of int32 [nt]
+ * (0-based gene of every transcript), x_isoform_init f32 [S][nt].  Adds an isoform block of parameters (own Adam
+ * state): qx_isoform_mean_loc [nt], qx_isoform_mean_softplus_scale [nt], qx_isoform_loc [S][nt],
+ * qx_isoform_softplus_scale [S][nt]; and appends noise (mean [nt], isoform [S][nt]) to the noise vector. */
+polee_status polee_regression_set_gene_likelihood(polee_regression *reg, polee_approx *ap, const int32_t *gene_of,
+                                                  const float *x_isoform_init);
+int64_t polee_regression_num_isoform_params(const polee_regression *reg);
+polee_status polee_regression_get_isoform_params(polee_regression *reg, float *params);
+polee_status polee_regression_set_isoform_params(polee_regression *reg, const float *params);
+/* gradient of the isoform block left by the last polee_regression_eval */
+polee_status polee_regression_get_isoform_grad(polee_regression *reg, float *grad);
 /* Samples sharded over ranks: every rank creates the model over ITS samples (S = local count, the
  * same F, n, hinges, x_init_mean and seed everywhere), so the shared parameters are replicas and qx_* are local.
  * Per step one sum all-reduce of (F+2) n + 32 f32 observation-model statistics is the only exchange. */

@@ -116,6 +116,37 @@ def _halfnormal_lp(x):
     return 0.5 * np.log(2.0 / np.pi) - 0.5 * np.square(x)
 
 
+ISO_PARAMS = [("qx_isoform_mean_loc", "t"), ("qx_isoform_mean_softplus_scale", "t"), ("qx_isoform_loc", "St"),
+              ("qx_isoform_softplus_scale", "St")]
+ISO_NOISE = [("x_isoform_mean", "t"), ("x_isoform", "St")]
+
+
+def unflatten_iso(vec, table, S, nt):
+    out, o = {}, 0
+    for name, code in table:
+        shp = (nt,) if code == "t" else (S, nt)
+        k = int(np.prod(shp))
+        out[name] = np.asarray(vec[o:o + k], np.float64).reshape(shp)
+        o += k
+    assert o == len(vec)
+    return out
+
+
+def isoform_terms(ip, ie, x_gene, gene_lik=None):
+    """Gene-level likelihood model (RNASeqGeneLinearRegression.likelihood_model / surrogate_likelihood_model,
+    models/polee_regression.py:558-596): returns log q - log p of the isoform block (with -gene_lik(x_gene, x_isoform)
+    when given) and the draws."""
+    sm = softplus(ip["qx_isoform_mean_softplus_scale"])
+    mean = ip["qx_isoform_mean_loc"] + sm * ie["x_isoform_mean"]
+    sx = softplus(ip["qx_isoform_softplus_scale"])
+    xi = ip["qx_isoform_loc"] + sx * ie["x_isoform"]
+    logq = np.sum(_normal_lp(mean, ip["qx_isoform_mean_loc"], sm)) + np.sum(_normal_lp(xi, ip["qx_isoform_loc"], sx))
+    logp = np.sum(_normal_lp(mean, 0.0, 2.0)) + np.sum(_normal_lp(xi, mean[None, :], 1.0))
+    if gene_lik is not None:
+        logp += float(np.sum(gene_lik(x_gene, xi)))
+    return float(logq - logp), xi
+
+
 def regression_loss(p, eps, design, W, sample_scales, x_bias_loc0, x_bias_scale0, use_distortion, scale_penalty,
                     use_point_estimates, lik=None):
     """loss = log q - log p at the draw defined by `eps`.  `lik(x) -> lp [S]` is the approximate likelihood

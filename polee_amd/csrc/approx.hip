@@ -277,10 +277,58 @@ struct polee_approx {
     DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
     DevBuf<double> d_sum_log_l, d_acc, d_npart, d_y, d_ygrad, d_invu, d_dots;
     DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
+    DevBuf<int32_t> d_gptr, d_gidx;  // genes as CSR over transcripts (gene-level wrapper), set by approx_set_genes
+    int32_t G = 0;
     ApproxView view() const { return ApproxView{S, n, d_efflens.p, d_mu.p, d_sigma.p, d_alpha.p}; }
 };
 
 namespace polee {
+// genes as CSR (transcripts of gene g: gidx[gptr[g] .. gptr[g+1])), kept on the device
+polee_status approx_set_genes(polee_approx *ap, const int32_t *gene_of, int32_t G)
+{
+    polee_ctx *ctx = ap->ctx;
+    const int n = ap->n;
+    if (!gene_of || G < 1 || G > n) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    std::vector<int32_t> gptr((size_t)G + 1, 0), gidx((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (gene_of[i] < 0 || gene_of[i] >= G)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of[%d] = %d outside 0..%d", i, gene_of[i], G - 1);
+        ++gptr[(size_t)gene_of[i] + 1];
+    }
+    for (int g = 0; g < G; ++g) {
+        if (gptr[(size_t)g + 1] == 0) return fail(ctx, POLEE_ERR_BAD_ARG, "gene %d has no transcript", g);
+        gptr[(size_t)g + 1] += gptr[g];
+    }
+    {
+        std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
+        for (int i = 0; i < n; ++i) gidx[(size_t)fill[gene_of[i]]++] = i;
+    }
+    POLEE_TRY(ap->d_gptr.upload(ctx, gptr));
+    POLEE_TRY(ap->d_gidx.upload(ctx, gidx));
+    ap->G = G;
+    return POLEE_OK;
+}
+
+// RNASeqGeneApproxLikelihoodDist._log_prob on device buffers, enqueued on the context's stream: d_xg [S][G],
+// d_xi [S][n] (OVERWRITTEN with d lp / d x_isoform when d_gg is given), d_lp [S], d_gg [S][G] or null.
+polee_status approx_gene_logprob_device(polee_approx *ap, const float *d_xg, float *d_xi, float *d_lp, float *d_gg)
+{
+    polee_ctx *ctx = ap->ctx;
+    if (ap->G < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "no gene map set");
+    const int S = ap->S, n = ap->n, G = ap->G;
+    const dim3 grid((unsigned)ceil_div(G, 256), (unsigned)S);
+    hipLaunchKernelGGL(gene_compose_kernel, grid, dim3(256), 0, ctx->stream, ap->d_gptr.p, ap->d_gidx.p, G, n, d_xg,
+                       d_xi, ap->d_x.p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(polee_approx_logprob_device(ap, ap->d_x.p, d_lp, d_gg ? ap->d_xgrad.p : nullptr));
+    if (d_gg) {
+        hipLaunchKernelGGL(gene_compose_grad_kernel, grid, dim3(256), 0, ctx->stream, ap->d_gptr.p, ap->d_gidx.p, G, n,
+                           d_xi, ap->d_xgrad.p, d_gg);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    return POLEE_OK;
+}
+
 polee_ctx *approx_ctx(const polee_approx *ap) { return ap->ctx; }
 void approx_dims(const polee_approx *ap, int32_t *S, int32_t *n)
 {
@@ -409,42 +457,18 @@ polee_status polee_approx_gene_logprob(polee_approx *ap, const float *x_gene, co
     polee_ctx *ctx = ap->ctx;
     POLEE_TRY(use_device(ctx));
     const int S = ap->S, n = ap->n;
-    if (!x_gene || !x_isoform || !gene_of || !lp || G < 1 || G > n) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (!x_gene || !x_isoform || !gene_of || !lp) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
     if ((gene_grad == nullptr) != (isoform_grad == nullptr))
         return fail(ctx, POLEE_ERR_BAD_ARG, "ask for both gradients or for none");
-    // genes as CSR (transcripts of gene g: gidx[gptr[g] .. gptr[g+1]))
-    std::vector<int32_t> gptr((size_t)G + 1, 0), gidx((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        if (gene_of[i] < 0 || gene_of[i] >= G) return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of[%d] = %d outside 0..%d", i, gene_of[i], G - 1);
-        ++gptr[(size_t)gene_of[i] + 1];
-    }
-    for (int g = 0; g < G; ++g) {
-        if (gptr[(size_t)g + 1] == 0) return fail(ctx, POLEE_ERR_BAD_ARG, "gene %d has no transcript", g);
-        gptr[(size_t)g + 1] += gptr[g];
-    }
-    {
-        std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
-        for (int i = 0; i < n; ++i) gidx[(size_t)fill[gene_of[i]]++] = i;
-    }
-    DevBuf<int32_t> d_gptr, d_gidx;
+    POLEE_TRY(approx_set_genes(ap, gene_of, G));
     DevBuf<float> d_xg, d_xi, d_gg;
     const size_t sn = (size_t)S * n, sg = (size_t)S * G;
-    POLEE_TRY(d_gptr.upload(ctx, gptr));
-    POLEE_TRY(d_gidx.upload(ctx, gidx));
     POLEE_TRY(d_xg.upload(ctx, x_gene, sg));
     POLEE_TRY(d_xi.upload(ctx, x_isoform, sn));
-    const dim3 grid((unsigned)ceil_div(G, 256), (unsigned)S);
-    hipLaunchKernelGGL(gene_compose_kernel, grid, dim3(256), 0, ctx->stream, d_gptr.p, d_gidx.p, G, n, d_xg.p, d_xi.p,
-                       ap->d_x.p);
-    POLEE_KERNEL_CHECK(ctx);
-    POLEE_TRY(polee_approx_logprob_device(ap, ap->d_x.p, ap->d_lp.p, gene_grad ? ap->d_xgrad.p : nullptr));
+    if (gene_grad) POLEE_TRY(d_gg.alloc(ctx, sg));
+    POLEE_TRY(approx_gene_logprob_device(ap, d_xg.p, d_xi.p, ap->d_lp.p, gene_grad ? d_gg.p : nullptr));
     POLEE_TRY(ap->d_lp.download(ctx, lp, S));
     if (gene_grad) {
-        POLEE_TRY(d_gg.alloc(ctx, sg));
-        // (d_xi is overwritten with the isoform gradient)
-        hipLaunchKernelGGL(gene_compose_grad_kernel, grid, dim3(256), 0, ctx->stream, d_gptr.p, d_gidx.p, G, n, d_xi.p,
-                           ap->d_xgrad.p, d_gg.p);
-        POLEE_KERNEL_CHECK(ctx);
         POLEE_TRY(d_gg.download(ctx, gene_grad, sg));
         POLEE_TRY(d_xi.download(ctx, isoform_grad, sn));
     }

@@ -160,5 +160,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // accessors of the approximation handle (approx.hip) for its consumers
 polee_ctx *approx_ctx(const polee_approx *ap);
 void approx_dims(const polee_approx *ap, int32_t *S, int32_t *n);
+polee_status approx_set_genes(polee_approx *ap, const int32_t *gene_of, int32_t G);
+polee_status approx_gene_logprob_device(polee_approx *ap, const float *d_xg, float *d_xi, float *d_lp, float *d_gg);
 
 }  // namespace polee

@@ -242,6 +242,53 @@ __global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float
     (void)bc;
 }
 
+// ---- gene-level model (RNASeqGeneLinearRegression, models/polee_regression.py:533-600): the features are genes and
+// the likelihood is reached through within-gene isoform log-expression x_isoform [S][nt] with
+//   x_isoform_mean ~ Normal(0, 2) [nt],  x_isoform ~ Normal(x_isoform_mean, 1),  both with Normal surrogates.
+// Isoform block of parameters: mean_loc [nt], mean_softplus_scale [nt], iso_loc [S][nt], iso_softplus_scale [S][nt];
+// noise: mean [nt], iso [S][nt].
+__global__ void reg_iso_sample_kernel(int S, int nt, const float *ip, const float *ieps, float *xi)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, snt = (int64_t)S * nt;
+    if (i >= snt) return;
+    xi[i] = ip[2 * (int64_t)nt + i] + softplusf(ip[2 * (int64_t)nt + snt + i]) * ieps[nt + i];
+}
+// gi = d lp / d x_isoform (from the gene-level likelihood); thread per transcript
+__global__ __launch_bounds__(256) void reg_iso_grad_kernel(int S, int nt, const float *__restrict__ ip,
+                                                           const float *__restrict__ ieps,
+                                                           const float *__restrict__ gi, float *__restrict__ ig,
+                                                           float *loss_slots)
+{
+    const int64_t ii = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, snt = (int64_t)S * nt;
+    const bool live = ii < nt;
+    const int64_t i = live ? ii : nt - 1;
+    const float *loc = ip + 2 * (int64_t)nt, *sr = loc + snt;
+    const float ms_raw = ip[nt + i], ms = softplusf(ms_raw), me = ieps[i];
+    const float m = ip[i] + ms * me;
+    float loss = -0.5f * me * me - logf(ms) - HALF_LOG2PI;               // log q(mean)
+    loss += 0.125f * m * m + 0.69314718055994530942f + HALF_LOG2PI;      // -log Normal(0, 2)(mean)
+    float Gm = 0.25f * m;
+    for (int s = 0; s < S; ++s) {
+        const int64_t o = (int64_t)s * nt + i;
+        const float sraw = sr[o], sx = softplusf(sraw), e = ieps[nt + o];
+        const float d = loc[o] + sx * e - m;
+        loss += 0.5f * d * d + HALF_LOG2PI;                              // -log Normal(mean, 1)(x_isoform)
+        loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;                  // log q(x_isoform)
+        Gm -= d;
+        const float Gx = d - gi[o];
+        if (live) {
+            ig[2 * (int64_t)nt + o] = Gx;
+            ig[2 * (int64_t)nt + snt + o] = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
+        }
+    }
+    if (live) {
+        ig[i] = Gm;
+        ig[nt + i] = (Gm * me - 1.0f / ms) * sigmoidf(ms_raw);
+    }
+    loss = wave_sum_to_lane63(live ? loss : 0.0f);
+    if ((threadIdx.x & 63) == 63) atomicAdd(&loss_slots[blockIdx.x % REG_SLOTS], loss);
+}
+
 // ---- data pass: what the S (local) samples say about each column ------------------------------------------
 // stats [F+2][n] + REG_SLOTS:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
 // row F+1  sum_s d(-log p_x)/d x_scale;  last REG_SLOTS values (summed by the reader)  loss terms of the samples (observation model, log q of x,
@@ -526,6 +573,12 @@ struct polee_regression {
     bool lse_valid = false;  // d_lse holds the log-sum-exp of a nearby qx_loc (shift of the multi-block kernel)
     DevBuf<float> d_lik_loc, d_lik_scale;  // point estimates + their scale: the Normal likelihood variant
     DevBuf<double> d_acc;
+    // gene-level model: the likelihood handle over nt transcripts and the isoform block (see reg_iso_grad_kernel)
+    polee_approx *gene_ap = nullptr;
+    int32_t nt = 0;
+    DevBuf<float> d_ip, d_ig, d_im, d_iv, d_ieps, d_xi;
+    int64_t num_iso_params() const { return gene_ap ? 2 * (int64_t)nt + 2 * (int64_t)v.S * nt : 0; }
+    int64_t num_iso_noise() const { return gene_ap ? (int64_t)nt + (int64_t)v.S * nt : 0; }
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
     int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + REG_SLOTS; }
 };
@@ -551,7 +604,12 @@ polee_status reg_data_pass(polee_regression *r)
         hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
                            r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
-        if (r->d_lik_loc.p) {
+        if (r->gene_ap) {
+            hipLaunchKernelGGL(reg_iso_sample_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256), 0,
+                               st, v.S, r->nt, r->d_ip.p, r->d_ieps.p, r->d_xi.p);
+            POLEE_KERNEL_CHECK(ctx);
+            POLEE_TRY(approx_gene_logprob_device(r->gene_ap, r->d_x.p, r->d_xi.p, r->d_lp.p, r->d_glik.p));
+        } else if (r->d_lik_loc.p) {
             hipLaunchKernelGGL(reg_normal_lik_kernel, dim3(v.S), dim3(1024), 0, st, v.n, r->d_x.p, r->d_lik_loc.p,
                                r->d_lik_scale.p, r->d_lp.p, r->d_glik.p);
             POLEE_KERNEL_CHECK(ctx);
@@ -559,7 +617,7 @@ polee_status reg_data_pass(polee_regression *r)
             POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
     }
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - REG_SLOTS, 0, sizeof(float) * REG_SLOTS, st));
-    const float *lp = (!v.point && (r->ap || r->d_lik_loc.p)) ? r->d_lp.p : nullptr;
+    const float *lp = (!v.point && (r->ap || r->d_lik_loc.p || r->gene_ap)) ? r->d_lp.p : nullptr;
     const dim3 grid((unsigned)ceil_div(v.n, REG_BLOCK));
 #define POLEE_REG_DATA(FT, DT)                                                                                          \
     hipLaunchKernelGGL((reg_data_kernel<FT, DT>), grid, dim3(REG_BLOCK), 0, st, v, r->d_p.p, r->d_eps.p, r->d_design.p, \
@@ -571,6 +629,9 @@ polee_status reg_data_pass(polee_regression *r)
     else if (v.deg == 15 && v.F == 4) POLEE_REG_DATA(4, 15);
     else POLEE_REG_DATA(0, 0);
 #undef POLEE_REG_DATA
+    if (r->gene_ap)  // (d_xi now holds d lp / d x_isoform)
+        hipLaunchKernelGGL(reg_iso_grad_kernel, dim3((unsigned)ceil_div(r->nt, 256)), dim3(256), 0, st, v.S, r->nt,
+                           r->d_ip.p, r->d_ieps.p, r->d_xi.p, r->d_ig.p, r->d_stats.p + r->num_stats() - REG_SLOTS);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -614,7 +675,11 @@ polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t se
 {
     polee_ctx *ctx = r->ctx;
     const int64_t ne = r->v.num_noise(), shared = r->v.e_x(), own = ne - shared;
-    if (noise) return r->d_eps.upload(ctx, noise, (size_t)ne);
+    if (noise) {
+        POLEE_TRY(r->d_eps.upload(ctx, noise, (size_t)ne));
+        if (r->gene_ap) POLEE_TRY(r->d_ieps.upload(ctx, noise + ne, (size_t)r->num_iso_noise()));
+        return POLEE_OK;
+    }
     const uint64_t salt = 0xD1B54A32D192ED03ull * (uint64_t)(r->comm ? r->comm->rank + 1 : 1);
     const uint64_t *sd = device_clock ? r->d_seed.p : nullptr;
     const uint32_t *tk = device_clock ? r->d_tick.p : nullptr;
@@ -622,6 +687,9 @@ polee_status reg_fill_noise(polee_regression *r, const float *noise, uint64_t se
                        shared, seed, step, sd, tk, (uint64_t)0, r->d_eps.p);
     hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(own, 4), 256)), dim3(256), 0, ctx->stream, own,
                        seed, step, sd, tk, salt, r->d_eps.p + shared);
+    if (r->gene_ap)
+        hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(r->num_iso_noise(), 4), 256)), dim3(256), 0,
+                           ctx->stream, r->num_iso_noise(), seed, step, sd, tk, salt ^ 0x69736f666f726d73ull, r->d_ieps.p);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -637,6 +705,10 @@ polee_status reg_enqueue_step(polee_regression *r, const float *noise, bool want
     hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, P, r->d_p.p,
                        r->d_g.p, r->d_m.p, r->d_v.p, r->d_lr.p, r->d_loss.p, want_trace ? r->d_trace.p : nullptr,
                        r->d_tick.p);
+    if (r->gene_ap)
+        hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(r->num_iso_params(), 256)), dim3(256), 0, ctx->stream,
+                           r->num_iso_params(), r->d_ip.p, r->d_ig.p, r->d_im.p, r->d_iv.p, r->d_lr.p, r->d_loss.p,
+                           (float *)nullptr, r->d_tick.p);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -750,7 +822,8 @@ void polee_regression_destroy(polee_regression *r)
 }
 
 int64_t polee_regression_num_params(const polee_regression *r) { return r ? r->v.num_params() : 0; }
-int64_t polee_regression_num_noise(const polee_regression *r) { return r ? r->v.num_noise() : 0; }
+int64_t polee_regression_num_noise(const polee_regression *r) { return r ? r->v.num_noise() + r->num_iso_noise() : 0; }
+int64_t polee_regression_num_isoform_params(const polee_regression *r) { return r ? r->num_iso_params() : 0; }
 int64_t polee_debug_regression_num_stats(const polee_regression *r) { return r ? r->num_stats() : 0; }
 
 polee_status polee_regression_get_params(polee_regression *r, float *params)
@@ -789,9 +862,75 @@ polee_status polee_regression_set_normal_likelihood(polee_regression *r, const f
     return r->d_lik_scale.upload(ctx, scale, sn);
 }
 
+polee_status polee_regression_set_gene_likelihood(polee_regression *r, polee_approx *ap, const int32_t *gene_of,
+                                                  const float *x_isoform_init)
+{
+    if (!r || !ap || !gene_of || !x_isoform_init) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    int32_t aS, nt;
+    approx_dims(ap, &aS, &nt);
+    if (approx_ctx(ap) != ctx || aS != r->v.S)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "the approximation handle holds %d samples, the model %d", aS, r->v.S);
+    if (r->v.point) return fail(ctx, POLEE_ERR_UNSUPPORTED, "the gene-level model is built without point estimates only");
+    if (r->comm && r->comm->nranks > 1)
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "the gene-level model is not sharded over ranks");
+    POLEE_TRY(approx_set_genes(ap, gene_of, r->v.n));  // the model's features are the genes
+    const int S = r->v.S;
+    const size_t snt = (size_t)S * nt;
+    std::vector<float> ip(2 * (size_t)nt + 2 * snt);
+    for (int i = 0; i < nt; ++i) {  // models/polee_regression.py:573-577
+        double m = 0.0;
+        for (int s = 0; s < S; ++s) m += x_isoform_init[(size_t)s * nt + i];
+        ip[(size_t)i] = (float)(m / S);
+        ip[(size_t)nt + i] = -2.0f;
+    }
+    std::copy_n(x_isoform_init, snt, ip.begin() + 2 * (size_t)nt);
+    std::fill_n(ip.begin() + 2 * (size_t)nt + snt, snt, -2.0f);
+    r->drop_graph();
+    r->gene_ap = ap;
+    r->nt = nt;
+    r->ap = nullptr;
+    const size_t np = ip.size();
+    POLEE_TRY(r->d_ip.upload(ctx, ip));
+    POLEE_TRY(r->d_ig.alloc(ctx, np));
+    POLEE_TRY(r->d_im.alloc(ctx, np));
+    POLEE_TRY(r->d_iv.alloc(ctx, np));
+    POLEE_TRY(r->d_ieps.alloc(ctx, (size_t)nt + snt));
+    POLEE_TRY(r->d_xi.alloc(ctx, snt));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_im.p, 0, sizeof(float) * np, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iv.p, 0, sizeof(float) * np, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return POLEE_OK;
+}
+
+polee_status polee_regression_get_isoform_params(polee_regression *r, float *params)
+{
+    if (!r || !params || !r->gene_ap) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "no isoform block");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_ip.download(r->ctx, params, (size_t)r->num_iso_params());
+}
+
+polee_status polee_regression_set_isoform_params(polee_regression *r, const float *params)
+{
+    if (!r || !params || !r->gene_ap) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "no isoform block");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_ip.upload(r->ctx, params, (size_t)r->num_iso_params());
+}
+
+// gradient of the isoform block left by the last polee_regression_eval
+polee_status polee_regression_get_isoform_grad(polee_regression *r, float *grad)
+{
+    if (!r || !grad || !r->gene_ap) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "no isoform block");
+    POLEE_TRY(use_device(r->ctx));
+    return r->d_ig.download(r->ctx, grad, (size_t)r->num_iso_params());
+}
+
 polee_status polee_regression_set_comm(polee_regression *r, polee_comm *comm)
 {
     if (!r) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    if (comm && comm->nranks > 1 && r->gene_ap)
+        return fail(r->ctx, POLEE_ERR_UNSUPPORTED, "the gene-level model is not sharded over ranks");
     if (comm && comm->ctx != r->ctx)
         return fail(r->ctx, POLEE_ERR_BAD_ARG, "communicator and model belong to different contexts");
     if (comm) ++comm->refs;
@@ -806,7 +945,7 @@ polee_status polee_debug_regression_data_pass(polee_regression *r, const float *
 {
     if (!r || !noise || !stats) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(r->ctx));
-    POLEE_TRY(r->d_eps.upload(r->ctx, noise, (size_t)r->v.num_noise()));
+    POLEE_TRY(reg_fill_noise(r, noise, 0, 0, false));
     POLEE_TRY(reg_data_pass(r));
     return r->d_stats.download(r->ctx, stats, (size_t)r->num_stats());
 }
@@ -842,7 +981,7 @@ polee_status polee_regression_fit(polee_regression *r, int32_t niter, uint64_t s
     POLEE_TRY(use_device(ctx));
     if (niter == 0) return POLEE_OK;
     hipStream_t st = ctx->stream;
-    const int64_t ne = r->v.num_noise();
+    const int64_t ne = r->v.num_noise() + r->num_iso_noise();
     if (r->d_trace.n < (size_t)niter) {  // (the trace's address is part of the captured step)
         r->drop_graph();
         POLEE_TRY(r->d_trace.alloc(ctx, std::max<size_t>((size_t)niter, 8192)));

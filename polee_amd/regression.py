@@ -49,7 +49,8 @@ class RNASeqLinearRegression:
 
     def __init__(self, F, x_init, likelihood_model, x_bias_loc0, x_bias_scale0, x_scale_hinges, sample_scales,
                  use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
-                 kernel_regression_bandwidth, ctx=None, comm=None, x_init_mean=None, normal_likelihood=None):
+                 kernel_regression_bandwidth, ctx=None, comm=None, x_init_mean=None, normal_likelihood=None,
+                 gene_likelihood=None):
         """comm / x_init_mean: samples sharded over ranks (polee_regression_set_comm) -- F, x_init, sample_scales are
         this rank's rows, x_init_mean the column means of x_init over all samples."""
         Fm = arr(np.atleast_2d(F), np.float32)
@@ -65,8 +66,11 @@ class RNASeqLinearRegression:
             raise ValueError("x_scale_hinges must hold kernel_regression_degree values")
         self.use_point_estimates = bool(use_point_estimates)
         self.likelihood_model = likelihood_model
-        if not self.use_point_estimates and likelihood_model is None and normal_likelihood is None:
+        if (not self.use_point_estimates and likelihood_model is None and normal_likelihood is None
+                and gene_likelihood is None):
             raise ValueError("a likelihood model is needed unless use_point_estimates")
+        if gene_likelihood is not None and ctx is None:
+            ctx = gene_likelihood[0].ctx
         self.ctx = ctx or (likelihood_model.ctx if likelihood_model is not None else default_context())
         self._h = C.c_void_p()
         ap = likelihood_model._h if (likelihood_model is not None and not self.use_point_estimates) else None
@@ -90,6 +94,19 @@ class RNASeqLinearRegression:
             if loc.shape != x0.shape or scale.shape != x0.shape:
                 raise ValueError("the Normal likelihood's loc and scale must be [S, n]")
             check(lib.polee_regression_set_normal_likelihood(self._h, ptr(loc, f32p), ptr(scale, f32p)), self.ctx._h)
+        self.num_isoform_params = 0
+        if gene_likelihood is not None:  # (RNASeqApproxLikelihood over the transcripts, 0-based gene of each, init)
+            lik, gene_of, xi0 = gene_likelihood
+            gene_of, xi0 = arr(gene_of, np.int32).reshape(-1), arr(np.atleast_2d(xi0), np.float32)
+            if gene_of.size != lik.n or xi0.shape != (self.num_samples, lik.n):
+                raise ValueError("gene_of must be [nt] and x_isoform_init [S, nt]")
+            self.likelihood_model = lik
+            check(lib.polee_regression_set_gene_likelihood(self._h, lik._h, ptr(gene_of, L.i32p), ptr(xi0, f32p)),
+                  self.ctx._h)
+            lib.polee_regression_num_isoform_params.restype = C.c_int64
+            lib.polee_regression_num_isoform_params.argtypes = [C.c_void_p]
+            self.num_isoform_params = int(lib.polee_regression_num_isoform_params(self._h))
+            self.num_noise = int(lib.polee_regression_num_noise(self._h))
         self.comm = comm
         if comm is not None:
             check(lib.polee_regression_set_comm(self._h, comm._h), self.ctx._h)
@@ -155,6 +172,24 @@ class RNASeqLinearRegression:
               self.ctx._h)
         return float(loss[0]), g
 
+    # ---- isoform block of the gene-level model
+    def get_isoform_params(self):
+        p = np.empty(self.num_isoform_params, np.float32)
+        check(L.lib().polee_regression_get_isoform_params(self._h, ptr(p, f32p)), self.ctx._h)
+        return p
+
+    def set_isoform_params(self, p):
+        p = arr(p, np.float32).reshape(-1)
+        if p.size != self.num_isoform_params:
+            raise ValueError("expected %d isoform parameters" % self.num_isoform_params)
+        check(L.lib().polee_regression_set_isoform_params(self._h, ptr(p, f32p)), self.ctx._h)
+
+    def isoform_gradients(self):
+        """Gradient of the isoform block left by the last loss_and_gradients()."""
+        g = np.empty(self.num_isoform_params, np.float32)
+        check(L.lib().polee_regression_get_isoform_grad(self._h, ptr(g, f32p)), self.ctx._h)
+        return g
+
     # test hooks: the two halves of a step (include/polee_hip_debug.h)
     def _data_pass(self, noise):
         z = arr(noise, np.float32).reshape(-1)
@@ -200,6 +235,36 @@ class RNASeqTranscriptLinearRegression(RNASeqLinearRegression):
         super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, x_scale_hinges, sample_scales,
                          use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
                          kernel_regression_bandwidth, ctx=ctx, comm=comm, x_init_mean=x_init_mean)
+
+
+class RNASeqGeneLinearRegression(RNASeqLinearRegression):
+    """RNASeqGeneLinearRegression (models/polee_regression.py:533-600): regression over gene expression with the
+    transcript-level approximate likelihood reached through within-gene isoform log-expression.
+    feature_idxs / transcript_idxs: the 1-based (gene, transcript) pairs of the reference; feature_sizes is unused
+    (the reference only forwards it).  Built without point estimates only."""
+
+    def __init__(self, vars, feature_idxs, transcript_idxs, x_gene_init, x_isoform_init, feature_sizes, F_arr,
+                 sample_scales, use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree=15,
+                 kernel_regression_bandwidth=1.0, ctx=None):
+        if use_point_estimates:
+            raise NotImplementedError("the gene-level model is built without point estimates only")
+        x_gene_init = np.asarray(x_gene_init, np.float32)
+        lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=ctx)
+        fi = np.asarray(feature_idxs, np.int64).reshape(-1) - 1
+        ti = np.asarray(transcript_idxs, np.int64).reshape(-1) - 1
+        gene_of = np.full(lik.n, -1, np.int64)
+        gene_of[ti] = fi
+        if (gene_of < 0).any():
+            raise ValueError("every transcript must belong to a gene")
+        super().__init__(F_arr, x_gene_init, None, math.log(1.0 / x_gene_init.shape[1]), 12.0, None, sample_scales,
+                         use_distortion, scale_penalty, False, kernel_regression_degree, kernel_regression_bandwidth,
+                         ctx=ctx or lik.ctx, gene_likelihood=(lik, gene_of, x_isoform_init))
+
+    def isoform_variables(self):
+        v, S, nt = self.get_isoform_params(), self.num_samples, self.likelihood_model.n
+        return dict(qx_isoform_mean_loc=v[:nt], qx_isoform_mean_softplus_scale=v[nt:2 * nt],
+                    qx_isoform_loc=v[2 * nt:2 * nt + S * nt].reshape(S, nt),
+                    qx_isoform_softplus_scale=v[2 * nt + S * nt:].reshape(S, nt))
 
 
 class RNASeqNormalTranscriptLinearRegression(RNASeqLinearRegression):

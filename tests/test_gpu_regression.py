@@ -310,3 +310,83 @@ def test_normal_likelihood_variant_matches_restatement(P, ctx):
     assert np.all(np.isfinite(out[-1]))
     with pytest.raises(P.PoleeError):
         P.RNASeqNormalTranscriptLinearRegression(None, x_loc, -x_scale, design, ss, True, pen, ctx=ctx)
+
+
+def test_gene_level_model_matches_restatement(P, ctx):
+    """RNASeqGeneLinearRegression (models/polee_regression.py:533-600): loss against the float64 restatement with the
+    C oracle's gene-level likelihood; gradients of the isoform block and of qx_loc against central differences of the
+    restatement + the oracle's analytic likelihood gradients."""
+    rng = np.random.default_rng(38)
+    S, F, nt, G, deg, pen = 3, 2, 160, 45, 5, 0.8
+    vars_, design, _ = _problem(rng, S, F, nt)
+    gene_of = np.concatenate([np.arange(G), rng.integers(0, G, nt - G)])
+    rng.shuffle(gene_of)
+    x_gene_init = (rng.normal(-np.log(G), 1.2, size=(1, G)) + rng.normal(0, 0.3, size=(S, G))).astype(np.float32)
+    x_iso_init = rng.normal(0, 1.0, size=(S, nt)).astype(np.float32)
+    ss = P.estimate_sample_scales(x_gene_init, upper_quantile=0.7)
+    reg = P.RNASeqGeneLinearRegression(vars_, gene_of + 1, np.arange(1, nt + 1), x_gene_init, x_iso_init, None, design, ss,
+                                       True, pen, False, kernel_regression_degree=deg, ctx=ctx)
+    n_iso_noise = nt + S * nt
+    assert reg.num_isoform_params == 2 * nt + 2 * S * nt and reg.num_noise == 2 + 5 * F * G + 2 * G + S * G + n_iso_noise
+    iv = reg.isoform_variables()
+    np.testing.assert_allclose(iv["qx_isoform_mean_loc"], x_iso_init.mean(axis=0), rtol=1e-5, atol=1e-6)
+    assert np.all(iv["qx_isoform_softplus_scale"] == -2.0) and np.all(iv["qx_isoform_mean_softplus_scale"] == -2.0)
+    theta = (reg.get_flat_params() + rng.normal(0, 0.2, size=reg.num_params)).astype(np.float32)
+    itheta = (reg.get_isoform_params() + rng.normal(0, 0.2, size=reg.num_isoform_params)).astype(np.float32)
+    reg.set_flat_params(theta)
+    reg.set_isoform_params(itheta)
+    eps = rng.normal(size=reg.num_noise).astype(np.float32)
+    loss, g = reg.loss_and_gradients(noise=eps)
+    gi = reg.isoform_gradients()
+    W = _oracle_setup(reg, design, x_gene_init, ss, deg, 1.0)
+    e = RR.unflatten(eps[:-n_iso_noise].astype(np.float64), RR.NOISE, S, F, G, deg)
+    ie = RR.unflatten_iso(eps[-n_iso_noise:].astype(np.float64), RR.ISO_NOISE, S, nt)
+    a = (vars_["efflen"], vars_["la_mu"], vars_["la_sigma"], vars_["la_alpha"], vars_["left_index"],
+         vars_["right_index"], vars_["leaf_index"])
+    common = dict(design=design.astype(np.float64), W=W, sample_scales=ss, x_bias_loc0=np.log(1.0 / G),
+                  x_bias_scale0=12.0, use_distortion=True, scale_penalty=pen, use_point_estimates=False)
+
+    def base(vec):
+        return RR.regression_loss(RR.unflatten(vec, RR.PARAMS, S, F, G, deg), e, lik=None, **common)
+
+    def iso(ivec, x_gene, with_lik):
+        lik = (lambda xg, xi: O.approx_gene_log_prob(xg.astype(np.float32), xi.astype(np.float32), gene_of, *a)) \
+            if with_lik else None
+        return RR.isoform_terms(RR.unflatten_iso(ivec, RR.ISO_PARAMS, S, nt), ie, x_gene, lik)
+
+    t64, i64 = theta.astype(np.float64), itheta.astype(np.float64)
+    lb, z = base(t64)
+    li, xi = iso(i64, z["x"], True)
+    assert abs(loss - (lb + li)) <= 1e-4 * abs(lb + li) + 1e-2, (loss, lb + li)
+    _, gg, gxi = O.approx_gene_log_prob(z["x"].astype(np.float32), xi.astype(np.float32), gene_of, *a, want_grad=True)
+    # isoform block: central differences of the restatement without the likelihood + analytic chain of the likelihood
+    o_loc, o_s = 2 * nt, 2 * nt + S * nt
+    scale = np.abs(gi).max()
+    for i in np.concatenate([rng.choice(2 * nt, 12, replace=False), o_loc + rng.choice(S * nt, 12, replace=False),
+                             o_s + rng.choice(S * nt, 12, replace=False)]):
+        h = 1e-4 * max(1.0, abs(i64[i]))
+        tp, tm = i64.copy(), i64.copy()
+        tp[i] += h
+        tm[i] -= h
+        fd = (iso(tp, z["x"], False)[0] - iso(tm, z["x"], False)[0]) / (2 * h)
+        if o_loc <= i < o_s:
+            fd -= gxi.reshape(-1)[i - o_loc]
+        elif i >= o_s:
+            k = i - o_s
+            fd -= gxi.reshape(-1)[k] * ie["x_isoform"].reshape(-1)[k] / (1.0 + np.exp(-i64[i]))
+        assert abs(gi[i] - fd) / (abs(fd) + 2e-3 * scale) < 1e-2, (i, gi[i], fd)
+    # gene-level qx_loc sees the likelihood through d lp / d x_gene
+    table = RR.unflatten(np.arange(t64.size), RR.PARAMS, S, F, G, deg)
+    o_qx = int(table["qx_loc"].reshape(-1)[0])
+    gs = np.abs(g).max()
+    for k in rng.choice(S * G, 12, replace=False):
+        i = o_qx + k
+        h = 1e-4 * max(1.0, abs(t64[i]))
+        tp, tm = t64.copy(), t64.copy()
+        tp[i] += h
+        tm[i] -= h
+        fd = (base(tp)[0] - base(tm)[0]) / (2 * h) - gg.reshape(-1)[k]
+        assert abs(g[i] - fd) / (abs(fd) + 2e-3 * gs) < 1e-2, (i, g[i], fd)
+    out = reg.fit(60, seed=4, return_trace=True)
+    assert np.all(np.isfinite(out[-1])) and out[-1][-10:].mean() < out[-1][:10].mean()
+    assert not np.allclose(reg.get_isoform_params(), itheta)
