@@ -385,7 +385,7 @@ int64_t polee_regression_num_params(const polee_regression *reg);
 int64_t polee_regression_num_noise(const polee_regression *reg);
 polee_status polee_regression_get_params(polee_regression *reg, float *params);
 polee_status polee_regression_set_params(polee_regression *reg, const float *params);
-/* RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): replace the likelihood term by
+/* RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): replace the likelihood term by
  * point estimates with a scale, loc[s][j] ~ Normal(log softmax(x[s])[j], scale[s][j]); loc, scale f32 [S][n]. */
 polee_status polee_regression_set_normal_likelihood(polee_regression *reg, const float *loc, const float *scale);
 /* RNASeqGeneLinearRegression (models/polee_regression.py:533-600): the model's n features are GENES and the

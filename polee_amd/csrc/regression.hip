@@ -195,7 +195,7 @@ __global__ void reg_sample_x_kernel(RegView v, const float *p, const float *eps,
     x[i] = p[v.o_qx_loc() + i] + softplusf(p[v.o_qx_s() + i]) * eps[v.e_x() + i];
 }
 
-// Likelihood of RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): the point estimates
+// Likelihood of RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): the point estimates
 // v [S][n] ~ Normal(log softmax(x), sigma).  One block per sample: lp[s] and glik = d lp / d x.
 __global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float *__restrict__ x,
                                                                const float *__restrict__ v,

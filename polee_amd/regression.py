@@ -268,7 +268,7 @@ class RNASeqGeneLinearRegression(RNASeqLinearRegression):
 
 
 class RNASeqNormalTranscriptLinearRegression(RNASeqLinearRegression):
-    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): point estimates and their standard
+    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): point estimates and their standard
     deviation in place of the approximate likelihood.  `vars` is unused, as in the reference."""
 
     def __init__(self, vars, x_likelihood_loc, x_likelihood_scale, F_arr, sample_scales, use_distortion, scale_penalty,

@@ -265,7 +265,7 @@ def test_regression_with_one_rank_communicator(P, ctx):
 
 
 def test_normal_likelihood_variant_matches_restatement(P, ctx):
-    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:463-507): loss and gradient against the
+    """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): loss and gradient against the
     float64 restatement with its Normal(log softmax(x), scale) likelihood, by central differences of the whole loss."""
     rng = np.random.default_rng(37)
     S, F, n, deg, pen = 3, 2, 130, 5, 0.9
