@@ -5,6 +5,7 @@ set -u
 TAG=${1:-run}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5  # (scratch of earlier runs would mix into the summary)
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --cpu-steps 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err

@@ -13,8 +13,9 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 s = json.load(open(os.path.join(src, "summary.json")))
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats:  # (the scratch directory may hold CSVs of earlier runs: the newest one belongs to this summary)
+    shutil.copy(stats[-1], os.path.join(dst, tag + "_kernel_stats.csv"))
 json.dump(s.get("pmc", {}), open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 bench = None
 try:
