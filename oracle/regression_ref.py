@@ -220,6 +220,31 @@ def regression_loss(p, eps, design, W, sample_scales, x_bias_loc0, x_bias_scale0
     return float(logq - logp), z
 
 
+def data_statistics(p, eps, design, W, sample_scales, use_distortion, scale_penalty, lik=None):
+    """What ONE rank's samples contribute to a step when the samples are sharded: the (F+2) x n
+    sums of the observation model x ~ Normal(x_loc - scale_s, x_scale) that the shared parameters' gradients need, and
+    the samples' own loss terms.  `p` / `eps` hold the shared entries and this rank's rows of qx_* / x.
+    rows 0..F-1: sum_s F_sf * (-(x - mu)/x_scale^2); row F: sum_s (x - mu)/x_scale^2; row F+1: sum_s (1/x_scale -
+    (x - mu)^2/x_scale^3).  Returns (stats [F+2, n], loss_of_samples)."""
+    design = np.asarray(design, np.float64)
+    w = p["qw_loc"] + softplus(p["qw_softplus_scale"]) * eps["w"]
+    b = p["qx_bias_loc"] + softplus(p["qx_bias_softplus_scale"]) * eps["x_bias"]
+    xs = softplus(p["qx_scale_loc"] + softplus(p["qx_scale_softplus_scale"]) * eps["x_scale"])
+    sx = softplus(p["qx_softplus_scale"])
+    x = p["qx_loc"] + sx * eps["x"]
+    weff = w + (p["qw_distortion_c_loc"] @ W if use_distortion else 0.0)
+    mu = design @ weff + b - np.asarray(sample_scales, np.float64).reshape(-1, 1)
+    a = (x - mu) / xs ** 2
+    stats = np.concatenate([-(design.T @ a), a.sum(axis=0, keepdims=True),
+                            (1.0 / xs - (x - mu) ** 2 / xs ** 3).sum(axis=0, keepdims=True)])
+    m = p["qx_loc"].max(axis=1)
+    t = m + np.log(np.exp(p["qx_loc"] - m[:, None]).sum(axis=1))
+    loss = -np.sum(_normal_lp(x, mu, xs)) + np.sum(_normal_lp(x, p["qx_loc"], sx)) - np.sum(_normal_lp(t, 0.0, scale_penalty))
+    if lik is not None:
+        loss -= float(np.sum(lik(x)))
+    return stats, float(loss)
+
+
 def adam_step(theta, g, m, v, t, lr=2e-3, b1=0.9, b2=0.999, eps=1e-7):
     """tf.optimizers.Adam (Keras): theta -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps), t = 1, 2, ..."""
     m[:] = b1 * m + (1 - b1) * g

@@ -237,6 +237,14 @@ def test_sample_sharding_statistics_reproduce_the_whole_model(P, ctx):
         st = sh._data_pass(ez)
         stats = stats + st.astype(np.float64)
         shards.append((sh, rows))
+    # the summed statistics are the float64 restatement's (rows: F sums for w, one for x_bias, one for x_scale)
+    W = _oracle_setup(whole, design, x_init, ss, deg, 1.0)
+    lik, _ = _lik(vars_)
+    st_o, loss_o = RR.data_statistics(RR.unflatten(theta.astype(np.float64), RR.PARAMS, S, F, n, deg),
+                                      RR.unflatten(eps.astype(np.float64), RR.NOISE, S, F, n, deg), design, W, ss, True,
+                                      0.8, lik=lik)
+    np.testing.assert_allclose(stats[:(F + 2) * n].reshape(F + 2, n), st_o, rtol=2e-4, atol=2e-4 * np.abs(st_o).max())
+    assert abs(stats[(F + 2) * n:].sum() - loss_o) <= 1e-4 * abs(loss_o)
     gs = np.abs(g).max()
     for sh, rows in shards:
         l, gg = sh._prior_pass(stats.astype(np.float32))

@@ -127,6 +127,70 @@ def test_two_rank_row_sharded_likelihood_sums_to_the_whole(tmp_path):
     assert d["lp_err"] < 1e-12 and d["g_err"] < 1e-12
 
 
+REG_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["POLEE_ROOT"])
+import numpy as np, torch
+import torch.distributed as dist
+from polee_amd.cohort import shard_samples
+from oracle import regression_ref as RR
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(7)          # the same problem on every rank
+S, F, n, deg = 5, 2, 40, 4
+x_init = rng.normal(-3, 1, size=(S, n))
+design = np.zeros((S, F)); design[:, 0] = 1; design[2:, 1] = 1
+ss = rng.normal(0, 0.2, size=S)
+mean = x_init.mean(axis=0)
+W = RR.kernel_regression_weights(1.0, mean, RR.choose_knots(mean.min(), mean.max(), deg))
+vec = RR.flatten(RR.initial_params(x_init, F, deg), RR.PARAMS)
+vec = vec + rng.normal(0, 0.2, size=vec.size)
+p = RR.unflatten(vec, RR.PARAMS, S, F, n, deg)
+eps = RR.unflatten(rng.normal(size=2 + 5 * F * n + 2 * n + S * n), RR.NOISE, S, F, n, deg)
+rows = shard_samples(S, world, rank)
+sl = slice(rows[0], rows[-1] + 1)
+def cut(d, names):
+    return {k: (v[sl] if k in names else v) for k, v in d.items()}
+st, loss = RR.data_statistics(cut(p, ("qx_loc", "qx_softplus_scale")), cut(eps, ("x",)), design[sl], W, ss[sl], True, 0.9)
+t = torch.tensor(np.concatenate([st.reshape(-1), [loss, len(rows)]]))
+dist.all_reduce(t)                      # the step's one exchange
+if rank == 0:
+    tot = t.numpy()
+    st_f, loss_f = RR.data_statistics(p, eps, design, W, ss, True, 0.9)
+    kw = dict(W=W, x_bias_loc0=-2.0, x_bias_scale0=12.0, use_distortion=True, scale_penalty=0.9, use_point_estimates=False)
+    whole, _ = RR.regression_loss(p, eps, design=design, sample_scales=ss, **kw)
+    none = slice(0, 0)
+    p0 = {k: (v[none] if k in ("qx_loc", "qx_softplus_scale") else v) for k, v in p.items()}
+    e0 = {k: (v[none] if k == "x" else v) for k, v in eps.items()}
+    prior, _ = RR.regression_loss(p0, e0, design=design[none], sample_scales=ss[none], **kw)
+    print(json.dumps({"samples": int(tot[-1]), "S": S,
+                      "stats_err": float(np.abs(tot[:-2] - st_f.reshape(-1)).max() / np.abs(st_f).max()),
+                      "loss_err": abs(tot[-2] - loss_f) / abs(loss_f),
+                      "decomposition_err": abs(prior + tot[-2] - whole) / abs(whole)}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sample_sharded_regression_statistics_sum_to_the_whole(tmp_path):
+    """SURVEY.md 8(e)(2): with the regression's samples sharded over ranks, one all-reduce of the (F+2) n observation
+    statistics and the samples' loss terms reproduces the whole model (float64 restatement on CPU here; the device
+    kernels are checked against the same decomposition in tests/test_gpu_regression.py)."""
+    script = tmp_path / "reg_worker.py"
+    script.write_text(REG_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, POLEE_ROOT=ROOT, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["samples"] == d["S"]
+    assert d["stats_err"] < 1e-12 and d["loss_err"] < 1e-12 and d["decomposition_err"] < 1e-12
+
+
 def test_shard_regression_inputs_partitions_the_samples():
     from polee_amd.cohort import shard_regression_inputs
     rng = np.random.default_rng(5)
