@@ -11,7 +11,7 @@
 //   sample x : x = qx_loc + softplus(qx_softplus_scale) eps                       -> x     [S][n]
 //   lik      : approximate likelihood of x with d/dx                              -> lp [S], glik [S][n]
 //   data     : one thread per feature j over this rank's samples: observation-model sums (F+2 per column),
-//              gradients of qx_loc / qx_softplus_scale, the samples' loss terms           -> stats [(F+2) n + 1]
+//              gradients of qx_loc / qx_softplus_scale, the samples' loss terms           -> stats [(F+2) n + 32]
 //   (samples sharded over ranks: ONE all-reduce of stats, polee_regression_set_comm)
 //   columns  : one thread per feature j: draws the horseshoe+ scales, w, x_bias, x_scale of its column,
 //              evaluates its share of log q - log p and all per-column gradients from stats; block-reduces
@@ -202,7 +202,6 @@ __global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float
                                                                const float *__restrict__ sigma, float *lp, float *glik)
 {
     __shared__ float red[16];
-    __shared__ float bc[2];
     const int s = blockIdx.x, tid = threadIdx.x;
     const float *xr = x + (int64_t)s * n, *vr = v + (int64_t)s * n, *sr = sigma + (int64_t)s * n;
     float *gr = glik + (int64_t)s * n;
@@ -239,7 +238,6 @@ __global__ __launch_bounds__(1024) void reg_normal_lik_kernel(int n, const float
         const float is = 1.0f / sr[j];
         gr[j] = (vr[j] - (xr[j] - lse)) * is * is - expf(xr[j] - lse) * R;
     }
-    (void)bc;
 }
 
 // ---- gene-level model (RNASeqGeneLinearRegression, models/polee_regression.py:533-600): the features are genes and
