@@ -66,8 +66,9 @@ struct ApproxLeafLoad {
 
 // npart[s][block] = lp + ladj contributions of the block's internal nodes (summed by approx_finish_lp_kernel: one
 // same-address atomic per block serialised ~800 deep per sample and dominated this kernel)
-__global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *npart, double *y_out,
-                                    double *y_grad_out, double *inv_u_out)
+// tpair (optional) [S][n-1][2]: the node's two tour terms of InvHSBGrad, -1/u -+ ..., for its left ([0]) and right ([1])
+// edge -- one 8-byte gather per tour element in the scan instead of three plus arithmetic
+__global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *npart, double *tpair)
 {
     __shared__ double smd[4];
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,9 +96,7 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
         ladj += (double)(logf(coshf(al - z_asinh)) - 0.5f * log1pf(z_std * z_std));  // :440-443
         const double lp = (-1.8378770664093453 - (double)(z * z)) / 2.0;              // :448, log(2 pi)
         contrib = lp + ladj;
-        if (y_out) y_out[(int64_t)s * nm1 + k] = y;
-        if (inv_u_out) inv_u_out[(int64_t)s * nm1 + k] = 1.0 / u;
-        if (y_grad_out) {
+        if (tpair) {
             // d(lp + ladj)/d y_logit, then d y_logit / d y and the -log y - log1p(-y) term
             // with c = asinh(z_std) - alpha: sinh(c) = z, cosh(c) = sqrt(1 + z^2) (no f64 hyperbolics needed)
             const double zs = z_std, zd = (double)z, ch = sqrt(1.0 + zd * zd);
@@ -105,7 +104,11 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
             const double d_lp = -zd * ch * rs;
             const double d_la = zd / ch * rs - zs * rs * rs;
             const double d_logit = (d_lp + d_la) / (double)sg;
-            y_grad_out[(int64_t)s * nm1 + k] = d_logit / (y * (1 - y)) + (-1 / y + 1 / (1 - y));
+            const double y_grad = d_logit / (y * (1 - y)) + (-1 / y + 1 / (1 - y));
+            const double iu = 1.0 / u;
+            double *tp = tpair + ((int64_t)s * nm1 + k) * 2;
+            tp[0] = -iu + (-y) * iu * y_grad;
+            tp[1] = -iu + (1.0 - y) * iu * y_grad;
         }
     }
     contrib = block_sum_f64(contrib, smd);
@@ -131,14 +134,11 @@ __global__ __launch_bounds__(256) void approx_finish_lp_kernel(ApproxView a, con
 // straight from the leaf prefix because sum q = 1 (u_root = 1, as the op assumes).
 struct ApproxGradLoad {
     PttView v;
-    const double *y, *y_grad, *inv_u;  // [S][n-1]
+    const double *tpair;  // [S][n-1][2], written by approx_nodes_kernel
     __device__ inline double term(int row, uint32_t code) const
     {
         if (code & 4u) return 0.0;
-        const int64_t o = (int64_t)row * (v.n - 1) + (code >> 4);
-        const double iu = inv_u[o], yy = y[o];
-        const double w = (code & 8u) ? (1.0 - yy) : -yy;
-        return -iu + w * iu * y_grad[o];
+        return tpair[((int64_t)row * (v.n - 1) + (code >> 4)) * 2 + ((code >> 3) & 1u)];
     }
     __device__ dd operator()(int row, int64_t e) const
     {
@@ -276,7 +276,7 @@ struct polee_approx {
     int32_t S = 0, n = 0;
     polee_ptt *t = nullptr;  // S trees (or 1 shared)
     DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
-    DevBuf<double> d_sum_log_l, d_acc, d_npart, d_y, d_ygrad, d_invu, d_dots;
+    DevBuf<double> d_sum_log_l, d_acc, d_npart, d_tpair, d_dots;
     DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
     DevBuf<int32_t> d_gptr, d_gidx;  // genes as CSR over transcripts (gene-level wrapper), set by approx_set_genes
     int32_t G = 0;
@@ -371,9 +371,7 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
     A(ap->d_acc.alloc(ctx, (size_t)S * 8));
     A(ap->d_npart.alloc(ctx, (size_t)S * (size_t)ceil_div(n - 1, 256)));
     A(ap->d_dots.alloc(ctx, (size_t)S * 2));
-    A(ap->d_y.alloc(ctx, sk));
-    A(ap->d_ygrad.alloc(ctx, sk));
-    A(ap->d_invu.alloc(ctx, sk));
+    A(ap->d_tpair.alloc(ctx, 2 * sk));
     A(ap->d_bp.alloc(ctx, sn));
     A(ap->d_x.alloc(ctx, sn));
     A(ap->d_xgrad.alloc(ctx, sn));
@@ -418,13 +416,12 @@ polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, flo
     hipError_t e = run_scan_partial<dd>(st, S, n, t->d_chunk.p, nullptr, load, emit);
     if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
-                       ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_y.p : nullptr, grad ? ap->d_ygrad.p : nullptr,
-                       grad ? ap->d_invu.p : nullptr);
+                       ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_tpair.p : nullptr);
     hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
                        (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp);
     POLEE_KERNEL_CHECK(ctx);
     if (grad) {
-        ApproxGradLoad gl{t->view(), ap->d_y.p, ap->d_ygrad.p, ap->d_invu.p};
+        ApproxGradLoad gl{t->view(), ap->d_tpair.p};
         ApproxGradEmit ge{gl, ap->view(), d_x, ap->d_acc.p, ap->d_bp.p};
         e = run_scan_partial<dd>(st, S, t->TL, t->d_chunk.p, t->d_part.p, gl, ge);
         if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
