@@ -300,6 +300,17 @@ polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigm
                                 const float *alpha, const float *z0_or_null, int32_t ndraws,
                                 uint64_t seed, float *xs);
 
+/* posterior_mean (src/approx-sampler.jl:86-117): mean over ndraws draws, each clamped to [1e-15, 0.9999999]
+ * (f32 accumulation in draw order, as the reference); pm f32 [n].  z0 as in polee_sampler_draw. */
+polee_status polee_sampler_posterior_mean(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                          const float *z0_or_null, int32_t ndraws, uint64_t seed, float *pm);
+/* Statistics.quantile(loaded_samples, transforms, qs, N) for one sample (src/approx-sampler.jl:50-83): element-wise
+ * quantiles (Julia's default definition, linear interpolation between order statistics) of ndraws draws;
+ * qs f64 [nq] (nq <= 8), quantiles f32 [nq][n]. */
+polee_status polee_sampler_quantiles(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                     const float *z0_or_null, int32_t ndraws, uint64_t seed, const double *qs,
+                                     int32_t nq, float *quantiles);
+
 /* ---- density of fitted approximations (regression consumer) --------------------------
  * Replaces RNASeqApproxLikelihoodDist._log_prob (src/polee_approx_likelihood.py:367-450)
  * and, with it, the InvHSB/InvHSBGrad ops inside TF's autodiff.  S samples, each with

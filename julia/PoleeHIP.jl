@@ -148,6 +148,29 @@ function rand_draws!(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{F
     return xs
 end
 
+"one sample of posterior_mean(loaded_samples, N) -- src/approx-sampler.jl:86-117"
+function posterior_mean(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{Float32}, alpha::Vector{Float32},
+                        N::Integer=100; seed::Integer=rand(UInt64))
+    pm = Vector{Float32}(undef, length(mu) + 1)
+    GC.@preserve mu sigma alpha pm check(
+        ccall((:polee_sampler_posterior_mean, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, UInt64, Ptr{Float32}),
+              t.h, mu, sigma, alpha, C_NULL, N, seed, pm), t.ctx.h)
+    return pm
+end
+
+"one sample of Statistics.quantile(loaded_samples, transforms, qs, N) -- src/approx-sampler.jl:50-83; n x length(qs)"
+function quantiles(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{Float32}, alpha::Vector{Float32},
+                   qs::Vector{Float64}=[0.01, 0.99], N::Integer=100; seed::Integer=rand(UInt64))
+    out = Matrix{Float32}(undef, length(mu) + 1, length(qs))
+    GC.@preserve mu sigma alpha qs out check(
+        ccall((:polee_sampler_quantiles, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, UInt64, Ptr{Float64}, Int32,
+               Ptr{Float32}),
+              t.h, mu, sigma, alpha, C_NULL, N, seed, qs, length(qs), out), t.ctx.h)
+    return out
+end
+
 "effective_length_jacobian_adjustment!(efflens, xs, xls, x_grad) -- src/likelihood.jl:93-110"
 function effective_length_jacobian_adjustment!(ctx::Context, efflens::Vector{Float32}, xs::Vector{Float32},
                                                xls::Vector{Float32}, x_grad::Vector{Float64})

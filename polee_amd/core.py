@@ -607,6 +607,32 @@ class ApproxLikelihoodSampler:
                                          ptr(z, f32p), int(ndraws), C.c_uint64(seed), ptr(xs, f32p)), t.ctx._h)
         return xs
 
+    def _next_seed(self):
+        seed = (self._seed + 0x632BE59BD9B4E019 * self._count) & 0xFFFFFFFFFFFFFFFF
+        self._count += 1
+        return seed
+
+    def posterior_mean(self, N=100, z0=None):
+        """One sample of posterior_mean (approx-sampler.jl:86-117): mean of N draws clamped to [1e-15, 0.9999999]."""
+        t = self.t
+        z = None if z0 is None else arr(z0, np.float32).reshape(N, t.n - 1)
+        pm = np.empty(t.n, np.float32)
+        check(L.lib().polee_sampler_posterior_mean(t._h, ptr(self.mu, f32p), ptr(self.sigma, f32p),
+                                                   ptr(self.alpha, f32p), ptr(z, f32p), int(N),
+                                                   C.c_uint64(self._next_seed()), ptr(pm, f32p)), t.ctx._h)
+        return pm
+
+    def quantile(self, qs=(0.01, 0.99), N=100, z0=None):
+        """One sample of Statistics.quantile (approx-sampler.jl:50-83): element-wise quantiles [len(qs), n] of N draws."""
+        t = self.t
+        z = None if z0 is None else arr(z0, np.float32).reshape(N, t.n - 1)
+        q = arr(qs, np.float64).reshape(-1)
+        out = np.empty((q.size, t.n), np.float32)
+        check(L.lib().polee_sampler_quantiles(t._h, ptr(self.mu, f32p), ptr(self.sigma, f32p), ptr(self.alpha, f32p),
+                                              ptr(z, f32p), int(N), C.c_uint64(self._next_seed()), ptr(q, L.f64p),
+                                              int(q.size), ptr(out, f32p)), t.ctx._h)
+        return out
+
 
 class RNASeqApproxLikelihood:
     """RNASeqApproxLikelihoodDist (polee_approx_likelihood.py:326-450) for S samples.

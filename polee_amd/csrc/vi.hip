@@ -277,6 +277,93 @@ polee_status polee_vi::one_step(bool apply, bool want_values, bool hook_outputs)
     return fail(ctx, POLEE_ERR_BAD_ARG, "num_mc_samples must be in 1..8");
 }
 
+namespace polee {
+
+// ndraws draws of the sampler into d_all [ndraws][n] (device), in batches of 8 rows
+static polee_status sampler_draw_device(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                        const float *z0, int32_t ndraws, uint64_t seed, DevBuf<float> &d_all)
+{
+    polee_ctx *ctx = t->ctx;
+    if (!mu || !sigma || !alpha || ndraws < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    if (t->T != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "the sampler needs a single tree");
+    const size_t n = t->n, nm1 = n - 1;
+    DevBuf<float> d_mu, d_sigma, d_alpha, d_z0;
+    POLEE_TRY(d_mu.upload(ctx, mu, nm1));
+    POLEE_TRY(d_sigma.upload(ctx, sigma, nm1));
+    POLEE_TRY(d_alpha.upload(ctx, alpha, nm1));
+    POLEE_TRY(d_all.alloc(ctx, (size_t)ndraws * n));
+    for (int32_t b0 = 0; b0 < ndraws; b0 += 8) {
+        const int32_t B = std::min(8, ndraws - b0);
+        POLEE_TRY(t->reserve(B));
+        if (z0) POLEE_TRY(d_z0.upload(ctx, z0 + (size_t)b0 * nm1, (size_t)B * nm1));
+        NoiseSrc noise{z0 ? d_z0.p : nullptr, seed + (uint64_t)b0 * 0x9E3779B97F4A7C15ull, B, (int64_t)nm1};
+        if (nm1 > 0) {
+            hipLaunchKernelGGL(sampler_y_kernel, dim3((unsigned)ceil_div(nm1, 256), B), dim3(256), 0, ctx->stream,
+                               d_mu.p, d_sigma.p, d_alpha.p, noise, t->d_ys.p);
+            POLEE_KERNEL_CHECK(ctx);
+        }
+        FwdOut o;
+        o.xs = d_all.p + (size_t)b0 * n;
+        o.xs_rs = n;
+        POLEE_TRY(ptt_forward_device(t, t->d_ys.p, B, o));
+    }
+    return POLEE_OK;
+}
+
+// posterior_mean (src/approx-sampler.jl:86-117): clamp every draw to [1e-15, 0.9999999], add them in draw order in
+// f32 (pm .+= xs), divide by N
+__global__ void sampler_mean_kernel(const float *xs, int ndraws, int64_t n, float *pm)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.0f;
+    for (int k = 0; k < ndraws; ++k) acc += fminf(fmaxf(xs[(int64_t)k * n + j], 1e-15f), 0.9999999f);
+    pm[j] = acc / (float)ndraws;
+}
+
+constexpr int SAMPLER_MAX_Q = 8;
+struct QuantileSpec {
+    int nq;
+    int j[SAMPLER_MAX_Q];         // 1-based lower order statistic
+    double gamma[SAMPLER_MAX_Q];  // interpolation weight
+};
+// Statistics.quantile per transcript over the draws (src/approx-sampler.jl:50-83): thread per transcript; the rank of
+// every draw by counting (ties broken by draw index), no sort.  The column is staged in LDS when it fits.
+__global__ __launch_bounds__(64) void sampler_quantile_kernel(const float *xs, int ndraws, int64_t n, QuantileSpec spec,
+                                                              int in_lds, float *out)
+{
+    extern __shared__ float col[];  // [ndraws][64]
+    const int64_t jj = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t j = jj < n ? jj : n - 1;
+    if (in_lds)
+        for (int k = 0; k < ndraws; ++k) col[k * 64 + threadIdx.x] = xs[(int64_t)k * n + j];
+    auto at = [&](int k) { return in_lds ? col[k * 64 + threadIdx.x] : xs[(int64_t)k * n + j]; };
+    float a[SAMPLER_MAX_Q], b[SAMPLER_MAX_Q];
+#pragma unroll
+    for (int i = 0; i < SAMPLER_MAX_Q; ++i) a[i] = b[i] = 0.0f;
+    for (int e = 0; e < ndraws; ++e) {
+        const float ve = at(e);
+        int rank = 0;
+        for (int i = 0; i < ndraws; ++i) {
+            const float vi = at(i);
+            rank += (vi < ve || (vi == ve && i < e)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < SAMPLER_MAX_Q; ++i)
+            if (i < spec.nq) {
+                if (rank == spec.j[i] - 1) a[i] = ve;
+                if (rank == spec.j[i] || ndraws == 1) b[i] = ve;
+            }
+    }
+    if (jj < n)
+#pragma unroll
+        for (int i = 0; i < SAMPLER_MAX_Q; ++i)
+            if (i < spec.nq) out[(int64_t)i * n + j] = (float)((double)a[i] + spec.gamma[i] * (double)(b[i] - a[i]));
+}
+
+}  // namespace polee
+using namespace polee;
+
 extern "C" {
 
 void polee_vi_default_opts(polee_vi_opts *o)
@@ -651,33 +738,56 @@ polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigm
     if (!t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null tree");
     polee_ctx *ctx = t->ctx;
     POLEE_TRY(use_device(ctx));
-    if (!mu || !sigma || !alpha || !xs || ndraws < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
-    if (t->T != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "the sampler needs a single tree");
-    const size_t n = t->n, nm1 = n - 1;
-    DevBuf<float> d_mu, d_sigma, d_alpha, d_z0, d_x;
-    POLEE_TRY(d_mu.upload(ctx, mu, nm1));
-    POLEE_TRY(d_sigma.upload(ctx, sigma, nm1));
-    POLEE_TRY(d_alpha.upload(ctx, alpha, nm1));
-    POLEE_TRY(d_x.alloc(ctx, n));
-    // draws are processed in batches of 8 rows
-    for (int32_t b0 = 0; b0 < ndraws; b0 += 8) {
-        const int32_t B = std::min(8, ndraws - b0);
-        POLEE_TRY(t->reserve(B));
-        if (z0) POLEE_TRY(d_z0.upload(ctx, z0 + (size_t)b0 * nm1, (size_t)B * nm1));
-        NoiseSrc noise{z0 ? d_z0.p : nullptr, seed + (uint64_t)b0 * 0x9E3779B97F4A7C15ull, B, (int64_t)nm1};
-        if (nm1 > 0) {
-            hipLaunchKernelGGL(sampler_y_kernel, dim3((unsigned)ceil_div(nm1, 256), B), dim3(256), 0, ctx->stream,
-                               d_mu.p, d_sigma.p, d_alpha.p, noise, t->d_ys.p);
-            POLEE_KERNEL_CHECK(ctx);
-        }
-        POLEE_TRY(t->d_f32a.alloc(ctx, (size_t)B * n));
-        FwdOut o;
-        o.xs = t->d_f32a.p;
-        o.xs_rs = n;
-        POLEE_TRY(ptt_forward_device(t, t->d_ys.p, B, o));
-        POLEE_TRY(t->d_f32a.download(ctx, xs + (size_t)b0 * n, (size_t)B * n));
+    if (!xs) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<float> d_all;
+    POLEE_TRY(sampler_draw_device(t, mu, sigma, alpha, z0, ndraws, seed, d_all));
+    return d_all.download(ctx, xs, (size_t)ndraws * t->n);
+}
+
+polee_status polee_sampler_posterior_mean(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                          const float *z0, int32_t ndraws, uint64_t seed, float *pm)
+{
+    if (!t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null tree");
+    polee_ctx *ctx = t->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!pm) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<float> d_all, d_pm;
+    POLEE_TRY(sampler_draw_device(t, mu, sigma, alpha, z0, ndraws, seed, d_all));
+    POLEE_TRY(d_pm.alloc(ctx, (size_t)t->n));
+    hipLaunchKernelGGL(sampler_mean_kernel, dim3((unsigned)ceil_div(t->n, 256)), dim3(256), 0, ctx->stream, d_all.p,
+                       ndraws, (int64_t)t->n, d_pm.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return d_pm.download(ctx, pm, (size_t)t->n);
+}
+
+polee_status polee_sampler_quantiles(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                     const float *z0, int32_t ndraws, uint64_t seed, const double *qs, int32_t nq,
+                                     float *quantiles)
+{
+    if (!t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null tree");
+    polee_ctx *ctx = t->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!qs || !quantiles || nq < 1 || nq > SAMPLER_MAX_Q) return fail(ctx, POLEE_ERR_BAD_ARG, "1..%d quantiles", SAMPLER_MAX_Q);
+    QuantileSpec spec{};
+    spec.nq = nq;
+    for (int i = 0; i < nq; ++i) {
+        if (!(qs[i] >= 0.0 && qs[i] <= 1.0)) return fail(ctx, POLEE_ERR_BAD_ARG, "quantile %g outside [0, 1]", qs[i]);
+        // Statistics.quantile, default (type 7): aleph = (N-1) q + 1, j = clamp(trunc(aleph), 1, N-1), gamma = aleph - j
+        const double aleph = (double)(ndraws - 1) * qs[i] + 1.0;
+        const int j = ndraws == 1 ? 1 : std::min(std::max((int)aleph, 1), ndraws - 1);
+        spec.j[i] = j;
+        spec.gamma[i] = std::min(std::max(aleph - j, 0.0), 1.0);
     }
-    return POLEE_OK;
+    DevBuf<float> d_all, d_q;
+    POLEE_TRY(sampler_draw_device(t, mu, sigma, alpha, z0, ndraws, seed, d_all));
+    const int64_t n = t->n;
+    POLEE_TRY(d_q.alloc(ctx, (size_t)nq * n));
+    const bool in_lds = (size_t)ndraws * 64 * sizeof(float) <= 48 * 1024;
+    hipLaunchKernelGGL(sampler_quantile_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64),
+                       in_lds ? (size_t)ndraws * 64 * sizeof(float) : 0, ctx->stream, d_all.p, ndraws, n, spec,
+                       in_lds ? 1 : 0, d_q.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return d_q.download(ctx, quantiles, (size_t)nq * n);
 }
 
 }  // extern "C"

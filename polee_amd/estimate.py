@@ -107,3 +107,35 @@ def load_samples_from_specification(spec, n, gffhash=None, ptt_filename=None, ma
                            using_device=using_device, ctx=ctx)
     ls.sample_factors, ls.sample_names = sample_factors, sample_names
     return ls
+
+
+def quantile(loaded_samples, transforms, qs=(0.01, 0.99), N=100, seed=123456789):
+    """Statistics.quantile(loaded_samples, transforms, qs, N) (src/approx-sampler.jl:50-83): element-wise quantiles
+    of the approximated likelihood, [len(qs), num_samples, n]."""
+    from .core import ApproxLikelihoodSampler
+    ls = loaded_samples
+    S, n = ls.x0_values.shape
+    out = np.empty((len(qs), S, n), np.float32)
+    als = ApproxLikelihoodSampler()
+    als.seed(seed)
+    for i in range(S):
+        als.set_transform(transforms[i], ls.la_mu_values[i], ls.la_sigma_values[i], ls.la_alpha_values[i])
+        out[:, i, :] = als.quantile(qs, N)
+    return out
+
+
+def posterior_mean(loaded_samples, N=100, seed=123456789, ctx=None):
+    """posterior_mean(loaded_samples, N) (src/approx-sampler.jl:86-117): [num_samples, n]; the trees are read from
+    the samples' prepared files."""
+    from .core import ApproxLikelihoodSampler, PolyaTreeTransform
+    from . import h5io
+    ls = loaded_samples
+    pm = np.empty_like(np.asarray(ls.x0_values, np.float32))
+    als = ApproxLikelihoodSampler()
+    als.seed(seed)
+    for i, fn in enumerate(ls.sample_filenames):
+        d = h5io.read_prepared_sample(fn)
+        t = PolyaTreeTransform(d["node_parent_idxs"], d["node_js"], ctx=ctx)
+        als.set_transform(t, ls.la_mu_values[i], ls.la_sigma_values[i], ls.la_alpha_values[i])
+        pm[i] = als.posterior_mean(N)
+    return pm

@@ -479,6 +479,35 @@ def test_sampler_matches_oracle(P, ctx, prep_fixture):
     assert np.allclose(a.sum(axis=1), 1, atol=1e-4) and not np.allclose(a, b)
 
 
+def test_sampler_quantiles_and_posterior_mean(P, ctx, prep_fixture):
+    """Statistics.quantile / posterior_mean over sampler draws (src/approx-sampler.jl:50-117) with supplied noise,
+    against the oracle's draws and NumPy (np.quantile's default is Julia's default definition)."""
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    mu, sigma, alpha = prep_fixture["mu"], np.exp(prep_fixture["omega"]), prep_fixture["alpha"]
+    als = P.ApproxLikelihoodSampler()
+    als.set_transform(t, mu, sigma, alpha)
+    for N in (1, 7, 100):
+        z0 = np.stack([O.randn(t.n - 1, 900 + d) for d in range(N)])
+        draws = np.stack([O.sampler_draw(to, mu, sigma, alpha, z0[d]) for d in range(N)])
+        qs = (0.01, 0.25, 0.5, 0.99, 1.0)
+        q = als.quantile(qs, N, z0=z0)
+        qo = np.quantile(draws.astype(np.float64), qs, axis=0)
+        np.testing.assert_allclose(q, qo, rtol=3e-5, atol=1e-30)
+        pm = als.posterior_mean(N, z0=z0)
+        acc = np.zeros(t.n, np.float32)
+        for d in range(N):  # f32 accumulation in draw order, as the reference
+            acc += np.clip(draws[d], np.float32(1e-15), np.float32(0.9999999))
+        np.testing.assert_allclose(pm, acc / np.float32(N), rtol=3e-5, atol=1e-30)
+    # more draws than fit in LDS (global fallback) and the device RNG: quantiles are ordered and bracket the mean draw
+    q = als.quantile((0.05, 0.5, 0.95), 300)
+    assert np.all(q[0] <= q[1]) and np.all(q[1] <= q[2])
+    pm = als.posterior_mean(300)
+    assert abs(pm.sum() - 1) < 1e-3
+    with pytest.raises(P.PoleeError):
+        als.quantile((1.5,), 10)
+
+
 @pytest.mark.parametrize("shared", [False, True])
 def test_approx_logprob_and_gradient_match_oracle(P, ctx, shared):
     rng = np.random.default_rng(21)
