@@ -61,18 +61,30 @@ struct RegView {
     __host__ __device__ int num_red() const { return 1 + F * deg + 2 * deg; }
 };
 
-__device__ inline float softplusf(float x) { return x > 15.0f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
-__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-// psi(x), x > 0: recurrence up to x >= 6, then the asymptotic series
-__device__ inline float digammaf(float x)
+// The column kernels are VALU-bound (rocprofv3: ~7.4 k VALU instructions per thread with libm's exp / log / log1p and
+// IEEE division), so the elementwise math uses the hardware transcendentals (v_exp_f32, v_log_f32, v_rcp_f32,
+// v_sqrt_f32: 1 ulp each) -- errors of ~1e-6 relative, far inside the 1e-4 parity tolerance.
+__device__ inline float fexp(float x) { return __expf(x); }
+__device__ inline float flog(float x) { return __logf(x); }
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// log1p(t), 0 <= t <= 1, with full relative accuracy for small t (log(1 + t) would round 1 + t)
+__device__ inline float flog1p01(float t) { return t < 1e-3f ? t * (1.0f - t * (0.5f - t * (1.0f / 3.0f))) : flog(1.0f + t); }
+__device__ inline float softplusf(float x) { return fmaxf(x, 0.0f) + flog1p01(fexp(-fabsf(x))); }
+__device__ inline float sigmoidf(float x) { return frcp(1.0f + fexp(-x)); }
+// lgamma(x) and psi(x), x > 0, together: the recurrences lgamma(x) = lgamma(x+1) - log x, psi(x) = psi(x+1) - 1/x up to
+// x >= 8 (one log of the running product), then the Stirling / asymptotic series (truncation < 1e-8 at x = 8)
+__device__ inline void lgamma_digamma(float x, float &lg, float &psi)
 {
-    float r = 0.0f;
-    while (x < 6.0f) {
-        r -= 1.0f / x;
+    float prod = 1.0f, r = 0.0f;
+    while (x < 8.0f) {
+        prod *= x;
+        r -= frcp(x);
         x += 1.0f;
     }
-    const float i = 1.0f / x, i2 = i * i;
-    return r + logf(x) - 0.5f * i - i2 * (1.0f / 12.0f - i2 * (1.0f / 120.0f - i2 * (1.0f / 252.0f)));
+    const float i = frcp(x), i2 = i * i, lx = flog(x);
+    psi = r + lx - 0.5f * i - i2 * (1.0f / 12.0f - i2 * (1.0f / 120.0f - i2 * (1.0f / 252.0f)));
+    lg = (x - 0.5f) * lx - x + HALF_LOG2PI + i * (1.0f / 12.0f - i2 * (1.0f / 360.0f - i2 * (1.0f / 1260.0f))) - flog(prod);
 }
 
 // one draw of SoftplusNormal(loc, softplus(sraw)) (src/polee.py:24-33) and its share of log q
@@ -88,7 +100,7 @@ __device__ inline SpDraw sp_draw(float loc, float sraw, float eps)
     const float u = loc + d.s * eps;
     d.z = softplusf(u);
     d.sg = sigmoidf(u);
-    d.logq = -0.5f * eps * eps - logf(d.s) - HALF_LOG2PI + softplusf(-u);  // - log sigmoid(u)
+    d.logq = -0.5f * eps * eps - flog(d.s) - HALF_LOG2PI + softplusf(-u);  // - log sigmoid(u)
     return d;
 }
 // G = d(-log p)/dz  ->  d loss / d loc, d loss / d sraw
@@ -96,12 +108,12 @@ __device__ inline void sp_grad(const SpDraw &d, float G, float &gloc, float &gs)
 {
     const float a = G * d.sg - (1.0f - d.sg);
     gloc = a;
-    gs = (a * d.eps - 1.0f / d.s) * d.sgs;
+    gs = (a * d.eps - frcp(d.s)) * d.sgs;
 }
 // -log InverseGamma(0.5, 0.5)(z), -log HalfNormal(1)(z)
 __device__ inline float nlp_ig_half(float z)
 {
-    return -(0.5f * -0.69314718055994530942f - 0.57236494292470008707f - 1.5f * logf(z) - 0.5f / z);
+    return -(0.5f * -0.69314718055994530942f - 0.57236494292470008707f - 1.5f * flog(z) - 0.5f * frcp(z));
 }
 __device__ inline float nlp_halfnormal(float z) { return 0.22579135264472743236f + 0.5f * z * z; }  // -0.5 log(2/pi)
 
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(256) void reg_iso_grad_kernel(int S, int nt, const 
     const float *loc = ip + 2 * (int64_t)nt, *sr = loc + snt;
     const float ms_raw = ip[nt + i], ms = softplusf(ms_raw), me = ieps[i];
     const float m = ip[i] + ms * me;
-    float loss = -0.5f * me * me - logf(ms) - HALF_LOG2PI;               // log q(mean)
+    float loss = -0.5f * me * me - flog(ms) - HALF_LOG2PI;               // log q(mean)
     loss += 0.125f * m * m + 0.69314718055994530942f + HALF_LOG2PI;      // -log Normal(0, 2)(mean)
     float Gm = 0.25f * m;
     for (int s = 0; s < S; ++s) {
@@ -271,17 +283,17 @@ __global__ __launch_bounds__(256) void reg_iso_grad_kernel(int S, int nt, const 
         const float sraw = sr[o], sx = softplusf(sraw), e = ieps[nt + o];
         const float d = loc[o] + sx * e - m;
         loss += 0.5f * d * d + HALF_LOG2PI;                              // -log Normal(mean, 1)(x_isoform)
-        loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;                  // log q(x_isoform)
+        loss += -0.5f * e * e - flog(sx) - HALF_LOG2PI;                  // log q(x_isoform)
         Gm -= d;
         const float Gx = d - gi[o];
         if (live) {
             ig[2 * (int64_t)nt + o] = Gx;
-            ig[2 * (int64_t)nt + snt + o] = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
+            ig[2 * (int64_t)nt + snt + o] = (Gx * e - frcp(sx)) * sigmoidf(sraw);
         }
     }
     if (live) {
         ig[i] = Gm;
-        ig[nt + i] = (Gm * me - 1.0f / ms) * sigmoidf(ms_raw);
+        ig[nt + i] = (Gm * me - frcp(ms)) * sigmoidf(ms_raw);
     }
     loss = wave_sum_to_lane63(live ? loss : 0.0f);
     if ((threadIdx.x & 63) == 63) atomicAdd(&loss_slots[blockIdx.x % REG_SLOTS], loss);
@@ -324,9 +336,10 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
     }
     const float b = p[v.o_bias_loc() + j] + softplusf(p[v.o_bias_s() + j]) * eps[v.e_bias() + j];
     const float xsz = softplusf(p[v.o_xs_loc() + j] + softplusf(p[v.o_xs_s() + j]) * eps[v.e_xs() + j]);
-    const float inv = 1.0f / xsz, inv2 = inv * inv, lxs = logf(xsz);
+    const float inv = frcp(xsz), inv2 = inv * inv, lxs = flog(xsz);
     const float ipen2 = 1.0f / (v.penalty * v.penalty);
     float loss = 0.0f, sum_a = 0.0f, sum_xs = 0.0f;
+#pragma unroll 2  // (the samples' loads are independent: two in flight per lane)
     for (int s = 0; s < v.S; ++s) {
         float xl = b;
 #pragma unroll UF
@@ -344,9 +357,9 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
         if (!v.point) {
             const float sraw = p[v.o_qx_s() + sj], sx = softplusf(sraw), e = eps[v.e_x() + sj];
             const float Gx = a - glik[sj];
-            gl = Gx + lse[s] * ipen2 * expf(p[v.o_qx_loc() + sj] - lse[s]);
-            gs = (Gx * e - 1.0f / sx) * sigmoidf(sraw);
-            loss += -0.5f * e * e - logf(sx) - HALF_LOG2PI;
+            gl = Gx + lse[s] * ipen2 * fexp(p[v.o_qx_loc() + sj] - lse[s]);
+            gs = (Gx * e - frcp(sx)) * sigmoidf(sraw);
+            loss += -0.5f * e * e - flog(sx) - HALF_LOG2PI;
         }
         if (live) g[v.o_qx_loc() + sj] = gl, g[v.o_qx_s() + sj] = gs;
     }
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     float loss = 0.0f, S1 = 0.0f;
     // global horseshoe scale (every thread recomputes the two scalars)
     const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
-    const float gscale = gn.z * sqrtf(gv.z);
+    const float gscale = gn.z * fsqrt(gv.z);
 
     // ---- horseshoe+ scales and w of every factor
 #pragma unroll UF
@@ -412,26 +425,28 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         const SpDraw l2n = sp_draw(pc[6 * Fn], pc[7 * Fn], ec[3 * Fn]);
         const float sraw_w = pc[9 * Fn], s_w = softplusf(sraw_w), e_w = ec[4 * Fn];
         const float w = pc[8 * Fn] + s_w * e_w;
-        const float sw = (l1n.z * sqrtf(l1v.z)) * (l2n.z * sqrtf(l2v.z)) * gscale;
-        const float r = w / sw, q = 1.0f - r * r;
+        const float sw = (l1n.z * fsqrt(l1v.z)) * (l2n.z * fsqrt(l2v.z)) * gscale;
+        const float isw = frcp(sw), r = w * isw, q = 1.0f - r * r;
         S1 += q;
-        loss += l1v.logq + l1n.logq + l2v.logq + l2n.logq + (-0.5f * e_w * e_w - logf(s_w) - HALF_LOG2PI);
+        loss += l1v.logq + l1n.logq + l2v.logq + l2n.logq + (-0.5f * e_w * e_w - flog(s_w) - HALF_LOG2PI);
         loss += nlp_ig_half(l1v.z) + nlp_halfnormal(l1n.z) + nlp_ig_half(l2v.z) + nlp_halfnormal(l2n.z);
-        loss += 0.5f * r * r + logf(sw) + HALF_LOG2PI;
+        loss += 0.5f * r * r + flog(sw) + HALF_LOG2PI;
         float a, b;
-        sp_grad(l1v, 1.5f / l1v.z - 0.5f / (l1v.z * l1v.z) + 0.5f * q / l1v.z, a, b);
+        float iz = frcp(l1v.z);
+        sp_grad(l1v, iz * (1.5f + 0.5f * q - 0.5f * iz), a, b);  // 1.5/z - 0.5/z^2 + 0.5 q/z
         if (live) gc[0 * Fn] = a, gc[1 * Fn] = b;
-        sp_grad(l1n, l1n.z + q / l1n.z, a, b);
+        sp_grad(l1n, l1n.z + q * frcp(l1n.z), a, b);
         if (live) gc[2 * Fn] = a, gc[3 * Fn] = b;
-        sp_grad(l2v, 1.5f / l2v.z - 0.5f / (l2v.z * l2v.z) + 0.5f * q / l2v.z, a, b);
+        iz = frcp(l2v.z);
+        sp_grad(l2v, iz * (1.5f + 0.5f * q - 0.5f * iz), a, b);
         if (live) gc[4 * Fn] = a, gc[5 * Fn] = b;
-        sp_grad(l2n, l2n.z + q / l2n.z, a, b);
+        sp_grad(l2n, l2n.z + q * frcp(l2n.z), a, b);
         if (live) gc[6 * Fn] = a, gc[7 * Fn] = b;
         const float gacc = stats[idx];
-        const float Gw = r / sw + gacc;
+        const float Gw = r * isw + gacc;
         if (live) {
             gc[8 * Fn] = Gw;
-            gc[9 * Fn] = (Gw * e_w - 1.0f / s_w) * sigmoidf(sraw_w);
+            gc[9 * Fn] = (Gw * e_w - frcp(s_w)) * sigmoidf(sraw_w);
         }
         if (v.use_distortion) {
 #pragma unroll UD
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     // ---- x_bias, x_scale
     const float s_b = softplusf(p[v.o_bias_s() + j]), e_b = eps[v.e_bias() + j];
     const float b = p[v.o_bias_loc() + j] + s_b * e_b;
-    loss += -0.5f * e_b * e_b - logf(s_b) - HALF_LOG2PI;
+    loss += -0.5f * e_b * e_b - flog(s_b) - HALF_LOG2PI;
     const SpDraw xs = sp_draw(p[v.o_xs_loc() + j], p[v.o_xs_s() + j], eps[v.e_xs() + j]);
     loss += xs.logq;
     float alpha = 0.0f, beta = 0.0f;
@@ -455,16 +470,19 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         alpha += s_cc[d] * wdj;
         beta += s_sc[d] * wdj;
     }
-    const float inv = 1.0f / xs.z, inv2 = inv * inv, lxs = logf(xs.z);
+    const float inv = frcp(xs.z), inv2 = inv * inv, lxs = flog(xs.z);
     const float Gxs = (alpha + 1.0f) * inv - beta * inv2 + stats[(int64_t)(F + 1) * n + j];
     const float db = (b - v.bias_loc0) / v.bias_scale0;
     const float Gb = db / v.bias_scale0 - stats[(int64_t)F * n + j];
     loss += 0.5f * db * db + logf(v.bias_scale0) + HALF_LOG2PI;
-    loss += -(alpha * logf(beta) - lgammaf(alpha) - (alpha + 1.0f) * lxs - beta * inv);
-    const float g_alpha = -logf(beta) + digammaf(alpha) + lxs, g_beta = -alpha / beta + inv;
+    const float lbeta = flog(beta);
+    float lg_alpha, psi_alpha;
+    lgamma_digamma(alpha, lg_alpha, psi_alpha);
+    loss += -(alpha * lbeta - lg_alpha - (alpha + 1.0f) * lxs - beta * inv);
+    const float g_alpha = -lbeta + psi_alpha + lxs, g_beta = -alpha * frcp(beta) + inv;
     if (live) {
         g[v.o_bias_loc() + j] = Gb;
-        g[v.o_bias_s() + j] = (Gb * e_b - 1.0f / s_b) * sigmoidf(p[v.o_bias_s() + j]);
+        g[v.o_bias_s() + j] = (Gb * e_b - frcp(s_b)) * sigmoidf(p[v.o_bias_s() + j]);
         float a, c;
         sp_grad(xs, Gxs, a, c);
         g[v.o_xs_loc() + j] = a;
