@@ -3,14 +3,13 @@ import numpy as np
 import torch
 torch.cuda.init()  # (torch's HIP runtime must come up before libpolee_hip's in a shared process)
 import polee_amd as P
-from oracle import oracle as O
 from tools import synth
 n = 200000
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 rng = np.random.default_rng(0)
 smp = synth.make_sample(n, 1000000, 8.0, 1)
 par, js = synth.make_tree(smp['gene'], 1)
-l, r, f = O.make_inverse_ptt_params(par, js)
+l, r, f = P.make_inverse_ptt_params(par, js)
 L_, R_, F_ = (np.tile(a, (S, 1)) for a in (l, r, f))
 eff = np.tile(smp['effective_lengths'], (S, 1)).astype(np.float32)
 mu = rng.normal(0, 2, (S, n - 1)).astype(np.float32)

@@ -3,7 +3,6 @@ n=200k transcripts, synthetic approximation parameters.  usage: regression_bench
 import os, sys, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 import polee_amd as P
-from oracle import oracle as O  # only make_inverse_ptt_params (index arrays of a tree), not timed
 from tools import synth
 n = 200000
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -11,7 +10,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 rng = np.random.default_rng(0)
 smp = synth.make_sample(n, 1000000, 8.0, 1)
 par, js = synth.make_tree(smp['gene'], 1)
-l, r, f = O.make_inverse_ptt_params(par, js)
+l, r, f = P.make_inverse_ptt_params(par, js)
 eff = np.tile(smp['effective_lengths'], (S, 1)).astype(np.float32)
 mu = rng.normal(0, 2, (S, n - 1)).astype(np.float32)
 sigma = np.exp(rng.normal(-1, 1, (S, n - 1))).astype(np.float32)
