@@ -60,6 +60,9 @@ polee_status polee_debug_regression_data_pass(polee_regression *reg, const float
 polee_status polee_debug_regression_prior_pass(polee_regression *reg, const float *stats, float *loss,
                                                float *grad_or_null);
 
+/* fast_log (csrc/scan.hpp), the double-precision log of the tree kernels, element-wise (tests check it against libm) */
+polee_status polee_debug_fast_log(polee_ctx *ctx, const double *x, int64_t count, double *out);
+
 #ifdef __cplusplus
 }
 #endif

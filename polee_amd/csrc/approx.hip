@@ -83,8 +83,8 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
         const double ul = dd_diff(Cr[hi1], Cr[mid]);
         const double u = ul + ur;
         const double y = ul / u;                                    // hsb_ops.cpp:230
-        double ladj = -log(u);                                      // hsb_ops.cpp:231
-        const double y_log = log(y), y_1mlog = log1p(-y);           // :418-419
+        double ladj = -fast_log(u);                                 // hsb_ops.cpp:231
+        const double y_log = fast_log(y), y_1mlog = fast_log(1.0 - y);  // :418-419 (log1p(-y))
         const float y_logit = (float)(y_log - y_1mlog);             // :421
         ladj += (double)(float)(-y_log - y_1mlog);                  // :423-425
         const float muk = a.mu[(int64_t)s * nm1 + k], sg = a.sigma[(int64_t)s * nm1 + k];

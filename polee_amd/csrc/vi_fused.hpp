@@ -135,8 +135,8 @@ __device__ inline void sample_node(float m, float om, float al, const Noise &noi
         }
         y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
         ys[k * K + d] = y;
-        lyy[(k * 2 + 0) * K + d] = log1p(-y);
-        lyy[(k * 2 + 1) * K + d] = log(y);
+        lyy[(k * 2 + 0) * K + d] = fast_log(1.0 - y);  // log1p(-y): y is clamped to [eps, 1 - eps]
+        lyy[(k * 2 + 1) * K + d] = fast_log(y);
     }
 }
 

@@ -822,3 +822,21 @@ def test_factored_vi_trajectory_with_supplied_noise(P, ctx, lm_fixture, prep_fix
     # the multiplicities matter: the unweighted fit sees a different likelihood
     ref1 = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=1, num_mc=K, z0=z0[:K * (f["n"] - 1)], gradonly=False)
     assert abs(ref1["lp_mean"][0] - ref["lp_mean"][0]) > 0.1 * abs(ref1["lp_mean"][0])
+
+
+def test_fast_log_is_a_double_precision_log(P, ctx):
+    """The tree kernels take log y, log(1 - y), log u per node in double; csrc/scan.hpp's fast_log replaces libm's
+    (a third of the f64 instructions).  It must stay a double-precision log: <= 4 ulp over the whole range."""
+    import ctypes as C
+    from polee_amd import _lib as L
+    rng = np.random.default_rng(40)
+    x = np.concatenate([rng.uniform(0, 1, 200000), 10.0 ** rng.uniform(-300, 300, 200000),
+                        1 - 10.0 ** rng.uniform(-16, -1, 50000), 1 + 10.0 ** rng.uniform(-16, -1, 50000),
+                        [1.0, 0.5, 2.0, 0.7071067811865476, 1e-10, 1 - 1e-10, 5e-324, 1.7976931348623157e308]])
+    out = np.empty_like(x)
+    L.check(L.lib().polee_debug_fast_log(ctx._h, x.ctypes.data_as(L.f64p), C.c_int64(x.size), out.ctypes.data_as(L.f64p)),
+            ctx._h)
+    ref = np.log(x)
+    ulp = np.abs(out - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
+    assert out[x == 1.0].max() == 0.0 and np.all(np.isfinite(out))
+    assert ulp.max() <= 4, (ulp.max(), x[ulp.argmax()])
