@@ -186,7 +186,7 @@ inline hipError_t run_scan(hipStream_t stream, int rows, int64_t len, T *chunk_b
 }
 
 // Block-wide sum of doubles (256 threads); result valid in thread 0.
-// log(x) for finite x > 0 in double, ~2 ulp: x = m 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s),
+// log(x) in double, ~2 ulp: x = m 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s),
 // s = (m - 1)/(m + 1), |s| <= 0.172, odd series to s^21.  About a third of the f64 instructions of libm's log (the
 // tree kernels take two or three double logs per node and draw, and an f64 VALU op holds a SIMD for 8 cycles).
 __device__ inline double fast_log(double x)
@@ -216,7 +216,9 @@ __device__ inline double fast_log(double x)
     p = fma(p, s2, 1.0 / 3.0);
     p = fma(p, s2, 1.0);
     const double ed = (double)e;
-    return fma(ed, 0x1.62e42fee00000p-1, fma(ed, 0x1.a39ef35793c76p-33, 2.0 * s * p));
+    const double r0 = fma(ed, 0x1.62e42fee00000p-1, fma(ed, 0x1.a39ef35793c76p-33, 2.0 * s * p));
+    // libm's edge cases: log(0) = -inf, log(x < 0) = log(nan) = nan, log(inf) = inf
+    return x > 0.0 ? (x < HUGE_VAL ? r0 : x) : (x == 0.0 ? -HUGE_VAL : __builtin_nan(""));
 }
 
 __device__ inline double block_sum_f64(double v, double *smem4)

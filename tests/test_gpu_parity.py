@@ -840,3 +840,7 @@ def test_fast_log_is_a_double_precision_log(P, ctx):
     ulp = np.abs(out - ref) / np.maximum(np.spacing(np.abs(ref)), 5e-324)
     assert out[x == 1.0].max() == 0.0 and np.all(np.isfinite(out))
     assert ulp.max() <= 4, (ulp.max(), x[ulp.argmax()])
+    edge = np.array([0.0, -1.0, np.inf, np.nan])
+    eo = np.empty_like(edge)
+    L.check(L.lib().polee_debug_fast_log(ctx._h, edge.ctypes.data_as(L.f64p), C.c_int64(4), eo.ctypes.data_as(L.f64p)), ctx._h)
+    assert eo[0] == -np.inf and np.isnan(eo[1]) and eo[2] == np.inf and np.isnan(eo[3])
