@@ -19,7 +19,7 @@
 namespace polee {
 
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_ITEMS = 2;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
 
 struct dd {
