@@ -54,10 +54,13 @@ def _oracle_setup(reg, design, x_init, ss, deg, bandwidth):
     return RR.kernel_regression_weights(bandwidth, mean, hinges)
 
 
-@pytest.mark.parametrize("use_distortion,point", [(True, False), (False, False), (True, True)])
-def test_loss_and_gradient_match_restatement(P, ctx, use_distortion, point):
+@pytest.mark.parametrize("use_distortion,point,F,deg", [(True, False, 2, 5), (False, False, 2, 5), (True, True, 2, 5),
+                                                         # the fixed-trip-count kernel instances (15 hinges, F <= 4)
+                                                         (True, False, 1, 15), (True, False, 3, 15),
+                                                         (True, False, 4, 15), (True, False, 5, 15)])
+def test_loss_and_gradient_match_restatement(P, ctx, use_distortion, point, F, deg):
     rng = np.random.default_rng(31)
-    S, F, n, deg, pen = 4, 2, 150, 5, 0.7
+    S, n, pen = 4, 150, 0.7
     vars_, design, x_init = _problem(rng, S, F, n)
     ss = P.estimate_sample_scales(x_init, upper_quantile=0.8)
     reg = P.RNASeqTranscriptLinearRegression(vars_, x_init, design, ss, use_distortion, pen, point,
