@@ -32,6 +32,9 @@ WORKLOADS = {
     "small": (20000, 3000000, 8.0),
     "c2": (200000, 30000000, 8.0),
     "c5": (200000, 150000000, 8.0),
+    # secondary metric: regression steps/s, S samples x F = 2 factors x n transcripts; own code path
+    "c3": (200000, 6, 2),
+    "c4": (200000, 8, 2),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -39,6 +42,46 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def algorithmic_bytes_per_pass(nnz, m, n, K):
     """nnz*(4 B value + 4 B column) + (m+1)*4 B row offsets + K*n*8 B (read x, write grad)."""
     return nnz * 8 + (m + 1) * 4 + K * n * 8
+
+
+def regression_bench(args):
+    """`--workload c3|c4`: the regression model's variational step (models/polee_regression.py fit) on one GPU:
+    BASELINE configs 3 / 4's per-GPU share, synthetic approximation parameters (mu ~ N(0,2),
+    omega ~ N(-1,1), alpha ~ N(0,.3)), device RNG.  A step = one draw of every latent, loss + gradient, Adam."""
+    import numpy as np
+    import polee_amd as P
+    from tools import synth
+    n, S, F = WORKLOADS[args.workload]
+    rng = np.random.default_rng(args.seed)
+    smp = synth.make_sample(n, 1000000, 8.0, 1)
+    parents, js = synth.make_tree(smp["gene"], 1)
+    li, ri, fi = P.make_inverse_ptt_params(parents, js)
+    ctx = P.Context(0)
+    vars_ = dict(efflen=np.tile(smp["effective_lengths"], (S, 1)).astype(np.float32),
+                 la_mu=rng.normal(0, 2, (S, n - 1)).astype(np.float32),
+                 la_sigma=np.exp(rng.normal(-1, 1, (S, n - 1))).astype(np.float32),
+                 la_alpha=rng.normal(0, .3, (S, n - 1)).astype(np.float32), left_index=li[None], right_index=ri[None],
+                 leaf_index=fi[None])
+    lik = P.RNASeqApproxLikelihood(vars_, ctx=ctx)
+    x0 = np.log(np.maximum(lik.sample(seed=1), 1e-12)).astype(np.float32)
+    design = np.zeros((S, F), np.float32)
+    design[:, 0] = 1
+    design[S // 2:, 1] = 1
+    reg = P.RNASeqTranscriptLinearRegression(lik, x0, design, P.estimate_sample_scales(x0), True, 1.0, False, ctx=ctx)
+    reg.fit(max(args.warmup, 1), seed=args.seed)
+    t0 = time.perf_counter()
+    trace = reg.fit(args.steps, seed=args.seed, return_trace=True)[-1]  # synchronises before returning
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "regression steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: regression step, S=%d samples x F=%d factors x n=%d transcripts, 15 hinges, "
+                               "likelihood on, device RNG" % (args.workload.upper(), S, F, n)},
+        "detail": {"loss_first": float(trace[0]), "loss_last": float(trace[-1]),
+                   "finite": bool(np.all(np.isfinite(trace))), "parameters": reg.num_params,
+                   "note": "latency / gather bound (SURVEY.md 8(d)): no roofline claim for this step"},
+    }))
 
 
 def main():
@@ -57,6 +100,8 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
+    if args.workload in ("c3", "c4"):
+        return regression_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
