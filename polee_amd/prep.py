@@ -10,6 +10,12 @@ the reference.
 
     python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method cluster|sequential]
         [--ptt-tree tree.h5] [--no-efflen-jacobian] [--seed N] [--device D]
+
+`polee prep-salmon` (src/main.jl:723-750): the factored likelihood of `salmon quant -d` output on a given tree:
+
+    python -m polee_amd.prep --salmon salmon_quant_dir --ptt-tree tree.h5 --transcript-ids ids.txt -o prepared-sample.h5
+
+(`ids.txt`: one transcript id per line in the tree's order, i.e. the `transcript_ids` dataset of the PTT file).
 """
 import argparse
 import sys
@@ -41,9 +47,34 @@ def approximate_likelihood_to_file(approx, likelihood_matrix_filename, output_fi
     return params
 
 
+def approximate_salmon_likelihood_to_file(approx, salmon_dir, transcript_ids, tree_filename, output_filename,
+                                          use_efflen_jacobian=True, seed=123456789, ctx=None, args=""):
+    """polee_prep_salmon (src/main.jl:723-750): load_salmon_likelihood -> factored fit on the given tree -> file."""
+    from .salmon import load_salmon_likelihood
+    ctx = ctx or Context(0)
+    t0 = time.time()
+    s = load_salmon_likelihood(salmon_dir, transcript_ids)
+    t_read = time.time() - t0
+    t0 = time.time()
+    sample = s.to_sample(ctx=ctx)
+    t_layout = time.time() - t0
+    parents, js = h5io.read_transformation(tree_filename)
+    if len(js) != 2 * s.n - 1:
+        raise ValueError("the tree has %d nodes, salmon reports %d transcripts" % (len(js), s.n))
+    tree = PolyaTreeTransform(parents, js, ctx=ctx)
+    t0 = time.time()
+    params = approximate_likelihood(approx, sample, tree, use_efflen_jacobian=use_efflen_jacobian, seed=seed)
+    t_fit = time.time() - t0
+    h5io.write_approximation(output_filename, s.m, s.n, s.efflens, params, args=args)
+    params["timings"] = {"read_s": t_read, "device_layout_s": t_layout, "tree_and_fit_s": t_fit}
+    return params
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m polee_amd.prep", description=__doc__.split("\n\n")[0])
-    ap.add_argument("likelihood_matrix", metavar="likelihood-matrix.h5")
+    ap.add_argument("likelihood_matrix", metavar="likelihood-matrix.h5", nargs="?")
+    ap.add_argument("--salmon", default=None, metavar="salmon_quant_dir", help="prep-salmon: salmon quant -d output")
+    ap.add_argument("--transcript-ids", default=None, metavar="ids.txt", help="with --salmon: transcript ids, tree order")
     ap.add_argument("-o", "--output", default="prepared-sample.h5", metavar="prepared-sample.h5")
     ap.add_argument("--tree-method", default="cluster", choices=["cluster", "sequential"])
     ap.add_argument("--ptt-tree", default=None, metavar="tree.h5", help="use this tree topology (polee fit-tree output)")
@@ -51,6 +82,21 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=123456789)
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
+    if a.salmon is not None:
+        if a.ptt_tree is None or a.transcript_ids is None:
+            ap.error("--salmon needs --ptt-tree and --transcript-ids")
+        with open(a.transcript_ids) as f:
+            ids = [line.rstrip("\n") for line in f if line.strip()]
+        params = approximate_salmon_likelihood_to_file(LogitSkewNormalPTTApprox("static"), a.salmon, ids, a.ptt_tree,
+                                                       a.output, use_efflen_jacobian=not a.no_efflen_jacobian,
+                                                       seed=a.seed, ctx=Context(a.device),
+                                                       args=" ".join(argv or sys.argv[1:]))
+        t = params["timings"]
+        print("wrote %s (n=%d): salmon read %.2f s, device layout %.2f s, fit %.2f s"
+              % (a.output, len(params["mu"]) + 1, t["read_s"], t["device_layout_s"], t["tree_and_fit_s"]))
+        return 0
+    if a.likelihood_matrix is None:
+        ap.error("give a likelihood matrix or --salmon")
     params = approximate_likelihood_to_file(LogitSkewNormalPTTApprox(a.tree_method), a.likelihood_matrix, a.output,
                                             use_efflen_jacobian=not a.no_efflen_jacobian,
                                             tree_topology_input_filename=a.ptt_tree, seed=a.seed,

@@ -78,3 +78,43 @@ def test_factored_likelihood_from_salmon_output_matches_oracle(tmp_path):
     lpo, go = so.factored_log_likelihood(s.ks, x)
     assert abs(lp - lpo) <= 1e-4 * abs(lpo)
     np.testing.assert_allclose(g, go, rtol=1e-4, atol=1e-4 * np.abs(go).max())
+
+
+@pytest.mark.gpu
+def test_prep_salmon_file_to_file(tmp_path):
+    """`polee prep-salmon` (src/main.jl:723-750) through python -m polee_amd.prep: salmon directory + tree file in,
+    prepared sample out; the fit explains the equivalence-class counts better than the starting point."""
+    import polee_amd as P
+    from polee_amd import h5io, prep
+    from conftest import random_tree
+    from oracle import oracle as O
+    rng = np.random.default_rng(52)
+    n = 50
+    d, names_polee, *_ = _example(tmp_path, rng, n=n, m=600)
+    parents, js = random_tree(n, rng)
+    tree_file, ids_file, out_file = str(tmp_path / "tree.h5"), str(tmp_path / "ids.txt"), str(tmp_path / "prep.h5")
+    with h5io.File(tree_file, "w") as h:
+        h.write("node_parent_idxs", np.ascontiguousarray(parents, np.int32))
+        h.write("node_js", np.ascontiguousarray(js, np.int32))
+    with open(ids_file, "w") as f:
+        f.write("\n".join(names_polee) + "\n")
+    assert prep.main(["--salmon", d, "--ptt-tree", tree_file, "--transcript-ids", ids_file, "-o", out_file]) == 0
+    got = h5io.read_prepared_sample(out_file)
+    assert got["n"] == n and got["m"] == 600
+    np.testing.assert_array_equal(got["node_js"], js)
+    assert all(np.all(np.isfinite(got[k])) and got[k].shape == (n - 1,) for k in ("mu", "omega", "alpha"))
+    # draws from the fit have a higher factored likelihood than draws from the initial approximation
+    s = load_salmon_likelihood(d, names_polee)
+    so, to = O.Sample(s.m, s.n, s.colptr, s.rowval, s.nzval), O.PTT(parents, js)
+
+    def mean_lp(mu, omega, alpha):
+        lps = []
+        for k in range(20):
+            x = O.sampler_draw(to, mu, np.exp(omega), alpha, O.randn(n - 1, 700 + k))
+            lps.append(so.factored_log_likelihood(s.ks, np.maximum(x, 1e-12).astype(np.float32))[0])
+        return np.mean(lps)
+
+    zero = np.zeros(n - 1, np.float32)
+    assert mean_lp(got["mu"], got["omega"], got["alpha"]) > mean_lp(zero, zero, zero) + 100
+    with pytest.raises(SystemExit):
+        prep.main(["--salmon", d, "-o", out_file])
