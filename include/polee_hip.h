@@ -388,9 +388,9 @@ polee_status polee_approx_splicing_moments(polee_approx *ap, const int32_t *feat
  * x_scale [n]; x [S][n]. */
 polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap_or_null, int32_t S, int32_t F, int32_t n,
                                      const float *design, const float *x_init, const float *x_init_mean_or_null,
-                                     const float *sample_scales, const float *hinges_or_null, int32_t degree, float bandwidth, float x_bias_loc0,
-                                     float x_bias_scale0, int use_distortion, float scale_penalty,
-                                     int use_point_estimates, polee_regression **out);
+                                     const float *sample_scales, const float *hinges_or_null, int32_t degree,
+                                     float bandwidth, float x_bias_loc0, float x_bias_scale0, int use_distortion,
+                                     float scale_penalty, int use_point_estimates, polee_regression **out);
 void polee_regression_destroy(polee_regression *reg);
 int64_t polee_regression_num_params(const polee_regression *reg);
 int64_t polee_regression_num_noise(const polee_regression *reg);
