@@ -511,19 +511,25 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
 }
 
 // the global horseshoe scale and the distortion / mean-variance coefficients (one wave; lane i takes coefficient i)
-__global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *p, const float *eps, const float *small,
-                                                        const float *stats, const double *loss_acc, float *g,
-                                                        float *loss_out)
+// (it leaves every accumulator it has read at zero for the next step: no memsets between steps)
+__global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *p, const float *eps, float *small,
+                                                        float *stats, double *loss_acc, float *g, float *loss_out)
 {
     const int lane = threadIdx.x, nred = v.num_red();
     auto slots = [&](int i) {  // sum of accumulator i over its copies
         float t = 0.0f;
-        for (int k = 0; k < REG_SLOTS; ++k) t += small[(int64_t)k * nred + i];
+        for (int k = 0; k < REG_SLOTS; ++k) {
+            t += small[(int64_t)k * nred + i];
+            small[(int64_t)k * nred + i] = 0.0f;
+        }
         return t;
     };
     double loss = 0.0;
-    if (lane < REG_SLOTS)  // the columns' terms + the samples' terms (summed over ranks)
+    if (lane < REG_SLOTS) {  // the columns' terms + the samples' terms (summed over ranks)
         loss = loss_acc[lane] + (double)stats[(int64_t)(v.F + 2) * v.n + lane];
+        loss_acc[lane] = 0.0;
+        stats[(int64_t)(v.F + 2) * v.n + lane] = 0.0f;
+    }
     if (lane == 0) {
         const float S1 = slots(0);
         const SpDraw gv = sp_draw(p[0], p[1], eps[0]), gn = sp_draw(p[2], p[3], eps[1]);
@@ -632,7 +638,7 @@ polee_status reg_data_pass(polee_regression *r)
         } else if (r->ap)
             POLEE_TRY(polee_approx_logprob_device(r->ap, r->d_x.p, r->d_lp.p, r->d_glik.p));
     }
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - REG_SLOTS, 0, sizeof(float) * REG_SLOTS, st));
+    // (the loss slots of d_stats, d_acc and d_small are zero here: reg_finish_kernel clears what it reads)
     const float *lp = (!v.point && (r->ap || r->d_lik_loc.p || r->gene_ap)) ? r->d_lp.p : nullptr;
     const dim3 grid((unsigned)ceil_div(v.n, REG_BLOCK));
 #define POLEE_REG_DATA(FT, DT)                                                                                          \
@@ -658,8 +664,6 @@ polee_status reg_prior_pass(polee_regression *r)
     polee_ctx *ctx = r->ctx;
     const RegView &v = r->v;
     hipStream_t st = ctx->stream;
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_acc.p, 0, sizeof(double) * REG_SLOTS, st));
-    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_small.p, 0, sizeof(float) * REG_SLOTS * v.num_red(), st));
     const dim3 grid((unsigned)ceil_div(v.n, REG_BLOCK));
 #define POLEE_REG_COLS(FT, DT)                                                                                     \
     hipLaunchKernelGGL((reg_cols_kernel<FT, DT>), grid, dim3(REG_BLOCK), 0, st, v, r->d_p.p, r->d_eps.p, r->d_W.p, \
@@ -815,6 +819,9 @@ polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S
         if (e == hipSuccess) e = hipMemsetAsync(r->d_glik.p, 0, sizeof(float) * sn, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_lse.p, 0, sizeof(float) * S, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(r->d_lse_acc.p, 0, sizeof(float) * S, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_acc.p, 0, sizeof(double) * REG_SLOTS, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_small.p, 0, sizeof(float) * REG_SLOTS * v.num_red(), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(r->d_stats.p, 0, sizeof(float) * r->num_stats(), ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = fail(ctx, POLEE_ERR_HIP, "memset failed: %s", hipGetErrorString(e));
     }
@@ -962,8 +969,14 @@ polee_status polee_debug_regression_data_pass(polee_regression *r, const float *
     if (!r || !noise || !stats) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(r->ctx));
     POLEE_TRY(reg_fill_noise(r, noise, 0, 0, false));
+    POLEE_HIP_TRY(r->ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - REG_SLOTS, 0, sizeof(float) * REG_SLOTS,
+                                         r->ctx->stream));
     POLEE_TRY(reg_data_pass(r));
-    return r->d_stats.download(r->ctx, stats, (size_t)r->num_stats());
+    POLEE_TRY(r->d_stats.download(r->ctx, stats, (size_t)r->num_stats()));
+    // no finish kernel follows a bare data pass: leave the loss slots clean for the next step
+    POLEE_HIP_TRY(r->ctx, hipMemsetAsync(r->d_stats.p + r->num_stats() - REG_SLOTS, 0, sizeof(float) * REG_SLOTS,
+                                         r->ctx->stream));
+    return POLEE_OK;
 }
 
 polee_status polee_debug_regression_prior_pass(polee_regression *r, const float *stats, float *loss, float *grad)
