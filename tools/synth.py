@@ -15,7 +15,12 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB):
-            subprocess.check_call(["make", "-s", "-C", _HERE])
+            # (several ranks of one job may arrive here together: one builds, the others wait on the lock)
+            import fcntl
+            with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if not os.path.exists(_LIB):
+                    subprocess.check_call(["make", "-s", "-C", _HERE])
         _lib = C.CDLL(_LIB)
         _lib.synth_create.restype = C.c_void_p
         _lib.synth_count.restype = C.c_int64
