@@ -589,6 +589,8 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         // operand reads: for the narrow stream (one 16-row tile) both phases' reads are issued together up front;
         // the wide stream reads per group of 4 steps / per tile, to stay inside the register budget
         constexpr bool WIDE = NT > 1;
+        // (with multiplicities the ks row is read after phase 1; the debug switch that skips phase 1 skips the reads)
+        const bool EARLY_REFILL = !WIDE && !HAS_KS && !(dbg & 4);
         auto read_tile = [&](int mt, f32x4 (&dst)[4]) {
             const int t = 16 * mt + tt;  // rows t >= w read whatever follows in the ring: their D2 rows are never used
             const char *vrow = ring_at(256u + (uint32_t)t * 256u);
@@ -613,6 +615,16 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
                             const int t = min(4 * st + q, w - 1);  // rows >= w: B is 0 there, A only has to be finite
                             av1[u] = *reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)t * 256u) + ((tt + t) & 15) * 16);
                         }
+                    }
+                    if (EARLY_REFILL) {
+                        // narrow stream: every operand of the slice is now on its way into registers; once the LDS
+                        // reads have landed the slice's ring bytes are free, so the DMA for the pieces behind it is
+                        // issued BEFORE the two MFMA phases instead of after them
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        pos += bytes;
+                        pos_r += bytes;
+                        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+                        refill(min(npieces, (int)(pos >> 10) + RP));
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -671,10 +683,12 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         STAMP(5);  // phase 2
 
         // the slice is consumed: refill the ring behind it
-        pos += bytes;
-        pos_r += bytes;
-        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
-        refill(min(npieces, (int)(pos >> 10) + RP));
+        if (!EARLY_REFILL) {
+            pos += bytes;
+            pos_r += bytes;
+            pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+            refill(min(npieces, (int)(pos >> 10) + RP));
+        }
         STAMP(6);  // refill
     }
     if (pend_w != 0) flush();
