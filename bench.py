@@ -44,6 +44,18 @@ def algorithmic_bytes_per_pass(nnz, m, n, K):
     return nnz * 8 + (m + 1) * 4 + K * n * 8
 
 
+def emit(out):
+    """The ONE JSON line, as the last thing on stdout: native libraries (RCCL's version banner) write through C stdio,
+    whose buffer would otherwise be flushed after Python's at exit."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def regression_bench(args):
     """`--workload c3|c4`: the regression model's variational step (models/polee_regression.py fit) on one GPU:
     BASELINE configs 3 / 4's per-GPU share, synthetic approximation parameters (mu ~ N(0,2),
@@ -72,7 +84,7 @@ def regression_bench(args):
     t0 = time.perf_counter()
     trace = reg.fit(args.steps, seed=args.seed, return_trace=True)[-1]  # synchronises before returning
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
+    emit(({
         "metric": "regression steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -277,7 +289,7 @@ def main():
         out["detail"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
 
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
