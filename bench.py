@@ -56,44 +56,139 @@ def emit(out):
     print(json.dumps(out), flush=True)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (one process per GPU, RCCL) before this process has touched the GPU, relay the
+    child's output and exit with its return code.  (No os.exec*: a process is never replaced here.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")  # re-emitted below as the LAST line
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc != 0 or line is not None else 1)
+
+
+def init_ranks():
+    """(world, rank, local_rank, dist-or-None, backend).  Test hooks (a box with fewer GPUs than ranks):
+    POLEE_BENCH_BACKEND=gloo keeps the bookkeeping collectives on the CPU, POLEE_BENCH_FORCE_DEVICE=<id> puts every
+    rank on that GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("POLEE_BENCH_BACKEND", "nccl")
+    if "POLEE_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["POLEE_BENCH_FORCE_DEVICE"])
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend)
+        dist = dist_mod
+    return world, rank, local_rank, dist, backend
+
+
 def regression_bench(args):
-    """`--workload c3|c4`: the regression model's variational step (models/polee_regression.py fit) on one GPU:
-    BASELINE configs 3 / 4's per-GPU share, synthetic approximation parameters (mu ~ N(0,2),
-    omega ~ N(-1,1), alpha ~ N(0,.3)), device RNG.  A step = one draw of every latent, loss + gradient, Adam."""
+    """`--workload c3|c4`: the regression model's variational step (models/polee_regression.py fit): synthetic
+    approximation parameters (mu ~ N(0,2), omega ~ N(-1,1), alpha ~ N(0,.3)), device RNG.  A step = one
+    draw of every latent, loss + gradient, Adam.  C3 = BASELINE configs[2]: S = 6 samples in total, sharded over the
+    ranks ("strong"); C4 = configs[3]: 8 samples per GPU ("weak", S = 8 x ranks).  With more than one rank the samples
+    are sharded (cohort.shard_regression_inputs) and the (F+2) n sufficient statistics of the shared parameters are
+    all-reduced once per step over RCCL (polee_regression_set_comm)."""
     import numpy as np
+    world, rank, local_rank, dist, backend = init_ranks()
     import polee_amd as P
+    from polee_amd.cohort import Ranks, shard_regression_inputs
     from tools import synth
+    ranks = Ranks(dist, "cuda" if dist is not None and backend == "nccl" else None)
     n, S, F = WORKLOADS[args.workload]
-    rng = np.random.default_rng(args.seed)
+    weak = args.workload == "c4"
+    if weak:
+        S *= world
+    rng = np.random.default_rng(args.seed)  # every rank draws the whole cohort's inputs and keeps its rows
     smp = synth.make_sample(n, 1000000, 8.0, 1)
     parents, js = synth.make_tree(smp["gene"], 1)
     li, ri, fi = P.make_inverse_ptt_params(parents, js)
-    ctx = P.Context(0)
+    ctx = P.Context(local_rank if world > 1 else 0)
     vars_ = dict(efflen=np.tile(smp["effective_lengths"], (S, 1)).astype(np.float32),
                  la_mu=rng.normal(0, 2, (S, n - 1)).astype(np.float32),
                  la_sigma=np.exp(rng.normal(-1, 1, (S, n - 1))).astype(np.float32),
                  la_alpha=rng.normal(0, .3, (S, n - 1)).astype(np.float32), left_index=li[None], right_index=ri[None],
                  leaf_index=fi[None])
-    lik = P.RNASeqApproxLikelihood(vars_, ctx=ctx)
-    x0 = np.log(np.maximum(lik.sample(seed=1), 1e-12)).astype(np.float32)
     design = np.zeros((S, F), np.float32)
     design[:, 0] = 1
     design[S // 2:, 1] = 1
-    reg = P.RNASeqTranscriptLinearRegression(lik, x0, design, P.estimate_sample_scales(x0), True, 1.0, False, ctx=ctx)
+    # initial values: log of one draw of every sample's approximation (estimate.jl:436-455 uses the mean of 30)
+    x0 = np.empty((S, n), np.float32)
+    for s0 in range(0, S, 8):
+        sl = slice(s0, min(S, s0 + 8))
+        v = {k: (a[sl] if a.shape[0] == S and S > 1 else a) for k, a in vars_.items()}
+        x0[sl] = np.log(np.maximum(P.RNASeqApproxLikelihood(v, ctx=ctx).sample(seed=1 + s0), 1e-12))
+    scales = P.estimate_sample_scales(x0)
+    comm = None
+    if world > 1:
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = P.Comm(ctx, world, rank, broadcast=bcast)
+        kw = shard_regression_inputs(vars_, x0, design, scales, world, rank)
+        lik = P.RNASeqApproxLikelihood(kw["vars"], ctx=ctx)
+        reg = P.RNASeqTranscriptLinearRegression(lik, kw["x_init"], kw["F_arr"], kw["sample_scales"], True, 1.0, False,
+                                                 ctx=ctx, comm=comm, x_init_mean=kw["x_init_mean"])
+    else:
+        lik = P.RNASeqApproxLikelihood(vars_, ctx=ctx)
+        reg = P.RNASeqTranscriptLinearRegression(lik, x0, design, scales, True, 1.0, False, ctx=ctx)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            if backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
+        ctx.synchronize()
+
     reg.fit(max(args.warmup, 1), seed=args.seed)
+    barrier()
     t0 = time.perf_counter()
     trace = reg.fit(args.steps, seed=args.seed, return_trace=True)[-1]  # synchronises before returning
-    elapsed = time.perf_counter() - t0
-    emit(({
-        "metric": "regression steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: regression step, S=%d samples x F=%d factors x n=%d transcripts, 15 hinges, "
-                               "likelihood on, device RNG" % (args.workload.upper(), S, F, n)},
-        "detail": {"loss_first": float(trace[0]), "loss_last": float(trace[-1]),
-                   "finite": bool(np.all(np.isfinite(trace))), "parameters": reg.num_params,
-                   "note": "latency / gather bound (SURVEY.md 8(d)): no roofline claim for this step"},
-    }))
+    barrier()
+    elapsed = ranks.max(time.perf_counter() - t0)
+    if rank == 0:
+        emit(({
+            "metric": "regression steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: regression step, S=%d samples x F=%d factors x n=%d transcripts, 15 hinges, "
+                                   "likelihood on, device RNG" % (args.workload.upper(), S, F, n),
+                       "parallelism": "samples sharded over %d GPU(s), %d on rank 0, one all-reduce of (F+2) n f32 "
+                                      "statistics per step" % (world, reg.num_samples) if world > 1 else "1 GPU"},
+            "detail": {"loss_first": float(trace[0]), "loss_last": float(trace[-1]),
+                       "finite": bool(np.all(np.isfinite(trace))), "parameters": reg.num_params,
+                       "note": "latency / gather bound (SURVEY.md 8(d)): no roofline claim for this step"},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -112,27 +207,26 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # nothing above this line touches the GPU
     if args.workload in ("c3", "c4"):
         return regression_bench(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # test hooks (a box with fewer GPUs than ranks): POLEE_BENCH_BACKEND=gloo keeps the bookkeeping collectives on the
-    # CPU, POLEE_BENCH_FORCE_DEVICE=<id> puts every rank on that GPU
-    backend = os.environ.get("POLEE_BENCH_BACKEND", "nccl")
-    if "POLEE_BENCH_FORCE_DEVICE" in os.environ:
-        local_rank = int(os.environ["POLEE_BENCH_FORCE_DEVICE"])
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist_mod.init_process_group(backend)
-        dist = dist_mod
+    world, rank, local_rank, dist, backend = init_ranks()
+    if os.environ.get("POLEE_BENCH_DRY") == "1":
+        # launch-path test hook for boxes without a GPU (tests/test_multiproc.py): rendezvous, barrier, max-over-ranks
+        # and the JSON relay only -- no fit runs and no rate is reported
+        from polee_amd.cohort import Ranks
+        ranks = Ranks(dist, None)
+        ranks.barrier()
+        t, seen = ranks.max(0.001 * (rank + 1)), int(ranks.sum(1))
+        if rank == 0:
+            emit({"metric": "approx-lik VI iters/sec", "value": None, "unit": "VI iters/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": seen,
+                  "slowest_rank_s": t})
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import polee_amd as P
     from polee_amd.cohort import Ranks, sample_seed
@@ -186,8 +280,9 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
         for c in ctxs:
             c.synchronize()
 
@@ -221,13 +316,20 @@ def main():
     # the whole pass is one launch (loglik_fused_kernel: three kinds of workgroups, one per row stream)
     bytes_dom = bytes_pass
     achieved = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile.sh): a capture is
+    # only valid for the workload / draws / tree it was taken at -- otherwise null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            cap = json.load(open(tpath))
+            if (cap.get("draws"), cap.get("tree"), cap.get("nnz")) == (K, args.tree, info["nnz"]):
+                traffic = cap.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # what the launch physically moves: the slice stream once + the x / g windows (dictionary entries x K x 4 B, each way)
+    phys_bytes = sum(info["stream_bytes_hbm"]) + 2 * 4 * K * info.get("dict_entries", 0)
+    phys = phys_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     out = {
         "metric": "approx-lik VI iters/sec",
@@ -258,6 +360,8 @@ def main():
             "kernel_ms_avg": kern_ms, "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_dom,
             "slice_stream_bytes_per_launch": sum(info["stream_bytes_hbm"]),
+            # the device layout is smaller than CSR, so the memory system itself runs at:
+            "physical_bytes_per_launch": phys_bytes, "physical_GBs": phys, "physical_frac": phys / HBM_PEAK_GBS,
             "stream_share_of_nnz": [v / max(info["nnz"], 1) for v in info["stream_nnz"]],
         },
         "detail": {
@@ -276,6 +380,7 @@ def main():
         so = O.Sample(m, n, colptr, rowval, nzval)
         to = O.PTT(parents, js)
         t_prep = time.time() - t0
+        O.set_num_threads(O.physical_cores())  # the reference's default: one thread per PHYSICAL core (polee:8-12)
         t0 = time.time()
         O.approximate_likelihood(so, to, smp["effective_lengths"], num_steps=args.cpu_steps, num_mc=K,
                                  seed=args.seed)

@@ -422,3 +422,24 @@ def approx_gene_log_prob(x_gene, x_iso, gene_of, efflens, mu, sigma, alpha, left
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def set_num_threads(t):
+    lib().oracle_set_num_threads(int(t))
+
+
+def physical_cores():
+    """Physical cores of this host (distinct (socket, core) pairs of /proc/cpuinfo): the reference's default thread
+    count (polee:8-12)."""
+    pairs, phys, n = set(), "0", 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                n += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+    except OSError:
+        pass
+    return len(pairs) or n or (os.cpu_count() or 1)

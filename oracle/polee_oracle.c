@@ -1040,6 +1040,17 @@ int oracle_num_threads(void)
 #endif
 }
 
+/* The reference runs on the PHYSICAL cores by default (polee:8-12 sets JULIA_NUM_THREADS from lscpu's
+ * cores-per-socket x sockets); bench.py's cpu_baseline leg sets the same count here. */
+void oracle_set_num_threads(int t)
+{
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 /* src/polee_gene_expression.py:14-90 RNASeqGeneApproxLikelihoodDist: transcript log-expression from gene-level
  * and within-gene isoform log-expression, as the reference composes it (f32, no max shift: :30-60):
  *   x_exp[i] = exp(x_iso[i]) * (exp(x_gene[g]) / sum_{i' in g} exp(x_iso[i']));  x = log(x_exp)

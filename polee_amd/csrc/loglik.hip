@@ -800,14 +800,12 @@ static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g,
     const size_t lds = (size_t)fused_ring_total<K>() + ((size_t)2 * lcap * K + 2) * sizeof(float) +
                        4 * sizeof(double);
     const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
-    static bool attr_set = false;
-    if (!attr_set) {  // (a 1024-transcript dictionary at K = 8 needs 64 KiB of windows)
-        (void)hipFuncSetAttribute((const void *)loglik_fused_kernel<K, LP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  128 * 1024);  // (this kernel also has a little static LDS)
-        (void)hipGetLastError();
-        attr_set = true;
+    // The attribute belongs to (device, kernel instance): set before every launch (a host-side table write), so that a
+    // second context on another GPU of the same process gets it too; checked.
+    if (lds > 64 * 1024 || !h.big_tiles.empty() || no_ring) {
+        const hipError_t ea = hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (ea != hipSuccess) return ea;
     }
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     if (!no_ring && tiles_a > 0 && lds <= 64 * 1024) {

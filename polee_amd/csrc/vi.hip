@@ -647,7 +647,6 @@ polee_status polee_vi_eval_gradients(polee_vi *vi, float *xs, double *x_grad, do
         POLEE_TRY(vi->d_rows.download(ctx, rs.data(), K * 2));
         for (size_t d = 0; d < K; ++d) ladj[d] = el[d * 2] + el[d * 2 + 1] + rs[d * 2 + 1];
     }
-    // the hook must not leave a stale flag behind
     return POLEE_OK;
 }
 

@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys,
     if (mu_grad_out) mu_grad_out[k] = mu_g;
     if (omega_grad_out) omega_grad_out[k] = om_g;
     if (alpha_grad_out) alpha_grad_out[k] = al_g;
-    if (!(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
+    // (the gradient test hook, apply == 0, reports its gradients to the caller and must not leave a flag behind for a
+    // step that was never applied)
+    if (apply && !(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
     if (apply) {
         float p = muk, mm = m_mu[k], vv = v_mu[k];
         adam_one(p, mm, vv, mu_g, adam, adam.max_mu);

@@ -1,5 +1,6 @@
-"""Full-size (BASELINE.json configs[1]: n=200 000 x m=30 000 000, ~240 M nnz) checks on the GPU through
-size-independent properties -- the oracle cannot visit this size in seconds."""
+"""Full-size (BASELINE.json configs[1]: n=200 000 x m=30 000 000, ~240 M nnz; configs[4]: m = 150 M) checks on the GPU
+through size-independent properties (homogeneity, scaling, round trips, a second kernel over the same slices).  The
+comparison with the CPU oracle at these sizes is tests/test_gpu_configs.py."""
 import ctypes as C
 
 import numpy as np
