@@ -137,11 +137,13 @@ typedef struct {
     int32_t max_row_nnz;
     int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
     /* the three row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):   */
-    /* [0] uniform slices, sets of <= 18 transcripts; [1] uniform, 19..28; [2] everything else */
+    /* [0] uniform slices, sets of <= 16 transcripts; [1] uniform, 17..32; [2] everything else */
     int64_t stream_rows[3];  /* fragments                                               */
     int64_t stream_nnz[3];   /* non-zeros of X                                          */
     int64_t stream_tiles[3]; /* workgroups per launch                                   */
     int64_t stream_bytes_hbm[3]; /* bytes of the slice stream each launch reads          */
+    int64_t dict_entries;    /* entries of all tile dictionaries: x is gathered into, and the gradient flushed */
+                             /* from, one window of dict_entries x K floats per pass                           */
 } polee_loglik_info;
 polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info);
 

@@ -54,7 +54,7 @@ class LoglikInfo(C.Structure):
                 ("num_tiles", C.c_int64), ("padded_nnz", C.c_int64), ("device_bytes", C.c_int64),
                 ("stream_bytes", C.c_int64), ("num_empty_rows", C.c_int64), ("max_row_nnz", C.c_int32),
                 ("max_tile_cols", C.c_int32), ("stream_rows", C.c_int64 * 3), ("stream_nnz", C.c_int64 * 3),
-                ("stream_tiles", C.c_int64 * 3), ("stream_bytes_hbm", C.c_int64 * 3)]
+                ("stream_tiles", C.c_int64 * 3), ("stream_bytes_hbm", C.c_int64 * 3), ("dict_entries", C.c_int64)]
 
 
 class PsellView(C.Structure):

@@ -110,6 +110,10 @@ struct PsellArgs {
     // transposed copy of the mixed tiles (PsellHost::tdata)
     const uint8_t *tdata;
     const uint32_t *tgroup_off, *ttile_group;
+    // the persistent streaming kernel
+    int tiles_a1;           // tiles [0, tiles_a1): stream A1, [tiles_a1, tiles_a): A2
+    const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
+    const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
 };
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -350,25 +354,31 @@ __device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrow
     }
 }
 
-// ---- stream A: uniform slices, LDS-DMA streamed, transposed accumulation --------------------------------
-// Every slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs
-// of consecutive slices with the same set are marked by the builder.  For such a slice
-//     s[r][k]  = sum_t V[r][t] x[c_t][k]          (phase 1, lane = fragment r; x rows are LDS broadcasts)
-//     G[t][k] += sum_r V[r][t] ks_r / s[r][k]     (phase 2, lane = one (t, k) pair)
-// Phase 2 is the transpose of phase 1.  Instead of summing 64 lanes with DPP, the weights W[k][r] are
-// written to LDS and every lane walks the 64 fragments for its own (t, k) with 16-byte LDS reads of
-// V[t][.] (already in the ring) and W[k][.]; the partial G stays in ONE register per lane for the whole
-// run and is added to the tile window once, by its owner, when the run ends.  No cross-lane reduction,
-// ~60 VGPRs, so occupancy is set by LDS (ring size), not registers.
+// ---- streams A and B in ONE persistent launch ---------------------------------------------------------------
+// A uniform slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs of
+// consecutive slices with the same set are marked by the builder.  For such a slice V[t][r] (w x 64):
+//     S[r][k]  = sum_t V[t][r] x[c_t][k]          (phase 1)
+//     G[t][k] += sum_r V[t][r] ks_r / S[r][k]     (phase 2 = the transpose of phase 1)
+// Both run on the matrix cores (exact-f32 MFMA), the weights never leave the registers, and the partial G stays
+// in registers for the whole run; it is added to the tile's LDS window when the run ends.
 //
-// Streaming: each wave owns a contiguous byte range of the slice stream (its quarter of the tile) and
-// pulls it through a private LDS ring of RP KiB with `global_load_lds_dwordx4` (1 KiB per
-// wave-instruction, no VGPR destination), RP pieces ahead; HBM sees every byte of X exactly once.
+// Streaming: each wave owns a contiguous byte range of the tile's slice stream and pulls it through a private LDS
+// ring with `global_load_lds_dwordx4` (1 KiB per wave-instruction, no VGPR destination), ring-size ahead; HBM sees
+// every byte of X exactly once.
+//
+// Persistence: the grid is (workgroups per CU) x (CUs); every workgroup walks its own column of a static schedule
+// (sched[pos], pos = block + round * grid: tiles dealt in snake order of their cost, small tiles spread between the
+// large ones).  While a tile streams, everything the NEXT tile needs arrives in the background by LDS-DMA: its x
+// window (one contiguous piece of xwin, gathered once per pass by xwin_gather_kernel), the transcript ids of its
+// dictionary (for the flush) and the slice offsets of each wave's share; a wave that has finished its slices
+// starts the next tile's ring before the workgroup's barrier.  A tile therefore has no dependent global latency in
+// front of its first slice; the counted `s_waitcnt vmcnt(N)` of the slice loop account for these extra operations.
 #ifndef POLEE_DMA_POLICY
 #define POLEE_DMA_POLICY " nt"  // X is read once per pass: non-temporal keeps it from evicting x / g lines
 #endif
-__device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst)
+__device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst_any)
 {
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" POLEE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
@@ -376,34 +386,75 @@ __device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst)
         : "v"(gsrc_lane), "s"(lds_dst)
         : "memory");
 }
+// the same with the default cache policy (x windows: written by the previous kernel, re-read by nobody else)
+__device__ inline void dma_1k_keep(const void *gsrc_lane, uint32_t lds_dst_any)
+{
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+// 4 bytes per lane: 64 arbitrary dwords -> 256 contiguous LDS bytes
+__device__ inline void dma_256(const void *gsrc_lane, uint32_t lds_dst_any)
+{
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+__device__ inline uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const char *)p);
+}
 
 // waits until at most `allowed` of this wave's vector-memory operations are outstanding (rounded down
 // to an encodable step: waiting for fewer outstanding operations is always safe)
 __device__ inline void wait_vm_outstanding(int allowed)
 {
-    if (allowed >= 10)
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (allowed >= 8)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (allowed >= 6)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (allowed >= 5)
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (allowed >= 4)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (allowed >= 3)
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (allowed >= 2)
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (allowed >= 1)
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (allowed >= 8) {
+        if (allowed >= 14)
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (allowed >= 12)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (allowed >= 10)
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (allowed >= 4) {
+        if (allowed >= 7)
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else if (allowed >= 6)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (allowed >= 5)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        if (allowed >= 3)
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (allowed >= 2)
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (allowed >= 1)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its vector-memory queue
+// (__syncthreads() would drain the LDS-DMA ring that has just been started for the next tile)
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 #ifdef POLEE_STAMPS
-// diagnostic build only: where does a wave of the uniform kernel spend its cycles?
-__device__ unsigned long long g_stamps[16];
+// diagnostic build only: where does a wave of the streaming kernel spend its cycles?
+__device__ unsigned long long g_stamps[24];
 #define STAMP(i)                                                          \
     do {                                                                  \
         const unsigned long long now__ = __builtin_amdgcn_s_memtime();    \
@@ -413,94 +464,45 @@ __device__ unsigned long long g_stamps[16];
 #else
 #define STAMP(i) do { } while (0)
 #endif
+constexpr int NSTAMP = 16;  // (diagnostic build)
 
-// One tile of a uniform stream.  RB = ring bytes per active wave, NW = waves that own slices (the others only
-// take part in the staging and the barriers), WMAXR = widest transcript set of the stream.
-template <int K, uint32_t RB, int NW, int WMAXR, bool WANT_LP, bool HAS_KS>
-__device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, const char *rings,
-                                         float *xw, float *gw, double *lp_red)
+// what a wave knows about its share of the current uniform tile
+struct WaveStream {
+    uint32_t ent;         // slice offset (+ flags) of slice sb + lane, one per lane
+    int nsl;              // slices owned by this wave
+    int npieces;          // 1 KiB pieces of its byte range
+    int issued, islot;    // pieces requested so far; ring slot of the next one
+    int primed;           // pieces requested before the tile's loop started
+    const uint8_t *gsrc;  // start of the byte range + lane * 16
+};
+
+template <uint32_t RB>
+__device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target)
 {
     constexpr int RP = (int)(RB / 1024u);
-    const uint8_t *__restrict__ data = A.data;
-    const uint32_t *__restrict__ slice_off = A.slice_off;
-    const uint32_t *__restrict__ tile_slice = A.tile_slice;
-    const uint32_t *__restrict__ tile_dict = A.tile_dict;
-    const uint32_t *__restrict__ dict = A.dict;
-    const float *__restrict__ x = A.x;
-    float *__restrict__ g = A.g;
-    double *__restrict__ lp = A.lp;
-
-#ifdef POLEE_STAMPS
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t d0 = tile_dict[tile];
-    const int L = (int)(tile_dict[tile + 1] - d0);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s0 = tile_slice[tile], s1 = tile_slice[tile + 1];
-    // each active wave takes a contiguous share of the tile's slices: runs stay inside one wave
-    const uint32_t per = (s1 - s0 + (uint32_t)NW - 1u) / (uint32_t)NW;
-    const uint32_t sb = wave < NW ? min(s0 + (uint32_t)wave * per, s1) : s1;
-    const uint32_t se = wave < NW ? min(sb + per, s1) : s1;
-
-    // slice offsets (+ flags in the top bits) of this wave's range, one per lane: a wave owns at most 63
-    // slices (tiles hold <= 64).  They are read with v_readlane inside the loop, so that the loop contains
-    // no compiler-visible memory load: a compiler-inserted s_waitcnt vmcnt(0) there would drain the
-    // LDS-DMA prefetch queue on every slice.
-    const uint32_t ent = slice_off[min(sb + (uint32_t)lane, se)];
-    // start streaming this wave's byte range before anything else
-    const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ent, 0) & PSELL_OFF_MASK;
-    const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)(se - sb)) & PSELL_OFF_MASK;  // 128-byte units
-    const int npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
-    const uint8_t *gsrc = data + (size_t)cb * 128 + lane * 16;
-    const char *ring = rings + (wave < NW ? wave : 0) * RB;
-    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(uintptr_t)(__attribute__((address_space(3))) const char *)ring);
-    int issued = 0, islot = 0;
-    auto refill = [&](int target) {
-        for (; issued < target; ++issued) {
-            dma_1k(gsrc + (size_t)issued * 1024, ring_lds + (uint32_t)islot * 1024u);
-            islot = islot + 1 == RP ? 0 : islot + 1;
-        }
-    };
-    refill(min(npieces, RP));
-
-    // stage the tile window: x[dict[l]][k] -> LDS, zero the accumulators.  Loads are issued for the whole
-    // window before any is consumed (two dependent HBM/L2 latencies per tile instead of 2 per 256 entries)
-    {
-        constexpr int NB = (PSELL_TILE_COLS_TARGET * K + 255) / 256;  // covers every tile built with the soft cap
-        float xv[NB];
-        uint32_t dv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = threadIdx.x + 256 * b;
-            dv[b] = i < L * K ? dict[d0 + i / K] : 0u;
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = threadIdx.x + 256 * b;
-            xv[b] = i < L * K ? x[(size_t)dv[b] * K + (i - (i / K) * K)] : 0.0f;
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int i = threadIdx.x + 256 * b;
-            if (i < L * K) {
-                xw[i] = xv[b];
-                gw[i] = 0.0f;
-            }
-        }
-        for (int i = threadIdx.x + 256 * NB; i < L * K; i += 256) {  // tiles with a larger dictionary (very long rows)
-            const int l = i / K, k = i - l * K;
-            xw[i] = x[(size_t)dict[d0 + l] * K + k];
-            gw[i] = 0.0f;
-        }
+    for (; ws.issued < target; ++ws.issued) {
+        dma_1k(ws.gsrc + (size_t)ws.issued * 1024, ring_lds + (uint32_t)ws.islot * 1024u);
+        ws.islot = ws.islot + 1 == RP ? 0 : ws.islot + 1;
     }
-    __syncthreads();
-    STAMP(0);  // prologue: first DMAs, window staging, barrier
+}
 
-    // Both phases run on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate -- bit-for-bit an
-    // fmaf chain); lane l = (tt = l & 15, q = l >> 4).  A slice is a (w x 64) block V[t][r]:
+// The slice loop of one wave over its share of a uniform tile.  RB = ring bytes per active wave, WMAXR = widest
+// transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
+// the first refill (the previous tile's flush, the next tile's prefetch): they are younger than the primed pieces
+// and older than every other piece, so only waits for primed pieces have to allow for them.
+template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS>
+__device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
+                                      double &lpacc, int dbg
+#ifdef POLEE_STAMPS
+                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+#endif
+)
+{
+    constexpr int RP = (int)(RB / 1024u);
+    const int lane = threadIdx.x & 63;
+    const uint32_t ring_lds = lds_addr(ring);
+
+    // lane l = (tt = l & 15, q = l >> 4).  A slice is a (w x 64) block V[t][r]:
     //   phase 1   S[r][k] = sum_t V[t][r] x[c_t][k]      M = r (4 tiles: tile e holds rows 4 i + e), N = k, inner = t
     //       A[i][kk=q] = V[4 step + q][4 i + e]  -- one 16-byte LDS read per step feeds the 4 row tiles
     //       B[kk=q][tt] = x[c_{4 step + q}][tt]  -- constant over a run, kept in registers (xq)
@@ -516,7 +518,6 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
     constexpr int NT = (WMAXR + 15) / 16;  // 16-row tiles of transcripts (phase 2)
     constexpr int NS = (WMAXR + 3) / 4;    // steps of 4 transcripts (phase 1)
     const int tt = lane & 15, q = lane >> 4;
-    double lpacc = 0.0;        // draw tt, fragments 16 q .. 16 q + 15 of every slice
     f32x4 acc0[NT], acc1[NT];  // two accumulation chains per tile (dependent MFMA latency 40 > issue 32)
     uint2 colq[NT];            // tile-local ids of transcripts 16 mt + 4 q + (0..3) of the current run, 16 bit each
     float xq[NS];              // x[c_{4 step + q}][tt] of the current run
@@ -548,10 +549,9 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
 
     uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
     uint32_t pos_r = 0;  // pos modulo the ring size
-    for (uint32_t s = sb; s < se; ++s) {
-        const int si = (int)(s - sb);
-        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent, si);
-        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ent, si + 1);
+    for (int si = 0; si < ws.nsl; ++si) {
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
         const uint32_t units = off_next - off;
@@ -559,14 +559,14 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
         const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
         STAMP(1);  // slice bookkeeping
-        wait_vm_outstanding(issued - (int)((pos + bytes + 1023u) >> 10));
+        {
+            const int need = (int)((pos + bytes + 1023u) >> 10);
+            wait_vm_outstanding(ws.issued - need + (need <= ws.primed ? extras : 0));
+        }
         STAMP(2);  // waiting for the DMA
         auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
             uint32_t a = pos_r + rel;
-            if ((RB & (RB - 1)) == 0)
-                a &= RB - 1;
-            else
-                a = a >= RB ? a - RB : a;
+            a = a >= RB ? a - RB : a;
             return ring + a;
         };
         if (pend_w != 0 && !(flags & 2)) flush();
@@ -624,7 +624,7 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
                         pos += bytes;
                         pos_r += bytes;
                         pos_r = pos_r >= RB ? pos_r - RB : pos_r;
-                        refill(min(npieces, (int)(pos >> 10) + RP));
+                        ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -684,160 +684,442 @@ __device__ inline void uniform_tile_body(const PsellArgs &A, int tile, int dbg, 
 
         // the slice is consumed: refill the ring behind it
         if (!EARLY_REFILL) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             pos += bytes;
             pos_r += bytes;
             pos_r = pos_r >= RB ? pos_r - RB : pos_r;
-            refill(min(npieces, (int)(pos >> 10) + RP));
+            ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
         }
         STAMP(6);  // refill
     }
     if (pend_w != 0) flush();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(7);  // final flush
-    __syncthreads();
-    STAMP(8);  // waiting for the other waves of the workgroup
-    if (!(dbg & 1))
-        for (int i = threadIdx.x; i < L * K; i += 256) {
-            const int l = i / K, k = i - l * K;
-            const float v = gw[i];
-            if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
+}
+
+// sweep 1 + sweep 2 of one mixed (stream B) tile inside the persistent kernel; the tile's x window is in LDS (xw),
+// gw is zero on entry; W rows live in the ring area (no ring is active while a mixed tile runs).
+template <int K, bool WANT_LP, bool HAS_KS>
+__device__ inline void mixed_stream(const PsellArgs &A, int tile, uint32_t s0, uint32_t s1, float *wrows,
+                                    const float *xw, float *gw, double (&lpacc)[K])
+{
+    const uint8_t *__restrict__ data = A.data;
+    const uint32_t *__restrict__ slice_off = A.slice_off;
+    const float *__restrict__ slice_ks = A.slice_ks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (uint32_t s = s0 + wave; s < s1; s += 4) {
+        const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
+        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
+        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
+        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+        float sacc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        int t = 0;
+        for (; t + 8 <= w; t += 8) {
+            float v[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = vals[(t + u) * 64];
+                c[u] = cols[(t + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
         }
-    if (WANT_LP) {
-        // lane (tt, q) holds the share of draw tt: sum the four q, then one f64 atomic per wave and draw
-        double v = lpacc;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lane < K) atomicAdd(lp + lane, v);
+        {  // remainder (< 8): loads predicated, all in flight together
+            float v[8];
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = t + u < w;
+                v[u] = live ? vals[(t + u) * 64] : 0.0f;
+                c[u] = live ? (int)cols[(t + u) * 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
+        }
+        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
+        float *wr = wrows + ((size_t)(s - s0) * 64 + lane) * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wr[k] = fast_weight(ksv, sacc[k]);
+            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
+        }
     }
-#ifdef POLEE_STAMPS
-    STAMP(9);  // global flush
-    if (lane == 0) {
-        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
-        atomicAdd(&g_stamps[10], (unsigned long long)(se - sb));
-        atomicAdd(&g_stamps[11], 1ull);
+    __syncthreads();
+
+    const int tb = tile - A.tiles_a;
+    const uint32_t g0 = A.ttile_group[tb], g1 = A.ttile_group[tb + 1];
+    for (uint32_t gi = g0 + wave; gi < g1; gi += 4) {
+        const uint32_t off = A.tgroup_off[gi];
+        const int width = (int)((A.tgroup_off[gi + 1] - off - 1u) / 3u);
+        const uint8_t *base = A.tdata + (size_t)off * 128;
+        const int vc = reinterpret_cast<const uint16_t *>(base)[lane];
+        const float *vval = reinterpret_cast<const float *>(base + 128) + lane;
+        const uint16_t *vrow = reinterpret_cast<const uint16_t *>(base + 128 + (size_t)width * 256) + lane;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+        int e = 0;
+        for (; e + 8 <= width; e += 8) {
+            float v[8];
+            int r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = vval[(e + u) * 64];
+                r[u] = vrow[(e + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
+        }
+        {
+            float v[8];
+            int r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = e + u < width;
+                v[u] = live ? vval[(e + u) * 64] : 0.0f;
+                r[u] = live ? (int)vrow[(e + u) * 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (acc[k] != 0.0f) atomicAdd(gw + vc * K + k, acc[k]);
     }
-#endif
 }
 
 #ifdef POLEE_STAMPS
 extern "C" int polee_debug_read_stamps(unsigned long long *out)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
+    unsigned long long z[24] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) == hipSuccess ? 0 : 1;
 }
 #endif
 
-// LDS layout of the fused kernel: [32 KiB rings][xw: lcap*K][gw: lcap*K][lp_red: 4 doubles]
-constexpr uint32_t FUSED_RINGS = 24576u;  // 4 x 6 KiB (A1) or 2 x 12 KiB (A2)
-// the ring area also holds stream B's weight rows (16 slices x 64 fragments x K draws)
-template <int K>
-constexpr uint32_t fused_ring_total()
+// x window of every tile, contiguous: xwin[e * K + k] = x[dict[e]][k] for every dictionary entry e (tiles' dictionaries
+// start at multiples of 4 entries, so a tile's window starts 16-byte aligned).  One pass over 4 B x K per entry.
+__global__ void xwin_gather_kernel(const uint32_t *__restrict__ dict, const float *__restrict__ x, int K, int64_t total,
+                                   float *__restrict__ xwin)
 {
-    return PSELL_TILE_SLICES_B * 64 * K * 4 > (int)FUSED_RINGS ? (uint32_t)(PSELL_TILE_SLICES_B * 64 * K * 4) : FUSED_RINGS;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t e = i / K;
+    xwin[i] = x[(size_t)dict[e] * K + (int)(i - e * K)];
 }
 
-// The whole likelihood pass as ONE launch with three kinds of workgroups (block index ranges), so that the
-// three streams of X share the machine without cross-stream events:
-//   [0, nb_b)              stream B  (mixed slices; compute heavy, dispatched first)
-//   [nb_b, nb_b + nb_a2)   stream A2 (uniform, sets of 19..28 transcripts): 2 active waves x 16 KiB ring
-//   the rest               stream A1 (uniform, sets of <= 18 transcripts):   4 waves x 8 KiB ring
-// LDS (53 KiB) lets 3 workgroups share a CU; the backend is told so that it can keep LDS reads in flight
-// rather than minimise VGPRs.
+// LDS layout of the streaming kernel:
+//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2); stream B's weight rows][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][lp]
+constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
+template <int K>
+constexpr uint32_t stream_ring_total()
+{
+    return PSELL_TILE_SLICES_B * 64 * K * 4 > (int)STREAM_RINGS ? (uint32_t)(PSELL_TILE_SLICES_B * 64 * K * 4) : STREAM_RINGS;
+}
+template <int K>
+constexpr uint32_t stream_xw_bytes()  // whole 1 KiB pieces
+{
+    return ((uint32_t)PSELL_TILE_COLS_TARGET * K * 4u + 1023u) & ~1023u;
+}
+template <int K>
+constexpr uint32_t stream_lds_bytes()
+{
+    return stream_ring_total<K>() + 3u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 64u;
+}
+
 template <int K, bool WANT_LP, bool HAS_KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void loglik_fused_kernel(PsellArgs A, int tiles_a1, int tiles_a, int nb_b, int nb_a2, int dbg)
+void loglik_stream_kernel(PsellArgs A, int dbg)
 {
     extern __shared__ float lds[];
-    const char *rings = reinterpret_cast<const char *>(lds);
-    float *xw = lds + fused_ring_total<K>() / 4;
-    float *gw = xw + (size_t)A.lcap * K;
-    double *lp_red = reinterpret_cast<double *>(gw + (size_t)((A.lcap * K + 1) & ~1));
-    // The three kinds are interleaved over the grid (stream B and A2 workgroups are latency-bound chains of
-    // dependent loads; spread among the A1 workgroups their stalls are covered by A1's streaming).  They
-    // are spread over the first 7/8 of the grid so that the launch does not end on a slow workgroup.
-    const int b = blockIdx.x;
-    const int total = (int)gridDim.x;
-    const int span = max(max(total - total / 8, nb_b), 1);
-    auto before = [](int i, int count, int span_) -> int {  // how many of `count` blocks precede position i
-        return (int)min((long long)count, (long long)i * count / span_);
+    constexpr uint32_t XWB = stream_xw_bytes<K>();
+    char *const base = reinterpret_cast<char *>(lds);
+    char *const rings = base;
+    auto xw_of = [&](int b) -> float * { return reinterpret_cast<float *>(base + stream_ring_total<K>() + (uint32_t)b * XWB); };
+    float *const gw = reinterpret_cast<float *>(base + stream_ring_total<K>() + 2 * XWB);
+    auto ids_of = [&](int b) -> uint32_t * {
+        return reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + (uint32_t)b * (PSELL_TILE_COLS_TARGET * 4));
     };
-    const int nbb = before(b, nb_b, span);
-    if (before(b + 1, nb_b, span) > nbb) {
-        mixed_tile_body<K, WANT_LP, HAS_KS>(A, tiles_a + nbb, lds, xw, gw, lp_red);  // W rows live in the ring area
-        return;
+    uint32_t *const entb = reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t G = gridDim.x;
+    const PosDesc *__restrict__ sched = A.sched;
+    const uint8_t *__restrict__ xwin_b = reinterpret_cast<const uint8_t *>(A.xwin);
+#ifdef POLEE_STAMPS
+    unsigned long long st_acc[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    unsigned long long n_slices = 0, n_tiles = 0;
+#endif
+
+    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a ? 1 : 2); };
+    // this wave's share [sb, se) of an A tile's slices: a contiguous block, so that runs stay inside one wave
+    auto share = [&](int kind, uint32_t s0, uint32_t s1, uint32_t &sb, uint32_t &se) {
+        const uint32_t nw = kind == 0 ? 4u : 2u;
+        const uint32_t per = (s1 - s0 + nw - 1u) / nw;
+        sb = (uint32_t)wave < nw ? min(s0 + (uint32_t)wave * per, s1) : s1;
+        se = (uint32_t)wave < nw ? min(sb + per, s1) : s1;
+    };
+    // requests everything tile `t` needs besides its slice stream; returns the number of vector-memory operations
+    auto prefetch = [&](const PosDesc &t, int buf) -> int {
+        int cnt = 0;
+        const int npx = (int)((t.L * (uint32_t)K * 4u + 1023u) >> 10);
+        const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4 + lane * 16;
+        const uint32_t dst = lds_addr(xw_of(buf));
+        for (int p = wave; p < npx; p += 4) {
+            dma_1k_keep(src + (size_t)p * 1024, dst + (uint32_t)p * 1024u);
+            ++cnt;
+        }
+        if ((uint32_t)wave * 64u < t.L) {  // transcript ids of the dictionary (for the flush)
+            dma_256(A.dict + t.d0 + min((uint32_t)wave * 64u + (uint32_t)lane, t.L - 1u), lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
+            ++cnt;
+        }
+        const int kind = kind_of(t.tile);
+        if (kind < 2) {  // slice offsets of this wave's share, one per lane
+            uint32_t sb, se;
+            share(kind, t.s0, t.s1, sb, se);
+            dma_256(A.slice_off + min(sb + (uint32_t)lane, se), lds_addr(entb) + (uint32_t)wave * 256u);
+            ++cnt;
+        }
+        return cnt;
+    };
+    // after the prefetch has landed: this wave's stream state for tile `t`, ring started
+    WaveStream ws;
+    auto start_ring = [&](const PosDesc &t) {
+        const int kind = kind_of(t.tile);
+        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
+        if (kind >= 2) return;
+        uint32_t sb, se;
+        share(kind, t.s0, t.s1, sb, se);
+        ws.ent = entb[wave * 64 + lane];
+        ws.nsl = (int)(se - sb);
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
+        const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
+        ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
+        ws.gsrc = A.data + (size_t)cb * 128 + lane * 16;
+        if (kind == 0) {
+            ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, (int)(STREAM_RB1 / 1024u)));
+        } else {
+            ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, (int)(STREAM_RB2 / 1024u)));
+        }
+        ws.primed = ws.issued;
+    };
+
+    double lp_a = 0.0;  // uniform tiles: lane (tt, q) holds the share of draw tt
+    double lp_b[K];     // mixed tiles: lane = fragment
+#pragma unroll
+    for (int k = 0; k < K; ++k) lp_b[k] = 0.0;
+
+    PosDesc cur = sched[blockIdx.x];
+    if (cur.tile == POS_NONE) return;
+    for (int i = threadIdx.x; i < (int)(XWB / 4u); i += 256) gw[i] = 0.0f;
+    (void)prefetch(cur, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    start_ring(cur);
+    int young = 0;  // vector-memory operations issued after the ring was started (see uniform_stream)
+    lds_barrier();
+    int buf = 0;
+    for (uint32_t round = 0;; ++round) {
+        const PosDesc nxt = sched[blockIdx.x + (round + 1u) * G];
+        const bool more = nxt.tile != POS_NONE;
+        const int kind = kind_of(cur.tile);
+        if (more) young += prefetch(nxt, buf ^ 1);
+        STAMP(0);  // between tiles: prefetch issue
+        if (kind == 0) {
+            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw, lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                                             , st_acc, st_last
+#endif
+            );
+        } else if (kind == 1) {
+            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw, lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                                           , st_acc, st_last
+#endif
+            );
+        } else {
+            mixed_stream<K, WANT_LP, HAS_KS>(A, (int)cur.tile, cur.s0, cur.s1, reinterpret_cast<float *>(rings), xw_of(buf), gw, lp_b);
+        }
+#ifdef POLEE_STAMPS
+        n_slices += (unsigned long long)ws.nsl;
+        ++n_tiles;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also: the next tile's prefetch has landed)
+        STAMP(7);  // draining the queue after the last slice
+        young = 0;
+        // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
+        // of uniform tile); otherwise the ring area may still be in use by a slower wave
+        const bool early = more && kind < 2 && kind_of(nxt.tile) == kind;
+        if (early) start_ring(nxt);
+        lds_barrier();  // every wave's contributions are in gw
+        STAMP(8);  // waiting for the other waves of the workgroup
+        if (more && !early) start_ring(nxt);
+        {
+            const int LK = (int)cur.L * K;
+            const uint32_t *ids = ids_of(buf);
+            constexpr int NBF = (PSELL_TILE_COLS_TARGET * K + 255) / 256;
+#pragma unroll
+            for (int b = 0; b < NBF; ++b) {
+                const int i0 = b * 256 + wave * 64;
+                if (i0 < LK) {  // (wave-uniform: the whole wave issues the atomic, idle lanes add 0 to a valid address)
+                    const int i = i0 + lane;
+                    const bool act = i < LK;
+                    const int l = act ? i / K : 0;
+                    const int k = act ? i - l * K : 0;
+                    const float v = act ? gw[i] : 0.0f;
+                    if (act) gw[i] = 0.0f;
+                    float *dst = A.g + (size_t)ids[l] * K + k;
+                    if (!(dbg & 1)) {
+                        asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+                        ++young;  // (younger than the pieces of the ring that has just been started)
+                    }
+                }
+            }
+        }
+        lds_barrier();  // gw is zero again, the next x window is complete
+        STAMP(9);  // flush
+        if (!more) break;
+        cur = nxt;
+        buf ^= 1;
     }
-    const int r = b - nbb, rest = total - nb_b;
-    const int span2 = max(max(rest - rest / 8, nb_a2), 1);
-    const int na2 = before(r, nb_a2, span2);
-    if (before(r + 1, nb_a2, span2) > na2) {
-        uniform_tile_body<K, 12288u, 2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(A, tiles_a1 + na2, dbg, rings, xw, gw,
-                                                                         lp_red);
-    } else {
-        uniform_tile_body<K, 6144u, 4, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(A, r - na2, dbg, rings, xw, gw, lp_red);
+    if (WANT_LP) {
+        double v = lp_a;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < K) atomicAdd(A.lp + lane, v);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double u = lp_b[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) u += __shfl_down(u, d, 64);
+            if (lane == 0 && u != 0.0) atomicAdd(A.lp + k, u);
+        }
     }
+#ifdef POLEE_STAMPS
+    STAMP(10);
+    if (lane == 0) {
+        for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+        atomicAdd(&g_stamps[16], n_slices);
+        atomicAdd(&g_stamps[17], n_tiles);
+        atomicAdd(&g_stamps[18], 1ull);
+    }
+#endif
+}
+
+// Static schedule of the streaming kernel for a grid of G workgroups: tiles (all but the few "big" ones) sorted by
+// cost, dealt to the workgroups in snake order (equal sums), and inside every workgroup's list the small latency-bound
+// tiles (streams A2, B) spread evenly between the streaming A1 tiles.
+static polee_status ensure_schedule(polee_loglik *ll, int G)
+{
+    if (ll->sched_grid == G && ll->d_sched.p) return POLEE_OK;
+    const PsellHost &h = ll->host;
+    const int64_t nt = h.num_tiles;
+    std::vector<uint8_t> is_big((size_t)nt, 0);
+    for (uint32_t t : h.big_tiles) is_big[t] = 1;
+    std::vector<uint32_t> order;
+    order.reserve((size_t)nt);
+    for (int64_t t = 0; t < nt; ++t)
+        if (!is_big[t]) order.push_back((uint32_t)t);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ll->tile_cost[a] > ll->tile_cost[b]; });
+    std::vector<std::vector<uint32_t>> lists((size_t)G);
+    for (size_t i = 0; i < order.size(); ++i) {
+        const size_t r = i / (size_t)G, c = i % (size_t)G;
+        lists[(r & 1) ? (size_t)G - 1 - c : c].push_back(order[i]);
+    }
+    size_t rounds = 0;
+    for (auto &l : lists) rounds = std::max(rounds, l.size());
+    std::vector<PosDesc> sched((rounds + 1) * (size_t)G);
+    for (auto &d : sched) {
+        d = PosDesc();
+        d.tile = POS_NONE;
+    }
+    for (int b = 0; b < G; ++b) {
+        std::vector<uint32_t> big, small;
+        for (uint32_t t : lists[b]) ((int64_t)t < h.num_tiles_a1 ? big : small).push_back(t);
+        const size_t n = big.size() + small.size();
+        size_t ib = 0, is = 0;
+        for (size_t j = 0; j < n; ++j) {
+            // position j takes a small tile when the running share of small tiles falls behind (phase shifted per block)
+            const size_t want = ((j + 1 + (size_t)(b % 3)) * small.size()) / (n + 2);
+            const bool take_small = (is < small.size()) && (ib >= big.size() || is < want);
+            const uint32_t t = take_small ? small[is++] : big[ib++];
+            PosDesc &d = sched[j * (size_t)G + (size_t)b];
+            d.tile = t;
+            d.s0 = h.tile_slice[t];
+            d.s1 = h.tile_slice[t + 1];
+            d.d0 = h.tile_dict[t];
+            d.L = h.tile_cols[t];
+        }
+    }
+    POLEE_TRY(ll->d_sched.upload(ll->ctx, sched));
+    ll->sched_grid = G;
+    return POLEE_OK;
 }
 
 template <int K, bool LP, bool KS>
-static hipError_t launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
+static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
+    polee_ctx *ctx = ll->ctx;
     const PsellHost &h = ll->host;
     const int lcap_all = std::max(h.max_tile_cols, 1);
-    // tiles around a fragment with > 256 transcripts (rare, a few rows each) do not fit the fused kernel's LDS
-    // windows: it skips them and loglik_psell_kernel takes them in a second, small launch
-    const bool fusable = !h.big_tiles.empty() || lcap_all <= PSELL_TILE_COLS_TARGET;
-    const int lcap = fusable ? std::min(lcap_all, (int)PSELL_TILE_COLS_TARGET) : lcap_all;
-    hipStream_t st = ll->ctx->stream;
+    hipStream_t st = ctx->stream;
     static const bool no_ring_env = getenv("POLEE_NO_RING") != nullptr;
     const bool no_ring = no_ring_env || ll->force_mixed;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
-    const PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
-                      ll->d_slice_ks.p, d_x, d_g, d_lp, lcap, (int)h.num_tiles_a,
-                      ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p};
+    PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
+                ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
+                ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p,
+                (int)h.num_tiles_a1, ll->d_xwin.p, nullptr};
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
-    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= 6 * 1024, "A1 slices (+ ks row) must fit a 6 KiB ring");
-    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= 12 * 1024, "A2 slices (+ ks row) must fit a 12 KiB ring");
-    const size_t lds = (size_t)fused_ring_total<K>() + ((size_t)2 * lcap * K + 2) * sizeof(float) +
-                       4 * sizeof(double);
-    const int tiles_a1 = (int)h.num_tiles_a1, tiles_a = (int)h.num_tiles_a, tiles = (int)h.num_tiles;
-    // The attribute belongs to (device, kernel instance): set before every launch (a host-side table write), so that a
-    // second context on another GPU of the same process gets it too; checked.
-    if (lds > 64 * 1024 || !h.big_tiles.empty() || no_ring) {
-        const hipError_t ea = hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (ea != hipSuccess) return ea;
-    }
-    if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
-    if (!no_ring && tiles_a > 0 && lds <= 64 * 1024) {
-        int nb_b = tiles - tiles_a, nb_a2 = tiles_a - tiles_a1, nb_a1 = tiles_a1;
-        if (dbg & 32) nb_b = 0;
-        if (dbg & 128) nb_a2 = 0;
-
-        hipLaunchKernelGGL((loglik_fused_kernel<K, LP, KS>), dim3((unsigned)(nb_b + nb_a2 + nb_a1)), dim3(256), lds, st,
-                           A, tiles_a1, tiles_a, nb_b, nb_a2, dbg);
+    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
+    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM_RB2, "A2 slices (+ ks row) must fit their ring");
+    const size_t lds = stream_lds_bytes<K>();
+    const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
+    // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
+    // write), so that a second context on another GPU of the same process gets it too; checked.
+    if (lds_psell > 48 * 1024 && (!h.big_tiles.empty() || no_ring))
+        POLEE_HIP_TRY(ctx, hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    if (!no_ring) {
+        int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0];
+        if (occ == 0) {
+            int nb = 0;
+            POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS>, 256, lds));
+            occ = std::max(1, std::min(nb, 4));
+        }
+        const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1));
+        POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
+        A.sched = ll->d_sched.p;
+        const int64_t total = ll->dict_len * K;
+        hipLaunchKernelGGL(xwin_gather_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, ll->d_dict.p, d_x, K,
+                           total, ll->d_xwin.p);
+        if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
+        hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
+        if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
         if (!h.big_tiles.empty()) {
-            PsellArgs Ab = A;
-            Ab.lcap = lcap_all;
-            const size_t lds_b = (size_t)2 * lcap_all * K * sizeof(float);
-            hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.big_tiles.size()), dim3(256), lds_b, st,
-                               Ab, 0, ll->d_big_tiles.p);
+            // tiles around a fragment with more than 128 transcripts (rare, a few rows each) do not fit the streaming
+            // kernel's LDS windows: the schedule leaves them out and the per-tile kernel takes them
+            hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.big_tiles.size()), dim3(256), lds_psell, st,
+                               A, 0, ll->d_big_tiles.p);
         }
     } else {
-        // no uniform stream, or the cross-check switch: every tile as mixed slices with the per-run DPP kernel
-        PsellArgs Ab = A;
-        Ab.lcap = lcap_all;
-        const size_t lds_b = (size_t)2 * lcap_all * K * sizeof(float);
-        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles), dim3(256), lds_b, st, Ab, 0,
+        // the cross-check switch: every tile as mixed slices with the per-run DPP kernel
+        if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
+        hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.num_tiles), dim3(256), lds_psell, st, A, 0,
                            (const uint32_t *)nullptr);
+        if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     }
-    if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
-    return hipGetLastError();
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
 }
 
 template <int K>
-static hipError_t launch_k(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
+static polee_status launch_k(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
-    if (ll->host.num_tiles == 0) return hipSuccess;
+    if (ll->host.num_tiles == 0) return POLEE_OK;
     if (d_lp) return ll->has_ks ? launch_variant<K, true, true>(ll, d_x, d_g, d_lp)
                                 : launch_variant<K, true, false>(ll, d_x, d_g, d_lp);
     return ll->has_ks ? launch_variant<K, false, true>(ll, d_x, d_g, d_lp)
@@ -865,19 +1147,16 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
     }
     ll->cur_e0 = e0;
     ll->cur_e1 = e1;
-    hipError_t e = hipSuccess;
     switch (K) {
-        case 1: e = launch_k<1>(ll, d_x, d_g, d_lp); break;
-        case 2: e = launch_k<2>(ll, d_x, d_g, d_lp); break;
-        case 3: e = launch_k<3>(ll, d_x, d_g, d_lp); break;
-        case 4: e = launch_k<4>(ll, d_x, d_g, d_lp); break;
-        case 5: e = launch_k<5>(ll, d_x, d_g, d_lp); break;
-        case 6: e = launch_k<6>(ll, d_x, d_g, d_lp); break;
-        case 7: e = launch_k<7>(ll, d_x, d_g, d_lp); break;
-        case 8: e = launch_k<8>(ll, d_x, d_g, d_lp); break;
+        case 1: return launch_k<1>(ll, d_x, d_g, d_lp);
+        case 2: return launch_k<2>(ll, d_x, d_g, d_lp);
+        case 3: return launch_k<3>(ll, d_x, d_g, d_lp);
+        case 4: return launch_k<4>(ll, d_x, d_g, d_lp);
+        case 5: return launch_k<5>(ll, d_x, d_g, d_lp);
+        case 6: return launch_k<6>(ll, d_x, d_g, d_lp);
+        case 7: return launch_k<7>(ll, d_x, d_g, d_lp);
+        default: return launch_k<8>(ll, d_x, d_g, d_lp);
     }
-    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "likelihood kernel launch failed: %s", hipGetErrorString(e));
-    return POLEE_OK;
 }
 
 // [rows][n] <-> [n][rows] re-layout between the host API (one expression vector per row)
@@ -970,6 +1249,27 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_tdata.upload(ctx, h.tdata)) ||
         (s = ll->d_tgroup_off.upload(ctx, h.tgroup_off)) || (s = ll->d_ttile_group.upload(ctx, h.ttile_group)) ||
         (s = ll->d_big_tiles.upload(ctx, h.big_tiles)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        loglik_release(ll);
+        return s;
+    }
+    // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
+    // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule
+    ll->dict_len = (int64_t)h.dict.size();
+    ll->tile_cost.assign((size_t)h.num_tiles, 0.0f);
+    for (int64_t t = 0; t < h.num_tiles; ++t) {
+        const double slice_bytes = 128.0 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
+        double c = slice_bytes + 4096.0;
+        if (t >= h.num_tiles_a) {
+            const int64_t tb = t - h.num_tiles_a;
+            c += 128.0 * (double)(h.tgroup_off[h.ttile_group[tb + 1]] - h.tgroup_off[h.ttile_group[tb]]);
+            c *= 2.0;
+        } else if (t >= h.num_tiles_a1) {
+            c *= 1.5;
+        }
+        ll->tile_cost[(size_t)t] = (float)c;
+    }
+    if ((s = ll->d_xwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512)) ||
+        (s = ensure_schedule(ll, (int)std::min<int64_t>((int64_t)4 * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1))))) {
         loglik_release(ll);
         return s;
     }
@@ -1151,6 +1451,7 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
         info->stream_tiles[i] = tiles[i];
         info->stream_bytes_hbm[i] = h.stream_bytes[i];
     }
+    info->dict_entries = ll->dict_len;
     return POLEE_OK;
 }
 

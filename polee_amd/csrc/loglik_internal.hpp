@@ -9,12 +9,15 @@
 //     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
 //     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
 //     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
-//   * Consecutive slices form a TILE (64 / 8 / 16 slices in streams A1 / A2 / B), processed by one
+//   * Consecutive slices form a TILE (64 / 8 / 16 slices in streams A1 / A2 / B), the unit of work of one
 //     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
 //     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
-//     pass 256 entries), so an entry costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
-//   * The kernel stages the tile's x[dict][K] into LDS, accumulates the tile's gradient
-//     contributions in LDS (ds_add_f32) and flushes L*K values to HBM per tile.
+//     pass 128 entries), so an entry costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
+//     Every tile's dictionary starts at a multiple of 4 entries (padded with transcript 0), so that its
+//     x window -- x[dict][K], gathered once per pass into one contiguous buffer by xwin_gather_kernel --
+//     starts 16-byte aligned and reaches LDS by LDS-DMA like the slice stream.
+//   * The kernel accumulates the tile's gradient contributions in LDS (ds_add_f32) and flushes L*K
+//     values to HBM per tile.
 //   * Rows are split into three streams: A = slices whose rows all share one transcript set (whole
 //     64-row slices of every run of identical rows, plus run remainders of >= 32 rows, zero padded;
 //     A1 = sets of <= 18 transcripts, A2 = 19..28), B = everything else.  Tiles [0, num_tiles_a1)
@@ -34,16 +37,26 @@ namespace polee {
 
 constexpr int PSELL_LANES = 64;
 constexpr int PSELL_MAX_TILE_COLS = 1024;     // hard limit = longest supported row
-constexpr int PSELL_TILE_COLS_TARGET = 256;   // a tile is closed when its dictionary would grow past this
+constexpr int PSELL_TILE_COLS_TARGET = 128;   // a tile is closed when its dictionary would grow past this
+constexpr int PSELL_DICT_ALIGN = 4;           // a tile's dictionary starts at a multiple of this many entries
 constexpr int PSELL_TILE_SLICES_A1 = 64;      // slices per tile (= per workgroup) in each stream
 constexpr int PSELL_TILE_SLICES_A2 = 8;
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
-constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (8 KiB LDS ring, one 16-row MFMA tile)
-constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (16 KiB LDS ring, two MFMA tiles)
+constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, one 16-row MFMA tile)
+constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two MFMA tiles)
 constexpr int PSELL_VCOL_CAP = 32;         // stream B: entries per virtual column (lane) of the transposed copy
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
+
+// One position of the streaming kernel's static schedule (workgroup b walks positions b, b + grid, b + 2 grid, ...).
+struct PosDesc {
+    uint32_t tile;    // POS_NONE: the column ends here
+    uint32_t s0, s1;  // slices of the tile
+    uint32_t d0, L;   // first dictionary entry, entries in use
+    uint32_t pad[3];
+};
+constexpr uint32_t POS_NONE = 0xffffffffu;
 
 struct PsellHost {
     int64_t m = 0, n = 0, nnz = 0;
@@ -56,7 +69,8 @@ struct PsellHost {
     std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units in bits 0..29, slice flags in bits 30..31
     std::vector<uint32_t> tile_slice;  // [num_tiles+1]
-    std::vector<uint32_t> tile_dict;   // [num_tiles+1]
+    std::vector<uint32_t> tile_dict;   // [num_tiles+1], multiples of PSELL_DICT_ALIGN
+    std::vector<uint32_t> tile_cols;   // [num_tiles] dictionary entries in use (the rest, up to tile_dict[t+1], is padding)
     std::vector<uint32_t> dict;        // transcript ids (0-based)
     std::vector<uint32_t> big_tiles;   // tiles whose dictionary exceeds PSELL_TILE_COLS_TARGET (a fragment with > 256 transcripts)
     std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
@@ -92,6 +106,13 @@ struct polee_loglik {
     polee::DevBuf<uint8_t> d_tdata;
     polee::DevBuf<uint32_t> d_tgroup_off, d_ttile_group, d_big_tiles;
     polee::DevBuf<float> d_slice_ks;
+    // the streaming kernel: per-pass x windows, static schedule (built for the grid of the first launch)
+    polee::DevBuf<float> d_xwin;
+    polee::DevBuf<polee::PosDesc> d_sched;
+    int sched_grid = 0;
+    std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
+    int64_t dict_len = 0;
+    int occ_cache[polee::PSELL_MAX_K + 1][2][2] = {};
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;

@@ -334,8 +334,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     auto close_tile = [&]() {
         if (tile_nslices == 0) return;
         out.tile_slice.push_back((uint32_t)out.num_slices);
+        out.tile_cols.push_back(tile_cols);
+        while (out.dict.size() % PSELL_DICT_ALIGN) out.dict.push_back(0u);  // (never referenced by a slice)
+        // (kernels that size their windows by tile_dict differences see the padded count)
+        out.max_tile_cols = std::max<int32_t>(out.max_tile_cols, (int32_t)(out.dict.size() - out.tile_dict.back()));
         out.tile_dict.push_back((uint32_t)out.dict.size());
-        out.max_tile_cols = std::max<int32_t>(out.max_tile_cols, (int32_t)tile_cols);
         if (tile_cols > (uint32_t)PSELL_TILE_COLS_TARGET) out.big_tiles.push_back((uint32_t)out.num_tiles);
         ++out.num_tiles;
         ++tile_id;
@@ -403,6 +406,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.slice_off.reserve(tot_slices + 1);
         out.tile_slice.reserve(tot_tiles + 1);
         out.tile_dict.reserve(tot_tiles + 1);
+        out.tile_cols.reserve(tot_tiles);
         out.dict.reserve(tot_dict);
         out.slice_flags.reserve(tot_slices);
         out.row_order.reserve(tot_slices * 64);
@@ -429,6 +433,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (size_t q = 1; q < f.tile_slice.size(); ++q) out.tile_slice.push_back(f.tile_slice[q] + slice_base);
             for (size_t q = 1; q < f.tile_dict.size(); ++q) out.tile_dict.push_back(f.tile_dict[q] + dict_base);
             out.dict.insert(out.dict.end(), f.dict.begin(), f.dict.end());
+            out.tile_cols.insert(out.tile_cols.end(), f.tile_cols.begin(), f.tile_cols.end());
             out.slice_flags.insert(out.slice_flags.end(), f.slice_flags.begin(), f.slice_flags.end());
             out.row_order.insert(out.row_order.end(), f.row_order.begin(), f.row_order.end());
             if (ks) out.slice_ks.insert(out.slice_ks.end(), f.slice_ks.begin(), f.slice_ks.end());
@@ -473,7 +478,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         std::vector<float> eval;
         for (int64_t tb = 0; tb < ntb; ++tb) {
             const int64_t tile = out.num_tiles_a + tb;
-            const uint32_t d0 = out.tile_dict[tile], L = out.tile_dict[tile + 1] - d0;
+            const uint32_t d0 = out.tile_dict[tile], L = out.tile_cols[tile];
             const uint32_t s0 = out.tile_slice[tile], s1 = out.tile_slice[tile + 1];
             for (uint32_t l = 0; l < L; ++l) col_local[out.dict[d0 + l]] = (uint16_t)l;
             // counting sort of the tile's entries by tile-local transcript id

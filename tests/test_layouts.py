@@ -213,7 +213,8 @@ def _emulate_psell(ps, x, n):
                 assert vrow.max() < wrows.shape[1] and vcol.max() < d1 - d0
                 for k in range(K):
                     np.add.at(gw[k], vcol, (vval * wrows[k][vrow]).sum(axis=0))
-        g[:, dic] += gw
+        for k in range(K):  # (a tile's dictionary is padded with transcript 0 to a multiple of 4 entries)
+            np.add.at(g[k], dic, gw[k])
     return lp, g
 
 

@@ -1,4 +1,4 @@
-"""Where a wave of the uniform-stream part of loglik_fused_kernel spends its cycles (diagnostic build:
+"""Where a wave of loglik_stream_kernel spends its cycles (diagnostic build:
 `make -C polee_amd/csrc EXTRA=-DPOLEE_STAMPS`, then run this on the GPU box; rebuild without the flag afterwards)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
@@ -15,16 +15,18 @@ sample = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ct
 tree = P.PolyaTreeTransform(parents, js, ctx=ctx)
 fit = P.LikelihoodApproximationFit(sample, tree, num_steps=40, num_mc_samples=6, seed=1)
 fit.run(5); fit.sync()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 f = L.lib().polee_debug_read_stamps
 f(out)  # reset
 fit.run(20); fit.sync()
 f(out)
 v = np.array(list(out), np.float64)
-names = ["tile setup (dict, x window, barrier)", "slice bookkeeping", "waiting for the DMA", "run change: flush + column lookup",
-         "phase 1 (LDS reads, MFMA, weights)", "phase 2 (MFMA)", "refill (DMA issue)", "final flush of the run",
-         "waiting for the other waves", "global flush (atomics)"]
-tot = v[:10].sum()
-for nm, x in zip(names, v[:10]):
-    print("%-42s %5.1f %%" % (nm, 100 * x / tot))
-print("waves measured: %d, mean cycles per wave (memtime units): %.0f" % (v[11], v[10] / max(v[11], 1)))
+names = {0: "between tiles: schedule read + prefetch issue", 1: "slice bookkeeping", 2: "waiting for the DMA",
+         3: "run change: flush + column lookup", 4: "phase 1 (LDS reads, refill, MFMA, weights)", 5: "phase 2 (MFMA)",
+         6: "refill (wide stream)", 7: "end of the wave's slices: run flush + queue drain",
+         8: "waiting for the other waves (barrier A)", 9: "tile flush (atomics) + barrier B", 10: "kernel tail (lp)"}
+tot = v[:16].sum()
+for i, nm in names.items():
+    print("%-52s %5.1f %%" % (nm, 100 * v[i] / tot))
+print("waves: %d, tiles per wave %.1f, slices per wave %.1f, mean cycles per wave (memtime units): %.0f"
+      % (v[18], v[17] / max(v[18], 1), v[16] / max(v[18], 1), tot / max(v[18], 1)))
