@@ -93,6 +93,12 @@ __device__ inline float fast_weight(float ksv, float s)
     // ks / s with v_rcp_f32 (1 ulp): well inside the 1e-4 budget, 10x fewer instructions than a division
     return s > 0.0f ? ksv * __builtin_amdgcn_rcpf(s) : 0.0f;  // padded lanes (and empty rows) have s = 0
 }
+// 1 / s for the matrix-core path, two instructions: padded lanes have s = 0 AND only zero values, so their weight only
+// has to be finite (1 / FLT_MIN x 0 = 0); a real row sum is never below FLT_MIN (values >= 1e-12, x >= 1e-16 ...)
+__device__ inline float unit_weight(float s)
+{
+    return __builtin_amdgcn_rcpf(fmaxf(s, 1.17549435e-38f));
+}
 
 // ---- stream B (and fallback for very wide rows): mixed slices ---------------------------------------
 // Two sweeps over each slice straight from global memory (the second one hits L1/L2); contributions
@@ -376,35 +382,29 @@ __device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrow
 #ifndef POLEE_DMA_POLICY
 #define POLEE_DMA_POLICY " nt"  // X is read once per pass: non-temporal keeps it from evicting x / g lines
 #endif
-__device__ inline void dma_1k(const void *gsrc_lane, uint32_t lds_dst_any)
+// LDS-DMA forms: wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane; the LDS destination is
+// M0 + lane * (bytes per lane).  The leading s_nop 4 covers a base that has just come out of v_readfirstlane
+// (VALU-written SGPR -> VMEM read: 5 wait states, which the compiler does not insert for an asm statement).  (M0 is not restored: nothing else in these kernels uses it -- LDS instructions
+// on gfx9 do not -- and the base / offset registers are not rewritten per piece.)
+__device__ inline void dma_1k(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
-    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" POLEE_DMA_POLICY "\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc_lane), "s"(lds_dst)
-        : "memory");
-}
-// the same with the default cache policy (x windows: written by the previous kernel, re-read by nobody else)
-__device__ inline void dma_1k_keep(const void *gsrc_lane, uint32_t lds_dst_any)
-{
-    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(lds_dst)
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" POLEE_DMA_POLICY
+                 :
+                 : "s"(base_uniform), "v"(voff), "s"(lds_dst)
                  : "memory");
 }
-// 4 bytes per lane: 64 arbitrary dwords -> 256 contiguous LDS bytes
-__device__ inline void dma_256(const void *gsrc_lane, uint32_t lds_dst_any)
+// the same with the default cache policy (x windows: written by the previous kernel)
+__device__ inline void dma_1k_keep(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
-    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);  // (wave-uniform by construction)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(lds_dst)
-                 : "memory");
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
+}
+// 4 bytes per lane: 64 dwords -> 256 contiguous LDS bytes
+__device__ inline void dma_256(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
+{
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
 }
 __device__ inline uint32_t lds_addr(const void *p)
 {
@@ -473,17 +473,25 @@ struct WaveStream {
     int npieces;          // 1 KiB pieces of its byte range
     int issued, islot;    // pieces requested so far; ring slot of the next one
     int primed;           // pieces requested before the tile's loop started
-    const uint8_t *gsrc;  // start of the byte range + lane * 16
+    const uint8_t *gsrc;  // start of the byte range (wave-uniform)
 };
 
 template <uint32_t RB>
 __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target)
 {
     constexpr int RP = (int)(RB / 1024u);
-    for (; ws.issued < target; ++ws.issued) {
-        dma_1k(ws.gsrc + (size_t)ws.issued * 1024, ring_lds + (uint32_t)ws.islot * 1024u);
-        ws.islot = ws.islot + 1 == RP ? 0 : ws.islot + 1;
+    // (wave-uniform counters: say so, or the loop below is compiled as a divergent loop on vector registers)
+    int issued = __builtin_amdgcn_readfirstlane(ws.issued), islot = __builtin_amdgcn_readfirstlane(ws.islot);
+    target = __builtin_amdgcn_readfirstlane(target);
+    const uint32_t voff = (uint32_t)(threadIdx.x & 63) * 16u;
+    const uint8_t *src = ws.gsrc + (size_t)issued * 1024;
+    for (; issued < target; ++issued) {
+        dma_1k(src, voff, ring_lds + (uint32_t)islot * 1024u);
+        src += 1024;
+        islot = islot + 1 == RP ? 0 : islot + 1;
     }
+    ws.issued = issued;
+    ws.islot = islot;
 }
 
 // The slice loop of one wave over its share of a uniform tile.  RB = ring bytes per active wave, WMAXR = widest
@@ -498,7 +506,8 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #endif
 )
 {
-    constexpr int RP = (int)(RB / 1024u);
+    constexpr int RPFULL = (int)(RB / 1024u);
+    const int RP = ((dbg >> 8) & 15) ? min(RPFULL, (WMAXR > 16 ? 2 : 1) * ((dbg >> 8) & 15)) : RPFULL;  // (experiment: pieces requested ahead)
     const int lane = threadIdx.x & 63;
     const uint32_t ring_lds = lds_addr(ring);
 
@@ -530,7 +539,22 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
     for (int st = 0; st < NS; ++st) xq[st] = 0.0f;
     int pend_w = 0;  // transcripts of the current run (0: no run open)
+    bool pend_packed = false;  // the run accumulates in the packed (two 8 x 8 blocks) layout
     auto flush = [&]() {
+        if (NT == 1 && pend_packed) {
+            // D[(h, t)][(h', k)]: lane (n = tt, q), register v holds row m = 4 q + v; useful where h = q >> 1 equals
+            // h' = tt >> 3: transcript t = 4 (q & 1) + v (colq was read for q & 1), draw k = tt & 7
+            const f32x4 sum = acc0[0] + acc1[0];
+            const unsigned cid[4] = {colq[0].x & 0xffffu, colq[0].x >> 16, colq[0].y & 0xffffu, colq[0].y >> 16};
+            const bool mine = (q >> 1) == (tt >> 3) && (tt & 7) < K;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (mine && 4 * (q & 1) + v < pend_w && sum[v] != 0.0f) atomicAdd(gw + cid[v] * K + (tt & 7), sum[v]);
+            acc0[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pend_w = 0;
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             if (16 * mt < pend_w) {
@@ -547,6 +571,27 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         pend_w = 0;
     };
 
+    // Operand addresses.  A slice starts at a multiple of 256 bytes and the ring holds whole 256-byte rows, so a row
+    // never straddles the ring's end: address = ring + wrap(pos_r + 256 + 256 t) + (offset inside the row), and for a
+    // lane the row t and the offset are constants.  Rows t >= w of a step (B = 0 there) read whatever follows the slice
+    // in the ring -- stream bytes or the zeros the ring was initialised with, always finite.
+    // (the narrow stream keeps these constants in registers; the wide one, short of registers, recomputes them)
+    constexpr bool PRE = NT == 1;
+    const uint32_t q256 = 256u * (uint32_t)q;
+    auto k2f = [&](int st) -> uint32_t { return ring_lds + (uint32_t)((tt + 4 * st + q) & 15) * 16u; };  // phase 1, step st: row 4 st + q, chunk (tt + row) & 15
+    auto c2f = [&](int mt, int j) -> uint32_t { return ring_lds + (uint32_t)((4 * q + j + 16 * mt + tt) & 15) * 16u; };  // phase 2, tile mt: row 16 mt + tt
+    uint32_t k2[PRE ? NS : 1];
+    uint32_t c2[PRE ? 4 : 1];
+    if (PRE) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) k2[PRE ? st : 0] = k2f(st);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c2[PRE ? j : 0] = c2f(0, j);
+    }
+    auto lds_f4 = [](uint32_t a) -> f32x4 {
+        return *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)a);
+    };
+
     uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
     uint32_t pos_r = 0;  // pos modulo the ring size
     for (int si = 0; si < ws.nsl; ++si) {
@@ -558,10 +603,13 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         const int w = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // 256-byte header (column ids) + w rows of 64 values (+ ks row)
         const uint32_t bytes = units * 128u;
         // all pieces covering [pos, pos+bytes) must have landed
+        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the short non-matrix sections of a slice win the issue arbitration (-2.5 %)
         STAMP(1);  // slice bookkeeping
         {
             const int need = (int)((pos + bytes + 1023u) >> 10);
-            wait_vm_outstanding(ws.issued - need + (need <= ws.primed ? extras : 0));
+            if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);  // (only with a shortened look-ahead: experiments)
+            // (wave-uniform: said explicitly, or the ladder below is compiled with vector compares and exec masks)
+            wait_vm_outstanding(__builtin_amdgcn_readfirstlane(ws.issued - need + (need <= ws.primed ? extras : 0)));
         }
         STAMP(2);  // waiting for the DMA
         auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
@@ -571,9 +619,10 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         };
         if (pend_w != 0 && !(flags & 2)) flush();
         if (pend_w == 0) {  // a new run: the tile-local ids of its transcripts and their x rows
+            pend_packed = NT == 1 && K <= 8 && w <= 8 && !(dbg & 32);
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt)
-                colq[mt] = *reinterpret_cast<const uint2 *>(ring_at((uint32_t)(32 * mt + 8 * q)));
+                colq[mt] = *reinterpret_cast<const uint2 *>(ring_at((uint32_t)(32 * mt + 8 * (pend_packed ? (q & 1) : q))));
             int cl[NS];
 #pragma unroll
             for (int st = 0; st < NS; ++st)
@@ -591,14 +640,31 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         constexpr bool WIDE = NT > 1;
         // (with multiplicities the ks row is read after phase 1; the debug switch that skips phase 1 skips the reads)
         const bool EARLY_REFILL = !WIDE && !HAS_KS && !(dbg & 4);
+        auto wrap = [&](uint32_t a) -> uint32_t { return min(a, a - RB); };  // a < 2 RB: a mod RB (unsigned wrap-around)
         auto read_tile = [&](int mt, f32x4 (&dst)[4]) {
-            const int t = 16 * mt + tt;  // rows t >= w read whatever follows in the ring: their D2 rows are never used
-            const char *vrow = ring_at(256u + (uint32_t)t * 256u);
+            // rows t >= w read whatever follows in the ring: their D2 rows are never used
+            const uint32_t row = wrap(pos_r + 256u + 256u * (uint32_t)(16 * mt + tt));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4 *>(vrow + ((4 * q + j + t) & 15) * 16);
+            for (int j = 0; j < 4; ++j) dst[j] = lds_f4(row + (PRE ? c2[PRE ? j : 0] : c2f(mt, j)));
         };
+        // Narrow sets (w <= 8) use HALF the phase-2 instructions: the 16 x 16 tile holds two 8 x 8 problems, rows
+        // m = (h, t) and columns n = (h', k) with h, h' the halves {j = 0, 1} / {j = 2, 3} of every lane group's 16
+        // fragments; the diagonal blocks h = h' are the two halves' contributions to G[t][k], the others are unused.
+        //     A[(h, t)][kk = q] = V[t][16 q + 4 (jj + 2 h) + e]          two 16-byte reads per lane instead of four
+        //     B[kk = q][(h', k)] = W[k][16 q + 4 (jj + 2 h') + e]        lanes tt < 8: their own D1[e][jj];
+        //                                                                lanes tt >= 8: D1[e][jj + 2] of lane tt - 8 (DPP)
+        const bool packed = !WIDE && K <= 8 && w <= 8 && !(dbg & 32);
         f32x4 av2[4];
-        if (!WIDE) read_tile(0, av2);
+        if (!WIDE) {
+            if (packed) {
+                const uint32_t row = wrap(pos_r + 256u + 256u * (uint32_t)(tt & 7));
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    av2[jj] = lds_f4(row + ring_lds + (uint32_t)((4 * q + jj + 2 * (tt >> 3) + (tt & 7)) & 15) * 16u);
+            } else {
+                read_tile(0, av2);
+            }
+        }
         // phase 1
         f32x4 d1[4];
 #pragma unroll
@@ -611,21 +677,21 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int st = g0 + u;
-                        if (st < NS && 4 * st < w) {
-                            const int t = min(4 * st + q, w - 1);  // rows >= w: B is 0 there, A only has to be finite
-                            av1[u] = *reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)t * 256u) + ((tt + t) & 15) * 16);
-                        }
+                        if (st < NS && 4 * st < w) av1[u] = lds_f4(wrap((pos_r + 256u + 1024u * (uint32_t)st) + q256) + (PRE ? k2[PRE ? st : 0] : k2f(st)));
                     }
                     if (EARLY_REFILL) {
                         // narrow stream: every operand of the slice is now on its way into registers; once the LDS
                         // reads have landed the slice's ring bytes are free, so the DMA for the pieces behind it is
                         // issued BEFORE the two MFMA phases instead of after them
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        STAMP(11);  // operand reads landed
                         pos += bytes;
                         pos_r += bytes;
                         pos_r = pos_r >= RB ? pos_r - RB : pos_r;
                         ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
+                        STAMP(6);  // refill
                     }
+                    if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int st = g0 + u;
@@ -638,6 +704,10 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
                 }
             }
         }
+#ifdef POLEE_STAMPS
+        asm volatile("s_nop 0" : "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]));  // (the stamp waits for the MFMA results)
+        STAMP(14);  // phase 1 MFMAs
+#endif
         // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt
         if (HAS_KS) {
             // the multiplicities travel with the slice (its last row): no global load in this loop
@@ -659,12 +729,25 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
                 for (int v = 0; v < 4; ++v) {
                     const float sv = d1[e][v];
                     if (WANT_LP && sv > 0.0f) lpacc += log((double)sv);
-                    d1[e][v] = fast_weight(1.0f, sv);
+                    d1[e][v] = unit_weight(sv);
                 }
         }
 
         STAMP(4);  // phase 1
-        if (!(dbg & 2)) {
+        if (!(dbg & 2) && packed) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)  // row_shr:8 into lanes 8..15 of every row of 16 (bank mask 0xc); lanes 0..7 keep their own
+                    b[e] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d1[e][jj]), __float_as_int(d1[e][jj + 2]),
+                                                                      0x118, 0xf, 0xc, false));
+                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][0], b[0], acc0[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][1], b[1], acc1[0], 0, 0, 0);
+                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][2], b[2], acc0[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][3], b[3], acc1[0], 0, 0, 0);
+            }
+        } else if (!(dbg & 2)) {
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
                 if (16 * mt < w) {
@@ -698,13 +781,13 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 // sweep 1 + sweep 2 of one mixed (stream B) tile inside the persistent kernel; the tile's x window is in LDS (xw),
 // gw is zero on entry; W rows live in the ring area (no ring is active while a mixed tile runs).
 template <int K, bool WANT_LP, bool HAS_KS>
-__device__ inline void mixed_stream(const PsellArgs &A, int tile, uint32_t s0, uint32_t s1, float *wrows,
+__device__ inline void mixed_stream(const PsellArgs &A, int tile, uint32_t s0, uint32_t s1, int wave, float *wrows,
                                     const float *xw, float *gw, double (&lpacc)[K])
 {
     const uint8_t *__restrict__ data = A.data;
     const uint32_t *__restrict__ slice_off = A.slice_off;
     const float *__restrict__ slice_ks = A.slice_ks;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;  // (wave: the caller's wave-uniform copy)
 
     for (uint32_t s = s0 + wave; s < s1; s += 4) {
         const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
@@ -811,7 +894,7 @@ __global__ void xwin_gather_kernel(const uint32_t *__restrict__ dict, const floa
 }
 
 // LDS layout of the streaming kernel:
-//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2); stream B's weight rows][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][lp]
+//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2); stream B's weight rows][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
 template <int K>
 constexpr uint32_t stream_ring_total()
@@ -826,7 +909,7 @@ constexpr uint32_t stream_xw_bytes()  // whole 1 KiB pieces
 template <int K>
 constexpr uint32_t stream_lds_bytes()
 {
-    return stream_ring_total<K>() + 3u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 64u;
+    return stream_ring_total<K>() + 3u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u;
 }
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -843,6 +926,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         return reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + (uint32_t)b * (PSELL_TILE_COLS_TARGET * 4));
     };
     uint32_t *const entb = reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
+    uint32_t *const descb = entb + 4 * 64;  // 2 x 64 words: the schedule entry two rounds ahead, by LDS-DMA
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -867,27 +951,29 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     auto prefetch = [&](const PosDesc &t, int buf) -> int {
         int cnt = 0;
         const int npx = (int)((t.L * (uint32_t)K * 4u + 1023u) >> 10);
-        const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4 + lane * 16;
+        const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4;
         const uint32_t dst = lds_addr(xw_of(buf));
         for (int p = wave; p < npx; p += 4) {
-            dma_1k_keep(src + (size_t)p * 1024, dst + (uint32_t)p * 1024u);
+            dma_1k_keep(src + (size_t)p * 1024, (uint32_t)lane * 16u, dst + (uint32_t)p * 1024u);
             ++cnt;
         }
         if ((uint32_t)wave * 64u < t.L) {  // transcript ids of the dictionary (for the flush)
-            dma_256(A.dict + t.d0 + min((uint32_t)wave * 64u + (uint32_t)lane, t.L - 1u), lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
+            dma_256(A.dict + t.d0 + (uint32_t)wave * 64u, min((uint32_t)lane, t.L - 1u - (uint32_t)wave * 64u) * 4u,
+                    lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
             ++cnt;
         }
         const int kind = kind_of(t.tile);
         if (kind < 2) {  // slice offsets of this wave's share, one per lane
             uint32_t sb, se;
             share(kind, t.s0, t.s1, sb, se);
-            dma_256(A.slice_off + min(sb + (uint32_t)lane, se), lds_addr(entb) + (uint32_t)wave * 256u);
+            dma_256(A.slice_off + sb, min((uint32_t)lane, se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
             ++cnt;
         }
         return cnt;
     };
     // after the prefetch has landed: this wave's stream state for tile `t`, ring started
     WaveStream ws;
+    const int ahead = (dbg >> 8) & 15;  // (experiment: pieces requested ahead; 0 = the whole ring)
     auto start_ring = [&](const PosDesc &t) {
         const int kind = kind_of(t.tile);
         ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
@@ -899,11 +985,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
-        ws.gsrc = A.data + (size_t)cb * 128 + lane * 16;
+        ws.gsrc = A.data + (size_t)cb * 128;
         if (kind == 0) {
-            ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, (int)(STREAM_RB1 / 1024u)));
+            ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, ahead ? min(ahead, (int)(STREAM_RB1 / 1024u)) : (int)(STREAM_RB1 / 1024u)));
         } else {
-            ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, (int)(STREAM_RB2 / 1024u)));
+            ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, ahead ? min(2 * ahead, (int)(STREAM_RB2 / 1024u)) : (int)(STREAM_RB2 / 1024u)));
         }
         ws.primed = ws.issued;
     };
@@ -915,7 +1001,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 
     PosDesc cur = sched[blockIdx.x];
     if (cur.tile == POS_NONE) return;
+    PosDesc nxt = sched[blockIdx.x + G];
     for (int i = threadIdx.x; i < (int)(XWB / 4u); i += 256) gw[i] = 0.0f;
+    // the rings start out as zeros: operand rows past a slice's last transcript are read (and multiplied by 0), so
+    // whatever lies behind a slice in the ring has to be finite
+    for (int i = threadIdx.x; i < (int)(stream_ring_total<K>() / 16u); i += 256)
+        reinterpret_cast<float4 *>(rings)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lds_barrier();
     (void)prefetch(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     start_ring(cur);
@@ -923,10 +1015,15 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     lds_barrier();
     int buf = 0;
     for (uint32_t round = 0;; ++round) {
-        const PosDesc nxt = sched[blockIdx.x + (round + 1u) * G];
         const bool more = nxt.tile != POS_NONE;
         const int kind = kind_of(cur.tile);
         if (more) young += prefetch(nxt, buf ^ 1);
+        if (wave == 0) {
+            // the schedule entry after the next (a scalar load here would stall every tile by its latency; through LDS it
+            // arrives in the background like everything else and is read after the tile's barriers)
+            dma_256(sched + blockIdx.x + (size_t)(round + 2u) * G, (uint32_t)(lane & 7) * 4u, lds_addr(descb + (round & 1u) * 64u));
+            ++young;
+        }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
             uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw, lp_a, dbg
@@ -941,7 +1038,8 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #endif
             );
         } else {
-            mixed_stream<K, WANT_LP, HAS_KS>(A, (int)cur.tile, cur.s0, cur.s1, reinterpret_cast<float *>(rings), xw_of(buf), gw, lp_b);
+            mixed_stream<K, WANT_LP, HAS_KS>(A, (int)cur.tile, cur.s0, cur.s1, wave, reinterpret_cast<float *>(rings), xw_of(buf), gw, lp_b);
+            STAMP(12);  // a mixed tile's two sweeps
         }
 #ifdef POLEE_STAMPS
         n_slices += (unsigned long long)ws.nsl;
@@ -954,9 +1052,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
         const bool early = more && kind < 2 && kind_of(nxt.tile) == kind;
         if (early) start_ring(nxt);
+        STAMP(13);  // starting the next ring (before the barrier)
         lds_barrier();  // every wave's contributions are in gw
         STAMP(8);  // waiting for the other waves of the workgroup
         if (more && !early) start_ring(nxt);
+        STAMP(13);  // starting the next ring (after the barrier)
         {
             const int LK = (int)cur.L * K;
             const uint32_t *ids = ids_of(buf);
@@ -964,25 +1064,34 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #pragma unroll
             for (int b = 0; b < NBF; ++b) {
                 const int i0 = b * 256 + wave * 64;
-                if (i0 < LK) {  // (wave-uniform: the whole wave issues the atomic, idle lanes add 0 to a valid address)
-                    const int i = i0 + lane;
-                    const bool act = i < LK;
-                    const int l = act ? i / K : 0;
-                    const int k = act ? i - l * K : 0;
-                    const float v = act ? gw[i] : 0.0f;
-                    if (act) gw[i] = 0.0f;
-                    float *dst = A.g + (size_t)ids[l] * K + k;
-                    if (!(dbg & 1)) {
-                        asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
-                        ++young;  // (younger than the pieces of the ring that has just been started)
+                if (i0 < LK) {  // (wave-uniform; lane 0 of the wave is active, so the wave issues exactly one atomic here)
+                    int i = i0 + lane;
+                    asm volatile("" : "+v"(i));  // (keeps i / K from being hoisted out of the tile loop and spilled)
+                    if (i < LK) {
+                        const int l = i / K;
+                        const int k = i - l * K;
+                        const float v = gw[i];
+                        gw[i] = 0.0f;
+                        float *dst = A.g + (size_t)ids[l] * K + k;
+                        if (!(dbg & 1)) asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
                     }
+                    if (!(dbg & 1)) ++young;  // (younger than the pieces of the ring that has just been started)
                 }
             }
         }
+        STAMP(15);  // flush issue
         lds_barrier();  // gw is zero again, the next x window is complete
-        STAMP(9);  // flush
+        STAMP(9);  // barrier B
         if (!more) break;
         cur = nxt;
+        {
+            const uint32_t *dp = descb + (round & 1u) * 64u;
+            nxt.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[0]);
+            nxt.s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[1]);
+            nxt.s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[2]);
+            nxt.d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[3]);
+            nxt.L = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[4]);
+        }
         buf ^= 1;
     }
     if (WANT_LP) {
@@ -1031,7 +1140,7 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     }
     size_t rounds = 0;
     for (auto &l : lists) rounds = std::max(rounds, l.size());
-    std::vector<PosDesc> sched((rounds + 1) * (size_t)G);
+    std::vector<PosDesc> sched((rounds + 3) * (size_t)G);  // (the kernel reads up to two rounds past a column's end)
     for (auto &d : sched) {
         d = PosDesc();
         d.tile = POS_NONE;
@@ -1089,6 +1198,9 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
             int nb = 0;
             POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS>, 256, lds));
             occ = std::max(1, std::min(nb, 4));
+            if (getenv("POLEE_DEBUG_PRINT"))
+                fprintf(stderr, "[loglik] stream kernel K=%d: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
+                        K, nb, lds, occ, ctx->num_cus);
         }
         const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1));
         POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)

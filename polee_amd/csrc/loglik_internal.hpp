@@ -48,6 +48,7 @@ constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A
 constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two MFMA tiles)
 constexpr int PSELL_VCOL_CAP = 32;         // stream B: entries per virtual column (lane) of the transposed copy
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
+constexpr int PSELL_MIN_UNION_ROWS = 24;    // smallest group of leftover rows stored as a union slice
 
 // One position of the streaming kernel's static schedule (workgroup b walks positions b, b + grid, b + 2 grid, ...).
 struct PosDesc {

@@ -152,6 +152,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     // A run of r rows contributes floor(r/64) whole slices to A, and its remainder as one more
     // (zero-padded) uniform slice when the remainder is at least 32 rows.
     std::vector<uint32_t> run_end;  // for stream A rows: index (in `rows`) one past the row's slice
+    std::vector<uint8_t> is_union;  // for stream A rows: the row's slice is a union slice
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
@@ -163,6 +164,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
         });
         std::vector<uint32_t> ra1, ra2, rb, e1, e2;
+        std::vector<uint8_t> u1, u2;  // row belongs to a union slice
         size_t i = 0;
         while (i < rows.size()) {
             size_t j = i + 1;
@@ -174,13 +176,80 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
             std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? ra1 : ra2;
             std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? e1 : e2;
+            std::vector<uint8_t> &du = len <= (uint64_t)PSELL_NARROW_MAX ? u1 : u2;
             for (size_t q = 0; q < take; ++q) {
+                du.push_back(0);
                 dst.push_back(rows[i + q]);
                 // slice boundary inside the run: after every 64 rows, and at the end of the taken part
                 de.push_back((q + 1) % PSELL_LANES == 0 || q + 1 == take ? 1u : 0u);
             }
             rb.insert(rb.end(), rows.begin() + i + take, rows.begin() + j);
             i = j;
+        }
+        // UNION slices: the leftover rows (runs and run remainders of < 32 rows) of neighbouring transcript sets are packed
+        // into uniform slices whose header is the UNION of their sets, rows holding zeros for the transcripts they are
+        // not compatible with (a zero adds nothing to a row sum and nothing to a gradient, exactly).  Rows are visited
+        // in the order of their first transcript; a row joins the open group while the union stays within the stream's
+        // set size, a misfit is deferred once; groups of fewer than PSELL_MIN_UNION_ROWS rows stay in stream B.
+        static const bool no_union = getenv("POLEE_PSELL_NO_UNION") != nullptr;
+        if (!no_union && !rb.empty()) {
+            std::vector<uint64_t> k2(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;  // (columns ascend within a row)
+            std::vector<uint32_t> idx(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) idx[q] = (uint32_t)q;
+            radix_sort_pairs(k2, idx);
+            std::vector<uint32_t> cand(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) cand[q] = rb[idx[q]];
+            std::vector<uint32_t> keep_b;
+            for (int cls = 0; cls < 2; ++cls) {  // narrow sets first, then the wide ones
+                const size_t cap = cls == 0 ? (size_t)PSELL_NARROW_MAX : (size_t)PSELL_WIDE_MAX;
+                std::vector<uint32_t> &dst = cls == 0 ? ra1 : ra2;
+                std::vector<uint32_t> &de = cls == 0 ? e1 : e2;
+                std::vector<uint8_t> &du = cls == 0 ? u1 : u2;
+                std::vector<uint32_t> pool, deferred, group, uni, tmp;
+                for (uint32_t r : cand) {
+                    const uint64_t len = rowptr[r + 1] - rowptr[r];
+                    if (cls == 0 ? len <= (uint64_t)PSELL_NARROW_MAX : (len > (uint64_t)PSELL_NARROW_MAX && len <= (uint64_t)PSELL_WIDE_MAX))
+                        pool.push_back(r);
+                    else if (cls == 0 && len > (uint64_t)PSELL_WIDE_MAX)
+                        keep_b.push_back(r);
+                }
+                auto close_group = [&]() {
+                    if (group.size() >= (size_t)PSELL_MIN_UNION_ROWS) {
+                        for (size_t q = 0; q < group.size(); ++q) {
+                            dst.push_back(group[q]);
+                            de.push_back(q + 1 == group.size() ? 1u : 0u);
+                            du.push_back(1);
+                        }
+                    } else {
+                        keep_b.insert(keep_b.end(), group.begin(), group.end());
+                    }
+                    group.clear();
+                    uni.clear();
+                };
+                for (int pass = 0; pass < 2; ++pass) {
+                    const std::vector<uint32_t> &src = pass == 0 ? pool : deferred;
+                    for (uint32_t r : src) {
+                        const uint32_t *cb = col + rowptr[r], *ce = col + rowptr[r + 1];
+                        tmp.resize(uni.size() + (size_t)(ce - cb));
+                        tmp.resize((size_t)(std::set_union(uni.begin(), uni.end(), cb, ce, tmp.begin()) - tmp.begin()));
+                        if (tmp.size() <= cap && group.size() < (size_t)PSELL_LANES) {
+                            uni.swap(tmp);
+                            group.push_back(r);
+                            continue;
+                        }
+                        if (pass == 0 && group.size() < 48 && uni.size() + 1 < cap) {
+                            deferred.push_back(r);  // an outlier (a neighbouring gene's isoform): try again in the second pass
+                            continue;
+                        }
+                        close_group();
+                        uni.assign(cb, ce);
+                        group.push_back(r);
+                    }
+                    close_group();
+                }
+            }
+            rb.swap(keep_b);
         }
         out.rows_a1 = (int64_t)ra1.size();
         out.rows_a = (int64_t)(ra1.size() + ra2.size());
@@ -189,6 +258,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         rows.insert(rows.end(), rb.begin(), rb.end());
         run_end.swap(e1);
         run_end.insert(run_end.end(), e2.begin(), e2.end());
+        is_union.swap(u1);
+        is_union.insert(is_union.end(), u2.begin(), u2.end());
     }
 
     lap("runs / stream split");
@@ -249,11 +320,26 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
     slice_rows.reserve(PSELL_LANES);
     std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
+    std::vector<uint32_t> pattern, utmp;  // transcript set of the slice being closed (uniform streams)
     bool prev_uniform = false;
+    bool slice_union = false;  // the slice being formed is a union slice
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
         uint32_t w = 0;
         for (uint32_t r : slice_rows) w = std::max<uint32_t>(w, (uint32_t)(rowptr[r + 1] - rowptr[r]));
+        if (cur_stream < 2) {  // the slice's transcript set: its rows' common set, or their union
+            const uint32_t r0 = slice_rows[0];
+            pattern.assign(col + rowptr[r0], col + rowptr[r0 + 1]);
+            if (slice_union) {
+                for (size_t lane = 1; lane < slice_rows.size(); ++lane) {
+                    const uint32_t r = slice_rows[lane];
+                    utmp.resize(pattern.size() + (size_t)(rowptr[r + 1] - rowptr[r]));
+                    utmp.resize((size_t)(std::set_union(pattern.begin(), pattern.end(), col + rowptr[r], col + rowptr[r + 1], utmp.begin()) - utmp.begin()));
+                    pattern.swap(utmp);
+                }
+            }
+            w = (uint32_t)pattern.size();
+        }
         const size_t base = out.data.size();
         if (cur_stream < 2) {
             // uniform streams: the 64 fragments share one transcript set, so the column ids are stored once:
@@ -267,12 +353,19 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
             uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
             float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
-            const uint64_t b0 = rowptr[slice_rows[0]];
-            for (uint32_t t = 0; t < w; ++t) hdr[t] = col_local[col[b0 + t]];
+            for (uint32_t t = 0; t < w; ++t) hdr[t] = col_local[pattern[t]];
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
-                const uint64_t b = rowptr[slice_rows[lane]];
+                const uint64_t b = rowptr[slice_rows[lane]], e = rowptr[slice_rows[lane] + 1];
                 // element r of row t sits at position (r + 4 t) & 63: bank-conflict-free operand reads for the MFMA phase
-                for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[b + t];
+                if (!slice_union) {
+                    for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[b + t];
+                } else {  // the row's entries at the positions of their transcripts in the union, zeros elsewhere
+                    uint32_t t = 0;
+                    for (uint64_t k = b; k < e; ++k) {
+                        while (pattern[t] != col[k]) ++t;
+                        vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[k];
+                    }
+                }
             }
         } else {
             // mixed stream: float val[w][64]; uint16 lcol[w][64], padded to a multiple of 256 bytes
@@ -300,7 +393,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // flags: bit0 = all 64 lanes hold rows with one and the same transcript set ("uniform"),
         //        bit1 = uniform and the same set as the previous slice of this tile ("continues")
         uint8_t flags = 0;
-        {
+        if (cur_stream < 2) {
+            flags |= 1;
+            if (prev_uniform && tile_nslices > 0 && prev_pattern == pattern) flags |= 2;
+            prev_pattern = pattern;
+            prev_uniform = true;
+        } else {
             const uint32_t r0 = slice_rows[0];
             const uint64_t b0 = rowptr[r0], len0 = rowptr[r0 + 1] - b0;
             bool uni = true;
@@ -311,9 +409,6 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
             if (uni) {
                 flags |= 1;
-                if (prev_uniform && tile_nslices > 0 && prev_pattern.size() == len0 &&
-                    std::equal(prev_pattern.begin(), prev_pattern.end(), col + b0))
-                    flags |= 2;
                 prev_pattern.assign(col + b0, col + b0 + len0);
             }
             prev_uniform = uni;
@@ -330,6 +425,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         ++out.num_slices;
         ++tile_nslices;
         slice_rows.clear();
+        slice_union = false;
     };
     auto close_tile = [&]() {
         if (tile_nslices == 0) return;
@@ -366,6 +462,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
         slice_rows.push_back(r);
+        if (cur_stream < 2 && is_union[ri]) slice_union = true;
         const bool boundary = cur_stream < 2 ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
         if (boundary) {
             close_slice();

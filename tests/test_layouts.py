@@ -225,7 +225,9 @@ def test_psell_layout_reproduces_oracle_on_fixture(lm_fixture):
     ro = ps["row_order"]
     assert sorted(ro[ro != 0xFFFFFFFF].tolist()) == list(range(f["m"]))  # every fragment exactly once
     assert ps["max_tile_cols"] <= 1024
-    assert ps["padded_nnz"] < 1.6 * ps["nnz"], ps["padded_nnz"] / ps["nnz"]
+    # (stored entries / non-zeros: zero lanes of partial slices and the zeros of union slices, on a sample of only 19 743
+    # fragments in ~1 300 distinct transcript sets; 1.02 at BASELINE's C2)
+    assert ps["padded_nnz"] < 1.8 * ps["nnz"], ps["padded_nnz"] / ps["nnz"]
     rng = np.random.default_rng(0)
     x = rng.dirichlet(np.ones(f["n"]), size=3).astype(np.float32)
     lp, g = _emulate_psell(ps, x, f["n"])

@@ -21,10 +21,12 @@ f(out)  # reset
 fit.run(20); fit.sync()
 f(out)
 v = np.array(list(out), np.float64)
-names = {0: "between tiles: schedule read + prefetch issue", 1: "slice bookkeeping", 2: "waiting for the DMA",
-         3: "run change: flush + column lookup", 4: "phase 1 (LDS reads, refill, MFMA, weights)", 5: "phase 2 (MFMA)",
-         6: "refill (wide stream)", 7: "end of the wave's slices: run flush + queue drain",
-         8: "waiting for the other waves (barrier A)", 9: "tile flush (atomics) + barrier B", 10: "kernel tail (lp)"}
+names = {0: "prefetch issue for the next tile", 1: "slice bookkeeping", 2: "waiting for the DMA",
+         3: "run change: flush + column lookup", 11: "operand reads issued and landed (lgkmcnt 0)", 6: "ring refill (DMA issue)",
+         14: "phase 1 MFMAs", 4: "weights", 5: "phase 2 (MFMA)",
+         12: "mixed tile: the two sweeps", 7: "end of the wave's slices: run flush + queue drain",
+         13: "next ring started (before / after the barrier)", 8: "waiting for the other waves (barrier A)",
+         15: "tile flush issue (LDS -> global atomics)", 9: "barrier B", 10: "kernel tail (lp)"}
 tot = v[:16].sum()
 for i, nm in names.items():
     print("%-52s %5.1f %%" % (nm, 100 * v[i] / tot))

@@ -23,7 +23,7 @@ try:
     json.dump(bench, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"), indent=1)
 except Exception:
     pass
-dom = [k for k in s.get("pmc", {}) if "loglik_fused_kernel<6" in k]
+dom = [k for k in s.get("pmc", {}) if "loglik_stream_kernel<6" in k]
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), "",
          "Command: `tools/profile.sh %s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-steps 0`" % tag,
          "plus separate `--pmc` passes (SQ / LDS / MFMA / FETCH_SIZE / WRITE_SIZE).", "",
