@@ -35,12 +35,7 @@ typedef struct {
     const uint8_t *slice_flags; /* [num_slices] bit0 uniform, bit1 continues previous      */
     int64_t num_tiles_a;        /* tiles [0, num_tiles_a) hold COMPACT slices:             */
                                 /*   uint16 lcol[128] (w used); float val[w][64]           */
-    int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): transcript sets of <= 18        */
-    /* transposed copy of the mixed tiles (tiles >= num_tiles_a), see loglik_internal.hpp:          */
-    int64_t num_groups, tdata_bytes;
-    const uint8_t *tdata;        /* group: uint16 vcol[64]; float vval[width][64]; uint16 vrow[width][64] */
-    const uint32_t *tgroup_off;  /* [num_groups+1], 128-byte units                          */
-    const uint32_t *ttile_group; /* [num_tiles - num_tiles_a + 1]                           */
+    int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): transcript sets of <= 16        */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

@@ -63,9 +63,7 @@ class PsellView(C.Structure):
                 ("data_bytes", C.c_int64), ("dict_len", C.c_int64), ("max_row_nnz", C.c_int32),
                 ("max_tile_cols", C.c_int32), ("data", u8p), ("slice_off", u32p), ("tile_slice", u32p),
                 ("tile_dict", u32p), ("dict", u32p), ("row_order", u32p), ("slice_ks", f32p), ("slice_flags", u8p),
-                ("num_tiles_a", C.c_int64), ("num_tiles_a1", C.c_int64),
-                ("num_groups", C.c_int64), ("tdata_bytes", C.c_int64), ("tdata", u8p), ("tgroup_off", u32p),
-                ("ttile_group", u32p)]
+                ("num_tiles_a", C.c_int64), ("num_tiles_a1", C.c_int64)]
 
 
 def lib():

@@ -74,8 +74,6 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->slice_flags = h.slice_flags.data();
     v->num_tiles_a = h.num_tiles_a;
     v->num_tiles_a1 = h.num_tiles_a1;
-    v->num_groups = h.num_groups; v->tdata_bytes = (int64_t)h.tdata.size();
-    v->tdata = h.tdata.data(); v->tgroup_off = h.tgroup_off.data(); v->ttile_group = h.ttile_group.data();
     return POLEE_OK;
 }
 

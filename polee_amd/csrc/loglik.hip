@@ -2,13 +2,14 @@
 // Replaces pAt_mul_B!/pAt_mulinv_B! (src/sparse.jl:6-40) and log_likelihood /
 // factored_log_likelihood (src/likelihood.jl:36-85) with ONE pass over X that evaluates
 // K expression vectors at once:
-//     s_i[k] = sum_j X_ij x_j[k]        (row sums, in registers: one lane owns one row)
+//     s_i[k] = sum_j X_ij x_j[k]
 //     lp[k] += ks_i log s_i[k]
 //     g_j[k] += X_ij ks_i / s_i[k]      (accumulated per tile in LDS, flushed once)
 // The reference makes two passes (CSR for s, CSC for g) per draw, i.e. 2*K passes per VI
-// step; this file makes one, as a single launch (loglik_fused_kernel) whose workgroups are of
-// three kinds, one per row stream of the PSELL layout (loglik_internal.hpp).
-// Roofline: HBM-bound, no MFMA (0.25 flop/B).
+// step; this file makes one: loglik_stream_kernel, a persistent launch that streams the
+// uniform slices of the PSELL layout (loglik_internal.hpp) through LDS rings.
+// Roofline: HBM-bound by bytes (0.25 flop/B); the two small dense products per slice run on the
+// exact-f32 matrix instruction because that removes the cross-lane sums, not for flops.
 #include "loglik_internal.hpp"
 #include "wave.hpp"
 
@@ -113,9 +114,6 @@ struct PsellArgs {
     double *lp;
     int lcap;
     int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layout
-    // transposed copy of the mixed tiles (PsellHost::tdata)
-    const uint8_t *tdata;
-    const uint32_t *tgroup_off, *ttile_group;
     // the persistent streaming kernel
     int tiles_a1;           // tiles [0, tiles_a1): stream A1, [tiles_a1, tiles_a): A2
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
@@ -227,140 +225,7 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile
     psell_tile_body<K, WANT_LP, HAS_KS>(A, tile, lds, lds + (size_t)A.lcap * K, lp_red);
 }
 
-// ---- stream B inside the fused launch: row sweep, then column sweep ---------------------------------------
-// Sweep 1 (lane = fragment, row-major slices) leaves the weights W[row][k] = ks / s of the tile's <= 1024
-// fragments in LDS.  Sweep 2 walks the tile's TRANSPOSED copy: every lane owns a piece (<= 32 entries) of one
-// transcript's entries and gathers the weights of their fragments, G[c][k] = sum_e v_e W[row_e][k] -- no
-// cross-lane sums, one LDS add per (piece, k).
-template <int K, bool WANT_LP, bool HAS_KS>
-__device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrows, float *xw, float *gw, double *lp_red)
-{
-    const uint8_t *__restrict__ data = A.data;
-    const uint32_t *__restrict__ slice_off = A.slice_off;
-    const uint32_t *__restrict__ dict = A.dict;
-    const float *__restrict__ slice_ks = A.slice_ks;
-    const float *__restrict__ x = A.x;
-    float *__restrict__ g = A.g;
-
-    const uint32_t d0 = A.tile_dict[tile];
-    const int L = (int)(A.tile_dict[tile + 1] - d0);
-    if (L > A.lcap) return;  // a tile around a fragment with > 256 transcripts: left to loglik_psell_kernel
-    for (int i = threadIdx.x; i < L * K; i += 256) {
-        const int l = i / K, k = i - l * K;
-        xw[i] = x[(size_t)dict[d0 + l] * K + k];
-        gw[i] = 0.0f;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t s0 = A.tile_slice[tile], s1 = A.tile_slice[tile + 1];
-    double lpacc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
-
-    for (uint32_t s = s0 + wave; s < s1; s += 4) {
-        const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
-        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
-        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
-        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
-        float sacc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
-        int t = 0;
-        for (; t + 8 <= w; t += 8) {
-            float v[8];
-            int c[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = vals[(t + u) * 64];
-                c[u] = cols[(t + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
-        }
-        {  // remainder (< 8): loads predicated, all in flight together
-            float v[8];
-            int c[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = t + u < w;
-                v[u] = live ? vals[(t + u) * 64] : 0.0f;
-                c[u] = live ? (int)cols[(t + u) * 64] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
-        }
-        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
-        float *wr = wrows + ((size_t)(s - s0) * 64 + lane) * K;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            wr[k] = fast_weight(ksv, sacc[k]);
-            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
-        }
-    }
-    __syncthreads();
-
-    const int tb = tile - A.tiles_a;
-    const uint32_t g0 = A.ttile_group[tb], g1 = A.ttile_group[tb + 1];
-    for (uint32_t gi = g0 + wave; gi < g1; gi += 4) {
-        const uint32_t off = A.tgroup_off[gi];
-        const int width = (int)((A.tgroup_off[gi + 1] - off - 1u) / 3u);
-        const uint8_t *base = A.tdata + (size_t)off * 128;
-        const int vc = reinterpret_cast<const uint16_t *>(base)[lane];
-        const float *vval = reinterpret_cast<const float *>(base + 128) + lane;
-        const uint16_t *vrow = reinterpret_cast<const uint16_t *>(base + 128 + (size_t)width * 256) + lane;
-        float acc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-        int e = 0;
-        for (; e + 8 <= width; e += 8) {
-            float v[8];
-            int r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = vval[(e + u) * 64];
-                r[u] = vrow[(e + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
-        }
-        {
-            float v[8];
-            int r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = e + u < width;
-                v[u] = live ? vval[(e + u) * 64] : 0.0f;
-                r[u] = live ? (int)vrow[(e + u) * 64] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (acc[k] != 0.0f) atomicAdd(gw + vc * K + k, acc[k]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L * K; i += 256) {
-        const int l = i / K, k = i - l * K;
-        const float v = gw[i];
-        if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
-    }
-    if (WANT_LP) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double v = lpacc[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-            if (lane == 0) lp_red[wave] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) atomicAdd(A.lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
-            __syncthreads();
-        }
-    }
-}
-
-// ---- streams A and B in ONE persistent launch ---------------------------------------------------------------
+// ---- the uniform streams in ONE persistent launch --------------------------------------------------------------
 // A uniform slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs of
 // consecutive slices with the same set are marked by the builder.  For such a slice V[t][r] (w x 64):
 //     S[r][k]  = sum_t V[t][r] x[c_t][k]          (phase 1)
@@ -382,6 +247,14 @@ __device__ inline void mixed_tile_body(const PsellArgs &A, int tile, float *wrow
 #ifndef POLEE_DMA_POLICY
 #define POLEE_DMA_POLICY " nt"  // X is read once per pass: non-temporal keeps it from evicting x / g lines
 #endif
+// a wave-uniform pointer the compiler cannot prove uniform, as an SGPR pair
+__device__ inline const void *uniform_ptr(const void *p)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
 // LDS-DMA forms: wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane; the LDS destination is
 // M0 + lane * (bytes per lane).  The leading s_nop 4 covers a base that has just come out of v_readfirstlane
 // (VALU-written SGPR -> VMEM read: 5 wait states, which the compiler does not insert for an asm statement).  (M0 is not restored: nothing else in these kernels uses it -- LDS instructions
@@ -484,7 +357,7 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
     int issued = __builtin_amdgcn_readfirstlane(ws.issued), islot = __builtin_amdgcn_readfirstlane(ws.islot);
     target = __builtin_amdgcn_readfirstlane(target);
     const uint32_t voff = (uint32_t)(threadIdx.x & 63) * 16u;
-    const uint8_t *src = ws.gsrc + (size_t)issued * 1024;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(uniform_ptr(ws.gsrc + (size_t)issued * 1024));
     for (; issued < target; ++issued) {
         dma_1k(src, voff, ring_lds + (uint32_t)islot * 1024u);
         src += 1024;
@@ -778,101 +651,6 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
     if (pend_w != 0) flush();
 }
 
-// sweep 1 + sweep 2 of one mixed (stream B) tile inside the persistent kernel; the tile's x window is in LDS (xw),
-// gw is zero on entry; W rows live in the ring area (no ring is active while a mixed tile runs).
-template <int K, bool WANT_LP, bool HAS_KS>
-__device__ inline void mixed_stream(const PsellArgs &A, int tile, uint32_t s0, uint32_t s1, int wave, float *wrows,
-                                    const float *xw, float *gw, double (&lpacc)[K])
-{
-    const uint8_t *__restrict__ data = A.data;
-    const uint32_t *__restrict__ slice_off = A.slice_off;
-    const float *__restrict__ slice_ks = A.slice_ks;
-    const int lane = threadIdx.x & 63;  // (wave: the caller's wave-uniform copy)
-
-    for (uint32_t s = s0 + wave; s < s1; s += 4) {
-        const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
-        const int w = (int)(((slice_off[s + 1] & PSELL_OFF_MASK) - off) / 3u);
-        const float *vals = reinterpret_cast<const float *>(data + (size_t)off * 128) + lane;
-        const uint16_t *cols = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
-        float sacc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
-        int t = 0;
-        for (; t + 8 <= w; t += 8) {
-            float v[8];
-            int c[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = vals[(t + u) * 64];
-                c[u] = cols[(t + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
-        }
-        {  // remainder (< 8): loads predicated, all in flight together
-            float v[8];
-            int c[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = t + u < w;
-                v[u] = live ? vals[(t + u) * 64] : 0.0f;
-                c[u] = live ? (int)cols[(t + u) * 64] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
-        }
-        const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
-        float *wr = wrows + ((size_t)(s - s0) * 64 + lane) * K;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            wr[k] = fast_weight(ksv, sacc[k]);
-            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] += (double)ksv * log((double)sacc[k]);
-        }
-    }
-    __syncthreads();
-
-    const int tb = tile - A.tiles_a;
-    const uint32_t g0 = A.ttile_group[tb], g1 = A.ttile_group[tb + 1];
-    for (uint32_t gi = g0 + wave; gi < g1; gi += 4) {
-        const uint32_t off = A.tgroup_off[gi];
-        const int width = (int)((A.tgroup_off[gi + 1] - off - 1u) / 3u);
-        const uint8_t *base = A.tdata + (size_t)off * 128;
-        const int vc = reinterpret_cast<const uint16_t *>(base)[lane];
-        const float *vval = reinterpret_cast<const float *>(base + 128) + lane;
-        const uint16_t *vrow = reinterpret_cast<const uint16_t *>(base + 128 + (size_t)width * 256) + lane;
-        float acc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-        int e = 0;
-        for (; e + 8 <= width; e += 8) {
-            float v[8];
-            int r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = vval[(e + u) * 64];
-                r[u] = vrow[(e + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
-        }
-        {
-            float v[8];
-            int r[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = e + u < width;
-                v[u] = live ? vval[(e + u) * 64] : 0.0f;
-                r[u] = live ? (int)vrow[(e + u) * 64] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fma_row<K>(v[u], wrows + r[u] * K, acc);
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (acc[k] != 0.0f) atomicAdd(gw + vc * K + k, acc[k]);
-    }
-}
-
 #ifdef POLEE_STAMPS
 extern "C" int polee_debug_read_stamps(unsigned long long *out)
 {
@@ -894,12 +672,12 @@ __global__ void xwin_gather_kernel(const uint32_t *__restrict__ dict, const floa
 }
 
 // LDS layout of the streaming kernel:
-//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2); stream B's weight rows][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
+//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2)][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
 template <int K>
 constexpr uint32_t stream_ring_total()
 {
-    return PSELL_TILE_SLICES_B * 64 * K * 4 > (int)STREAM_RINGS ? (uint32_t)(PSELL_TILE_SLICES_B * 64 * K * 4) : STREAM_RINGS;
+    return STREAM_RINGS;
 }
 template <int K>
 constexpr uint32_t stream_xw_bytes()  // whole 1 KiB pieces
@@ -939,13 +717,16 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     unsigned long long n_slices = 0, n_tiles = 0;
 #endif
 
-    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a ? 1 : 2); };
+    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : 1; };  // A1 / A2 (the schedule holds no others)
     // this wave's share [sb, se) of an A tile's slices: a contiguous block, so that runs stay inside one wave
-    auto share = [&](int kind, uint32_t s0, uint32_t s1, uint32_t &sb, uint32_t &se) {
-        const uint32_t nw = kind == 0 ? 4u : 2u;
-        const uint32_t per = (s1 - s0 + nw - 1u) / nw;
-        sb = (uint32_t)wave < nw ? min(s0 + (uint32_t)wave * per, s1) : s1;
-        se = (uint32_t)wave < nw ? min(sb + per, s1) : s1;
+    auto share = [&](int kind, const PosDesc &t, uint32_t &sb, uint32_t &se) {
+        const int nw = kind == 0 ? 4 : 2;
+        uint32_t a1 = t.c1, a2 = t.c2, a3 = t.c3;
+        asm volatile("" : "+s"(a1), "+s"(a2), "+s"(a3));  // (opaque: or the selects below become an indexed load of a PosDesc kept in scratch memory)
+        const uint32_t lo = wave == 0 ? t.s0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));
+        const uint32_t hi = wave + 1 >= nw ? t.s1 : (wave == 0 ? a1 : (wave == 1 ? a2 : a3));
+        sb = wave < nw ? lo : t.s1;
+        se = wave < nw ? hi : t.s1;
     };
     // requests everything tile `t` needs besides its slice stream; returns the number of vector-memory operations
     auto prefetch = [&](const PosDesc &t, int buf) -> int {
@@ -954,19 +735,19 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4;
         const uint32_t dst = lds_addr(xw_of(buf));
         for (int p = wave; p < npx; p += 4) {
-            dma_1k_keep(src + (size_t)p * 1024, (uint32_t)lane * 16u, dst + (uint32_t)p * 1024u);
+            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)lane * 16u, dst + (uint32_t)p * 1024u);
             ++cnt;
         }
         if ((uint32_t)wave * 64u < t.L) {  // transcript ids of the dictionary (for the flush)
-            dma_256(A.dict + t.d0 + (uint32_t)wave * 64u, min((uint32_t)lane, t.L - 1u - (uint32_t)wave * 64u) * 4u,
+            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)lane, t.L - 1u - (uint32_t)wave * 64u) * 4u,
                     lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
             ++cnt;
         }
         const int kind = kind_of(t.tile);
-        if (kind < 2) {  // slice offsets of this wave's share, one per lane
+        {  // slice offsets of this wave's share, one per lane
             uint32_t sb, se;
-            share(kind, t.s0, t.s1, sb, se);
-            dma_256(A.slice_off + sb, min((uint32_t)lane, se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
+            share(kind, t, sb, se);
+            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)lane, se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
             ++cnt;
         }
         return cnt;
@@ -977,15 +758,14 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     auto start_ring = [&](const PosDesc &t) {
         const int kind = kind_of(t.tile);
         ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
-        if (kind >= 2) return;
         uint32_t sb, se;
-        share(kind, t.s0, t.s1, sb, se);
+        share(kind, t, sb, se);
         ws.ent = entb[wave * 64 + lane];
         ws.nsl = (int)(se - sb);
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
-        ws.gsrc = A.data + (size_t)cb * 128;
+        ws.gsrc = reinterpret_cast<const uint8_t *>(uniform_ptr(A.data + (size_t)cb * 128));
         if (kind == 0) {
             ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, ahead ? min(ahead, (int)(STREAM_RB1 / 1024u)) : (int)(STREAM_RB1 / 1024u)));
         } else {
@@ -994,10 +774,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         ws.primed = ws.issued;
     };
 
-    double lp_a = 0.0;  // uniform tiles: lane (tt, q) holds the share of draw tt
-    double lp_b[K];     // mixed tiles: lane = fragment
-#pragma unroll
-    for (int k = 0; k < K; ++k) lp_b[k] = 0.0;
+    double lp_a = 0.0;  // lane (tt, q) holds the share of draw tt
 
     PosDesc cur = sched[blockIdx.x];
     if (cur.tile == POS_NONE) return;
@@ -1021,7 +798,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         if (wave == 0) {
             // the schedule entry after the next (a scalar load here would stall every tile by its latency; through LDS it
             // arrives in the background like everything else and is read after the tile's barriers)
-            dma_256(sched + blockIdx.x + (size_t)(round + 2u) * G, (uint32_t)(lane & 7) * 4u, lds_addr(descb + (round & 1u) * 64u));
+            dma_256(uniform_ptr(sched + blockIdx.x + (size_t)(round + 2u) * G), (uint32_t)(lane & 7) * 4u, lds_addr(descb + (round & 1u) * 64u));
             ++young;
         }
         STAMP(0);  // between tiles: prefetch issue
@@ -1031,15 +808,12 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
                                                                              , st_acc, st_last
 #endif
             );
-        } else if (kind == 1) {
+        } else {
             uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw, lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                            , st_acc, st_last
 #endif
             );
-        } else {
-            mixed_stream<K, WANT_LP, HAS_KS>(A, (int)cur.tile, cur.s0, cur.s1, wave, reinterpret_cast<float *>(rings), xw_of(buf), gw, lp_b);
-            STAMP(12);  // a mixed tile's two sweeps
         }
 #ifdef POLEE_STAMPS
         n_slices += (unsigned long long)ws.nsl;
@@ -1050,7 +824,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         young = 0;
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
-        const bool early = more && kind < 2 && kind_of(nxt.tile) == kind;
+        const bool early = more && kind_of(nxt.tile) == kind;
         if (early) start_ring(nxt);
         STAMP(13);  // starting the next ring (before the barrier)
         lds_barrier();  // every wave's contributions are in gw
@@ -1091,6 +865,9 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             nxt.s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[2]);
             nxt.d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[3]);
             nxt.L = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[4]);
+            nxt.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[5]);
+            nxt.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[6]);
+            nxt.c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[7]);
         }
         buf ^= 1;
     }
@@ -1099,13 +876,6 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < K) atomicAdd(A.lp + lane, v);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double u = lp_b[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) u += __shfl_down(u, d, 64);
-            if (lane == 0 && u != 0.0) atomicAdd(A.lp + k, u);
-        }
     }
 #ifdef POLEE_STAMPS
     STAMP(10);
@@ -1118,20 +888,16 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #endif
 }
 
-// Static schedule of the streaming kernel for a grid of G workgroups: tiles (all but the few "big" ones) sorted by
-// cost, dealt to the workgroups in snake order (equal sums), and inside every workgroup's list the small latency-bound
-// tiles (streams A2, B) spread evenly between the streaming A1 tiles.
+// Static schedule of the streaming kernel for a grid of G workgroups: the uniform tiles sorted by cost, dealt to the
+// workgroups in snake order (equal sums), and inside every workgroup's list the wide tiles (stream A2, two active
+// waves) spread evenly between the A1 tiles.
 static polee_status ensure_schedule(polee_loglik *ll, int G)
 {
     if (ll->sched_grid == G && ll->d_sched.p) return POLEE_OK;
     const PsellHost &h = ll->host;
-    const int64_t nt = h.num_tiles;
-    std::vector<uint8_t> is_big((size_t)nt, 0);
-    for (uint32_t t : h.big_tiles) is_big[t] = 1;
     std::vector<uint32_t> order;
-    order.reserve((size_t)nt);
-    for (int64_t t = 0; t < nt; ++t)
-        if (!is_big[t]) order.push_back((uint32_t)t);
+    order.reserve((size_t)h.num_tiles_a);
+    for (int64_t t = 0; t < h.num_tiles_a; ++t) order.push_back((uint32_t)t);  // (the mixed tiles behind them go to the per-tile kernel)
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ll->tile_cost[a] > ll->tile_cost[b]; });
     std::vector<std::vector<uint32_t>> lists((size_t)G);
     for (size_t i = 0; i < order.size(); ++i) {
@@ -1161,6 +927,9 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
             d.s1 = h.tile_slice[t + 1];
             d.d0 = h.tile_dict[t];
             d.L = h.tile_cols[t];
+            d.c1 = ll->tile_cut[(size_t)3 * t];
+            d.c2 = ll->tile_cut[(size_t)3 * t + 1];
+            d.c3 = ll->tile_cut[(size_t)3 * t + 2];
         }
     }
     POLEE_TRY(ll->d_sched.upload(ll->ctx, sched));
@@ -1180,7 +949,6 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                ll->d_tdata.p, ll->d_tgroup_off.p, ll->d_ttile_group.p,
                 (int)h.num_tiles_a1, ll->d_xwin.p, nullptr};
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
     static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
@@ -1189,7 +957,8 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
-    if (lds_psell > 48 * 1024 && (!h.big_tiles.empty() || no_ring))
+    const int64_t tiles_b = h.num_tiles - h.num_tiles_a;
+    if (lds_psell > 48 * 1024 && (tiles_b > 0 || no_ring))
         POLEE_HIP_TRY(ctx, hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     if (!no_ring) {
@@ -1211,11 +980,10 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
         if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
         hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
         if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
-        if (!h.big_tiles.empty()) {
-            // tiles around a fragment with more than 128 transcripts (rare, a few rows each) do not fit the streaming
-            // kernel's LDS windows: the schedule leaves them out and the per-tile kernel takes them
-            hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.big_tiles.size()), dim3(256), lds_psell, st,
-                               A, 0, ll->d_big_tiles.p);
+        if (tiles_b > 0) {
+            // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes
+            hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds_psell, st, A,
+                               (int)h.num_tiles_a, (const uint32_t *)nullptr);
         }
     } else {
         // the cross-check switch: every tile as mixed slices with the per-run DPP kernel
@@ -1358,9 +1126,8 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
     if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
-        (s = ll->d_dict.upload(ctx, h.dict)) || (s = ll->d_tdata.upload(ctx, h.tdata)) ||
-        (s = ll->d_tgroup_off.upload(ctx, h.tgroup_off)) || (s = ll->d_ttile_group.upload(ctx, h.ttile_group)) ||
-        (s = ll->d_big_tiles.upload(ctx, h.big_tiles)) || (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (s = ll->d_dict.upload(ctx, h.dict)) ||
+        (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
         loglik_release(ll);
         return s;
     }
@@ -1371,14 +1138,32 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     for (int64_t t = 0; t < h.num_tiles; ++t) {
         const double slice_bytes = 128.0 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
         double c = slice_bytes + 4096.0;
-        if (t >= h.num_tiles_a) {
-            const int64_t tb = t - h.num_tiles_a;
-            c += 128.0 * (double)(h.tgroup_off[h.ttile_group[tb + 1]] - h.tgroup_off[h.ttile_group[tb]]);
-            c *= 2.0;
-        } else if (t >= h.num_tiles_a1) {
-            c *= 1.5;
-        }
+        if (t >= h.num_tiles_a1) c *= 1.5;  // (the wide stream runs on two of the four waves)
         ll->tile_cost[(size_t)t] = (float)c;
+    }
+    // the waves of a uniform tile take contiguous blocks of its slices with about equal matrix-core work
+    // (phase 1: 4 ceil(w / 4) instructions, phase 2: 8 for w <= 8, else 16 per 16 transcripts; + a fixed part)
+    ll->tile_cut.assign((size_t)3 * h.num_tiles, 0u);
+    for (int64_t t = 0; t < h.num_tiles; ++t) {
+        const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
+        uint32_t *cut = &ll->tile_cut[(size_t)3 * t];
+        cut[0] = cut[1] = cut[2] = s1;
+        if (t >= h.num_tiles_a) continue;
+        const int nw = t < h.num_tiles_a1 ? 4 : 2;
+        auto cost = [&](uint32_t sl) {
+            const uint32_t units = (h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK);
+            const int w = (int)(units / 2u) - 1 - (ll->has_ks ? 1 : 0);
+            return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
+        };
+        double total = 0.0;
+        for (uint32_t sl = s0; sl < s1; ++sl) total += cost(sl);
+        double acc = 0.0;
+        int wv = 1;
+        for (uint32_t sl = s0; sl < s1 && wv < nw; ++sl) {
+            acc += cost(sl);
+            // a wave owns at most 63 slices (one offset per lane + the end)
+            while (wv < nw && (acc >= total * wv / nw || sl + 1 - (wv == 1 ? s0 : cut[wv - 2]) >= 63u)) cut[wv++ - 1] = sl + 1;
+        }
     }
     if ((s = ll->d_xwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512)) ||
         (s = ensure_schedule(ll, (int)std::min<int64_t>((int64_t)4 * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1))))) {
@@ -1389,8 +1174,6 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     std::vector<uint8_t>().swap(h.data);
     std::vector<uint32_t>().swap(h.slice_off);
     std::vector<uint32_t>().swap(h.dict);
-    std::vector<uint8_t>().swap(h.tdata);
-    std::vector<uint32_t>().swap(h.tgroup_off);
     std::vector<float>().swap(h.slice_ks);
     std::vector<uint8_t>().swap(h.slice_flags);
     std::vector<uint32_t>().swap(h.row_order);

@@ -12,24 +12,28 @@
 //   * Consecutive slices form a TILE (64 / 8 / 16 slices in streams A1 / A2 / B), the unit of work of one
 //     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
 //     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
-//     pass 128 entries), so an entry costs 4 + 2 = 6 bytes instead of CSR's 4 + 4 (+ row pointers).
-//     Every tile's dictionary starts at a multiple of 4 entries (padded with transcript 0), so that its
-//     x window -- x[dict][K], gathered once per pass into one contiguous buffer by xwin_gather_kernel --
-//     starts 16-byte aligned and reaches LDS by LDS-DMA like the slice stream.
+//     pass 128 entries).  Every tile's dictionary starts at a multiple of 4 entries (padded with
+//     transcript 0), so that its x window -- x[dict][K], gathered once per pass into one contiguous buffer
+//     by xwin_gather_kernel -- starts 16-byte aligned and reaches LDS by LDS-DMA like the slice stream.
 //   * The kernel accumulates the tile's gradient contributions in LDS (ds_add_f32) and flushes L*K
 //     values to HBM per tile.
-//   * Rows are split into three streams: A = slices whose rows all share one transcript set (whole
-//     64-row slices of every run of identical rows, plus run remainders of >= 32 rows, zero padded;
-//     A1 = sets of <= 18 transcripts, A2 = 19..28), B = everything else.  Tiles [0, num_tiles_a1)
-//     are A1, [num_tiles_a1, num_tiles_a) A2, the rest B.  One launch (loglik_fused_kernel)
-//     processes all three with differently specialised workgroups: A by uniform_tile_body (LDS-DMA
-//     streaming, transposed accumulation through LDS, no cross-lane traffic), B by psell_tile_body
-//     (per-run DPP sums).
+//   * Rows are split into three streams, each a contiguous range of tiles:
+//       A1, A2 = UNIFORM slices: all rows of a slice share one transcript set, stored once per slice
+//                (uint16 lcol[128] header + float val[w][64], 4 B per entry): whole 64-row slices of every
+//                run of identical rows, run remainders of >= 32 rows (zero padded), and UNION slices --
+//                the leftover rows of neighbouring sets packed under the union of their sets, with zeros
+//                where a row lacks a transcript (a zero adds nothing to a row sum or a gradient, exactly).
+//                A1 = sets of <= 16 transcripts, A2 = 17..32.  Tiles [0, num_tiles_a1) are A1,
+//                [num_tiles_a1, num_tiles_a) A2.  One persistent launch (loglik_stream_kernel) streams them.
+//       B      = rows with more than 32 transcripts (mixed slices, 6 B per entry): rare; the per-tile
+//                kernel loglik_psell_kernel takes them in a second, small launch.  That kernel also runs
+//                over the uniform slices on request (polee_debug_loglik_force_mixed): the independent second
+//                algorithm of the cross-check tests.
 //   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
 //     share one transcript set) and "continues" (the same set as the previous slice).  Runs of such
 //     slices -- the bulk of real and synthetic data, where many fragments fall into the same
-//     equivalence class -- keep their gradient contributions in one register per lane.
-// HBM traffic per likelihood pass ~ 6 B/nnz (+ padding + dictionaries), read once.
+//     equivalence class -- keep their gradient contributions in registers.
+// HBM traffic per likelihood pass ~ 4.9 B/nnz at BASELINE's C2 (CSR: 8 B + row pointers), read once.
 #pragma once
 #include "common.hpp"
 
@@ -46,16 +50,15 @@ constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
 constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, one 16-row MFMA tile)
 constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two MFMA tiles)
-constexpr int PSELL_VCOL_CAP = 32;         // stream B: entries per virtual column (lane) of the transposed copy
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
-constexpr int PSELL_MIN_UNION_ROWS = 24;    // smallest group of leftover rows stored as a union slice
+constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 
 // One position of the streaming kernel's static schedule (workgroup b walks positions b, b + grid, b + 2 grid, ...).
 struct PosDesc {
     uint32_t tile;    // POS_NONE: the column ends here
     uint32_t s0, s1;  // slices of the tile
     uint32_t d0, L;   // first dictionary entry, entries in use
-    uint32_t pad[3];
+    uint32_t c1, c2, c3;  // uniform tiles: the waves stream slices [s0, c1), [c1, c2), [c2, c3), [c3, s1) (balanced on cost)
 };
 constexpr uint32_t POS_NONE = 0xffffffffu;
 
@@ -76,15 +79,6 @@ struct PsellHost {
     std::vector<uint32_t> big_tiles;   // tiles whose dictionary exceeds PSELL_TILE_COLS_TARGET (a fragment with > 256 transcripts)
     std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
-    // stream B only: the tile's entries a second time, grouped by transcript ("virtual columns": a transcript
-    // of the tile with many entries is cut into pieces of <= PSELL_VCOL_CAP entries; pieces are sorted by
-    // length and packed 64 to a GROUP, one per lane).  Group block:
-    //   uint16 vcol[64] (tile-local transcript id per lane); float vval[width][64]; uint16 vrow[width][64]
-    // (vrow = fragment index inside the tile, slice*64 + lane; padding has vval = 0, vrow = 0).
-    std::vector<uint8_t> tdata;
-    std::vector<uint32_t> tgroup_off;   // [num_groups+1], 128-byte units into tdata
-    std::vector<uint32_t> ttile_group;  // [num_tiles - num_tiles_a + 1] group range of each stream-B tile
-    int64_t num_groups = 0;
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
 };
 
@@ -104,14 +98,13 @@ struct polee_loglik {
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
-    polee::DevBuf<uint8_t> d_tdata;
-    polee::DevBuf<uint32_t> d_tgroup_off, d_ttile_group, d_big_tiles;
     polee::DevBuf<float> d_slice_ks;
     // the streaming kernel: per-pass x windows, static schedule (built for the grid of the first launch)
     polee::DevBuf<float> d_xwin;
     polee::DevBuf<polee::PosDesc> d_sched;
     int sched_grid = 0;
     std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
+    std::vector<uint32_t> tile_cut;  // [3 * num_tiles] slice boundaries between the waves of a uniform tile
     int64_t dict_len = 0;
     int occ_cache[polee::PSELL_MAX_K + 1][2][2] = {};
     // staging for the host-pointer API

@@ -563,82 +563,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         });
         segs.clear();
     }
-    std::vector<uint16_t> col_local((size_t)n, 0);  // (scratch of the transposed-copy pass below)
     lap("slices and tiles");
-    // 3. stream B: transposed copy of every tile (see PsellHost::tdata)
-    {
-        const int64_t ntb = out.num_tiles - out.num_tiles_a;
-        out.ttile_group.assign(1, 0);
-        out.tgroup_off.assign(1, 0);
-        std::vector<uint32_t> cnt, start, piece_col, piece_beg, piece_len, order;
-        std::vector<uint16_t> erow;
-        std::vector<float> eval;
-        for (int64_t tb = 0; tb < ntb; ++tb) {
-            const int64_t tile = out.num_tiles_a + tb;
-            const uint32_t d0 = out.tile_dict[tile], L = out.tile_cols[tile];
-            const uint32_t s0 = out.tile_slice[tile], s1 = out.tile_slice[tile + 1];
-            for (uint32_t l = 0; l < L; ++l) col_local[out.dict[d0 + l]] = (uint16_t)l;
-            // counting sort of the tile's entries by tile-local transcript id
-            cnt.assign(L + 1, 0);
-            for (uint32_t s = s0; s < s1; ++s)
-                for (int lane = 0; lane < PSELL_LANES; ++lane) {
-                    const uint32_t r = out.row_order[(size_t)s * 64 + lane];
-                    if (r == 0xffffffffu) continue;
-                    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) ++cnt[col_local[col[k]] + 1];
-                }
-            for (uint32_t l = 0; l < L; ++l) cnt[l + 1] += cnt[l];
-            start.assign(cnt.begin(), cnt.end());
-            erow.resize(cnt[L]);
-            eval.resize(cnt[L]);
-            for (uint32_t s = s0; s < s1; ++s)
-                for (int lane = 0; lane < PSELL_LANES; ++lane) {
-                    const uint32_t r = out.row_order[(size_t)s * 64 + lane];
-                    if (r == 0xffffffffu) continue;
-                    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-                        const uint32_t p = start[col_local[col[k]]]++;
-                        erow[p] = (uint16_t)((s - s0) * 64 + lane);
-                        eval[p] = val[k];
-                    }
-                }
-            // cut into pieces of <= PSELL_VCOL_CAP entries, longest first
-            piece_col.clear(); piece_beg.clear(); piece_len.clear();
-            for (uint32_t l = 0; l < L; ++l)
-                for (uint32_t b = cnt[l]; b < cnt[l + 1]; b += PSELL_VCOL_CAP) {
-                    piece_col.push_back(l);
-                    piece_beg.push_back(b);
-                    piece_len.push_back(std::min<uint32_t>(PSELL_VCOL_CAP, cnt[l + 1] - b));
-                }
-            order.resize(piece_col.size());
-            for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-            std::stable_sort(order.begin(), order.end(),
-                             [&](uint32_t a, uint32_t b) { return piece_len[a] > piece_len[b]; });
-            for (size_t g0 = 0; g0 < order.size(); g0 += PSELL_LANES) {
-                const size_t g1 = std::min(order.size(), g0 + PSELL_LANES);
-                const uint32_t width = piece_len[order[g0]];
-                const size_t base = out.tdata.size();
-                out.tdata.resize(base + 128 + (size_t)width * 384, 0);
-                uint16_t *vcol = reinterpret_cast<uint16_t *>(out.tdata.data() + base);
-                float *vval = reinterpret_cast<float *>(out.tdata.data() + base + 128);
-                uint16_t *vrow = reinterpret_cast<uint16_t *>(out.tdata.data() + base + 128 + (size_t)width * 256);
-                for (size_t i = g0; i < g1; ++i) {
-                    const uint32_t pc = order[i], lane = (uint32_t)(i - g0);
-                    vcol[lane] = (uint16_t)piece_col[pc];
-                    for (uint32_t e = 0; e < piece_len[pc]; ++e) {
-                        vval[(size_t)e * 64 + lane] = eval[piece_beg[pc] + e];
-                        vrow[(size_t)e * 64 + lane] = erow[piece_beg[pc] + e];
-                    }
-                }
-                out.tgroup_off.push_back((uint32_t)(out.tdata.size() / 128));
-                ++out.num_groups;
-            }
-            out.ttile_group.push_back((uint32_t)out.num_groups);
-        }
-        if (out.tdata.size() / 128 >= (1ull << 32)) return "matrix too large (transposed copy of the mixed stream)";
-        out.stream_bytes[2] += (int64_t)out.tdata.size();
-    }
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
-    lap("transposed copy (B)");
     if (out.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
     // the two flag bits of slice s ride in the top bits of slice_off[s] (one scalar/lane load per slice)
     for (int64_t s = 0; s < out.num_slices; ++s) out.slice_off[s] |= (uint32_t)(out.slice_flags[s] & 3u) << 30;

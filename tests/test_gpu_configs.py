@@ -107,7 +107,9 @@ def test_c1_whole_fit_replayed_against_oracle(P):
     so, to = O.Sample(m, n, colptr, rowval, nzval), O.PTT(parents, js)
     steps, K = 500, 6
     z0 = O.randn(steps * K * (n - 1), 17)
+    O.set_num_threads(min(8, O.physical_cores()))  # (12 000 parallel regions over 1 000 transcripts: hundreds of threads only add fork/join time)
     ref = O.approximate_likelihood(so, to, smp["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False)
+    O.set_num_threads(O.physical_cores())
     got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
                                    gradonly=False)
     rel = np.abs(got["lp_mean"] - ref["lp_mean"]) / np.abs(ref["lp_mean"])

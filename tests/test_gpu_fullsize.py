@@ -27,8 +27,9 @@ def test_c2_layout_accounts_for_every_nonzero(c2):
     info = s.info
     assert info["nnz"] == smp["nnz"] and info["num_empty_rows"] == 0
     assert sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == M
-    assert info["padded_nnz"] < 1.1 * info["nnz"]
-    assert info["stream_nnz"][0] > 0.5 * info["nnz"]  # most of X is in uniform slices
+    assert info["padded_nnz"] < 1.15 * info["nnz"]  # (zero lanes of partial slices + the zeros of union slices)
+    assert info["stream_nnz"][0] > 0.5 * info["nnz"]  # most of X is in narrow uniform slices
+    assert info["stream_nnz"][2] == 0  # no fragment of this sample has more than 32 transcripts: nothing is left to the mixed stream
 
 
 def test_c2_homogeneity_and_kernel_cross_check(c2):

@@ -150,9 +150,6 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     out["tile_dict"] = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).copy()
     out["dict"] = np.ctypeslib.as_array(v.dict, shape=(v.dict_len,)).copy()
     out["row_order"] = np.ctypeslib.as_array(v.row_order, shape=(v.num_slices * 64,)).copy()
-    out["tdata"] = np.ctypeslib.as_array(v.tdata, shape=(v.tdata_bytes,)).copy() if v.tdata_bytes else np.zeros(0, np.uint8)
-    out["tgroup_off"] = np.ctypeslib.as_array(v.tgroup_off, shape=(v.num_groups + 1,)).copy()
-    out["ttile_group"] = np.ctypeslib.as_array(v.ttile_group, shape=(v.num_tiles - v.num_tiles_a + 1,)).copy()
     out["ks"] = None if not v.slice_ks else np.ctypeslib.as_array(v.slice_ks, shape=(v.num_slices * 64,)).copy()
     L.lib().polee_debug_psell_free(h)
     return out
@@ -168,9 +165,6 @@ def _emulate_psell(ps, x, n):
         dic = ps["dict"][d0:d1].astype(np.int64)
         xw = x[:, dic].astype(np.float32)
         gw = np.zeros((K, d1 - d0))
-        mixed = t >= ps["num_tiles_a"]
-        s_first = int(ps["tile_slice"][t])
-        wrows = np.zeros((K, 64 * (int(ps["tile_slice"][t + 1]) - s_first)))
         for s in range(ps["tile_slice"][t], ps["tile_slice"][t + 1]):
             off = int(ps["slice_off"][s]) * 128
             nbytes = int(ps["slice_off"][s + 1]) * 128 - off
@@ -196,23 +190,7 @@ def _emulate_psell(ps, x, n):
                 live = sacc > 0
                 wk = np.where(live, ksv / np.where(live, sacc, 1), 0.0)
                 lp[k] += (ksv[live] * np.log(sacc[live])).sum()
-                if mixed:  # mixed_tile_body: weights go to LDS, the gradient comes from the transposed copy
-                    wrows[k, (s - s_first) * 64:(s - s_first + 1) * 64] = wk
-                else:
-                    np.add.at(gw[k], cols.ravel(), (vals * wk[None, :]).ravel())
-        if mixed:
-            tb = t - ps["num_tiles_a"]
-            td = ps["tdata"]
-            for gi in range(ps["ttile_group"][tb], ps["ttile_group"][tb + 1]):
-                off = int(ps["tgroup_off"][gi]) * 128
-                width = (int(ps["tgroup_off"][gi + 1]) * 128 - off - 128) // 384
-                assert 1 <= width <= 32
-                vcol = td[off:off + 128].view(np.uint16).astype(np.int64)
-                vval = td[off + 128:off + 128 + width * 256].view(np.float32).reshape(width, 64).astype(np.float64)
-                vrow = td[off + 128 + width * 256:off + 128 + width * 384].view(np.uint16).reshape(width, 64).astype(np.int64)
-                assert vrow.max() < wrows.shape[1] and vcol.max() < d1 - d0
-                for k in range(K):
-                    np.add.at(gw[k], vcol, (vval * wrows[k][vrow]).sum(axis=0))
+                np.add.at(gw[k], cols.ravel(), (vals * wk[None, :]).ravel())
         for k in range(K):  # (a tile's dictionary is padded with transcript 0 to a multiple of 4 entries)
             np.add.at(g[k], dic, gw[k])
     return lp, g

@@ -31,7 +31,7 @@ ts = np.ctypeslib.as_array(v.tile_slice, shape=(v.num_tiles + 1,)).astype(np.int
 td = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).astype(np.int64)
 ta1, ta = int(v.num_tiles_a1), int(v.num_tiles_a)
 print("tiles", v.num_tiles, "A1", ta1, "A2", ta - ta1, "B", v.num_tiles - ta, "slices", v.num_slices, "dict", v.dict_len,
-      "data MB", v.data_bytes / 1e6, "tdata MB", v.tdata_bytes / 1e6)
+      "data MB", v.data_bytes / 1e6)
 for name, a, b in (("A1", 0, ta1), ("A2", ta1, ta), ("B", ta, int(v.num_tiles))):
     if b <= a:
         continue
