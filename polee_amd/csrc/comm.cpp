@@ -24,10 +24,21 @@ Rccl *rccl(std::string &err)
     static bool tried = false;
     if (!tried) {
         tried = true;
-        // a copy that is already in the process (e.g. PyTorch's) wins; otherwise the ROCm one
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-            if (r.lib) break;
+        // RCCL must sit on the SAME HIP runtime as this library (its streams and device pointers are ours).  A process
+        // may hold two ROCm stacks -- /opt/rocm and the one bundled with PyTorch -- so first take the librccl that lies
+        // next to the libamdhip64 this library is bound to; an RCCL copy picked up by name alone may belong to the other
+        // stack (ncclCommInitRank then fails with "unhandled cuda error").
+        Dl_info hip_info;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &hip_info) && hip_info.dli_fname) {
+            std::string dir(hip_info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                    r.lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (r.lib) break;
+                }
+            }
         }
         if (!r.lib)
             for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
