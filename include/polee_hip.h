@@ -210,6 +210,10 @@ typedef struct {
     double max_mu_step, max_omega_step, max_alpha_step; /* 0.2, 0.2, 0.02 */
     int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events  */
     int32_t reserved;
+    const int32_t *gene_of;      /* optional HOST int32[n]: gene index of every transcript (0-based, -1 = none   */
+                                 /* known) = gene_noninformative = true (likelihood-approximation.jl:475-491,     */
+                                 /* 535-538: gene_noninformative_prior! after the effective-length adjustment,   */
+                                 /* which it needs: use_efflen_jacobian must be on).  NULL: off (the CLI default) */
 } polee_vi_opts;
 void polee_vi_default_opts(polee_vi_opts *opts);
 
@@ -301,6 +305,13 @@ polee_status polee_vi_set_comm(polee_vi *vi, polee_comm *comm_or_null);
 polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigma,
                                 const float *alpha, const float *z0_or_null, int32_t ndraws,
                                 uint64_t seed, float *xs);
+
+/* Initial values of the model entry, load_samples_hdf5 (src/estimate.jl:436-455): the mean of ndraws (30 there) draws
+ * z0 -> sinh-asinh -> logistic, y clamped to [LIKAP_Y_EPS, 1 - LIKAP_Y_EPS] -> transform!, each draw divided by the
+ * effective lengths and renormalised; x0 f32 [n].  z0 as in polee_sampler_draw. */
+polee_status polee_sampler_initial_values(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                          const float *efflens, const float *z0_or_null, int32_t ndraws,
+                                          uint64_t seed, float *x0);
 
 /* posterior_mean (src/approx-sampler.jl:86-117): mean over ndraws draws, each clamped to [1e-15, 0.9999999]
  * (f32 accumulation in draw order, as the reference); pm f32 [n].  z0 as in polee_sampler_draw. */

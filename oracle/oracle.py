@@ -296,8 +296,9 @@ def randn(n, seed):
 
 
 def approximate_likelihood(sample, ptt, efflens, num_steps=500, num_mc=6, use_efflen_jacobian=True,
-                           gradonly=True, z0=None, seed=123456789, ks=None, init_only=False):
-    """src/likelihood-approximation.jl:395-575. Returns dict(mu, omega, alpha[, elbo, lp_mean])."""
+                           gradonly=True, z0=None, seed=123456789, ks=None, init_only=False, gene_of=None):
+    """src/likelihood-approximation.jl:395-575. Returns dict(mu, omega, alpha[, elbo, lp_mean]).
+    gene_of (int32[n], -1 = no gene known): gene_noninformative = true (:475-491, 535-538)."""
     efflens = _f32(efflens)
     nm1 = sample.n - 1
     mu, omega, alpha = (np.zeros(nm1, np.float32) for _ in range(3))
@@ -308,10 +309,16 @@ def approximate_likelihood(sample, ptt, efflens, num_steps=500, num_mc=6, use_ef
         assert z0.size == num_steps * num_mc * nm1
     if ks is not None:
         ks = np.ascontiguousarray(ks, dtype=np.int64)
+    ng = 0
+    if gene_of is not None:
+        gene_of = np.ascontiguousarray(gene_of, np.int32)
+        assert gene_of.size == sample.n
+        ng = int(gene_of.max(initial=-1)) + 1
     rc = lib().oracle_approximate_likelihood(
         sample.h, ptt.h, _p(efflens, c_f32p), _p(ks, c_i64p), int(num_steps), int(num_mc),
         int(use_efflen_jacobian), int(gradonly), _p(z0, c_f32p), C.c_uint64(seed), int(init_only),
-        _p(mu, c_f32p), _p(omega, c_f32p), _p(alpha, c_f32p), _p(elbo, c_f64p), _p(lpm, c_f64p))
+        _p(mu, c_f32p), _p(omega, c_f32p), _p(alpha, c_f32p), _p(elbo, c_f64p), _p(lpm, c_f64p),
+        _p(gene_of, c_i32p), C.c_int64(ng))
     if rc != 0:
         raise FloatingPointError("non-finite gradient (likelihood-approximation.jl:559)")
     return dict(mu=mu, omega=omega, alpha=alpha, elbo=elbo, lp_mean=lpm)

@@ -691,8 +691,11 @@ int oracle_approximate_likelihood(oracle_sample *s, oracle_ptt *t, const float *
                                   const int64_t *ks, int num_steps, int num_mc,
                                   int use_efflen_jacobian, int gradonly, const float *z0,
                                   uint64_t seed, int init_only, float *mu, float *omega,
-                                  float *alpha, double *elbo_out, double *lp_mean_out)
+                                  float *alpha, double *elbo_out, double *lp_mean_out,
+                                  const int32_t *gene_of, int64_t num_genes)
 {
+    /* gene_of (optional, int32[n], -1 = no gene known): gene_noninformative = true
+     * (likelihood-approximation.jl:475-491, 535-538); num_genes = 1 + the largest index */
     int64_t n = s->n, nm1 = n - 1;
     float *m_mu = calloc(nm1, 4), *m_omega = calloc(nm1, 4), *m_alpha = calloc(nm1, 4);
     float *v_mu = calloc(nm1, 4), *v_omega = calloc(nm1, 4), *v_alpha = calloc(nm1, 4);
@@ -740,6 +743,8 @@ int oracle_approximate_likelihood(oracle_sample *s, oracle_ptt *t, const float *
                            : oracle_log_likelihood(s, xs, x_grad, gradonly);
             if (use_efflen_jacobian)
                 lp += oracle_effective_length_jacobian_adjustment(efflens, xs, xls, x_grad, n);
+            if (gene_of && num_genes > 0) /* :535-538 (xls is what the adjustment above left) */
+                lp += oracle_gene_noninformative_prior(efflens, xls, xs, x_grad, gene_of, n, num_genes);
             lp_sum += lp;
             elbo = lp + (double)skew_ladj + (double)ln_ladj + hsb_ladj; /* '=' as at :537 */
 

@@ -261,6 +261,23 @@ def effective_length_jacobian_adjustment(efflens, xs, x_grad, ctx=None):
     return (xls[0], g[0]) if single else (xls, g)
 
 
+def _gene_of(gene_transcripts, n):
+    """The reference's Dict{gene id -> 1-based transcript indexes} (likelihood-approximation.jl:476-487), or an int array
+    gene_of[n] (0-based gene index, -1 = no gene known), as the int32 array the C ABI takes."""
+    if isinstance(gene_transcripts, dict):
+        gene_of = np.full(n, -1, np.int32)
+        for gi, idxs in enumerate(gene_transcripts.values()):
+            for i in idxs:
+                if not 1 <= i <= n:
+                    raise ValueError("transcript index %d out of range" % i)
+                gene_of[i - 1] = gi
+        return gene_of
+    gene_of = arr(gene_transcripts, np.int32).reshape(-1)
+    if gene_of.size != n:
+        raise ValueError("gene_of must have one entry per transcript")
+    return gene_of
+
+
 def gene_noninformative_prior(efflens, xls, xs, x_grad, gene_transcripts, ctx=None):
     """gene_noninformative_prior! (likelihood.jl:114-159) -> adjusted x_grad.
 
@@ -271,17 +288,7 @@ def gene_noninformative_prior(efflens, xls, xs, x_grad, gene_transcripts, ctx=No
     single = xs.ndim == 1
     xs2 = xs.reshape(1, -1) if single else xs
     K, n = xs2.shape
-    if isinstance(gene_transcripts, dict):
-        gene_of = np.full(n, -1, np.int32)
-        for gi, idxs in enumerate(gene_transcripts.values()):
-            for i in idxs:
-                if not 1 <= i <= n:
-                    raise ValueError("transcript index %d out of range" % i)
-                gene_of[i - 1] = gi
-    else:
-        gene_of = arr(gene_transcripts, np.int32).reshape(-1)
-        if gene_of.size != n:
-            raise ValueError("gene_of must have one entry per transcript")
+    gene_of = _gene_of(gene_transcripts, n)
     g = arr(x_grad, np.float64).reshape(K, n).copy()
     check(L.lib().polee_gene_noninformative_prior(ctx._h, ptr(efflens, f32p), ptr(xls.reshape(K, n), f32p),
                                                   ptr(xs2, f32p), K, C.c_int64(n), ptr(gene_of, L.i32p), ptr(g, f64p)),
@@ -429,7 +436,11 @@ class LikelihoodApproximationFit:
     """State of one fit (polee_vi): lets callers step the VI loop and inspect it."""
 
     def __init__(self, sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES,
-                 use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False, comm=None):
+                 use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False, comm=None,
+                 gene_transcripts=None, adam=None):
+        """gene_transcripts (Dict gene -> 1-based transcript indexes, or gene_of int[n]): gene_noninformative = true.
+        adam: optional overrides of the optimiser constants of polee_vi_opts (adam_initial_learning_rate, adam_rm,
+        max_mu_step, ...; defaults = the reference's, constants.jl:48-65)."""
         self.sample, self.t, self.ctx = sample, t, sample.ctx
         self.comm = comm
         efflens = sample.effective_lengths if efflens is None else efflens
@@ -446,6 +457,18 @@ class LikelihoodApproximationFit:
             if self._z0.size != num_steps * num_mc_samples * (sample.n - 1):
                 raise ValueError("z0 must have num_steps*num_mc_samples*(n-1) elements")
             o.z0 = ptr(self._z0, f32p)
+        for key, val in (adam or {}).items():
+            if not (key.startswith("adam_") or key.startswith("max_")) or not hasattr(o, key):
+                raise ValueError("unknown optimiser constant %r" % (key,))
+            setattr(o, key, float(val))
+        self._gene_of = None
+        if gene_transcripts is not None:
+            self._gene_of = _gene_of(gene_transcripts, sample.n)
+            if (self._gene_of >= 0).any():
+                o.gene_of = ptr(self._gene_of, L.i32p)
+            else:  # (likelihood-approximation.jl:487-490)
+                import warnings
+                warnings.warn("'--gene-noninformative' used, but no gene information available")
         self.opts = o
         self.n, self.K = sample.n, int(num_mc_samples)
         self._h = C.c_void_p()
@@ -509,13 +532,16 @@ class LikelihoodApproximationFit:
 
 def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, use_efflen_jacobian=True,
                            num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES, gradonly=True,
-                           seed=123456789, z0=None):
+                           seed=123456789, z0=None, gene_transcripts=None):
     """approximate_likelihood(::LogitSkewNormalPTTApprox, sample) (likelihood-approximation.jl:395-624).
-    Returns the params Dict: mu, omega, alpha (+ node_parent_idxs, node_js when the tree carries them)."""
+    Returns the params Dict: mu, omega, alpha (+ node_parent_idxs, node_js when the tree carries them).
+    gene_noninformative = True needs the genes of the transcripts (the reference takes them from the sample's
+    transcript metadata, :475-487): `gene_transcripts` = Dict gene id -> 1-based transcript indexes, or an int array
+    gene_of[n] (-1 = none known); with no gene information the option is switched off with the reference's warning."""
     if not isinstance(approx, LogitSkewNormalPTTApprox):
         raise NotImplementedError("only LogitSkewNormalPTTApprox is built (the alt approximations are out of scope)")
-    if gene_noninformative:
-        raise NotImplementedError("gene_noninformative prior (likelihood.jl:114-159) is disabled on the CLI path and not built")
+    if gene_noninformative and gene_transcripts is None:
+        gene_transcripts = np.full(sample.n, -1, np.int32)
     if t is None:  # PolyaTreeTransform(X, approx.treemethod) (ptt.jl:35-52, likelihood-approximation.jl:425-440)
         if approx.treemethod == "cluster":
             if getattr(sample, "_csc", None) is None:
@@ -528,7 +554,8 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
             raise ValueError("%r is not a supported Polya tree transform heuristic" % (approx.treemethod,))
         t = PolyaTreeTransform(parents, js, ctx=sample.ctx)
     fit = LikelihoodApproximationFit(sample, t, num_steps=num_steps, num_mc_samples=num_mc_samples,
-                                     use_efflen_jacobian=use_efflen_jacobian, gradonly=gradonly, seed=seed, z0=z0)
+                                     use_efflen_jacobian=use_efflen_jacobian, gradonly=gradonly, seed=seed, z0=z0,
+                                     gene_transcripts=gene_transcripts if gene_noninformative else None)
     fit.run(num_steps)
     fit.sync()
     mu, omega, alpha = fit.params()
@@ -621,6 +648,20 @@ class ApproxLikelihoodSampler:
                                                    ptr(self.alpha, f32p), ptr(z, f32p), int(N),
                                                    C.c_uint64(self._next_seed()), ptr(pm, f32p)), t.ctx._h)
         return pm
+
+    def initial_values(self, efflens, N=30, z0=None):
+        """x0 of load_samples_hdf5 (estimate.jl:436-455): mean of N draws with y clamped to [LIKAP_Y_EPS, 1 - LIKAP_Y_EPS],
+        each divided by the effective lengths and renormalised."""
+        t = self.t
+        z = None if z0 is None else arr(z0, np.float32).reshape(N, t.n - 1)
+        l = arr(efflens, np.float32).reshape(-1)
+        if l.size != t.n:
+            raise ValueError("efflens must have one entry per transcript")
+        x0 = np.empty(t.n, np.float32)
+        check(L.lib().polee_sampler_initial_values(t._h, ptr(self.mu, f32p), ptr(self.sigma, f32p), ptr(self.alpha, f32p),
+                                                   ptr(l, f32p), ptr(z, f32p), int(N), C.c_uint64(self._next_seed()),
+                                                   ptr(x0, f32p)), t.ctx._h)
+        return x0
 
     def quantile(self, qs=(0.01, 0.99), N=100, z0=None):
         """One sample of Statistics.quantile (approx-sampler.jl:50-83): element-wise quantiles [len(qs), n] of N draws."""

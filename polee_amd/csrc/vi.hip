@@ -88,8 +88,8 @@ __global__ void aos_to_rows_f32_kernel(const float *in, int K, int64_t n, float 
 }
 
 // x_grad after the effective length adjustment, as rows [K][n] f64 (test hook output).
-__global__ void vi_xgrad_rows_kernel(const float *g, const float *efflens, const double *csum, int K, int64_t n,
-                                     double *out)
+__global__ void vi_xgrad_rows_kernel(const float *g, const float *efflens, const double *csum, GenePrior gp, int K,
+                                     int64_t n, double *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * K) return;
@@ -97,6 +97,13 @@ __global__ void vi_xgrad_rows_kernel(const float *g, const float *efflens, const
     const int64_t tid = i - (int64_t)k * n;
     double xg = (double)g[tid * K + k];
     if (efflens) xg -= (double)((float)n * (1.0f / efflens[tid])) / csum[k];
+    if (gp.gene_of) {  // (as bwd_values)
+        const int gene = gp.gene_of[tid];
+        const int kg = gene >= 0 ? gp.gene_k[gene] : 0;
+        const double c = csum[k], inv_l = (double)(1.0f / efflens[tid]);
+        const double xlg = kg > 1 ? -(double)(kg - 1) / gp.gene_c[(size_t)gene * K + k] : 0.0;
+        xg += xlg * (inv_l / c) + inv_l * (gp.M / (c * c));
+    }
     out[i] = xg;
 }
 
@@ -116,14 +123,18 @@ __global__ void vi_inverse_nodes_kernel(PttView v, const dd *C, double *ys)
 }
 
 // sampler: rand! (approx-sampler.jl:37-44) -- no clamp of ys
-__global__ void sampler_y_kernel(const float *mu, const float *sigma, const float *alpha, NoiseSrc noise, double *ys)
+// (y_eps > 0: the clamp of the initial-value draws, estimate.jl:443-447)
+__global__ void sampler_y_kernel(const float *mu, const float *sigma, const float *alpha, NoiseSrc noise, double y_eps,
+                                 double *ys)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int d = blockIdx.y;
     if (k >= noise.nm1) return;
     const float z0 = noise.get(1, d, k);
     const float zs = sinhf(alpha[k] + asinhf(z0));
-    ys[(int64_t)d * noise.nm1 + k] = (double)logistic_f32(mu[k] + zs * sigma[k]);
+    double y = (double)logistic_f32(mu[k] + zs * sigma[k]);
+    if (y_eps > 0.0) y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
+    ys[(int64_t)d * noise.nm1 + k] = y;
 }
 
 __global__ void export_noise_kernel(NoiseSrc noise, int step, float *out)
@@ -152,6 +163,12 @@ struct polee_vi {
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
     DevBuf<int> d_flag;
+    // gene_noninformative (opts.gene_of): gene of every transcript, members per gene, per-gene sums of a step
+    DevBuf<int32_t> d_gene_of;
+    DevBuf<int> d_gene_k;
+    DevBuf<double> d_gene_c;
+    int32_t num_genes = 0;
+    double gene_M = 0.0;
     // outputs of the test hook
     DevBuf<double> d_ygrad, d_xgrad_rows;
     DevBuf<float> d_mug, d_omg, d_alg, d_x_rows;
@@ -206,12 +223,20 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_g.p, (size_t)n * K, false));
         if (want_values) POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_lp.p, (size_t)K, true));
     }
+    // gene_noninformative: the per-gene sums of this step's draws (likelihood-approximation.jl:535-538)
+    GenePrior gp{nullptr, nullptr, nullptr, 0.0};
+    if (vi->num_genes > 0) {
+        gp = GenePrior{vi->d_gene_of.p, vi->d_gene_k.p, vi->d_gene_c.p, vi->gene_M};
+        POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_gene_c.p, 0, sizeof(double) * (size_t)vi->num_genes * K, st));
+        hipLaunchKernelGGL((vi_gene_sums_kernel<K>), dim3((unsigned)ceil_div((int64_t)n, 256)), dim3(256), 0, st, vi->d_x.p,
+                           vi->d_efflens.p, vi->d_part_c.p, nch_f, (int64_t)n, gp, vi->d_gene_c.p);
+    }
     // backward: double-double prefix over leaves of u * (g - efflen term)
     hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
-                       eff, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
+                       eff, vi->d_part_c.p, nch_f, vi->d_csum.p, gp, chunk_b);
     if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
     hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
-                       eff, vi->d_csum.p, chunk_b, vi->d_C.p, own_b);
+                       eff, vi->d_csum.p, gp, chunk_b, vi->d_C.p, own_b);
     POLEE_KERNEL_CHECK(ctx);
     if (want_values) {
         hipLaunchKernelGGL((vi_values_finish_kernel<K>), dim3(1), dim3(256), 0, st, vi->d_part_ladj.p, nch_f,
@@ -220,7 +245,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     }
     if (hook_outputs) {
         hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st,
-                           vi->d_g.p, eff, vi->d_csum.p, K, (int64_t)n, vi->d_xgrad_rows.p);
+                           vi->d_g.p, eff, vi->d_csum.p, gp, K, (int64_t)n, vi->d_xgrad_rows.p);
         POLEE_KERNEL_CHECK(ctx);
     }
     // update
@@ -281,7 +306,8 @@ namespace polee {
 
 // ndraws draws of the sampler into d_all [ndraws][n] (device), in batches of 8 rows
 static polee_status sampler_draw_device(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
-                                        const float *z0, int32_t ndraws, uint64_t seed, DevBuf<float> &d_all)
+                                        const float *z0, int32_t ndraws, uint64_t seed, DevBuf<float> &d_all,
+                                        double y_eps = 0.0)
 {
     polee_ctx *ctx = t->ctx;
     if (!mu || !sigma || !alpha || ndraws < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
@@ -299,7 +325,7 @@ static polee_status sampler_draw_device(polee_ptt *t, const float *mu, const flo
         NoiseSrc noise{z0 ? d_z0.p : nullptr, seed + (uint64_t)b0 * 0x9E3779B97F4A7C15ull, B, (int64_t)nm1};
         if (nm1 > 0) {
             hipLaunchKernelGGL(sampler_y_kernel, dim3((unsigned)ceil_div(nm1, 256), B), dim3(256), 0, ctx->stream,
-                               d_mu.p, d_sigma.p, d_alpha.p, noise, t->d_ys.p);
+                               d_mu.p, d_sigma.p, d_alpha.p, noise, y_eps, t->d_ys.p);
             POLEE_KERNEL_CHECK(ctx);
         }
         FwdOut o;
@@ -319,6 +345,27 @@ __global__ void sampler_mean_kernel(const float *xs, int ndraws, int64_t n, floa
     float acc = 0.0f;
     for (int k = 0; k < ndraws; ++k) acc += fminf(fmaxf(xs[(int64_t)k * n + j], 1e-15f), 0.9999999f);
     pm[j] = acc / (float)ndraws;
+}
+
+// initial values of the model entry (src/estimate.jl:436-455): every draw is divided by the effective lengths and
+// renormalised (x0 ./= efflen; x0 ./= sum(x0), Float32), the draws are averaged
+__global__ void x0_sums_kernel(const float *xs, const float *efflens, int64_t n, double *sums)
+{
+    __shared__ double smd[4];
+    const int d = blockIdx.y;
+    double q = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        q += (double)(xs[(int64_t)d * n + j] / efflens[j]);
+    q = block_sum_f64(q, smd);
+    if (threadIdx.x == 0) atomicAdd(&sums[d], q);
+}
+__global__ void x0_mean_kernel(const float *xs, const float *efflens, const double *sums, int ndraws, int64_t n, float *x0)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.0f;
+    for (int d = 0; d < ndraws; ++d) acc += (xs[(int64_t)d * n + j] / efflens[j]) / (float)sums[d];
+    x0[j] = acc / (float)ndraws;
 }
 
 constexpr int SAMPLER_MAX_Q = 8;
@@ -387,6 +434,8 @@ void polee_vi_default_opts(polee_vi_opts *o)
     o->max_omega_step = 2e-1;
     o->max_alpha_step = 2e-2;
     o->profile = 0;
+    o->reserved = 0;
+    o->gene_of = nullptr;
 }
 
 polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflens, const polee_vi_opts *opts,
@@ -408,6 +457,25 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     if (o.num_mc_samples < 1 || o.num_mc_samples > PSELL_MAX_K)
         return fail(ctx, POLEE_ERR_BAD_ARG, "num_mc_samples must be in 1..8");
     if (o.num_steps < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "num_steps must be >= 0");
+    // gene_noninformative: members per gene and M = sum over genes of (members - 1)
+    std::vector<int> gene_k;
+    double gene_M = 0.0;
+    if (o.gene_of) {
+        if (!o.use_efflen_jacobian)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of needs use_efflen_jacobian (gene_noninformative_prior! works on the "
+                                                "xls of the effective-length adjustment, likelihood.jl:114-159)");
+        int32_t ng = 0;
+        for (int64_t i = 0; i < ll->n; ++i) {
+            if (o.gene_of[i] < -1) return fail(ctx, POLEE_ERR_BAD_ARG, "gene_of[%lld] = %d", (long long)i, o.gene_of[i]);
+            ng = std::max(ng, o.gene_of[i] + 1);
+        }
+        gene_k.assign((size_t)ng, 0);
+        for (int64_t i = 0; i < ll->n; ++i)
+            if (o.gene_of[i] >= 0) ++gene_k[o.gene_of[i]];
+        for (int k : gene_k)
+            if (k > 1) gene_M += (double)(k - 1);
+        // (no gene information at all: the reference warns and switches the option off, :487-490)
+    }
     polee_vi *vi = new (std::nothrow) polee_vi();
     if (!vi) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
     vi->ctx = ctx;
@@ -449,6 +517,14 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     A(vi->d_ladj_el.alloc(ctx, PSELL_MAX_K * 2));
     A(vi->d_rows.alloc(ctx, PSELL_MAX_K * 2));
     A(vi->d_flag.alloc(ctx, 1));
+    if (!gene_k.empty()) {
+        vi->num_genes = (int32_t)gene_k.size();
+        vi->gene_M = gene_M;
+        A(vi->d_gene_of.upload(ctx, o.gene_of, n));
+        A(vi->d_gene_k.upload(ctx, gene_k));
+        A(vi->d_gene_c.alloc(ctx, gene_k.size() * K));
+    }
+    vi->o.gene_of = nullptr;  // (host memory is borrowed for the call only)
     vi->trace_cap = o.gradonly ? 0 : std::max(o.num_steps, 1);
     if (!o.gradonly) {
         A(vi->d_elbo.alloc(ctx, vi->trace_cap));
@@ -702,11 +778,12 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         if (rc != POLEE_OK) break;
         rc = loglik_eval_device(ll, vi->d_x.p, 1, vi->d_g.p, nullptr);
         if (rc != POLEE_OK) break;
+        const GenePrior no_gp{nullptr, nullptr, nullptr, 0.0};
         hipLaunchKernelGGL((vi_bwd_reduce_kernel<1>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p,
-                           vi->d_g.p, vi->d_efflens.p, vi->d_part_c.p, nch_f, vi->d_csum.p, chunk_b);
+                           vi->d_g.p, vi->d_efflens.p, vi->d_part_c.p, nch_f, vi->d_csum.p, no_gp, chunk_b);
         hipLaunchKernelGGL((scan_spine_kernel<VD<1>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
         hipLaunchKernelGGL((vi_bwd_apply_kernel<1>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p,
-                           vi->d_g.p, vi->d_efflens.p, vi->d_csum.p, chunk_b, vi->d_C.p, 0);
+                           vi->d_g.p, vi->d_efflens.p, vi->d_csum.p, no_gp, chunk_b, vi->d_C.p, 0);
         AdamConsts a;
         a.lr = std::max(o.adam_min_learning_rate,
                         o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));
@@ -741,6 +818,29 @@ polee_status polee_sampler_draw(polee_ptt *t, const float *mu, const float *sigm
     DevBuf<float> d_all;
     POLEE_TRY(sampler_draw_device(t, mu, sigma, alpha, z0, ndraws, seed, d_all));
     return d_all.download(ctx, xs, (size_t)ndraws * t->n);
+}
+
+polee_status polee_sampler_initial_values(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,
+                                          const float *efflens, const float *z0, int32_t ndraws, uint64_t seed, float *x0)
+{
+    if (!t) return fail(nullptr, POLEE_ERR_BAD_ARG, "null tree");
+    polee_ctx *ctx = t->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!x0 || !efflens) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<float> d_all, d_l, d_x0;
+    DevBuf<double> d_sums;
+    POLEE_TRY(sampler_draw_device(t, mu, sigma, alpha, z0, ndraws, seed, d_all, 1e-10 /* LIKAP_Y_EPS */));
+    const int64_t n = t->n;
+    POLEE_TRY(d_l.upload(ctx, efflens, (size_t)n));
+    POLEE_TRY(d_x0.alloc(ctx, (size_t)n));
+    POLEE_TRY(d_sums.alloc(ctx, (size_t)ndraws));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d_sums.p, 0, sizeof(double) * ndraws, ctx->stream));
+    hipLaunchKernelGGL(x0_sums_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 256), (unsigned)ndraws), dim3(256), 0,
+                       ctx->stream, d_all.p, d_l.p, n, d_sums.p);
+    hipLaunchKernelGGL(x0_mean_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_all.p, d_l.p, d_sums.p,
+                       ndraws, n, d_x0.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return d_x0.download(ctx, x0, (size_t)n);
 }
 
 polee_status polee_sampler_posterior_mean(polee_ptt *t, const float *mu, const float *sigma, const float *alpha,

@@ -277,20 +277,69 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
     }
 }
 
+// gene_noninformative_prior! (likelihood.jl:114-159) inside the loop: gene_of == nullptr = off.
+//   xl_grad_i = -(k_g - 1) / c_g for the k_g > 1 transcripts of gene g, c_g = sum of their xls (vi_gene_sums_kernel);
+//   x_grad_i += xl_grad_i (1/efflen_i) / c + (1/efflen_i) offdiag / c^2,  c = sum_i x_i / efflen_i,
+//   offdiag = sum_i -xl_grad_i xls_i = sum_g (k_g - 1) = M: a constant of the annotation (computed once on the host)
+struct GenePrior {
+    const int32_t *gene_of;
+    const int *gene_k;     // transcripts per gene
+    const double *gene_c;  // [num_genes][K]
+    double M;
+};
+
 // summand of the backward scan at leaf position pos: a = u * x_grad, with the effective-length Jacobian
 // term folded in (likelihood.jl:102-104): x_grad[j] -= n * (1/efflen_j) / sum_i x_i/efflen_i
 template <int K>
 __device__ inline void bwd_values(const PttView &v, int64_t pos, const double *__restrict__ uleaf,
                                   const float *__restrict__ g, const float *__restrict__ efflens,
-                                  const double *csum, VD<K> &a)
+                                  const double *csum, const GenePrior &gp, VD<K> &a)
 {
     const int tid = v.leaf_tid[pos];
-    const float nl = efflens ? (float)v.n * (1.0f / efflens[tid]) : 0.0f;  // Int * Float32 -> Float32 in the reference
+    const float inv_lf = efflens ? 1.0f / efflens[tid] : 0.0f;
+    const float nl = (float)v.n * inv_lf;  // Int * Float32 -> Float32 in the reference
+    int gene = -1, kg = 0;
+    if (gp.gene_of) {
+        gene = gp.gene_of[tid];
+        kg = gene >= 0 ? gp.gene_k[gene] : 0;
+    }
 #pragma unroll
     for (int d = 0; d < K; ++d) {
         double xg = (double)g[(size_t)tid * K + d];
         if (efflens) xg -= (double)nl / csum[d];
+        if (gp.gene_of) {
+            const double c = csum[d], inv_l = (double)inv_lf;
+            const double xlg = kg > 1 ? -(double)(kg - 1) / gp.gene_c[(size_t)gene * K + d] : 0.0;
+            xg += xlg * (inv_l / c) + inv_l * (gp.M / (c * c));
+        }
         a.v[d] = dd_make(uleaf[(size_t)pos * K + d] * xg);
+    }
+}
+
+// per-gene sums of xls = f32(f32(x / efflen) / c) for the prior above (likelihood.jl:126-128 on the xls that
+// effective_length_jacobian_adjustment! leaves, likelihood.jl:97-100); gene_c must be zero on entry
+template <int K>
+__global__ __launch_bounds__(256) void vi_gene_sums_kernel(const float *__restrict__ xs, const float *__restrict__ efflens,
+                                                          const double *__restrict__ part_c, int nchunks_fwd, int64_t n,
+                                                          GenePrior gp, double *__restrict__ gene_c)
+{
+    __shared__ double smd[4 * K];
+    double c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) c[d] = 0.0;
+    for (int ch = threadIdx.x; ch < nchunks_fwd; ch += 256)
+#pragma unroll
+        for (int d = 0; d < K; ++d) c[d] += part_c[(size_t)ch * K + d];
+    block_sum_vec<K>(c, smd);
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= n) return;
+    const int gene = gp.gene_of[tid];
+    if (gene < 0 || gp.gene_k[gene] <= 1) return;
+    const float inv_l = 1.0f / efflens[tid];
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const float xl = xs[(size_t)tid * K + d] * inv_l;
+        atomicAdd(&gene_c[(size_t)gene * K + d], (double)(float)((double)xl / c[d]));
     }
 }
 
@@ -300,7 +349,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_reduce_kernel(PttView v, 
                                                                     const float *__restrict__ g,
                                                                     const float *__restrict__ efflens,
                                                                     const double *__restrict__ part_c, int nchunks_fwd,
-                                                                    double *__restrict__ csum_out,
+                                                                    double *__restrict__ csum_out, GenePrior gp,
                                                                     VD<K> *__restrict__ chunk_sums)
 {
     __shared__ VD<K> smem[SCAN_THREADS / 64];
@@ -320,7 +369,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_reduce_kernel(PttView v, 
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j)
         if (base + j < v.n) {
-            bwd_values<K>(v, base + j, uleaf, g, efflens, c, a);
+            bwd_values<K>(v, base + j, uleaf, g, efflens, c, gp, a);
             acc = ScanOps<VD<K>>::add(acc, a);
         }
     VD<K> tot;
@@ -333,7 +382,7 @@ template <int K>
 __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, const double *__restrict__ uleaf,
                                                                    const float *__restrict__ g,
                                                                    const float *__restrict__ efflens,
-                                                                   const double *__restrict__ csum,
+                                                                   const double *__restrict__ csum, GenePrior gp,
                                                                    const VD<K> *__restrict__ chunk_offsets,
                                                                    dd *__restrict__ C, int own_prefix)
 {
@@ -347,7 +396,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         if (base + j < v.n)
-            bwd_values<K>(v, base + j, uleaf, g, efflens, c, val[j]);
+            bwd_values<K>(v, base + j, uleaf, g, efflens, c, gp, val[j]);
         else
             val[j] = ScanOps<VD<K>>::zero();
         acc = ScanOps<VD<K>>::add(acc, val[j]);

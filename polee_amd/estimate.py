@@ -61,7 +61,7 @@ def create_variables(ls, ctx=None):
 
 
 def load_samples_hdf5(filenames, n, gffhash=None, ptt_filename=None, check_gff_hash=True, using_device=True,
-                      num_init_draws=30, seed=123456789, ctx=None):
+                      num_init_draws=30, seed=123456789, ctx=None, init_noise=None):
     """load_samples_hdf5 (estimate.jl:338-499).  `n` = number of transcripts (length(ts) in the reference),
     `gffhash` = raw hash bytes of the annotation (ts_metadata.gffhash) for the consistency check."""
     S, N = len(filenames), 2 * n - 1
@@ -72,6 +72,7 @@ def load_samples_hdf5(filenames, n, gffhash=None, ptt_filename=None, check_gff_h
     left, right, leaf = (np.empty((T, N), np.int32) for _ in range(3))
     if shared:
         left[0], right[0], leaf[0] = make_inverse_ptt_params(*h5io.read_transformation(ptt_filename))
+    trees = []  # (node_parent_idxs, node_js) of every sample (for the initial-value draws)
     for i, filename in enumerate(filenames):
         s = h5io.read_prepared_sample(filename)  # raises on a version mismatch (estimate.jl:388)
         if s["n"] != n:
@@ -85,15 +86,27 @@ def load_samples_hdf5(filenames, n, gffhash=None, ptt_filename=None, check_gff_h
             if s["node_parent_idxs"] is None:
                 raise ValueError("%s holds no tree and no --ptt-tree file was given" % filename)
             left[i], right[i], leaf[i] = make_inverse_ptt_params(s["node_parent_idxs"], s["node_js"])
+            trees.append((s["node_parent_idxs"], s["node_js"]))
     ls = LoadedSamples(efflen, np.zeros((S, n), np.float32), mu, sigma, alpha, left, right, leaf, filenames)
     if using_device:
         create_variables(ls, ctx)
-        # reasonable initial values: mean of 30 draws from each approximation (estimate.jl:436-455), on the GPU
-        ap = ls.variables["approx"]
-        acc = np.zeros((S, n), np.float64)
-        for d in range(num_init_draws):
-            acc += ap.sample(seed=seed + d)
-        ls.x0_values = (acc / num_init_draws).astype(np.float32)
+        # reasonable initial values: the mean of 30 draws from each approximation, drawn as the reference draws them
+        # (estimate.jl:436-455: y clamped to LIKAP_Y_EPS, transform!, / effective lengths, renormalised), on the GPU;
+        # `init_noise` (optional, [S][num_init_draws][n-1]) replaces the device RNG (parity tests)
+        from .core import ApproxLikelihoodSampler, PolyaTreeTransform
+        als = ApproxLikelihoodSampler()
+        als.seed(seed)
+        shared_tree = None
+        for i in range(S):
+            if shared:
+                if shared_tree is None:
+                    shared_tree = PolyaTreeTransform(*h5io.read_transformation(ptt_filename), ctx=ctx)
+                t = shared_tree
+            else:
+                t = PolyaTreeTransform(trees[i][0], trees[i][1], ctx=ctx)
+            als.set_transform(t, mu[i], sigma[i], alpha[i])
+            z0 = None if init_noise is None else np.asarray(init_noise, np.float32)[i]
+            ls.x0_values[i] = als.initial_values(efflen[i], num_init_draws, z0=z0)
     return ls
 
 

@@ -399,6 +399,58 @@ def test_vi_trajectory_with_supplied_noise(P, ctx, lm_fixture, prep_fixture):
     assert (got["node_parent_idxs"] == prep_fixture["node_parent_idxs"]).all()
 
 
+def test_vi_trajectory_with_gene_noninformative_prior(P, ctx, lm_fixture, prep_fixture):
+    """gene_noninformative = true as an option of the loop (likelihood-approximation.jl:475-491, 535-538): single-step
+    x gradients and a five-iteration trajectory against the oracle with the same gene annotation and noise."""
+    f = lm_fixture
+    n = f["n"]
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    so = O.Sample(f["m"], n, f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(prep_fixture["node_parent_idxs"], prep_fixture["node_js"])
+    rng = np.random.default_rng(21)
+    gene_of = rng.integers(0, n // 3, size=n).astype(np.int32)
+    gene_of[rng.random(n) < 0.1] = -1  # transcripts without a known gene
+    steps, K = 5, 6
+    z0 = O.randn(steps * K * (n - 1), 9)
+    ref = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False,
+                                   gene_of=gene_of)
+    plain = O.approximate_likelihood(so, to, f["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False)
+    got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
+                                   gradonly=False, gene_noninformative=True, gene_transcripts=gene_of)
+    assert np.abs(ref["mu"] - plain["mu"]).max() > 1e-2  # the prior does change the trajectory
+    for key in ("mu", "omega", "alpha"):
+        ok = np.abs(got[key] - ref[key]) <= 2e-4 * (1 + np.abs(ref[key]))
+        assert ok.mean() >= 0.99, (key, ok.mean())
+    np.testing.assert_allclose(got["lp_mean"], ref["lp_mean"], rtol=1e-5)
+    # the Dict form of the reference (gene id -> 1-based transcript indexes) gives the same fit
+    d = {}
+    for i, gi in enumerate(gene_of):
+        if gi >= 0:
+            d.setdefault("g%d" % gi, []).append(i + 1)
+    got2 = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
+                                    gene_noninformative=True, gene_transcripts=d)
+    np.testing.assert_allclose(got2["mu"], got["mu"], rtol=1e-4, atol=1e-4)
+    # single-draw x gradients (the hook returns x_grad after both adjustments)
+    fit = P.LikelihoodApproximationFit(s, t, num_steps=2, num_mc_samples=K, gradonly=False, seed=5, gene_transcripts=gene_of)
+    fit.set_params(prep_fixture["mu"], prep_fixture["omega"], prep_fixture["alpha"])
+    zz = fit.export_noise(1)
+    out = fit.eval_gradients()
+    for dd_ in range(K):
+        r = O.vi_draw_gradients(so, to, f["effective_lengths"], prep_fixture["mu"], prep_fixture["omega"],
+                                prep_fixture["alpha"], zz[dd_])
+        xs = r["xs"]
+        xl = (xs / f["effective_lengths"]).astype(np.float32)
+        xls = (xl.astype(np.float64) / xl.astype(np.float64).sum()).astype(np.float32)
+        want = O.gene_noninformative_prior(f["effective_lengths"], xls, xs, r["x_grad"], gene_of)
+        np.testing.assert_allclose(out["x_grad"][dd_], want, rtol=1e-4, atol=1e-6 * np.abs(want).max())
+    # no gene information at all: warning, option off (likelihood-approximation.jl:487-490)
+    with pytest.warns(UserWarning, match="no gene information"):
+        got3 = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
+                                        gradonly=False, gene_noninformative=True)
+    np.testing.assert_allclose(got3["lp_mean"], plain["lp_mean"], rtol=1e-5)
+
+
 def _expected_loglik(so, to, mu, omega, alpha, efflens, ndraws, seed):
     sigma = np.exp(omega)
     lps, pm = [], np.zeros(to.n)

@@ -1,0 +1,74 @@
+"""-m gpu twins of tests/test_oracle_pin.py: the same two reference-anchored statements, made by the HIP path through
+the C ABI (stationarity of the reference's fitted parameters under the device's ELBO gradient; the density of a
+sampler draw = normal density of z0 minus the forward log-determinants)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_oracle_pin import forward_chain, ladj_term_sizes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import polee_amd
+    return polee_amd
+
+
+def test_reference_parameters_are_stationary_for_the_device_gradient(P, lm_fixture, prep_fixture):
+    f, p = lm_fixture, prep_fixture
+    ctx = P.Context(0)
+    s = P.RNASeqSample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"], ctx=ctx)
+    t = P.PolyaTreeTransform(p["node_parent_idxs"], p["node_js"], ctx=ctx)
+    n, K = f["n"], 8
+    frozen = dict(max_mu_step=0.0, max_omega_step=0.0, max_alpha_step=0.0)  # steps advance the noise, not the parameters
+
+    def mean_grad(mu, steps):
+        fit = P.LikelihoodApproximationFit(s, t, num_steps=steps + 1, num_mc_samples=K, seed=7000, adam=frozen)
+        fit.set_params(mu, p["omega"], p["alpha"])
+        acc = np.zeros((3, n - 1))
+        for _ in range(steps):  # K fresh device-RNG draws per step
+            g = fit.eval_gradients()
+            acc += np.stack([g["mu_grad"], g["omega_grad"], g["alpha_grad"]])
+            fit.run(1)
+        fit.sync()
+        m, o, a = fit.params()
+        assert np.array_equal(m, np.asarray(mu, np.float32)) and np.array_equal(o, p["omega"])  # really frozen
+        return acc / steps  # (each is already the mean over K draws)
+
+    size = np.median(np.abs(mean_grad(p["mu"], 1500)), axis=1)
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    to = O.PTT(p["node_parent_idxs"], p["node_js"])
+    terms = ladj_term_sizes(so, to, f, p, 1000, 1000)
+    print("device mean gradient (median |.| per block):", size, "ladj terms:", terms)
+    assert (size < 0.2 * terms).all(), (size, terms)  # (12 000 draws: a little more Monte-Carlo noise than the CPU test's 20 000)
+    rng = np.random.default_rng(0)
+    moved = mean_grad((p["mu"] + rng.normal(0, 0.1, n - 1)).astype(np.float32), 400)
+    assert np.median(np.abs(moved[0])) > 3 * size[0]
+
+
+def test_device_density_of_a_sampler_draw_matches_the_forward_log_determinants(P, lm_fixture, prep_fixture):
+    f, p = lm_fixture, prep_fixture
+    n, l = f["n"], f["effective_lengths"].astype(np.float64)
+    ctx = P.Context(0)
+    li, ri, fi = P.make_inverse_ptt_params(p["node_parent_idxs"], p["node_js"])
+    sigma = np.exp(p["omega"])
+    S = 4
+    vars_ = dict(efflen=np.tile(f["effective_lengths"], (S, 1)), la_mu=np.tile(p["mu"], (S, 1)),
+                 la_sigma=np.tile(sigma, (S, 1)), la_alpha=np.tile(p["alpha"], (S, 1)),
+                 left_index=np.tile(li, (S, 1)), right_index=np.tile(ri, (S, 1)), leaf_index=np.tile(fi, (S, 1)))
+    ap = P.RNASeqApproxLikelihood(vars_, ctx=ctx)
+    to = O.PTT(p["node_parent_idxs"], p["node_js"])
+    z0 = np.stack([O.randn(n - 1, 4100 + i) for i in range(S)])
+    xt = ap.sample(z0=z0)  # the device's TF sampler
+    xs, expect = [], []
+    for i in range(S):
+        x, ladj1, ladj2, ladj3 = forward_chain(to, p, l, z0[i])
+        np.testing.assert_allclose(np.log(xt[i].astype(np.float64)), x, rtol=2e-5, atol=1e-5)
+        pe = np.exp(x)
+        extra = x.sum() - (n - 1) * np.log(pe.sum()) + np.log(l).sum() - np.log((pe * l).sum())
+        expect.append((-np.log(2 * np.pi) * (n - 1) - (z0[i].astype(np.float64) ** 2).sum()) / 2 - (ladj1 + ladj2 + ladj3) + extra)
+        xs.append(x.astype(np.float32))
+    got = ap.log_prob(np.stack(xs))
+    np.testing.assert_allclose(np.asarray(got, np.float64).reshape(-1), expect, rtol=1e-4)

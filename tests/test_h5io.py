@@ -86,15 +86,34 @@ def test_read_specification_and_loader_without_device(tmp_path, prep_fixture):
 
 @pytest.mark.gpu
 def test_loader_builds_device_likelihood(tmp_path, prep_fixture):
-    from polee_amd.estimate import load_samples_from_specification
+    """load_samples_from_specification on the device: the 7 variables of create_tensorflow_variables!, and x0 = the mean of
+    30 draws as estimate.jl:436-455 draws them, compared with the oracle's x0_draw on the same noise."""
+    from oracle import oracle as O
+    from polee_amd.estimate import load_samples_hdf5, load_samples_from_specification
     p = prep_fixture
     files = []
     for i in range(2):
         fn = str(tmp_path / ("s%d.prep.h5" % i))
-        h5io.write_approximation(fn, 19743, 313, p["effective_lengths"], p)
+        q = dict(p)
+        q["mu"] = p["mu"] + np.float32(0.25 * i)
+        h5io.write_approximation(fn, 19743, 313, p["effective_lengths"], q)
         files.append(fn)
     ls = load_samples_from_specification({"samples": [{"name": "a", "file": files[0]}, {"name": "b", "file": files[1]}]}, 313)
     assert set(ls.variables) >= {"efflen", "la_mu", "la_sigma", "la_alpha", "left_index", "right_index", "leaf_index"}
     assert ls.x0_values.shape == (2, 313) and np.allclose(ls.x0_values.sum(axis=1), 1, atol=1e-3)
     lp = ls.variables["approx"].log_prob(np.log(ls.x0_values))
     assert np.isfinite(lp).all()
+    # the same loader with supplied noise against the oracle, draw by draw
+    N = 30
+    noise = np.stack([np.stack([O.randn(312, 100 * i + d) for d in range(N)]) for i in range(2)])
+    ls2 = load_samples_hdf5(files, 313, num_init_draws=N, init_noise=noise)
+    to = O.PTT(p["node_parent_idxs"], p["node_js"])
+    for i in range(2):
+        mu = p["mu"] + np.float32(0.25 * i)
+        ref = np.zeros(313)
+        for d in range(N):
+            ref += O.x0_draw(to, mu, np.exp(p["omega"]), p["alpha"], p["effective_lengths"], noise[i, d])
+        np.testing.assert_allclose(ls2.x0_values[i], ref / N, rtol=2e-5, atol=1e-12)
+    # device-RNG initial values are the same statistic: close to the supplied-noise mean on the expressed transcripts
+    big = ls2.x0_values[0] > 1e-3
+    assert np.abs(np.log(ls.x0_values[0][big] / ls2.x0_values[0][big])).max() < 1.0
