@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _oracle_threads():
+    """The oracle forks an OpenMP team per call; on a 256-thread host the fixture-sized tests (313 transcripts) would
+    spend their time in fork/join.  Tests at BASELINE sizes raise the count themselves."""
+    try:
+        from oracle import oracle as O
+        O.set_num_threads(min(8, O.physical_cores()))
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def lm_fixture():
     """Reference-produced likelihood matrix (test/dataset/mBr_M_6w_1.likelihood-matrix.h5)."""

@@ -45,6 +45,7 @@ def c2(P):
 
 def test_c2_loglik_and_gradient_match_oracle(P, c2):
     ctx, smp, s, so, collen, parents, js = c2
+    O.set_num_threads(O.physical_cores())
     rng = np.random.default_rng(0)
     K = 6
     x = rng.gamma(0.3, size=(K, N)).astype(np.float32) + np.float32(1e-7)
@@ -74,6 +75,7 @@ def test_c2_three_vi_iterations_match_oracle(P, c2):
     """Three whole iterations (sampling, tree transform, likelihood over the 240 M non-zeros, backward, ADAM) with the
     same z0 on both sides (likelihood-approximation.jl:496-572)."""
     ctx, smp, s, so, collen, parents, js = c2
+    O.set_num_threads(O.physical_cores())
     t = P.PolyaTreeTransform(parents, js, ctx=ctx)
     to = O.PTT(parents, js)
     steps, K = 3, 6
@@ -107,9 +109,7 @@ def test_c1_whole_fit_replayed_against_oracle(P):
     so, to = O.Sample(m, n, colptr, rowval, nzval), O.PTT(parents, js)
     steps, K = 500, 6
     z0 = O.randn(steps * K * (n - 1), 17)
-    O.set_num_threads(min(8, O.physical_cores()))  # (12 000 parallel regions over 1 000 transcripts: hundreds of threads only add fork/join time)
     ref = O.approximate_likelihood(so, to, smp["effective_lengths"], num_steps=steps, num_mc=K, z0=z0, gradonly=False)
-    O.set_num_threads(O.physical_cores())
     got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0,
                                    gradonly=False)
     rel = np.abs(got["lp_mean"] - ref["lp_mean"]) / np.abs(ref["lp_mean"])
@@ -158,6 +158,7 @@ def test_c3_regression_eval_matches_restatement_at_200k(P, S, full):
     from oracle import regression_ref as RR
     rng = np.random.default_rng(41)
     F, n, deg, pen = 2, N, 15, 1.0
+    O.set_num_threads(O.physical_cores())
     ctx = P.Context(0)
     vars_, design, x_init = _c3_problem(P, S, F, n, rng)
     ss = P.estimate_sample_scales(x_init)
