@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--row-shard", action="store_true",
                     help="ONE sample for the whole job: its fragments are sharded over the GPUs and the likelihood "
                          "gradient is all-reduced once per pass (RCCL); strong scaling.  Default: one sample per GPU.")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="fixed-order gradient sums (bitwise reproducible; polee_loglik_set_deterministic) instead of atomics")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
@@ -269,7 +271,7 @@ def main():
         tree_i = P.PolyaTreeTransform(parents, js, ctx=ctx_i)
         t_build += time.time() - t0
         fits.append(P.LikelihoodApproximationFit(sample_i, tree_i, num_steps=max(total, 1), num_mc_samples=K,
-                                                 seed=args.seed, profile=True, comm=comm))
+                                                 seed=args.seed, profile=True, comm=comm, deterministic=args.deterministic))
         ctxs.append(ctx_i)
         if si == 0:
             smp, sample, tree, info = smp_i, sample_i, tree_i, sample_i.info

@@ -146,6 +146,12 @@ typedef struct {
                              /* from, one window of dict_entries x K floats per pass                           */
 } polee_loglik_info;
 polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info);
+/* Deterministic mode ("fixed reduction order ... bitwise stable"): the gradient (and lp) of a pass is
+ * summed in a fixed order -- per wave, per tile, then per transcript in tile order -- instead of with float atomics, so
+ * that two evaluations on the same inputs agree bit for bit (and with them a whole fit with the same noise).  About 25 %
+ * slower (three workgroups per CU instead of four, a second small kernel).  Rows with more than 32 transcripts are still
+ * added with atomics.  Default off. */
+polee_status polee_loglik_set_deterministic(polee_loglik *ll, int on);
 
 /* log_likelihood (src/likelihood.jl:36-56) for K expression vectors at once:
  * xs f32 [K][n] -> x_grad f64 [K][n] = sum_i X_ij / s_i  (x ks_i if factored);
@@ -209,7 +215,7 @@ typedef struct {
     double adam_rm;                    /* 0.7  */
     double max_mu_step, max_omega_step, max_alpha_step; /* 0.2, 0.2, 0.02 */
     int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events  */
-    int32_t reserved;
+    int32_t deterministic;       /* 1: polee_loglik_set_deterministic(ll, 1) for this fit's likelihood handle    */
     const int32_t *gene_of;      /* optional HOST int32[n]: gene index of every transcript (0-based, -1 = none   */
                                  /* known) = gene_noninformative = true (likelihood-approximation.jl:475-491,     */
                                  /* 535-538: gene_noninformative_prior! after the effective-length adjustment,   */

@@ -41,7 +41,7 @@ class ViOpts(C.Structure):
                 ("adam_initial_learning_rate", C.c_double), ("adam_learning_rate_decay", C.c_double),
                 ("adam_min_learning_rate", C.c_double), ("adam_eps", C.c_double), ("adam_rv", C.c_double),
                 ("adam_rm", C.c_double), ("max_mu_step", C.c_double), ("max_omega_step", C.c_double),
-                ("max_alpha_step", C.c_double), ("profile", C.c_int32), ("reserved", C.c_int32),
+                ("max_alpha_step", C.c_double), ("profile", C.c_int32), ("deterministic", C.c_int32),
                 ("gene_of", C.POINTER(C.c_int32))]
 
 

@@ -213,6 +213,10 @@ class RNASeqSample:
         except Exception:
             pass
 
+    def set_deterministic(self, on=True):
+        """Fixed-order (bitwise reproducible) gradient sums instead of float atomics (polee_loglik_set_deterministic)."""
+        check(L.lib().polee_loglik_set_deterministic(self._h, int(bool(on))), self.ctx._h)
+
     @property
     def info(self):
         i = L.LoglikInfo()
@@ -437,7 +441,7 @@ class LikelihoodApproximationFit:
 
     def __init__(self, sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES,
                  use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False, comm=None,
-                 gene_transcripts=None, adam=None):
+                 gene_transcripts=None, adam=None, deterministic=False):
         """gene_transcripts (Dict gene -> 1-based transcript indexes, or gene_of int[n]): gene_noninformative = true.
         adam: optional overrides of the optimiser constants of polee_vi_opts (adam_initial_learning_rate, adam_rm,
         max_mu_step, ...; defaults = the reference's, constants.jl:48-65)."""
@@ -457,6 +461,7 @@ class LikelihoodApproximationFit:
             if self._z0.size != num_steps * num_mc_samples * (sample.n - 1):
                 raise ValueError("z0 must have num_steps*num_mc_samples*(n-1) elements")
             o.z0 = ptr(self._z0, f32p)
+        o.deterministic = int(bool(deterministic))
         for key, val in (adam or {}).items():
             if not (key.startswith("adam_") or key.startswith("max_")) or not hasattr(o, key):
                 raise ValueError("unknown optimiser constant %r" % (key,))

@@ -118,6 +118,9 @@ struct PsellArgs {
     int tiles_a1;           // tiles [0, tiles_a1): stream A1, [tiles_a1, tiles_a): A2
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
+    // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
+    float *gwin;            // [dict entries][K], laid out like xwin
+    double *lpwin;          // [grid][K] per-workgroup log-likelihood sums
 };
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -417,12 +420,16 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         if (NT == 1 && pend_packed) {
             // D[(h, t)][(h', k)]: lane (n = tt, q), register v holds row m = 4 q + v; useful where h = q >> 1 equals
             // h' = tt >> 3: transcript t = 4 (q & 1) + v (colq was read for q & 1), draw k = tt & 7
-            const f32x4 sum = acc0[0] + acc1[0];
+            f32x4 sum = acc0[0] + acc1[0];
             const unsigned cid[4] = {colq[0].x & 0xffffu, colq[0].x >> 16, colq[0].y & 0xffffu, colq[0].y >> 16};
-            const bool mine = (q >> 1) == (tt >> 3) && (tt & 7) < K;
+            // the two halves' blocks (lanes (tt < 8, q < 2) and (tt + 8, q + 2)) meet in the lower lane: one add per
+            // address, in a fixed order
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sum[v] += __shfl(sum[v], lane + 40, 64);
+            const bool mine = q < 2 && tt < K && tt < 8;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (mine && 4 * (q & 1) + v < pend_w && sum[v] != 0.0f) atomicAdd(gw + cid[v] * K + (tt & 7), sum[v]);
+                if (mine && 4 * q + v < pend_w && sum[v] != 0.0f) atomicAdd(gw + cid[v] * K + tt, sum[v]);
             acc0[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             pend_w = 0;
@@ -671,8 +678,49 @@ __global__ void xwin_gather_kernel(const uint32_t *__restrict__ dict, const floa
     xwin[i] = x[(size_t)dict[e] * K + (int)(i - e * K)];
 }
 
+// deterministic mode, second kernel: g[j][k] += the windows' values of transcript j (tslot lists its dictionary entries,
+// ascending = tile order).  A thread per (j, k) walks a short list; a transcript present in more than GWIN_HEAVY tiles
+// gets a whole wave (gwin_reduce_heavy_kernel): lane l sums entries l, l + 64, ... in order and the 64 partial sums are
+// combined by a fixed shuffle tree -- a fixed order either way.  Block 0 also adds the workgroups' log-likelihood sums in
+// workgroup order.
+constexpr uint32_t GWIN_HEAVY = 32;
+__global__ void gwin_reduce_kernel(const uint32_t *__restrict__ tslot_ptr, const uint32_t *__restrict__ tslot,
+                                   const float *__restrict__ gwin, int K, int64_t n, float *__restrict__ g,
+                                   const double *__restrict__ lpwin, int nwg, double *__restrict__ lp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp && blockIdx.x == 0 && threadIdx.x < K) {
+        double s = 0.0;
+        for (int b = 0; b < nwg; ++b) s += lpwin[(size_t)b * K + threadIdx.x];
+        lp[threadIdx.x] += s;
+    }
+    if (i >= n * K) return;
+    const int64_t j = i / K;
+    const int k = (int)(i - j * K);
+    const uint32_t b = tslot_ptr[j], e1 = tslot_ptr[j + 1];
+    if (e1 - b > GWIN_HEAVY) return;
+    float s = 0.0f;
+    for (uint32_t e = b; e < e1; ++e) s += gwin[(size_t)tslot[e] * K + k];
+    g[i] += s;
+}
+__global__ __launch_bounds__(64) void gwin_reduce_heavy_kernel(const uint32_t *__restrict__ heavy,
+                                                             const uint32_t *__restrict__ tslot_ptr,
+                                                             const uint32_t *__restrict__ tslot,
+                                                             const float *__restrict__ gwin, int K, float *__restrict__ g)
+{
+    const uint32_t j = heavy[blockIdx.x];
+    const uint32_t b = tslot_ptr[j], e1 = tslot_ptr[j + 1];
+    for (int k = 0; k < K; ++k) {
+        float s = 0.0f;
+        for (uint32_t e = b + threadIdx.x; e < e1; e += 64) s += gwin[(size_t)tslot[e] * K + k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+        if (threadIdx.x == 0) g[(size_t)j * K + k] += s;
+    }
+}
+
 // LDS layout of the streaming kernel:
-//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2)][xw 0][xw 1][gw][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
+//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
 template <int K>
 constexpr uint32_t stream_ring_total()
@@ -684,26 +732,30 @@ constexpr uint32_t stream_xw_bytes()  // whole 1 KiB pieces
 {
     return ((uint32_t)PSELL_TILE_COLS_TARGET * K * 4u + 1023u) & ~1023u;
 }
-template <int K>
-constexpr uint32_t stream_lds_bytes()
+template <int K, bool DET>
+constexpr uint32_t stream_lds_bytes()  // (deterministic mode: one gradient window per wave)
 {
-    return stream_ring_total<K>() + 3u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u;
+    return stream_ring_total<K>() + (DET ? 6u : 3u) * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u;
 }
 
-template <int K, bool WANT_LP, bool HAS_KS>
+// DET: the deterministic mode -- bitwise reproducible gradients: each wave accumulates into its own LDS window (a wave's
+// LDS adds retire in program order), the tile's flush sums the four windows in wave order and STORES the result to the
+// tile's slot of gwin, and gwin_reduce_kernel adds a transcript's slots in tile order.
+template <int K, bool WANT_LP, bool HAS_KS, bool DET>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void loglik_stream_kernel(PsellArgs A, int dbg)
 {
     extern __shared__ float lds[];
     constexpr uint32_t XWB = stream_xw_bytes<K>();
+    constexpr uint32_t GWN = DET ? 4u : 1u;  // gradient windows
     char *const base = reinterpret_cast<char *>(lds);
     char *const rings = base;
     auto xw_of = [&](int b) -> float * { return reinterpret_cast<float *>(base + stream_ring_total<K>() + (uint32_t)b * XWB); };
     float *const gw = reinterpret_cast<float *>(base + stream_ring_total<K>() + 2 * XWB);
     auto ids_of = [&](int b) -> uint32_t * {
-        return reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + (uint32_t)b * (PSELL_TILE_COLS_TARGET * 4));
+        return reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + (2 + GWN) * XWB + (uint32_t)b * (PSELL_TILE_COLS_TARGET * 4));
     };
-    uint32_t *const entb = reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + 3 * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
+    uint32_t *const entb = reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + (2 + GWN) * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
     uint32_t *const descb = entb + 4 * 64;  // 2 x 64 words: the schedule entry two rounds ahead, by LDS-DMA
 
     const int lane = threadIdx.x & 63;
@@ -779,7 +831,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     PosDesc cur = sched[blockIdx.x];
     if (cur.tile == POS_NONE) return;
     PosDesc nxt = sched[blockIdx.x + G];
-    for (int i = threadIdx.x; i < (int)(XWB / 4u); i += 256) gw[i] = 0.0f;
+    for (int i = threadIdx.x; i < (int)(GWN * XWB / 4u); i += 256) gw[i] = 0.0f;
     // the rings start out as zeros: operand rows past a slice's last transcript are read (and multiplied by 0), so
     // whatever lies behind a slice in the ring has to be finite
     for (int i = threadIdx.x; i < (int)(stream_ring_total<K>() / 16u); i += 256)
@@ -798,18 +850,21 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         if (wave == 0) {
             // the schedule entry after the next (a scalar load here would stall every tile by its latency; through LDS it
             // arrives in the background like everything else and is read after the tile's barriers)
-            dma_256(uniform_ptr(sched + blockIdx.x + (size_t)(round + 2u) * G), (uint32_t)(lane & 7) * 4u, lds_addr(descb + (round & 1u) * 64u));
+            uint32_t off8;  // (lane & 7) * 4, computed here: hoisted out of the tile loop it was spilled, and its reload
+                            // (a scratch load the compiler waits for with vmcnt(0)) drained this wave's ring every tile
+            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(lane));
+            dma_256(uniform_ptr(sched + blockIdx.x + (size_t)(round + 2u) * G), off8, lds_addr(descb + (round & 1u) * 64u));
             ++young;
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
-            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw, lp_a, dbg
+            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif
             );
         } else {
-            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw, lp_a, dbg
+            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                            , st_acc, st_last
 #endif
@@ -844,10 +899,20 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
                     if (i < LK) {
                         const int l = i / K;
                         const int k = i - l * K;
-                        const float v = gw[i];
+                        float v = gw[i];
                         gw[i] = 0.0f;
-                        float *dst = A.g + (size_t)ids[l] * K + k;
-                        if (!(dbg & 1)) asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+                        if (DET) {  // the four waves' windows, in wave order; stored to the tile's slot
+#pragma unroll
+                            for (uint32_t wv = 1; wv < 4; ++wv) {
+                                v += gw[wv * (XWB / 4u) + i];
+                                gw[wv * (XWB / 4u) + i] = 0.0f;
+                            }
+                            float *dst = A.gwin + (size_t)cur.d0 * K + i;
+                            if (!(dbg & 1)) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+                        } else {
+                            float *dst = A.g + (size_t)ids[l] * K + k;
+                            if (!(dbg & 1)) asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+                        }
                     }
                     if (!(dbg & 1)) ++young;  // (younger than the pieces of the ring that has just been started)
                 }
@@ -871,7 +936,17 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         }
         buf ^= 1;
     }
-    if (WANT_LP) {
+    if (WANT_LP && DET) {
+        // per-workgroup sums in wave order, stored; gwin_reduce_kernel adds them in workgroup order
+        double v = lp_a;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        double *lpw = reinterpret_cast<double *>(gw);  // (the windows are idle now)
+        lds_barrier();
+        if (lane < K) lpw[wave * K + lane] = v;
+        lds_barrier();
+        if (threadIdx.x < K) A.lpwin[(size_t)blockIdx.x * K + threadIdx.x] = ((lpw[threadIdx.x] + lpw[K + threadIdx.x]) + lpw[2 * K + threadIdx.x]) + lpw[3 * K + threadIdx.x];
+    } else if (WANT_LP) {
         double v = lp_a;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
@@ -937,6 +1012,50 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     return POLEE_OK;
 }
 
+template <int K, bool LP, bool KS, bool DET>
+static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
+{
+    polee_ctx *ctx = ll->ctx;
+    const PsellHost &h = ll->host;
+    hipStream_t st = ctx->stream;
+    // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
+    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
+    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM_RB2, "A2 slices (+ ks row) must fit their ring");
+    const size_t lds = stream_lds_bytes<K, DET>();
+    int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0][DET ? 1 : 0];
+    if (occ == 0) {
+        int nb = 0;
+        POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS, DET>, 256, lds));
+        occ = std::max(1, std::min(nb, 4));
+        if (getenv("POLEE_DEBUG_PRINT"))
+            fprintf(stderr, "[loglik] stream kernel K=%d%s: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
+                    K, DET ? " (deterministic)" : "", nb, lds, occ, ctx->num_cus);
+    }
+    const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles_a, 1));
+    POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
+    A.sched = ll->d_sched.p;
+    if (DET) {
+        POLEE_TRY(ll->d_gwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512));
+        POLEE_TRY(ll->d_lpwin.alloc(ctx, (size_t)4 * ctx->num_cus * PSELL_MAX_K));
+        A.gwin = ll->d_gwin.p;
+        A.lpwin = ll->d_lpwin.p;
+    }
+    const int64_t total = ll->dict_len * K;
+    hipLaunchKernelGGL(xwin_gather_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, ll->d_dict.p, A.x, K,
+                       total, ll->d_xwin.p);
+    if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
+    hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
+    if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
+    if (DET) {
+        hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
+                           ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, G, A.lp);
+        if (ll->d_theavy.n > 0)
+            hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n), dim3(64), 0, st, ll->d_theavy.p,
+                               ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g);
+    }
+    return POLEE_OK;
+}
+
 template <int K, bool LP, bool KS>
 static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
@@ -949,11 +1068,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, ll->d_xwin.p, nullptr};
-    // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
-    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
-    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM_RB2, "A2 slices (+ ks row) must fit their ring");
-    const size_t lds = stream_lds_bytes<K>();
+                (int)h.num_tiles_a1, ll->d_xwin.p, nullptr, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
@@ -962,26 +1077,15 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
         POLEE_HIP_TRY(ctx, hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     if (!no_ring) {
-        int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0];
-        if (occ == 0) {
-            int nb = 0;
-            POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS>, 256, lds));
-            occ = std::max(1, std::min(nb, 4));
-            if (getenv("POLEE_DEBUG_PRINT"))
-                fprintf(stderr, "[loglik] stream kernel K=%d: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
-                        K, nb, lds, occ, ctx->num_cus);
+        if (h.num_tiles_a > 0) {
+            if (ll->deterministic)
+                POLEE_TRY((launch_stream<K, LP, KS, true>(ll, A, dbg)));
+            else
+                POLEE_TRY((launch_stream<K, LP, KS, false>(ll, A, dbg)));
         }
-        const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1));
-        POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
-        A.sched = ll->d_sched.p;
-        const int64_t total = ll->dict_len * K;
-        hipLaunchKernelGGL(xwin_gather_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, ll->d_dict.p, d_x, K,
-                           total, ll->d_xwin.p);
-        if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
-        hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
-        if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
         if (tiles_b > 0) {
-            // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes
+            // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes (with
+            // float atomics: a sample that has such rows is not bitwise reproducible in deterministic mode either)
             hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds_psell, st, A,
                                (int)h.num_tiles_a, (const uint32_t *)nullptr);
         }
@@ -1165,6 +1269,26 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
             while (wv < nw && (acc >= total * wv / nw || sl + 1 - (wv == 1 ? s0 : cut[wv - 2]) >= 63u)) cut[wv++ - 1] = sl + 1;
         }
     }
+    {   // deterministic mode: the dictionary entries of every transcript, ascending (= tile order), padding left out
+        std::vector<uint32_t> ptr((size_t)ll->n + 1, 0), slots;
+        for (int64_t t = 0; t < h.num_tiles_a; ++t)
+            for (uint32_t l = 0; l < h.tile_cols[t]; ++l) ++ptr[(size_t)h.dict[h.tile_dict[t] + l] + 1];
+        for (int64_t j = 0; j < ll->n; ++j) ptr[(size_t)j + 1] += ptr[(size_t)j];
+        slots.resize(ptr[(size_t)ll->n]);
+        std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+        for (int64_t t = 0; t < h.num_tiles_a; ++t)
+            for (uint32_t l = 0; l < h.tile_cols[t]; ++l) {
+                const uint32_t e = h.tile_dict[t] + l;
+                slots[cur[h.dict[e]]++] = e;
+            }
+        std::vector<uint32_t> heavy;
+        for (int64_t j = 0; j < ll->n; ++j)
+            if (ptr[(size_t)j + 1] - ptr[(size_t)j] > GWIN_HEAVY) heavy.push_back((uint32_t)j);
+        if ((s = ll->d_tslot_ptr.upload(ctx, ptr)) || (s = ll->d_tslot.upload(ctx, slots)) || (s = ll->d_theavy.upload(ctx, heavy))) {
+            loglik_release(ll);
+            return s;
+        }
+    }
     if ((s = ll->d_xwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512)) ||
         (s = ensure_schedule(ll, (int)std::min<int64_t>((int64_t)4 * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1))))) {
         loglik_release(ll);
@@ -1247,6 +1371,13 @@ std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_byte
 }  // namespace polee
 
 extern "C" {
+
+polee_status polee_loglik_set_deterministic(polee_loglik *ll, int on)
+{
+    if (!ll) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    ll->deterministic = on != 0;
+    return POLEE_OK;
+}
 
 polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on)
 {

@@ -106,7 +106,13 @@ struct polee_loglik {
     std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
     std::vector<uint32_t> tile_cut;  // [3 * num_tiles] slice boundaries between the waves of a uniform tile
     int64_t dict_len = 0;
-    int occ_cache[polee::PSELL_MAX_K + 1][2][2] = {};
+    int occ_cache[polee::PSELL_MAX_K + 1][2][2][2] = {};
+    // deterministic mode (polee_loglik_set_deterministic): per-tile gradient windows, per-workgroup lp sums, and the
+    // dictionary entries of every transcript in tile order
+    bool deterministic = false;
+    polee::DevBuf<float> d_gwin;
+    polee::DevBuf<double> d_lpwin;
+    polee::DevBuf<uint32_t> d_tslot_ptr, d_tslot, d_theavy;  // (d_theavy: transcripts present in many tiles)
     // staging for the host-pointer API
     polee::DevBuf<float> d_x_rows, d_x_aos, d_g_aos;
     polee::DevBuf<double> d_g_rows, d_lp;

@@ -434,7 +434,7 @@ void polee_vi_default_opts(polee_vi_opts *o)
     o->max_omega_step = 2e-1;
     o->max_alpha_step = 2e-2;
     o->profile = 0;
-    o->reserved = 0;
+    o->deterministic = 0;
     o->gene_of = nullptr;
 }
 
@@ -488,6 +488,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     vi->n = t->n;
     vi->K = o.num_mc_samples;
     ll->profile = o.profile != 0;
+    if (o.deterministic) ll->deterministic = true;
     const size_t n = vi->n, nm1 = std::max<size_t>(n - 1, 1), K = vi->K;
     polee_status s = POLEE_OK;
     auto A = [&](polee_status r) {

@@ -451,6 +451,43 @@ def test_vi_trajectory_with_gene_noninformative_prior(P, ctx, lm_fixture, prep_f
     np.testing.assert_allclose(got3["lp_mean"], plain["lp_mean"], rtol=1e-5)
 
 
+def test_deterministic_mode_is_bitwise_reproducible(P, ctx, lm_fixture, prep_fixture):
+    """polee_loglik_set_deterministic: fixed-order sums instead of float atomics.  Two evaluations of the same inputs
+    and two whole fits with the same noise agree BIT FOR BIT (the default mode does not promise that), and the values
+    are the default mode's up to float32 summation order."""
+    f = lm_fixture
+    s = _gpu_sample(P, ctx, f)
+    t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=ctx)
+    rng = np.random.default_rng(3)
+    x = rng.dirichlet(np.ones(f["n"]), size=6).astype(np.float32)
+    lp0, g0 = s.log_likelihood(x)
+    s.set_deterministic(True)
+    lp1, g1 = s.log_likelihood(x)
+    for _ in range(3):
+        lp2, g2 = s.log_likelihood(x)
+        assert np.array_equal(lp1, lp2) and np.array_equal(g1, g2)
+    np.testing.assert_allclose(lp1, lp0, rtol=1e-12)
+    np.testing.assert_allclose(g1, g0, rtol=2e-5, atol=1e-6 * np.abs(g0).max())
+    so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
+    for k in range(6):
+        lpo, go = so.log_likelihood(x[k])
+        assert abs(lp1[k] - lpo) <= 1e-6 * abs(lpo)
+        np.testing.assert_allclose(g1[k], go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
+    s.set_deterministic(False)
+    steps, K = 40, 6
+    z0 = O.randn(steps * K * (f["n"] - 1), 31)
+    fits = []
+    for _ in range(2):
+        fit = P.LikelihoodApproximationFit(s, t, num_steps=steps, num_mc_samples=K, z0=z0, gradonly=False, deterministic=True)
+        fit.run(steps)
+        fit.sync()
+        fits.append((fit.params(), fit.trace()))
+    for a, b in zip(fits[0][0], fits[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(fits[0][1][1], fits[1][1][1])  # the E[lp] trace too
+    s.set_deterministic(False)
+
+
 def _expected_loglik(so, to, mu, omega, alpha, efflens, ndraws, seed):
     sigma = np.exp(omega)
     lps, pm = [], np.zeros(to.n)
