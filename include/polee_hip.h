@@ -58,6 +58,8 @@ polee_status polee_ctx_create(int device, polee_ctx **out);
 void polee_ctx_destroy(polee_ctx *ctx);
 const char *polee_last_error(const polee_ctx *ctx_or_null);
 polee_status polee_ctx_synchronize(polee_ctx *ctx);
+/* free / total device memory of the context's GPU (hipMemGetInfo), in bytes; either pointer may be NULL */
+polee_status polee_ctx_mem_info(polee_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 void *polee_ctx_stream(polee_ctx *ctx); /* the context's hipStream_t */
 /* HIP-event stopwatch on the context's stream (bench.py times the hot path with it). */
 polee_status polee_ctx_timer_start(polee_ctx *ctx);

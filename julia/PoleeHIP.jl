@@ -119,7 +119,8 @@ mutable struct ViOpts
     adam_initial_learning_rate::Float64; adam_learning_rate_decay::Float64; adam_min_learning_rate::Float64
     adam_eps::Float64; adam_rv::Float64; adam_rm::Float64
     max_mu_step::Float64; max_omega_step::Float64; max_alpha_step::Float64
-    profile::Int32; reserved::Int32
+    profile::Int32; deterministic::Int32
+    gene_of::Ptr{Int32}   # optional: gene index of every transcript (0-based, -1 = none known) = gene_noninformative
     ViOpts() = (o = new(); ccall((:polee_vi_default_opts, LIB), Cvoid, (Ref{ViOpts},), o); o)
 end
 
@@ -128,10 +129,21 @@ approximate_likelihood(::LogitSkewNormalPTTApprox, sample) replacement: returns 
 ("mu", "omega", "alpha") exactly as likelihood-approximation.jl:615-623 does.
 """
 function approximate_likelihood(s::DeviceSample, t::PolyaTreeTransform, efflens::Vector{Float32};
-                                use_efflen_jacobian::Bool=true, seed::Integer=123456789)
-    o = ViOpts(); o.use_efflen_jacobian = use_efflen_jacobian; o.seed = seed
+                                use_efflen_jacobian::Bool=true, seed::Integer=123456789,
+                                gene_transcripts::Union{Nothing,Dict{String,Vector{Int}}}=nothing,  # gene_noninformative
+                                deterministic::Bool=false)
+    o = ViOpts(); o.use_efflen_jacobian = use_efflen_jacobian; o.seed = seed; o.deterministic = deterministic
+    # the reference's Dict{gene id -> transcript indexes} (likelihood-approximation.jl:475-487) as gene_of[n]
+    gene_of = Int32[]
+    if gene_transcripts !== nothing && !isempty(gene_transcripts)
+        gene_of = fill(Int32(-1), s.n)
+        for (gi, idxs) in enumerate(values(gene_transcripts)), i in idxs
+            gene_of[i] = gi - 1
+        end
+        o.gene_of = pointer(gene_of)
+    end
     mu = Vector{Float32}(undef, s.n - 1); omega = similar(mu); alpha = similar(mu)
-    GC.@preserve efflens mu omega alpha check(
+    GC.@preserve efflens mu omega alpha gene_of check(
         ccall((:polee_vi_fit, LIB), Cint,
               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ref{ViOpts}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
               s.h, t.h, efflens, o, mu, omega, alpha, C_NULL), s.ctx.h)
@@ -146,6 +158,17 @@ function rand_draws!(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{F
               (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, UInt64, Ptr{Float32}),
               t.h, mu, sigma, alpha, C_NULL, size(xs, 2), seed, xs), t.ctx.h)
     return xs
+end
+
+"x0 of load_samples_hdf5 -- src/estimate.jl:436-455: mean of N draws (y clamped, / efflens, renormalised)"
+function initial_values(t::PolyaTreeTransform, mu::Vector{Float32}, sigma::Vector{Float32}, alpha::Vector{Float32},
+                        efflens::Vector{Float32}, N::Integer=30; seed::Integer=rand(UInt64))
+    x0 = Vector{Float32}(undef, length(mu) + 1)
+    GC.@preserve mu sigma alpha efflens x0 check(
+        ccall((:polee_sampler_initial_values, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, UInt64, Ptr{Float32}),
+              t.h, mu, sigma, alpha, efflens, C_NULL, N, seed, x0), t.ctx.h)
+    return x0
 end
 
 "one sample of posterior_mean(loaded_samples, N) -- src/approx-sampler.jl:86-117"

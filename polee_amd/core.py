@@ -29,6 +29,12 @@ class Context:
         except Exception:
             pass
 
+    def mem_info(self):
+        """(free, total) device memory in bytes."""
+        f, t = C.c_int64(), C.c_int64()
+        check(L.lib().polee_ctx_mem_info(self._h, C.byref(f), C.byref(t)), self._h)
+        return f.value, t.value
+
     def synchronize(self):
         check(L.lib().polee_ctx_synchronize(self._h), self._h)
 

@@ -122,11 +122,43 @@ struct DevBuf {
     }
 };
 
+// host threads for the one-off layout work (bounded: the loops are memory-bound well before 64 threads)
+inline unsigned host_threads()
+{
+    static const unsigned n = [] {
+        unsigned cap = 48;
+        if (const char *e = getenv("POLEE_HOST_THREADS")) cap = (unsigned)std::max(1, atoi(e));
+        return std::max(1u, std::min(cap, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+
+// std::vector allocator that leaves trivially constructible elements uninitialised on resize (a 1 GB resize otherwise
+// spends its time writing zeros that are overwritten at once)
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = default_init_allocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+
 // f(lo, hi, thread) over [0, count) in chunks of `grain` on a few host threads (dynamic assignment)
 template <class F>
 inline void parallel_chunks(size_t count, size_t grain, F &&f)
 {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned hw = host_threads();
     const size_t nchunks = (count + grain - 1) / grain;
     if (hw == 1 || nchunks <= 1) {
         for (size_t c = 0; c < nchunks; ++c) f(c * grain, std::min(count, (c + 1) * grain), 0u);

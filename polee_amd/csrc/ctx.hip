@@ -79,6 +79,16 @@ polee_status polee_ctx_synchronize(polee_ctx *ctx)
     return POLEE_OK;
 }
 
+polee_status polee_ctx_mem_info(polee_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    POLEE_TRY(use_device(ctx));
+    size_t f = 0, t = 0;
+    POLEE_HIP_TRY(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return POLEE_OK;
+}
+
 void *polee_ctx_stream(polee_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 polee_status polee_ctx_timer_start(polee_ctx *ctx)

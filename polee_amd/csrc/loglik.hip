@@ -1228,7 +1228,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     PsellHost &h = ll->host;
     polee_status s;
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
-    if ((s = ll->d_data.upload(ctx, h.data)) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
+    if ((s = ll->d_data.upload(ctx, h.data.data(), h.data.size())) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) ||
         (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
@@ -1295,7 +1295,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         return s;
     }
     // keep only metadata on the host
-    std::vector<uint8_t>().swap(h.data);
+    decltype(h.data)().swap(h.data);
     std::vector<uint32_t>().swap(h.slice_off);
     std::vector<uint32_t>().swap(h.dict);
     std::vector<float>().swap(h.slice_ks);

@@ -70,7 +70,7 @@ struct PsellHost {
     int64_t rows_a1 = 0, num_tiles_a1 = 0;
     int64_t stream_rows[3] = {0, 0, 0}, stream_nnz[3] = {0, 0, 0}, stream_bytes[3] = {0, 0, 0};  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
     int32_t max_row = 0, max_tile_cols = 0;
-    std::vector<uint8_t> data;         // slice blocks, 384*w bytes each
+    std::vector<uint8_t, default_init_allocator<uint8_t>> data;  // slice blocks (resize(n) leaves new bytes uninitialised; resize(n, 0) zeroes)
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units in bits 0..29, slice flags in bits 30..31
     std::vector<uint32_t> tile_slice;  // [num_tiles+1]
     std::vector<uint32_t> tile_dict;   // [num_tiles+1], multiples of PSELL_DICT_ALIGN

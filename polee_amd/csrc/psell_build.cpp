@@ -28,7 +28,7 @@ static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> 
     if (N < 2) return;
     std::vector<uint64_t> k2(N);
     std::vector<uint32_t> v2(N);
-    const unsigned T = N < ((size_t)1 << 16) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned T = N < ((size_t)1 << 16) ? 1u : std::min(host_threads(), 32u);
     std::vector<std::vector<size_t>> hist(T, std::vector<size_t>(65536));
     auto run = [&](auto &&f) {
         if (T == 1) {
@@ -165,26 +165,63 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         });
         std::vector<uint32_t> ra1, ra2, rb, e1, e2;
         std::vector<uint8_t> u1, u2;  // row belongs to a union slice
-        size_t i = 0;
-        while (i < rows.size()) {
-            size_t j = i + 1;
-            while (j < rows.size() && !head[j]) ++j;
-            const size_t r = j - i;
-            const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
-            size_t take = (r / PSELL_LANES) * PSELL_LANES;
-            if (r - take >= (size_t)PSELL_MIN_UNIFORM_ROWS) take = r;
-            if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
-            std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? ra1 : ra2;
-            std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? e1 : e2;
-            std::vector<uint8_t> &du = len <= (uint64_t)PSELL_NARROW_MAX ? u1 : u2;
-            for (size_t q = 0; q < take; ++q) {
-                du.push_back(0);
-                dst.push_back(rows[i + q]);
-                // slice boundary inside the run: after every 64 rows, and at the end of the taken part
-                de.push_back((q + 1) % PSELL_LANES == 0 || q + 1 == take ? 1u : 0u);
+        // (on several host threads: chunks of rows that start at a run's head, each with its own output lists, which are
+        // then joined in chunk order -- the result does not depend on the number of threads)
+        struct Part {
+            std::vector<uint32_t> ra1, ra2, rb, e1, e2;
+        };
+        const size_t CH = (size_t)1 << 20;
+        const size_t nparts = std::max<size_t>(1, (rows.size() + CH - 1) / CH);
+        std::vector<size_t> pstart(nparts + 1, rows.size());
+        for (size_t p = 0; p < nparts; ++p) {
+            size_t a = p * CH;
+            while (a < rows.size() && !head[a]) ++a;  // (head[0] = 1)
+            pstart[p] = a;
+        }
+        std::vector<Part> parts(nparts);
+        parallel_chunks(nparts, 1, [&](size_t plo, size_t phi, unsigned) {
+            for (size_t p = plo; p < phi; ++p) {
+                Part &P = parts[p];
+                size_t i = pstart[p];
+                const size_t end = pstart[p + 1];
+                while (i < end) {
+                    size_t j = i + 1;
+                    while (j < rows.size() && !head[j]) ++j;
+                    const size_t r = j - i;
+                    const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
+                    size_t take = (r / PSELL_LANES) * PSELL_LANES;
+                    if (r - take >= (size_t)PSELL_MIN_UNIFORM_ROWS) take = r;
+                    if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
+                    std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? P.ra1 : P.ra2;
+                    std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? P.e1 : P.e2;
+                    for (size_t q = 0; q < take; ++q) {
+                        dst.push_back(rows[i + q]);
+                        // slice boundary inside the run: after every 64 rows, and at the end of the taken part
+                        de.push_back((q + 1) % PSELL_LANES == 0 || q + 1 == take ? 1u : 0u);
+                    }
+                    P.rb.insert(P.rb.end(), rows.begin() + i + take, rows.begin() + j);
+                    i = j;
+                }
             }
-            rb.insert(rb.end(), rows.begin() + i + take, rows.begin() + j);
-            i = j;
+        });
+        {
+            size_t n1 = 0, n2 = 0, nb = 0;
+            for (const Part &P : parts) {
+                n1 += P.ra1.size();
+                n2 += P.ra2.size();
+                nb += P.rb.size();
+            }
+            ra1.reserve(n1); e1.reserve(n1); ra2.reserve(n2); e2.reserve(n2); rb.reserve(nb);
+            for (Part &P : parts) {
+                ra1.insert(ra1.end(), P.ra1.begin(), P.ra1.end());
+                e1.insert(e1.end(), P.e1.begin(), P.e1.end());
+                ra2.insert(ra2.end(), P.ra2.begin(), P.ra2.end());
+                e2.insert(e2.end(), P.e2.begin(), P.e2.end());
+                rb.insert(rb.end(), P.rb.begin(), P.rb.end());
+                Part().ra1.swap(P.ra1);
+            }
+            u1.assign(ra1.size(), 0);
+            u2.assign(ra2.size(), 0);
         }
         // UNION slices: the leftover rows (runs and run remainders of < 32 rows) of neighbouring transcript sets are packed
         // into uniform slices whose header is the UNION of their sets, rows holding zeros for the transcripts they are
@@ -294,7 +331,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         }
     }
     static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
-    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nthreads = host_threads();
     std::vector<std::vector<uint32_t>> stamps(nthreads);
     std::vector<std::vector<uint16_t>> locals(nthreads);
     std::vector<uint32_t> next_tile_id(nthreads, 1);
@@ -556,9 +593,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // the bulk copy in parallel
         parallel_chunks(segs.size(), 1, [&](size_t lo, size_t hi, unsigned) {
             for (size_t si = lo; si < hi; ++si) {
-                const std::vector<uint8_t> &d = segs[si].frag.data;
+                auto &d = segs[si].frag.data;
                 if (!d.empty()) memcpy(out.data.data() + data_base[si], d.data(), d.size());
-                std::vector<uint8_t>().swap(segs[si].frag.data);
+                decltype(segs[si].frag.data)().swap(d);
             }
         });
         segs.clear();

@@ -792,14 +792,13 @@ def test_row_sharded_fit_with_one_rank_equals_the_plain_fit(P, ctx, lm_fixture, 
 def test_handles_release_device_memory(P, lm_fixture, prep_fixture):
     """create / destroy cycles of every handle type (in arbitrary finaliser order) give the device memory back."""
     import gc
-    import torch
     f = lm_fixture
-    torch.cuda.init()
+    probe = P.Context(0)
 
     def free_bytes():
         gc.collect()
-        torch.cuda.synchronize()
-        return torch.cuda.mem_get_info(0)[0]
+        probe.synchronize()
+        return probe.mem_info()[0]
 
     def cycle():
         ctx = P.Context(0)
