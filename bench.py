@@ -315,7 +315,7 @@ def main():
 
     kern_ms, pass_ms = avg("loglik_kernel_ms_avg"), avg("loglik_pass_ms_avg")
     bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
-    # the whole pass is one launch (loglik_fused_kernel: three kinds of workgroups, one per row stream)
+    # the pass is one persistent launch, loglik_stream_kernel (+ a 9 us gather of the x windows in front of it)
     bytes_dom = bytes_pass
     achieved = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile.sh): a capture is
@@ -329,7 +329,8 @@ def main():
                 traffic = cap.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    # what the launch physically moves: the slice stream once + the x / g windows (dictionary entries x K x 4 B, each way)
+    # what the launch physically moves: the slice stream once + the x windows read and the g windows added
+    # (dictionary entries x K x 4 B each way)
     phys_bytes = sum(info["stream_bytes_hbm"]) + 2 * 4 * K * info.get("dict_entries", 0)
     phys = phys_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
@@ -350,7 +351,7 @@ def main():
             "workload": "%s: one sample per GPU, n=%d transcripts x m=%d fragments, nnz=%d (%.2f/fragment), "
                         "K=%d draws per VI iteration, %s tree" % (args.workload.upper(), n, m, info["nnz"],
                                                                   info["nnz"] / m, K, args.tree),
-            "samples_per_gpu": S,
+            "samples_per_gpu": S, "draws": K, "tree": args.tree, "nnz": info["nnz"], "deterministic": bool(args.deterministic),
             "parallelism": "one sample row-sharded over %d GPU(s), 1 all-reduce of K*n f32 per pass" % world
                            if args.row_shard else "sample-per-GPU x%d, no collective" % world if S == 1 else
                            "%d concurrent samples per GPU x%d GPUs, no collective" % (S, world),

@@ -94,12 +94,10 @@ __device__ inline float fast_weight(float ksv, float s)
     // ks / s with v_rcp_f32 (1 ulp): well inside the 1e-4 budget, 10x fewer instructions than a division
     return s > 0.0f ? ksv * __builtin_amdgcn_rcpf(s) : 0.0f;  // padded lanes (and empty rows) have s = 0
 }
-// 1 / s for the matrix-core path, two instructions: padded lanes have s = 0 AND only zero values, so their weight only
-// has to be finite (1 / FLT_MIN x 0 = 0); a real row sum is never below FLT_MIN (values >= 1e-12, x >= 1e-16 ...)
-__device__ inline float unit_weight(float s)
-{
-    return __builtin_amdgcn_rcpf(fmaxf(s, 1.17549435e-38f));
-}
+// Row sums of the matrix-core path start from FLT_MIN instead of 0: a padded lane (no fragment: only zero values) then
+// has s = FLT_MIN and a finite weight 1 / FLT_MIN, which multiplies zeros; a real row sum (values >= 1e-12, x >= 1e-16:
+// s >= 1e-28) is unchanged by the addend, bit for bit.  The weight is then one v_rcp_f32, no compare or select.
+constexpr float ROWSUM_FLOOR = 1.17549435e-38f;
 
 // ---- stream B (and fallback for very wide rows): mixed slices ---------------------------------------
 // Two sweeps over each slice straight from global memory (the second one hits L1/L2); contributions
@@ -384,7 +382,10 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 {
     constexpr int RPFULL = (int)(RB / 1024u);
     const int RP = ((dbg >> 8) & 15) ? min(RPFULL, (WMAXR > 16 ? 2 : 1) * ((dbg >> 8) & 15)) : RPFULL;  // (experiment: pieces requested ahead)
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    // (opaque: the lane constants below are then recomputed per tile -- a few dozen instructions -- instead of being
+    // hoisted out of the kernel's tile loop, kept alive across it and spilled)
+    asm volatile("" : "+v"(lane));
     const uint32_t ring_lds = lds_addr(ring);
 
     // lane l = (tt = l & 15, q = l >> 4).  A slice is a (w x 64) block V[t][r]:
@@ -461,10 +462,12 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
     auto k2f = [&](int st) -> uint32_t { return ring_lds + (uint32_t)((tt + 4 * st + q) & 15) * 16u; };  // phase 1, step st: row 4 st + q, chunk (tt + row) & 15
     auto c2f = [&](int mt, int j) -> uint32_t { return ring_lds + (uint32_t)((4 * q + j + 16 * mt + tt) & 15) * 16u; };  // phase 2, tile mt: row 16 mt + tt
     uint32_t k2[PRE ? NS : 1];
-    uint32_t c2[PRE ? 4 : 1];
     if (PRE) {
 #pragma unroll
         for (int st = 0; st < NS; ++st) k2[PRE ? st : 0] = k2f(st);
+    }
+    uint32_t c2[PRE ? 4 : 1];
+    if (PRE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c2[PRE ? j : 0] = c2f(0, j);
     }
@@ -548,7 +551,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         // phase 1
         f32x4 d1[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) d1[e] = f32x4{ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR};
         if (!(dbg & 4)) {
 #pragma unroll
             for (int g0 = 0; g0 < NS; g0 += 4) {
@@ -598,8 +601,8 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sv = d1[e][v];
-                    if (WANT_LP && sv > 0.0f) lpacc += (double)kv[e] * log((double)sv);
-                    d1[e][v] = fast_weight(kv[e], sv);
+                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lpacc += (double)kv[e] * log((double)sv);
+                    d1[e][v] = kv[e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
                 }
             }
         } else {
@@ -608,8 +611,8 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float sv = d1[e][v];
-                    if (WANT_LP && sv > 0.0f) lpacc += log((double)sv);
-                    d1[e][v] = unit_weight(sv);
+                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lpacc += log((double)sv);
+                    d1[e][v] = __builtin_amdgcn_rcpf(sv);
                 }
         }
 

@@ -33,9 +33,13 @@ for r in s.get("kernel_stats", []):
 if dom:
     c = s["pmc"][dom[0]]
     hbm = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024
+    cfg = (bench or {}).get("config", {})
     json.dump({"kernel": dom[0], "hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB": c.get("FETCH_SIZE"),
                "WRITE_SIZE_KiB": c.get("WRITE_SIZE"), "correction": "fetch x2 (gfx950 wide coalesced loads), write x1",
-               "source": "profiles/%s_pmc.json" % tag}, open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
+               "source": "profiles/%s_pmc.json" % tag,
+               # the capture is valid for this workload only (bench.py emits `traffic` when these match its run)
+               "draws": cfg.get("draws"), "tree": cfg.get("tree"), "nnz": cfg.get("nnz")},
+              open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8
     lines += ["", "## Dominant kernel `%s`" % dom[0][:60], "",
               "* HBM traffic per launch (PMC): %.3f GB (FETCH_SIZE %.0f KiB x2 + WRITE_SIZE %.0f KiB)" % (hbm / 1e9, c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)),
