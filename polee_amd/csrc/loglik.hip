@@ -14,6 +14,7 @@
 #include "wave.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <type_traits>
 
@@ -1226,10 +1227,17 @@ polee_status polee_loglik::profile_collect()
     return POLEE_OK;
 }
 
+static double wall_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee_loglik **out)
 {
     PsellHost &h = ll->host;
     polee_status s;
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    const double t_begin = wall_now();
     h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
     if ((s = ll->d_data.upload(ctx, h.data.data(), h.data.size())) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
@@ -1238,6 +1246,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         loglik_release(ll);
         return s;
     }
+    if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "upload", wall_now() - t_begin);
     // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
     // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule
     ll->dict_len = (int64_t)h.dict.size();
@@ -1297,6 +1306,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         loglik_release(ll);
         return s;
     }
+    if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "upload + schedule + lists", wall_now() - t_begin);
     // keep only metadata on the host
     decltype(h.data)().swap(h.data);
     std::vector<uint32_t>().swap(h.slice_off);
@@ -1398,9 +1408,13 @@ polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, c
         return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_xt: bad argument");
     if (tcolptr[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "tcolptr[0] must be 1 (1-based)");
     const uint64_t nnz = tcolptr[m] - 1;
-    std::vector<uint64_t> rowptr(m + 1);
-    for (int64_t i = 0; i <= m; ++i) rowptr[i] = tcolptr[i] - 1;
-    std::vector<uint32_t> col(nnz);
+    const double t_begin = wall_now();
+    // (0-based copies; vectors that do not zero-fill a gigabyte first, filled on several threads)
+    std::vector<uint64_t, default_init_allocator<uint64_t>> rowptr(m + 1);
+    parallel_chunks((size_t)m + 1, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t i = lo; i < hi; ++i) rowptr[i] = tcolptr[i] - 1;
+    });
+    std::vector<uint32_t, default_init_allocator<uint32_t>> col(nnz);
     {
         std::atomic<int> bad{0};
         parallel_chunks((size_t)nnz, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
@@ -1419,6 +1433,7 @@ polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, c
     ll->n = n;
     ll->nnz = (int64_t)nnz;
     ll->has_ks = ks != nullptr;
+    if (getenv("POLEE_BUILD_TIMING")) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "0-based copies of the input", wall_now() - t_begin);
     std::string err = build_psell(m, n, rowptr.data(), col.data(), tnzval, ks, ll->host);
     if (!err.empty()) {
         loglik_release(ll);

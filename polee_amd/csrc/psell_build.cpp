@@ -243,7 +243,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 std::vector<uint32_t> &dst = cls == 0 ? ra1 : ra2;
                 std::vector<uint32_t> &de = cls == 0 ? e1 : e2;
                 std::vector<uint8_t> &du = cls == 0 ? u1 : u2;
-                std::vector<uint32_t> pool, deferred, group, uni, tmp;
+                std::vector<uint32_t> pool;
                 for (uint32_t r : cand) {
                     const uint64_t len = rowptr[r + 1] - rowptr[r];
                     if (cls == 0 ? len <= (uint64_t)PSELL_NARROW_MAX : (len > (uint64_t)PSELL_NARROW_MAX && len <= (uint64_t)PSELL_WIDE_MAX))
@@ -251,39 +251,64 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     else if (cls == 0 && len > (uint64_t)PSELL_WIDE_MAX)
                         keep_b.push_back(r);
                 }
-                auto close_group = [&]() {
-                    if (group.size() >= (size_t)PSELL_MIN_UNION_ROWS) {
-                        for (size_t q = 0; q < group.size(); ++q) {
-                            dst.push_back(group[q]);
-                            de.push_back(q + 1 == group.size() ? 1u : 0u);
-                            du.push_back(1);
-                        }
-                    } else {
-                        keep_b.insert(keep_b.end(), group.begin(), group.end());
-                    }
-                    group.clear();
-                    uni.clear();
+                // (chunks of 32 768 candidate rows are packed independently on several threads and joined in order: a
+                // group never spans two chunks, and the result does not depend on the number of threads)
+                struct UPart {
+                    std::vector<uint32_t> rows, ends, left;
                 };
-                for (int pass = 0; pass < 2; ++pass) {
-                    const std::vector<uint32_t> &src = pass == 0 ? pool : deferred;
-                    for (uint32_t r : src) {
-                        const uint32_t *cb = col + rowptr[r], *ce = col + rowptr[r + 1];
-                        tmp.resize(uni.size() + (size_t)(ce - cb));
-                        tmp.resize((size_t)(std::set_union(uni.begin(), uni.end(), cb, ce, tmp.begin()) - tmp.begin()));
-                        if (tmp.size() <= cap && group.size() < (size_t)PSELL_LANES) {
-                            uni.swap(tmp);
-                            group.push_back(r);
-                            continue;
+                const size_t UCH = (size_t)1 << 15;
+                const size_t nup = std::max<size_t>(1, (pool.size() + UCH - 1) / UCH);
+                std::vector<UPart> uparts(nup);
+                parallel_chunks(nup, 1, [&](size_t ulo, size_t uhi, unsigned) {
+                    std::vector<uint32_t> deferred, group, uni, tmp;
+                    for (size_t up = ulo; up < uhi; ++up) {
+                        UPart &U = uparts[up];
+                        auto close_group = [&]() {
+                            if (group.size() >= (size_t)PSELL_MIN_UNION_ROWS) {
+                                for (size_t q = 0; q < group.size(); ++q) {
+                                    U.rows.push_back(group[q]);
+                                    U.ends.push_back(q + 1 == group.size() ? 1u : 0u);
+                                }
+                            } else {
+                                U.left.insert(U.left.end(), group.begin(), group.end());
+                            }
+                            group.clear();
+                            uni.clear();
+                        };
+                        deferred.clear();
+                        const size_t p0 = up * UCH, p1 = std::min(pool.size(), p0 + UCH);
+                        for (int pass = 0; pass < 2; ++pass) {
+                            const uint32_t *src = pass == 0 ? pool.data() + p0 : deferred.data();
+                            const size_t cnt = pass == 0 ? p1 - p0 : deferred.size();
+                            std::vector<uint32_t> next_deferred;
+                            for (size_t qi = 0; qi < cnt; ++qi) {
+                                const uint32_t r = src[qi];
+                                const uint32_t *cb = col + rowptr[r], *ce = col + rowptr[r + 1];
+                                tmp.resize(uni.size() + (size_t)(ce - cb));
+                                tmp.resize((size_t)(std::set_union(uni.begin(), uni.end(), cb, ce, tmp.begin()) - tmp.begin()));
+                                if (tmp.size() <= cap && group.size() < (size_t)PSELL_LANES) {
+                                    uni.swap(tmp);
+                                    group.push_back(r);
+                                    continue;
+                                }
+                                if (pass == 0 && group.size() < 48 && uni.size() + 1 < cap) {
+                                    next_deferred.push_back(r);  // an outlier (a neighbouring gene's isoform): second pass
+                                    continue;
+                                }
+                                close_group();
+                                uni.assign(cb, ce);
+                                group.push_back(r);
+                            }
+                            close_group();
+                            if (pass == 0) deferred.swap(next_deferred);
                         }
-                        if (pass == 0 && group.size() < 48 && uni.size() + 1 < cap) {
-                            deferred.push_back(r);  // an outlier (a neighbouring gene's isoform): try again in the second pass
-                            continue;
-                        }
-                        close_group();
-                        uni.assign(cb, ce);
-                        group.push_back(r);
                     }
-                    close_group();
+                });
+                for (UPart &U : uparts) {
+                    dst.insert(dst.end(), U.rows.begin(), U.rows.end());
+                    de.insert(de.end(), U.ends.begin(), U.ends.end());
+                    du.insert(du.end(), U.rows.size(), (uint8_t)1);
+                    keep_b.insert(keep_b.end(), U.left.begin(), U.left.end());
                 }
             }
             rb.swap(keep_b);
@@ -311,7 +336,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     std::vector<Segment> segs;
     {
         static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
-        const size_t SEG_ROWS = seg_env >= 64 ? seg_env : (size_t)1 << 20;
+        const size_t SEG_ROWS = seg_env >= 64 ? seg_env : (size_t)1 << 18;  // (a few hundred segments at BASELINE's C2: enough for ~50 host threads)
         const size_t bounds[4] = {0, (size_t)out.rows_a1, (size_t)out.rows_a, rows.size()};
         for (int st = 0; st < 3; ++st) {
             size_t a = bounds[st];
