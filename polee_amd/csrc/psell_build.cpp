@@ -558,6 +558,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             tot_tiles += (size_t)sg.frag.num_tiles;
             tot_dict += sg.frag.dict.size();
         }
+        out.data.reserve(tot_data + 4096);  // (the caller appends slack for the kernel's whole-piece reads: no reallocation)
         out.data.resize(tot_data);
         out.slice_off.assign(1, 0);
         out.tile_slice.assign(1, 0);
