@@ -68,6 +68,7 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env.setdefault("POLEE_HOST_THREADS", str(max(4, (os.cpu_count() or 8) // args.gpus)))  # (layout build threads per rank)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
