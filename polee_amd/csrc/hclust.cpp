@@ -218,12 +218,19 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     std::vector<uint32_t> cand, uniq;
     std::vector<double> csim, usim;
     const unsigned hw_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    double t_merge = 0, t_eval = 0, t_eval_heavy = 0, t_pop = 0;
+    size_t n_heavy = 0, n_pops = 0, n_cand = 0, n_uniq = 0;
     while (!queue.empty()) {
+        const double tp0 = timing ? now() : 0.0;
         const Edge e = queue.pop();
+        ++n_pops;
+        if (timing) t_pop += now() - tp0;
         if (deleted[e.j1] || deleted[e.j2]) continue;  // stale edge
         const uint32_t k = (uint32_t)nodes.size();
         nodes.push_back(TreeNode{0, (int32_t)e.j1, (int32_t)e.j2});
+        const double tm0 = timing ? now() : 0.0;
         read_sets.push_back(merge_sets(read_sets[e.j1], read_sets[e.j2]));
+        if (timing) t_merge += now() - tm0;
         neighbors.emplace_back();
         alive.push_back(1);
         deleted.push_back(0);
@@ -247,7 +254,12 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         auto eval = [&](size_t lo, size_t hi) {
             for (size_t c = lo; c < hi; ++c) usim[c] = relative_intersection(read_sets[uniq[c]], read_sets[k]);
         };
-        if (work > (size_t)4000000 && uniq.size() >= 8 && hw_threads > 1) {  // a heavy merge: share it out
+        const double te0 = timing ? now() : 0.0;
+        n_cand += cand.size();
+        n_uniq += uniq.size();
+        const bool heavy = work > (size_t)4000000 && uniq.size() >= 8 && hw_threads > 1;
+        if (heavy) ++n_heavy;
+        if (heavy) {  // a heavy merge: share it out
             const unsigned nt = (unsigned)std::min<size_t>(hw_threads, uniq.size() / 4);
             std::vector<std::thread> pool;
             for (unsigned th = 1; th < nt; ++th)
@@ -257,6 +269,7 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         } else {
             eval(0, uniq.size());
         }
+        if (timing) (heavy ? t_eval_heavy : t_eval) += now() - te0;
         csim.resize(cand.size());
         for (size_t c = 0; c < cand.size(); ++c)
             csim[c] = usim[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), cand[c]) - uniq.begin())];
@@ -268,6 +281,9 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         }
     }
 
+    if (timing)
+        fprintf(stderr, "[hclust]   pops %zu (%.3f s), merge_sets %.3f s, similarities %.3f s light + %.3f s in %zu heavy merges, "
+                        "candidates %zu, distinct %zu\n", n_pops, t_pop, t_merge, t_eval, t_eval_heavy, n_heavy, n_cand, n_uniq);
     lap("greedy joining");
     // remaining components: smallest first (:244-258)
     BinHeap<NodeWithSize, SizeBefore> rest;
