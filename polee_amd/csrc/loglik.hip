@@ -673,13 +673,22 @@ extern "C" int polee_debug_read_stamps(unsigned long long *out)
 
 // x window of every tile, contiguous: xwin[e * K + k] = x[dict[e]][k] for every dictionary entry e (tiles' dictionaries
 // start at multiples of 4 entries, so a tile's window starts 16-byte aligned).  One pass over 4 B x K per entry.
-__global__ void xwin_gather_kernel(const uint32_t *__restrict__ dict, const float *__restrict__ x, int K, int64_t total,
-                                   float *__restrict__ xwin)
+template <int K>
+__global__ __launch_bounds__(256) void xwin_gather_kernel(const uint32_t *__restrict__ dict, const float *__restrict__ x,
+                                                         int64_t entries, float *__restrict__ xwin)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t e = i / K;
-    xwin[i] = x[(size_t)dict[e] * K + (int)(i - e * K)];
+    // a thread per dictionary entry: K adjacent floats in, K adjacent floats out (8-byte accesses when K is even)
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    const float *src = x + (size_t)dict[e] * K;
+    float *dst = xwin + (size_t)e * K;
+    if constexpr (K % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) reinterpret_cast<float2 *>(dst)[k] = reinterpret_cast<const float2 *>(src)[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = src[k];
+    }
 }
 
 // deterministic mode, second kernel: g[j][k] += the windows' values of transcript j (tslot lists its dictionary entries,
@@ -1044,9 +1053,8 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         A.gwin = ll->d_gwin.p;
         A.lpwin = ll->d_lpwin.p;
     }
-    const int64_t total = ll->dict_len * K;
-    hipLaunchKernelGGL(xwin_gather_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, ll->d_dict.p, A.x, K,
-                       total, ll->d_xwin.p);
+    hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, ll->d_dict.p,
+                       A.x, ll->dict_len, ll->d_xwin.p);
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
