@@ -336,7 +336,7 @@ def main():
     if os.path.exists(tpath):
         try:
             cap = json.load(open(tpath))
-            if (cap.get("draws"), cap.get("tree"), cap.get("nnz")) == (K, args.tree, info["nnz"]):
+            if (cap.get("draws"), cap.get("tree"), cap.get("nnz")) == (K, args.tree, info["nnz"]) and not args.deterministic:
                 traffic = cap.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
