@@ -157,9 +157,9 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
         const int w = compact ? (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0) : (int)(units / 3u);  // (+ a ks row when factored)
-        // (compact slices store element r of row t at position (r + 4 t) & 63, see uniform_tile_body)
+        // (compact slices store element r of row t at position psell_row_pos(stream, t, r) of the row)
         const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0));
-        auto vat = [&](int t) -> float { return vbase[t * 64 + (compact ? ((lane + 4 * t) & 63) : lane)]; };
+        auto vat = [&](int t) -> float { return vbase[t * 64 + (compact ? (int)psell_row_pos(tile < A.tiles_a1 ? 0 : 1, (uint32_t)t, (uint32_t)lane) : lane)]; };
         const uint16_t *cols = compact ? reinterpret_cast<const uint16_t *>(data + (size_t)off * 128)
                                        : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
         const int cstride = compact ? 1 : 64;
@@ -320,6 +320,16 @@ __device__ inline void wait_vm_outstanding(int allowed)
     }
 }
 
+// This lane's index in its wave, computed where it is used (two instructions): a lane index kept in a register across
+// the tile loop is spilled under the slice loop's register pressure, and its reload comes with an s_waitcnt vmcnt(0) that
+// drains the LDS-DMA ring which has just been started.
+__device__ inline int wave_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its vector-memory queue
 // (__syncthreads() would drain the LDS-DMA ring that has just been started for the next tile)
 __device__ inline void lds_barrier()
@@ -369,7 +379,7 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
     // (wave-uniform counters: say so, or the loop below is compiled as a divergent loop on vector registers)
     int issued = __builtin_amdgcn_readfirstlane(ws.issued), islot = __builtin_amdgcn_readfirstlane(ws.islot);
     target = __builtin_amdgcn_readfirstlane(target);
-    const uint32_t voff = (uint32_t)(threadIdx.x & 63) * 16u;
+    const uint32_t voff = (uint32_t)wave_lane() * 16u;
     const uint8_t *src = reinterpret_cast<const uint8_t *>(uniform_ptr(ws.gsrc + (size_t)issued * 1024));
     for (; issued < target; ++issued) {
         dma_1k(src, voff, ring_lds + (uint32_t)islot * 1024u);
@@ -384,20 +394,40 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
 // transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
 // the first refill (the previous tile's flush, the next tile's prefetch): they are younger than the primed pieces
 // and older than every other piece, so only waits for primed pieces have to allow for them.
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, class Hook>
+__device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
+                                     uint32_t aux_lds, double &lpacc, int dbg
+#ifdef POLEE_STAMPS
+                                     , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+#endif
+                                     , const Hook &hook);
+
 template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS, class Hook = NoHook>
 __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
-                                      double &lpacc, int dbg
+                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                       , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
 #endif
                                       , const Hook &hook = Hook())
 {
+    if constexpr (WMAXR <= PSELL_NARROW_MAX) {
+#ifdef POLEE_KEEP_OLD_NARROW
+        if (!(dbg & 32))  // (dbg & 32: the 16 x 16 x 4 formulation below, for A/B runs)
+#endif
+        {
+            narrow_stream<K, RB, WANT_LP, HAS_KS, Hook>(ws, ring, extras, xw, gw, aux_lds, lpacc, dbg
+#ifdef POLEE_STAMPS
+                                                        , st_acc, st_last
+#endif
+                                                        , hook);
+            return;
+        }
+    }
     constexpr int RPFULL = (int)(RB / 1024u);
     const int RP = ((dbg >> 8) & 15) ? min(RPFULL, (WMAXR > 16 ? 2 : 1) * ((dbg >> 8) & 15)) : RPFULL;  // (experiment: pieces requested ahead)
-    int lane = threadIdx.x & 63;
-    // (opaque: the lane constants below are then recomputed per tile -- a few dozen instructions -- instead of being
-    // hoisted out of the kernel's tile loop, kept alive across it and spilled)
-    asm volatile("" : "+v"(lane));
+    // (computed here, opaquely: the lane constants below are then recomputed per tile -- a few dozen instructions --
+    // instead of being hoisted out of the kernel's tile loop, kept alive across it and spilled)
+    const int lane = wave_lane();
     const uint32_t ring_lds = lds_addr(ring);
 
     // lane l = (tt = l & 15, q = l >> 4).  A slice is a (w x 64) block V[t][r]:
@@ -677,6 +707,320 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
     if (pend_w != 0) flush();
 }
 
+
+// ---- the slice loop of the narrow stream (transcript sets of <= 16): batched outer products ---------------------------
+// With K <= 8 draws the 16-column MFMA tile of uniform_stream is at most half used.  v_mfma_f32_4x4x1_16b_f32 computes
+// sixteen independent 4 x 4 outer products D[b][i][j] += A[b][i] B[b][j] (A in lane 4 b + i, B in lane 4 b + j, D in
+// register i of lane 4 b + j) in 8 cycles, a quarter of the 16 x 16 x 4 tile's 32, and fits the problem exactly:
+//   phase 1   S[r][k] = sum_t V[t][r] x[c_t][k]    block b = fragments 4 b + (0..3), i = fragment, j = draw (k = 4 kg + j,
+//             kg < ceil(K / 4)): one instruction per transcript t and draw group, A = V[t][lane] -- one 4-byte LDS read
+//             per lane and transcript -- and B = x[c_t][4 kg + (lane & 3)], constant over a run (registers);
+//             d1[kg], register i of lane (b, j) = S[4 b + i][4 kg + j]
+//   weights   W = ks / S in place (v_rcp_f32): 4 ceil(K / 4) reciprocals per lane instead of 16
+//   phase 2   G[t][k] += sum_r V[t][r] W[r][k]     per group g of 4 transcripts and fragment index i: block b adds the
+//             outer product of V[4 g + (0..3)][4 b + i] with W[4 b + i][4 kg + (0..3)] -- B is d1[kg][i] as it stands,
+//             A is a 4-byte LDS read of row 4 g + (lane & 3) -- into acc[g][kg]; the sixteen blocks hold partial sums
+//             over their four fragments, added across lanes (DPP) when the run is flushed.
+// MFMA issue cycles of a slice of w transcripts at K = 6:  64 ceil(w / 4) + 64 ceil(w / 4)  against  128 ceil(w / 4) +
+// 256 or 512 before.  Element r of row t is stored at position r ^ (t & 3) of the row (psell_row_pos, stream 0): both
+// read patterns -- lane l reads position l ^ (t & 3) of row t; lane (b, i') reads position (4 b + i) ^ i' of row
+// 4 g + i' -- then touch 64 different banks.
+//
+// The loop is written for a short instruction stream (a wave issues at most one instruction every four cycles, and the
+// bookkeeping around the matrix instructions was three quarters of what it issued):
+//   * the slice body exists in 4 x 2 straight-line versions: groups of four transcripts (1..4) x "the slice's bytes are
+//     contiguous in the ring" (every operand address is one per-slice base register plus an immediate offset) or "they
+//     wrap around its end" (a third of the slices: addresses computed row by row);
+//   * at a run's start lanes t < 16 compute, once, the LDS addresses of transcript t's x row and gradient row (rows
+//     t >= w of the last group point at a row of zeros / at a scratch row: no masks in the loads and in the flush);
+//   * the flush adds a group's four transcripts under one exec mask.
+// `aux_lds`: LDS address of 32 bytes of zeros followed by 32 bytes of scratch.
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, class Hook>
+__device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
+                                     uint32_t aux_lds, double &lpacc, int dbg
+#ifdef POLEE_STAMPS
+                                     , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+#endif
+                                     , const Hook &hook)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) float *lds_cfp;
+    typedef __attribute__((address_space(3))) float *lds_fp;
+    constexpr int WMAX = PSELL_NARROW_MAX;
+    static_assert(WMAX == 16, "four groups of four transcripts");
+    constexpr int KG = (K + 3) / 4;
+    constexpr int RP = (int)(RB / 1024u);
+    const int lane = wave_lane();  // (see uniform_stream: per-tile lane constants instead of spilled ones)
+    const uint32_t ring_lds = lds_addr(ring);
+    const uint32_t xw_lds = lds_addr(xw), gw_lds = lds_addr(gw);
+    const int j = lane & 3, b = lane >> 2;
+    const uint32_t j4 = 4u * (uint32_t)j;
+    // phase 1 reads position lane ^ (t & 3) of row t; phase 2, fragment index u, position (4 b + u) ^ j = lane ^ u of
+    // row 4 g + j: the same four lane constants, plus 256 j
+    uint32_t lc1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lc1[u] = ring_lds + ((uint32_t)(lane ^ u) << 2);
+    const uint32_t j256 = 256u * (uint32_t)j;
+    auto lds_f = [](uint32_t a) -> float { return *reinterpret_cast<lds_cfp>((uintptr_t)a); };
+    auto wrap_u = [&](uint32_t a) -> uint32_t {  // uniform ring offset a < 2 RB
+        a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+        return a >= RB ? a - RB : a;
+    };
+
+    f32x4 acc[4][KG];  // acc[g][kg], register v of lane (b, j): block b's part of G[4 g + v][4 kg + j]
+    float xq[8][KG];   // x[c_t][4 kg + j] of the run's first eight transcripts (the others': re-read per slice, see below)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) acc[g][kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) xq[t][kg] = 0.0f;
+    uint32_t xav = aux_lds, gav = aux_lds + 32u;  // lane t < 16: LDS addresses of the x row / gradient row of the run's transcript t
+    int pend_w = 0;
+    double lpn[KG];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) lpn[kg] = 0.0;
+
+    // Flush of a group of four transcripts: acc[g][kg][v], lane (b, j) is block b's part of G[4 g + v][4 kg + j].  The
+    // four registers v are first added across the wave's four rows of 16 lanes and scattered (gfx950 lane swaps: row r
+    // is left with transcript VROW[r]'s sums, block by block), then across a row's four blocks (DPP): lanes 12..15 of
+    // every row hold one finished sum each and ONE LDS add per (group, draw group) writes 16 different addresses.
+    // (Adding the rows' partial sums to the same addresses instead -- four-way conflicts in four times as many LDS
+    // atomics -- cost a quarter of the kernel's time.)
+    auto flush_group = [&](int g) {
+        const uint32_t ga0 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 0), ga2 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 2);
+        const uint32_t ga1 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 1), ga3 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 3);
+        // row 0: transcript 4 g, row 1: 4 g + 2, row 2: 4 g + 1, row 3: 4 g + 3
+        const uint32_t ga = ((lane & 32) ? ((lane & 16) ? ga3 : ga1) : ((lane & 16) ? ga2 : ga0)) + j4;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[g][kg][0]), __float_as_uint(acc[g][kg][1]), false, false);
+            const float ab = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+            auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[g][kg][2]), __float_as_uint(acc[g][kg][3]), false, false);
+            const float cd = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+            auto r3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ab), __float_as_uint(cd), false, false);
+            float q = __uint_as_float(r3[0]) + __uint_as_float(r3[1]);
+            q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0x114, 0xf, 0xf, true));  // row_shr:4
+            q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0x118, 0xf, 0xf, true));  // row_shr:8
+            if ((lane & 12) == 12 && 4 * kg + j < K && !(dbg & 2))
+                __hip_atomic_fetch_add(reinterpret_cast<lds_fp>((uintptr_t)(ga + 16u * (uint32_t)kg)), q, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            acc[g][kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto flush = [&]() {
+        flush_group(0);
+        if (pend_w > 4) flush_group(1);
+        if (pend_w > 8) flush_group(2);
+        if (pend_w > 12) flush_group(3);
+        pend_w = 0;
+    };
+    auto load_x_group = [&](int g, float (*dst)[KG]) {  // x[c_t][4 kg + j] of transcripts 4 g .. 4 g + 3
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)xav, 4 * g + u) + j4;
+            dst[u][0] = lds_f(a);
+            if (KG > 1) dst[u][KG > 1 ? 1 : 0] = lds_f(a + 16u);  // (draws >= K: a neighbour's values, in columns that are never used)
+        }
+    };
+
+    uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
+    uint32_t pos_r = 0;  // pos modulo the ring size
+    for (int si = 0; si < ws.nsl; ++si) {
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
+        const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
+        const int flags = (int)(e0 >> 30);
+        const uint32_t units = off_next - off;
+        const int w = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);
+        const uint32_t bytes = units * 128u;
+        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
+        STAMP(1);  // slice bookkeeping
+        hook.before_slice(ws);
+        {
+            const int need = (int)((pos + bytes + 1023u) >> 10);
+            int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
+            if (!std::is_same<Hook, NoHook>::value) allowed += need <= ws.ex2_at ? ws.ex2_cnt : 0;
+            wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
+            if (!std::is_same<Hook, NoHook>::value && ws.sig_at >= 0 && need > ws.sig_at) hook.landed(ws);
+        }
+        STAMP(2);  // waiting for the DMA
+        if (pend_w != 0 && !(flags & 2)) flush();
+        if (pend_w == 0 && !((dbg & 64) && si > 0)) {
+            // a new run: lane t < 16 reads transcript t's tile-local id from the slice's header and turns it into the
+            // addresses of its x row and its gradient row; then the x values of the run, four transcripts at a time
+            const uint32_t cid = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
+                (uintptr_t)(ring_lds + pos_r + 2u * (uint32_t)(lane & 15)));
+            const bool live = (lane & 15) < w;
+            xav = live ? xw_lds + cid * (uint32_t)(K * 4) : aux_lds;
+            gav = live ? gw_lds + cid * (uint32_t)(K * 4) : aux_lds + 32u;
+            load_x_group(0, xq);
+            if (w > 4) load_x_group(1, xq + 4);
+        }
+        STAMP(3);  // run change: flush + column lookup
+
+        const uint32_t row0 = wrap_u(pos_r + 256u);
+        f32x4 d1[KG];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) d1[kg] = f32x4{ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR};
+        f32x4 kv = f32x4{1.f, 1.f, 1.f, 1.f};
+        auto consumed = [&]() {
+            // every operand of the slice is in registers: its ring bytes are free, the DMA for the pieces behind it goes
+            // out before the (rest of the) matrix phases
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(11);  // operand reads landed
+            pos += bytes;
+            pos_r += bytes;
+            pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+            ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
+            STAMP(6);  // refill
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+        };
+        // NG = groups of four transcripts of the slice; FAST = its bytes do not wrap around the ring's end
+        auto body = [&](auto NGc, auto FASTc) {
+            constexpr int NG = decltype(NGc)::value;
+            constexpr bool FAST = decltype(FASTc)::value;
+            float pv[8], qv[2][4];  // the operands of two groups at a time
+            uint32_t bp[4];
+            if (FAST) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bp[u] = lc1[u] + pos_r;
+            }
+            auto read_p = [&](int g0, int g1) {  // phase-1 operands of groups g0 .. g1 - 1: V[t][lane]
+#pragma unroll
+                for (int g = g0; g < g1; ++g) {
+                    if (FAST) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pv[4 * (g - g0) + u] = lds_f(bp[u] + 256u + 1024u * (uint32_t)g + 256u * (uint32_t)u);
+                    } else {
+                        const uint32_t rg = wrap_u(row0 + 1024u * (uint32_t)g);  // row 4 g
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pv[4 * (g - g0) + u] = lds_f(lc1[u] + wrap_u(rg + 256u * (uint32_t)u));
+                    }
+                }
+            };
+            auto read_q = [&](int g0, int g1) {  // phase-2 operands: V[4 g + j][4 b + u]
+#pragma unroll
+                for (int g = g0; g < g1; ++g) {
+                    if (FAST) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) qv[g - g0][u] = lds_f(bp[u] + j256 + 256u + 1024u * (uint32_t)g);
+                    } else {
+                        const uint32_t rg = wrap_u(row0 + 1024u * (uint32_t)g);
+                        const uint32_t jr = rg + 256u * (uint32_t)j;
+                        const uint32_t back = jr >= RB ? RB : 0u;  // (the ring's end may fall inside this group of rows)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) qv[g - g0][u] = lds_f(lc1[u] + j256 + rg - back);
+                    }
+                }
+            };
+            auto phase1 = [&](const float *p4, const float (*x4)[KG]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) d1[kg] = __builtin_amdgcn_mfma_f32_4x4x1f32(p4[u], x4[u][kg], d1[kg], 0, 0, 0);
+            };
+            auto weights = [&]() {  // in place: d1[kg][i] of lane (b, j) belongs to fragment 4 b + i, draw 4 kg + j
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float sv = d1[kg][i];
+                        if (WANT_LP && 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR)
+                            lpn[kg] += HAS_KS ? (double)kv[i] * log((double)sv) : log((double)sv);
+                        d1[kg][i] = HAS_KS ? kv[i] * __builtin_amdgcn_rcpf(sv) : __builtin_amdgcn_rcpf(sv);  // (padded fragments: ks = 0)
+                    }
+            };
+            auto phase2 = [&](int g, const float *q4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) acc[g][kg] = __builtin_amdgcn_mfma_f32_4x4x1f32(q4[i], d1[kg][i], acc[g][kg], 0, 0, 0);
+            };
+            if (HAS_KS)  // the multiplicities travel with the slice (its last row, stored in fragment order)
+                kv = *reinterpret_cast<const f32x4 *>(ring + wrap_u(row0 + 256u * (uint32_t)w) + 16u * (uint32_t)b);
+            if (NG <= 2) {
+                // all operands at once; the slice's ring bytes are free before the matrix phases
+                read_p(0, NG);
+                read_q(0, NG);
+                consumed();
+                phase1(pv, xq);
+                if (NG > 1) phase1(pv + 4, xq + 4);
+                weights();
+                phase2(0, qv[0]);
+                if (NG > 1) phase2(1, qv[1]);
+            } else {
+                // (registers hold the x rows of eight transcripts: those of the third and fourth group are re-read from
+                // the window for every slice.)  Two LDS round trips: the phase-1 operands, then -- overlapping the
+                // reciprocals -- the phase-2 operands, in the registers the first ones have left
+                float pw[8], xr[8][KG], qw[2][4];
+                read_p(0, 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pw[u] = pv[u];
+                read_p(2, NG);
+                if (!(dbg & 4)) {
+                    load_x_group(2, xr);
+                    if (NG > 3) load_x_group(3, xr + 4);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int kg = 0; kg < KG; ++kg) xr[u][kg] = xq[u][kg];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+                phase1(pw, xq);
+                phase1(pw + 4, xq + 4);
+                phase1(pv, xr);
+                if (NG > 3) phase1(pv + 4, xr + 4);
+                read_q(0, 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qw[0][u] = qv[0][u];
+                    qw[1][u] = qv[1][u];
+                }
+                read_q(2, NG);
+                weights();
+                consumed();
+                phase2(0, qw[0]);
+                phase2(1, qw[1]);
+                phase2(2, qv[0]);
+                if (NG > 3) phase2(3, qv[1]);
+            }
+        };
+        using std::integral_constant;
+        const bool fast = pos_r + bytes <= RB;
+        if (fast) {
+            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, true>());
+            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, true>());
+            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, true>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, true>());
+        } else {
+            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, false>());
+            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, false>());
+            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, false>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, false>());
+        }
+        pend_w = w;
+        STAMP(5);  // phase 2
+    }
+    if (pend_w != 0) flush();
+    if (WANT_LP) {
+        // into the caller's accumulator, whose lane l < 16 collects draw l: the sixteen blocks' sums of draw 4 kg + j
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            double v = lpn[kg];
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16 && (lane >> 2) == kg && lane < K) lpacc += v;
+        }
+    }
+}
+
 #ifdef POLEE_STAMPS
 extern "C" int polee_debug_read_stamps(unsigned long long *out)
 {
@@ -763,7 +1107,7 @@ constexpr uint32_t stream_xw_bytes()  // whole 1 KiB pieces
 template <int K, bool DET>
 constexpr uint32_t stream_lds_bytes()  // (deterministic mode: one gradient window per wave)
 {
-    return stream_ring_total<K>() + (DET ? 6u : 3u) * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u;
+    return stream_ring_total<K>() + (DET ? 6u : 3u) * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u + 64u;
 }
 
 // DET: the deterministic mode -- bitwise reproducible gradients: each wave accumulates into its own LDS window (a wave's
@@ -785,8 +1129,8 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     };
     uint32_t *const entb = reinterpret_cast<uint32_t *>(base + stream_ring_total<K>() + (2 + GWN) * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
     uint32_t *const descb = entb + 4 * 64;  // 2 x 64 words: the schedule entry two rounds ahead, by LDS-DMA
+    float *const auxz = reinterpret_cast<float *>(descb + 2 * 64);  // 8 zeros, 8 words of scratch (narrow_stream)
 
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t G = gridDim.x;
     const PosDesc *__restrict__ sched = A.sched;
@@ -815,11 +1159,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4;
         const uint32_t dst = lds_addr(xw_of(buf));
         for (int p = wave; p < npx; p += 4) {
-            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)lane * 16u, dst + (uint32_t)p * 1024u);
+            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)wave_lane() * 16u, dst + (uint32_t)p * 1024u);
             ++cnt;
         }
         if ((uint32_t)wave * 64u < t.L) {  // transcript ids of the dictionary (for the flush)
-            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)lane, t.L - 1u - (uint32_t)wave * 64u) * 4u,
+            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)wave_lane(), t.L - 1u - (uint32_t)wave * 64u) * 4u,
                     lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
             ++cnt;
         }
@@ -827,7 +1171,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         {  // slice offsets of this wave's share, one per lane
             uint32_t sb, se;
             share(kind, t, sb, se);
-            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)lane, se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
+            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)wave_lane(), se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
             ++cnt;
         }
         return cnt;
@@ -841,7 +1185,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         ws.ex2_cnt = 0; ws.ex2_at = 0; ws.sig_at = -1;
         uint32_t sb, se;
         share(kind, t, sb, se);
-        ws.ent = entb[wave * 64 + lane];
+        ws.ent = entb[wave * 64 + wave_lane()];
         ws.nsl = (int)(se - sb);
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
@@ -865,6 +1209,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     // whatever lies behind a slice in the ring has to be finite
     for (int i = threadIdx.x; i < (int)(stream_ring_total<K>() / 16u); i += 256)
         reinterpret_cast<float4 *>(rings)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 16) auxz[threadIdx.x] = 0.0f;
     lds_barrier();
     (void)prefetch(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -881,19 +1226,19 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             // arrives in the background like everything else and is read after the tile's barriers)
             uint32_t off8;  // (lane & 7) * 4, computed here: hoisted out of the tile loop it was spilled, and its reload
                             // (a scratch load the compiler waits for with vmcnt(0)) drained this wave's ring every tile
-            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(lane));
+            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(wave_lane()));
             dma_256(uniform_ptr(sched + blockIdx.x + (size_t)(round + 2u) * G), off8, lds_addr(descb + (round & 1u) * 64u));
             ++young;
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
-            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
+            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif
             );
         } else {
-            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
+            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                            , st_acc, st_last
 #endif
@@ -923,7 +1268,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             for (int b = 0; b < NBF; ++b) {
                 const int i0 = b * 256 + wave * 64;
                 if (i0 < LK) {  // (wave-uniform; lane 0 of the wave is active, so the wave issues exactly one atomic here)
-                    int i = i0 + lane;
+                    int i = i0 + wave_lane();
                     asm volatile("" : "+v"(i));  // (keeps i / K from being hoisted out of the tile loop and spilled)
                     if (i < LK) {
                         const int l = i / K;
@@ -972,18 +1317,18 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         v += __shfl_xor(v, 32, 64);
         double *lpw = reinterpret_cast<double *>(gw);  // (the windows are idle now)
         lds_barrier();
-        if (lane < K) lpw[wave * K + lane] = v;
+        if (wave_lane() < K) lpw[wave * K + wave_lane()] = v;
         lds_barrier();
         if (threadIdx.x < K) A.lpwin[(size_t)blockIdx.x * K + threadIdx.x] = ((lpw[threadIdx.x] + lpw[K + threadIdx.x]) + lpw[2 * K + threadIdx.x]) + lpw[3 * K + threadIdx.x];
     } else if (WANT_LP) {
         double v = lp_a;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < K) atomicAdd(A.lp + lane, v);
+        if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
     }
 #ifdef POLEE_STAMPS
     STAMP(10);
-    if (lane == 0) {
+    if (wave_lane() == 0) {
         for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
         atomicAdd(&g_stamps[16], n_slices);
         atomicAdd(&g_stamps[17], n_tiles);
@@ -1012,7 +1357,7 @@ constexpr uint32_t STREAM2_RB1 = 6144u, STREAM2_RB2 = 12288u, STREAM2_RINGS = 24
 template <int K>
 constexpr uint32_t stream2_lds_bytes()
 {
-    return STREAM2_RINGS + 4u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u + 64u;
+    return STREAM2_RINGS + 4u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u + 64u + 64u;
 }
 
 __device__ inline uint32_t lds_load_u32(const uint32_t *p)
@@ -1046,8 +1391,8 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
     uint32_t *const descb = entb + 4 * 64;   // 2 x 64 words: descb[j & 1] = the schedule entry of tile j + 1
     uint32_t *const syncw = descb + 2 * 64;  // [0..1] arrivals, [2..3] tiles flushed per buffer, [4..5] landed prefetch parts
     uint32_t *const arr = syncw, *const fl = syncw + 2, *const xr = syncw + 4;
+    float *const auxz = reinterpret_cast<float *>(syncw + 16);  // 8 zeros, 8 words of scratch (narrow_stream)
 
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t G = gridDim.x;
     const PosDesc *__restrict__ sched = A.sched;
@@ -1077,23 +1422,23 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4;
         const uint32_t dst = lds_addr(xw_of(buf));
         for (int p = wave; p < npx; p += 4) {
-            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)lane * 16u, dst + (uint32_t)p * 1024u);
+            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)wave_lane() * 16u, dst + (uint32_t)p * 1024u);
             ++cnt;
         }
         if ((uint32_t)wave * 64u < t.L) {
-            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)lane, t.L - 1u - (uint32_t)wave * 64u) * 4u,
+            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)wave_lane(), t.L - 1u - (uint32_t)wave * 64u) * 4u,
                     lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
             ++cnt;
         }
         {
             uint32_t sb, se;
             share(kind_of(t.tile), t, sb, se);
-            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)lane, se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
+            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)wave_lane(), se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
             ++cnt;
         }
         if (wave == 0) {
             uint32_t off8;
-            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(lane));
+            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(wave_lane()));
             dma_256(uniform_ptr(sched + pos_after), off8, lds_addr(descb + (uint32_t)buf * 64u));
             ++cnt;
         }
@@ -1106,7 +1451,7 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         ws.ex2_cnt = 0; ws.ex2_at = 0; ws.sig_at = -1;
         uint32_t sb, se;
         share(kind, t, sb, se);
-        ws.ent = entb[wave * 64 + lane];
+        ws.ent = entb[wave * 64 + wave_lane()];
         ws.nsl = (int)(se - sb);
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;
@@ -1138,6 +1483,7 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
     for (int i = threadIdx.x; i < (int)(2u * XWB / 4u); i += 256) gw_of(0)[i] = 0.0f;  // (both windows: they are adjacent)
     for (int i = threadIdx.x; i < (int)(STREAM2_RINGS / 16u); i += 256)
         reinterpret_cast<float4 *>(rings)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 16) auxz[threadIdx.x] = 0.0f;
     if (threadIdx.x < 16) syncw[threadIdx.x] = threadIdx.x == 4 ? 4u : 0u;  // (tile 0's prefetch is complete after the barrier below)
     lds_barrier();
     (void)prefetch(cur, 0u, (size_t)blockIdx.x + G);
@@ -1169,7 +1515,7 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         __device__ void landed(WaveStream &w) const
         {
             if (to_signal && !pending) {
-                if ((threadIdx.x & 63) == 0) atomicAdd(xr_next, 1u);
+                if (wave_lane() == 0) atomicAdd(xr_next, 1u);
                 to_signal = false;
             }
             w.sig_at = -1;
@@ -1193,13 +1539,13 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         }
         STAMP(0);
         if (kind == 0) {
-            uniform_stream<K, STREAM2_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + wave * STREAM2_RB1, young, xw_of(b), gw_of(b), lp_a, dbg
+            uniform_stream<K, STREAM2_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + wave * STREAM2_RB1, young, xw_of(b), gw_of(b), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                                     , st_acc, st_last
 #endif
                                                                                     , hook);
         } else {
-            uniform_stream<K, STREAM2_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + (wave < 2 ? wave : 0) * STREAM2_RB2, young, xw_of(b), gw_of(b), lp_a, dbg
+            uniform_stream<K, STREAM2_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + (wave < 2 ? wave : 0) * STREAM2_RB2, young, xw_of(b), gw_of(b), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                                   , st_acc, st_last
 #endif
@@ -1216,7 +1562,7 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's part of the next tile's prefetch has landed)
         if (hook.to_signal) {
-            if (lane == 0) atomicAdd(&xr[b ^ 1], 1u);
+            if (wave_lane() == 0) atomicAdd(&xr[b ^ 1], 1u);
             hook.to_signal = false;
         }
         STAMP(7);
@@ -1227,15 +1573,15 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         // arrival; the fourth to arrive flushes the tile's window
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's adds into the window are done)
         uint32_t order = 0;
-        if (lane == 0) order = atomicAdd(&arr[b], 1u);
+        if (wave_lane() == 0) order = atomicAdd(&arr[b], 1u);
         order = (uint32_t)__builtin_amdgcn_readfirstlane((int)order);
         if (order == 3u) {
-            if (lane == 0) arr[b] = 0u;
+            if (wave_lane() == 0) arr[b] = 0u;
             const int LK = (int)cur.L * K;
             const uint32_t *ids = ids_of(b);
             float *gwb = gw_of(b);
             for (int i0 = 0; i0 < LK; i0 += 64) {
-                const int i = i0 + lane;
+                const int i = i0 + wave_lane();
                 if (i < LK) {
                     const int l = i / K;
                     const int k = i - l * K;
@@ -1247,7 +1593,7 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
                 if (!(dbg & 1)) ++young;  // (younger than the pieces of the ring that has just been started)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is zero again before the tile counts as flushed)
-            if (lane == 0) atomicAdd(&fl[b], 1u);
+            if (wave_lane() == 0) atomicAdd(&fl[b], 1u);
         }
         STAMP(15);
         if (!more) break;
@@ -1264,11 +1610,11 @@ void loglik_stream2_kernel(PsellArgs A, int dbg)
         double v = lp_a;
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < K) atomicAdd(A.lp + lane, v);
+        if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
     }
 #ifdef POLEE_STAMPS
     STAMP(10);
-    if (lane == 0) {
+    if (wave_lane() == 0) {
         for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
         atomicAdd(&g_stamps[16], n_slices);
         atomicAdd(&g_stamps[17], n_tiles);

@@ -418,14 +418,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (uint32_t t = 0; t < w; ++t) hdr[t] = col_local[pattern[t]];
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
                 const uint64_t b = rowptr[slice_rows[lane]], e = rowptr[slice_rows[lane] + 1];
-                // element r of row t sits at position (r + 4 t) & 63: bank-conflict-free operand reads for the MFMA phase
+                // element r of row t sits at position psell_row_pos(stream, t, r): bank-conflict-free operand reads for the MFMA phases
                 if (!slice_union) {
-                    for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[b + t];
+                    for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + psell_row_pos(cur_stream, t, (uint32_t)lane)] = val[b + t];
                 } else {  // the row's entries at the positions of their transcripts in the union, zeros elsewhere
                     uint32_t t = 0;
                     for (uint64_t k = b; k < e; ++k) {
                         while (pattern[t] != col[k]) ++t;
-                        vals[(size_t)t * 64 + ((lane + 4 * t) & 63)] = val[k];
+                        vals[(size_t)t * 64 + psell_row_pos(cur_stream, t, (uint32_t)lane)] = val[k];
                     }
                 }
             }

@@ -141,7 +141,7 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
     out = dict(num_slices=v.num_slices, num_tiles=v.num_tiles, padded_nnz=v.padded_nnz, nnz=v.nnz,
                empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz,
-               num_tiles_a=v.num_tiles_a)
+               num_tiles_a=v.num_tiles_a, num_tiles_a1=v.num_tiles_a1)
     out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
     raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
     out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
@@ -177,8 +177,12 @@ def _emulate_psell(ps, x, n):
                 hdr = data[off:off + 256].view(np.uint16)[:w].astype(np.int64)
                 cols = np.repeat(hdr[:, None], 64, axis=1)
                 rot = data[off + 256:off + 256 + w * 256].view(np.float32).reshape(w, 64)
-                # element r of row t is stored at position (r + 4 t) & 63
-                vals = np.stack([rot[tt][(np.arange(64) + 4 * tt) & 63] for tt in range(w)]) if w else rot
+                # element r of row t is stored at position r ^ (t & 3) (stream A1) / (r + 4 t) & 63 (stream A2)
+                r64 = np.arange(64)
+                if t < ps["num_tiles_a1"]:
+                    vals = np.stack([rot[tt][r64 ^ (tt & 3)] for tt in range(w)]) if w else rot
+                else:
+                    vals = np.stack([rot[tt][(r64 + 4 * tt) & 63] for tt in range(w)]) if w else rot
             else:
                 w = nbytes // 384
                 vals = data[off:off + w * 256].view(np.float32).reshape(w, 64)

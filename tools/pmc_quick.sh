@@ -13,7 +13,7 @@ for f in glob.glob('p/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r['Kernel_Name'][:50]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in acc.items():
-        if 'fused' in k:
+        if 'stream' in k:
             for c, v in sorted(cs.items()): print('%-28s %16.0f' % (c, sum(v)/len(v)))
 PY
 find $OUT -name "*.csv" -size +2M -delete
