@@ -359,17 +359,6 @@ struct WaveStream {
     int issued, islot;    // pieces requested so far; ring slot of the next one
     int primed;           // pieces requested before the tile's loop started
     const uint8_t *gsrc;  // start of the byte range (wave-uniform)
-    // the decoupled kernel only: a second group of extra operations issued in the middle of the loop (the deferred
-    // prefetch), when `ex2_at` pieces had been requested; and the piece count after whose wait the prefetch group is
-    // known to have landed (in-order queue), so that the wave can say so to the others (`sig_at` < 0: nothing to say)
-    int ex2_cnt, ex2_at;
-    int sig_at;
-};
-
-// what the decoupled kernel hooks into the slice loop (the default does nothing)
-struct NoHook {
-    __device__ void before_slice(WaveStream &) const {}
-    __device__ void landed(WaveStream &) const {}
 };
 
 template <uint32_t RB>
@@ -394,32 +383,29 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
 // transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
 // the first refill (the previous tile's flush, the next tile's prefetch): they are younger than the primed pieces
 // and older than every other piece, so only waits for primed pieces have to allow for them.
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, class Hook>
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
 __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
 #endif
-                                     , const Hook &hook);
+                                     );
 
-template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS, class Hook = NoHook>
+template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS>
 __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                       uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                       , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
 #endif
-                                      , const Hook &hook = Hook())
+                                      )
 {
     if constexpr (WMAXR <= PSELL_NARROW_MAX) {
-#ifdef POLEE_KEEP_OLD_NARROW
-        if (!(dbg & 32))  // (dbg & 32: the 16 x 16 x 4 formulation below, for A/B runs)
-#endif
-        {
-            narrow_stream<K, RB, WANT_LP, HAS_KS, Hook>(ws, ring, extras, xw, gw, aux_lds, lpacc, dbg
+        {  // (the narrow stream has its own formulation; what follows serves the wide one)
+            narrow_stream<K, RB, WANT_LP, HAS_KS>(ws, ring, extras, xw, gw, aux_lds, lpacc, dbg
 #ifdef POLEE_STAMPS
-                                                        , st_acc, st_last
+                                                  , st_acc, st_last
 #endif
-                                                        , hook);
+                                                  );
             return;
         }
     }
@@ -530,15 +516,12 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         // all pieces covering [pos, pos+bytes) must have landed
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the short non-matrix sections of a slice win the issue arbitration (-2.5 %)
         STAMP(1);  // slice bookkeeping
-        hook.before_slice(ws);
         {
             const int need = (int)((pos + bytes + 1023u) >> 10);
             if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);  // (only with a shortened look-ahead: experiments)
             // (wave-uniform: said explicitly, or the ladder below is compiled with vector compares and exec masks)
             int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
-            if (!std::is_same<Hook, NoHook>::value) allowed += need <= ws.ex2_at ? ws.ex2_cnt : 0;
             wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
-            if (!std::is_same<Hook, NoHook>::value && ws.sig_at >= 0 && need > ws.sig_at) hook.landed(ws);
         }
         STAMP(2);  // waiting for the DMA
         auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
@@ -735,13 +718,13 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 //     t >= w of the last group point at a row of zeros / at a scratch row: no masks in the loads and in the flush);
 //   * the flush adds a group's four transcripts under one exec mask.
 // `aux_lds`: LDS address of 32 bytes of zeros followed by 32 bytes of scratch.
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, class Hook>
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
 __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
 #endif
-                                     , const Hook &hook)
+                                     )
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) float *lds_cfp;
@@ -838,13 +821,10 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         const uint32_t bytes = units * 128u;
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
         STAMP(1);  // slice bookkeeping
-        hook.before_slice(ws);
         {
             const int need = (int)((pos + bytes + 1023u) >> 10);
             int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
-            if (!std::is_same<Hook, NoHook>::value) allowed += need <= ws.ex2_at ? ws.ex2_cnt : 0;
             wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
-            if (!std::is_same<Hook, NoHook>::value && ws.sig_at >= 0 && need > ws.sig_at) hook.landed(ws);
         }
         STAMP(2);  // waiting for the DMA
         if (pend_w != 0 && !(flags & 2)) flush();
@@ -1182,7 +1162,6 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     auto start_ring = [&](const PosDesc &t) {
         const int kind = kind_of(t.tile);
         ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
-        ws.ex2_cnt = 0; ws.ex2_at = 0; ws.sig_at = -1;
         uint32_t sb, se;
         share(kind, t, sb, se);
         ws.ent = entb[wave * 64 + wave_lane()];
@@ -1338,291 +1317,6 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 }
 
 
-// ---- the same pass with the four waves of a workgroup DECOUPLED ------------------------------------------------------
-// In loglik_stream_kernel a wave that has finished its share of a tile waits at a barrier for the other three (12-14 %
-// of a wave's time: the shares are balanced on work, the waits are the random differences of four in-order instruction
-// streams that share their SIMDs with other workgroups).  Here a wave goes on to the next tile at once:
-//   * two gradient windows (tile i uses gw[i & 1]); a wave "arrives" at the end of its share (LDS counter), and the wave
-//     whose arrival is the fourth flushes the window by itself and counts the tile as flushed (fl[i & 1]);
-//   * the prefetch for tile i + 1 (x window, dictionary ids, slice offsets, the schedule entry after it) overwrites the
-//     buffers of tile i - 1, so a wave issues it only once tile i - 1 is flushed -- at the tile's start if that is so
-//     already, else between two slices as soon as it is (the counted waits know where in the queue it went);
-//   * a wave tells the others when its part of a prefetch has LANDED (xr[b], at the first wait for a ring piece that was
-//     requested after it: the queue completes in order), and starts tile i only when all four parts of tile i's
-//     prefetch have: nobody reads an x window, an id or a schedule entry that another wave's DMA is still writing.
-// Consequence: a wave is never more than one tile ahead of the slowest, and nothing waits unless it is.  Where the ring
-// geometry changes (narrow <-> wide tiles) the waves meet at a real barrier.  Spins are bounded (a trap after ~1 s).
-// Not used in deterministic mode (that keeps per-wave windows and the barrier structure above).
-constexpr uint32_t STREAM2_RB1 = 6144u, STREAM2_RB2 = 12288u, STREAM2_RINGS = 24576u;
-template <int K>
-constexpr uint32_t stream2_lds_bytes()
-{
-    return STREAM2_RINGS + 4u * stream_xw_bytes<K>() + 2u * PSELL_TILE_COLS_TARGET * 4u + 4u * 256u + 2u * 256u + 64u + 64u;
-}
-
-__device__ inline uint32_t lds_load_u32(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// spins (politely) until *p >= want; a wave that would spin for about a second traps instead of hanging the GPU
-__device__ inline void lds_wait_ge(const uint32_t *p, uint32_t want)
-{
-    for (uint32_t spins = 0; (int32_t)(lds_load_u32(p) - want) < 0; ++spins) {
-        __builtin_amdgcn_s_sleep(8);
-        if (spins > (1u << 24)) __builtin_trap();
-    }
-    asm volatile("" ::: "memory");  // (what the other waves wrote before they counted is read after this point)
-}
-
-template <int K, bool WANT_LP, bool HAS_KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void loglik_stream2_kernel(PsellArgs A, int dbg)
-{
-    extern __shared__ float lds[];
-    constexpr uint32_t XWB = stream_xw_bytes<K>();
-    char *const base = reinterpret_cast<char *>(lds);
-    char *const rings = base;
-    auto xw_of = [&](int b) -> float * { return reinterpret_cast<float *>(base + STREAM2_RINGS + (uint32_t)b * XWB); };
-    auto gw_of = [&](int b) -> float * { return reinterpret_cast<float *>(base + STREAM2_RINGS + (2u + (uint32_t)b) * XWB); };
-    auto ids_of = [&](int b) -> uint32_t * {
-        return reinterpret_cast<uint32_t *>(base + STREAM2_RINGS + 4 * XWB + (uint32_t)b * (PSELL_TILE_COLS_TARGET * 4));
-    };
-    uint32_t *const entb = reinterpret_cast<uint32_t *>(base + STREAM2_RINGS + 4 * XWB + 2 * PSELL_TILE_COLS_TARGET * 4);
-    uint32_t *const descb = entb + 4 * 64;   // 2 x 64 words: descb[j & 1] = the schedule entry of tile j + 1
-    uint32_t *const syncw = descb + 2 * 64;  // [0..1] arrivals, [2..3] tiles flushed per buffer, [4..5] landed prefetch parts
-    uint32_t *const arr = syncw, *const fl = syncw + 2, *const xr = syncw + 4;
-    float *const auxz = reinterpret_cast<float *>(syncw + 16);  // 8 zeros, 8 words of scratch (narrow_stream)
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t G = gridDim.x;
-    const PosDesc *__restrict__ sched = A.sched;
-    const uint8_t *__restrict__ xwin_b = reinterpret_cast<const uint8_t *>(A.xwin);
-#ifdef POLEE_STAMPS
-    unsigned long long st_acc[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-    unsigned long long n_slices = 0, n_tiles = 0;
-#endif
-
-    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : 1; };
-    auto share = [&](int kind, const PosDesc &t, uint32_t &sb, uint32_t &se) {
-        const int nw = kind == 0 ? 4 : 2;
-        uint32_t a1 = t.c1, a2 = t.c2, a3 = t.c3;
-        asm volatile("" : "+s"(a1), "+s"(a2), "+s"(a3));
-        const uint32_t lo = wave == 0 ? t.s0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));
-        const uint32_t hi = wave + 1 >= nw ? t.s1 : (wave == 0 ? a1 : (wave == 1 ? a2 : a3));
-        sb = wave < nw ? lo : t.s1;
-        se = wave < nw ? hi : t.s1;
-    };
-    // this wave's part of the prefetch for tile `t` = tile number j of this workgroup (buffers j & 1); `pos_after` is the
-    // schedule position of tile j + 1, whose entry wave 0 fetches along.  Returns the number of vector-memory operations.
-    auto prefetch = [&](const PosDesc &t, uint32_t j, size_t pos_after) -> int {
-        int cnt = 0;
-        const int buf = (int)(j & 1u);
-        const int npx = (int)((t.L * (uint32_t)K * 4u + 1023u) >> 10);
-        const uint8_t *src = xwin_b + (size_t)t.d0 * K * 4;
-        const uint32_t dst = lds_addr(xw_of(buf));
-        for (int p = wave; p < npx; p += 4) {
-            dma_1k_keep(uniform_ptr(src + (size_t)p * 1024), (uint32_t)wave_lane() * 16u, dst + (uint32_t)p * 1024u);
-            ++cnt;
-        }
-        if ((uint32_t)wave * 64u < t.L) {
-            dma_256(uniform_ptr(A.dict + t.d0 + (uint32_t)wave * 64u), min((uint32_t)wave_lane(), t.L - 1u - (uint32_t)wave * 64u) * 4u,
-                    lds_addr(ids_of(buf)) + (uint32_t)wave * 256u);
-            ++cnt;
-        }
-        {
-            uint32_t sb, se;
-            share(kind_of(t.tile), t, sb, se);
-            dma_256(uniform_ptr(A.slice_off + sb), min((uint32_t)wave_lane(), se - sb) * 4u, lds_addr(entb) + (uint32_t)wave * 256u);
-            ++cnt;
-        }
-        if (wave == 0) {
-            uint32_t off8;
-            asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(wave_lane()));
-            dma_256(uniform_ptr(sched + pos_after), off8, lds_addr(descb + (uint32_t)buf * 64u));
-            ++cnt;
-        }
-        return cnt;
-    };
-    WaveStream ws;
-    auto start_ring = [&](const PosDesc &t) {
-        const int kind = kind_of(t.tile);
-        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
-        ws.ex2_cnt = 0; ws.ex2_at = 0; ws.sig_at = -1;
-        uint32_t sb, se;
-        share(kind, t, sb, se);
-        ws.ent = entb[wave * 64 + wave_lane()];
-        ws.nsl = (int)(se - sb);
-        const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
-        const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;
-        ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
-        ws.gsrc = reinterpret_cast<const uint8_t *>(uniform_ptr(A.data + (size_t)cb * 128));
-        if (kind == 0)
-            ring_refill<STREAM2_RB1>(ws, lds_addr(rings + wave * STREAM2_RB1), min(ws.npieces, (int)(STREAM2_RB1 / 1024u)));
-        else
-            ring_refill<STREAM2_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM2_RB2), min(ws.npieces, (int)(STREAM2_RB2 / 1024u)));
-        ws.primed = ws.issued;
-    };
-    auto read_desc = [&](int slot) -> PosDesc {
-        const uint32_t *dp = descb + (uint32_t)slot * 64u;
-        PosDesc d;
-        d.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[0]);
-        d.s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[1]);
-        d.s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[2]);
-        d.d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[3]);
-        d.L = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[4]);
-        d.c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[5]);
-        d.c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[6]);
-        d.c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[7]);
-        return d;
-    };
-
-    double lp_a = 0.0;
-    PosDesc cur = sched[blockIdx.x];
-    if (cur.tile == POS_NONE) return;
-    for (int i = threadIdx.x; i < (int)(2u * XWB / 4u); i += 256) gw_of(0)[i] = 0.0f;  // (both windows: they are adjacent)
-    for (int i = threadIdx.x; i < (int)(STREAM2_RINGS / 16u); i += 256)
-        reinterpret_cast<float4 *>(rings)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x < 16) auxz[threadIdx.x] = 0.0f;
-    if (threadIdx.x < 16) syncw[threadIdx.x] = threadIdx.x == 4 ? 4u : 0u;  // (tile 0's prefetch is complete after the barrier below)
-    lds_barrier();
-    (void)prefetch(cur, 0u, (size_t)blockIdx.x + G);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    start_ring(cur);
-    int young = 0;
-    lds_barrier();
-
-    // hook of the slice loop: the deferred prefetch and the "landed" signal
-    struct Hook {
-        decltype(prefetch) &pf;
-        const uint32_t *fl_other;  // flushed-tile counter of the buffers the next tile will use
-        uint32_t *xr_next;         // landed-parts counter of those buffers
-        uint32_t need_fl;          // ... which must have reached this before they may be overwritten
-        PosDesc nxt;
-        uint32_t jn;               // the next tile's number
-        size_t pos_after;
-        mutable bool pending;      // the prefetch has not been issued yet
-        mutable bool to_signal;    // its landing has not been announced yet
-        __device__ void before_slice(WaveStream &w) const
-        {
-            if (pending && (int32_t)(lds_load_u32(fl_other) - need_fl) >= 0) {
-                w.ex2_cnt = pf(nxt, jn, pos_after);
-                w.ex2_at = w.issued;
-                w.sig_at = w.issued;
-                pending = false;
-            }
-        }
-        __device__ void landed(WaveStream &w) const
-        {
-            if (to_signal && !pending) {
-                if (wave_lane() == 0) atomicAdd(xr_next, 1u);
-                to_signal = false;
-            }
-            w.sig_at = -1;
-        }
-    };
-
-    for (uint32_t j = 0;; ++j) {  // j = number of the tile within this workgroup's column of the schedule
-        const int b = (int)(j & 1u);
-        lds_wait_ge(&xr[b], 4u * ((j >> 1) + 1u));  // every wave's part of this tile's prefetch has landed
-        const PosDesc nxt = read_desc(b);
-        const bool more = nxt.tile != POS_NONE;
-        const int kind = kind_of(cur.tile);
-        Hook hook{prefetch, &fl[b ^ 1], &xr[b ^ 1], (j + 1u) >> 1, nxt, j + 1u, (size_t)blockIdx.x + (size_t)(j + 2u) * G, more, more};
-        ws.ex2_cnt = 0;
-        ws.ex2_at = 0;
-        ws.sig_at = -1;
-        if (more && (int32_t)(lds_load_u32(&fl[b ^ 1]) - ((j + 1u) >> 1)) >= 0) {  // tile j - 1 is flushed already: prefetch now
-            young += prefetch(nxt, j + 1u, (size_t)blockIdx.x + (size_t)(j + 2u) * G);
-            hook.pending = false;
-            ws.sig_at = ws.primed;
-        }
-        STAMP(0);
-        if (kind == 0) {
-            uniform_stream<K, STREAM2_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + wave * STREAM2_RB1, young, xw_of(b), gw_of(b), lds_addr(auxz), lp_a, dbg
-#ifdef POLEE_STAMPS
-                                                                                    , st_acc, st_last
-#endif
-                                                                                    , hook);
-        } else {
-            uniform_stream<K, STREAM2_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS, Hook>(ws, rings + (wave < 2 ? wave : 0) * STREAM2_RB2, young, xw_of(b), gw_of(b), lds_addr(auxz), lp_a, dbg
-#ifdef POLEE_STAMPS
-                                                                                  , st_acc, st_last
-#endif
-                                                                                  , hook);
-        }
-#ifdef POLEE_STAMPS
-        n_slices += (unsigned long long)ws.nsl;
-        ++n_tiles;
-#endif
-        if (hook.pending) {  // (this wave is a whole tile ahead of the slowest: the only place where it waits for it)
-            lds_wait_ge(&fl[b ^ 1], (j + 1u) >> 1);
-            (void)prefetch(nxt, j + 1u, (size_t)blockIdx.x + (size_t)(j + 2u) * G);
-            hook.pending = false;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's part of the next tile's prefetch has landed)
-        if (hook.to_signal) {
-            if (wave_lane() == 0) atomicAdd(&xr[b ^ 1], 1u);
-            hook.to_signal = false;
-        }
-        STAMP(7);
-        young = 0;
-        const bool same_kind = more && kind_of(nxt.tile) == kind;
-        if (same_kind) start_ring(nxt);  // (this wave's own ring: free as soon as its slices are done)
-        STAMP(13);
-        // arrival; the fourth to arrive flushes the tile's window
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's adds into the window are done)
-        uint32_t order = 0;
-        if (wave_lane() == 0) order = atomicAdd(&arr[b], 1u);
-        order = (uint32_t)__builtin_amdgcn_readfirstlane((int)order);
-        if (order == 3u) {
-            if (wave_lane() == 0) arr[b] = 0u;
-            const int LK = (int)cur.L * K;
-            const uint32_t *ids = ids_of(b);
-            float *gwb = gw_of(b);
-            for (int i0 = 0; i0 < LK; i0 += 64) {
-                const int i = i0 + wave_lane();
-                if (i < LK) {
-                    const int l = i / K;
-                    const int k = i - l * K;
-                    const float v = gwb[i];
-                    gwb[i] = 0.0f;
-                    float *dst = A.g + (size_t)ids[l] * K + k;
-                    if (!(dbg & 1)) asm volatile("global_atomic_add_f32 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
-                }
-                if (!(dbg & 1)) ++young;  // (younger than the pieces of the ring that has just been started)
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the window is zero again before the tile counts as flushed)
-            if (wave_lane() == 0) atomicAdd(&fl[b], 1u);
-        }
-        STAMP(15);
-        if (!more) break;
-        if (!same_kind) {  // the ring geometry changes: everybody must have left the old rings
-            young = 0;  // (the barrier's wait below covers the flush)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            start_ring(nxt);
-        }
-        STAMP(8);
-        cur = nxt;
-    }
-    if (WANT_LP) {
-        double v = lp_a;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
-    }
-#ifdef POLEE_STAMPS
-    STAMP(10);
-    if (wave_lane() == 0) {
-        for (int i = 0; i < NSTAMP; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
-        atomicAdd(&g_stamps[16], n_slices);
-        atomicAdd(&g_stamps[17], n_tiles);
-        atomicAdd(&g_stamps[18], 1ull);
-    }
-#endif
-}
-
 // Static schedule of the streaming kernel for a grid of G workgroups: the uniform tiles sorted by cost, dealt to the
 // workgroups in snake order (equal sums), and inside every workgroup's list the wide tiles (stream A2, two active
 // waves) spread evenly between the A1 tiles.
@@ -1681,20 +1375,11 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
     static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
     static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM_RB2, "A2 slices (+ ks row) must fit their ring");
-    static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM2_RB1, "A1 slices (+ ks row) must fit the decoupled kernel's ring");
-    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM2_RB2, "A2 slices (+ ks row) must fit the decoupled kernel's ring");
-    // the barrier version is the default (measured faster: 0.329 vs 0.350 ms at C2);
-    // POLEE_STREAM_DECOUPLED=1 selects the version with decoupled waves (A/B runs)
-    static const bool decoupled_env = getenv("POLEE_STREAM_DECOUPLED") != nullptr;
-    const bool decoupled = !DET && decoupled_env;
-    const size_t lds = decoupled ? stream2_lds_bytes<K>() : stream_lds_bytes<K, DET>();
+    const size_t lds = stream_lds_bytes<K, DET>();
     int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0][DET ? 1 : 0];
     if (occ == 0) {
         int nb = 0;
-        if (decoupled)
-            POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream2_kernel<K, LP, KS>, 256, lds));
-        else
-            POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS, DET>, 256, lds));
+        POLEE_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, loglik_stream_kernel<K, LP, KS, DET>, 256, lds));
         occ = std::max(1, std::min(nb, 4));
         if (getenv("POLEE_DEBUG_PRINT"))
             fprintf(stderr, "[loglik] stream kernel K=%d%s: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
@@ -1712,10 +1397,7 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, ll->d_dict.p,
                        A.x, ll->dict_len, ll->d_xwin.p);
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
-    if (decoupled)
-        hipLaunchKernelGGL((loglik_stream2_kernel<K, LP, KS>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
-    else
-        hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
+    hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     if (DET) {
         hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
