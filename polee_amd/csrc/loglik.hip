@@ -379,18 +379,12 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
     ws.islot = islot;
 }
 
-// The slice loop of one wave over its share of a uniform tile.  RB = ring bytes per active wave, WMAXR = widest
-// transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
+// The slice loop of one wave over its share of a tile of the WIDE stream (16 x 16 x 4 matrix tiles; the narrow stream has
+// its own loop, narrow_stream below; this one is written for any width -- with WMAXR <= 16 and its packed variant for sets
+// of <= 8 it was the narrow stream's loop until the outer-product formulation).  RB = ring bytes per active wave, WMAXR =
+// widest transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
 // the first refill (the previous tile's flush, the next tile's prefetch): they are younger than the primed pieces
 // and older than every other piece, so only waits for primed pieces have to allow for them.
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
-__device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
-                                     uint32_t aux_lds, double &lpacc, int dbg
-#ifdef POLEE_STAMPS
-                                     , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
-#endif
-                                     );
-
 template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS>
 __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                       uint32_t aux_lds, double &lpacc, int dbg
@@ -399,16 +393,6 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #endif
                                       )
 {
-    if constexpr (WMAXR <= PSELL_NARROW_MAX) {
-        {  // (the narrow stream has its own formulation; what follows serves the wide one)
-            narrow_stream<K, RB, WANT_LP, HAS_KS>(ws, ring, extras, xw, gw, aux_lds, lpacc, dbg
-#ifdef POLEE_STAMPS
-                                                  , st_acc, st_last
-#endif
-                                                  );
-            return;
-        }
-    }
     constexpr int RPFULL = (int)(RB / 1024u);
     const int RP = ((dbg >> 8) & 15) ? min(RPFULL, (WMAXR > 16 ? 2 : 1) * ((dbg >> 8) & 15)) : RPFULL;  // (experiment: pieces requested ahead)
     // (computed here, opaquely: the lane constants below are then recomputed per tile -- a few dozen instructions --
@@ -1211,7 +1195,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
-            uniform_stream<K, STREAM_RB1, PSELL_NARROW_MAX, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif

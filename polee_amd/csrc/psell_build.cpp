@@ -356,6 +356,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         }
     }
     static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
+    static const int a2cap = getenv("POLEE_TILE_A2") ? atoi(getenv("POLEE_TILE_A2")) : PSELL_TILE_SLICES_A2;
     const unsigned nthreads = host_threads();
     std::vector<std::vector<uint32_t>> stamps(nthreads);
     std::vector<std::vector<uint16_t>> locals(nthreads);
@@ -530,7 +531,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
             const uint32_t cap = cur_stream == 0 ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
-                                 : cur_stream == 1 ? PSELL_TILE_SLICES_A2 : PSELL_TILE_SLICES_B;
+                                 : cur_stream == 1 ? (uint32_t)a2cap : PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }
     }
