@@ -9,6 +9,7 @@
 // a stable sort, neighbour lists in insertion order, and visits the remaining components in ascending node id
 // (the one place where Julia's hash order cannot be followed).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -63,6 +64,9 @@ struct BinHeap {
             for (;;) {
                 const size_t l = 2 * i, r = l + 1;
                 if (l > len) break;
+                // (the four grandchildren are adjacent: their line is on its way while the children are compared -- with
+                // millions of edges every level below the first few is a cache miss)
+                if (4 * i <= len) __builtin_prefetch(&xs[4 * i - 1]);
                 const size_t j = (r > len || before(xs[l - 1], xs[r - 1])) ? l : r;
                 if (before(xs[j - 1], y)) {
                     xs[i - 1] = xs[j - 1];
@@ -82,7 +86,7 @@ struct SizeBefore {
     bool operator()(const NodeWithSize &a, const NodeWithSize &b) const { return a.size < b.size; }  // min-heap
 };
 
-typedef std::vector<uint32_t> ReadSet;
+typedef std::vector<uint32_t, default_init_allocator<uint32_t>> ReadSet;  // (resize does not zero-fill)
 
 // hclust.jl:116-135
 size_t intersection_size(const ReadSet &a, const ReadSet &b)
@@ -124,9 +128,8 @@ double relative_intersection(const ReadSet &a, const ReadSet &b)
 // hclust.jl:150-190
 ReadSet merge_sets(const ReadSet &a, const ReadSet &b)
 {
-    ReadSet out;
-    out.reserve(a.size() + b.size());
-    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(out));
+    ReadSet out(a.size() + b.size());
+    out.resize((size_t)(std::set_union(a.begin(), a.end(), b.begin(), b.end(), out.begin()) - out.begin()));
     return out;
 }
 
@@ -176,12 +179,21 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     std::vector<char> alive((size_t)n + 1, 1), deleted((size_t)n + 1, 0);
     nodes.reserve(2 * (size_t)n);
     read_sets.reserve(2 * (size_t)n);
-    for (int64_t j = 1; j <= n; ++j) {
-        const uint32_t t = idxs[(size_t)j - 1];
-        nodes[(size_t)j].j = t + 1;
-        read_sets[(size_t)j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
-        for (size_t e = 1; e < read_sets[(size_t)j].size(); ++e)
-            if (read_sets[(size_t)j][e] <= read_sets[(size_t)j][e - 1]) return "row indexes of a column are not ascending";
+    {
+        std::atomic<int> bad{0};
+        parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t q = lo; q < hi; ++q) {
+                const size_t j = q + 1;
+                const uint32_t t = idxs[q];
+                nodes[j].j = t + 1;
+                read_sets[j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
+                for (size_t e = 1; e < read_sets[j].size(); ++e)
+                    if (read_sets[j][e] <= read_sets[j][e - 1]) bad = 1;
+                if (!read_sets[j].empty() && (read_sets[j].front() < 1 || (int64_t)read_sets[j].back() > m)) bad = 2;
+            }
+        });
+        if (bad == 1) return "row indexes of a column are not ascending";
+        if (bad == 2) return "row index out of range";
     }
 
     // initial edges (:225-236)
@@ -192,7 +204,7 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     // (the n x 25 similarities are independent: computed by a few threads, then pushed in the reference's order)
     std::vector<float> sims((size_t)n * K, 0.0f);
     {
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned hw = host_threads();
         std::vector<std::thread> pool;
         for (unsigned th = 0; th < hw; ++th)
             pool.emplace_back([&, th]() {
@@ -215,8 +227,11 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     lap("initial edges");
 
     // greedy joining (:262-308)
-    std::vector<uint32_t> cand, uniq;
+    std::vector<uint32_t> cand, uniq, cslot;
     std::vector<double> csim, usim;
+    std::vector<uint32_t> stamp(2 * (size_t)n + 2, 0), slot(2 * (size_t)n + 2, 0);  // (node ids are 1 .. 2 n - 1; k > n >= 1 is never 0)
+    std::vector<uint64_t> bits(((size_t)m >> 6) + 2, 0);  // (read ids are 1 .. m)
+    const bool no_bitmap = getenv("POLEE_HCLUST_NO_BITMAP") != nullptr;  // (A/B check of the bitmap evaluation)
     const unsigned hw_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     double t_merge = 0, t_eval = 0, t_eval_heavy = 0, t_pop = 0;
     size_t n_heavy = 0, n_pops = 0, n_cand = 0, n_uniq = 0;
@@ -244,15 +259,41 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         for (const auto &ab : pair)
             for (uint32_t l : neighbors[ab[0]])
                 if (l != ab[1] && !deleted[l]) cand.push_back(l);
-        // every distinct neighbour is evaluated once (the two lists overlap and contain repeats)
-        uniq.assign(cand.begin(), cand.end());
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        // every distinct neighbour is evaluated once (the two lists overlap and contain repeats): distinct ids in the
+        // order of their first appearance, found with a stamp per node instead of a sort
+        uniq.clear();
+        cslot.resize(cand.size());
+        for (size_t c = 0; c < cand.size(); ++c) {
+            const uint32_t l = cand[c];
+            if (stamp[l] != k) {
+                stamp[l] = k;
+                slot[l] = (uint32_t)uniq.size();
+                uniq.push_back(l);
+            }
+            cslot[c] = slot[l];
+        }
         usim.resize(uniq.size());
         size_t work = 0;
         for (uint32_t l : uniq) work += read_sets[l].size() + read_sets[k].size();
+        // the new node's read set is one operand of every evaluation of this merge: mark its reads in a bitmap once, a
+        // neighbour's intersection is then a sum of bits over ITS reads (|neighbour| look-ups instead of a walk over
+        // |neighbour| + |new node| elements; the counts, hence the similarities, are the same)
+        const ReadSet &ks = read_sets[k];
+        const bool use_bits = uniq.size() >= 3 && !ks.empty() && !no_bitmap;
+        if (use_bits)
+            for (uint32_t v : ks) bits[v >> 6] |= 1ull << (v & 63u);
         auto eval = [&](size_t lo, size_t hi) {
-            for (size_t c = lo; c < hi; ++c) usim[c] = relative_intersection(read_sets[uniq[c]], read_sets[k]);
+            for (size_t c = lo; c < hi; ++c) {
+                const ReadSet &a = read_sets[uniq[c]];
+                if (!use_bits) {
+                    usim[c] = relative_intersection(a, ks);
+                    continue;
+                }
+                size_t is = 0;
+                if (!a.empty() && a.front() <= ks.back() && a.back() >= ks.front())
+                    for (uint32_t v : a) is += (size_t)((bits[v >> 6] >> (v & 63u)) & 1ull);
+                usim[c] = a.empty() ? 0.0 : (double)is / (double)(a.size() + ks.size() - is);
+            }
         };
         const double te0 = timing ? now() : 0.0;
         n_cand += cand.size();
@@ -269,10 +310,12 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         } else {
             eval(0, uniq.size());
         }
+        if (use_bits)
+            for (uint32_t v : ks) bits[v >> 6] = 0;
         if (timing) (heavy ? t_eval_heavy : t_eval) += now() - te0;
         csim.resize(cand.size());
-        for (size_t c = 0; c < cand.size(); ++c)
-            csim[c] = usim[(size_t)(std::lower_bound(uniq.begin(), uniq.end(), cand[c]) - uniq.begin())];
+        for (size_t c = 0; c < cand.size(); ++c) csim[c] = usim[cslot[c]];
+        neighbors[k].reserve(cand.size());
         for (size_t c = 0; c < cand.size(); ++c) {
             const uint32_t l = cand[c];
             if (csim[c] != 0) queue.push(Edge{l, k, (float)csim[c]});
