@@ -48,8 +48,8 @@ constexpr int PSELL_TILE_SLICES_A2 = 8;
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
-constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, one 16-row MFMA tile)
-constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two MFMA tiles)
+constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, four groups of four transcripts: narrow_stream)
+constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two 16-row MFMA tiles: uniform_stream)
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
 // A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
