@@ -394,7 +394,9 @@ def main():
         so = O.Sample(m, n, colptr, rowval, nzval)
         to = O.PTT(parents, js)
         t_prep = time.time() - t0
-        O.set_num_threads(O.physical_cores())  # the reference's default: one thread per PHYSICAL core (polee:8-12)
+        # the reference's default: one thread per PHYSICAL core (polee:8-12) -- of those this process may use (a container's
+        # CPU quota counts: threads beyond it are only throttled)
+        O.set_num_threads(O.physical_cores())
         t0 = time.time()
         O.approximate_likelihood(so, to, smp["effective_lengths"], num_steps=args.cpu_steps, num_mc=K,
                                  seed=args.seed)
@@ -402,8 +404,9 @@ def main():
         out["cpu_baseline"] = {
             "value": args.cpu_steps / t_cpu, "unit": "VI iters/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%d full VI iteration(s) (K=%d draws, %d likelihood passes) of the oracle on the SAME %s sample "
-                      "(%.1f s of CPU work; setup %.1f s not counted)" % (args.cpu_steps, K, 2 * K * args.cpu_steps,
-                                                                          args.workload.upper(), t_cpu, t_prep),
+                      "(%.1f s of CPU work; setup %.1f s not counted); host CPUs usable: %s"
+                      % (args.cpu_steps, K, 2 * K * args.cpu_steps, args.workload.upper(), t_cpu, t_prep,
+                         "cgroup quota %d" % O.cpu_quota() if O.cpu_quota() else "all"),
         }
         out["detail"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
 

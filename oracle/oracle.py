@@ -449,4 +449,29 @@ def physical_cores():
                 pairs.add((phys, line.split(":")[1].strip()))
     except OSError:
         pass
-    return len(pairs) or n or (os.cpu_count() or 1)
+    cores = len(pairs) or n or (os.cpu_count() or 1)
+    # a container may be given fewer CPUs than the machine has (cgroup CPU quota): threads beyond it are only throttled
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    q = cpu_quota()
+    return max(1, min(cores, q)) if q else cores
+
+
+def cpu_quota():
+    """CPUs this process may use according to its cgroup's CPU quota (cgroup v2 cpu.max / v1 cfs quota), rounded up;
+    None when unlimited."""
+    try:
+        a = open("/sys/fs/cgroup/cpu.max").read().split()
+        if a and a[0] != "max":
+            return max(1, -(-int(a[0]) // int(a[1])))
+        return None
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, -(-quota // period)) if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None

@@ -30,3 +30,4 @@ from .estimate import LoadedSamples, load_samples_from_specification, load_sampl
 from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegression, RNASeqNormalTranscriptLinearRegression, RNASeqGeneLinearRegression, estimate_sample_scales,  # noqa: F401,E402
                          find_minimum_effect_size, write_regression_effects)
 from .salmon import load_salmon_likelihood, SalmonLikelihood  # noqa: F401,E402
+from .cohort import approximate_likelihood_cohort  # noqa: F401,E402

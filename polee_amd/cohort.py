@@ -97,3 +97,37 @@ def shard_regression_inputs(vars, x_init, F_arr, sample_scales, world_size, rank
     return dict(vars=v, x_init=x_init[sl], F_arr=np.asarray(F_arr)[sl],
                 sample_scales=np.asarray(sample_scales).reshape(S, -1)[sl],
                 x_init_mean=x_init.astype(np.float64).mean(axis=0).astype(np.float32))
+
+
+def approximate_likelihood_cohort(approx, samples, workers=4, device=0, on_result=None, **kwargs):
+    """`approximate_likelihood` (likelihood-approximation.jl:395-624) for the samples of a cohort, `workers` of them in
+    flight on ONE GPU.  Per sample the reference's `prep-sample` (main.jl:560-660) builds the tree from X on the CPU
+    (hclust.jl), then fits; here a fit occupies the GPU for a fraction of a second while the host side of the same sample
+    -- tree construction, device layout build -- takes seconds, so the samples are pipelined: every worker thread takes
+    one sample through all stages on its own `Context` (= HIP stream); the C library releases the GIL, the host stages of
+    some samples run under the device stage of others, and two fits that meet on the device share it (one's sparse pass
+    under the other's tree kernels, like `bench.py --samples-per-gpu`).
+
+    samples: iterable of zero-argument callables, each returning `(m, n, colptr, rowval, nzval, effective_lengths)`
+             (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
+             `workers` matrices are in host memory at a time -- or of such tuples.
+    on_result(index, params): optional callback as results arrive (e.g. the prep HDF5 writer); else a list is returned.
+    kwargs: passed to `approximate_likelihood` (num_steps, num_mc_samples, seed, gene_noninformative, ...).
+    Returns the list of params dicts in the order of `samples` (None where `on_result` consumed them)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import core
+
+    def job(item):
+        idx, src = item
+        m, n, colptr, rowval, nzval, efflens = src() if callable(src) else src
+        ctx = core.Context(device)
+        sample = core.RNASeqSample(m, n, colptr, rowval, nzval, efflens, ctx=ctx)
+        params = core.approximate_likelihood(approx, sample, **kwargs)
+        del sample
+        if on_result is not None:
+            on_result(idx, params)
+            return None
+        return params
+
+    with ThreadPoolExecutor(max_workers=max(1, int(workers))) as ex:
+        return list(ex.map(job, enumerate(samples)))

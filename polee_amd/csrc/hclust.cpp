@@ -232,7 +232,7 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     std::vector<uint32_t> stamp(2 * (size_t)n + 2, 0), slot(2 * (size_t)n + 2, 0);  // (node ids are 1 .. 2 n - 1; k > n >= 1 is never 0)
     std::vector<uint64_t> bits(((size_t)m >> 6) + 2, 0);  // (read ids are 1 .. m)
     const bool no_bitmap = getenv("POLEE_HCLUST_NO_BITMAP") != nullptr;  // (A/B check of the bitmap evaluation)
-    const unsigned hw_threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned hw_threads = std::min(32u, host_threads());
     double t_merge = 0, t_eval = 0, t_eval_heavy = 0, t_pop = 0;
     size_t n_heavy = 0, n_pops = 0, n_cand = 0, n_uniq = 0;
     while (!queue.empty()) {

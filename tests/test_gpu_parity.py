@@ -932,3 +932,32 @@ def test_fast_log_is_a_double_precision_log(P, ctx):
     eo = np.empty_like(edge)
     L.check(L.lib().polee_debug_fast_log(ctx._h, edge.ctypes.data_as(L.f64p), C.c_int64(4), eo.ctypes.data_as(L.f64p)), ctx._h)
     assert eo[0] == -np.inf and np.isnan(eo[1]) and eo[2] == np.inf and np.isnan(eo[3])
+
+
+def test_cohort_pipeline_matches_sequential_fits(P, lm_fixture):
+    """approximate_likelihood_cohort: several samples in flight on one GPU (a worker thread and a HIP stream each, host
+    stages of one under the device stage of another) give what one-at-a-time calls give: the same tree node for node,
+    and the same fitted parameters up to the float32 summation order of the likelihood's atomics."""
+    f = lm_fixture
+    rng = np.random.default_rng(11)
+    samples = []
+    for i in range(5):  # the fixture's matrix with perturbed probabilities: different samples, same support
+        nz = (f["nzval"] * rng.uniform(0.5, 1.5, size=f["nzval"].shape)).astype(np.float32)
+        samples.append((f["m"], f["n"], f["colptr"], f["rowval"], nz, f["effective_lengths"]))
+    approx = P.LogitSkewNormalPTTApprox("cluster")
+    kw = dict(num_steps=30, num_mc_samples=6, seed=5)
+    seq = []
+    for s in samples:
+        ctx = P.Context(0)
+        seq.append(P.approximate_likelihood(approx, P.RNASeqSample(*s, ctx=ctx), **kw))
+    calls = []
+    lazy = [(lambda s=s: (calls.append(1), s)[1]) for s in samples]  # sources may be callables (loaded inside the worker)
+    par = P.approximate_likelihood_cohort(approx, lazy, workers=3, **kw)
+    assert len(par) == len(samples) and len(calls) == len(samples)
+    for a, b in zip(seq, par):
+        assert (a["node_parent_idxs"] == b["node_parent_idxs"]).all() and (a["node_js"] == b["node_js"]).all()
+        for key in ("mu", "omega", "alpha"):
+            np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-3)
+    got = {}
+    assert P.approximate_likelihood_cohort(approx, samples[:2], workers=2, on_result=lambda i, p: got.__setitem__(i, p), **kw) == [None, None]
+    assert sorted(got) == [0, 1] and np.isfinite(got[1]["mu"]).all()
