@@ -1,1 +1,1 @@
-for t in 16 48 16 48; do echo "THREADS=$t"; POLEE_HOST_THREADS=$t POLEE_BUILD_TIMING=1 timeout 600 python tools/probe/time_fit.py 2>&1 | grep -E "loglik create|psell" | awk '{s+=$(NF-1)} END {print "sum of laps", s}'; POLEE_HOST_THREADS=$t python tools/probe/hclust_time.py 2>&1 | tail -1; done
+for v in 0 4096; do POLEE_DBG_ABLATE=$v timeout 600 python tools/probe/time_fit.py 2>&1 | tail -1; done
