@@ -370,7 +370,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "loglik_stream_kernel<%d, false, false>" % K,
+            "kernel": "loglik_stream_kernel<%d, false, false, %s>" % (K, "true" if args.deterministic else "false"),
             "kernel_ms_avg": kern_ms, "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_dom,
             "slice_stream_bytes_per_launch": sum(info["stream_bytes_hbm"]),
