@@ -109,7 +109,7 @@ def approximate_likelihood_cohort(approx, samples, workers=4, device=0, on_resul
     under the other's tree kernels, like `bench.py --samples-per-gpu`).
 
     samples: iterable of zero-argument callables, each returning `(m, n, colptr, rowval, nzval, effective_lengths)`
-             (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
+             or the dict of `h5io.read_likelihood_matrix` (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
              `workers` matrices are in host memory at a time -- or of such tuples.
     on_result(index, params): optional callback as results arrive (e.g. the prep HDF5 writer); else a list is returned.
     kwargs: passed to `approximate_likelihood` (num_steps, num_mc_samples, seed, gene_noninformative, ...).
@@ -119,7 +119,10 @@ def approximate_likelihood_cohort(approx, samples, workers=4, device=0, on_resul
 
     def job(item):
         idx, src = item
-        m, n, colptr, rowval, nzval, efflens = src() if callable(src) else src
+        lm = src() if callable(src) else src
+        if isinstance(lm, dict):  # h5io.read_likelihood_matrix
+            lm = tuple(lm[key] for key in ("m", "n", "colptr", "rowval", "nzval", "effective_lengths"))
+        m, n, colptr, rowval, nzval, efflens = lm
         ctx = core.Context(device)
         sample = core.RNASeqSample(m, n, colptr, rowval, nzval, efflens, ctx=ctx)
         params = core.approximate_likelihood(approx, sample, **kwargs)
