@@ -959,5 +959,6 @@ def test_cohort_pipeline_matches_sequential_fits(P, lm_fixture):
         for key in ("mu", "omega", "alpha"):
             np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-3)
     got = {}
-    assert P.approximate_likelihood_cohort(approx, samples[:2], workers=2, on_result=lambda i, p: got.__setitem__(i, p), **kw) == [None, None]
+    as_dicts = [dict(zip(("m", "n", "colptr", "rowval", "nzval", "effective_lengths"), s)) for s in samples[:2]]  # (h5io.read_likelihood_matrix)
+    assert P.approximate_likelihood_cohort(approx, as_dicts, workers=2, on_result=lambda i, p: got.__setitem__(i, p), **kw) == [None, None]
     assert sorted(got) == [0, 1] and np.isfinite(got[1]["mu"]).all()
