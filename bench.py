@@ -29,6 +29,8 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     # name: (n, m, mean nnz/fragment)
     "c1": (1000, 100000, 2.2),
+    # REAL-STRUCTURE workload: the reference's likelihood-matrix fixture (tests/golden) tiled block-diagonally 639 times
+    "fixture": (313 * 639, 19743 * 639, 42775 / 19743),
     "small": (20000, 3000000, 8.0),
     "c2": (200000, 30000000, 8.0),
     "c5": (200000, 150000000, 8.0),
@@ -42,6 +44,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def algorithmic_bytes_per_pass(nnz, m, n, K):
     """nnz*(4 B value + 4 B column) + (m+1)*4 B row offsets + K*n*8 B (read x, write grad)."""
     return nnz * 8 + (m + 1) * 4 + K * n * 8
+
+
+def source_id():
+    """Identifies the BUILD a measurement belongs to: a hash of the sparse kernel's sources and build flags (the GPU box
+    has no .git).  A PMC capture (profiles/traffic_*.json) carries the id of the build it was taken with, and
+    `roofline.traffic` is emitted only when it equals this run's."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("loglik.hip", "loglik_internal.hpp", "psell_build.cpp", "wave.hpp", "common.hpp", "Makefile"):
+        with open(os.path.join(ROOT, "polee_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def emit(out):
@@ -211,6 +225,12 @@ def main():
                     help="VI iterations of a THROWAWAY fit of the same sample run before the warmup steps, so that the GPU "
                          "is at its sustained clocks when the short timed region starts (a real fit is 500 iterations; "
                          "the driver times 20); 0 = none")
+    ap.add_argument("--set-diversity", type=float, default=0.0, metavar="P",
+                    help="per-entry dropout probability of the generator (first entry of a fragment kept): fragments of a "
+                         "gene stop sharing a handful of transcript sets; 0 = the generator as built")
+    ap.add_argument("--literal-subsets", action="store_true",
+                    help="every fragment draws its own random subset of its gene's isoforms (SURVEY 8(d)'s literal wording) "
+                         "instead of one of the gene's <= 12 compatibility patterns")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
@@ -254,7 +274,11 @@ def main():
     for si in range(S):
         t0 = time.time()
         # (row-sharded: every rank generates the same sample and keeps its block of fragments)
-        smp_i = synth.make_sample(n, m, mean_nnz, seed=sample_seed(args.seed, 0 if args.row_shard else rank * S + si))
+        if args.workload == "fixture":
+            smp_i = synth.tile_fixture(639)
+        else:
+            smp_i = synth.make_sample(n, m, mean_nnz, seed=sample_seed(args.seed, 0 if args.row_shard else rank * S + si),
+                                      dropout=args.set_diversity, literal=args.literal_subsets)
         parents, js = synth.make_tree(smp_i["gene"], seed=args.seed, kind=args.tree)
         t_gen += time.time() - t0
         ctx_i = P.Context(local_rank if world > 1 else 0)
@@ -325,25 +349,35 @@ def main():
                 / max(launches, 1))
 
     kern_ms, pass_ms = avg("loglik_kernel_ms_avg"), avg("loglik_pass_ms_avg")
+    # ALGORITHMIC bytes of a pass (CSR with u32 ids) and the bytes the device layout PHYSICALLY moves: the
+    # slice streams read once + the x windows read and the gradient windows added (dictionary entries x K x 4 B each
+    # way).  The layout stores a slice's transcript ids once (or as a 16-bit mask per fragment), so physical < algorithmic
+    # and "algorithmic bytes / time" can exceed the HBM peak without the memory system being saturated: `frac` is therefore
+    # the PHYSICAL fraction -- bytes that really move / kernel time / peak -- and the CSR-equivalent figure is reported
+    # beside it as `effective_*`.  The dominant kernel is the persistent launch over the uniform streams; the mixed
+    # stream's tiles (rows that fit no uniform slice) run in a second launch, inside `pass_ms`.
     bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
-    # the pass is one persistent launch, loglik_stream_kernel (+ a 9 us gather of the x windows in front of it)
-    bytes_dom = bytes_pass
-    achieved = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    sb = info["stream_bytes_hbm"]
+    win_bytes = 2 * 4 * K * info.get("dict_entries", 0)
+    phys_bytes_pass = sum(sb) + win_bytes
+    uniform_share = sum(info["stream_nnz"][:3]) / max(info["nnz"], 1)
+    phys_bytes_dom = sum(sb[:3]) + win_bytes * (sum(info["stream_tiles"][:3]) / max(sum(info["stream_tiles"]), 1))
+    bytes_dom = bytes_pass * uniform_share
+    achieved = phys_bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    effective = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    sid = source_id()
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile.sh): a capture is
-    # only valid for the workload / draws / tree it was taken at -- otherwise null
+    # valid for the build and the workload it was taken with -- otherwise null
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
     if os.path.exists(tpath):
         try:
             cap = json.load(open(tpath))
-            if (cap.get("draws"), cap.get("tree"), cap.get("nnz")) == (K, args.tree, info["nnz"]) and not args.deterministic:
+            if ((cap.get("draws"), cap.get("tree"), cap.get("nnz"), cap.get("source_id")) == (K, args.tree, info["nnz"], sid)
+                    and not args.deterministic):
                 traffic = cap.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    # what the launch physically moves: the slice stream once + the x windows read and the g windows added
-    # (dictionary entries x K x 4 B each way)
-    phys_bytes = sum(info["stream_bytes_hbm"]) + 2 * 4 * K * info.get("dict_entries", 0)
-    phys = phys_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     out = {
         "metric": "approx-lik VI iters/sec",
@@ -363,6 +397,7 @@ def main():
                         "K=%d draws per VI iteration, %s tree" % (args.workload.upper(), n, m, info["nnz"],
                                                                   info["nnz"] / m, K, args.tree),
             "samples_per_gpu": S, "draws": K, "tree": args.tree, "nnz": info["nnz"], "deterministic": bool(args.deterministic),
+            "set_diversity": args.set_diversity, "literal_subsets": bool(args.literal_subsets),
             "parallelism": "one sample row-sharded over %d GPU(s), 1 all-reduce of K*n f32 per pass" % world
                            if args.row_shard else "sample-per-GPU x%d, no collective" % world if S == 1 else
                            "%d concurrent samples per GPU x%d GPUs, no collective" % (S, world),
@@ -370,16 +405,23 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "definition": "achieved = bytes the device layout moves per launch (slice streams + x / gradient windows) / "
+                          "kernel time; effective_* = SURVEY 8(d)'s CSR-equivalent bytes of the same rows / the same time",
             "kernel": "loglik_stream_kernel<%d, false, false, %s>" % (K, "true" if args.deterministic else "false"),
-            "kernel_ms_avg": kern_ms, "launches": int(launches),
+            "kernel_ms_avg": kern_ms, "pass_ms_avg": pass_ms, "launches": int(launches),
+            "physical_bytes_per_launch": phys_bytes_dom,
             "algorithmic_bytes_per_launch": bytes_dom,
-            "slice_stream_bytes_per_launch": sum(info["stream_bytes_hbm"]),
-            # the device layout is smaller than CSR, so the memory system itself runs at:
-            "physical_bytes_per_launch": phys_bytes, "physical_GBs": phys, "physical_frac": phys / HBM_PEAK_GBS,
+            "effective_GBs": effective, "effective_frac": effective / HBM_PEAK_GBS,
+            "physical_over_algorithmic": phys_bytes_dom / max(bytes_dom, 1),
+            # the whole pass (gather + persistent launch + the mixed stream's launch), same two definitions
+            "pass_physical_GBs": phys_bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
+            "pass_effective_GBs": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
             "stream_share_of_nnz": [v / max(info["nnz"], 1) for v in info["stream_nnz"]],
+            "stream_bytes_per_nnz": [b / max(v, 1) for b, v in zip(sb, info["stream_nnz"])],
+            "layout_bytes_per_nnz": sum(sb) / max(info["nnz"], 1), "csr_bytes_per_nnz": (8 * info["nnz"] + 4 * (m + 1)) / max(info["nnz"], 1),
         },
         "detail": {
-            "hip_event_ms_per_step": ev_ms / args.steps, "prewarm_steps": args.prewarm, "gen_s": t_gen, "device_layout_build_s": t_build,
+            "source_id": sid, "hip_event_ms_per_step": ev_ms / args.steps, "prewarm_steps": args.prewarm, "gen_s": t_gen, "device_layout_build_s": t_build,
             "padded_nnz_ratio": info["padded_nnz"] / max(info["nnz"], 1), "num_tiles": info["num_tiles"],
             "max_tile_cols": info["max_tile_cols"],
         },

@@ -138,12 +138,13 @@ typedef struct {
     int64_t num_empty_rows;  /* fragments with no compatible transcript (skipped)       */
     int32_t max_row_nnz;
     int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
-    /* the three row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):   */
-    /* [0] uniform slices, sets of <= 16 transcripts; [1] uniform, 17..32; [2] everything else */
-    int64_t stream_rows[3];  /* fragments                                               */
-    int64_t stream_nnz[3];   /* non-zeros of X                                          */
-    int64_t stream_tiles[3]; /* workgroups per launch                                   */
-    int64_t stream_bytes_hbm[3]; /* bytes of the slice stream each launch reads          */
+    /* the four row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):            */
+    /* [0] dense uniform slices, sets of <= 16 transcripts; [1] masked uniform slices, unions of <= 16 */
+    /* (fragments whose sets differ); [2] dense uniform, 17..32; [3] mixed slices: everything else     */
+    int64_t stream_rows[4];  /* fragments                                               */
+    int64_t stream_nnz[4];   /* non-zeros of X                                          */
+    int64_t stream_tiles[4]; /* tiles (workgroup-sized units of work)                   */
+    int64_t stream_bytes_hbm[4]; /* bytes of the slice stream a pass reads                */
     int64_t dict_entries;    /* entries of all tile dictionaries: x is gathered into, and the gradient flushed */
                              /* from, one window of dict_entries x K floats per pass                           */
 } polee_loglik_info;
@@ -229,12 +230,13 @@ typedef struct {
     int32_t steps_done;
     int32_t nonfinite_step;        /* first step with a non-finite gradient, 0 if none    */
     double loglik_kernel_ms_avg;   /* profile=1: mean duration of the dominant sparse     */
-                                   /* kernel (uniform stream A1; the whole pass if none)  */
+                                   /* kernel (the persistent launch over the uniform streams) */
     int64_t loglik_kernel_launches;
     double last_elbo;              /* !gradonly: reference-style elbo of the last step    */
     double last_lp_mean;           /* !gradonly: mean log-likelihood over the K draws     */
     double loglik_pass_ms_avg;     /* profile=1: mean duration of one whole likelihood    */
-                                   /* pass (all three concurrent launches)                */
+                                   /* pass: the x-window gather, the persistent launch     */
+                                   /* and, if the sample has mixed tiles, their launch     */
 } polee_vi_stats;
 
 /* Builds the state and the initial values mu = logit(inverse_transform(1/n)),

@@ -35,7 +35,13 @@ typedef struct {
     const uint8_t *slice_flags; /* [num_slices] bit0 uniform, bit1 continues previous      */
     int64_t num_tiles_a;        /* tiles [0, num_tiles_a) hold COMPACT slices:             */
                                 /*   uint16 lcol[128] (w used); float val[w][64]           */
-    int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): transcript sets of <= 16        */
+    int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): dense, transcript sets of <= 16 */
+    int64_t num_tiles_a1m;      /* tiles [num_tiles_a1, num_tiles_a1m): MASKED slices:      */
+                                /*   uint16 lcol[16] (0xffff past the union); at byte 128   */
+                                /*   uint16 mask[64]; float val[i][64] = i-th non-zero of   */
+                                /*   the lane's fragment; [num_tiles_a1m, num_tiles_a): dense, 17..32 */
+    const uint8_t *slice_w;     /* [num_slices] transcripts of the slice's set / longest row (mixed) */
+    int64_t stream_rows[4], stream_nnz[4], stream_bytes[4]; /* as in polee_loglik_info */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

@@ -74,6 +74,13 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->slice_flags = h.slice_flags.data();
     v->num_tiles_a = h.num_tiles_a;
     v->num_tiles_a1 = h.num_tiles_a1;
+    v->num_tiles_a1m = h.num_tiles_a1m;
+    v->slice_w = h.slice_w.data();
+    for (int i = 0; i < 4; ++i) {
+        v->stream_rows[i] = h.stream_rows[i];
+        v->stream_nnz[i] = h.stream_nnz[i];
+        v->stream_bytes[i] = h.stream_bytes[i];
+    }
     return POLEE_OK;
 }
 

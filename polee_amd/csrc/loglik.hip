@@ -112,9 +112,10 @@ struct PsellArgs {
     float *g;
     double *lp;
     int lcap;
-    int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layout
+    int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layouts
     // the persistent streaming kernel
-    int tiles_a1;           // tiles [0, tiles_a1): stream A1, [tiles_a1, tiles_a): A2
+    int tiles_a1;           // tiles [0, tiles_a1): stream A1 (dense narrow), [tiles_a1, tiles_a1m): A1M (masked), [tiles_a1m, tiles_a): A2
+    int tiles_a1m;
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
@@ -151,17 +152,30 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 #pragma unroll
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
 
+    const int stream = tile < A.tiles_a1 ? PSELL_A1 : (tile < A.tiles_a1m ? PSELL_A1M : (tile < A.tiles_a ? PSELL_A2 : PSELL_B));
     for (uint32_t s = s0 + wave; s < s1; s += 4) {
         const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
         const uint32_t units = (slice_off[s + 1] & PSELL_OFF_MASK) - off;
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
+        // masked slices: uint16 lcol[16], uint16 mask[64] at byte 128, then float val[i][64] = the lane's i-th non-zero;
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
-        const int w = compact ? (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0) : (int)(units / 3u);  // (+ a ks row when factored)
+        const int nrows = compact ? (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0) : (int)(units / 3u);  // (+ a ks row when factored)
+        const bool masked = stream == PSELL_A1M;
+        const uint16_t *hdr = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128);
+        int w = nrows;
+        uint32_t mk = 0;
+        if (masked) {
+            w = 0;
+            while (w < PSELL_NARROW_MAX && hdr[w] != PSELL_NO_COL) ++w;
+            mk = hdr[64 + lane];
+        }
         // (compact slices store element r of row t at position psell_row_pos(stream, t, r) of the row)
         const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0));
-        auto vat = [&](int t) -> float { return vbase[t * 64 + (compact ? (int)psell_row_pos(tile < A.tiles_a1 ? 0 : 1, (uint32_t)t, (uint32_t)lane) : lane)]; };
-        const uint16_t *cols = compact ? reinterpret_cast<const uint16_t *>(data + (size_t)off * 128)
-                                       : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
+        auto vat = [&](int t) -> float {
+            if (masked) return (mk >> t) & 1u ? vbase[__popc(mk & ((1u << t) - 1u)) * 64 + lane] : 0.0f;
+            return vbase[t * 64 + (compact ? (int)psell_row_pos(stream, (uint32_t)t, (uint32_t)lane) : lane)];
+        };
+        const uint16_t *cols = compact ? hdr : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
         const int cstride = compact ? 1 : 64;
 
         // sweep 1: row sums s[k] = sum_t v[t] * x[c[t]][k]
@@ -702,7 +716,40 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 //     t >= w of the last group point at a row of zeros / at a scratch row: no masks in the loads and in the flush);
 //   * the flush adds a group's four transcripts under one exec mask.
 // `aux_lds`: LDS address of 32 bytes of zeros followed by 32 bytes of scratch.
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
+// 4 x 4 transpose inside every quad of lanes: lane j of a quad ends up with register j of the quad's lanes 0..3 in
+// a0..a3 (out[i] of lane j = in[j] of lane i).  Two rounds of "keep or take the neighbour's" with DPP quad permutes
+// folded into the selects (v_cndmask_b32_dpp: D = vcc ? src1 : permuted src0) -- 8 vector instructions for 16 values.
+// (Inline assembly: the compiler's hazard recogniser does not look inside, so the block starts with the two wait states a
+// DPP read of a freshly written VGPR needs; inside it every such pair is at least two instructions apart.)
+__device__ inline void quad_transpose(float &a0, float &a1, float &a2, float &a3)
+{
+    float y0, y1, y2, y3;
+    const uint64_t E = 0x5555555555555555ull, L = 0x3333333333333333ull;  // lanes with bit 0 / bit 1 of their index clear
+    asm volatile("s_nop 1\n\t"
+                 "s_mov_b64 vcc, %8\n\t"
+                 "v_cndmask_b32_dpp %4, %1, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // y0 = even ? a0 : a1 of lane ^ 1
+                 "v_cndmask_b32_dpp %6, %3, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // y2 = even ? a2 : a3 of lane ^ 1
+                 "s_not_b64 vcc, vcc\n\t"
+                 "v_cndmask_b32_dpp %5, %0, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // y1 = odd ? a1 : a0 of lane ^ 1
+                 "v_cndmask_b32_dpp %7, %2, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"  // y3 = odd ? a3 : a2 of lane ^ 1
+                 "s_mov_b64 vcc, %9\n\t"
+                 "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  // z0 = low ? y0 : y2 of lane ^ 2
+                 "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  // z1 = low ? y1 : y3 of lane ^ 2
+                 "s_not_b64 vcc, vcc\n\t"
+                 "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"  // z2 = high ? y2 : y0 of lane ^ 2
+                 "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"        // z3 = high ? y3 : y1 of lane ^ 2
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+                 : "s"(E), "s"(L)
+                 : "vcc", "scc");
+}
+
+// MASKED: the tile's slices are masked slices (stream A1M, loglik_internal.hpp): a fragment's values are stored packed
+// (its i-th non-zero in row i) with a 16-bit mask of the union's transcripts it has.  Lane r expands its own fragment
+// for phase 1 -- V[t][r] = bit t of its mask ? row (number of lower mask bits) : 0, one LDS read at a running address per
+// transcript, conflict free because every lane reads its own column -- and phase 2's operands V[4 g + j][4 b + i] are
+// exactly the quad transposes of the phase-1 registers: no second LDS pass, and the slice's ring bytes are free before
+// the first matrix instruction.
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, bool MASKED>
 __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
@@ -746,6 +793,7 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         for (int kg = 0; kg < KG; ++kg) xq[t][kg] = 0.0f;
     uint32_t xav = aux_lds, gav = aux_lds + 32u;  // lane t < 16: LDS addresses of the x row / gradient row of the run's transcript t
     int pend_w = 0;
+    int run_w = 0;  // (MASKED) transcripts of the current run's union
     double lpn[KG];
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) lpn[kg] = 0.0;
@@ -801,7 +849,8 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
         const uint32_t units = off_next - off;
-        const int w = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);
+        const int nrows = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // rows of 64 values: the set's transcripts / (MASKED) the longest fragment
+        int w = MASKED ? run_w : nrows;
         const uint32_t bytes = units * 128u;
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
         STAMP(1);  // slice bookkeeping
@@ -817,7 +866,11 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             // addresses of its x row and its gradient row; then the x values of the run, four transcripts at a time
             const uint32_t cid = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
                 (uintptr_t)(ring_lds + pos_r + 2u * (uint32_t)(lane & 15)));
-            const bool live = (lane & 15) < w;
+            const bool live = MASKED ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < w;
+            if (MASKED) {
+                run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
+                w = run_w;
+            }
             xav = live ? xw_lds + cid * (uint32_t)(K * 4) : aux_lds;
             gav = live ? gw_lds + cid * (uint32_t)(K * 4) : aux_lds + 32u;
             load_x_group(0, xq);
@@ -904,8 +957,41 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
                     for (int kg = 0; kg < KG; ++kg) acc[g][kg] = __builtin_amdgcn_mfma_f32_4x4x1f32(q4[i], d1[kg][i], acc[g][kg], 0, 0, 0);
             };
             if (HAS_KS)  // the multiplicities travel with the slice (its last row, stored in fragment order)
-                kv = *reinterpret_cast<const f32x4 *>(ring + wrap_u(row0 + 256u * (uint32_t)w) + 16u * (uint32_t)b);
-            if (NG <= 2) {
+                kv = *reinterpret_cast<const f32x4 *>(ring + wrap_u(row0 + 256u * (uint32_t)nrows) + 16u * (uint32_t)b);
+            if (MASKED) {
+                // this lane's fragment, expanded by its mask: transcript t of the union is in row (number of mask bits
+                // below t) of the slice when bit t is set; `a` runs through the rows' addresses.  Rows past the fragment's
+                // last non-zero (and past the slice: the bytes behind it in the ring) are read and masked away.
+                const uint32_t mk = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
+                    (uintptr_t)(ring_lds + pos_r + 128u + 2u * (uint32_t)lane));
+                float mv[4 * NG];
+                uint32_t a = lc1[0] + row0;
+                const uint32_t lim = lc1[0] + RB;  // (slices that wrap around the ring's end)
+#pragma unroll
+                for (int t = 0; t < 4 * NG; ++t) {
+                    mv[t] = lds_f(a);
+                    a += ((mk >> t) & 1u) << 8;
+                    if (!FAST) a = a >= lim ? a - RB : a;
+                }
+                consumed();
+#pragma unroll
+                for (int t = 0; t < 4 * NG; ++t) mv[t] = __uint_as_float(__float_as_uint(mv[t]) & (uint32_t)(((int)(mk << (31 - t))) >> 31));
+                phase1(mv, xq);
+                if (NG > 1) phase1(mv + 4, xq + 4);
+                if (NG > 2) {  // (registers hold the x rows of eight transcripts: the others' are re-read per slice)
+                    float xr[8][KG];
+                    load_x_group(2, xr);
+                    if (NG > 3) load_x_group(3, xr + 4);
+                    phase1(mv + 8, xr);
+                    if (NG > 3) phase1(mv + (NG > 3 ? 12 : 0), xr + 4);
+                }
+                weights();
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    quad_transpose(mv[4 * g], mv[4 * g + 1], mv[4 * g + 2], mv[4 * g + 3]);
+                    phase2(g, mv + 4 * g);
+                }
+            } else if (NG <= 2) {
                 // all operands at once; the slice's ring bytes are free before the matrix phases
                 read_p(0, NG);
                 read_q(0, NG);
@@ -1105,10 +1191,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     unsigned long long n_slices = 0, n_tiles = 0;
 #endif
 
-    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : 1; };  // A1 / A2 (the schedule holds no others)
+    // 0 = A1 (dense narrow), 2 = A1M (masked narrow), 1 = A2 (wide: two active waves, 14 KiB rings); the schedule holds no others
+    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a1m ? 2 : 1); };
     // this wave's share [sb, se) of an A tile's slices: a contiguous block, so that runs stay inside one wave
     auto share = [&](int kind, const PosDesc &t, uint32_t &sb, uint32_t &se) {
-        const int nw = kind == 0 ? 4 : 2;
+        const int nw = kind != 1 ? 4 : 2;
         uint32_t a1 = t.c1, a2 = t.c2, a3 = t.c3;
         asm volatile("" : "+s"(a1), "+s"(a2), "+s"(a3));  // (opaque: or the selects below become an indexed load of a PosDesc kept in scratch memory)
         const uint32_t lo = wave == 0 ? t.s0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));
@@ -1154,7 +1241,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
         ws.gsrc = reinterpret_cast<const uint8_t *>(uniform_ptr(A.data + (size_t)cb * 128));
-        if (kind == 0) {
+        if (kind != 1) {
             ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, ahead ? min(ahead, (int)(STREAM_RB1 / 1024u)) : (int)(STREAM_RB1 / 1024u)));
         } else {
             ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, ahead ? min(2 * ahead, (int)(STREAM_RB2 / 1024u)) : (int)(STREAM_RB2 / 1024u)));
@@ -1195,7 +1282,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                                             , st_acc, st_last
+#endif
+            );
+        } else if (kind == 2) {
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif
@@ -1216,7 +1309,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         young = 0;
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
-        const bool early = more && kind_of(nxt.tile) == kind;
+        const bool early = more && (kind_of(nxt.tile) == 1) == (kind == 1);  // (the narrow kinds share a ring geometry)
         if (early) start_ring(nxt);
         STAMP(13);  // starting the next ring (before the barrier)
         lds_barrier();  // every wave's contributions are in gw
@@ -1326,7 +1419,7 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     }
     for (int b = 0; b < G; ++b) {
         std::vector<uint32_t> big, small;
-        for (uint32_t t : lists[b]) ((int64_t)t < h.num_tiles_a1 ? big : small).push_back(t);
+        for (uint32_t t : lists[b]) (h.stream_of_tile(t) != PSELL_A2 ? big : small).push_back(t);
         const size_t n = big.size() + small.size();
         size_t ib = 0, is = 0;
         for (size_t j = 0; j < n; ++j) {
@@ -1405,7 +1498,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, ll->d_xwin.p, nullptr, nullptr, nullptr};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, ll->d_xwin.p, nullptr, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
@@ -1452,11 +1545,13 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
     polee_ctx *ctx = ll->ctx;
     if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
     // (the pass is a single launch: one pair of events brackets both the kernel and the pass)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // (profiling: one pair of events brackets the dominant launch, a second pair the whole pass -- the x-window gather in
+    // front of it and the mixed stream's launch behind it)
+    hipEvent_t e0 = nullptr, e1 = nullptr, p0 = nullptr, p1 = nullptr;
     if (ll->profile) {
-        if (ll->prof_used + 2 > ll->prof_events.size()) {
+        if (ll->prof_used + 4 > ll->prof_events.size()) {
             if (ll->prof_events.size() >= 8192) POLEE_TRY(ll->profile_collect());
-            while (ll->prof_used + 2 > ll->prof_events.size()) {
+            while (ll->prof_used + 4 > ll->prof_events.size()) {
                 hipEvent_t a;
                 POLEE_HIP_TRY(ctx, hipEventCreate(&a));
                 ll->prof_events.push_back(a);
@@ -1464,20 +1559,26 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         }
         e0 = ll->prof_events[ll->prof_used];
         e1 = ll->prof_events[ll->prof_used + 1];
-        ll->prof_used += 2;
+        p0 = ll->prof_events[ll->prof_used + 2];
+        p1 = ll->prof_events[ll->prof_used + 3];
+        ll->prof_used += 4;
     }
     ll->cur_e0 = e0;
     ll->cur_e1 = e1;
+    if (p0) (void)hipEventRecord(p0, ctx->stream);
+    polee_status st;
     switch (K) {
-        case 1: return launch_k<1>(ll, d_x, d_g, d_lp);
-        case 2: return launch_k<2>(ll, d_x, d_g, d_lp);
-        case 3: return launch_k<3>(ll, d_x, d_g, d_lp);
-        case 4: return launch_k<4>(ll, d_x, d_g, d_lp);
-        case 5: return launch_k<5>(ll, d_x, d_g, d_lp);
-        case 6: return launch_k<6>(ll, d_x, d_g, d_lp);
-        case 7: return launch_k<7>(ll, d_x, d_g, d_lp);
-        default: return launch_k<8>(ll, d_x, d_g, d_lp);
+        case 1: st = launch_k<1>(ll, d_x, d_g, d_lp); break;
+        case 2: st = launch_k<2>(ll, d_x, d_g, d_lp); break;
+        case 3: st = launch_k<3>(ll, d_x, d_g, d_lp); break;
+        case 4: st = launch_k<4>(ll, d_x, d_g, d_lp); break;
+        case 5: st = launch_k<5>(ll, d_x, d_g, d_lp); break;
+        case 6: st = launch_k<6>(ll, d_x, d_g, d_lp); break;
+        case 7: st = launch_k<7>(ll, d_x, d_g, d_lp); break;
+        default: st = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
+    if (p1) (void)hipEventRecord(p1, ctx->stream);
+    return st;
 }
 
 // [rows][n] <-> [n][rows] re-layout between the host API (one expression vector per row)
@@ -1549,11 +1650,13 @@ polee_status polee_loglik::profile_collect()
 {
     if (prof_used == 0) return POLEE_OK;
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i + 1 < prof_used; i += 2) {
-        float ms = 0.f;
-        POLEE_HIP_TRY(ctx, hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
+    for (size_t i = 0; i + 3 < prof_used; i += 4) {
+        float ms = 0.f, pass_ms = 0.f;
+        // (a sample without uniform tiles never records the kernel pair: its pass is the mixed launch)
+        if (hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]) != hipSuccess) ms = 0.f;
+        POLEE_HIP_TRY(ctx, hipEventElapsedTime(&pass_ms, prof_events[i + 2], prof_events[i + 3]));
         prof_ms_total += ms;
-        prof_pass_ms_total += ms;
+        prof_pass_ms_total += pass_ms;
         ++prof_launches;
     }
     prof_used = 0;
@@ -1587,7 +1690,13 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     for (int64_t t = 0; t < h.num_tiles; ++t) {
         const double slice_bytes = 128.0 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
         double c = slice_bytes + 4096.0;
-        if (t >= h.num_tiles_a1) c *= 1.5;  // (the wide stream runs on two of the four waves)
+        const int st = h.stream_of_tile(t);
+        if (st == PSELL_A2) c *= 1.5;  // (the wide stream runs on two of the four waves)
+        if (st == PSELL_A1M) {  // (a masked slice costs the matrix cores what the dense slice of its union would)
+            double dense = 4096.0;
+            for (uint32_t sl = h.tile_slice[t]; sl < h.tile_slice[t + 1]; ++sl) dense += 256.0 * (h.slice_w[sl] + 1);
+            c = std::max(c, 0.5 * (c + dense));
+        }
         ll->tile_cost[(size_t)t] = (float)c;
     }
     // the waves of a uniform tile take contiguous blocks of its slices with about equal matrix-core work
@@ -1598,10 +1707,9 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         uint32_t *cut = &ll->tile_cut[(size_t)3 * t];
         cut[0] = cut[1] = cut[2] = s1;
         if (t >= h.num_tiles_a) continue;
-        const int nw = t < h.num_tiles_a1 ? 4 : 2;
+        const int nw = h.stream_of_tile(t) != PSELL_A2 ? 4 : 2;
         auto cost = [&](uint32_t sl) {
-            const uint32_t units = (h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK);
-            const int w = (int)(units / 2u) - 1 - (ll->has_ks ? 1 : 0);
+            const int w = h.slice_w[sl];
             return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
         };
         double total = 0.0;
@@ -1646,6 +1754,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     std::vector<uint32_t>().swap(h.dict);
     std::vector<float>().swap(h.slice_ks);
     std::vector<uint8_t>().swap(h.slice_flags);
+    std::vector<uint8_t>().swap(h.slice_w);
     std::vector<uint32_t>().swap(h.row_order);
     *out = ll;
     return POLEE_OK;
@@ -1821,8 +1930,8 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_empty_rows = h.empty_rows;
     info->max_row_nnz = h.max_row;
     info->max_tile_cols = h.max_tile_cols;
-    const int64_t tiles[3] = {h.num_tiles_a1, h.num_tiles_a - h.num_tiles_a1, h.num_tiles - h.num_tiles_a};
-    for (int i = 0; i < 3; ++i) {
+    const int64_t tiles[PSELL_NSTREAMS] = {h.num_tiles_a1, h.num_tiles_a1m - h.num_tiles_a1, h.num_tiles_a - h.num_tiles_a1m, h.num_tiles - h.num_tiles_a};
+    for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         info->stream_rows[i] = h.stream_rows[i];
         info->stream_nnz[i] = h.stream_nnz[i];
         info->stream_tiles[i] = tiles[i];

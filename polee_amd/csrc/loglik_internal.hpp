@@ -9,7 +9,7 @@
 //     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
 //     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
 //     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
-//   * Consecutive slices form a TILE (64 / 8 / 16 slices in streams A1 / A2 / B), the unit of work of one
+//   * Consecutive slices form a TILE (64 / 64 / 8 / 16 slices in streams A1 / A1M / A2 / B), the unit of work of one
 //     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
 //     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
 //     pass 128 entries).  Every tile's dictionary starts at a multiple of 4 entries (padded with
@@ -17,20 +17,27 @@
 //     by xwin_gather_kernel -- starts 16-byte aligned and reaches LDS by LDS-DMA like the slice stream.
 //   * The kernel accumulates the tile's gradient contributions in LDS (ds_add_f32) and flushes L*K
 //     values to HBM per tile.
-//   * Rows are split into three streams, each a contiguous range of tiles:
-//       A1, A2 = UNIFORM slices: all rows of a slice share one transcript set, stored once per slice
-//                (uint16 lcol[128] header + float val[w][64], 4 B per entry): whole 64-row slices of every
-//                run of identical rows, run remainders of >= 32 rows (zero padded), and UNION slices --
-//                the leftover rows of neighbouring sets packed under the union of their sets, with zeros
-//                where a row lacks a transcript (a zero adds nothing to a row sum or a gradient, exactly).
-//                A1 = sets of <= 16 transcripts, A2 = 17..32.  Tiles [0, num_tiles_a1) are A1,
-//                [num_tiles_a1, num_tiles_a) A2.  One persistent launch (loglik_stream_kernel) streams them.
-//       B      = rows with more than 32 transcripts (mixed slices, 6 B per entry): rare; the per-tile
-//                kernel loglik_psell_kernel takes them in a second, small launch.  That kernel also runs
-//                over the uniform slices on request (polee_debug_loglik_force_mixed): the independent second
-//                algorithm of the cross-check tests.
+//   * Rows are split into four streams, each a contiguous range of tiles (in this order):
+//       A1, A1M, A2 = UNIFORM slices: all rows of a slice are stored under ONE transcript set, kept once per slice.
+//         A1  (dense, sets of <= 16): uint16 lcol[128] header + float val[w][64], 4 B per entry: whole 64-row slices of
+//              every run of identical rows, run remainders of >= 32 rows (zero padded), and dense UNION slices -- leftover
+//              rows of neighbouring sets packed under the union of their sets with zeros where a row lacks a transcript
+//              (a zero adds nothing to a row sum or a gradient, exactly) -- when the union is (almost) full.
+//         A1M (MASKED, unions of <= 16): leftover rows whose sets differ -- any 64 rows whose union has <= 16 transcripts.
+//              Header: uint16 lcol[16] (0xffff past the union), at byte 128 uint16 mask[64] (bit t of mask[r]: fragment r
+//              is compatible with transcript t of the union); then float val[i][64], the i-th non-zero of fragment r at
+//              position r of row i, for i < the longest row of the slice.  Zeros cost no bytes: 4 B per non-zero + 4 B per
+//              fragment + padding to the slice's longest row -- never more than the dense union slice, and below CSR's
+//              8 B per non-zero + 4 B per fragment whatever the sets look like.  The kernel expands a fragment's values
+//              with its mask (rank = popcount of the lower bits) and runs the same matrix-core phases.
+//         A2  (dense, sets of 17..32): runs, remainders and union slices that are at least as small as the mixed form.
+//         One persistent launch (loglik_stream_kernel) streams all three.
+//       B     = MIXED slices (float val[w][64]; uint16 lcol[w][64], 6 B per entry): rows with more than 32 transcripts
+//              and the leftover rows that fit no uniform slice at a lower cost; the per-tile kernel loglik_psell_kernel
+//              takes them in a second launch.  That kernel also runs over the uniform slices on request
+//              (polee_debug_loglik_force_mixed): the independent second algorithm of the cross-check tests.
 //   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
-//     share one transcript set) and "continues" (the same set as the previous slice).  Runs of such
+//     are stored under one transcript set) and "continues" (the same set as the previous slice).  Runs of such
 //     slices -- the bulk of real and synthetic data, where many fragments fall into the same
 //     equivalence class -- keep their gradient contributions in registers.
 // HBM traffic per likelihood pass ~ 4.9 B/nnz at BASELINE's C2 (CSR: 8 B + row pointers), read once.
@@ -53,7 +60,10 @@ constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
 // A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
-constexpr uint32_t psell_row_pos(int stream, uint32_t t, uint32_t r) { return stream == 0 ? (r ^ (t & 3u)) : ((r + 4u * t) & 63u); }
+enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_B = 3, PSELL_NSTREAMS = 4 };  // streams, in tile order
+constexpr uint32_t psell_row_pos(int stream, uint32_t t, uint32_t r) { return stream == PSELL_A1 ? (r ^ (t & 3u)) : (stream == PSELL_A2 ? ((r + 4u * t) & 63u) : r); }
+constexpr uint16_t PSELL_NO_COL = 0xffffu;  // header entries of a masked slice past its union
+constexpr double PSELL_MIXED_BYTES_PER_NNZ = 6.6;  // what a leftover row costs in the mixed stream (6 B per entry + padding): a uniform slice must not cost more
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 
@@ -71,8 +81,10 @@ struct PsellHost {
     int64_t num_slices = 0, num_tiles = 0, padded_nnz = 0, empty_rows = 0;
     // stream A (tiles [0, num_tiles_a)): only slices whose 64 rows share one transcript set
     int64_t rows_a = 0, num_tiles_a = 0, num_slices_a = 0;
-    int64_t rows_a1 = 0, num_tiles_a1 = 0;
-    int64_t stream_rows[3] = {0, 0, 0}, stream_nnz[3] = {0, 0, 0}, stream_bytes[3] = {0, 0, 0};  // A1 = tiles [0, num_tiles_a1): sets of <= PSELL_NARROW_MAX transcripts
+    int64_t rows_a1 = 0, num_tiles_a1 = 0;    // A1 = tiles [0, num_tiles_a1): dense, sets of <= PSELL_NARROW_MAX transcripts
+    int64_t rows_a1m = 0, num_tiles_a1m = 0;  // A1M = tiles [num_tiles_a1, num_tiles_a1m): masked; A2 = [num_tiles_a1m, num_tiles_a)
+    int64_t stream_rows[PSELL_NSTREAMS] = {}, stream_nnz[PSELL_NSTREAMS] = {}, stream_bytes[PSELL_NSTREAMS] = {};
+    int stream_of_tile(int64_t t) const { return t < num_tiles_a1 ? PSELL_A1 : (t < num_tiles_a1m ? PSELL_A1M : (t < num_tiles_a ? PSELL_A2 : PSELL_B)); }
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t, default_init_allocator<uint8_t>> data;  // slice blocks (resize(n) leaves new bytes uninitialised; resize(n, 0) zeroes)
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units in bits 0..29, slice flags in bits 30..31
@@ -82,6 +94,7 @@ struct PsellHost {
     std::vector<uint32_t> dict;        // transcript ids (0-based)
     std::vector<uint32_t> big_tiles;   // tiles whose dictionary exceeds PSELL_TILE_COLS_TARGET (a fragment with > 256 transcripts)
     std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
+    std::vector<uint8_t> slice_w;      // [num_slices] transcripts of the slice's set (uniform streams) / longest row (mixed)
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
 };

@@ -111,8 +111,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 uint32_t h = 0x12345u, first = col[b];
                 for (uint64_t k = b; k < e; ++k) {
                     if (col[k] >= (uint64_t)n) err = 3;
+                    if (k > b && col[k] <= col[k - 1]) err = 4;  // (the union / mask packing below walks a row's ids in order)
                     h = mix32(h, col[k]);
-                    first = std::min(first, col[k]);
                 }
                 mr = std::max(mr, (int32_t)len);
                 keys[i] = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)std::min<uint64_t>(len, 255) << 32) | h;
@@ -124,6 +124,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (err == 1) return "row offsets are not monotone";
         if (err == 2) return "a fragment is compatible with more than 1024 transcripts";
         if (err == 3) return "transcript index out of range";
+        if (err == 4) return "the transcript ids of a fragment must be strictly ascending (sorted, no duplicates)";
         out.empty_rows = empties;
         out.max_row = max_row;
         if (out.empty_rows > 0) {  // drop the empty rows (stable)
@@ -144,15 +145,16 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     keys.clear();
     keys.shrink_to_fit();
 
-    // 1b. runs of rows with the same transcript set.  Rows are split into three streams, each a
-    // contiguous tile range processed by a differently specialised kernel launch:
-    //   A1: uniform slices (every valid row of a slice has the same transcript set), set size <= 18
-    //   A2: uniform slices, set size 19..28
-    //   B : everything else (short runs, small run remainders, very wide rows)
-    // A run of r rows contributes floor(r/64) whole slices to A, and its remainder as one more
-    // (zero-padded) uniform slice when the remainder is at least 32 rows.
-    std::vector<uint32_t> run_end;  // for stream A rows: index (in `rows`) one past the row's slice
-    std::vector<uint8_t> is_union;  // for stream A rows: the row's slice is a union slice
+    // 1b. runs of rows with the same transcript set, and the split into the four streams (loglik_internal.hpp):
+    //   A1 / A2: a run of r identical rows contributes floor(r / 64) whole slices, and its remainder as one more
+    //            (zero-padded) slice when the remainder is at least 32 rows;
+    //   the LEFTOVER rows (short runs, small remainders) are packed greedily, in the order of their first transcript,
+    //            into groups of up to 64 rows whose UNION has <= 16 (<= 32 for rows of 17..32) transcripts.  A group is
+    //            stored in the cheapest form: a dense union slice (A1 / A2), a masked slice (A1M; narrow class only) --
+    //            or, when neither is below what its rows cost in the mixed stream, not as a group at all;
+    //   B:       rows of more than 32 transcripts and the leftover rows of rejected groups.
+    std::vector<uint32_t> run_end;   // for the uniform streams' rows: 1 = the row's slice ends after it
+    std::vector<uint8_t> row_form;   // for the uniform streams' rows: 0 exact run, 1 dense union, 2 masked
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
@@ -163,8 +165,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         parallel_chunks(rows.size(), (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
             for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
         });
-        std::vector<uint32_t> ra1, ra2, rb, e1, e2;
-        std::vector<uint8_t> u1, u2;  // row belongs to a union slice
+        struct RowList {
+            std::vector<uint32_t> rows, ends;
+            std::vector<uint8_t> form;
+        };
+        RowList S1, S1M, S2;  // A1, A1M, A2
+        std::vector<uint32_t> rb;
         // (on several host threads: chunks of rows that start at a run's head, each with its own output lists, which are
         // then joined in chunk order -- the result does not depend on the number of threads)
         struct Part {
@@ -179,6 +185,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             pstart[p] = a;
         }
         std::vector<Part> parts(nparts);
+        static const int min_uniform = getenv("POLEE_PSELL_MIN_UNIFORM") ? atoi(getenv("POLEE_PSELL_MIN_UNIFORM")) : PSELL_MIN_UNIFORM_ROWS;
         parallel_chunks(nparts, 1, [&](size_t plo, size_t phi, unsigned) {
             for (size_t p = plo; p < phi; ++p) {
                 Part &P = parts[p];
@@ -190,7 +197,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     const size_t r = j - i;
                     const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
                     size_t take = (r / PSELL_LANES) * PSELL_LANES;
-                    if (r - take >= (size_t)PSELL_MIN_UNIFORM_ROWS) take = r;
+                    if (r - take >= (size_t)min_uniform) take = r;
                     if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
                     std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? P.ra1 : P.ra2;
                     std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? P.e1 : P.e2;
@@ -211,24 +218,29 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 n2 += P.ra2.size();
                 nb += P.rb.size();
             }
-            ra1.reserve(n1); e1.reserve(n1); ra2.reserve(n2); e2.reserve(n2); rb.reserve(nb);
+            S1.rows.reserve(n1); S1.ends.reserve(n1); S2.rows.reserve(n2); S2.ends.reserve(n2); rb.reserve(nb);
             for (Part &P : parts) {
-                ra1.insert(ra1.end(), P.ra1.begin(), P.ra1.end());
-                e1.insert(e1.end(), P.e1.begin(), P.e1.end());
-                ra2.insert(ra2.end(), P.ra2.begin(), P.ra2.end());
-                e2.insert(e2.end(), P.e2.begin(), P.e2.end());
+                S1.rows.insert(S1.rows.end(), P.ra1.begin(), P.ra1.end());
+                S1.ends.insert(S1.ends.end(), P.e1.begin(), P.e1.end());
+                S2.rows.insert(S2.rows.end(), P.ra2.begin(), P.ra2.end());
+                S2.ends.insert(S2.ends.end(), P.e2.begin(), P.e2.end());
                 rb.insert(rb.end(), P.rb.begin(), P.rb.end());
                 Part().ra1.swap(P.ra1);
             }
-            u1.assign(ra1.size(), 0);
-            u2.assign(ra2.size(), 0);
+            S1.form.assign(S1.rows.size(), 0);
+            S2.form.assign(S2.rows.size(), 0);
         }
-        // UNION slices: the leftover rows (runs and run remainders of < 32 rows) of neighbouring transcript sets are packed
-        // into uniform slices whose header is the UNION of their sets, rows holding zeros for the transcripts they are
-        // not compatible with (a zero adds nothing to a row sum and nothing to a gradient, exactly).  Rows are visited
-        // in the order of their first transcript; a row joins the open group while the union stays within the stream's
-        // set size, a misfit is deferred once; groups of fewer than PSELL_MIN_UNION_ROWS rows stay in stream B.
+        // Packing of the leftover rows.  Rows are visited in the order of their first transcript (then length, then set:
+        // equal sets stay neighbours); a row joins the open group while the union stays within the class's width and the
+        // group has fewer than 64 rows, a misfit is deferred once.  A closed group of rows with cnt_r non-zeros, union w,
+        // longest row M costs 256 (w + 1) bytes as a dense union slice, 256 (M + 1) as a masked slice (M <= w: never
+        // more), and about 6.6 sum(cnt_r) in the mixed stream; it takes the cheapest form, the dense one when masking
+        // would save less than `mask_gain` of its bytes (the masked form costs the kernel ~5 more vector instructions
+        // per transcript of the union).  So the layout's bytes per non-zero stay below CSR's for any sparsity pattern.
         static const bool no_union = getenv("POLEE_PSELL_NO_UNION") != nullptr;
+        static const bool no_mask = getenv("POLEE_PSELL_NO_MASK") != nullptr;
+        static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.15;
+        const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
             std::vector<uint64_t> k2(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;  // (columns ascend within a row)
@@ -240,9 +252,6 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             std::vector<uint32_t> keep_b;
             for (int cls = 0; cls < 2; ++cls) {  // narrow sets first, then the wide ones
                 const size_t cap = cls == 0 ? (size_t)PSELL_NARROW_MAX : (size_t)PSELL_WIDE_MAX;
-                std::vector<uint32_t> &dst = cls == 0 ? ra1 : ra2;
-                std::vector<uint32_t> &de = cls == 0 ? e1 : e2;
-                std::vector<uint8_t> &du = cls == 0 ? u1 : u2;
                 std::vector<uint32_t> pool;
                 for (uint32_t r : cand) {
                     const uint64_t len = rowptr[r + 1] - rowptr[r];
@@ -254,7 +263,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 // (chunks of 32 768 candidate rows are packed independently on several threads and joined in order: a
                 // group never spans two chunks, and the result does not depend on the number of threads)
                 struct UPart {
-                    std::vector<uint32_t> rows, ends, left;
+                    RowList dense, masked;
+                    std::vector<uint32_t> left;
                 };
                 const size_t UCH = (size_t)1 << 15;
                 const size_t nup = std::max<size_t>(1, (pool.size() + UCH - 1) / UCH);
@@ -264,10 +274,34 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     for (size_t up = ulo; up < uhi; ++up) {
                         UPart &U = uparts[up];
                         auto close_group = [&]() {
-                            if (group.size() >= (size_t)PSELL_MIN_UNION_ROWS) {
+                            if (group.empty()) return;
+                            size_t total = 0, longest = 0;
+                            for (uint32_t r : group) {
+                                const size_t c = (size_t)(rowptr[r + 1] - rowptr[r]);
+                                total += c;
+                                longest = std::max(longest, c);
+                            }
+                            const double dense_bytes = 256.0 * (double)(uni.size() + 1 + ks_rows);
+                            const double masked_bytes = cls == 0 && !no_mask ? 256.0 * (double)(longest + 1 + ks_rows) : 1e30;
+                            const double mixed_bytes = PSELL_MIXED_BYTES_PER_NNZ * (double)total;
+                            RowList *dst = nullptr;
+                            uint8_t form = 1;
+                            if (std::min(dense_bytes, masked_bytes) <= mixed_bytes || group.size() < (size_t)PSELL_MIN_UNION_ROWS) {
+                                if (masked_bytes < (1.0 - mask_gain) * dense_bytes) {
+                                    dst = &U.masked;
+                                    form = 2;
+                                } else if (dense_bytes <= mixed_bytes || masked_bytes > mixed_bytes) {
+                                    dst = &U.dense;
+                                } else {  // (the dense form is within mask_gain of the masked one but above the mixed cost)
+                                    dst = &U.masked;
+                                    form = 2;
+                                }
+                            }
+                            if (dst) {
                                 for (size_t q = 0; q < group.size(); ++q) {
-                                    U.rows.push_back(group[q]);
-                                    U.ends.push_back(q + 1 == group.size() ? 1u : 0u);
+                                    dst->rows.push_back(group[q]);
+                                    dst->ends.push_back(q + 1 == group.size() ? 1u : 0u);
+                                    dst->form.push_back(form);
                                 }
                             } else {
                                 U.left.insert(U.left.end(), group.begin(), group.end());
@@ -304,24 +338,51 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                         }
                     }
                 });
+                RowList &D = cls == 0 ? S1 : S2;
                 for (UPart &U : uparts) {
-                    dst.insert(dst.end(), U.rows.begin(), U.rows.end());
-                    de.insert(de.end(), U.ends.begin(), U.ends.end());
-                    du.insert(du.end(), U.rows.size(), (uint8_t)1);
+                    D.rows.insert(D.rows.end(), U.dense.rows.begin(), U.dense.rows.end());
+                    D.ends.insert(D.ends.end(), U.dense.ends.begin(), U.dense.ends.end());
+                    D.form.insert(D.form.end(), U.dense.form.begin(), U.dense.form.end());
+                    S1M.rows.insert(S1M.rows.end(), U.masked.rows.begin(), U.masked.rows.end());
+                    S1M.ends.insert(S1M.ends.end(), U.masked.ends.begin(), U.masked.ends.end());
+                    S1M.form.insert(S1M.form.end(), U.masked.form.begin(), U.masked.form.end());
                     keep_b.insert(keep_b.end(), U.left.begin(), U.left.end());
                 }
             }
             rb.swap(keep_b);
         }
-        out.rows_a1 = (int64_t)ra1.size();
-        out.rows_a = (int64_t)(ra1.size() + ra2.size());
-        rows.swap(ra1);
-        rows.insert(rows.end(), ra2.begin(), ra2.end());
+        // the mixed stream: rows in the order of their first transcript (small tile dictionaries), and inside every
+        // block of 1024 rows -- a tile's worth -- by descending length (little padding inside a slice)
+        if (!rb.empty()) {
+            std::vector<uint64_t> k2(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;
+            std::vector<uint32_t> idx(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) idx[q] = (uint32_t)q;
+            radix_sort_pairs(k2, idx);
+            std::vector<uint32_t> sorted(rb.size());
+            for (size_t q = 0; q < rb.size(); ++q) sorted[q] = rb[idx[q]];
+            rb.swap(sorted);
+            const size_t BL = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
+            parallel_chunks((rb.size() + BL - 1) / BL, 16, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t blk = lo; blk < hi; ++blk)
+                    std::stable_sort(rb.begin() + blk * BL, rb.begin() + std::min(rb.size(), (blk + 1) * BL), [&](uint32_t r1, uint32_t r2) {
+                        return rowptr[r1 + 1] - rowptr[r1] > rowptr[r2 + 1] - rowptr[r2];
+                    });
+            });
+        }
+        out.rows_a1 = (int64_t)S1.rows.size();
+        out.rows_a1m = out.rows_a1 + (int64_t)S1M.rows.size();
+        out.rows_a = out.rows_a1m + (int64_t)S2.rows.size();
+        rows.swap(S1.rows);
+        rows.insert(rows.end(), S1M.rows.begin(), S1M.rows.end());
+        rows.insert(rows.end(), S2.rows.begin(), S2.rows.end());
         rows.insert(rows.end(), rb.begin(), rb.end());
-        run_end.swap(e1);
-        run_end.insert(run_end.end(), e2.begin(), e2.end());
-        is_union.swap(u1);
-        is_union.insert(is_union.end(), u2.begin(), u2.end());
+        run_end.swap(S1.ends);
+        run_end.insert(run_end.end(), S1M.ends.begin(), S1M.ends.end());
+        run_end.insert(run_end.end(), S2.ends.begin(), S2.ends.end());
+        row_form.swap(S1.form);
+        row_form.insert(row_form.end(), S1M.form.begin(), S1M.form.end());
+        row_form.insert(row_form.end(), S2.form.begin(), S2.form.end());
     }
 
     lap("runs / stream split");
@@ -330,20 +391,20 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     // concatenated afterwards.  The cut points depend on the data only, not on the number of threads.
     struct Segment {
         size_t ra, rb;  // rows[ra, rb)
-        int stream;     // 0 = A1, 1 = A2, 2 = B
+        int stream;     // PSELL_A1, PSELL_A1M, PSELL_A2, PSELL_B
         PsellHost frag;
     };
     std::vector<Segment> segs;
     {
         static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
         const size_t SEG_ROWS = seg_env >= 64 ? seg_env : (size_t)1 << 18;  // (a few hundred segments at BASELINE's C2: enough for ~50 host threads)
-        const size_t bounds[4] = {0, (size_t)out.rows_a1, (size_t)out.rows_a, rows.size()};
-        for (int st = 0; st < 3; ++st) {
+        const size_t bounds[PSELL_NSTREAMS + 1] = {0, (size_t)out.rows_a1, (size_t)out.rows_a1m, (size_t)out.rows_a, rows.size()};
+        for (int st = 0; st < PSELL_NSTREAMS; ++st) {
             size_t a = bounds[st];
             while (a < bounds[st + 1]) {
                 size_t e = std::min(bounds[st + 1], a + SEG_ROWS);
                 if (e < bounds[st + 1]) {
-                    if (st < 2) {
+                    if (st != PSELL_B) {
                         while (e < bounds[st + 1] && !run_end[e - 1]) ++e;  // uniform streams: end on a closed slice
                     } else {  // mixed stream: whole tiles of 16 slices
                         const size_t tile_rows = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
@@ -385,15 +446,17 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
     std::vector<uint32_t> pattern, utmp;  // transcript set of the slice being closed (uniform streams)
     bool prev_uniform = false;
-    bool slice_union = false;  // the slice being formed is a union slice
+    int slice_form = 0;  // the slice being formed: 0 rows of one set, 1 dense union, 2 masked
+    const bool uniform_stream = cur_stream != PSELL_B;
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
-        uint32_t w = 0;
-        for (uint32_t r : slice_rows) w = std::max<uint32_t>(w, (uint32_t)(rowptr[r + 1] - rowptr[r]));
-        if (cur_stream < 2) {  // the slice's transcript set: its rows' common set, or their union
+        uint32_t w = 0, longest = 0;
+        for (uint32_t r : slice_rows) longest = std::max<uint32_t>(longest, (uint32_t)(rowptr[r + 1] - rowptr[r]));
+        w = longest;
+        if (uniform_stream) {  // the slice's transcript set: its rows' common set, or their union
             const uint32_t r0 = slice_rows[0];
             pattern.assign(col + rowptr[r0], col + rowptr[r0 + 1]);
-            if (slice_union) {
+            if (slice_form != 0) {
                 for (size_t lane = 1; lane < slice_rows.size(); ++lane) {
                     const uint32_t r = slice_rows[lane];
                     utmp.resize(pattern.size() + (size_t)(rowptr[r + 1] - rowptr[r]));
@@ -404,8 +467,32 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             w = (uint32_t)pattern.size();
         }
         const size_t base = out.data.size();
-        if (cur_stream < 2) {
-            // uniform streams: the 64 fragments share one transcript set, so the column ids are stored once:
+        uint32_t stored_rows = w;  // rows of 64 values the slice stores
+        if (cur_stream == PSELL_A1M) {
+            // masked slice: uint16 lcol[16] (PSELL_NO_COL past the union); at byte 128 uint16 mask[64]; then
+            // float val[i][64] = the i-th non-zero of the fragment in lane r, i < longest row (+ the ks row)
+            stored_rows = longest;
+            out.data.resize(base + 256 + (size_t)longest * 256 + (ks ? 256 : 0), 0);
+            uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
+            uint16_t *mask = hdr + 64;
+            float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
+            for (uint32_t t = 0; t < (uint32_t)PSELL_NARROW_MAX; ++t) hdr[t] = t < w ? col_local[pattern[t]] : PSELL_NO_COL;
+            for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
+                const uint64_t b = rowptr[slice_rows[lane]], e = rowptr[slice_rows[lane] + 1];
+                uint32_t t = 0, mk = 0;
+                for (uint64_t k = b; k < e; ++k) {
+                    while (pattern[t] != col[k]) ++t;
+                    mk |= 1u << t;
+                    vals[(size_t)(k - b) * 64 + lane] = val[k];
+                }
+                mask[lane] = (uint16_t)mk;
+            }
+            if (ks) {
+                float *kr = reinterpret_cast<float *>(out.data.data() + base + 256 + (size_t)longest * 256);
+                for (size_t lane = 0; lane < slice_rows.size(); ++lane) kr[lane] = (float)ks[slice_rows[lane]];
+            }
+        } else if (uniform_stream) {
+            // dense uniform slice: the 64 fragments share one transcript set, so the column ids are stored once:
             //   uint16 lcol[128] (256-byte header, w used) ; float val[w][64] (rows rotated, see below)
             // with row multiplicities (factored likelihood) a last row float ks[64] follows, so that they reach the
             // kernel through the same stream as the values
@@ -420,7 +507,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
                 const uint64_t b = rowptr[slice_rows[lane]], e = rowptr[slice_rows[lane] + 1];
                 // element r of row t sits at position psell_row_pos(stream, t, r): bank-conflict-free operand reads for the MFMA phases
-                if (!slice_union) {
+                if (slice_form == 0) {
                     for (uint32_t t = 0; t < w; ++t) vals[(size_t)t * 64 + psell_row_pos(cur_stream, t, (uint32_t)lane)] = val[b + t];
                 } else {  // the row's entries at the positions of their transcripts in the union, zeros elsewhere
                     uint32_t t = 0;
@@ -453,10 +540,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.row_order.push_back(valid ? slice_rows[lane] : 0xffffffffu);
             if (ks) out.slice_ks.push_back(valid ? (float)ks[slice_rows[lane]] : 0.0f);
         }
-        // flags: bit0 = all 64 lanes hold rows with one and the same transcript set ("uniform"),
+        // flags: bit0 = all 64 lanes are stored under one transcript set ("uniform"),
         //        bit1 = uniform and the same set as the previous slice of this tile ("continues")
         uint8_t flags = 0;
-        if (cur_stream < 2) {
+        if (uniform_stream) {
             flags |= 1;
             if (prev_uniform && tile_nslices > 0 && prev_pattern == pattern) flags |= 2;
             prev_pattern = pattern;
@@ -477,18 +564,19 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             prev_uniform = uni;
         }
         out.slice_flags.push_back(flags);
+        out.slice_w.push_back((uint8_t)std::min<uint32_t>(w, 255));
         {
             const int st = cur_stream;
             out.stream_rows[st] += (int64_t)slice_rows.size();
             for (uint32_t r : slice_rows) out.stream_nnz[st] += (int64_t)(rowptr[r + 1] - rowptr[r]);
             out.stream_bytes[st] += (int64_t)(out.data.size() - base);
         }
-        out.padded_nnz += (int64_t)w * 64;
+        out.padded_nnz += (int64_t)stored_rows * 64;
         out.slice_off.push_back((uint32_t)(out.data.size() / 128));
         ++out.num_slices;
         ++tile_nslices;
         slice_rows.clear();
-        slice_union = false;
+        slice_form = 0;
     };
     auto close_tile = [&]() {
         if (tile_nslices == 0) return;
@@ -525,13 +613,13 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
         slice_rows.push_back(r);
-        if (cur_stream < 2 && is_union[ri]) slice_union = true;
-        const bool boundary = cur_stream < 2 ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
+        if (uniform_stream) slice_form = std::max<int>(slice_form, row_form[ri]);
+        const bool boundary = uniform_stream ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
         if (boundary) {
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
-            const uint32_t cap = cur_stream == 0 ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
-                                 : cur_stream == 1 ? (uint32_t)a2cap : PSELL_TILE_SLICES_B;
+            const uint32_t cap = cur_stream == PSELL_A1 || cur_stream == PSELL_A1M ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
+                                 : cur_stream == PSELL_A2 ? (uint32_t)a2cap : PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }
     }
@@ -570,22 +658,25 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.tile_cols.reserve(tot_tiles);
         out.dict.reserve(tot_dict);
         out.slice_flags.reserve(tot_slices);
+        out.slice_w.reserve(tot_slices);
         out.row_order.reserve(tot_slices * 64);
         if (ks) out.slice_ks.reserve(tot_slices * 64);
         std::vector<size_t> data_base(segs.size());
         size_t dbase = 0;
         int last_stream = 0;
+        auto stream_ends = [&](int st) {  // stream `st` ends at the current tile / slice count
+            if (st == PSELL_A1) out.num_tiles_a1 = out.num_tiles;
+            if (st == PSELL_A1M) out.num_tiles_a1m = out.num_tiles;
+            if (st == PSELL_A2) {
+                out.num_tiles_a = out.num_tiles;
+                out.num_slices_a = out.num_slices;
+            }
+        };
         for (size_t si = 0; si < segs.size(); ++si) {
             Segment &sg = segs[si];
             PsellHost &f = sg.frag;
             // stream boundaries in tile / slice numbering
-            for (; last_stream < sg.stream; ++last_stream) {
-                if (last_stream == 0) out.num_tiles_a1 = out.num_tiles;
-                if (last_stream == 1) {
-                    out.num_tiles_a = out.num_tiles;
-                    out.num_slices_a = out.num_slices;
-                }
-            }
+            for (; last_stream < sg.stream; ++last_stream) stream_ends(last_stream);
             data_base[si] = dbase;
             const uint32_t unit_base = (uint32_t)(dbase / 128), slice_base = (uint32_t)out.num_slices,
                            dict_base = (uint32_t)out.dict.size(), tile_base = (uint32_t)out.num_tiles;
@@ -596,10 +687,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.dict.insert(out.dict.end(), f.dict.begin(), f.dict.end());
             out.tile_cols.insert(out.tile_cols.end(), f.tile_cols.begin(), f.tile_cols.end());
             out.slice_flags.insert(out.slice_flags.end(), f.slice_flags.begin(), f.slice_flags.end());
+            out.slice_w.insert(out.slice_w.end(), f.slice_w.begin(), f.slice_w.end());
             out.row_order.insert(out.row_order.end(), f.row_order.begin(), f.row_order.end());
             if (ks) out.slice_ks.insert(out.slice_ks.end(), f.slice_ks.begin(), f.slice_ks.end());
             for (uint32_t bt : f.big_tiles) out.big_tiles.push_back(bt + tile_base);
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < PSELL_NSTREAMS; ++q) {
                 out.stream_rows[q] += f.stream_rows[q];
                 out.stream_nnz[q] += f.stream_nnz[q];
                 out.stream_bytes[q] += f.stream_bytes[q];
@@ -610,13 +702,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.num_tiles += f.num_tiles;
             dbase += f.data.size();
         }
-        for (; last_stream < 2; ++last_stream) {
-            if (last_stream == 0) out.num_tiles_a1 = out.num_tiles;
-            if (last_stream == 1) {
-                out.num_tiles_a = out.num_tiles;
-                out.num_slices_a = out.num_slices;
-            }
-        }
+        for (; last_stream < PSELL_B; ++last_stream) stream_ends(last_stream);
         // the bulk copy in parallel
         parallel_chunks(segs.size(), 1, [&](size_t lo, size_t hi, unsigned) {
             for (size_t si = lo; si < hi; ++si) {

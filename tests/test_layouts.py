@@ -141,7 +141,8 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
     out = dict(num_slices=v.num_slices, num_tiles=v.num_tiles, padded_nnz=v.padded_nnz, nnz=v.nnz,
                empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz,
-               num_tiles_a=v.num_tiles_a, num_tiles_a1=v.num_tiles_a1)
+               num_tiles_a=v.num_tiles_a, num_tiles_a1=v.num_tiles_a1, num_tiles_a1m=v.num_tiles_a1m)
+    out["slice_w"] = np.ctypeslib.as_array(v.slice_w, shape=(v.num_slices,)).copy()
     out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
     raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
     out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
@@ -168,9 +169,34 @@ def _emulate_psell(ps, x, n):
         for s in range(ps["tile_slice"][t], ps["tile_slice"][t + 1]):
             off = int(ps["slice_off"][s]) * 128
             nbytes = int(ps["slice_off"][s + 1]) * 128 - off
-            if t < ps["num_tiles_a"]:  # compact uniform slice: one column-id header, then the values
-                w = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
+            if ps["num_tiles_a1"] <= t < ps["num_tiles_a1m"]:
+                # masked uniform slice: uint16 lcol[16] (0xffff past the union), uint16 mask[64] at byte 128, then
+                # val[i][r] = the i-th non-zero of the fragment in lane r
+                nrows = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
                 assert ps["slice_flags"][s] & 1
+                hdr = data[off:off + 32].view(np.uint16).astype(np.int64)
+                w = int((hdr != 0xFFFF).sum())
+                assert w == ps["slice_w"][s] and (hdr[:w] != 0xFFFF).all() and 1 <= w <= 16
+                mask = data[off + 128:off + 256].view(np.uint16).astype(np.int64)
+                packed = data[off + 256:off + 256 + nrows * 256].view(np.float32).reshape(nrows, 64)
+                if ps["ks"] is not None:
+                    np.testing.assert_array_equal(data[off + 256 + nrows * 256:off + 512 + nrows * 256].view(np.float32),
+                                                  ps["ks"][s * 64:(s + 1) * 64])
+                assert (mask >> w == 0).all()
+                cnt = np.array([bin(int(mk)).count("1") for mk in mask])
+                assert cnt.max() == nrows  # padded to the slice's longest fragment, no further
+                vals = np.zeros((w, 64), np.float32)
+                for r in range(64):
+                    i = 0
+                    for tt in range(w):
+                        if (mask[r] >> tt) & 1:
+                            vals[tt, r] = packed[i, r]
+                            i += 1
+                    assert (packed[i:, r] == 0).all()
+                cols = np.repeat(hdr[:w, None], 64, axis=1)
+            elif t < ps["num_tiles_a"]:  # compact uniform slice: one column-id header, then the values
+                w = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
+                assert ps["slice_flags"][s] & 1 and w == ps["slice_w"][s]
                 if ps["ks"] is not None:  # the multiplicities also travel as the slice's last row
                     np.testing.assert_array_equal(data[off + 256 + w * 256:off + 512 + w * 256].view(np.float32),
                                                   ps["ks"][s * 64:(s + 1) * 64])
@@ -180,6 +206,7 @@ def _emulate_psell(ps, x, n):
                 # element r of row t is stored at position r ^ (t & 3) (stream A1) / (r + 4 t) & 63 (stream A2)
                 r64 = np.arange(64)
                 if t < ps["num_tiles_a1"]:
+                    assert w <= 16
                     vals = np.stack([rot[tt][r64 ^ (tt & 3)] for tt in range(w)]) if w else rot
                 else:
                     vals = np.stack([rot[tt][(r64 + 4 * tt) & 63] for tt in range(w)]) if w else rot

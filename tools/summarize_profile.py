@@ -38,7 +38,8 @@ if dom:
                "WRITE_SIZE_KiB": c.get("WRITE_SIZE"), "correction": "fetch x2 (gfx950 wide coalesced loads), write x1",
                "source": "profiles/%s_pmc.json" % tag,
                # the capture is valid for this workload only (bench.py emits `traffic` when these match its run)
-               "draws": cfg.get("draws"), "tree": cfg.get("tree"), "nnz": cfg.get("nnz")},
+               "draws": cfg.get("draws"), "tree": cfg.get("tree"), "nnz": cfg.get("nnz"),
+               "source_id": (bench or {}).get("detail", {}).get("source_id")},
               open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8
     lines += ["", "## Dominant kernel `%s`" % dom[0][:60], "",

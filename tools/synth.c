@@ -10,6 +10,11 @@
  * draws a gene with probability ~ abundance x total length x isoforms^gamma (gamma is solved
  * so that the MEAN nnz per fragment hits the target), then one of the gene's patterns, and
  * with probability 0.05 one extra isoform of the neighbouring gene.
+ * Set diversity (how many fragments share a transcript set; synth_set_diversity): `dropout` p drops every entry of a
+ * fragment but its first independently with probability p, so that fragments of a gene stop sharing a handful of sets;
+ * `literal` = SURVEY 8(d)'s literal wording, every fragment draws its OWN random non-empty subset of its gene's isoforms
+ * (each isoform with probability 0.75) instead of one of the gene's <= 12 patterns.  Both off: the stream of random
+ * numbers, hence the sample, is the one of rounds 1-2.
  * X_ij = LogNormal(0,1)/efflen_j clipped to [1e-12 (MIN_FRAG_PROB, constants.jl:45), 1e-3].
  * Fragments are emitted in gene (= genomic) order, as src/rnaseq_sample.jl:399-419 produces
  * them, with no empty rows.  Output is Xt (CSR of X): tcolptr u64 [m+1] 1-based, trowval u32
@@ -59,6 +64,8 @@ typedef struct {
     gene_t *genes;
     float *efflens;
     double gamma, mean_nnz;
+    double dropout; /* per-entry dropout probability (first entry kept) */
+    int literal;    /* every fragment draws its own subset of the gene's isoforms */
 } synth_t;
 
 static double mean_nnz_for(const synth_t *s, const double *base, double gamma, double *w)
@@ -154,6 +161,19 @@ static inline int gen_fragment(const synth_t *s, int g, rng_t *r, uint32_t *cols
     int k = 0;
     while (k < ge->npat - 1 && u > ge->pat_cum[k]) ++k;
     uint32_t mask = ge->pat_mask[k];
+    if (s->literal) {
+        mask = 0;
+        for (int i = 0; i < ge->niso; ++i) if (rng_unif(r) < 0.75) mask |= 1u << i;
+        if (!mask) mask = 1u << (rng_next(r) % ge->niso);
+    }
+    if (s->dropout > 0.0) {
+        int first = 1;
+        for (int i = 0; i < ge->niso; ++i)
+            if (mask & (1u << i)) {
+                if (!first && rng_unif(r) < s->dropout) mask &= ~(1u << i);
+                first = 0;
+            }
+    }
     int cnt = 0;
     int extra = -1;
     if (rng_unif(r) < 0.05 && s->G > 1) {
@@ -213,6 +233,8 @@ void synth_fill(synth_t *s, const uint64_t *tcolptr, uint32_t *trowval, float *t
     memcpy(efflens, s->efflens, sizeof(float) * s->n);
 }
 
+/* call before synth_count */
+void synth_set_diversity(synth_t *s, double dropout, int literal) { s->dropout = dropout; s->literal = literal; }
 int32_t synth_num_genes(const synth_t *s) { return s->G; }
 double synth_mean_nnz(const synth_t *s) { return s->mean_nnz; }
 double synth_gamma(const synth_t *s) { return s->gamma; }

@@ -29,10 +29,14 @@ def lib():
     return _lib
 
 
-def make_sample(n, m, mean_nnz=8.0, seed=123456789):
-    """Returns dict(m, n, nnz, tcolptr u64[m+1], trowval u32, tnzval f32, effective_lengths f32[n], gene i32[n])."""
+def make_sample(n, m, mean_nnz=8.0, seed=123456789, dropout=0.0, literal=False):
+    """Returns dict(m, n, nnz, tcolptr u64[m+1], trowval u32, tnzval f32, effective_lengths f32[n], gene i32[n]).
+    dropout / literal: set diversity (see synth.c) -- per-entry dropout probability; every fragment its own random subset
+    of its gene's isoforms (SURVEY 8(d)'s literal wording) instead of one of the gene's <= 12 patterns."""
     L = lib()
     h = C.c_void_p(L.synth_create(C.c_int64(n), C.c_int64(m), C.c_double(mean_nnz), C.c_uint64(seed)))
+    if dropout or literal:
+        L.synth_set_diversity(h, C.c_double(dropout), C.c_int(1 if literal else 0))
     tcolptr = np.zeros(m + 1, np.uint64)
     nnz = L.synth_count(h, tcolptr.ctypes.data_as(C.c_void_p))
     trowval = np.empty(nnz, np.uint32)
@@ -105,3 +109,33 @@ def make_tree(gene, seed=1, kind="hclust"):
             stack.append(("t", lo, cut, me)); stack.append(("t", cut, hi, me))
     assert idx == 2 * n - 1
     return parents, js
+
+
+def tile_fixture(reps, golden_dir=None):
+    """REAL-STRUCTURE workload: the reference's likelihood-matrix fixture (tests/golden, m = 19 743 fragments x n = 313
+    transcripts, 42 775 non-zeros, 496 distinct transcript sets) tiled block-diagonally `reps` times -- reps = 639 gives
+    n ~ 200 k, m ~ 12.6 M with the real distribution of set sizes and run lengths.  Same dict as make_sample (gene =
+    one pseudo-gene per 4 transcripts of a block, only used to build a tree)."""
+    import scipy.sparse as sp
+    g = golden_dir or os.path.join(os.path.dirname(_HERE), "tests", "golden")
+    d = np.load(os.path.join(g, "mBr_M_6w_1.likelihood-matrix.npz"))
+    m0, n0 = int(d["m"].item()), int(d["n"].item())
+    X = sp.csc_matrix((d["nzval"].astype(np.float32), d["rowval"].astype(np.int64) - 1, d["colptr"].astype(np.int64) - 1),
+                      shape=(m0, n0)).tocsr()
+    X.sort_indices()
+    nnz0 = X.nnz
+    m, n = m0 * reps, n0 * reps
+    ptr0 = X.indptr.astype(np.uint64)
+    tcolptr = np.empty(m + 1, np.uint64)
+    tcolptr[0] = 1
+    trowval = np.empty(nnz0 * reps, np.uint32)
+    tnzval = np.empty(nnz0 * reps, np.float32)
+    idx0 = X.indices.astype(np.uint32) + 1
+    for b in range(reps):
+        tcolptr[1 + b * m0:1 + (b + 1) * m0] = ptr0[1:] + np.uint64(b * nnz0 + 1)
+        trowval[b * nnz0:(b + 1) * nnz0] = idx0 + np.uint32(b * n0)
+        tnzval[b * nnz0:(b + 1) * nnz0] = X.data
+    eff = np.tile(d["effective_lengths"].astype(np.float32), reps)
+    gene = (np.arange(n) // 4).astype(np.int32)
+    return dict(m=m, n=n, nnz=nnz0 * reps, tcolptr=tcolptr, trowval=trowval, tnzval=tnzval, effective_lengths=eff,
+                gene=gene, num_genes=int(gene[-1]) + 1, gamma=0.0)
