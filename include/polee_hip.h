@@ -138,13 +138,16 @@ typedef struct {
     int64_t num_empty_rows;  /* fragments with no compatible transcript (skipped)       */
     int32_t max_row_nnz;
     int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
-    /* the four row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):            */
-    /* [0] dense uniform slices, sets of <= 16 transcripts; [1] masked uniform slices, unions of <= 16 */
-    /* (fragments whose sets differ); [2] dense uniform, 17..32; [3] mixed slices: everything else     */
-    int64_t stream_rows[4];  /* fragments                                               */
-    int64_t stream_nnz[4];   /* non-zeros of X                                          */
-    int64_t stream_tiles[4]; /* tiles (workgroup-sized units of work)                   */
-    int64_t stream_bytes_hbm[4]; /* bytes of the slice stream a pass reads                */
+    /* the six row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp; entries 6, 7   */
+    /* are reserved): [0] dense uniform slices, sets of <= 16 transcripts; [1] masked uniform slices,   */
+    /* unions of <= 16 (fragments whose sets differ); [2] dense uniform, 17..32; [3] masked uniform,    */
+    /* unions of 17..32; [4] mixed slices of unrelated fragments of <= 15 transcripts -- [0..4] are one */
+    /* persistent launch; [5] mixed slices of longer fragments (more than 32 transcripts, as a rule): a */
+    /* second launch                                                                                    */
+    int64_t stream_rows[8];  /* fragments                                               */
+    int64_t stream_nnz[8];   /* non-zeros of X                                          */
+    int64_t stream_tiles[8]; /* tiles (workgroup-sized units of work)                   */
+    int64_t stream_bytes_hbm[8]; /* bytes of the slice stream a pass reads                */
     int64_t dict_entries;    /* entries of all tile dictionaries: x is gathered into, and the gradient flushed */
                              /* from, one window of dict_entries x K floats per pass                           */
 } polee_loglik_info;

@@ -37,11 +37,19 @@ typedef struct {
                                 /*   uint16 lcol[128] (w used); float val[w][64]           */
     int64_t num_tiles_a1;       /* tiles [0, num_tiles_a1): dense, transcript sets of <= 16 */
     int64_t num_tiles_a1m;      /* tiles [num_tiles_a1, num_tiles_a1m): MASKED slices:      */
-                                /*   uint16 lcol[16] (0xffff past the union); at byte 128   */
-                                /*   uint16 mask[64]; float val[i][64] = i-th non-zero of   */
-                                /*   the lane's fragment; [num_tiles_a1m, num_tiles_a): dense, 17..32 */
+                                /*   uint32 hw[64]: low half = mask of the lane's fragment, */
+                                /*   high half (lanes < 16) = id of that transcript of the  */
+                                /*   union, 0x8000 past it; float val[i][64] = i-th non-zero */
+                                /*   of the lane's fragment                                 */
+    int64_t num_tiles_a2;       /* [num_tiles_a1m, num_tiles_a2): dense, 17..32;            */
+                                /* [num_tiles_a2, num_tiles_a): MASKED, unions of 17..32:   */
+                                /*   two header rows hw[2][64] (mask bits 0..15 / 16..31,   */
+                                /*   ids of transcripts 0..15 / 16..31)                     */
     const uint8_t *slice_w;     /* [num_slices] transcripts of the slice's set / longest row (mixed) */
-    int64_t stream_rows[4], stream_nnz[4], stream_bytes[4]; /* as in polee_loglik_info */
+    int64_t num_tiles_s;        /* [num_tiles_a, num_tiles_s): mixed slices of fragments of <= 15 transcripts (with
+                                   multiplicities a row float ks[64] follows at the next multiple of 256 bytes):
+                                   tiles [0, num_tiles_s) are the persistent launch's share                      */
+    int64_t stream_rows[8], stream_nnz[8], stream_bytes[8]; /* as in polee_loglik_info */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

@@ -54,8 +54,8 @@ class LoglikInfo(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int64), ("nnz", C.c_int64), ("num_slices", C.c_int64),
                 ("num_tiles", C.c_int64), ("padded_nnz", C.c_int64), ("device_bytes", C.c_int64),
                 ("stream_bytes", C.c_int64), ("num_empty_rows", C.c_int64), ("max_row_nnz", C.c_int32),
-                ("max_tile_cols", C.c_int32), ("stream_rows", C.c_int64 * 4), ("stream_nnz", C.c_int64 * 4),
-                ("stream_tiles", C.c_int64 * 4), ("stream_bytes_hbm", C.c_int64 * 4), ("dict_entries", C.c_int64)]
+                ("max_tile_cols", C.c_int32), ("stream_rows", C.c_int64 * 8), ("stream_nnz", C.c_int64 * 8),
+                ("stream_tiles", C.c_int64 * 8), ("stream_bytes_hbm", C.c_int64 * 8), ("dict_entries", C.c_int64)]
 
 
 class PsellView(C.Structure):
@@ -64,8 +64,8 @@ class PsellView(C.Structure):
                 ("data_bytes", C.c_int64), ("dict_len", C.c_int64), ("max_row_nnz", C.c_int32),
                 ("max_tile_cols", C.c_int32), ("data", u8p), ("slice_off", u32p), ("tile_slice", u32p),
                 ("tile_dict", u32p), ("dict", u32p), ("row_order", u32p), ("slice_ks", f32p), ("slice_flags", u8p),
-                ("num_tiles_a", C.c_int64), ("num_tiles_a1", C.c_int64), ("num_tiles_a1m", C.c_int64), ("slice_w", u8p),
-                ("stream_rows", C.c_int64 * 4), ("stream_nnz", C.c_int64 * 4), ("stream_bytes", C.c_int64 * 4)]
+                ("num_tiles_a", C.c_int64), ("num_tiles_a1", C.c_int64), ("num_tiles_a1m", C.c_int64), ("num_tiles_a2", C.c_int64), ("slice_w", u8p), ("num_tiles_s", C.c_int64),
+                ("stream_rows", C.c_int64 * 8), ("stream_nnz", C.c_int64 * 8), ("stream_bytes", C.c_int64 * 8)]
 
 
 def lib():

@@ -75,8 +75,11 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->num_tiles_a = h.num_tiles_a;
     v->num_tiles_a1 = h.num_tiles_a1;
     v->num_tiles_a1m = h.num_tiles_a1m;
+    v->num_tiles_a2 = h.num_tiles_a2;
+    v->num_tiles_s = h.num_tiles_s;
     v->slice_w = h.slice_w.data();
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) v->stream_rows[i] = v->stream_nnz[i] = v->stream_bytes[i] = 0;
+    for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         v->stream_rows[i] = h.stream_rows[i];
         v->stream_nnz[i] = h.stream_nnz[i];
         v->stream_bytes[i] = h.stream_bytes[i];

@@ -114,8 +114,9 @@ struct PsellArgs {
     int lcap;
     int tiles_a;  // tiles [0, tiles_a) use the compact uniform slice layouts
     // the persistent streaming kernel
-    int tiles_a1;           // tiles [0, tiles_a1): stream A1 (dense narrow), [tiles_a1, tiles_a1m): A1M (masked), [tiles_a1m, tiles_a): A2
-    int tiles_a1m;
+    int tiles_a1;           // tiles [0, tiles_a1): stream A1 (dense narrow), [tiles_a1, tiles_a1m): A1M (masked narrow),
+    int tiles_a1m, tiles_a2;  // [tiles_a1m, tiles_a2): A2 (dense wide), [tiles_a2, tiles_a): A2M (masked wide)
+    int tiles_s;              // [tiles_a, tiles_s): BN (mixed narrow); the persistent launch's share ends here
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
@@ -152,31 +153,37 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 #pragma unroll
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
 
-    const int stream = tile < A.tiles_a1 ? PSELL_A1 : (tile < A.tiles_a1m ? PSELL_A1M : (tile < A.tiles_a ? PSELL_A2 : PSELL_B));
+    const int stream = tile < A.tiles_a1 ? PSELL_A1 : (tile < A.tiles_a1m ? PSELL_A1M : (tile < A.tiles_a2 ? PSELL_A2 : (tile < A.tiles_a ? PSELL_A2M : (tile < A.tiles_s ? PSELL_BN : PSELL_B))));
     for (uint32_t s = s0 + wave; s < s1; s += 4) {
         const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
         const uint32_t units = (slice_off[s + 1] & PSELL_OFF_MASK) - off;
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
-        // masked slices: uint16 lcol[16], uint16 mask[64] at byte 128, then float val[i][64] = the lane's i-th non-zero;
+        // masked slices: one (A1M) or two (A2M) rows of uint32 hw[64] (low half: 16 bits of the lane's mask, high half:
+        // transcript ids), then float val[i][64] = the lane's i-th non-zero;
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
-        const int nrows = compact ? (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0) : (int)(units / 3u);  // (+ a ks row when factored)
-        const bool masked = stream == PSELL_A1M;
+        const bool masked = stream == PSELL_A1M || stream == PSELL_A2M;
+        const int hrows = stream == PSELL_A2M ? 2 : 1;
+        const int nrows = compact ? (int)(units / 2u) - hrows - (HAS_KS ? 1 : 0)  // (+ a ks row when factored: uniform streams and BN)
+                                  : (int)((units - (HAS_KS && stream == PSELL_BN ? 2u : 0u)) / 3u);
         const uint16_t *hdr = reinterpret_cast<const uint16_t *>(data + (size_t)off * 128);
         int w = nrows;
         uint32_t mk = 0;
+        auto hdr_id = [&](int t) -> uint16_t { return hdr[128 * (t >> 4) + 2 * (t & 15) + 1]; };  // (masked slices)
         if (masked) {
             w = 0;
-            while (w < PSELL_NARROW_MAX && hdr[w] != PSELL_NO_COL) ++w;
-            mk = hdr[64 + lane];
+            while (w < 16 * hrows && hdr_id(w) != PSELL_NO_COL) ++w;
+            mk = hdr[2 * lane];
+            if (hrows == 2) mk |= (uint32_t)hdr[128 + 2 * lane] << 16;
         }
         // (compact slices store element r of row t at position psell_row_pos(stream, t, r) of the row)
-        const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 : 0));
+        const float *vbase = reinterpret_cast<const float *>(data + (size_t)off * 128 + (compact ? 256 * hrows : 0));
         auto vat = [&](int t) -> float {
             if (masked) return (mk >> t) & 1u ? vbase[__popc(mk & ((1u << t) - 1u)) * 64 + lane] : 0.0f;
             return vbase[t * 64 + (compact ? (int)psell_row_pos(stream, (uint32_t)t, (uint32_t)lane) : lane)];
         };
         const uint16_t *cols = compact ? hdr : reinterpret_cast<const uint16_t *>(data + (size_t)off * 128 + (size_t)w * 256) + lane;
         const int cstride = compact ? 1 : 64;
+        auto cat = [&](int t) -> int { return masked ? (int)hdr_id(t) : (int)cols[t * cstride]; };
 
         // sweep 1: row sums s[k] = sum_t v[t] * x[c[t]][k]
         float sacc[K];
@@ -189,12 +196,12 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = vat(t + u);
-                c[u] = cols[(t + u) * cstride];
+                c[u] = cat(t + u);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) fma_row<K>(v[u], xw + c[u] * K, sacc);
         }
-        for (; t < w; ++t) fma_row<K>(vat(t), xw + (int)cols[t * cstride] * K, sacc);
+        for (; t < w; ++t) fma_row<K>(vat(t), xw + cat(t) * K, sacc);
         const float ksv = HAS_KS ? slice_ks[(size_t)s * 64 + lane] : 1.0f;
         float wk[K];
 #pragma unroll
@@ -205,7 +212,7 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         // sweep 2 (slice is L1/L2 resident): g[c[t]][k] += v[t] * w[k], summed per run of equal ids
         for (t = 0; t < w; ++t) {
             const float v = vat(t);
-            const int c = cols[t * cstride];
+            const int c = cat(t);
             float q[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) q[k] = v * wk[k];
@@ -865,7 +872,7 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             // a new run: lane t < 16 reads transcript t's tile-local id from the slice's header and turns it into the
             // addresses of its x row and its gradient row; then the x values of the run, four transcripts at a time
             const uint32_t cid = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
-                (uintptr_t)(ring_lds + pos_r + 2u * (uint32_t)(lane & 15)));
+                (uintptr_t)(ring_lds + pos_r + (MASKED ? 4u * (uint32_t)(lane & 15) + 2u : 2u * (uint32_t)(lane & 15))));
             const bool live = MASKED ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < w;
             if (MASKED) {
                 run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
@@ -963,7 +970,7 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
                 // below t) of the slice when bit t is set; `a` runs through the rows' addresses.  Rows past the fragment's
                 // last non-zero (and past the slice: the bytes behind it in the ring) are read and masked away.
                 const uint32_t mk = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
-                    (uintptr_t)(ring_lds + pos_r + 128u + 2u * (uint32_t)lane));
+                    (uintptr_t)(lc1[0] + pos_r));  // low half of header word `lane`
                 float mv[4 * NG];
                 uint32_t a = lc1[0] + row0;
                 const uint32_t lim = lc1[0] + RB;  // (slices that wrap around the ring's end)
@@ -1059,6 +1066,388 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
     if (pend_w != 0) flush();
     if (WANT_LP) {
         // into the caller's accumulator, whose lane l < 16 collects draw l: the sixteen blocks' sums of draw 4 kg + j
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            double v = lpn[kg];
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16 && (lane >> 2) == kg && lane < K) lpacc += v;
+        }
+    }
+}
+
+// ---- the slice loop of the MIXED NARROW stream (BN: unrelated fragments of <= 16 transcripts) ----------------------------
+// Lane = fragment, any 64 fragments of the tile: val[w][64]; lcol[w][64] (tile-local ids, 16 bit).  Two sweeps over the
+// slice in the wave's LDS ring: row sums by gathers from the tile's x window, then the gradient contributions summed per
+// run of lanes with the same transcript (segmented DPP scan) and added to the tile's gradient window by the last lane of
+// every run.  ~3x the instructions of a matrix-core slice per entry, but 64 fragments per slice whatever their sets: the
+// place for fragments without company, inside the same launch.  Every LDS access names its address space: a generic
+// (flat) access would count against vmcnt and break the ring's counted waits.
+template <int K>
+__device__ inline void scatter_runs_lds(int c, float (&q)[K], uint32_t gw_lds, int lane)
+{
+    typedef __attribute__((address_space(3))) float *lds_fp;
+    auto add = [](uint32_t a, float v) {
+        __hip_atomic_fetch_add(reinterpret_cast<lds_fp>((uintptr_t)a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const int c0 = __builtin_amdgcn_readfirstlane(c);
+    if (__all(c == c0)) {  // one column for the whole wavefront: plain wave sum
+        wave_sum_to_lane63_n<K>(q);
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) add(gw_lds + (uint32_t)(c0 * K + k) * 4u, q[k]);
+        }
+        return;
+    }
+    const int cprev = __builtin_amdgcn_update_dpp(-1, c, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const unsigned long long heads = __ballot(c != cprev);  // lane 0 compares with -1: always a head
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int dist = lane - (63 - __clzll(heads & upto));  // distance to the head of this lane's run
+    const int rl = lane & 15;
+    const float m1 = dist >= 1 ? 1.f : 0.f, m2 = dist >= 2 ? 1.f : 0.f, m4 = dist >= 4 ? 1.f : 0.f,
+                m8 = dist >= 8 ? 1.f : 0.f;
+    const float mb15 = dist > rl ? 1.f : 0.f;           // run started in an earlier row of 16
+    const float mb31 = dist > (lane & 31) ? 1.f : 0.f;  // run started before lane 32
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x111, 0xf>(q[k]), m1, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x112, 0xf>(q[k]), m2, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x114, 0xf>(q[k]), m4, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x118, 0xf>(q[k]), m8, q[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x142, 0xa>(q[k]), mb15, q[k]);  // row_bcast:15 -> rows 1, 3
+#pragma unroll
+    for (int k = 0; k < K; ++k) q[k] = fmaf(dpp_mov0<0x143, 0xc>(q[k]), mb31, q[k]);  // row_bcast:31 -> rows 2, 3
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (tail) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (q[k] != 0.0f) add(gw_lds + (uint32_t)(c * K + k) * 4u, q[k]);
+    }
+}
+
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
+__device__ inline void mixed_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw, double &lpacc, int dbg
+#ifdef POLEE_STAMPS
+                                    , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+#endif
+                                    )
+{
+    typedef const __attribute__((address_space(3))) float *lds_cfp;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) f32x2 *lds_cf2p;
+    typedef const __attribute__((address_space(3))) uint16_t *lds_cu16p;
+    constexpr int RP = (int)(RB / 1024u);
+    const int lane = wave_lane();
+    const uint32_t ring_lds = lds_addr(ring);
+    const uint32_t xw_lds = lds_addr(xw), gw_lds = lds_addr(gw);
+    const uint32_t la4 = ring_lds + 4u * (uint32_t)lane, la2 = ring_lds + 2u * (uint32_t)lane;
+    auto wrap_u = [&](uint32_t a) -> uint32_t {  // uniform ring offset a < 2 RB
+        a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+        return a >= RB ? a - RB : a;
+    };
+    auto x_row_fma = [&](float v, uint32_t c, float (&sacc)[K]) {  // sacc[k] += v x[c][k]
+        const uint32_t a = xw_lds + c * (uint32_t)(K * 4);
+        if constexpr (K % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f32x2 x = *reinterpret_cast<lds_cf2p>((uintptr_t)(a + 8u * (uint32_t)k));
+                sacc[2 * k] = fmaf(v, x.x, sacc[2 * k]);
+                sacc[2 * k + 1] = fmaf(v, x.y, sacc[2 * k + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, *reinterpret_cast<lds_cfp>((uintptr_t)(a + 4u * (uint32_t)k)), sacc[k]);
+        }
+    };
+    double lpk[WANT_LP ? K : 1];
+#pragma unroll
+    for (int k = 0; k < (WANT_LP ? K : 1); ++k) lpk[k] = 0.0;
+
+    uint32_t pos = 0, pos_r = 0;
+    for (int si = 0; si < ws.nsl; ++si) {
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
+        const uint32_t units = (e1 & PSELL_OFF_MASK) - (e0 & PSELL_OFF_MASK);
+        const int w = (int)((units - (HAS_KS ? 2u : 0u)) / 3u);  // float val[w][64]; uint16 lcol[w][64]; padding to 256 B; (float ks[64])
+        const uint32_t bytes = units * 128u;
+        STAMP(1);
+        {
+            const int need = (int)((pos + bytes + 1023u) >> 10);
+            if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);
+            int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
+            wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
+        }
+        STAMP(2);
+        const uint32_t cols0 = pos_r + 256u * (uint32_t)w;  // (not wrapped yet)
+        float sacc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        for (int t = 0; t < w; ++t) {
+            const float v = *reinterpret_cast<lds_cfp>((uintptr_t)(la4 + wrap_u(pos_r + 256u * (uint32_t)t)));
+            const uint32_t c = *reinterpret_cast<lds_cu16p>((uintptr_t)(la2 + wrap_u(cols0 + 128u * (uint32_t)t)));
+            x_row_fma(v, c, sacc);
+        }
+        float ksv = 1.0f;
+        if (HAS_KS) ksv = *reinterpret_cast<lds_cfp>((uintptr_t)(la4 + wrap_u(pos_r + bytes - 256u)));
+        float wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wk[k] = fast_weight(ksv, sacc[k]);  // (lanes without a fragment: s = 0, weight 0)
+            if (WANT_LP && sacc[k] > 0.0f) lpk[WANT_LP ? k : 0] += (double)ksv * log((double)sacc[k]);
+        }
+        STAMP(4);
+        for (int t = 0; t < w; ++t) {
+            const float v = *reinterpret_cast<lds_cfp>((uintptr_t)(la4 + wrap_u(pos_r + 256u * (uint32_t)t)));
+            const int c = (int)*reinterpret_cast<lds_cu16p>((uintptr_t)(la2 + wrap_u(cols0 + 128u * (uint32_t)t)));
+            float q[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) q[k] = v * wk[k];
+            if (!(dbg & 2)) scatter_runs_lds<K>(c, q, gw_lds, lane);
+        }
+        STAMP(5);
+        // the slice is consumed: refill the ring behind it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pos += bytes;
+        pos_r += bytes;
+        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+        ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
+        STAMP(6);
+    }
+    if (WANT_LP) {
+        // into the caller's accumulator, whose lane l < 16 collects draw l
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = lpk[WANT_LP ? k : 0];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            if (lane == k) lpacc += v;
+        }
+    }
+}
+
+// ---- the slice loop of the WIDE MASKED stream (A2M: unions of 17..32 transcripts, fragments whose sets differ) ------------
+// The narrow masked formulation (lane = fragment, batched 4 x 4 outer products, phase-2 operands by quad transposes) with
+// the union's transcripts in two halves: phase 1 runs over all of them, the weights follow, then phase 2 and the flush
+// of the first sixteen transcripts' gradients and of the rest -- one set of accumulators serves both halves, so nothing
+// stays in registers across slices (leftover fragments rarely come in runs of slices with the same union; when they do,
+// only the header work is saved).  Header: two rows of uint32 hw[64]: the low halves are bits 0..15 / 16..31 of the
+// fragment's mask, the high halves of the first sixteen words of a row the tile-local ids of transcripts 0..15 / 16..31
+// (PSELL_NO_COL past the union) -- every word a finite float, see loglik_internal.hpp.  Two waves of the workgroup work on
+// such a tile, with the wide stream's 14 KiB rings (a slice is up to 2 + 32 + 1 rows).
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
+__device__ inline void wide_masked_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
+                                          uint32_t aux_lds, double &lpacc, int dbg
+#ifdef POLEE_STAMPS
+                                          , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+#endif
+                                          )
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) float *lds_cfp;
+    typedef __attribute__((address_space(3))) float *lds_fp;
+    typedef const __attribute__((address_space(3))) uint16_t *lds_cu16p;
+    constexpr int KG = (K + 3) / 4;
+    constexpr int RP = (int)(RB / 1024u);
+    const int lane = wave_lane();
+    const uint32_t ring_lds = lds_addr(ring);
+    const uint32_t xw_lds = lds_addr(xw), gw_lds = lds_addr(gw);
+    const int j = lane & 3, b = lane >> 2;
+    const uint32_t j4 = 4u * (uint32_t)j;
+    const uint32_t la = ring_lds + 4u * (uint32_t)lane;  // this lane's column of a row of the ring
+    auto lds_f = [](uint32_t a) -> float { return *reinterpret_cast<lds_cfp>((uintptr_t)a); };
+    auto wrap_u = [&](uint32_t a) -> uint32_t {  // uniform ring offset a < 2 RB
+        a = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+        return a >= RB ? a - RB : a;
+    };
+    f32x4 acc[4][KG];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) acc[g][kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane t < 16: LDS addresses of the x row / gradient row of the union's transcripts t and 16 + t
+    uint32_t xav0 = aux_lds, gav0 = aux_lds + 32u, xav1 = aux_lds, gav1 = aux_lds + 32u;
+    int run_w = 0;
+    double lpn[KG];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) lpn[kg] = 0.0;
+
+    auto flush_group = [&](int g, uint32_t gav) {  // (as in narrow_stream)
+        const uint32_t ga0 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 0), ga2 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 2);
+        const uint32_t ga1 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 1), ga3 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 3);
+        const uint32_t ga = ((lane & 32) ? ((lane & 16) ? ga3 : ga1) : ((lane & 16) ? ga2 : ga0)) + j4;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[g][kg][0]), __float_as_uint(acc[g][kg][1]), false, false);
+            const float ab = __uint_as_float(r1[0]) + __uint_as_float(r1[1]);
+            auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[g][kg][2]), __float_as_uint(acc[g][kg][3]), false, false);
+            const float cd = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+            auto r3 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ab), __float_as_uint(cd), false, false);
+            float q = __uint_as_float(r3[0]) + __uint_as_float(r3[1]);
+            q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0x114, 0xf, 0xf, true));  // row_shr:4
+            q += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0x118, 0xf, 0xf, true));  // row_shr:8
+            if ((lane & 12) == 12 && 4 * kg + j < K && !(dbg & 2))
+                __hip_atomic_fetch_add(reinterpret_cast<lds_fp>((uintptr_t)(ga + 16u * (uint32_t)kg)), q, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            acc[g][kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto load_x_group = [&](int g, uint32_t xav, float (*dst)[KG]) {  // x[c_t][4 kg + j] of transcripts 4 g .. 4 g + 3 of a half
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)xav, 4 * g + u) + j4;
+            dst[u][0] = lds_f(a);
+            if (KG > 1) dst[u][KG > 1 ? 1 : 0] = lds_f(a + 16u);
+        }
+    };
+
+    uint32_t pos = 0, pos_r = 0;
+    for (int si = 0; si < ws.nsl; ++si) {
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
+        const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
+        const int flags = (int)(e0 >> 30);
+        const uint32_t units = off_next - off;
+        const int nrows = (int)(units / 2u) - 2 - (HAS_KS ? 1 : 0);  // rows of 64 values = the longest fragment of the slice
+        const uint32_t bytes = units * 128u;
+        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
+        STAMP(1);
+        {
+            const int need = (int)((pos + bytes + 1023u) >> 10);
+            if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);
+            int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
+            wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
+        }
+        STAMP(2);
+        const uint32_t hdr1 = wrap_u(pos_r + 256u);  // second header row
+        if (run_w == 0 || !(flags & 2)) {
+            // a new union: lane t < 16 turns the tile-local ids of transcripts t and 16 + t into the addresses of their x
+            // rows and gradient rows
+            const uint32_t c0 = *reinterpret_cast<lds_cu16p>((uintptr_t)(ring_lds + pos_r + 4u * (uint32_t)(lane & 15) + 2u));
+            const uint32_t c1 = *reinterpret_cast<lds_cu16p>((uintptr_t)(ring_lds + hdr1 + 4u * (uint32_t)(lane & 15) + 2u));
+            const bool live0 = c0 != (uint32_t)PSELL_NO_COL, live1 = c1 != (uint32_t)PSELL_NO_COL;
+            run_w = __builtin_popcount((uint32_t)__ballot(live0) & 0xffffu) + __builtin_popcount((uint32_t)__ballot(live1) & 0xffffu);
+            xav0 = live0 ? xw_lds + c0 * (uint32_t)(K * 4) : aux_lds;
+            gav0 = live0 ? gw_lds + c0 * (uint32_t)(K * 4) : aux_lds + 32u;
+            xav1 = live1 ? xw_lds + c1 * (uint32_t)(K * 4) : aux_lds;
+            gav1 = live1 ? gw_lds + c1 * (uint32_t)(K * 4) : aux_lds + 32u;
+        }
+        STAMP(3);
+        const uint32_t mk = (uint32_t)*reinterpret_cast<lds_cu16p>((uintptr_t)(la + pos_r)) |
+                            ((uint32_t)*reinterpret_cast<lds_cu16p>((uintptr_t)(la + hdr1)) << 16);
+        const uint32_t row0 = wrap_u(pos_r + 512u);
+        f32x4 d1[KG];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) d1[kg] = f32x4{ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR};
+        f32x4 kv = f32x4{1.f, 1.f, 1.f, 1.f};
+        auto consumed = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(11);
+            pos += bytes;
+            pos_r += bytes;
+            pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+            ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
+            STAMP(6);
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+        };
+        auto body = [&](auto NGHc, auto FASTc) {
+            constexpr int NGH = decltype(NGHc)::value;  // groups of four transcripts in the second half
+            constexpr bool FAST = decltype(FASTc)::value;
+            float mvA[16], mvB[4 * NGH];
+            uint32_t a = la + row0;
+            const uint32_t lim = la + RB;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                mvA[t] = lds_f(a);
+                a += ((mk >> t) & 1u) << 8;
+                if (!FAST) a = a >= lim ? a - RB : a;
+            }
+#pragma unroll
+            for (int t = 0; t < 4 * NGH; ++t) {
+                mvB[t] = lds_f(a);
+                a += ((mk >> (16 + t)) & 1u) << 8;
+                if (!FAST) a = a >= lim ? a - RB : a;
+            }
+            if (HAS_KS) kv = *reinterpret_cast<const f32x4 *>(ring + wrap_u(row0 + 256u * (uint32_t)nrows) + 16u * (uint32_t)b);
+            consumed();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) mvA[t] = __uint_as_float(__float_as_uint(mvA[t]) & (uint32_t)(((int)(mk << (31 - t))) >> 31));
+#pragma unroll
+            for (int t = 0; t < 4 * NGH; ++t) mvB[t] = __uint_as_float(__float_as_uint(mvB[t]) & (uint32_t)(((int)(mk << (15 - t))) >> 31));
+            auto phase1 = [&](const float *p4, const float (*x4)[KG]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) d1[kg] = __builtin_amdgcn_mfma_f32_4x4x1f32(p4[u], x4[u][kg], d1[kg], 0, 0, 0);
+            };
+            auto phase2 = [&](int g, const float *q4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) acc[g][kg] = __builtin_amdgcn_mfma_f32_4x4x1f32(q4[i], d1[kg][i], acc[g][kg], 0, 0, 0);
+            };
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                float xr[8][KG];
+                load_x_group(g, xav0, xr);
+                load_x_group(g + 1, xav0, xr + 4);
+                phase1(mvA + 4 * g, xr);
+                phase1(mvA + 4 * g + 4, xr + 4);
+            }
+#pragma unroll
+            for (int g = 0; g < NGH; g += 2) {
+                float xr[8][KG];
+                load_x_group(g, xav1, xr);
+                if (g + 1 < NGH) load_x_group(g + 1, xav1, xr + 4);
+                phase1(mvB + 4 * g, xr);
+                if (g + 1 < NGH) phase1(mvB + (g + 1 < NGH ? 4 * g + 4 : 0), xr + 4);
+            }
+            // weights, in place: d1[kg][i] of lane (b, j) belongs to fragment 4 b + i, draw 4 kg + j
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sv = d1[kg][i];
+                    if (WANT_LP && 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR)
+                        lpn[kg] += HAS_KS ? (double)kv[i] * log((double)sv) : log((double)sv);
+                    d1[kg][i] = HAS_KS ? kv[i] * __builtin_amdgcn_rcpf(sv) : __builtin_amdgcn_rcpf(sv);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                quad_transpose(mvA[4 * g], mvA[4 * g + 1], mvA[4 * g + 2], mvA[4 * g + 3]);
+                phase2(g, mvA + 4 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) flush_group(g, gav0);
+#pragma unroll
+            for (int g = 0; g < NGH; ++g) {
+                quad_transpose(mvB[4 * g], mvB[4 * g + 1], mvB[4 * g + 2], mvB[4 * g + 3]);
+                phase2(g, mvB + 4 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < NGH; ++g) flush_group(g, gav1);
+        };
+        using std::integral_constant;
+        const bool fast = pos_r + bytes <= RB;
+        const int w = run_w;
+        if (fast) {
+            if (w <= 20) body(integral_constant<int, 1>(), integral_constant<bool, true>());
+            else if (w <= 24) body(integral_constant<int, 2>(), integral_constant<bool, true>());
+            else if (w <= 28) body(integral_constant<int, 3>(), integral_constant<bool, true>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, true>());
+        } else {
+            if (w <= 20) body(integral_constant<int, 1>(), integral_constant<bool, false>());
+            else if (w <= 24) body(integral_constant<int, 2>(), integral_constant<bool, false>());
+            else if (w <= 28) body(integral_constant<int, 3>(), integral_constant<bool, false>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, false>());
+        }
+        STAMP(5);
+    }
+    if (WANT_LP) {
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
             double v = lpn[kg];
@@ -1191,11 +1580,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     unsigned long long n_slices = 0, n_tiles = 0;
 #endif
 
-    // 0 = A1 (dense narrow), 2 = A1M (masked narrow), 1 = A2 (wide: two active waves, 14 KiB rings); the schedule holds no others
-    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a1m ? 2 : 1); };
+    // 0 = A1 (dense narrow), 2 = A1M (masked narrow); 1 = A2 (dense wide), 3 = A2M (masked wide) -- the odd kinds: two active
+    // waves, 14 KiB rings; the schedule holds no others
+    // 4 = BN (mixed narrow: four waves, 7 KiB rings)
+    auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a1m ? 2 : ((int)tile < A.tiles_a2 ? 1 : ((int)tile < A.tiles_a ? 3 : 4))); };
     // this wave's share [sb, se) of an A tile's slices: a contiguous block, so that runs stay inside one wave
     auto share = [&](int kind, const PosDesc &t, uint32_t &sb, uint32_t &se) {
-        const int nw = kind != 1 ? 4 : 2;
+        const int nw = (kind & 1) ? 2 : 4;
         uint32_t a1 = t.c1, a2 = t.c2, a3 = t.c3;
         asm volatile("" : "+s"(a1), "+s"(a2), "+s"(a3));  // (opaque: or the selects below become an indexed load of a PosDesc kept in scratch memory)
         const uint32_t lo = wave == 0 ? t.s0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));
@@ -1241,7 +1632,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
         ws.gsrc = reinterpret_cast<const uint8_t *>(uniform_ptr(A.data + (size_t)cb * 128));
-        if (kind != 1) {
+        if (!(kind & 1)) {
             ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, ahead ? min(ahead, (int)(STREAM_RB1 / 1024u)) : (int)(STREAM_RB1 / 1024u)));
         } else {
             ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, ahead ? min(2 * ahead, (int)(STREAM_RB2 / 1024u)) : (int)(STREAM_RB2 / 1024u)));
@@ -1293,6 +1684,18 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
                                                                              , st_acc, st_last
 #endif
             );
+        } else if (kind == 4) {
+            mixed_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                         , st_acc, st_last
+#endif
+            );
+        } else if (kind == 3) {
+            wide_masked_stream<K, STREAM_RB2, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                               , st_acc, st_last
+#endif
+            );
         } else {
             uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
@@ -1309,7 +1712,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         young = 0;
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
-        const bool early = more && (kind_of(nxt.tile) == 1) == (kind == 1);  // (the narrow kinds share a ring geometry)
+        const bool early = more && ((kind_of(nxt.tile) ^ kind) & 1) == 0;  // (the narrow kinds share a ring geometry, and so do the wide ones)
         if (early) start_ring(nxt);
         STAMP(13);  // starting the next ring (before the barrier)
         lds_barrier();  // every wave's contributions are in gw
@@ -1402,8 +1805,8 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     if (ll->sched_grid == G && ll->d_sched.p) return POLEE_OK;
     const PsellHost &h = ll->host;
     std::vector<uint32_t> order;
-    order.reserve((size_t)h.num_tiles_a);
-    for (int64_t t = 0; t < h.num_tiles_a; ++t) order.push_back((uint32_t)t);  // (the mixed tiles behind them go to the per-tile kernel)
+    order.reserve((size_t)h.num_tiles_s);
+    for (int64_t t = 0; t < h.num_tiles_s; ++t) order.push_back((uint32_t)t);  // (the wide mixed tiles behind them go to the per-tile kernel)
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ll->tile_cost[a] > ll->tile_cost[b]; });
     std::vector<std::vector<uint32_t>> lists((size_t)G);
     for (size_t i = 0; i < order.size(); ++i) {
@@ -1419,7 +1822,7 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     }
     for (int b = 0; b < G; ++b) {
         std::vector<uint32_t> big, small;
-        for (uint32_t t : lists[b]) (h.stream_of_tile(t) != PSELL_A2 ? big : small).push_back(t);
+        for (uint32_t t : lists[b]) (h.stream_of_tile(t) != PSELL_A2 && h.stream_of_tile(t) != PSELL_A2M ? big : small).push_back(t);
         const size_t n = big.size() + small.size();
         size_t ib = 0, is = 0;
         for (size_t j = 0; j < n; ++j) {
@@ -1451,7 +1854,8 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     hipStream_t st = ctx->stream;
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
     static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
-    static_assert((PSELL_WIDE_MAX + 2) * 256 + 1024 <= STREAM_RB2, "A2 slices (+ ks row) must fit their ring");
+    static_assert(((PSELL_MIXED_NARROW_MAX * 384 + 255) & ~255) + 256 + 1024 <= STREAM_RB1, "BN slices (+ ks row) must fit their ring");
+    static_assert((PSELL_WIDE_MAX + 3) * 256 + 1024 <= STREAM_RB2, "A2 / A2M slices (+ ks row) must fit their ring");
     const size_t lds = stream_lds_bytes<K, DET>();
     int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0][DET ? 1 : 0];
     if (occ == 0) {
@@ -1462,7 +1866,7 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
             fprintf(stderr, "[loglik] stream kernel K=%d%s: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
                     K, DET ? " (deterministic)" : "", nb, lds, occ, ctx->num_cus);
     }
-    const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles_a, 1));
+    const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles_s, 1));
     POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
     A.sched = ll->d_sched.p;
     if (DET) {
@@ -1498,16 +1902,16 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, ll->d_xwin.p, nullptr, nullptr, nullptr};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
-    const int64_t tiles_b = h.num_tiles - h.num_tiles_a;
+    const int64_t tiles_b = h.num_tiles - h.num_tiles_s;
     if (lds_psell > 48 * 1024 && (tiles_b > 0 || no_ring))
         POLEE_HIP_TRY(ctx, hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     if (!no_ring) {
-        if (h.num_tiles_a > 0) {
+        if (h.num_tiles_s > 0) {
             if (ll->deterministic)
                 POLEE_TRY((launch_stream<K, LP, KS, true>(ll, A, dbg)));
             else
@@ -1517,7 +1921,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
             // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes (with
             // float atomics: a sample that has such rows is not bitwise reproducible in deterministic mode either)
             hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds_psell, st, A,
-                               (int)h.num_tiles_a, (const uint32_t *)nullptr);
+                               (int)h.num_tiles_s, (const uint32_t *)nullptr);
         }
     } else {
         // the cross-check switch: every tile as mixed slices with the per-run DPP kernel
@@ -1691,8 +2095,9 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         const double slice_bytes = 128.0 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
         double c = slice_bytes + 4096.0;
         const int st = h.stream_of_tile(t);
-        if (st == PSELL_A2) c *= 1.5;  // (the wide stream runs on two of the four waves)
-        if (st == PSELL_A1M) {  // (a masked slice costs the matrix cores what the dense slice of its union would)
+        if (st == PSELL_BN) c *= 3.0;  // (lane-per-fragment sweeps: ~3x the instructions per byte)
+        if (st == PSELL_A2 || st == PSELL_A2M) c *= 1.5;  // (the wide streams run on two of the four waves)
+        if (st == PSELL_A1M || st == PSELL_A2M) {  // (a masked slice costs the matrix cores what the dense slice of its union would)
             double dense = 4096.0;
             for (uint32_t sl = h.tile_slice[t]; sl < h.tile_slice[t + 1]; ++sl) dense += 256.0 * (h.slice_w[sl] + 1);
             c = std::max(c, 0.5 * (c + dense));
@@ -1706,10 +2111,11 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
         uint32_t *cut = &ll->tile_cut[(size_t)3 * t];
         cut[0] = cut[1] = cut[2] = s1;
-        if (t >= h.num_tiles_a) continue;
-        const int nw = h.stream_of_tile(t) != PSELL_A2 ? 4 : 2;
+        if (t >= h.num_tiles_s) continue;
+        const int nw = h.stream_of_tile(t) != PSELL_A2 && h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
         auto cost = [&](uint32_t sl) {
             const int w = h.slice_w[sl];
+            if (h.stream_of_tile(t) == PSELL_BN) return 6.0 * w + 4.0;  // (instructions per entry, not matrix-core work)
             return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
         };
         double total = 0.0;
@@ -1724,12 +2130,12 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     }
     {   // deterministic mode: the dictionary entries of every transcript, ascending (= tile order), padding left out
         std::vector<uint32_t> ptr((size_t)ll->n + 1, 0), slots;
-        for (int64_t t = 0; t < h.num_tiles_a; ++t)
+        for (int64_t t = 0; t < h.num_tiles_s; ++t)
             for (uint32_t l = 0; l < h.tile_cols[t]; ++l) ++ptr[(size_t)h.dict[h.tile_dict[t] + l] + 1];
         for (int64_t j = 0; j < ll->n; ++j) ptr[(size_t)j + 1] += ptr[(size_t)j];
         slots.resize(ptr[(size_t)ll->n]);
         std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
-        for (int64_t t = 0; t < h.num_tiles_a; ++t)
+        for (int64_t t = 0; t < h.num_tiles_s; ++t)
             for (uint32_t l = 0; l < h.tile_cols[t]; ++l) {
                 const uint32_t e = h.tile_dict[t] + l;
                 slots[cur[h.dict[e]]++] = e;
@@ -1930,7 +2336,9 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_empty_rows = h.empty_rows;
     info->max_row_nnz = h.max_row;
     info->max_tile_cols = h.max_tile_cols;
-    const int64_t tiles[PSELL_NSTREAMS] = {h.num_tiles_a1, h.num_tiles_a1m - h.num_tiles_a1, h.num_tiles_a - h.num_tiles_a1m, h.num_tiles - h.num_tiles_a};
+    const int64_t tiles[PSELL_NSTREAMS] = {h.num_tiles_a1, h.num_tiles_a1m - h.num_tiles_a1, h.num_tiles_a2 - h.num_tiles_a1m,
+                                           h.num_tiles_a - h.num_tiles_a2, h.num_tiles_s - h.num_tiles_a, h.num_tiles - h.num_tiles_s};
+    for (int i = 0; i < 8; ++i) info->stream_rows[i] = info->stream_nnz[i] = info->stream_tiles[i] = info->stream_bytes_hbm[i] = 0;
     for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         info->stream_rows[i] = h.stream_rows[i];
         info->stream_nnz[i] = h.stream_nnz[i];

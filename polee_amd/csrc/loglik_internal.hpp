@@ -9,7 +9,7 @@
 //     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
 //     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
 //     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
-//   * Consecutive slices form a TILE (64 / 64 / 8 / 16 slices in streams A1 / A1M / A2 / B), the unit of work of one
+//   * Consecutive slices form a TILE (64 / 64 / 8 / 16 / 16 / 16 slices in streams A1 / A1M / A2 / A2M / BN / B), the unit of work of one
 //     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
 //     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
 //     pass 128 entries).  Every tile's dictionary starts at a multiple of 4 entries (padded with
@@ -17,25 +17,35 @@
 //     by xwin_gather_kernel -- starts 16-byte aligned and reaches LDS by LDS-DMA like the slice stream.
 //   * The kernel accumulates the tile's gradient contributions in LDS (ds_add_f32) and flushes L*K
 //     values to HBM per tile.
-//   * Rows are split into four streams, each a contiguous range of tiles (in this order):
-//       A1, A1M, A2 = UNIFORM slices: all rows of a slice are stored under ONE transcript set, kept once per slice.
+//   * Rows are split into six streams, each a contiguous range of tiles (in this order):
+//       A1, A1M, A2, A2M = UNIFORM slices: all rows of a slice are stored under ONE transcript set, kept once per slice.
 //         A1  (dense, sets of <= 16): uint16 lcol[128] header + float val[w][64], 4 B per entry: whole 64-row slices of
 //              every run of identical rows, run remainders of >= 32 rows (zero padded), and dense UNION slices -- leftover
 //              rows of neighbouring sets packed under the union of their sets with zeros where a row lacks a transcript
 //              (a zero adds nothing to a row sum or a gradient, exactly) -- when the union is (almost) full.
 //         A1M (MASKED, unions of <= 16): leftover rows whose sets differ -- any 64 rows whose union has <= 16 transcripts.
-//              Header: uint16 lcol[16] (0xffff past the union), at byte 128 uint16 mask[64] (bit t of mask[r]: fragment r
-//              is compatible with transcript t of the union); then float val[i][64], the i-th non-zero of fragment r at
-//              position r of row i, for i < the longest row of the slice.  Zeros cost no bytes: 4 B per non-zero + 4 B per
+//              Header: uint32 hw[64] -- low half of hw[r] = the mask of fragment r (bit t: it is compatible with
+//              transcript t of the union), high half of hw[t], t < 16, = the tile-local id of transcript t (0x8000 past
+//              the union); then float val[i][64], the i-th non-zero of fragment r at position r of row i, for i < the
+//              longest row of the slice.  (Every 32-bit word of a slice is a FINITE float -- ids < 128 or 0x8000 in the
+//              high halves: the dense streams' kernels read the rows behind a slice's last transcript from their LDS
+//              rings and multiply them by zero, and a ring may still hold a masked tile's bytes.)  Zeros cost no bytes: 4 B per non-zero + 4 B per
 //              fragment + padding to the slice's longest row -- never more than the dense union slice, and below CSR's
 //              8 B per non-zero + 4 B per fragment whatever the sets look like.  The kernel expands a fragment's values
 //              with its mask (rank = popcount of the lower bits) and runs the same matrix-core phases.
-//         A2  (dense, sets of 17..32): runs, remainders and union slices that are at least as small as the mixed form.
-//         One persistent launch (loglik_stream_kernel) streams all three.
-//       B     = MIXED slices (float val[w][64]; uint16 lcol[w][64], 6 B per entry): rows with more than 32 transcripts
-//              and the leftover rows that fit no uniform slice at a lower cost; the per-tile kernel loglik_psell_kernel
-//              takes them in a second launch.  That kernel also runs over the uniform slices on request
-//              (polee_debug_loglik_force_mixed): the independent second algorithm of the cross-check tests.
+//         A2  (dense, sets of 17..32): runs, remainders and union slices that are (almost) full.
+//         A2M (MASKED, unions of 17..32): the leftover rows that fit no union of 16 -- fragments of a gene with many
+//              isoforms.  Header: two rows of uint32 hw[64] (mask bits 0..15 / 16..31 in the low halves, the ids of
+//              transcripts 0..15 / 16..31 in the high halves of each row's first sixteen words); values as in A1M.
+//       BN, B = MIXED slices (float val[w][64]; uint16 lcol[w][64], 6 B per entry, any 64 fragments of the tile): the
+//              leftover rows that fit no uniform slice at CSR's cost or less -- unrelated fragments, fewer than a handful
+//              of which share any 32 transcripts.  BN: rows of <= 15 transcripts (with multiplicities a row float ks[64]
+//              follows, at the next multiple of 256 bytes), lane = fragment, gathers from / LDS adds into the tile's
+//              windows.
+//         One persistent launch (loglik_stream_kernel) streams these five: the usual sample needs no other.
+//              B: rows of more than 16 transcripts that found no uniform slice (more than 32, as a rule); the per-tile
+//              kernel loglik_psell_kernel takes them in a second launch.  That kernel also runs over all other slices
+//              on request (polee_debug_loglik_force_mixed): the independent second algorithm of the cross-check tests.
 //   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
 //     are stored under one transcript set) and "continues" (the same set as the previous slice).  Runs of such
 //     slices -- the bulk of real and synthetic data, where many fragments fall into the same
@@ -60,10 +70,12 @@ constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
 // A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
-enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_B = 3, PSELL_NSTREAMS = 4 };  // streams, in tile order
+enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_NSTREAMS = 6 };  // streams, in tile order
+constexpr int PSELL_MIXED_NARROW_MAX = 15;  // longest row of stream BN (its slices pass through the narrow streams' 7 KiB rings)
+constexpr int PSELL_TILE_SLICES_A2M = 16;
+constexpr int PSELL_TILE_SLICES_BN = 64;
 constexpr uint32_t psell_row_pos(int stream, uint32_t t, uint32_t r) { return stream == PSELL_A1 ? (r ^ (t & 3u)) : (stream == PSELL_A2 ? ((r + 4u * t) & 63u) : r); }
-constexpr uint16_t PSELL_NO_COL = 0xffffu;  // header entries of a masked slice past its union
-constexpr double PSELL_MIXED_BYTES_PER_NNZ = 6.6;  // what a leftover row costs in the mixed stream (6 B per entry + padding): a uniform slice must not cost more
+constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice past its union (0x8000xxxx is a finite float)
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 
@@ -82,9 +94,14 @@ struct PsellHost {
     // stream A (tiles [0, num_tiles_a)): only slices whose 64 rows share one transcript set
     int64_t rows_a = 0, num_tiles_a = 0, num_slices_a = 0;
     int64_t rows_a1 = 0, num_tiles_a1 = 0;    // A1 = tiles [0, num_tiles_a1): dense, sets of <= PSELL_NARROW_MAX transcripts
-    int64_t rows_a1m = 0, num_tiles_a1m = 0;  // A1M = tiles [num_tiles_a1, num_tiles_a1m): masked; A2 = [num_tiles_a1m, num_tiles_a)
+    int64_t rows_a1m = 0, num_tiles_a1m = 0;  // A1M = tiles [num_tiles_a1, num_tiles_a1m): masked
+    int64_t rows_a2 = 0, num_tiles_a2 = 0;    // A2 = [num_tiles_a1m, num_tiles_a2): dense wide; A2M = [num_tiles_a2, num_tiles_a): masked wide
+    int64_t rows_s = 0, num_tiles_s = 0;      // BN = [num_tiles_a, num_tiles_s): mixed narrow -- [0, num_tiles_s) is the persistent launch's share; B = the rest
     int64_t stream_rows[PSELL_NSTREAMS] = {}, stream_nnz[PSELL_NSTREAMS] = {}, stream_bytes[PSELL_NSTREAMS] = {};
-    int stream_of_tile(int64_t t) const { return t < num_tiles_a1 ? PSELL_A1 : (t < num_tiles_a1m ? PSELL_A1M : (t < num_tiles_a ? PSELL_A2 : PSELL_B)); }
+    int stream_of_tile(int64_t t) const
+    {
+        return t < num_tiles_a1 ? PSELL_A1 : (t < num_tiles_a1m ? PSELL_A1M : (t < num_tiles_a2 ? PSELL_A2 : (t < num_tiles_a ? PSELL_A2M : (t < num_tiles_s ? PSELL_BN : PSELL_B))));
+    }
     int32_t max_row = 0, max_tile_cols = 0;
     std::vector<uint8_t, default_init_allocator<uint8_t>> data;  // slice blocks (resize(n) leaves new bytes uninitialised; resize(n, 0) zeroes)
     std::vector<uint32_t> slice_off;   // [num_slices+1], 128-byte units in bits 0..29, slice flags in bits 30..31

@@ -155,6 +155,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     //   B:       rows of more than 32 transcripts and the leftover rows of rejected groups.
     std::vector<uint32_t> run_end;   // for the uniform streams' rows: 1 = the row's slice ends after it
     std::vector<uint8_t> row_form;   // for the uniform streams' rows: 0 exact run, 1 dense union, 2 masked
+    std::vector<uint32_t> row_gid;   // ... forms 1, 2: the row's group (index into `patterns`)
+    std::vector<std::vector<uint32_t>> patterns;  // transcript set (union) of every group of leftover rows
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
@@ -168,8 +170,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         struct RowList {
             std::vector<uint32_t> rows, ends;
             std::vector<uint8_t> form;
+            std::vector<uint32_t> gid;  // union / masked rows: index of the group's transcript set in `patterns`
         };
-        RowList S1, S1M, S2;  // A1, A1M, A2
+        RowList S1, S1M, S2, S2M;  // A1, A1M, A2, A2M
         std::vector<uint32_t> rb;
         // (on several host threads: chunks of rows that start at a run's head, each with its own output lists, which are
         // then joined in chunk order -- the result does not depend on the number of threads)
@@ -185,6 +188,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             pstart[p] = a;
         }
         std::vector<Part> parts(nparts);
+        static const bool no_runs = getenv("POLEE_PSELL_NO_RUNS") != nullptr;  // (experiments: every row goes through the packing of leftover rows)
         static const int min_uniform = getenv("POLEE_PSELL_MIN_UNIFORM") ? atoi(getenv("POLEE_PSELL_MIN_UNIFORM")) : PSELL_MIN_UNIFORM_ROWS;
         parallel_chunks(nparts, 1, [&](size_t plo, size_t phi, unsigned) {
             for (size_t p = plo; p < phi; ++p) {
@@ -198,7 +202,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     const uint64_t len = rowptr[rows[i] + 1] - rowptr[rows[i]];
                     size_t take = (r / PSELL_LANES) * PSELL_LANES;
                     if (r - take >= (size_t)min_uniform) take = r;
-                    if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
+                    if (len > (uint64_t)PSELL_WIDE_MAX || no_runs) take = 0;
                     std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? P.ra1 : P.ra2;
                     std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? P.e1 : P.e2;
                     for (size_t q = 0; q < take; ++q) {
@@ -229,17 +233,26 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
             S1.form.assign(S1.rows.size(), 0);
             S2.form.assign(S2.rows.size(), 0);
+            S1.gid.assign(S1.rows.size(), 0);
+            S2.gid.assign(S2.rows.size(), 0);
         }
         // Packing of the leftover rows.  Rows are visited in the order of their first transcript (then length, then set:
-        // equal sets stay neighbours); a row joins the open group while the union stays within the class's width and the
-        // group has fewer than 64 rows, a misfit is deferred once.  A closed group of rows with cnt_r non-zeros, union w,
-        // longest row M costs 256 (w + 1) bytes as a dense union slice, 256 (M + 1) as a masked slice (M <= w: never
-        // more), and about 6.6 sum(cnt_r) in the mixed stream; it takes the cheapest form, the dense one when masking
-        // would save less than `mask_gain` of its bytes (the masked form costs the kernel ~5 more vector instructions
-        // per transcript of the union).  So the layout's bytes per non-zero stay below CSR's for any sparsity pattern.
+        // equal sets stay neighbours); a row joins the open group while the union stays within the pass's width and the
+        // group has fewer than 64 rows, a misfit is deferred once.  Two passes: unions of <= 16 over the rows of <= 16
+        // transcripts, then unions of <= 32 over everything the first pass left (fragments of genes with many isoforms,
+        // whose unions pass 16 after two or three rows) and the rows of 17..32.  A closed group of R rows with cnt_r
+        // non-zeros, union w, longest row M costs 256 (w + 1) bytes as a dense union slice and 256 (M + 1) (w <= 16) or
+        // 256 (M + 2) (w > 16) as a masked slice; it becomes a uniform slice of the cheaper form (the dense one when
+        // masking would save less than `mask_gain` of its bytes: the masked forms cost the kernel ~5 more vector
+        // instructions per transcript of the union) when that is no more than what CSR spends on its rows,
+        // 8 sum(cnt_r) + 4 R; otherwise its rows go on (to the second pass, then to the mixed stream: 6 B per entry +
+        // padding).  So the layout's bytes per non-zero stay below CSR's for any sparsity pattern, and the (slow) mixed
+        // kernel only sees fragments that are unrelated to their neighbours.
         static const bool no_union = getenv("POLEE_PSELL_NO_UNION") != nullptr;
         static const bool no_mask = getenv("POLEE_PSELL_NO_MASK") != nullptr;
         static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.15;
+        static const double over_budget = getenv("POLEE_PSELL_OVER_BUDGET") ? atof(getenv("POLEE_PSELL_OVER_BUDGET")) : 0.02;
+        static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
             std::vector<uint64_t> k2(rb.size());
@@ -249,22 +262,41 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             radix_sort_pairs(k2, idx);
             std::vector<uint32_t> cand(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) cand[q] = rb[idx[q]];
-            std::vector<uint32_t> keep_b;
-            for (int cls = 0; cls < 2; ++cls) {  // narrow sets first, then the wide ones
-                const size_t cap = cls == 0 ? (size_t)PSELL_NARROW_MAX : (size_t)PSELL_WIDE_MAX;
-                std::vector<uint32_t> pool;
-                for (uint32_t r : cand) {
-                    const uint64_t len = rowptr[r + 1] - rowptr[r];
-                    if (cls == 0 ? len <= (uint64_t)PSELL_NARROW_MAX : (len > (uint64_t)PSELL_NARROW_MAX && len <= (uint64_t)PSELL_WIDE_MAX))
-                        pool.push_back(r);
-                    else if (cls == 0 && len > (uint64_t)PSELL_WIDE_MAX)
-                        keep_b.push_back(r);
+            std::vector<uint32_t> keep_b, pool, next_pool;
+            // pass 0: unions of <= 16; pass 1: unions of <= 32 over what is left.  What finds no company in either goes to
+            // the mixed streams: rows of <= 16 transcripts to BN, inside the persistent launch.  Rows of 17..32 would need
+            // the per-tile kernel's extra launch (30 us for a handful of rows), so the second pass keeps their groups even
+            // above CSR's cost, as long as the whole excess stays within `over_budget` of the matrix's CSR bytes.
+            for (int pass_w = 0; pass_w < 2; ++pass_w) {
+                const size_t cap = pass_w == 1 ? (size_t)PSELL_WIDE_MAX : (size_t)PSELL_NARROW_MAX;
+                pool.clear();
+                if (pass_w == 0) {
+                    for (uint32_t r : cand) {
+                        const uint64_t len = rowptr[r + 1] - rowptr[r];
+                        if (len <= (uint64_t)PSELL_NARROW_MAX) pool.push_back(r);
+                        else if (len <= (uint64_t)PSELL_WIDE_MAX) next_pool.push_back(r);
+                        else keep_b.push_back(r);
+                    }
+                } else {
+                    // the previous pass's rejects (pass 1: and the rows of 17..32), merged back into first-transcript order
+                    std::vector<uint64_t> k3(next_pool.size());
+                    for (size_t q = 0; q < next_pool.size(); ++q) k3[q] = ((uint64_t)col[rowptr[next_pool[q]]] << 32) | q;
+                    std::vector<uint32_t> i3(next_pool.size());
+                    for (size_t q = 0; q < next_pool.size(); ++q) i3[q] = (uint32_t)q;
+                    radix_sort_pairs(k3, i3);
+                    pool.resize(next_pool.size());
+                    for (size_t q = 0; q < next_pool.size(); ++q) pool[q] = next_pool[i3[q]];
+                    next_pool.clear();
                 }
                 // (chunks of 32 768 candidate rows are packed independently on several threads and joined in order: a
                 // group never spans two chunks, and the result does not depend on the number of threads)
+                double pool_csr_bytes = 0.0;
+                for (uint32_t r : pool) pool_csr_bytes += 8.0 * (double)(rowptr[r + 1] - rowptr[r]) + 4.0;
+                const double matrix_csr_bytes = 8.0 * (double)rowptr[m] + 4.0 * (double)m;
                 struct UPart {
-                    RowList dense, masked;
+                    RowList dense1, masked1, dense2, masked2;
                     std::vector<uint32_t> left;
+                    std::vector<std::vector<uint32_t>> pats;  // the sets of this part's groups (RowList::gid is local to the part)
                 };
                 const size_t UCH = (size_t)1 << 15;
                 const size_t nup = std::max<size_t>(1, (pool.size() + UCH - 1) / UCH);
@@ -273,44 +305,58 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     std::vector<uint32_t> deferred, group, uni, tmp;
                     for (size_t up = ulo; up < uhi; ++up) {
                         UPart &U = uparts[up];
+                        const size_t p0 = up * UCH, p1 = std::min(pool.size(), p0 + UCH);
+                        // (second pass only) what the part's groups may spend above CSR's cost of their rows, so that a
+                        // few fragments without company do not cost a pass the mixed stream's extra launch
+                        // (over_budget of the whole matrix's CSR bytes, shared out by the parts' candidate rows)
+                        double allowance = 0.0;
+                        if (pass_w == 1) {
+                            for (size_t q = p0; q < p1; ++q) allowance += 8.0 * (double)(rowptr[pool[q] + 1] - rowptr[pool[q]]) + 4.0;
+                            allowance *= over_budget * matrix_csr_bytes / std::max(pool_csr_bytes, 1.0);
+                        }
+                        // A GROUP = consecutive candidates under one union; it is cut into slices of 64 rows which all
+                        // carry the group's union -- runs of slices with the same set, whose gradient stays in registers.
                         auto close_group = [&]() {
                             if (group.empty()) return;
-                            size_t total = 0, longest = 0;
-                            for (uint32_t r : group) {
-                                const size_t c = (size_t)(rowptr[r + 1] - rowptr[r]);
-                                total += c;
-                                longest = std::max(longest, c);
-                            }
-                            const double dense_bytes = 256.0 * (double)(uni.size() + 1 + ks_rows);
-                            const double masked_bytes = cls == 0 && !no_mask ? 256.0 * (double)(longest + 1 + ks_rows) : 1e30;
-                            const double mixed_bytes = PSELL_MIXED_BYTES_PER_NNZ * (double)total;
-                            RowList *dst = nullptr;
-                            uint8_t form = 1;
-                            if (std::min(dense_bytes, masked_bytes) <= mixed_bytes || group.size() < (size_t)PSELL_MIN_UNION_ROWS) {
-                                if (masked_bytes < (1.0 - mask_gain) * dense_bytes) {
-                                    dst = &U.masked;
-                                    form = 2;
-                                } else if (dense_bytes <= mixed_bytes || masked_bytes > mixed_bytes) {
-                                    dst = &U.dense;
-                                } else {  // (the dense form is within mask_gain of the masked one but above the mixed cost)
-                                    dst = &U.masked;
-                                    form = 2;
+                            const bool narrow = uni.size() <= (size_t)PSELL_NARROW_MAX;
+                            const uint32_t pid = (uint32_t)U.pats.size();
+                            bool any = false;
+                            for (size_t c0 = 0; c0 < group.size(); c0 += PSELL_LANES) {
+                                const size_t c1 = std::min(group.size(), c0 + (size_t)PSELL_LANES);
+                                size_t total = 0, longest = 0;
+                                for (size_t q = c0; q < c1; ++q) {
+                                    const size_t c = (size_t)(rowptr[group[q] + 1] - rowptr[group[q]]);
+                                    total += c;
+                                    longest = std::max(longest, c);
+                                }
+                                const double dense_bytes = 256.0 * (double)(uni.size() + 1 + ks_rows);
+                                const double masked_bytes = no_mask ? 1e30 : 256.0 * (double)(longest + (narrow ? 1 : 2) + ks_rows);
+                                const double budget = 8.0 * (double)total + 4.0 * (double)(c1 - c0);  // (CSR's cost of these rows)
+                                const double cost = std::min(dense_bytes, masked_bytes);
+                                bool worth = cost <= budget;
+                                if (!worth && longest > (size_t)PSELL_MIXED_NARROW_MAX && cost - budget <= allowance) {
+                                    allowance -= cost - budget;
+                                    worth = true;
+                                }
+                                if (worth) {
+                                    const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
+                                    RowList &dst = narrow ? (masked ? U.masked1 : U.dense1) : (masked ? U.masked2 : U.dense2);
+                                    for (size_t q = c0; q < c1; ++q) {
+                                        dst.rows.push_back(group[q]);
+                                        dst.ends.push_back(q + 1 == c1 ? 1u : 0u);
+                                        dst.form.push_back(masked ? 2 : 1);
+                                        dst.gid.push_back(pid);
+                                    }
+                                    any = true;
+                                } else {
+                                    U.left.insert(U.left.end(), group.begin() + c0, group.begin() + c1);
                                 }
                             }
-                            if (dst) {
-                                for (size_t q = 0; q < group.size(); ++q) {
-                                    dst->rows.push_back(group[q]);
-                                    dst->ends.push_back(q + 1 == group.size() ? 1u : 0u);
-                                    dst->form.push_back(form);
-                                }
-                            } else {
-                                U.left.insert(U.left.end(), group.begin(), group.end());
-                            }
+                            if (any) U.pats.push_back(uni);
                             group.clear();
                             uni.clear();
                         };
                         deferred.clear();
-                        const size_t p0 = up * UCH, p1 = std::min(pool.size(), p0 + UCH);
                         for (int pass = 0; pass < 2; ++pass) {
                             const uint32_t *src = pass == 0 ? pool.data() + p0 : deferred.data();
                             const size_t cnt = pass == 0 ? p1 - p0 : deferred.size();
@@ -320,7 +366,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                                 const uint32_t *cb = col + rowptr[r], *ce = col + rowptr[r + 1];
                                 tmp.resize(uni.size() + (size_t)(ce - cb));
                                 tmp.resize((size_t)(std::set_union(uni.begin(), uni.end(), cb, ce, tmp.begin()) - tmp.begin()));
-                                if (tmp.size() <= cap && group.size() < (size_t)PSELL_LANES) {
+                                // (a group that already fills a slice takes more rows only while that costs the matrix
+                                // cores nothing: the same number of groups of four transcripts)
+                                if (tmp.size() <= cap && (group.size() < (size_t)PSELL_LANES || (tmp.size() + 3) / 4 == (uni.size() + 3) / 4) &&
+                                    group.size() < max_group) {
                                     uni.swap(tmp);
                                     group.push_back(r);
                                     continue;
@@ -338,51 +387,75 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                         }
                     }
                 });
-                RowList &D = cls == 0 ? S1 : S2;
+                uint32_t gid_base = 0;
+                auto append = [&](RowList &D, const RowList &U) {
+                    D.rows.insert(D.rows.end(), U.rows.begin(), U.rows.end());
+                    D.ends.insert(D.ends.end(), U.ends.begin(), U.ends.end());
+                    D.form.insert(D.form.end(), U.form.begin(), U.form.end());
+                    for (uint32_t g : U.gid) D.gid.push_back(g + gid_base);
+                };
                 for (UPart &U : uparts) {
-                    D.rows.insert(D.rows.end(), U.dense.rows.begin(), U.dense.rows.end());
-                    D.ends.insert(D.ends.end(), U.dense.ends.begin(), U.dense.ends.end());
-                    D.form.insert(D.form.end(), U.dense.form.begin(), U.dense.form.end());
-                    S1M.rows.insert(S1M.rows.end(), U.masked.rows.begin(), U.masked.rows.end());
-                    S1M.ends.insert(S1M.ends.end(), U.masked.ends.begin(), U.masked.ends.end());
-                    S1M.form.insert(S1M.form.end(), U.masked.form.begin(), U.masked.form.end());
-                    keep_b.insert(keep_b.end(), U.left.begin(), U.left.end());
+                    gid_base = (uint32_t)patterns.size();
+                    for (auto &pt : U.pats) patterns.push_back(std::move(pt));
+                    append(S1, U.dense1);
+                    append(S1M, U.masked1);
+                    append(S2, U.dense2);
+                    append(S2M, U.masked2);
+                    std::vector<uint32_t> &left = pass_w == 0 ? next_pool : keep_b;
+                    left.insert(left.end(), U.left.begin(), U.left.end());
                 }
             }
             rb.swap(keep_b);
         }
-        // the mixed stream: rows in the order of their first transcript (small tile dictionaries), and inside every
-        // block of 1024 rows -- a tile's worth -- by descending length (little padding inside a slice)
+        // the mixed streams -- BN: rows of <= 16 transcripts, B: the others -- each in the order of the rows' first
+        // transcripts (small tile dictionaries), and inside every block of 1024 rows -- a tile's worth -- by descending
+        // length (little padding inside a slice)
+        std::vector<uint32_t> rbn;
         if (!rb.empty()) {
             std::vector<uint64_t> k2(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;
             std::vector<uint32_t> idx(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) idx[q] = (uint32_t)q;
             radix_sort_pairs(k2, idx);
-            std::vector<uint32_t> sorted(rb.size());
-            for (size_t q = 0; q < rb.size(); ++q) sorted[q] = rb[idx[q]];
-            rb.swap(sorted);
+            std::vector<uint32_t> wide;
+            static const bool no_bn = getenv("POLEE_PSELL_NO_BN") != nullptr;  // (experiments: every mixed row to the per-tile kernel)
+            for (size_t q = 0; q < rb.size(); ++q) {
+                const uint32_t r = rb[idx[q]];
+                (rowptr[r + 1] - rowptr[r] <= (uint64_t)PSELL_MIXED_NARROW_MAX && !no_bn ? rbn : wide).push_back(r);
+            }
+            rb.swap(wide);
             const size_t BL = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
-            parallel_chunks((rb.size() + BL - 1) / BL, 16, [&](size_t lo, size_t hi, unsigned) {
-                for (size_t blk = lo; blk < hi; ++blk)
-                    std::stable_sort(rb.begin() + blk * BL, rb.begin() + std::min(rb.size(), (blk + 1) * BL), [&](uint32_t r1, uint32_t r2) {
-                        return rowptr[r1 + 1] - rowptr[r1] > rowptr[r2 + 1] - rowptr[r2];
-                    });
-            });
+            for (std::vector<uint32_t> *lst : {&rbn, &rb})
+                parallel_chunks((lst->size() + BL - 1) / BL, 16, [&](size_t lo, size_t hi, unsigned) {
+                    for (size_t blk = lo; blk < hi; ++blk)
+                        std::stable_sort(lst->begin() + blk * BL, lst->begin() + std::min(lst->size(), (blk + 1) * BL), [&](uint32_t r1, uint32_t r2) {
+                            return rowptr[r1 + 1] - rowptr[r1] > rowptr[r2 + 1] - rowptr[r2];
+                        });
+                });
         }
         out.rows_a1 = (int64_t)S1.rows.size();
         out.rows_a1m = out.rows_a1 + (int64_t)S1M.rows.size();
-        out.rows_a = out.rows_a1m + (int64_t)S2.rows.size();
+        out.rows_a2 = out.rows_a1m + (int64_t)S2.rows.size();
+        out.rows_a = out.rows_a2 + (int64_t)S2M.rows.size();
+        out.rows_s = out.rows_a + (int64_t)rbn.size();
         rows.swap(S1.rows);
         rows.insert(rows.end(), S1M.rows.begin(), S1M.rows.end());
         rows.insert(rows.end(), S2.rows.begin(), S2.rows.end());
+        rows.insert(rows.end(), S2M.rows.begin(), S2M.rows.end());
+        rows.insert(rows.end(), rbn.begin(), rbn.end());
         rows.insert(rows.end(), rb.begin(), rb.end());
         run_end.swap(S1.ends);
         run_end.insert(run_end.end(), S1M.ends.begin(), S1M.ends.end());
         run_end.insert(run_end.end(), S2.ends.begin(), S2.ends.end());
+        run_end.insert(run_end.end(), S2M.ends.begin(), S2M.ends.end());
         row_form.swap(S1.form);
         row_form.insert(row_form.end(), S1M.form.begin(), S1M.form.end());
         row_form.insert(row_form.end(), S2.form.begin(), S2.form.end());
+        row_form.insert(row_form.end(), S2M.form.begin(), S2M.form.end());
+        row_gid.swap(S1.gid);
+        row_gid.insert(row_gid.end(), S1M.gid.begin(), S1M.gid.end());
+        row_gid.insert(row_gid.end(), S2.gid.begin(), S2.gid.end());
+        row_gid.insert(row_gid.end(), S2M.gid.begin(), S2M.gid.end());
     }
 
     lap("runs / stream split");
@@ -391,20 +464,20 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     // concatenated afterwards.  The cut points depend on the data only, not on the number of threads.
     struct Segment {
         size_t ra, rb;  // rows[ra, rb)
-        int stream;     // PSELL_A1, PSELL_A1M, PSELL_A2, PSELL_B
+        int stream;     // PSELL_A1 .. PSELL_B
         PsellHost frag;
     };
     std::vector<Segment> segs;
     {
         static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
         const size_t SEG_ROWS = seg_env >= 64 ? seg_env : (size_t)1 << 18;  // (a few hundred segments at BASELINE's C2: enough for ~50 host threads)
-        const size_t bounds[PSELL_NSTREAMS + 1] = {0, (size_t)out.rows_a1, (size_t)out.rows_a1m, (size_t)out.rows_a, rows.size()};
+        const size_t bounds[PSELL_NSTREAMS + 1] = {0, (size_t)out.rows_a1, (size_t)out.rows_a1m, (size_t)out.rows_a2, (size_t)out.rows_a, (size_t)out.rows_s, rows.size()};
         for (int st = 0; st < PSELL_NSTREAMS; ++st) {
             size_t a = bounds[st];
             while (a < bounds[st + 1]) {
                 size_t e = std::min(bounds[st + 1], a + SEG_ROWS);
                 if (e < bounds[st + 1]) {
-                    if (st != PSELL_B) {
+                    if (st != PSELL_B && st != PSELL_BN) {
                         while (e < bounds[st + 1] && !run_end[e - 1]) ++e;  // uniform streams: end on a closed slice
                     } else {  // mixed stream: whole tiles of 16 slices
                         const size_t tile_rows = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
@@ -444,10 +517,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
     slice_rows.reserve(PSELL_LANES);
     std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
-    std::vector<uint32_t> pattern, utmp;  // transcript set of the slice being closed (uniform streams)
+    std::vector<uint32_t> pattern;  // transcript set of the slice being closed (uniform streams)
     bool prev_uniform = false;
     int slice_form = 0;  // the slice being formed: 0 rows of one set, 1 dense union, 2 masked
-    const bool uniform_stream = cur_stream != PSELL_B;
+    uint32_t slice_gid = 0;  // ... forms 1, 2: its group
+    const bool uniform_stream = cur_stream != PSELL_B && cur_stream != PSELL_BN;
     auto close_slice = [&]() {
         if (slice_rows.empty()) return;
         uint32_t w = 0, longest = 0;
@@ -455,28 +529,25 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         w = longest;
         if (uniform_stream) {  // the slice's transcript set: its rows' common set, or their union
             const uint32_t r0 = slice_rows[0];
-            pattern.assign(col + rowptr[r0], col + rowptr[r0 + 1]);
-            if (slice_form != 0) {
-                for (size_t lane = 1; lane < slice_rows.size(); ++lane) {
-                    const uint32_t r = slice_rows[lane];
-                    utmp.resize(pattern.size() + (size_t)(rowptr[r + 1] - rowptr[r]));
-                    utmp.resize((size_t)(std::set_union(pattern.begin(), pattern.end(), col + rowptr[r], col + rowptr[r + 1], utmp.begin()) - utmp.begin()));
-                    pattern.swap(utmp);
-                }
-            }
+            if (slice_form != 0)
+                pattern = patterns[slice_gid];  // the union of the slice's GROUP (a superset of its rows' sets)
+            else
+                pattern.assign(col + rowptr[r0], col + rowptr[r0 + 1]);
             w = (uint32_t)pattern.size();
         }
         const size_t base = out.data.size();
         uint32_t stored_rows = w;  // rows of 64 values the slice stores
-        if (cur_stream == PSELL_A1M) {
-            // masked slice: uint16 lcol[16] (PSELL_NO_COL past the union); at byte 128 uint16 mask[64]; then
-            // float val[i][64] = the i-th non-zero of the fragment in lane r, i < longest row (+ the ks row)
+        if (cur_stream == PSELL_A1M || cur_stream == PSELL_A2M) {
+            // masked slice: header rows of uint32 hw[64] -- one for unions of <= 16, two for 17..32: low half = bits
+            // 0..15 (16..31) of the mask of the fragment in lane r; high half, r < 16: tile-local id of transcript r
+            // (16 + r) of the union, PSELL_NO_COL past it -- then float val[i][64] = the i-th non-zero of the fragment in
+            // lane r, i < longest row (+ the ks row)
+            const size_t hrows = cur_stream == PSELL_A1M ? 1 : 2;
             stored_rows = longest;
-            out.data.resize(base + 256 + (size_t)longest * 256 + (ks ? 256 : 0), 0);
-            uint16_t *hdr = reinterpret_cast<uint16_t *>(out.data.data() + base);
-            uint16_t *mask = hdr + 64;
-            float *vals = reinterpret_cast<float *>(out.data.data() + base + 256);
-            for (uint32_t t = 0; t < (uint32_t)PSELL_NARROW_MAX; ++t) hdr[t] = t < w ? col_local[pattern[t]] : PSELL_NO_COL;
+            out.data.resize(base + 256 * hrows + (size_t)longest * 256 + (ks ? 256 : 0), 0);
+            uint32_t *hw = reinterpret_cast<uint32_t *>(out.data.data() + base);
+            float *vals = reinterpret_cast<float *>(out.data.data() + base + 256 * hrows);
+            for (uint32_t t = 0; t < 16u * hrows; ++t) hw[(t >> 4) * 64 + (t & 15)] = (uint32_t)(t < w ? col_local[pattern[t]] : PSELL_NO_COL) << 16;
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
                 const uint64_t b = rowptr[slice_rows[lane]], e = rowptr[slice_rows[lane] + 1];
                 uint32_t t = 0, mk = 0;
@@ -485,10 +556,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     mk |= 1u << t;
                     vals[(size_t)(k - b) * 64 + lane] = val[k];
                 }
-                mask[lane] = (uint16_t)mk;
+                hw[lane] |= mk & 0xffffu;
+                if (hrows == 2) hw[64 + lane] |= mk >> 16;
             }
             if (ks) {
-                float *kr = reinterpret_cast<float *>(out.data.data() + base + 256 + (size_t)longest * 256);
+                float *kr = reinterpret_cast<float *>(out.data.data() + base + 256 * hrows + (size_t)longest * 256);
                 for (size_t lane = 0; lane < slice_rows.size(); ++lane) kr[lane] = (float)ks[slice_rows[lane]];
             }
         } else if (uniform_stream) {
@@ -518,8 +590,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 }
             }
         } else {
-            // mixed stream: float val[w][64]; uint16 lcol[w][64], padded to a multiple of 256 bytes
-            out.data.resize(base + (((size_t)w * 384 + 255) & ~(size_t)255), 0);
+            // mixed streams: float val[w][64]; uint16 lcol[w][64], padded to a multiple of 256 bytes; in stream BN with
+            // multiplicities a row float ks[64] follows
+            const size_t body = ((size_t)w * 384 + 255) & ~(size_t)255;
+            out.data.resize(base + body + (ks && cur_stream == PSELL_BN ? 256 : 0), 0);
+            if (ks && cur_stream == PSELL_BN) {
+                float *kr = reinterpret_cast<float *>(out.data.data() + base + body);
+                for (size_t lane = 0; lane < slice_rows.size(); ++lane) kr[lane] = (float)ks[slice_rows[lane]];
+            }
             float *vals = reinterpret_cast<float *>(out.data.data() + base);
             uint16_t *lcols = reinterpret_cast<uint16_t *>(out.data.data() + base + (size_t)w * 256);
             for (size_t lane = 0; lane < slice_rows.size(); ++lane) {
@@ -595,17 +673,21 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
 
     for (size_t ri = sg.ra; ri < sg.rb; ++ri) {
         const uint32_t r = rows[ri];
-        const uint64_t b = rowptr[r], e = rowptr[r + 1];
+        // the transcripts this row needs in the tile's dictionary: its own, or -- a row of a union / masked group -- the
+        // whole set of its group (the slice's header lists every one of them)
+        const bool grouped = uniform_stream && row_form[ri] != 0;
+        const uint32_t *cb = grouped ? patterns[row_gid[ri]].data() : col + rowptr[r];
+        const uint32_t *ce = grouped ? cb + patterns[row_gid[ri]].size() : col + rowptr[r + 1];
         for (;;) {
             uint32_t fresh = 0;
-            for (uint64_t k = b; k < e; ++k) fresh += col_stamp[col[k]] != tile_id;
+            for (const uint32_t *c = cb; c < ce; ++c) fresh += col_stamp[*c] != tile_id;
             if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && slice_rows.empty())) break;
             // does not fit into the current tile: finish it (possibly with a partial slice)
             close_slice();
             close_tile();
         }
-        for (uint64_t k = b; k < e; ++k) {
-            const uint32_t c = col[k];
+        for (const uint32_t *cp = cb; cp < ce; ++cp) {
+            const uint32_t c = *cp;
             if (col_stamp[c] != tile_id) {
                 col_stamp[c] = tile_id;
                 col_local[c] = (uint16_t)tile_cols++;
@@ -613,13 +695,17 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
         slice_rows.push_back(r);
-        if (uniform_stream) slice_form = std::max<int>(slice_form, row_form[ri]);
+        if (uniform_stream) {
+            slice_form = std::max<int>(slice_form, row_form[ri]);
+            slice_gid = row_gid[ri];
+        }
         const bool boundary = uniform_stream ? run_end[ri] != 0 : slice_rows.size() == PSELL_LANES;
         if (boundary) {
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
             const uint32_t cap = cur_stream == PSELL_A1 || cur_stream == PSELL_A1M ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
-                                 : cur_stream == PSELL_A2 ? (uint32_t)a2cap : PSELL_TILE_SLICES_B;
+                                 : cur_stream == PSELL_A2 ? (uint32_t)a2cap : cur_stream == PSELL_A2M ? (uint32_t)PSELL_TILE_SLICES_A2M
+                                 : cur_stream == PSELL_BN ? (uint32_t)PSELL_TILE_SLICES_BN : (uint32_t)PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }
     }
@@ -667,10 +753,12 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         auto stream_ends = [&](int st) {  // stream `st` ends at the current tile / slice count
             if (st == PSELL_A1) out.num_tiles_a1 = out.num_tiles;
             if (st == PSELL_A1M) out.num_tiles_a1m = out.num_tiles;
-            if (st == PSELL_A2) {
+            if (st == PSELL_A2) out.num_tiles_a2 = out.num_tiles;
+            if (st == PSELL_A2M) {
                 out.num_tiles_a = out.num_tiles;
                 out.num_slices_a = out.num_slices;
             }
+            if (st == PSELL_BN) out.num_tiles_s = out.num_tiles;
         };
         for (size_t si = 0; si < segs.size(); ++si) {
             Segment &sg = segs[si];

@@ -48,7 +48,10 @@ def test_diverse_sets_match_oracle(P, ctx, case, K):
                        xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
     info = s.info
     assert sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == m
-    assert info["stream_nnz"][1] > 0.02 * smp["nnz"], info["stream_nnz"]  # the masked stream is in use
+    assert info["stream_nnz"][1] > 0.02 * smp["nnz"], info["stream_nnz"]  # the masked streams are in use
+    assert info["stream_nnz"][3] > 0.01 * smp["nnz"], info["stream_nnz"]
+    assert info["stream_nnz"][4] < 0.05 * smp["nnz"], info["stream_nnz"]  # ... and little is left to the mixed one
+    assert info["stream_tiles"][5] == 0  # one launch
     # never more bytes than CSR, whatever the sets look like
     csr = 8 * smp["nnz"] + 4 * (m + 1)
     assert sum(info["stream_bytes_hbm"]) < 0.85 * csr, (sum(info["stream_bytes_hbm"]) / smp["nnz"], csr / smp["nnz"])
@@ -83,7 +86,7 @@ def test_diverse_sets_with_multiplicities_and_deterministic_mode(P, ctx):
     lp1, g1 = s.log_likelihood(x)
     lp2, g2 = s.log_likelihood(x)
     L.check(L.lib().polee_loglik_set_deterministic(s._h, 0))
-    if s.info["stream_tiles"][3] == 0:  # (mixed tiles use float atomics in either mode)
+    if s.info["stream_tiles"][5] == 0:  # (the per-tile kernel's tiles use float atomics in either mode)
         assert (g1 == g2).all() and (lp1 == lp2).all()
     lp3, g3 = s.log_likelihood(x)
     np.testing.assert_allclose(g1, g3, rtol=2e-4, atol=1e-6 * np.abs(g3).max())

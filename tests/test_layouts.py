@@ -141,7 +141,8 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
     out = dict(num_slices=v.num_slices, num_tiles=v.num_tiles, padded_nnz=v.padded_nnz, nnz=v.nnz,
                empty=v.num_empty_rows, max_tile_cols=v.max_tile_cols, max_row=v.max_row_nnz,
-               num_tiles_a=v.num_tiles_a, num_tiles_a1=v.num_tiles_a1, num_tiles_a1m=v.num_tiles_a1m)
+               num_tiles_a=v.num_tiles_a, num_tiles_a1=v.num_tiles_a1, num_tiles_a1m=v.num_tiles_a1m, num_tiles_a2=v.num_tiles_a2, num_tiles_s=v.num_tiles_s,
+               stream_nnz=list(v.stream_nnz), stream_bytes=list(v.stream_bytes))
     out["slice_w"] = np.ctypeslib.as_array(v.slice_w, shape=(v.num_slices,)).copy()
     out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
     raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
@@ -169,20 +170,25 @@ def _emulate_psell(ps, x, n):
         for s in range(ps["tile_slice"][t], ps["tile_slice"][t + 1]):
             off = int(ps["slice_off"][s]) * 128
             nbytes = int(ps["slice_off"][s + 1]) * 128 - off
-            if ps["num_tiles_a1"] <= t < ps["num_tiles_a1m"]:
-                # masked uniform slice: uint16 lcol[16] (0xffff past the union), uint16 mask[64] at byte 128, then
-                # val[i][r] = the i-th non-zero of the fragment in lane r
-                nrows = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
+            if ps["num_tiles_a1"] <= t < ps["num_tiles_a1m"] or ps["num_tiles_a2"] <= t < ps["num_tiles_a"]:
+                # masked uniform slice: one (unions of <= 16) or two (17..32) header rows of uint32 hw[64] (low half: 16
+                # bits of the mask of the fragment in lane r; high half of a row's hw[t], t < 16: tile-local id of that
+                # transcript of the union, 0x8000 past it), then val[i][r] = the i-th non-zero of the fragment in lane r
+                hrows = 1 if t < ps["num_tiles_a1m"] else 2
+                nrows = nbytes // 256 - hrows - (0 if ps["ks"] is None else 1)
                 assert ps["slice_flags"][s] & 1
-                hdr = data[off:off + 32].view(np.uint16).astype(np.int64)
-                w = int((hdr != 0xFFFF).sum())
-                assert w == ps["slice_w"][s] and (hdr[:w] != 0xFFFF).all() and 1 <= w <= 16
-                mask = data[off + 128:off + 256].view(np.uint16).astype(np.int64)
-                packed = data[off + 256:off + 256 + nrows * 256].view(np.float32).reshape(nrows, 64)
+                hw = data[off:off + 256 * hrows].view(np.uint32).astype(np.int64).reshape(hrows, 64)
+                assert np.isfinite(data[off:off + nbytes].view(np.float32)).all()  # (stale ring bytes are multiplied by 0)
+                hdr = (hw[:, :16] >> 16).ravel()
+                w = int((hdr != 0x8000).sum())
+                assert w == ps["slice_w"][s] and (hdr[:w] != 0x8000).all() and (hw[:, 16:] >> 16 == 0).all()
+                assert 1 <= w <= 16 if hrows == 1 else 17 <= w <= 32
+                mask = (hw[0] & 0xFFFF) | ((hw[1] & 0xFFFF) << 16 if hrows == 2 else 0)
+                voff = off + 256 * hrows
+                packed = data[voff:voff + nrows * 256].view(np.float32).reshape(nrows, 64)
                 if ps["ks"] is not None:
-                    np.testing.assert_array_equal(data[off + 256 + nrows * 256:off + 512 + nrows * 256].view(np.float32),
+                    np.testing.assert_array_equal(data[voff + nrows * 256:voff + 256 + nrows * 256].view(np.float32),
                                                   ps["ks"][s * 64:(s + 1) * 64])
-                assert (mask >> w == 0).all()
                 cnt = np.array([bin(int(mk)).count("1") for mk in mask])
                 assert cnt.max() == nrows  # padded to the slice's longest fragment, no further
                 vals = np.zeros((w, 64), np.float32)
@@ -193,6 +199,7 @@ def _emulate_psell(ps, x, n):
                             vals[tt, r] = packed[i, r]
                             i += 1
                     assert (packed[i:, r] == 0).all()
+                assert (mask >> w == 0).all()
                 cols = np.repeat(hdr[:w, None], 64, axis=1)
             elif t < ps["num_tiles_a"]:  # compact uniform slice: one column-id header, then the values
                 w = nbytes // 256 - 1 - (0 if ps["ks"] is None else 1)
@@ -210,8 +217,13 @@ def _emulate_psell(ps, x, n):
                     vals = np.stack([rot[tt][r64 ^ (tt & 3)] for tt in range(w)]) if w else rot
                 else:
                     vals = np.stack([rot[tt][(r64 + 4 * tt) & 63] for tt in range(w)]) if w else rot
-            else:
-                w = nbytes // 384
+            else:  # mixed slice (stream BN: with multiplicities a row float ks[64] follows at the next multiple of 256 bytes)
+                has_ks_row = ps["ks"] is not None and t < ps["num_tiles_s"]
+                w = (nbytes - (256 if has_ks_row else 0)) // 384
+                assert min(w, 255) == ps["slice_w"][s]
+                if has_ks_row:
+                    np.testing.assert_array_equal(data[off + nbytes - 256:off + nbytes].view(np.float32), ps["ks"][s * 64:(s + 1) * 64])
+                    assert w <= 15
                 vals = data[off:off + w * 256].view(np.float32).reshape(w, 64)
                 cols = data[off + w * 256:off + w * 384].view(np.uint16).reshape(w, 64).astype(np.int64)
             assert cols.max(initial=0) < d1 - d0

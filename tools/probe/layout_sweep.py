@@ -32,8 +32,8 @@ def build_stats(smp):
                stored_bytes_per_nnz=(v.data_bytes + 4 * (v.num_slices + 1) + 4 * v.dict_len) / nnz,
                csr_bytes_per_nnz=(8 * nnz + 4 * (m + 1)) / nnz, build_s=dt, tiles=int(v.num_tiles),
                tiles_a=int(v.num_tiles_a), tiles_a1=int(v.num_tiles_a1),
-               share=[v.stream_nnz[i] / nnz for i in range(4)],
-               bpn=[v.stream_bytes[i] / max(v.stream_nnz[i], 1) for i in range(4)])
+               share=[v.stream_nnz[i] / nnz for i in range(6)],
+               bpn=[v.stream_bytes[i] / max(v.stream_nnz[i], 1) for i in range(6)])
     L.lib().polee_debug_psell_free(h)
     return out
 
@@ -54,7 +54,7 @@ def cases(wl, names):
 if __name__ == "__main__":
     wl = sys.argv[1] if len(sys.argv) > 1 else "small"
     names = sys.argv[2:] or ["p0", "p0.1", "p0.3", "literal", "fixture"]
-    print("| input | nnz/row | stored entries / nnz | stored bytes / nnz | CSR bytes / nnz | build s | share of nnz: dense<=16 / masked / dense 17..32 / mixed | slice bytes / nnz per stream |")
+    print("| input | nnz/row | stored entries / nnz | stored bytes / nnz | CSR bytes / nnz | build s | share of nnz: dense<=16 / masked<=16 / dense 17..32 / masked 17..32 / mixed<=15 / mixed (2nd launch) | slice bytes / nnz per stream |")
     print("|---|---|---|---|---|---|---|---|")
     for name, smp in cases(wl, names):
         s = build_stats(smp)
