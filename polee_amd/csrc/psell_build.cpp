@@ -252,6 +252,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         static const bool no_mask = getenv("POLEE_PSELL_NO_MASK") != nullptr;
         static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.15;
         static const double over_budget = getenv("POLEE_PSELL_OVER_BUDGET") ? atof(getenv("POLEE_PSELL_OVER_BUDGET")) : 0.02;
+        static const double relax = getenv("POLEE_PSELL_RELAX") ? atof(getenv("POLEE_PSELL_RELAX")) : 2.0;
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
@@ -334,7 +335,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                                 const double budget = 8.0 * (double)total + 4.0 * (double)(c1 - c0);  // (CSR's cost of these rows)
                                 const double cost = std::min(dense_bytes, masked_bytes);
                                 bool worth = cost <= budget;
-                                if (!worth && longest > (size_t)PSELL_MIXED_NARROW_MAX && cost - budget <= allowance) {
+                                // (second pass: a slice up to `relax` times CSR's cost is still better than what is left
+                                // for its rows -- mixed tiles of some twenty unrelated fragments each --, and rows too long
+                                // for stream BN are kept at any cost; both within the allowance)
+                                if (!worth && pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX) && cost - budget <= allowance) {
                                     allowance -= cost - budget;
                                     worth = true;
                                 }
