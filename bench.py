@@ -122,6 +122,25 @@ def init_ranks():
     return world, rank, local_rank, dist, backend
 
 
+def make_comm(P, ctx, world, rank, dist, backend):
+    """The fit's / model's communicator: RCCL (one GPU per rank), or -- test hook POLEE_BENCH_BACKEND=gloo, ranks sharing a
+    GPU -- the library's host-staged communicator over the gloo group."""
+    if dist is not None and backend != "nccl":
+        import torch
+
+        def allreduce(a):
+            dist.all_reduce(torch.from_numpy(a))  # (shares the array's memory: summed in place)
+        return P.HostComm(ctx, world, rank, allreduce)
+
+    def bcast(raw):
+        if dist is None:
+            return raw
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    return P.Comm(ctx, world, rank, broadcast=bcast)
+
+
 def regression_bench(args):
     """`--workload c3|c4`: the regression model's variational step (models/polee_regression.py fit): synthetic
     approximation parameters (mu ~ N(0,2), omega ~ N(-1,1), alpha ~ N(0,.3)), device RNG.  A step = one
@@ -161,11 +180,7 @@ def regression_bench(args):
     scales = P.estimate_sample_scales(x0)
     comm = None
     if world > 1:
-        def bcast(raw):
-            box = [raw]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comm = P.Comm(ctx, world, rank, broadcast=bcast)
+        comm = make_comm(P, ctx, world, rank, dist, backend)
         kw = shard_regression_inputs(vars_, x0, design, scales, world, rank)
         lik = P.RNASeqApproxLikelihood(kw["vars"], ctx=ctx)
         reg = P.RNASeqTranscriptLinearRegression(lik, kw["x_init"], kw["F_arr"], kw["sample_scales"], True, 1.0, False,
@@ -288,14 +303,7 @@ def main():
             from polee_amd.cohort import shard_rows, take_rows
             r0, r1 = shard_rows(smp_i["tcolptr"], world, rank)
             xt_i, m_i = take_rows(smp_i["tcolptr"], smp_i["trowval"], smp_i["tnzval"], r0, r1), r1 - r0
-
-            def bcast(raw):
-                if dist is None:
-                    return raw
-                box = [raw]
-                dist.broadcast_object_list(box, src=0)
-                return box[0]
-            comm = P.Comm(ctx_i, world, rank, broadcast=bcast)
+            comm = make_comm(P, ctx_i, world, rank, dist, backend)
         sample_i = P.RNASeqSample(m_i, n, None, None, None, smp_i["effective_lengths"], ctx=ctx_i, xt=xt_i)
         tree_i = P.PolyaTreeTransform(parents, js, ctx=ctx_i)
         t_build += time.time() - t0

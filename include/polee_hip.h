@@ -155,8 +155,9 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
 /* Deterministic mode ("fixed reduction order ... bitwise stable"): the gradient (and lp) of a pass is
  * summed in a fixed order -- per wave, per tile, then per transcript in tile order -- instead of with float atomics, so
  * that two evaluations on the same inputs agree bit for bit (and with them a whole fit with the same noise).  About 25 %
- * slower (three workgroups per CU instead of four, a second small kernel).  Rows with more than 32 transcripts are still
- * added with atomics.  Default off. */
+ * slower (three workgroups per CU instead of four, a second small kernel).  Fragments in the per-tile kernel's stream
+ * (polee_loglik_info.stream_tiles[5] > 0: more than 32 transcripts, as a rule) are still added with float atomics: the
+ * guarantee holds when that stream is empty.  Default off. */
 polee_status polee_loglik_set_deterministic(polee_loglik *ll, int on);
 
 /* log_likelihood (src/likelihood.jl:36-56) for K expression vectors at once:
@@ -221,7 +222,8 @@ typedef struct {
     double adam_rm;                    /* 0.7  */
     double max_mu_step, max_omega_step, max_alpha_step; /* 0.2, 0.2, 0.02 */
     int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events  */
-    int32_t deterministic;       /* 1: polee_loglik_set_deterministic(ll, 1) for this fit's likelihood handle    */
+    int32_t deterministic;       /* 1: this fit's likelihood passes run in deterministic mode (the handle's own  */
+                                 /* polee_loglik_set_deterministic setting is untouched)                         */
     const int32_t *gene_of;      /* optional HOST int32[n]: gene index of every transcript (0-based, -1 = none   */
                                  /* known) = gene_noninformative = true (likelihood-approximation.jl:475-491,     */
                                  /* 535-538: gene_noninformative_prior! after the effective-length adjustment,   */
@@ -303,6 +305,13 @@ typedef struct polee_comm polee_comm;
 polee_status polee_comm_unique_id(uint8_t id[POLEE_COMM_ID_BYTES]);
 polee_status polee_comm_create(polee_ctx *ctx, int32_t nranks, int32_t rank,
                                const uint8_t id[POLEE_COMM_ID_BYTES], polee_comm **out);
+/* The same communicator interface over a HOST all-reduce supplied by the caller (MPI_Allreduce, a torch.distributed
+ * gloo group, ...): the library stages the buffer through host memory (stream-synchronising; for clusters without
+ * RCCL between the ranks, and for tests that run two ranks on one GPU).  `allreduce(user, buf, count, is_f64)` must sum
+ * `buf` (count f32 / f64 values) over all ranks in place and return 0. */
+typedef int (*polee_host_allreduce_fn)(void *user, void *buf, int64_t count, int is_f64);
+polee_status polee_comm_create_host(polee_ctx *ctx, int32_t nranks, int32_t rank, polee_host_allreduce_fn allreduce,
+                                    void *user, polee_comm **out);
 void polee_comm_destroy(polee_comm *comm);
 int32_t polee_comm_rank(const polee_comm *comm);
 int32_t polee_comm_size(const polee_comm *comm);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpolee_hip.so")
+# (POLEE_HIP_LIB: another build of the same library -- the toolchain gate test loads csrc/libpolee_hip_untuned.so)
+LIB_PATH = os.environ.get("POLEE_HIP_LIB") or os.path.join(_HERE, "csrc", "libpolee_hip.so")
 
 _lib = None
 

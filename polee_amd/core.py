@@ -442,6 +442,31 @@ class Comm:
         return v
 
 
+class HostComm(Comm):
+    """The communicator interface over a HOST all-reduce supplied by the caller (polee_comm_create_host): `allreduce`
+    receives a float32 / float64 NumPy array and must sum it over all ranks IN PLACE (MPI Allreduce, a torch.distributed
+    gloo group, ...).  For clusters without RCCL between the ranks and for tests with several ranks on one GPU."""
+
+    _CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+    def __init__(self, ctx, world_size, rank, allreduce):
+        self.ctx, self.world_size, self.rank = ctx, int(world_size), int(rank)
+
+        def cb(_user, buf, count, is_f64):
+            try:
+                ct = C.c_double if is_f64 else C.c_float
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ct)), shape=(int(count),))
+                allreduce(a)
+                return 0
+            except Exception:  # (an exception must not unwind through the C frames)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = HostComm._CB(cb)  # (kept alive with the handle)
+        self._h = C.c_void_p()
+        check(L.lib().polee_comm_create_host(ctx._h, self.world_size, self.rank, self._cb, None, C.byref(self._h)), ctx._h)
+
+
 class LikelihoodApproximationFit:
     """State of one fit (polee_vi): lets callers step the VI loop and inspect it."""
 

@@ -1,8 +1,10 @@
 // Collective for a sample whose fragments are sharded over the GPUs of a node: every rank
 // holds a contiguous block of X's rows and the full O(n) state; per likelihood pass the partial gradients
 // (K*n f32) and log-likelihoods are summed over ranks with ONE all-reduce; everything else is replicated.
-// RCCL is bound at run time (dlopen) so that single-GPU users need not have it.
+// RCCL is bound at run time (dlopen) so that single-GPU users need not have it; the prototypes, the id type and the
+// enumerators come from its own header, <rccl/rccl.h>.
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include "comm_internal.hpp"
 
@@ -11,11 +13,11 @@ namespace polee {
 namespace {
 struct Rccl {
     void *lib = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
 Rccl *rccl(std::string &err)
@@ -59,16 +61,28 @@ Rccl *rccl(std::string &err)
     }
     return &r;
 }
-constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values (rccl.h)
 }  // namespace
 
 polee_status comm_allreduce_device(polee_comm *c, void *buf, size_t count, bool f64)
 {
+    if (c->host_allreduce) {
+        // host-staged communicator (polee_comm_create_host): the buffer goes through host memory and the caller's
+        // all-reduce (MPI, gloo, ...) -- for clusters without RCCL between the ranks, and for two ranks sharing one GPU
+        const size_t bytes = count * (f64 ? sizeof(double) : sizeof(float));
+        c->staging.resize(bytes);
+        POLEE_HIP_TRY(c->ctx, hipMemcpyAsync(c->staging.data(), buf, bytes, hipMemcpyDeviceToHost, c->ctx->stream));
+        POLEE_HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+        const int rc = c->host_allreduce(c->host_user, c->staging.data(), (int64_t)count, f64 ? 1 : 0);
+        if (rc != 0) return fail(c->ctx, POLEE_ERR_HIP, "the host all-reduce callback failed (%d)", rc);
+        POLEE_HIP_TRY(c->ctx, hipMemcpyAsync(buf, c->staging.data(), bytes, hipMemcpyHostToDevice, c->ctx->stream));
+        POLEE_HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+        return POLEE_OK;
+    }
     std::string err;
     Rccl *r = rccl(err);
     if (!r) return fail(c->ctx, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
-    const int rc = r->AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, c->comm, c->ctx->stream);
-    if (rc != 0)
+    const ncclResult_t rc = r->AllReduce(buf, buf, count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<ncclComm_t>(c->comm), c->ctx->stream);
+    if (rc != ncclSuccess)
         return fail(c->ctx, POLEE_ERR_HIP, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
     return POLEE_OK;
 }
@@ -85,9 +99,11 @@ polee_status polee_comm_unique_id(uint8_t id[POLEE_COMM_ID_BYTES])
     std::string err;
     Rccl *r = rccl(err);
     if (!r) return fail(nullptr, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
-    static_assert(sizeof(RcclUniqueId) == POLEE_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-    const int rc = r->GetUniqueId(id);
-    if (rc != 0) return fail(nullptr, POLEE_ERR_HIP, "ncclGetUniqueId failed (%d)", rc);
+    static_assert(sizeof(ncclUniqueId) == POLEE_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId uid;
+    const ncclResult_t rc = r->GetUniqueId(&uid);
+    if (rc != ncclSuccess) return fail(nullptr, POLEE_ERR_HIP, "ncclGetUniqueId failed (%d)", (int)rc);
+    memcpy(id, &uid, POLEE_COMM_ID_BYTES);
     return POLEE_OK;
 }
 
@@ -100,11 +116,11 @@ polee_status polee_comm_create(polee_ctx *ctx, int32_t nranks, int32_t rank, con
     std::string err;
     Rccl *r = rccl(err);
     if (!r) return fail(ctx, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
-    RcclUniqueId uid;
-    memcpy(uid.bytes, id, POLEE_COMM_ID_BYTES);
-    void *comm = nullptr;
-    const int rc = r->CommInitRank(&comm, nranks, uid, rank);
-    if (rc != 0 || !comm)
+    ncclUniqueId uid;
+    memcpy(&uid, id, POLEE_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = r->CommInitRank(&comm, nranks, uid, rank);
+    if (rc != ncclSuccess || !comm)
         return fail(ctx, POLEE_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
     polee_comm *c = new (std::nothrow) polee_comm();
     if (!c) {
@@ -120,14 +136,34 @@ polee_status polee_comm_create(polee_ctx *ctx, int32_t nranks, int32_t rank, con
     return POLEE_OK;
 }
 
+polee_status polee_comm_create_host(polee_ctx *ctx, int32_t nranks, int32_t rank, polee_host_allreduce_fn allreduce, void *user,
+                                    polee_comm **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!out || !allreduce || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_comm_create_host: bad argument (rank %d of %d)", rank, nranks);
+    polee_comm *c = new (std::nothrow) polee_comm();
+    if (!c) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    c->ctx = ctx;
+    c->host_allreduce = allreduce;
+    c->host_user = user;
+    c->nranks = nranks;
+    c->rank = rank;
+    ctx_retain(ctx);
+    *out = c;
+    return POLEE_OK;
+}
+
 void polee_comm_destroy(polee_comm *c)
 {
     if (!c) return;
     if (--c->refs > 0) return;
     std::string err;
-    if (Rccl *r = rccl(err)) {
-        (void)hipStreamSynchronize(c->ctx->stream);
-        r->CommDestroy(c->comm);
+    if (c->comm) {
+        if (Rccl *r = rccl(err)) {
+            (void)hipStreamSynchronize(c->ctx->stream);
+            r->CommDestroy(static_cast<ncclComm_t>(c->comm));
+        }
     }
     polee_ctx *ctx = c->ctx;
     delete c;

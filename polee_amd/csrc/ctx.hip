@@ -27,7 +27,11 @@ using namespace polee;
 
 extern "C" {
 
-const char *polee_version(void) { return "polee_hip 0.1 (gfx950)"; }
+#ifndef POLEE_BUILD_INFO
+#define POLEE_BUILD_INFO "unknown compiler"
+#endif
+// (the build records the hipcc version and the backend tuning flags loglik.hip was compiled with: csrc/Makefile)
+const char *polee_version(void) { return "polee_hip 0.3 (gfx950); " POLEE_BUILD_INFO; }
 
 polee_status polee_ctx_create(int device, polee_ctx **out)
 {

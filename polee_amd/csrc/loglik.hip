@@ -288,19 +288,19 @@ __device__ inline void dma_1k(const void *base_uniform, uint32_t voff, uint32_t 
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" POLEE_DMA_POLICY
                  :
                  : "s"(base_uniform), "v"(voff), "s"(lds_dst)
-                 : "memory");
+                 : "memory", "m0");
 }
 // the same with the default cache policy (x windows: written by the previous kernel)
 __device__ inline void dma_1k_keep(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
 // 4 bytes per lane: 64 dwords -> 256 contiguous LDS bytes
 __device__ inline void dma_256(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory", "m0");
 }
 __device__ inline uint32_t lds_addr(const void *p)
 {

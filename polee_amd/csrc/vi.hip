@@ -218,7 +218,13 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
-    POLEE_TRY(loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr));
+    {
+        const bool det_saved = vi->ll->deterministic;
+        if (o.deterministic) vi->ll->deterministic = true;
+        const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr);
+        vi->ll->deterministic = det_saved;
+        POLEE_TRY(ls);
+    }
     if (vi->comm) {  // this rank saw only its block of fragments: x_grad and lp are sums over fragments
         POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_g.p, (size_t)n * K, false));
         if (want_values) POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_lp.p, (size_t)K, true));
@@ -488,7 +494,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     vi->n = t->n;
     vi->K = o.num_mc_samples;
     ll->profile = o.profile != 0;
-    if (o.deterministic) ll->deterministic = true;
+    // (opts.deterministic belongs to THIS fit: applied around its likelihood passes, the handle's own setting restored)
     const size_t n = vi->n, nm1 = std::max<size_t>(n - 1, 1), K = vi->K;
     polee_status s = POLEE_OK;
     auto A = [&](polee_status r) {

@@ -1,6 +1,8 @@
-"""More than one process on the GPU box: the launch path of `bench.py --gpus N` with real fits, and -- when the box
-has at least two GPUs -- the RCCL exchange steps of SURVEY.md 8(e) with two ranks (row-sharded fit, sample-sharded
-regression).  The driver's GPU boxes hold ONE MI355X, where RCCL cannot place two ranks; those tests skip there."""
+"""More than one process on the GPU box: the launch path of `bench.py --gpus N` with real fits, and the exchange steps
+of SURVEY.md 8(e) with TWO RANKS (row-sharded fit, sample-sharded regression).  With at least two GPUs they run over
+RCCL; the driver's GPU boxes hold ONE MI355X, where RCCL cannot place two ranks: there both ranks share the GPU and the
+all-reduce goes through the library's host-staged communicator (polee_comm_create_host) over a gloo group -- the same
+polee_vi_set_comm / polee_regression_set_comm paths, a different transport."""
 import json
 import os
 import subprocess
@@ -44,17 +46,17 @@ def test_bench_gpus_2_runs_two_fits_on_this_box():
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
 
 
+def _hooks():
+    return {} if _num_gpus() >= 2 else dict(POLEE_BENCH_BACKEND="gloo", POLEE_BENCH_FORCE_DEVICE="0")
+
+
 def test_bench_row_shard_two_ranks():
-    if _num_gpus() < 2:
-        pytest.skip("RCCL needs one GPU per rank; this box has %d" % _num_gpus())
-    d = _bench(["--gpus", "2", "--workload", "c1", "--steps", "20", "--warmup", "3", "--row-shard"])
+    d = _bench(["--gpus", "2", "--workload", "c1", "--steps", "20", "--warmup", "3", "--row-shard"], **_hooks())
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
 
 
 def test_bench_regression_two_ranks():
-    if _num_gpus() < 2:
-        pytest.skip("RCCL needs one GPU per rank; this box has %d" % _num_gpus())
-    d = _bench(["--gpus", "2", "--workload", "c3", "--steps", "20", "--warmup", "3"])
+    d = _bench(["--gpus", "2", "--workload", "c3", "--steps", "20", "--warmup", "3"], **_hooks())
     assert d["n_gpus"] == 2 and d["detail"]["finite"]
 
 
@@ -64,8 +66,13 @@ sys.path.insert(0, os.environ["POLEE_ROOT"])
 import numpy as np, scipy.sparse as sp, torch
 import torch.distributed as dist
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-torch.cuda.set_device(local)
-dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+host = os.environ.get("POLEE_TEST_TRANSPORT") == "host"  # both ranks on GPU 0, all-reduce staged through gloo
+if host:
+    local = 0
+    dist.init_process_group("gloo")
+else:
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 import polee_amd as P
 from polee_amd.cohort import shard_rows, take_rows
 g = os.path.join(os.environ["POLEE_ROOT"], "tests", "golden")
@@ -79,7 +86,10 @@ steps, K = 25, 6
 z0 = np.random.default_rng(11).standard_normal(steps * K * (n - 1)).astype(np.float32)
 def bcast(raw):
     box = [raw]; dist.broadcast_object_list(box, src=0); return box[0]
-comm = P.Comm(ctx, world, rank, broadcast=bcast)
+if host:
+    comm = P.HostComm(ctx, world, rank, lambda a: dist.all_reduce(torch.from_numpy(a)))
+else:
+    comm = P.Comm(ctx, world, rank, broadcast=bcast)
 r0, r1 = shard_rows(tp, world, rank)
 s = P.RNASeqSample(r1 - r0, n, None, None, None, d["effective_lengths"], ctx=ctx, xt=take_rows(tp, tr, tv, r0, r1))
 t = P.PolyaTreeTransform(pr["node_parent_idxs"], pr["node_js"], ctx=ctx)
@@ -101,11 +111,13 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_rccl_row_sharded_fit_equals_single_rank(tmp_path):
-    """the row-sharded VI path (all-reduce of g and lp on the fit's stream) with TWO RCCL ranks: the fitted
+@pytest.mark.parametrize("transport", ["rccl", "host"])
+def test_two_rank_row_sharded_fit_equals_single_rank(tmp_path, transport):
+    """The row-sharded VI path (all-reduce of g and lp per pass, polee_vi_set_comm) with TWO ranks: the fitted
     parameters are identical on both ranks and equal the single-rank fit of the whole sample up to the f32 summation
-    order of the gradient."""
-    if _num_gpus() < 2:
+    order of the gradient.  "rccl": one GPU per rank; "host": both ranks on GPU 0, the library's host-staged
+    communicator over gloo (runs on the 1-GPU boxes)."""
+    if transport == "rccl" and _num_gpus() < 2:
         pytest.skip("RCCL needs one GPU per rank; this box has %d" % _num_gpus())
     import socket
     script = tmp_path / "row_fit_worker.py"
@@ -115,7 +127,8 @@ def test_two_rank_rccl_row_sharded_fit_equals_single_rank(tmp_path):
         port = s.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         env=_clean_env(POLEE_ROOT=ROOT), capture_output=True, text=True, timeout=600)
+                         env=_clean_env(POLEE_ROOT=ROOT, **({"POLEE_TEST_TRANSPORT": "host"} if transport == "host" else {})),
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["replica_diff"] == 0.0
