@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <queue>
 #include <type_traits>
 
 namespace polee {
@@ -119,6 +120,11 @@ struct PsellArgs {
     int tiles_s;              // [tiles_a, tiles_s): BN (mixed narrow); the persistent launch's share ends here
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
+    // dynamic schedule (the default; the deterministic mode keeps the static one): the tiles in descending order of their
+    // cost, POS_NONE behind them; workgroup b starts with positions b, b + G, b + 2 G and draws every further position
+    // from the counter dyn_ctr[0] (+ 3 G); dyn_ctr[1] counts the workgroups that are done -- the last one resets both
+    const PosDesc *sched_dyn;
+    unsigned int *dyn_ctr;
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
     float *gwin;            // [dict entries][K], laid out like xwin
     double *lpwin;          // [grid][K] per-workgroup log-likelihood sums
@@ -280,27 +286,29 @@ __device__ inline const void *uniform_ptr(const void *p)
 }
 // LDS-DMA forms: wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane; the LDS destination is
 // M0 + lane * (bytes per lane).  The leading s_nop 4 covers a base that has just come out of v_readfirstlane
-// (VALU-written SGPR -> VMEM read: 5 wait states, which the compiler does not insert for an asm statement).  (M0 is not restored: nothing else in these kernels uses it -- LDS instructions
-// on gfx9 do not -- and the base / offset registers are not rewritten per piece.)
+// (VALU-written SGPR -> VMEM read: 5 wait states, which the compiler does not insert for an asm statement).  (M0 is not restored, and it
+// cannot be declared clobbered: hipcc treats M0 as a reserved register and warns that such a clobber is not honoured.
+// Nothing else in these kernels uses it -- LDS instructions on gfx9 do not, there is no movrel / sendmsg -- and the base /
+// offset registers are not rewritten per piece.)
 __device__ inline void dma_1k(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" POLEE_DMA_POLICY
                  :
                  : "s"(base_uniform), "v"(voff), "s"(lds_dst)
-                 : "memory", "m0");
+                 : "memory");
 }
 // the same with the default cache policy (x windows: written by the previous kernel)
 __device__ inline void dma_1k_keep(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
 }
 // 4 bytes per lane: 64 dwords -> 256 contiguous LDS bytes
 __device__ inline void dma_256(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
 }
 __device__ inline uint32_t lds_addr(const void *p)
 {
@@ -361,6 +369,7 @@ __device__ inline void lds_barrier()
 #ifdef POLEE_STAMPS
 // diagnostic build only: where does a wave of the streaming kernel spend its cycles?
 __device__ unsigned long long g_stamps[24];
+
 #define STAMP(i)                                                          \
     do {                                                                  \
         const unsigned long long now__ = __builtin_amdgcn_s_memtime();    \
@@ -369,6 +378,11 @@ __device__ unsigned long long g_stamps[24];
     } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#endif
+#ifdef POLEE_TILE_CYCLES
+// second diagnostic build (cheap: one clock read per tile): how long does every tile / every workgroup take?
+__device__ unsigned long long g_tile_cycles[1 << 17];  // per tile: wave 0's time from the previous tile's end to this tile's end
+__device__ unsigned long long g_wg_cycles[4096];       // per workgroup: wave 0's time in the kernel
 #endif
 constexpr int NSTAMP = 16;  // (diagnostic build)
 
@@ -1460,6 +1474,16 @@ __device__ inline void wide_masked_stream(WaveStream &ws, const char *ring, int 
     }
 }
 
+#ifdef POLEE_TILE_CYCLES
+extern "C" int polee_debug_read_tile_cycles(unsigned long long *tiles, int ntiles, unsigned long long *wgs, int nwgs)
+{
+    if (hipMemcpyFromSymbol(tiles, HIP_SYMBOL(g_tile_cycles), sizeof(unsigned long long) * (size_t)ntiles) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_wg_cycles), sizeof(unsigned long long) * (size_t)nwgs) != hipSuccess) return 1;
+    static unsigned long long z[1 << 17];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_cycles), z, sizeof(unsigned long long) * (1 << 17)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_cycles), z, sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef POLEE_STAMPS
 extern "C" int polee_debug_read_stamps(unsigned long long *out)
 {
@@ -1572,12 +1596,25 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t G = gridDim.x;
-    const PosDesc *__restrict__ sched = A.sched;
+    // Static schedule: every workgroup walks its own column.  Dynamic schedule: one list, longest tile first; a workgroup
+    // owns its next two tiles (the next one's x window, ids and offsets are on their way while the current one streams)
+    // and, while a tile streams, wave 0 draws the position after those from a global counter -- one atomic per tile, its
+    // result read at the tile's end.  Workgroups then finish within one (small, late) tile of each other whatever the
+    // cost model says: with the static lists the slowest workgroup was 20 - 30 % above the mean (tile times depend on
+    // what the neighbours on the CU are doing, not only on the tile).
+    const bool dyn = A.dyn_ctr != nullptr;
+    const PosDesc *__restrict__ sched = dyn ? A.sched_dyn : A.sched;
+    uint32_t p2 = blockIdx.x + 2u * G;  // (wave 0) position of the tile after the next one
+    unsigned int drawn = 0u;
     const uint8_t *__restrict__ xwin_b = reinterpret_cast<const uint8_t *>(A.xwin);
 #ifdef POLEE_STAMPS
     unsigned long long st_acc[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
     unsigned long long n_slices = 0, n_tiles = 0;
+#endif
+#ifdef POLEE_TILE_CYCLES
+    const unsigned long long t_wg0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t_tile0 = t_wg0;
 #endif
 
     // 0 = A1 (dense narrow), 2 = A1M (masked narrow); 1 = A2 (dense wide), 3 = A2M (masked wide) -- the odd kinds: two active
@@ -1643,7 +1680,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     double lp_a = 0.0;  // lane (tt, q) holds the share of draw tt
 
     PosDesc cur = sched[blockIdx.x];
-    if (cur.tile == POS_NONE) return;
+    if (cur.tile == POS_NONE) return;  // (the grid never exceeds the number of tiles)
     PosDesc nxt = sched[blockIdx.x + G];
     for (int i = threadIdx.x; i < (int)(GWN * XWB / 4u); i += 256) gw[i] = 0.0f;
     // the rings start out as zeros: operand rows past a slice's last transcript are read (and multiplied by 0), so
@@ -1668,8 +1705,14 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             uint32_t off8;  // (lane & 7) * 4, computed here: hoisted out of the tile loop it was spilled, and its reload
                             // (a scratch load the compiler waits for with vmcnt(0)) drained this wave's ring every tile
             asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(wave_lane()));
-            dma_256(uniform_ptr(sched + blockIdx.x + (size_t)(round + 2u) * G), off8, lds_addr(descb + (round & 1u) * 64u));
+            dma_256(uniform_ptr(sched + p2), off8, lds_addr(descb + (round & 1u) * 64u));
             ++young;
+            if (dyn) {
+                // (a compiler-visible atomic with a result: the compiler waits for it where `drawn` is read, after this
+                // tile's queue has been drained anyway; until then it is one more young operation for the counted waits)
+                if (wave_lane() == 0) drawn = __hip_atomic_fetch_add(A.dyn_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++young;
+            }
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
@@ -1754,8 +1797,16 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         STAMP(15);  // flush issue
         lds_barrier();  // gw is zero again, the next x window is complete
         STAMP(9);  // barrier B
+#ifdef POLEE_TILE_CYCLES
+        if (threadIdx.x == 0 && cur.tile < (1u << 17)) {
+            const unsigned long long now_t = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_tile_cycles[cur.tile], now_t - t_tile0);
+            t_tile0 = now_t;
+        }
+#endif
         if (!more) break;
         cur = nxt;
+        if (wave == 0) p2 = dyn ? 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) : p2 + G;
         {
             const uint32_t *dp = descb + (round & 1u) * 64u;
             nxt.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[0]);
@@ -1785,6 +1836,16 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         v += __shfl_xor(v, 32, 64);
         if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
     }
+    if (dyn && threadIdx.x == 0) {
+        // (every draw of this launch has been made before the last workgroup arrives here)
+        if (__hip_atomic_fetch_add(A.dyn_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
+            __hip_atomic_store(A.dyn_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.dyn_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#ifdef POLEE_TILE_CYCLES
+    if (threadIdx.x == 0 && blockIdx.x < 4096) atomicAdd(&g_wg_cycles[blockIdx.x], __builtin_amdgcn_s_memtime() - t_wg0);
+#endif
 #ifdef POLEE_STAMPS
     STAMP(10);
     if (wave_lane() == 0) {
@@ -1808,10 +1869,21 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     order.reserve((size_t)h.num_tiles_s);
     for (int64_t t = 0; t < h.num_tiles_s; ++t) order.push_back((uint32_t)t);  // (the wide mixed tiles behind them go to the per-tile kernel)
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ll->tile_cost[a] > ll->tile_cost[b]; });
+    // longest tile first, each to the workgroup with the least work so far (ties: the lowest index): with a handful of
+    // tiles per workgroup the makespan of this greedy rule is within a few per cent of the mean load, where dealing the
+    // sorted tiles out in rounds left the last round's granularity as a tail
     std::vector<std::vector<uint32_t>> lists((size_t)G);
-    for (size_t i = 0; i < order.size(); ++i) {
-        const size_t r = i / (size_t)G, c = i % (size_t)G;
-        lists[(r & 1) ? (size_t)G - 1 - c : c].push_back(order[i]);
+    {
+        typedef std::pair<double, int> Load;  // (work so far, workgroup)
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int b = 0; b < G; ++b) heap.push(Load(0.0, b));
+        for (uint32_t t : order) {
+            Load l = heap.top();
+            heap.pop();
+            lists[(size_t)l.second].push_back(t);
+            l.first += (double)ll->tile_cost[t];
+            heap.push(l);
+        }
     }
     size_t rounds = 0;
     for (auto &l : lists) rounds = std::max(rounds, l.size());
@@ -1843,6 +1915,47 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     }
     POLEE_TRY(ll->d_sched.upload(ll->ctx, sched));
     ll->sched_grid = G;
+    if (!ll->d_sched_dyn.p) {
+        // the dynamic schedule's list (any grid): the tiles by descending cost, POS_NONE behind them
+        std::vector<PosDesc> dynl(order.size() + (size_t)4 * 4 * 256 + 64);
+        for (auto &d : dynl) {
+            d = PosDesc();
+            d.tile = POS_NONE;
+        }
+        // Order: inside every stream by descending cost; the streams MERGED at equal pace (a tile's key is its rank
+        // among its stream's tiles divided by their number), so that every stretch of the list holds the streams in
+        // their overall proportions -- while a workgroup is on a wide tile (two of its four waves at work) its
+        // neighbours on the CU are mostly on narrow ones -- and the list ends with the cheapest tiles of every stream.
+        std::vector<uint32_t> dorder(order);
+        {
+            static const bool plain = getenv("POLEE_DYN_PLAIN_ORDER") != nullptr;  // (A/B: descending cost over all streams)
+            std::vector<double> key((size_t)h.num_tiles_s, 0.0);
+            size_t cnt[PSELL_NSTREAMS] = {}, seen[PSELL_NSTREAMS] = {};
+            for (uint32_t t : order) ++cnt[h.stream_of_tile(t)];
+            for (uint32_t t : order) {
+                const int st = h.stream_of_tile(t);
+                key[t] = ((double)seen[st] + 0.5) / (double)cnt[st];
+                ++seen[st];
+            }
+            if (!plain) std::stable_sort(dorder.begin(), dorder.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        }
+        for (size_t i = 0; i < dorder.size(); ++i) {
+            const uint32_t t = dorder[i];
+            PosDesc &d = dynl[i];
+            d.tile = t;
+            d.s0 = h.tile_slice[t];
+            d.s1 = h.tile_slice[t + 1];
+            d.d0 = h.tile_dict[t];
+            d.L = h.tile_cols[t];
+            d.c1 = ll->tile_cut[(size_t)3 * t];
+            d.c2 = ll->tile_cut[(size_t)3 * t + 1];
+            d.c3 = ll->tile_cut[(size_t)3 * t + 2];
+        }
+        ll->dyn_pad = dynl.size() - order.size();
+        POLEE_TRY(ll->d_sched_dyn.upload(ll->ctx, dynl));
+        std::vector<unsigned int> zero(2, 0u);
+        POLEE_TRY(ll->d_dyn_ctr.upload(ll->ctx, zero));
+    }
     return POLEE_OK;
 }
 
@@ -1869,6 +1982,11 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles_s, 1));
     POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
     A.sched = ll->d_sched.p;
+    static const bool static_sched = getenv("POLEE_STATIC_SCHED") != nullptr;  // (A/B)
+    if (!DET && !static_sched && (size_t)3 * (size_t)G + 8 <= ll->dyn_pad) {
+        A.sched_dyn = ll->d_sched_dyn.p;
+        A.dyn_ctr = ll->d_dyn_ctr.p;
+    }
     if (DET) {
         POLEE_TRY(ll->d_gwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512));
         POLEE_TRY(ll->d_lpwin.alloc(ctx, (size_t)4 * ctx->num_cus * PSELL_MAX_K));
@@ -1902,7 +2020,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
@@ -2090,22 +2208,27 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
     // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule
     ll->dict_len = (int64_t)h.dict.size();
+    // Cost model of the static schedule, MEASURED: time of every tile of a C2 sample (generator as built and with dropout
+    // 0.3) from a clock read per tile (diagnostic build POLEE_TILE_CYCLES, tools/probe/tile_cycles.py), regressed per
+    // stream on the bytes the tile streams: cycles = fixed + per KiB x KiB, R^2 0.6 - 0.9, mean error per tile ~15 %:
+    //     A1 8.7 k + 350   A1M 9 k + 750   A2 5 k + 620   A2M 5 k + 1400   BN 2 k + 3100
+    // (dense narrow slices cost what their bytes cost; masked ones also the matrix-core work of their union; the wide
+    // streams run on two of the four waves; BN sweeps lane per fragment).  The first model -- bytes + 4 KiB, x 1.5 for the
+    // wide streams -- left the slowest workgroup 25 - 30 % above the mean.
     ll->tile_cost.assign((size_t)h.num_tiles, 0.0f);
+    static const bool old_cost = getenv("POLEE_OLD_COST") != nullptr;  // (A/B)
     for (int64_t t = 0; t < h.num_tiles; ++t) {
-        const double slice_bytes = 128.0 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
-        double c = slice_bytes + 4096.0;
+        const double kib = 0.125 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
+        static const double fixed[PSELL_NSTREAMS] = {8700.0, 9000.0, 5000.0, 5000.0, 2000.0, 2000.0};
+        static const double per_kib[PSELL_NSTREAMS] = {350.0, 750.0, 620.0, 1400.0, 3100.0, 3100.0};
         const int st = h.stream_of_tile(t);
-        if (st == PSELL_BN) c *= 3.0;  // (lane-per-fragment sweeps: ~3x the instructions per byte)
-        if (st == PSELL_A2 || st == PSELL_A2M) c *= 1.5;  // (the wide streams run on two of the four waves)
-        if (st == PSELL_A1M || st == PSELL_A2M) {  // (a masked slice costs the matrix cores what the dense slice of its union would)
-            double dense = 4096.0;
-            for (uint32_t sl = h.tile_slice[t]; sl < h.tile_slice[t + 1]; ++sl) dense += 256.0 * (h.slice_w[sl] + 1);
-            c = std::max(c, 0.5 * (c + dense));
-        }
+        double c = fixed[st] + per_kib[st] * kib;
+        if (old_cost) c = (kib * 1024.0 + 4096.0) * (st == PSELL_A2 || st == PSELL_A2M ? 1.5 : 1.0);
         ll->tile_cost[(size_t)t] = (float)c;
     }
     // the waves of a uniform tile take contiguous blocks of its slices with about equal matrix-core work
     // (phase 1: 4 ceil(w / 4) instructions, phase 2: 8 for w <= 8, else 16 per 16 transcripts; + a fixed part)
+    static const bool bytes_cut = getenv("POLEE_BYTES_CUT") != nullptr;  // (A/B: the waves' shares balanced on bytes)
     ll->tile_cut.assign((size_t)3 * h.num_tiles, 0u);
     for (int64_t t = 0; t < h.num_tiles; ++t) {
         const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
@@ -2115,6 +2238,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         const int nw = h.stream_of_tile(t) != PSELL_A2 && h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
         auto cost = [&](uint32_t sl) {
             const int w = h.slice_w[sl];
+            if (bytes_cut) return 512.0 + 128.0 * (double)((h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK));
             if (h.stream_of_tile(t) == PSELL_BN) return 6.0 * w + 4.0;  // (instructions per entry, not matrix-core work)
             return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
         };
@@ -2126,6 +2250,12 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
             acc += cost(sl);
             // a wave owns at most 63 slices (one offset per lane + the end)
             while (wv < nw && (acc >= total * wv / nw || sl + 1 - (wv == 1 ? s0 : cut[wv - 2]) >= 63u)) cut[wv++ - 1] = sl + 1;
+        }
+        // (the last wave takes what is left: if that is more than 63 slices -- cheap slices at the tile's start -- cut
+        // by count instead; the builder keeps a tile within 63 slices per active wave)
+        if (s1 - (nw > 1 ? cut[nw - 2] : s0) > 63u) {
+            const uint32_t per = (s1 - s0 + (uint32_t)nw - 1) / (uint32_t)nw;
+            for (int q = 1; q < nw; ++q) cut[q - 1] = std::min(s1, s0 + per * (uint32_t)q);
         }
     }
     {   // deterministic mode: the dictionary entries of every transcript, ascending (= tile order), padding left out

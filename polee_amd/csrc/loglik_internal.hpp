@@ -137,6 +137,9 @@ struct polee_loglik {
     polee::DevBuf<float> d_xwin;
     polee::DevBuf<polee::PosDesc> d_sched;
     int sched_grid = 0;
+    polee::DevBuf<polee::PosDesc> d_sched_dyn;  // dynamic schedule: the tiles by descending cost + POS_NONE padding
+    polee::DevBuf<unsigned int> d_dyn_ctr;      // {positions drawn, workgroups done}: zero between launches
+    size_t dyn_pad = 0;
     std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
     std::vector<uint32_t> tile_cut;  // [3 * num_tiles] slice boundaries between the waves of a uniform tile
     int64_t dict_len = 0;

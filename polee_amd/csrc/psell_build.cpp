@@ -495,6 +495,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     }
     static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
     static const int a2cap = getenv("POLEE_TILE_A2") ? atoi(getenv("POLEE_TILE_A2")) : PSELL_TILE_SLICES_A2;
+    static const int a2mcap = getenv("POLEE_TILE_A2M") ? std::min(atoi(getenv("POLEE_TILE_A2M")), 126) : PSELL_TILE_SLICES_A2M;
     const unsigned nthreads = host_threads();
     std::vector<std::vector<uint32_t>> stamps(nthreads);
     std::vector<std::vector<uint16_t>> locals(nthreads);
@@ -708,7 +709,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             close_slice();
             // small tiles for the two small streams (more workgroups, shorter tails)
             const uint32_t cap = cur_stream == PSELL_A1 || cur_stream == PSELL_A1M ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
-                                 : cur_stream == PSELL_A2 ? (uint32_t)a2cap : cur_stream == PSELL_A2M ? (uint32_t)PSELL_TILE_SLICES_A2M
+                                 : cur_stream == PSELL_A2 ? (uint32_t)std::min(a2cap, 126) : cur_stream == PSELL_A2M ? (uint32_t)a2mcap
                                  : cur_stream == PSELL_BN ? (uint32_t)PSELL_TILE_SLICES_BN : (uint32_t)PSELL_TILE_SLICES_B;
             if (tile_nslices >= cap) close_tile();
         }

@@ -5,7 +5,7 @@ OUT=gpurun_out/exp_$TAG; mkdir -p $OUT
 i=0
 for ENVS in "$@"; do
   i=$((i+1))
-  env $ENVS python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --prewarm 100 $ARGS > $OUT/$i.json 2> $OUT/$i.err
+  env $ENVS python3 bench.py --steps ${STEPS:-150} --warmup 5 --cpu-steps 0 --prewarm 200 $ARGS > $OUT/$i.json 2> $OUT/$i.err
   python3 - "$ENVS" $OUT/$i.json <<'PY'
 import json, sys
 try:
