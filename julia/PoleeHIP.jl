@@ -240,4 +240,246 @@ mutable struct Comm
     end
 end
 
+# ---- the VI loop as a handle (polee_vi_create / run / sync): step the fit, inspect it, shard it ----------------
+mutable struct ViStats
+    steps_done::Int32
+    nonfinite_step::Int32
+    loglik_kernel_ms_avg::Float64
+    loglik_kernel_launches::Int64
+    last_elbo::Float64
+    last_lp_mean::Float64
+    loglik_pass_ms_avg::Float64
+    ViStats() = new(0, 0, 0.0, 0, 0.0, 0.0, 0.0)
+end
+
+"State of one fit of approximate_likelihood(::LogitSkewNormalPTTApprox, ...) (likelihood-approximation.jl:395-624)"
+mutable struct LikelihoodApproximationFit
+    h::Ptr{Cvoid}
+    sample::DeviceSample
+    t::PolyaTreeTransform
+    function LikelihoodApproximationFit(s::DeviceSample, t::PolyaTreeTransform, efflens::Vector{Float32}, opts::ViOpts=ViOpts())
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve efflens check(ccall((:polee_vi_create, LIB), Cint,
+                                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ref{ViOpts}, Ref{Ptr{Cvoid}}),
+                                         s.h, t.h, efflens, opts, out), t.ctx.h)
+        f = new(out[], s, t)
+        finalizer(x -> ccall((:polee_vi_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), f)
+        return f
+    end
+end
+
+"enqueue nsteps iterations (no host synchronisation)"
+run!(f::LikelihoodApproximationFit, nsteps::Integer) =
+    check(ccall((:polee_vi_run, LIB), Cint, (Ptr{Cvoid}, Int32), f.h, nsteps), f.t.ctx.h)
+"wait for the stream; throws AssertionError on a non-finite gradient (likelihood-approximation.jl:559)"
+sync!(f::LikelihoodApproximationFit) = check(ccall((:polee_vi_sync, LIB), Cint, (Ptr{Cvoid},), f.h), f.t.ctx.h)
+
+function params(f::LikelihoodApproximationFit)
+    n = f.t.n
+    mu, omega, alpha = (Vector{Float32}(undef, n - 1) for _ in 1:3)
+    GC.@preserve mu omega alpha check(ccall((:polee_vi_get_params, LIB), Cint,
+                                            (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), f.h, mu, omega, alpha), f.t.ctx.h)
+    return mu, omega, alpha
+end
+
+function set_params!(f::LikelihoodApproximationFit, mu::Vector{Float32}, omega::Vector{Float32}, alpha::Vector{Float32})
+    GC.@preserve mu omega alpha check(ccall((:polee_vi_set_params, LIB), Cint,
+                                            (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), f.h, mu, omega, alpha), f.t.ctx.h)
+end
+
+function stats(f::LikelihoodApproximationFit)
+    st = ViStats()
+    check(ccall((:polee_vi_get_stats, LIB), Cint, (Ptr{Cvoid}, Ref{ViStats}), f.h, st), f.t.ctx.h)
+    return st
+end
+
+"per-step ELBO and mean log-likelihood (gradonly == 0 only)"
+function trace(f::LikelihoodApproximationFit)
+    k = Int(stats(f).steps_done)
+    elbo, lp = Vector{Float64}(undef, k), Vector{Float64}(undef, k)
+    GC.@preserve elbo lp check(ccall((:polee_vi_get_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), f.h, elbo, lp), f.t.ctx.h)
+    return elbo, lp
+end
+
+"row-sharded fit: this handle's sample holds one rank's block of fragments (SURVEY 8(e)(1))"
+set_comm!(f::LikelihoodApproximationFit, c) =
+    check(ccall((:polee_vi_set_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), f.h, c === nothing ? C_NULL : c.h), f.t.ctx.h)
+
+# ---- tree construction: hclust + order_nodes (src/hclust.jl:193-319, 361-389) -----------------------------------
+"X in CSC, 1-based (colptr UInt32 or UInt64), as in the likelihood-matrix HDF5 -> (node_parent_idxs, node_js)"
+function hclust(m::Integer, n::Integer, colptr::Union{Vector{UInt32},Vector{UInt64}}, rowval::Vector{UInt32})
+    parents, js = Vector{Int32}(undef, 2n - 1), Vector{Int32}(undef, 2n - 1)
+    GC.@preserve colptr rowval parents js check(
+        ccall((:polee_hclust, LIB), Cint, (Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+              m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js))
+    return parents, js
+end
+
+# ---- density of the fitted approximations: replaces create_tensorflow_variables! (src/estimate.jl:502-556) +
+#      RNASeqApproxLikelihoodDist (src/polee_approx_likelihood.py:367-450) -------------------------------------------
+"""
+    ApproxLikelihood(ctx, vars)
+
+`vars` is `LoadedSamples.variables` (estimate.jl:502-556): "efflen" [S,n], "la_mu" / "la_sigma" / "la_alpha" [S,n-1],
+"left_index" / "right_index" / "leaf_index" [S,N] (or [1,N] for one shared tree), as ROW-MAJOR C arrays -- i.e. pass
+`permutedims` of Julia's column-major matrices, or vectors already laid out sample by sample.
+"""
+mutable struct ApproxLikelihood
+    h::Ptr{Cvoid}
+    ctx::Context
+    S::Int
+    n::Int
+    function ApproxLikelihood(ctx::Context, S::Integer, n::Integer, efflen::Vector{Float32}, la_mu::Vector{Float32},
+                              la_sigma::Vector{Float32}, la_alpha::Vector{Float32}, left_index::Vector{Int32},
+                              right_index::Vector{Int32}, leaf_index::Vector{Int32}; shared_tree::Bool=false)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve efflen la_mu la_sigma la_alpha left_index right_index leaf_index check(
+            ccall((:polee_approx_create, LIB), Cint,
+                  (Ptr{Cvoid}, Int32, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Ptr{Int32},
+                   Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                  ctx.h, S, n, efflen, la_mu, la_sigma, la_alpha, left_index, right_index, leaf_index, shared_tree, out), ctx.h)
+        a = new(out[], ctx, S, n)
+        finalizer(x -> ccall((:polee_approx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), a)
+        return a
+    end
+end
+
+"log_prob(ap, x; grad) -- x Float32 [S*n] (sample by sample) unnormalised log expression -> lp [S] (, d lp / d x)"
+function log_prob(ap::ApproxLikelihood, x::Vector{Float32}; grad::Bool=false)
+    lp = Vector{Float32}(undef, ap.S)
+    g = grad ? Vector{Float32}(undef, ap.S * ap.n) : Float32[]
+    GC.@preserve x lp g check(ccall((:polee_approx_logprob, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                                    ap.h, x, lp, grad ? pointer(g) : C_NULL), ap.ctx.h)
+    return grad ? (lp, g) : lp
+end
+
+"rnaseq_approx_likelihood_sampler (polee_approx_likelihood.py:35-59): one draw per sample -> x Float32 [S*n]"
+function sample(ap::ApproxLikelihood; seed::Integer=0, z0::Union{Nothing,Vector{Float32}}=nothing)
+    x = Vector{Float32}(undef, ap.S * ap.n)
+    GC.@preserve x z0 check(ccall((:polee_approx_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, UInt64, Ptr{Float32}),
+                                  ap.h, z0 === nothing ? C_NULL : pointer(z0), seed, x), ap.ctx.h)
+    return x
+end
+
+"RNASeqGeneApproxLikelihoodDist (polee_gene_expression.py:14-90); gene_of: 0-based gene of every transcript"
+function gene_log_prob(ap::ApproxLikelihood, x_gene::Vector{Float32}, x_isoform::Vector{Float32}, gene_of::Vector{Int32},
+                       num_genes::Integer; grad::Bool=false)
+    lp = Vector{Float32}(undef, ap.S)
+    gg = grad ? Vector{Float32}(undef, ap.S * num_genes) : Float32[]
+    gi = grad ? Vector{Float32}(undef, ap.S * ap.n) : Float32[]
+    GC.@preserve x_gene x_isoform gene_of lp gg gi check(
+        ccall((:polee_approx_gene_logprob, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+              ap.h, x_gene, x_isoform, gene_of, num_genes, lp, grad ? pointer(gg) : C_NULL, grad ? pointer(gi) : C_NULL), ap.ctx.h)
+    return grad ? (lp, gg, gi) : lp
+end
+
+"approximate_feature_likelihood (polee_gene_expression.py:191-222): (loc, scale) Float32 [S*F]; pairs are 1-based"
+function feature_moments(ap::ApproxLikelihood, feature_idxs::Vector{Int32}, transcript_idxs::Vector{Int32}, F::Integer;
+                         num_mean_draws::Integer=1000, num_var_draws::Integer=1000, seed::Integer=0)
+    loc, scale = Vector{Float32}(undef, ap.S * F), Vector{Float32}(undef, ap.S * F)
+    GC.@preserve feature_idxs transcript_idxs loc scale check(
+        ccall((:polee_approx_feature_moments, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Int64, Int32, Int32, Int32, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+              ap.h, feature_idxs, transcript_idxs, length(feature_idxs), F, num_mean_draws, num_var_draws, seed, C_NULL, loc, scale),
+        ap.ctx.h)
+    return loc, scale
+end
+
+# ---- regression model: replaces the python-object protocol Regression(...).fit(niter)
+#      (src/regression.jl:319-327, models/polee_regression.py:18-340) ------------------------------------------------
+mutable struct Regression
+    h::Ptr{Cvoid}
+    ctx::Context
+    S::Int
+    F::Int
+    n::Int
+    """design Float32 [S*F], x_init Float32 [S*n] (row-major); hinges = nothing: choose_knots as
+    RNASeqTranscriptLinearRegression does (models/polee_regression.py:436-440)"""
+    function Regression(ctx::Context, ap::Union{Nothing,ApproxLikelihood}, S::Integer, F::Integer, n::Integer,
+                        design::Vector{Float32}, x_init::Vector{Float32}, sample_scales::Vector{Float32};
+                        x_init_mean::Union{Nothing,Vector{Float32}}=nothing, hinges::Union{Nothing,Vector{Float32}}=nothing,
+                        degree::Integer=15, bandwidth::Real=1.0, x_bias_loc0::Real=log(1 / n), x_bias_scale0::Real=12.0,
+                        use_distortion::Bool=true, scale_penalty::Real=1.0, use_point_estimates::Bool=false)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve design x_init sample_scales x_init_mean hinges check(
+            ccall((:polee_regression_create, LIB), Cint,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32},
+                   Int32, Cfloat, Cfloat, Cfloat, Cint, Cfloat, Cint, Ref{Ptr{Cvoid}}),
+                  ctx.h, ap === nothing ? C_NULL : ap.h, S, F, n, design, x_init,
+                  x_init_mean === nothing ? C_NULL : pointer(x_init_mean), sample_scales,
+                  hinges === nothing ? C_NULL : pointer(hinges), degree, bandwidth, x_bias_loc0, x_bias_scale0, use_distortion,
+                  scale_penalty, use_point_estimates, out), ctx.h)
+        r = new(out[], ctx, S, F, n)
+        finalizer(x -> ccall((:polee_regression_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), r)
+        return r
+    end
+end
+
+num_params(r::Regression) = Int(ccall((:polee_regression_num_params, LIB), Int64, (Ptr{Cvoid},), r.h))
+
+"fit(niter) (models/polee_regression.py:303-340); returns the loss trace"
+function fit!(r::Regression, niter::Integer; seed::Integer=0)
+    losses = Vector{Float32}(undef, niter)
+    GC.@preserve losses check(ccall((:polee_regression_fit, LIB), Cint, (Ptr{Cvoid}, Int32, UInt64, Ptr{Float32}, Ptr{Float32}),
+                                    r.h, niter, seed, C_NULL, losses), r.ctx.h)
+    return losses
+end
+
+"the flat parameter vector (order documented in include/polee_hip.h)"
+function flat_params(r::Regression)
+    p = Vector{Float32}(undef, num_params(r))
+    GC.@preserve p check(ccall((:polee_regression_get_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, p), r.ctx.h)
+    return p
+end
+
+"""
+(qx_loc[S,n], qw_loc[F,n], qw_scale[F,n], qx_bias[n], qx_scale[n]) as `Regression(...).fit(niter)` returns them
+(src/regression.jl:319-327): slices of the flat vector, softplus applied where the reference applies it.
+"""
+function fit_results(r::Regression; degree::Integer=15)
+    p = flat_params(r)
+    S, F, n = r.S, r.F, r.n
+    softplus(x) = log1p(exp(x))
+    o = 4 + F * degree + 2 * degree                     # scalars, distortion and mean-variance coefficients
+    blk(k) = reshape(p[o + k * F * n + 1:o + (k + 1) * F * n], n, F)'   # k-th [F][n] array (row-major) as an F x n matrix
+    qw_loc, qw_scale = blk(8), softplus.(blk(9))
+    o += 10 * F * n
+    qx_bias = p[o + 1:o + n]
+    qx_scale = softplus.(p[o + 2n + 1:o + 3n])
+    o += 4n
+    qx_loc = reshape(p[o + 1:o + S * n], n, S)'
+    return qx_loc, qw_loc, qw_scale, qx_bias, qx_scale
+end
+
+"samples sharded over ranks: one all-reduce of (F+2) n statistics per step (SURVEY 8(e)(2))"
+set_comm!(r::Regression, c) =
+    check(ccall((:polee_regression_set_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.h, c === nothing ? C_NULL : c.h), r.ctx.h)
+
+# ---- host-staged communicator: the all-reduce is the caller's (e.g. MPI.Allreduce!) ----------------------------------
+mutable struct HostComm
+    h::Ptr{Cvoid}
+    ctx::Context
+    allreduce::Function     # (buf::Vector{Float32} or Vector{Float64}) -> sums it over the ranks in place
+    cfun::Base.CFunction
+    function HostComm(ctx::Context, nranks::Integer, rank::Integer, allreduce::Function)
+        cb = function (user::Ptr{Cvoid}, buf::Ptr{Cvoid}, count::Int64, is_f64::Cint)::Cint
+            try
+                a = is_f64 != 0 ? unsafe_wrap(Array, Ptr{Float64}(buf), count) : unsafe_wrap(Array, Ptr{Float32}(buf), count)
+                allreduce(a)
+                return Cint(0)
+            catch
+                return Cint(1)
+            end
+        end
+        cfun = @cfunction($cb, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint))
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:polee_comm_create_host, LIB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                    ctx.h, nranks, rank, cfun, C_NULL, out), ctx.h)
+        c = new(out[], ctx, allreduce, cfun)
+        finalizer(x -> ccall((:polee_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+        return c
+    end
+end
+
 end # module
