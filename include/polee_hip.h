@@ -463,6 +463,60 @@ polee_status polee_regression_eval(polee_regression *reg, const float *noise_or_
 polee_status polee_regression_fit(polee_regression *reg, int32_t niter, uint64_t seed, const float *noise_or_null,
                                   float *loss_trace_or_null);
 
+/* ---- construction of the likelihood matrix (first slice) ------------------------------------
+ * Replaces, for pre-parsed inputs, the reference's intersection of alignment pairs with transcripts and the
+ * conditional fragment probabilities of its SimplisticFragModel (bias terms = 1):
+ *   parallel_intersection_loop (src/rnaseq_sample.jl:58-121), fragmentlength (src/transcripts.jl:273-446),
+ *   effective_length / condfragprob (src/fragmodel.jl:119-169), sortperm + compact_indexes! + sparse
+ *   (src/rnaseq_sample.jl:126-157, 470-489).
+ * BAM / GFF parsing, bias models and read assignment stay upstream.  Coordinates are 1-based inclusive.
+ *   transcripts  j = 0..n-1 (= t.metadata.id - 1): sequence id, strand (+1 / -1), exons ascending and disjoint
+ *   fragments    i = 0..m-1 = alignment pairs: sequence id, strand, the LEFTMOST mate (m1) and, for paired-end reads,
+ *                the other one (m2; m2_left == 0: single-end); per mate its CIGAR as (operation code, length) pairs
+ *                in BAM coding (0 M, 1 I, 2 D, 3 N, 4 S), cig?_ptr[i] .. cig?_ptr[i+1] into cig_op / cig_len (an
+ *                empty range = one match over [left, right]); m1_is_flag16: the lone mate's SAM flag is exactly 16
+ *                (the reference's test `aln.flag == SAM.FLAG_REVERSE != 0`, src/fragmodel.jl:130)
+ *   fragmodel    fraglen_pmf / fraglen_cdf f32 [2000] (index l-1 holds length l), the median, strand specificity,
+ *                alt_frag_model (src/fragmodel.jl:23-115)
+ * Result: X's rows compressed (what polee_loglik_create_from_xt takes): tcolptr u64 [rows+1] 1-based, trowval u32
+ * 1-based transcript ids ascending within a row, tnzval f32; effective_lengths f32 [n]; row_fragment i64 [rows] =
+ * the fragment of every row (fragments compatible with no transcript are dropped, as compact_indexes! does; rows keep
+ * the fragments' input order -- the reference numbers them in the order of its interval trees, a permutation the
+ * likelihood does not see). */
+typedef struct {
+    int32_t n;
+    const int32_t *seq;
+    const int8_t *strand;
+    const int64_t *exon_ptr;   /* [n+1] */
+    const int64_t *exon_first, *exon_last;
+} polee_xb_transcripts;
+typedef struct {
+    int64_t m;
+    const int32_t *seq;
+    const int8_t *strand;
+    const int64_t *m1_left, *m1_right, *m2_left, *m2_right;
+    const uint8_t *m1_is_flag16;
+    const int64_t *cig1_ptr, *cig2_ptr;  /* [m+1] each */
+    const uint8_t *cig_op;
+    const int32_t *cig_len;
+} polee_xb_fragments;
+typedef struct {
+    const float *fraglen_pmf, *fraglen_cdf;
+    int32_t fraglen_median;
+    float strand_specificity;
+    int32_t alt_frag_model;
+} polee_xb_fragmodel;
+typedef struct polee_xbuild polee_xbuild;
+polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *transcripts, const polee_xb_fragments *fragments,
+                              const polee_xb_fragmodel *fragmodel, polee_xbuild **out);
+void polee_xbuild_destroy(polee_xbuild *xb);
+/* rows and non-zeros of the result; kernel times (ms): effective lengths, counting pass, filling pass */
+polee_status polee_xbuild_sizes(const polee_xbuild *xb, int64_t *rows, int64_t *nnz, double *ms_efflen, double *ms_count,
+                                double *ms_fill);
+/* copies the result to host arrays (any pointer may be NULL) */
+polee_status polee_xbuild_get(const polee_xbuild *xb, uint64_t *tcolptr, uint32_t *trowval, float *tnzval,
+                              float *effective_lengths, int64_t *row_fragment);
+
 #ifdef __cplusplus
 }
 #endif

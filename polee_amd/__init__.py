@@ -12,6 +12,7 @@ would use).  Names, argument meaning and error behaviour follow the reference:
   ApproxLikelihoodSampler / rand!                                            src/approx-sampler.jl
   RNASeqApproxLikelihood(...).log_prob, rnaseq_approx_likelihood_sampler     src/polee_approx_likelihood.py
   RNASeqLinearRegression / RNASeqTranscriptLinearRegression(...).fit         models/polee_regression.py
+  build_likelihood_matrix (X from alignments, SimplisticFragModel)           src/rnaseq_sample.jl:58-121, src/fragmodel.jl
 
 All numerics run in libpolee_hip.so on the GPU; nothing here computes on the CPU.
 """
@@ -31,3 +32,4 @@ from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegressio
                          find_minimum_effect_size, write_regression_effects)
 from .salmon import load_salmon_likelihood, SalmonLikelihood  # noqa: F401,E402
 from .cohort import approximate_likelihood_cohort  # noqa: F401,E402
+from .xbuild import build_likelihood_matrix  # noqa: F401,E402

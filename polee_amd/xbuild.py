@@ -1,0 +1,71 @@
+"""Construction of the likelihood matrix on the GPU (polee_xbuild_*; SURVEY.md 8(f) f4, first slice): the host mirror of
+the reference's `RNASeqSample(fm::FragModel, rs::Reads, ts::Transcripts, ...)` (src/rnaseq_sample.jl:390-524) for
+pre-parsed inputs and the SimplisticFragModel (src/fragmodel.jl:23-169)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import check
+
+
+class _Transcripts(C.Structure):
+    _fields_ = [("n", C.c_int32), ("seq", C.c_void_p), ("strand", C.c_void_p), ("exon_ptr", C.c_void_p),
+                ("exon_first", C.c_void_p), ("exon_last", C.c_void_p)]
+
+
+class _Fragments(C.Structure):
+    _fields_ = [("m", C.c_int64), ("seq", C.c_void_p), ("strand", C.c_void_p), ("m1_left", C.c_void_p),
+                ("m1_right", C.c_void_p), ("m2_left", C.c_void_p), ("m2_right", C.c_void_p), ("m1_is_flag16", C.c_void_p),
+                ("cig1_ptr", C.c_void_p), ("cig2_ptr", C.c_void_p), ("cig_op", C.c_void_p), ("cig_len", C.c_void_p)]
+
+
+class _FragModel(C.Structure):
+    _fields_ = [("fraglen_pmf", C.c_void_p), ("fraglen_cdf", C.c_void_p), ("fraglen_median", C.c_int32),
+                ("strand_specificity", C.c_float), ("alt_frag_model", C.c_int32)]
+
+
+_T_TYPES = dict(seq=np.int32, strand=np.int8, exon_ptr=np.int64, exon_first=np.int64, exon_last=np.int64)
+_F_TYPES = dict(seq=np.int32, strand=np.int8, m1_left=np.int64, m1_right=np.int64, m2_left=np.int64, m2_right=np.int64,
+                m1_is_flag16=np.uint8, cig1_ptr=np.int64, cig2_ptr=np.int64, cig_op=np.uint8, cig_len=np.int32)
+
+
+def pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity, alt_frag_model):
+    """ctypes structs (+ the arrays they borrow) for polee_xbuild_run and for the oracle's twin of it."""
+    keep = []
+
+    def ptr(a, dt):
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+    T = _Transcripts(int(transcripts["n"]), *[ptr(transcripts[k], dt) for k, dt in _T_TYPES.items()])
+    F = _Fragments(int(fragments["m"]), *[ptr(fragments[k], dt) for k, dt in _F_TYPES.items()])
+    M = _FragModel(ptr(fraglen_pmf, np.float32), ptr(fraglen_cdf, np.float32), int(fraglen_median), float(strand_specificity),
+                   int(bool(alt_frag_model)))
+    return T, F, M, keep
+
+
+def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity=0.9,
+                            alt_frag_model=False, ctx=None):
+    """-> dict(m, n, nnz, tcolptr u64 [m+1], trowval u32, tnzval f32 (the rows of X, 1-based, what RNASeqSample(xt=...)
+    takes), effective_lengths f32 [n], row_fragment i64 [m], kernel_ms)."""
+    from .core import default_context
+    ctx = ctx or default_context()
+    T, F, M, keep = pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity, alt_frag_model)
+    h = C.c_void_p()
+    check(L.lib().polee_xbuild_run(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(h)), ctx._h)
+    try:
+        rows, nnz = C.c_int64(), C.c_int64()
+        ms = [C.c_double(), C.c_double(), C.c_double()]
+        check(L.lib().polee_xbuild_sizes(h, C.byref(rows), C.byref(nnz), *[C.byref(x) for x in ms]), ctx._h)
+        out = dict(m=rows.value, n=int(transcripts["n"]), nnz=nnz.value, tcolptr=np.empty(rows.value + 1, np.uint64),
+                   trowval=np.empty(nnz.value, np.uint32), tnzval=np.empty(nnz.value, np.float32),
+                   effective_lengths=np.empty(int(transcripts["n"]), np.float32), row_fragment=np.empty(rows.value, np.int64),
+                   kernel_ms=dict(efflen=ms[0].value, count=ms[1].value, fill=ms[2].value))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(L.lib().polee_xbuild_get(h, p(out["tcolptr"]), p(out["trowval"]), p(out["tnzval"]), p(out["effective_lengths"]),
+                                       p(out["row_fragment"])), ctx._h)
+    finally:
+        L.lib().polee_xbuild_destroy(h)
+    del keep
+    return out
