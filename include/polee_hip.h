@@ -143,7 +143,8 @@ typedef struct {
     /* unions of <= 16 (fragments whose sets differ); [2] dense uniform, 17..32; [3] masked uniform,    */
     /* unions of 17..32; [4] mixed slices of unrelated fragments of <= 15 transcripts -- [0..4] are one */
     /* persistent launch; [5] mixed slices of longer fragments (more than 32 transcripts, as a rule): a */
-    /* second launch                                                                                    */
+    /* second launch; [6] rows kept in CSR (fragments without any structure, whose sliced forms would   */
+    /* cost more than CSR: a random sparse matrix): a launch of their own, no tiles                      */
     int64_t stream_rows[8];  /* fragments                                               */
     int64_t stream_nnz[8];   /* non-zeros of X                                          */
     int64_t stream_tiles[8]; /* tiles (workgroup-sized units of work)                   */

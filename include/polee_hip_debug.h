@@ -50,6 +50,11 @@ typedef struct {
                                    multiplicities a row float ks[64] follows at the next multiple of 256 bytes):
                                    tiles [0, num_tiles_s) are the persistent launch's share                      */
     int64_t stream_rows[8], stream_nnz[8], stream_bytes[8]; /* as in polee_loglik_info */
+    int64_t csr_num_rows;        /* stream C: rows kept in CSR (every sliced form would cost more) */
+    const uint32_t *csr_rowptr;  /* [csr_num_rows + 1] 0-based                                     */
+    const uint32_t *csr_col;     /* 0-based transcript ids                                         */
+    const float *csr_val;
+    const uint32_t *csr_rows;    /* [csr_num_rows] original 0-based fragment of every row          */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

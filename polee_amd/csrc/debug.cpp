@@ -79,6 +79,11 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->num_tiles_s = h.num_tiles_s;
     v->slice_w = h.slice_w.data();
     for (int i = 0; i < 8; ++i) v->stream_rows[i] = v->stream_nnz[i] = v->stream_bytes[i] = 0;
+    v->csr_num_rows = (int64_t)h.csr_rows.size();
+    v->csr_rowptr = h.csr_rowptr.data();
+    v->csr_col = h.csr_col.data();
+    v->csr_val = h.csr_val.data();
+    v->csr_rows = h.csr_rows.data();
     for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         v->stream_rows[i] = h.stream_rows[i];
         v->stream_nnz[i] = h.stream_nnz[i];

@@ -254,6 +254,53 @@ __global__ __launch_bounds__(256) void loglik_psell_kernel(PsellArgs A, int tile
     psell_tile_body<K, WANT_LP, HAS_KS>(A, tile, lds, lds + (size_t)A.lcap * K, lp_red);
 }
 
+// ---- stream C: rows kept in CSR (fragments without any structure; loglik_internal.hpp) ------------------------------------------
+// Lane = fragment: row sums by gathers of x rows from global memory (x is a few MB: L2), then one float atomic per entry
+// and draw.  The general fallback -- any sparsity pattern, CSR's bytes -- and slow: nothing with structure ends up here.
+template <int K, bool WANT_LP, bool HAS_KS>
+__global__ __launch_bounds__(256) void loglik_csr_kernel(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                        const float *__restrict__ val, const float *__restrict__ ks, int64_t rows,
+                                                        const float *__restrict__ x, float *__restrict__ g, double *__restrict__ lp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double lpacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
+    if (i < rows) {
+        const uint32_t b = rowptr[i], e = rowptr[i + 1];
+        float sacc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) sacc[k] = 0.0f;
+        for (uint32_t p = b; p < e; ++p) fma_row<K>(val[p], x + (size_t)col[p] * K, sacc);
+        const float ksv = HAS_KS ? ks[i] : 1.0f;
+        float wk[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wk[k] = fast_weight(ksv, sacc[k]);
+            if (WANT_LP && sacc[k] > 0.0f) lpacc[k] = (double)ksv * log((double)sacc[k]);
+        }
+        for (uint32_t p = b; p < e; ++p) {
+            const float v = val[p];
+            float *gr = g + (size_t)col[p] * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) atomicAdd(gr + k, v * wk[k]);
+        }
+    }
+    if (WANT_LP) {
+        __shared__ double red[4];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = lpacc[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(lp + k, red[0] + red[1] + red[2] + red[3]);
+            __syncthreads();
+        }
+    }
+}
+
 // ---- the uniform streams in ONE persistent launch --------------------------------------------------------------
 // A uniform slice holds up to 64 fragments (one per lane) that share ONE transcript set (c_0..c_{w-1}); runs of
 // consecutive slices with the same set are marked by the builder.  For such a slice V[t][r] (w x 64):
@@ -2041,7 +2088,13 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
             hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds_psell, st, A,
                                (int)h.num_tiles_s, (const uint32_t *)nullptr);
         }
+        if (ll->csr_rows > 0)  // stream C: rows kept in CSR (float atomics: like stream B, outside the deterministic guarantee)
+            hipLaunchKernelGGL((loglik_csr_kernel<K, LP, KS>), dim3((unsigned)ceil_div(ll->csr_rows, 256)), dim3(256), 0, st,
+                               ll->d_csr_rowptr.p, ll->d_csr_col.p, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
     } else {
+        if (ll->csr_rows > 0)
+            hipLaunchKernelGGL((loglik_csr_kernel<K, LP, KS>), dim3((unsigned)ceil_div(ll->csr_rows, 256)), dim3(256), 0, st,
+                               ll->d_csr_rowptr.p, ll->d_csr_col.p, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
         // the cross-check switch: every tile as mixed slices with the per-run DPP kernel
         if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
         hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.num_tiles), dim3(256), lds_psell, st, A, 0,
@@ -2055,7 +2108,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
 template <int K>
 static polee_status launch_k(polee_loglik *ll, const float *d_x, float *d_g, double *d_lp)
 {
-    if (ll->host.num_tiles == 0) return POLEE_OK;
+    if (ll->host.num_tiles == 0 && ll->csr_rows == 0) return POLEE_OK;
     if (d_lp) return ll->has_ks ? launch_variant<K, true, true>(ll, d_x, d_g, d_lp)
                                 : launch_variant<K, true, false>(ll, d_x, d_g, d_lp);
     return ll->has_ks ? launch_variant<K, false, true>(ll, d_x, d_g, d_lp)
@@ -2200,10 +2253,14 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     if ((s = ll->d_data.upload(ctx, h.data.data(), h.data.size())) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) ||
-        (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks)))) {
+        (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks))) ||
+        (!h.csr_rows.empty() && ((s = ll->d_csr_rowptr.upload(ctx, h.csr_rowptr)) || (s = ll->d_csr_col.upload(ctx, h.csr_col)) ||
+                                 (s = ll->d_csr_val.upload(ctx, h.csr_val)) || (ll->has_ks && (s = ll->d_csr_ks.upload(ctx, h.csr_ks)))))) {
         loglik_release(ll);
         return s;
     }
+    ll->csr_rows = (int64_t)h.csr_rows.size();
+    ll->csr_nnz = (int64_t)h.csr_col.size();
     if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "upload", wall_now() - t_begin);
     // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
     // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule
@@ -2292,6 +2349,11 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     std::vector<uint8_t>().swap(h.slice_flags);
     std::vector<uint8_t>().swap(h.slice_w);
     std::vector<uint32_t>().swap(h.row_order);
+    std::vector<uint32_t>().swap(h.csr_rowptr);
+    std::vector<uint32_t>().swap(h.csr_col);
+    std::vector<uint32_t>().swap(h.csr_rows);
+    std::vector<float>().swap(h.csr_val);
+    std::vector<float>().swap(h.csr_ks);
     *out = ll;
     return POLEE_OK;
 }
@@ -2461,13 +2523,14 @@ polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *in
     info->num_tiles = h.num_tiles;
     info->padded_nnz = h.padded_nnz;
     info->stream_bytes = (int64_t)(ll->d_data.n + 4 * (ll->d_slice_off.n + ll->d_tile_slice.n + ll->d_tile_dict.n +
-                                                        ll->d_dict.n + ll->d_slice_ks.n));
+                                                        ll->d_dict.n + ll->d_slice_ks.n + ll->d_csr_rowptr.n + ll->d_csr_col.n +
+                                                        ll->d_csr_val.n + ll->d_csr_ks.n));
     info->device_bytes = info->stream_bytes;
     info->num_empty_rows = h.empty_rows;
     info->max_row_nnz = h.max_row;
     info->max_tile_cols = h.max_tile_cols;
     const int64_t tiles[PSELL_NSTREAMS] = {h.num_tiles_a1, h.num_tiles_a1m - h.num_tiles_a1, h.num_tiles_a2 - h.num_tiles_a1m,
-                                           h.num_tiles_a - h.num_tiles_a2, h.num_tiles_s - h.num_tiles_a, h.num_tiles - h.num_tiles_s};
+                                           h.num_tiles_a - h.num_tiles_a2, h.num_tiles_s - h.num_tiles_a, h.num_tiles - h.num_tiles_s, 0};
     for (int i = 0; i < 8; ++i) info->stream_rows[i] = info->stream_nnz[i] = info->stream_tiles[i] = info->stream_bytes_hbm[i] = 0;
     for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         info->stream_rows[i] = h.stream_rows[i];

@@ -46,6 +46,9 @@
 //              B: rows of more than 16 transcripts that found no uniform slice (more than 32, as a rule); the per-tile
 //              kernel loglik_psell_kernel takes them in a second launch.  That kernel also runs over all other slices
 //              on request (polee_debug_loglik_force_mixed): the independent second algorithm of the cross-check tests.
+//       C     = rows kept in CSR (u32 ids, f32 values, u32 row offsets: 8 B per non-zero + 4 B per row): fragments with no structure at all,
+//              whose mixed tiles would close on the dictionary before a slice is full -- the last resort that keeps
+//              the layout below CSR's size for ANY matrix; loglik_csr_kernel (lane = row, global gathers / atomics).
 //   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
 //     are stored under one transcript set) and "continues" (the same set as the previous slice).  Runs of such
 //     slices -- the bulk of real and synthetic data, where many fragments fall into the same
@@ -70,7 +73,7 @@ constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
 // A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
-enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_NSTREAMS = 6 };  // streams, in tile order
+enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_C = 6, PSELL_NSTREAMS = 7 };  // streams, in tile order (C has no tiles)
 constexpr int PSELL_MIXED_NARROW_MAX = 15;  // longest row of stream BN (its slices pass through the narrow streams' 7 KiB rings)
 constexpr int PSELL_TILE_SLICES_A2M = 16;
 constexpr int PSELL_TILE_SLICES_BN = 64;
@@ -114,6 +117,10 @@ struct PsellHost {
     std::vector<uint8_t> slice_w;      // [num_slices] transcripts of the slice's set (uniform streams) / longest row (mixed)
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane
+    // stream C: rows kept in CSR (0-based transcript ids) because every sliced form would cost more (psell_build.cpp)
+    std::vector<uint32_t> csr_rowptr;
+    std::vector<uint32_t> csr_col, csr_rows;  // csr_rows: original row ids
+    std::vector<float> csr_val, csr_ks;
 };
 
 // Builds the layout from X in CSR form (0-based): rowptr [m+1], col [nnz], val [nnz].
@@ -133,6 +140,10 @@ struct polee_loglik {
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
     polee::DevBuf<float> d_slice_ks;
+    polee::DevBuf<uint32_t> d_csr_rowptr;  // stream C (rows kept in CSR)
+    polee::DevBuf<uint32_t> d_csr_col;
+    polee::DevBuf<float> d_csr_val, d_csr_ks;
+    int64_t csr_rows = 0, csr_nnz = 0;
     // the streaming kernel: per-pass x windows, static schedule (built for the grid of the first launch)
     polee::DevBuf<float> d_xwin;
     polee::DevBuf<polee::PosDesc> d_sched;

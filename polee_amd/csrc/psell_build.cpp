@@ -437,6 +437,81 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                         });
                 });
         }
+        // Last resort, stream C: mixed tiles pay for a tile dictionary and for padding to the slice's longest row, and
+        // fragments without any structure (a random sparse matrix: every row in other transcripts than its neighbours)
+        // fill a 128-entry dictionary with less than one slice -- 15 - 20 bytes per non-zero.  The tiles the mixed
+        // streams WOULD form are simulated here (same order, same closing rules); rows of a tile that would cost more
+        // than CSR's 8 B per non-zero + 4 B per row are kept as they are, in CSR, for loglik_csr_kernel (lane = row,
+        // global gathers and atomics).  So no input makes the layout larger than CSR.
+        // (Only when that concerns a real share of the matrix -- more than `csr_min_share` of its non-zeros: a handful of
+        // fragments without company stay in stream BN, inside the persistent launch, rather than cost every pass a launch
+        // of their own.)
+        static const bool no_csr = getenv("POLEE_PSELL_NO_CSR") != nullptr;
+        static const double csr_min_share = getenv("POLEE_PSELL_CSR_MIN_SHARE") ? atof(getenv("POLEE_PSELL_CSR_MIN_SHARE")) : 0.005;
+        std::vector<uint32_t> rcsr;
+        const std::vector<uint32_t> rbn_all(rbn), rb_all(rb);
+        if (!no_csr) {
+            std::vector<uint32_t> stamp((size_t)n, 0);
+            uint32_t tile_stamp = 0;
+            for (std::vector<uint32_t> *lst : {&rbn, &rb}) {
+                const size_t cap_slices = lst == &rbn ? (size_t)PSELL_TILE_SLICES_BN : (size_t)PSELL_TILE_SLICES_B;
+                std::vector<uint32_t> kept;
+                size_t i = 0;
+                while (i < lst->size()) {
+                    // one simulated tile: rows i .. j-1
+                    ++tile_stamp;
+                    size_t j = i, dict = 0, nnz_t = 0, bytes = 0, slice_w = 0, in_slice = 0;
+                    while (j < lst->size() && j - i < cap_slices * PSELL_LANES) {
+                        const uint32_t r = (*lst)[j];
+                        size_t fresh = 0;
+                        for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) fresh += stamp[col[k]] != tile_stamp;
+                        if (dict + fresh > (size_t)PSELL_TILE_COLS_TARGET && j > i) break;
+                        for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) stamp[col[k]] = tile_stamp;
+                        dict += fresh;
+                        const size_t len = (size_t)(rowptr[r + 1] - rowptr[r]);
+                        nnz_t += len;
+                        slice_w = std::max(slice_w, len);
+                        if (++in_slice == (size_t)PSELL_LANES) {
+                            bytes += (slice_w * 384 + 255) & ~(size_t)255;
+                            slice_w = in_slice = 0;
+                        }
+                        ++j;
+                    }
+                    if (in_slice) bytes += (slice_w * 384 + 255) & ~(size_t)255;
+                    bytes += 4 * dict + 8;
+                    if (bytes > 8 * nnz_t + 4 * (j - i))
+                        rcsr.insert(rcsr.end(), lst->begin() + i, lst->begin() + j);
+                    else
+                        kept.insert(kept.end(), lst->begin() + i, lst->begin() + j);
+                    i = j;
+                }
+                lst->swap(kept);
+            }
+        }
+        {
+            uint64_t csr_nnz = 0;
+            for (uint32_t r : rcsr) csr_nnz += rowptr[r + 1] - rowptr[r];
+            if (csr_nnz >= (1ull << 32)) return "more than 2^32 non-zeros without any structure are not supported";
+            if ((double)csr_nnz < csr_min_share * (double)rowptr[m]) {  // not worth a launch: back to the mixed streams
+                rcsr.clear();
+                rbn = rbn_all;
+                rb = rb_all;
+            }
+        }
+        if (!rcsr.empty()) {
+            std::sort(rcsr.begin(), rcsr.end());  // (the fragments' input order: neighbouring rows, neighbouring transcripts)
+            out.csr_rowptr.assign(1, 0);
+            for (uint32_t r : rcsr) {
+                out.csr_col.insert(out.csr_col.end(), col + rowptr[r], col + rowptr[r + 1]);
+                out.csr_val.insert(out.csr_val.end(), val + rowptr[r], val + rowptr[r + 1]);
+                out.csr_rowptr.push_back((uint32_t)out.csr_col.size());
+                if (ks) out.csr_ks.push_back((float)ks[r]);
+            }
+            out.csr_rows = rcsr;
+            out.stream_rows[PSELL_C] = (int64_t)rcsr.size();
+            out.stream_nnz[PSELL_C] = (int64_t)out.csr_col.size();
+            out.stream_bytes[PSELL_C] = (int64_t)(8 * out.csr_col.size() + 4 * (rcsr.size() + 1));
+        }
         out.rows_a1 = (int64_t)S1.rows.size();
         out.rows_a1m = out.rows_a1 + (int64_t)S1M.rows.size();
         out.rows_a2 = out.rows_a1m + (int64_t)S2.rows.size();

@@ -29,7 +29,7 @@ def build_stats(smp):
     L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
     nnz = int(v.nnz)
     out = dict(nnz_per_row=nnz / m, stored_entries_per_nnz=v.padded_nnz / nnz,
-               stored_bytes_per_nnz=(v.data_bytes + 4 * (v.num_slices + 1) + 4 * v.dict_len) / nnz,
+               stored_bytes_per_nnz=(v.data_bytes + 4 * (v.num_slices + 1) + 4 * v.dict_len + v.stream_bytes[6]) / nnz,
                csr_bytes_per_nnz=(8 * nnz + 4 * (m + 1)) / nnz, build_s=dt, tiles=int(v.num_tiles),
                tiles_a=int(v.num_tiles_a), tiles_a1=int(v.num_tiles_a1),
                share=[v.stream_nnz[i] / nnz for i in range(6)],
