@@ -443,11 +443,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // streams WOULD form are simulated here (same order, same closing rules); rows of a tile that would cost more
         // than CSR's 8 B per non-zero + 4 B per row are kept as they are, in CSR, for loglik_csr_kernel (lane = row,
         // global gathers and atomics).  So no input makes the layout larger than CSR.
-        // (Only when that concerns a real share of the matrix -- more than `csr_min_share` of its non-zeros: a handful of
+        // (Only when that concerns a real share of the matrix -- more than `csr_min_share` (a tenth) of its non-zeros: a handful of
         // fragments without company stay in stream BN, inside the persistent launch, rather than cost every pass a launch
         // of their own.)
         static const bool no_csr = getenv("POLEE_PSELL_NO_CSR") != nullptr;
-        static const double csr_min_share = getenv("POLEE_PSELL_CSR_MIN_SHARE") ? atof(getenv("POLEE_PSELL_CSR_MIN_SHARE")) : 0.005;
+        static const double csr_min_share = getenv("POLEE_PSELL_CSR_MIN_SHARE") ? atof(getenv("POLEE_PSELL_CSR_MIN_SHARE")) : 0.10;
         std::vector<uint32_t> rcsr;
         const std::vector<uint32_t> rbn_all(rbn), rb_all(rb);
         if (!no_csr) {

@@ -151,15 +151,17 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     out["csr_col"] = np.ctypeslib.as_array(v.csr_col, shape=(nz,)).copy() if nz else np.zeros(0, np.uint32)
     out["csr_val"] = np.ctypeslib.as_array(v.csr_val, shape=(nz,)).copy() if nz else np.zeros(0, np.float32)
     out["csr_ks"] = None if ks is None else np.asarray(ks)[out["csr_rows"]].astype(np.float64)
-    out["data"] = np.ctypeslib.as_array(v.data, shape=(v.data_bytes,)).copy()
-    raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,)).copy()
+    def arr_of(ptr, count, dt):  # (an empty vector's data() may be NULL)
+        return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count and ptr else np.zeros(count, dt)
+    out["data"] = arr_of(v.data, v.data_bytes, np.uint8)
+    raw = arr_of(v.slice_off, v.num_slices + 1, np.uint32)
     out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
     out["slice_flags"] = (raw >> np.uint32(30))[:-1]
-    out["tile_slice"] = np.ctypeslib.as_array(v.tile_slice, shape=(v.num_tiles + 1,)).copy()
-    out["tile_dict"] = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).copy()
-    out["dict"] = np.ctypeslib.as_array(v.dict, shape=(v.dict_len,)).copy()
-    out["row_order"] = np.ctypeslib.as_array(v.row_order, shape=(v.num_slices * 64,)).copy()
-    out["ks"] = None if not v.slice_ks else np.ctypeslib.as_array(v.slice_ks, shape=(v.num_slices * 64,)).copy()
+    out["tile_slice"] = arr_of(v.tile_slice, v.num_tiles + 1, np.uint32)
+    out["tile_dict"] = arr_of(v.tile_dict, v.num_tiles + 1, np.uint32)
+    out["dict"] = arr_of(v.dict, v.dict_len, np.uint32)
+    out["row_order"] = arr_of(v.row_order, v.num_slices * 64, np.uint32)
+    out["ks"] = None if ks is None else arr_of(v.slice_ks, v.num_slices * 64, np.float32)
     L.lib().polee_debug_psell_free(h)
     return out
 
@@ -261,7 +263,8 @@ def test_psell_layout_reproduces_oracle_on_fixture(lm_fixture):
     ps = _psell(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
     assert ps["nnz"] == 42775 and ps["empty"] == 0 and ps["max_row"] == 15
     ro = ps["row_order"]
-    assert sorted(ro[ro != 0xFFFFFFFF].tolist()) == list(range(f["m"]))  # every fragment exactly once
+    assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["csr_rows"].tolist()) == list(range(f["m"]))  # every fragment exactly once
+    assert len(ps["csr_rows"]) == 0 and ps["num_tiles"] == ps["num_tiles_s"]  # real data: one launch
     assert ps["max_tile_cols"] <= 1024
     # (stored entries / non-zeros: zero lanes of partial slices and the zeros of union slices, on a sample of only 19 743
     # fragments in ~1 300 distinct transcript sets; 1.02 at BASELINE's C2)
@@ -276,17 +279,25 @@ def test_psell_layout_reproduces_oracle_on_fixture(lm_fixture):
         np.testing.assert_allclose(g[k], g_o, rtol=1e-6, atol=1e-9)
 
 
-def test_psell_ragged_and_empty_rows():
-    """Edge cases: empty rows, empty columns, a row hitting many transcripts, ks multiplicities."""
+@pytest.mark.parametrize("structured", [True, False])
+def test_psell_ragged_and_empty_rows(structured):
+    """Edge cases: empty rows, empty columns, a row hitting many transcripts, ks multiplicities.  structured: most rows in
+    equivalence classes (the 900-transcript row gets a mixed tile of its own, stream B); otherwise a random matrix, which
+    stays in CSR (stream C)."""
     rng = np.random.default_rng(4)
-    m, n = 700, 1500
+    m, n = (4000 if structured else 700), 1500  # (structured: the long row is a few per cent of the non-zeros)
     rows, cols = [], []
+    classes = [np.sort(rng.choice(n, 1 + int(rng.integers(0, 9)), replace=False)) for _ in range(10)]
     for i in range(m):
         if i % 50 == 7:
             continue  # empty fragment
-        ln = 1 + int(rng.integers(0, 4)) if i != 3 else 900
-        cs = np.sort(rng.choice(n, ln, replace=False))
-        rows += [i] * ln; cols += cs.tolist()
+        if i == 3:
+            cs = np.sort(rng.choice(n, 900, replace=False))
+        elif structured:
+            cs = classes[i % 10]
+        else:
+            cs = np.sort(rng.choice(n, 1 + int(rng.integers(0, 4)), replace=False))
+        rows += [i] * len(cs); cols += cs.tolist()
     rows, cols = np.array(rows), np.array(cols)
     vals = rng.uniform(1e-9, 1e-3, rows.size).astype(np.float32)
     order = np.lexsort((rows, cols))
@@ -294,7 +305,11 @@ def test_psell_ragged_and_empty_rows():
     colptr = np.zeros(n + 1, np.uint32); np.add.at(colptr, cols + 1, 1); colptr = np.cumsum(colptr).astype(np.uint32) + 1
     ks = rng.integers(1, 5, m).astype(np.int64)
     ps = _psell(m, n, colptr, (rows + 1).astype(np.uint32), vals, ks)
-    assert ps["empty"] == 14 and ps["max_row"] == 900 and ps["num_tiles"] >= 2
+    assert ps["empty"] == m // 50 and ps["max_row"] == 900
+    if structured:
+        assert ps["num_tiles"] > ps["num_tiles_s"] >= 1 and len(ps["csr_rows"]) == 0  # the long row: stream B
+    else:
+        assert len(ps["csr_rows"]) == m - m // 50 and ps["num_tiles"] == 0  # no structure: everything stays in CSR
     x = rng.dirichlet(np.ones(n), size=2).astype(np.float32)
     lp, g = _emulate_psell(ps, x, n)
     # reference semantics with numpy
