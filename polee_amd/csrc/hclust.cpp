@@ -152,6 +152,18 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
     };
     if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
     const int K = 25;  // neighbours compared left and right (:200)
+    // PRUNED neighbour lists (opt-in, POLEE_HCLUST_PRUNE=1): the reference
+    // lists a neighbour whether it shares reads or not, and re-evaluates it at every merge.  A neighbour without a common
+    // read never gets an edge -- a node that shares no read with j1 and none with j2 shares none with their union --, so it
+    // is left out of the lists: nine in ten of the +-25 window are such.  Every edge the reference pushes is still pushed,
+    // with the same similarity, in the same relative order; what changes is that a node listed by BOTH merged nodes (once
+    // without common reads) is a candidate once instead of twice, i.e. fewer duplicate edges in the heap -- which moves
+    // heap positions and therefore the reference's tie-breaking among EQUAL similarities.  The exact mode reproduces the
+    // reference's heap order node for node (tests/test_layouts.py against oracle/hclust_ref.py); the pruned mode builds a
+    // tree by the same greedy rule with different tie-breaks.
+    // (measured: 0.92 -> 0.79 s at n = 20 000, m = 3 M on 8 host threads -- the heap, not the lists, is the bulk -- so the
+    // exact mode stays the default and pruning is opt-in)
+    const bool prune = getenv("POLEE_HCLUST_PRUNE") != nullptr;
     static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
@@ -220,8 +232,10 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
             const float sim = sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)];
             if (sim > 0) queue.push(Edge{(uint32_t)j1, (uint32_t)j2, sim});
-            neighbors[(size_t)j1].push_back((uint32_t)j2);
-            neighbors[(size_t)j2].push_back((uint32_t)j1);
+            if (sim > 0 || !prune) {
+                neighbors[(size_t)j1].push_back((uint32_t)j2);
+                neighbors[(size_t)j2].push_back((uint32_t)j1);
+            }
         }
     std::vector<float>().swap(sims);
     lap("initial edges");
@@ -319,8 +333,10 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         for (size_t c = 0; c < cand.size(); ++c) {
             const uint32_t l = cand[c];
             if (csim[c] != 0) queue.push(Edge{l, k, (float)csim[c]});
-            neighbors[l].push_back(k);
-            neighbors[k].push_back(l);
+            if (csim[c] != 0 || !prune) {
+                neighbors[l].push_back(k);
+                neighbors[k].push_back(l);
+            }
         }
     }
 
