@@ -101,6 +101,35 @@ __device__ inline float fast_weight(float ksv, float s)
 // s >= 1e-28) is unchanged by the addend, bit for bit.  The weight is then one v_rcp_f32, no compare or select.
 constexpr float ROWSUM_FLOOR = 1.17549435e-38f;
 
+// Sum of the logs of a lane's row sums WITHOUT a logarithm in the slice loop.  log s = exponent(s) ln 2 + log mantissa(s), so
+// a lane keeps the PRODUCT of the mantissas (brought back into [0.5, 1) at every step) and the SUM of the exponents -- two
+// v_frexp pairs, a multiply and two integer adds per row sum, no float64 -- and takes one logarithm when its share of the
+// tile is done.  The mantissa product is rounded to float32 at every step: a relative 6e-8 per factor, i.e. an absolute
+// ~1e-6 on the log of a lane's ~100 row sums, against log-likelihoods of 1e6 .. 1e9.  (The float64 log per row sum that
+// stood here kept ~30 registers live inside the loop: with the masked streams in the same kernel the instances that
+// return lp spilled, and a spill's reload drains the LDS-DMA ring -- the pass took 1.40 ms instead of 0.25.)
+struct LogAcc {
+    float m;  // in [0.5, 1)
+    int e;
+    __device__ inline void init()
+    {
+        m = 0.5f;
+        e = 1;
+    }
+    __device__ inline void mul(float s, bool valid)  // *= s (valid) or *= 1
+    {
+        const float sv = valid ? s : 1.0f;
+        const float p = m * __builtin_amdgcn_frexp_mantf(sv);
+        m = __builtin_amdgcn_frexp_mantf(p);
+        e += __builtin_amdgcn_frexp_expf(sv) + __builtin_amdgcn_frexp_expf(p);
+    }
+    // (the mantissa's log with the hardware log2 -- an absolute 1e-7, once per lane and tile: no float64 logarithm, with its
+    // thirty live registers, anywhere in the kernel)
+    __device__ inline double log_value() const { return ((double)e + (double)__builtin_amdgcn_logf(m)) * 0.693147180559945309417; }
+};
+// multiplicities: ks log s with the hardware log2 (1 ulp of float32), summed in float64; x ln 2 at the end
+__device__ inline double ks_log2(float ksv, float s) { return (double)(ksv * __builtin_amdgcn_logf(s)); }
+
 // ---- stream B (and fallback for very wide rows): mixed slices ---------------------------------------
 // Two sweeps over each slice straight from global memory (the second one hits L1/L2); contributions
 // are summed per run of equal transcript ids with DPP before touching LDS.  Few registers -> high
@@ -510,6 +539,9 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
     for (int st = 0; st < NS; ++st) xq[st] = 0.0f;
     int pend_w = 0;  // transcripts of the current run (0: no run open)
+    LogAcc lpl;       // (WANT_LP) log of the product of this lane's row sums; with multiplicities: lp2 = sum ks log2 s
+    lpl.init();
+    double lp2 = 0.0;
     bool pend_packed = false;  // the run accumulates in the packed (two 8 x 8 blocks) layout
     auto flush = [&]() {
         if (NT == 1 && pend_packed) {
@@ -696,7 +728,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sv = d1[e][v];
-                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lpacc += (double)kv[e] * log((double)sv);
+                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lp2 += ks_log2(kv[e], sv);
                     d1[e][v] = kv[e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
                 }
             }
@@ -706,7 +738,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float sv = d1[e][v];
-                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lpacc += log((double)sv);
+                    if (WANT_LP) lpl.mul(sv, sv > 2.0f * ROWSUM_FLOOR);
                     d1[e][v] = __builtin_amdgcn_rcpf(sv);
                 }
         }
@@ -754,6 +786,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         STAMP(6);  // refill
     }
     if (pend_w != 0) flush();
+    if (WANT_LP) lpacc += HAS_KS ? lp2 * 0.693147180559945309417 : lpl.log_value();
 }
 
 
@@ -862,9 +895,13 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
     uint32_t xav = aux_lds, gav = aux_lds + 32u;  // lane t < 16: LDS addresses of the x row / gradient row of the run's transcript t
     int pend_w = 0;
     int run_w = 0;  // (MASKED) transcripts of the current run's union
-    double lpn[KG];
+    LogAcc lpl[KG];   // (WANT_LP) per draw group: log of the product of this lane's row sums (LogAcc above)
+    double lp2[KG];   // ... with multiplicities: sum of ks log2 s
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) lpn[kg] = 0.0;
+    for (int kg = 0; kg < KG; ++kg) {
+        lpl[kg].init();
+        lp2[kg] = 0.0;
+    }
 
     // Flush of a group of four transcripts: acc[g][kg][v], lane (b, j) is block b's part of G[4 g + v][4 kg + j].  The
     // four registers v are first added across the wave's four rows of 16 lanes and scattered (gfx950 lane swaps: row r
@@ -1013,8 +1050,14 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float sv = d1[kg][i];
-                        if (WANT_LP && 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR)
-                            lpn[kg] += HAS_KS ? (double)kv[i] * log((double)sv) : log((double)sv);
+                        if (WANT_LP) {
+                            const bool valid = 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR;
+                            if (HAS_KS) {
+                                if (valid) lp2[kg] += ks_log2(kv[i], sv);
+                            } else {
+                                lpl[kg].mul(sv, valid);
+                            }
+                        }
                         d1[kg][i] = HAS_KS ? kv[i] * __builtin_amdgcn_rcpf(sv) : __builtin_amdgcn_rcpf(sv);  // (padded fragments: ks = 0)
                     }
             };
@@ -1129,7 +1172,7 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         // into the caller's accumulator, whose lane l < 16 collects draw l: the sixteen blocks' sums of draw 4 kg + j
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-            double v = lpn[kg];
+            double v = HAS_KS ? lp2[kg] * 0.693147180559945309417 : lpl[kg].log_value();
             v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 8, 64);
             v += __shfl_xor(v, 16, 64);
@@ -1225,9 +1268,13 @@ __device__ inline void mixed_stream(WaveStream &ws, const char *ring, int extras
             for (int k = 0; k < K; ++k) sacc[k] = fmaf(v, *reinterpret_cast<lds_cfp>((uintptr_t)(a + 4u * (uint32_t)k)), sacc[k]);
         }
     };
-    double lpk[WANT_LP ? K : 1];
+    LogAcc lpl[WANT_LP ? K : 1];  // (WANT_LP) per draw (LogAcc above); with multiplicities lp2 = sum ks log2 s
+    double lp2[WANT_LP ? K : 1];
 #pragma unroll
-    for (int k = 0; k < (WANT_LP ? K : 1); ++k) lpk[k] = 0.0;
+    for (int k = 0; k < (WANT_LP ? K : 1); ++k) {
+        lpl[k].init();
+        lp2[k] = 0.0;
+    }
 
     uint32_t pos = 0, pos_r = 0;
     for (int si = 0; si < ws.nsl; ++si) {
@@ -1259,7 +1306,13 @@ __device__ inline void mixed_stream(WaveStream &ws, const char *ring, int extras
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             wk[k] = fast_weight(ksv, sacc[k]);  // (lanes without a fragment: s = 0, weight 0)
-            if (WANT_LP && sacc[k] > 0.0f) lpk[WANT_LP ? k : 0] += (double)ksv * log((double)sacc[k]);
+            if (WANT_LP) {
+                if (HAS_KS) {
+                    if (sacc[k] > 0.0f) lp2[WANT_LP ? k : 0] += ks_log2(ksv, sacc[k]);
+                } else {
+                    lpl[WANT_LP ? k : 0].mul(sacc[k], sacc[k] > 0.0f);
+                }
+            }
         }
         STAMP(4);
         for (int t = 0; t < w; ++t) {
@@ -1283,7 +1336,7 @@ __device__ inline void mixed_stream(WaveStream &ws, const char *ring, int extras
         // into the caller's accumulator, whose lane l < 16 collects draw l
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            double v = lpk[WANT_LP ? k : 0];
+            double v = HAS_KS ? lp2[WANT_LP ? k : 0] * 0.693147180559945309417 : lpl[WANT_LP ? k : 0].log_value();
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
             if (lane == k) lpacc += v;
@@ -1333,9 +1386,13 @@ __device__ inline void wide_masked_stream(WaveStream &ws, const char *ring, int 
     // lane t < 16: LDS addresses of the x row / gradient row of the union's transcripts t and 16 + t
     uint32_t xav0 = aux_lds, gav0 = aux_lds + 32u, xav1 = aux_lds, gav1 = aux_lds + 32u;
     int run_w = 0;
-    double lpn[KG];
+    LogAcc lpl[KG];  // (WANT_LP) see narrow_stream
+    double lp2[KG];
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) lpn[kg] = 0.0;
+    for (int kg = 0; kg < KG; ++kg) {
+        lpl[kg].init();
+        lp2[kg] = 0.0;
+    }
 
     auto flush_group = [&](int g, uint32_t gav) {  // (as in narrow_stream)
         const uint32_t ga0 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 0), ga2 = (uint32_t)__builtin_amdgcn_readlane((int)gav, 4 * g + 2);
@@ -1473,8 +1530,14 @@ __device__ inline void wide_masked_stream(WaveStream &ws, const char *ring, int 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float sv = d1[kg][i];
-                    if (WANT_LP && 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR)
-                        lpn[kg] += HAS_KS ? (double)kv[i] * log((double)sv) : log((double)sv);
+                    if (WANT_LP) {
+                        const bool valid = 4 * kg + j < K && sv > 2.0f * ROWSUM_FLOOR;
+                        if (HAS_KS) {
+                            if (valid) lp2[kg] += ks_log2(kv[i], sv);
+                        } else {
+                            lpl[kg].mul(sv, valid);
+                        }
+                    }
                     d1[kg][i] = HAS_KS ? kv[i] * __builtin_amdgcn_rcpf(sv) : __builtin_amdgcn_rcpf(sv);
                 }
 #pragma unroll
@@ -1511,7 +1574,7 @@ __device__ inline void wide_masked_stream(WaveStream &ws, const char *ring, int 
     if (WANT_LP) {
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-            double v = lpn[kg];
+            double v = HAS_KS ? lp2[kg] * 0.693147180559945309417 : lpl[kg].log_value();
             v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 8, 64);
             v += __shfl_xor(v, 16, 64);
@@ -1624,7 +1687,10 @@ constexpr uint32_t stream_lds_bytes()  // (deterministic mode: one gradient wind
 // LDS adds retire in program order), the tile's flush sums the four windows in wave order and STORES the result to the
 // tile's slot of gwin, and gwin_reduce_kernel adds a transcript's slots in tile order.
 template <int K, bool WANT_LP, bool HAS_KS, bool DET>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// (The instances that also return lp carry the log accumulators across the slice loops: at four waves per SIMD -- 128
+// registers -- they spill, and a spill's reload drains the LDS-DMA ring (measured: 1.40 ms per pass instead of 0.25).  They run
+// three workgroups per CU, 170 registers, no scratch.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WANT_LP ? 3 : 4, WANT_LP ? 3 : 4)))
 void loglik_stream_kernel(PsellArgs A, int dbg)
 {
     extern __shared__ float lds[];
