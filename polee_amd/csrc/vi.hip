@@ -160,6 +160,7 @@ struct polee_vi {
     polee_comm *comm = nullptr;  // row-sharded fit: sum the likelihood gradient (and lp) over ranks each pass
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<float> d_zcur;  // [n-1][K] the current iteration's N(0,1) draws
+    DevBuf<uint32_t> d_open_ptr, d_open_code;  // per forward-scan chunk: the tour's ENTER entries still open at its start
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
     DevBuf<int> d_flag;
@@ -206,7 +207,10 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
     // (up to 2048 chunks every apply workgroup sums the totals of the chunks before it itself: no spine launch)
     const int own_f = nch_f <= 2048, own_b = nch_b <= 2048;
-    if (nch_f > 1) {
+    const bool open_lists = vi->d_open_ptr.p != nullptr;
+    if (open_lists) {
+        // (the chunks' offsets come from the tree's open-edge lists: no reduce launch)
+    } else if (nch_f > 1) {
         hipLaunchKernelGGL((vi_fwd_reduce_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
         if (!own_f) hipLaunchKernelGGL((scan_spine_kernel<VK<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
     } else {
@@ -214,7 +218,8 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     }
     hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                        vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0);
+                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
+                       (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
@@ -518,6 +523,36 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         A(vi->d_part_ladj.alloc(ctx, nch * K));
         A(vi->d_csum.alloc(ctx, PSELL_MAX_K));
     }
+    {   // The forward scan's chunk offsets from the tree (vi_fwd_apply_kernel): for every chunk of the Euler tour the ENTER
+        // entries still open at its first entry = the path from the root to that point.  One walk over the tour with a
+        // stack; kept when the lists stay small (a caterpillar tree of 200 000 leaves would need n^2 / 1024 entries: the
+        // reduce launch stays for such trees).
+        static const bool no_open = getenv("POLEE_VI_NO_OPEN_LISTS") != nullptr;  // (A/B)
+        const std::vector<uint32_t> &code = t->plans[0].tour_code;
+        const int64_t TL = t->TL;
+        const int nch = std::max(scan_num_chunks(TL), 1);
+        const size_t limit = (size_t)8 << 20;
+        std::vector<uint32_t> optr((size_t)nch + 1, 0), ocode, stack;
+        bool ok = !no_open && t->T == 1 && (int64_t)code.size() == TL;
+        for (int64_t e = 0; ok && e < TL; ++e) {
+            if (e % SCAN_CHUNK == 0) {
+                optr[(size_t)(e / SCAN_CHUNK)] = (uint32_t)ocode.size();
+                ocode.insert(ocode.end(), stack.begin(), stack.end());
+                if (ocode.size() > limit) ok = false;
+            }
+            const uint32_t type = code[(size_t)e] & 3u;
+            if (type == TOUR_ENTER) stack.push_back(code[(size_t)e]);
+            else if (type == TOUR_EXIT) {
+                if (stack.empty()) ok = false; else stack.pop_back();
+            }
+        }
+        if (ok) {
+            optr[(size_t)nch] = (uint32_t)ocode.size();
+            if (ocode.empty()) ocode.push_back(4u | TOUR_LEAF);  // (never read)
+            A(vi->d_open_ptr.upload(ctx, optr));
+            A(vi->d_open_code.upload(ctx, ocode));
+        }
+    }
     A(vi->d_ygrad.alloc(ctx, nm1 * K));
     A(vi->d_xgrad_rows.alloc(ctx, n * K));
     A(vi->d_lp.alloc(ctx, PSELL_MAX_K));
@@ -776,7 +811,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         }
         hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                           vi->d_part_c.p, (double *)nullptr, 0);
+                           vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         POLEE_KERNEL_CHECK(ctx);
         return POLEE_OK;
     };

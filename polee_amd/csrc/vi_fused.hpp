@@ -218,7 +218,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                                                                    float *__restrict__ g,
                                                                    const float *__restrict__ efflens, float clamp_lo,
                                                                    float clamp_hi, double *__restrict__ part_c,
-                                                                   double *__restrict__ part_ladj, int own_prefix)
+                                                                   double *__restrict__ part_ladj, int own_prefix,
+                                                                   const uint32_t *__restrict__ open_ptr,
+                                                                   const uint32_t *__restrict__ open_code)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
@@ -235,8 +237,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
     }
     VK<K> tot;
     VK<K> off = block_exclusive_scan<VK<K>>(acc, smem, &tot);
-    // chunk_offsets holds the chunks' exclusive offsets (after a spine pass) or, with own_prefix, their totals
-    off = ScanOps<VK<K>>::add(own_prefix ? chunk_prefix<VK<K>>(chunk_offsets, blockIdx.x, smem) : chunk_offsets[blockIdx.x], off);
+    // The chunk's offset = the tour prefix in front of it.  Every ENTER before the chunk whose EXIT lies before it too has
+    // cancelled, so the prefix is the sum of the edge logs of the nodes that are OPEN at the chunk's first entry -- the
+    // path from the root to that point, a list fixed by the tree (open_ptr / open_code, built once per fit): with it the
+    // forward pass needs no reduce launch and no pass over the other chunks' totals.  Without the lists (very deep trees):
+    // chunk_offsets holds the chunks' exclusive offsets (after a spine pass) or, with own_prefix, their totals.
+    if (open_ptr) {
+        VK<K> acc2 = ScanOps<VK<K>>::zero(), edge2;
+        for (uint32_t e = open_ptr[blockIdx.x] + threadIdx.x; e < open_ptr[blockIdx.x + 1]; e += SCAN_THREADS)
+            acc2 = ScanOps<VK<K>>::add(acc2, tour_value<K>(open_code[e], lyy, edge2));  // (ENTER codes: + the edge's log)
+        VK<K> pre;
+        (void)block_exclusive_scan<VK<K>>(acc2, smem, &pre);
+        off = ScanOps<VK<K>>::add(pre, off);
+    } else {
+        off = ScanOps<VK<K>>::add(own_prefix ? chunk_prefix<VK<K>>(chunk_offsets, blockIdx.x, smem) : chunk_offsets[blockIdx.x], off);
+    }
     double pc[K], pl[K];
 #pragma unroll
     for (int d = 0; d < K; ++d) pc[d] = pl[d] = 0.0;
