@@ -2106,8 +2106,9 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         A.gwin = ll->d_gwin.p;
         A.lpwin = ll->d_lpwin.p;
     }
-    hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, ll->d_dict.p,
-                       A.x, ll->dict_len, ll->d_xwin.p);
+    if (!ll->xwin_ready)
+        hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, ll->d_dict.p,
+                           A.x, ll->dict_len, ll->d_xwin.p);
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
@@ -2181,8 +2182,9 @@ static polee_status launch_k(polee_loglik *ll, const float *d_x, float *d_g, dou
                       : launch_variant<K, false, false>(ll, d_x, d_g, d_lp);
 }
 
-polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp)
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready)
 {
+    ll->xwin_ready = xwin_ready;
     polee_ctx *ctx = ll->ctx;
     if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
     // (the pass is a single launch: one pair of events brackets both the kernel and the pass)
@@ -2402,6 +2404,10 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         }
     }
     if ((s = ll->d_xwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512)) ||
+        // (the dictionaries' padding entries are never referenced by a slice; they are read into LDS with their tile's
+        // window, and the VI loop's forward kernel -- which fills the windows through the slot lists -- does not write them)
+        (hipMemsetAsync(ll->d_xwin.p, 0, ((size_t)ll->dict_len * PSELL_MAX_K + 512) * sizeof(float), ctx->stream) != hipSuccess &&
+         (s = fail(ctx, POLEE_ERR_HIP, "hipMemset failed")) != POLEE_OK) ||
         (s = ensure_schedule(ll, (int)std::min<int64_t>((int64_t)4 * ctx->num_cus, std::max<int64_t>(h.num_tiles, 1))))) {
         loglik_release(ll);
         return s;

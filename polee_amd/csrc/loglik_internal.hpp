@@ -136,6 +136,7 @@ struct polee_loglik {
     int64_t m = 0, n = 0, nnz = 0;
     bool has_ks = false;
     bool force_mixed = false;  // debug: process every slice with the mixed-slice kernel
+    bool xwin_ready = false;   // (per call) the x windows are already filled
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;
@@ -181,5 +182,7 @@ namespace polee {
 // (also accumulated into).
 void loglik_retain(polee_loglik *ll);
 void loglik_release(polee_loglik *ll);
-polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp);
+// xwin_ready: the caller has already written the tiles' x windows (ll->d_xwin, through the slot lists d_tslot_ptr / d_tslot:
+// the VI loop's forward kernel does, saving the gather launch)
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready = false);
 }  // namespace polee

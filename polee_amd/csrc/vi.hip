@@ -208,6 +208,11 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // (up to 2048 chunks every apply workgroup sums the totals of the chunks before it itself: no spine launch)
     const int own_f = nch_f <= 2048, own_b = nch_b <= 2048;
     const bool open_lists = vi->d_open_ptr.p != nullptr;
+    // (Experiment, POLEE_VI_XWIN_FOLD=1: the forward kernel also writes the sparse pass's x windows through the slot lists,
+    // so that the gather launch in front of the pass goes.  Measured at C2: the pass loses its 6.9 us gather, the forward
+    // kernel gains ~17 us of scattered 24-byte stores behind two dependent loads -- 2 570 against 2 695 iterations/s.  Off.)
+    static const bool xwin_fold = getenv("POLEE_VI_XWIN_FOLD") != nullptr && getenv("POLEE_NO_RING") == nullptr;
+    const bool xwin_here = xwin_fold && !vi->ll->force_mixed && vi->ll->d_xwin.p && vi->ll->d_tslot_ptr.p && vi->ll->host.num_tiles_s > 0;
     if (open_lists) {
         // (the chunks' offsets come from the tree's open-edge lists: no reduce launch)
     } else if (nch_f > 1) {
@@ -219,14 +224,16 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                        vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
                        eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
-                       (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p);
+                       (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
+                       xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
+                       xwin_here ? vi->ll->d_xwin.p : nullptr);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
     {
         const bool det_saved = vi->ll->deterministic;
         if (o.deterministic) vi->ll->deterministic = true;
-        const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr);
+        const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr, xwin_here);
         vi->ll->deterministic = det_saved;
         POLEE_TRY(ls);
     }
@@ -811,7 +818,8 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         }
         hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                           vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                           vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr);
         POLEE_KERNEL_CHECK(ctx);
         return POLEE_OK;
     };

@@ -220,10 +220,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                                                                    float clamp_hi, double *__restrict__ part_c,
                                                                    double *__restrict__ part_ladj, int own_prefix,
                                                                    const uint32_t *__restrict__ open_ptr,
-                                                                   const uint32_t *__restrict__ open_code)
+                                                                   const uint32_t *__restrict__ open_code,
+                                                                   const uint32_t *__restrict__ tslot_ptr,
+                                                                   const uint32_t *__restrict__ tslot,
+                                                                   float *__restrict__ xwin)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
+    // x windows of the sparse pass (loglik_internal.hpp): a transcript's x row also goes to its slot in every tile
+    // dictionary that holds it (tslot lists) -- the gather launch in front of the pass is gone.  A thread writes up to
+    // XW_INLINE slots itself; transcripts in more tiles are written by the whole workgroup afterwards.
+    constexpr int XW_INLINE = 12, XW_DEFER = 48;
+    __shared__ uint32_t xw_tid[XW_DEFER];
+    __shared__ float xw_val[XW_DEFER][K];
+    __shared__ int xw_count;
+    if (xwin && threadIdx.x == 0) xw_count = 0;
+    if (xwin) __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     VK<K> val[SCAN_ITEMS], edge[SCAN_ITEMS];
     uint32_t code[SCAN_ITEMS];
@@ -275,12 +287,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                     g[(size_t)tid * K + d] = 0.0f;
                     pc[d] += (double)(x * inv_l);  // xls[i] = xs[i] / efflens[i] in f32 (likelihood.jl:97)
                 }
+                if (xwin) {
+                    const uint32_t sb = tslot_ptr[tid], se = tslot_ptr[tid + 1];
+                    int q = -1;
+                    if (se - sb > (uint32_t)XW_INLINE) q = atomicAdd(&xw_count, 1);
+                    if (q >= 0 && q < XW_DEFER) {
+                        xw_tid[q] = (uint32_t)tid;
+#pragma unroll
+                        for (int d = 0; d < K; ++d) xw_val[q][d] = xs[(size_t)tid * K + d];
+                    } else {
+                        for (uint32_t e = sb; e < se; ++e) {
+                            float *w = xwin + (size_t)tslot[e] * K;
+#pragma unroll
+                            for (int d = 0; d < K; ++d) w[d] = xs[(size_t)tid * K + d];
+                        }
+                    }
+                }
             } else if (type == TOUR_ENTER && part_ladj) {
 #pragma unroll
                 for (int d = 0; d < K; ++d) pl[d] += inc.v[d];
             }
         }
         off = inc;
+    }
+    if (xwin) {
+        __syncthreads();
+        const int cnt = min(xw_count, XW_DEFER);
+        for (int q = 0; q < cnt; ++q) {
+            const uint32_t tid = xw_tid[q], sb = tslot_ptr[tid], se = tslot_ptr[tid + 1];
+            for (uint32_t e = sb * K + threadIdx.x; e < se * K; e += SCAN_THREADS) {
+                const uint32_t slot = e / K, d = e - slot * K;
+                xwin[(size_t)tslot[slot] * K + d] = xw_val[q][d];
+            }
+        }
     }
     if (part_c) {
         block_sum_vec<K>(pc, smd);
