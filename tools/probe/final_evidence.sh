@@ -10,7 +10,7 @@ python3 bench.py --steps 20 --warmup 5 2> $O/bench_c2.err | tail -1 > $O/bench_c
 python3 bench.py --steps 500 --warmup 5 --cpu-steps 0 2>/dev/null | tail -1 > $O/bench_c2_500.json
 python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --deterministic 2>/dev/null | tail -1 > $O/bench_c2_det.json
 python3 bench.py --workload c5 --steps 20 --warmup 3 --cpu-steps 0 2>/dev/null | tail -1 > $O/bench_c5.json
-python3 bench.py --workload c3 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_c3.json
+python3 bench.py --workload c3 --steps 300 --warmup 10 2>/dev/null | tail -1 > $O/bench_c3.json
 for s in 2 4; do python3 bench.py --steps 50 --warmup 5 --cpu-steps 0 --samples-per-gpu $s 2>/dev/null | tail -1 > $O/bench_c2_cohort$s.json; done
 # the per-tile kernel alone over every slice (the cross-check algorithm; also what the mixed stream B runs on)
 POLEE_NO_RING=1 python3 bench.py --steps 10 --warmup 2 --cpu-steps 0 --prewarm 20 2>/dev/null | tail -1 > $O/bench_c2_per_tile_kernel.json
