@@ -444,6 +444,18 @@ polee_status polee_regression_set_normal_likelihood(polee_regression *reg, const
  * qx_isoform_softplus_scale [S][nt]; and appends noise (mean [nt], isoform [S][nt]) to the noise vector. */
 polee_status polee_regression_set_gene_likelihood(polee_regression *reg, polee_approx *ap, const int32_t *gene_of,
                                                   const float *x_isoform_init);
+/* RNASeqGeneIsoformLinearRegression (models/polee_regression.py:656-877): as above, but the isoform block is a
+ * regression of its own over the nt transcripts: x_isoform ~ Normal(x_isoform_bias + F_isoform w_isoform,
+ * x_isoform_scale) with horseshoe+ coefficients w_isoform [Fi][nt] (:698-720), x_isoform_bias ~ Normal(0, 2) (:722-724),
+ * x_isoform_scale ~ InverseGamma(0.001, 0.001) (:728-729) and the surrogates of :736-833.  design_isoform f32 [S][Fi].
+ * The isoform block then holds, in this order (the model's own order with the isoform design and no hinges):
+ * global scale variance loc / softplus_scale, global scale noncentered loc / softplus_scale; [Fi][nt] arrays local1
+ * variance loc / s, local1 noncentered loc / s, local2 variance loc / s, local2 noncentered loc / s, w loc / s;
+ * [nt] arrays bias loc / s, scale loc / s; [S][nt] arrays x_isoform loc / s.  Noise appended to the noise vector: 2
+ * globals, five [Fi][nt] arrays (the four scales, w), bias [nt], scale [nt], x_isoform [S][nt]. */
+polee_status polee_regression_set_gene_isoform_likelihood(polee_regression *reg, polee_approx *ap,
+                                                          const int32_t *gene_of, const float *x_isoform_init,
+                                                          const float *design_isoform, int32_t num_isoform_factors);
 int64_t polee_regression_num_isoform_params(const polee_regression *reg);
 polee_status polee_regression_get_isoform_params(polee_regression *reg, float *params);
 polee_status polee_regression_set_isoform_params(polee_regression *reg, const float *params);

@@ -456,6 +456,35 @@ end
 set_comm!(r::Regression, c) =
     check(ccall((:polee_regression_set_comm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.h, c === nothing ? C_NULL : c.h), r.ctx.h)
 
+"""
+gene-level likelihood on a model created over the genes (ap = nothing): RNASeqGeneLinearRegression
+(models/polee_regression.py:533-600), or with `F_isoform` (S x Fi) RNASeqGeneIsoformLinearRegression (:656-877).
+`gene_of`: 1-based gene of every transcript; `x_isoform_init`: S x nt.
+"""
+function set_gene_likelihood!(r::Regression, ap::ApproxLikelihood, gene_of::AbstractVector{<:Integer},
+                              x_isoform_init::AbstractMatrix; F_isoform::Union{Nothing,AbstractMatrix}=nothing)
+    g = Int32.(gene_of .- 1)
+    xi = Matrix{Float32}(x_isoform_init')            # row-major [S][nt]
+    if F_isoform === nothing
+        GC.@preserve g xi check(ccall((:polee_regression_set_gene_likelihood, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}), r.h, ap.h, g, xi), r.ctx.h)
+    else
+        Fi = Matrix{Float32}(F_isoform')             # row-major [S][Fi]
+        GC.@preserve g xi Fi check(ccall((:polee_regression_set_gene_isoform_likelihood, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Int32),
+            r.h, ap.h, g, xi, Fi, Int32(size(F_isoform, 2))), r.ctx.h)
+    end
+    return r
+end
+
+"the isoform block of a gene-level / gene-isoform model as a flat vector (order: include/polee_hip.h)"
+function isoform_params(r::Regression)
+    n = Int(ccall((:polee_regression_num_isoform_params, LIB), Int64, (Ptr{Cvoid},), r.h))
+    p = Vector{Float32}(undef, n)
+    GC.@preserve p check(ccall((:polee_regression_get_isoform_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, p), r.ctx.h)
+    return p
+end
+
 # ---- host-staged communicator: the all-reduce is the caller's (e.g. MPI.Allreduce!) ----------------------------------
 mutable struct HostComm
     h::Ptr{Cvoid}

@@ -147,6 +147,54 @@ def isoform_terms(ip, ie, x_gene, gene_lik=None):
     return float(logq - logp), xi
 
 
+def isoform_regression_terms(ip, ie, design_isoform, x_gene, gene_lik=None):
+    """Gene-isoform model (RNASeqGeneIsoformLinearRegression.likelihood_model / surrogate_likelihood_model,
+    models/polee_regression.py:696-733 and :777-830): log q - log p of the isoform block at the draw `ie` (with
+    -gene_lik(x_gene, x_isoform) when given) and the draws.  `ip` / `ie`: PARAMS / NOISE unflattened with F = the
+    isoform factors, n = the transcripts, deg = 0 (the block has the model's own order without the hinge arrays)."""
+    logq = 0.0
+
+    def sp_normal(loc, sraw, e):
+        nonlocal logq
+        s = softplus(ip[sraw])
+        u = ip[loc] + s * e
+        logq += np.sum(_normal_lp(u, ip[loc], s) - log_sigmoid(u))
+        return softplus(u)
+
+    def normal(loc, sraw, e):
+        nonlocal logq
+        s = softplus(ip[sraw])
+        v = ip[loc] + s * e
+        logq += np.sum(_normal_lp(v, ip[loc], s))
+        return v
+
+    gv = sp_normal("qw_global_scale_variance_loc", "qw_global_scale_variance_softplus_scale", ie["w_global_scale_variance"])
+    gn = sp_normal("qw_global_scale_noncentered_loc", "qw_global_scale_noncentered_softplus_scale",
+                   ie["w_global_scale_noncentered"])
+    l1v = sp_normal("qw_local1_scale_variance_loc", "qw_local1_scale_variance_softplus_scale", ie["w_local1_scale_variance"])
+    l1n = sp_normal("qw_local1_scale_noncentered_loc", "qw_local1_scale_noncentered_softplus_scale",
+                    ie["w_local1_scale_noncentered"])
+    l2v = sp_normal("qw_local2_scale_variance_loc", "qw_local2_scale_variance_softplus_scale", ie["w_local2_scale_variance"])
+    l2n = sp_normal("qw_local2_scale_noncentered_loc", "qw_local2_scale_noncentered_softplus_scale",
+                    ie["w_local2_scale_noncentered"])
+    w = normal("qw_loc", "qw_softplus_scale", ie["w"])
+    bias = normal("qx_bias_loc", "qx_bias_softplus_scale", ie["x_bias"])
+    xscale = sp_normal("qx_scale_loc", "qx_scale_softplus_scale", ie["x_scale"])
+    xi = normal("qx_loc", "qx_softplus_scale", ie["x"])
+    logp = np.sum(_invgamma_lp(gv, 0.5, 0.5)) + np.sum(_halfnormal_lp(gn))
+    logp += np.sum(_invgamma_lp(l1v, 0.5, 0.5)) + np.sum(_halfnormal_lp(l1n))
+    logp += np.sum(_invgamma_lp(l2v, 0.5, 0.5)) + np.sum(_halfnormal_lp(l2n))
+    w_scale = l1n * np.sqrt(l1v) * (l2n * np.sqrt(l2v)) * (gn * np.sqrt(gv))
+    logp += np.sum(_normal_lp(w, 0.0, w_scale))
+    logp += np.sum(_normal_lp(bias, 0.0, 2.0))
+    loc = bias[None, :] + np.asarray(design_isoform, np.float64) @ w
+    logp += np.sum(_invgamma_lp(xscale, 0.001, 0.001))
+    logp += np.sum(_normal_lp(xi, loc, xscale[None, :]))
+    if gene_lik is not None:
+        logp += float(np.sum(gene_lik(x_gene, xi)))
+    return float(logq - logp), xi
+
+
 def regression_loss(p, eps, design, W, sample_scales, x_bias_loc0, x_bias_scale0, use_distortion, scale_penalty,
                     use_point_estimates, lik=None):
     """loss = log q - log p at the draw defined by `eps`.  `lik(x) -> lp [S]` is the approximate likelihood

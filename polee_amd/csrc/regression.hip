@@ -40,6 +40,10 @@ struct RegView {
     int32_t S, F, n, deg;
     int32_t use_distortion, point;
     float bias_loc0, bias_scale0, penalty;
+    // > 0: x_scale ~ InverseGamma(fixed_ab, fixed_ab) instead of the kernel-regressed concentration / scale, and the
+    // observation model stands alone (no sample scales, no scale-drift penalty, no likelihood term of its own): the
+    // isoform block of the gene-isoform model (models/polee_regression.py:727-733), run with deg = 0
+    float fixed_ab = 0.0f;
     __host__ __device__ int64_t Fn() const { return (int64_t)F * n; }
     __host__ __device__ int64_t o_dist() const { return 4; }
     __host__ __device__ int64_t o_conc() const { return 4 + (int64_t)F * deg; }
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
     const float xsz = softplusf(p[v.o_xs_loc() + j] + softplusf(p[v.o_xs_s() + j]) * eps[v.e_xs() + j]);
     const float inv = frcp(xsz), inv2 = inv * inv, lxs = flog(xsz);
     const float ipen2 = 1.0f / (v.penalty * v.penalty);
+    const bool sub = v.fixed_ab > 0.0f;  // (then ss, x, lse are null: x is recomputed from its surrogate)
     float loss = 0.0f, sum_a = 0.0f, sum_xs = 0.0f;
 #pragma unroll 2  // (the samples' loads are independent: two in flight per lane)
     for (int s = 0; s < v.S; ++s) {
@@ -345,8 +350,9 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
 #pragma unroll UF
         for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
         const int64_t sj = (int64_t)s * n + j;
-        const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
-        const float d = xv - (xl - ss[s]);
+        const float xv = v.point ? p[v.o_qx_loc() + sj]
+                                 : (sub ? p[v.o_qx_loc() + sj] + softplusf(p[v.o_qx_s() + sj]) * eps[v.e_x() + sj] : x[sj]);
+        const float d = xv - (xl - (sub ? 0.0f : ss[s]));
         const float a = d * inv2;
         loss += 0.5f * d * a + lxs + HALF_LOG2PI;
         sum_xs += inv - d * a * inv;
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
         if (!v.point) {
             const float sraw = p[v.o_qx_s() + sj], sx = softplusf(sraw), e = eps[v.e_x() + sj];
             const float Gx = a - glik[sj];
-            gl = Gx + lse[s] * ipen2 * fexp(p[v.o_qx_loc() + sj] - lse[s]);
+            gl = sub ? Gx : Gx + lse[s] * ipen2 * fexp(p[v.o_qx_loc() + sj] - lse[s]);
             gs = (Gx * e - frcp(sx)) * sigmoidf(sraw);
             loss += -0.5f * e * e - flog(sx) - HALF_LOG2PI;
         }
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_data_kernel(RegView v, const fl
         stats[(int64_t)(F + 1) * n + j] = sum_xs;
     }
     loss = wave_sum(live ? loss : 0.0f);
-    if (blockIdx.x == 0 && tid == 0 && !v.point)
+    if (blockIdx.x == 0 && tid == 0 && !v.point && !sub)
         for (int s = 0; s < v.S; ++s) {  // per-sample terms: scale-drift penalty, approximate likelihood
             const float t = lse[s] / v.penalty;
             loss += 0.5f * t * t + logf(v.penalty) + HALF_LOG2PI - (lp ? lp[s] : 0.0f);
@@ -470,6 +476,7 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         alpha += s_cc[d] * wdj;
         beta += s_sc[d] * wdj;
     }
+    if (v.fixed_ab > 0.0f) alpha = beta = v.fixed_ab;
     const float inv = frcp(xs.z), inv2 = inv * inv, lxs = flog(xs.z);
     const float Gxs = (alpha + 1.0f) * inv - beta * inv2 + stats[(int64_t)(F + 1) * n + j];
     const float db = (b - v.bias_loc0) / v.bias_scale0;
@@ -513,7 +520,8 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
 // the global horseshoe scale and the distortion / mean-variance coefficients (one wave; lane i takes coefficient i)
 // (it leaves every accumulator it has read at zero for the next step: no memsets between steps)
 __global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *p, const float *eps, float *small,
-                                                        float *stats, double *loss_acc, float *g, float *loss_out)
+                                                        float *stats, double *loss_acc, float *g, float *loss_out,
+                                                        const float *extra_loss)
 {
     const int lane = threadIdx.x, nred = v.num_red();
     auto slots = [&](int i) {  // sum of accumulator i over its copies
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, 64);
-    if (lane == 0) loss_out[0] = (float)loss;
+    if (lane == 0) loss_out[0] = (float)(loss + (extra_loss ? (double)extra_loss[0] : 0.0));
 }
 
 // tf.optimizers.Adam: theta -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps)
@@ -599,8 +607,20 @@ struct polee_regression {
     polee_approx *gene_ap = nullptr;
     int32_t nt = 0;
     DevBuf<float> d_ip, d_ig, d_im, d_iv, d_ieps, d_xi;
-    int64_t num_iso_params() const { return gene_ap ? 2 * (int64_t)nt + 2 * (int64_t)v.S * nt : 0; }
-    int64_t num_iso_noise() const { return gene_ap ? (int64_t)nt + (int64_t)v.S * nt : 0; }
+    // gene-isoform model (RNASeqGeneIsoformLinearRegression, models/polee_regression.py:656-877): the isoform block
+    // is a regression of its own over the transcripts -- horseshoe+ coefficients over the isoform design, x_isoform_bias
+    // ~ Normal(0, 2), x_isoform_scale ~ InverseGamma(0.001, 0.001) -- laid out as a second RegView (vi, deg = 0) and
+    // run through the same data / column / finish kernels
+    bool iso_reg = false;
+    RegView vi{};
+    DevBuf<float> d_idesign, d_istats, d_ismall, d_iloss;
+    DevBuf<double> d_iacc;
+    int64_t num_iso_params() const
+    {
+        return !gene_ap ? 0 : (iso_reg ? vi.num_params() : 2 * (int64_t)nt + 2 * (int64_t)v.S * nt);
+    }
+    int64_t num_iso_noise() const { return !gene_ap ? 0 : (iso_reg ? vi.num_noise() : (int64_t)nt + (int64_t)v.S * nt); }
+    int64_t num_iso_stats() const { return (int64_t)(vi.F + 2) * vi.n + REG_SLOTS; }
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
     int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + REG_SLOTS; }
 };
@@ -627,8 +647,12 @@ polee_status reg_data_pass(polee_regression *r)
                            r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
         if (r->gene_ap) {
-            hipLaunchKernelGGL(reg_iso_sample_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256), 0,
-                               st, v.S, r->nt, r->d_ip.p, r->d_ieps.p, r->d_xi.p);
+            if (r->iso_reg)
+                hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256), 0,
+                                   st, r->vi, r->d_ip.p, r->d_ieps.p, r->d_xi.p);
+            else
+                hipLaunchKernelGGL(reg_iso_sample_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256),
+                                   0, st, v.S, r->nt, r->d_ip.p, r->d_ieps.p, r->d_xi.p);
             POLEE_KERNEL_CHECK(ctx);
             POLEE_TRY(approx_gene_logprob_device(r->gene_ap, r->d_x.p, r->d_xi.p, r->d_lp.p, r->d_glik.p));
         } else if (r->d_lik_loc.p) {
@@ -651,7 +675,12 @@ polee_status reg_data_pass(polee_regression *r)
     else if (v.deg == 15 && v.F == 4) POLEE_REG_DATA(4, 15);
     else POLEE_REG_DATA(0, 0);
 #undef POLEE_REG_DATA
-    if (r->gene_ap)  // (d_xi now holds d lp / d x_isoform)
+    if (r->gene_ap && r->iso_reg)  // (d_xi now holds d lp / d x_isoform): the isoform block's own data pass
+        hipLaunchKernelGGL((reg_data_kernel<0, 0>), dim3((unsigned)ceil_div(r->nt, REG_BLOCK)), dim3(REG_BLOCK), 0, st,
+                           r->vi, r->d_ip.p, r->d_ieps.p, r->d_idesign.p, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, r->d_xi.p, (const float *)nullptr, (const float *)nullptr, r->d_ig.p,
+                           r->d_istats.p);
+    else if (r->gene_ap)
         hipLaunchKernelGGL(reg_iso_grad_kernel, dim3((unsigned)ceil_div(r->nt, 256)), dim3(256), 0, st, v.S, r->nt,
                            r->d_ip.p, r->d_ieps.p, r->d_xi.p, r->d_ig.p, r->d_stats.p + r->num_stats() - REG_SLOTS);
     POLEE_KERNEL_CHECK(ctx);
@@ -674,8 +703,15 @@ polee_status reg_prior_pass(polee_regression *r)
     else if (v.deg == 15 && v.F == 4) POLEE_REG_COLS(4, 15);
     else POLEE_REG_COLS(0, 0);
 #undef POLEE_REG_COLS
+    if (r->iso_reg) {  // the isoform block's columns and its global scale; its loss joins the model's below
+        hipLaunchKernelGGL((reg_cols_kernel<0, 0>), dim3((unsigned)ceil_div(r->nt, REG_BLOCK)), dim3(REG_BLOCK), 0, st,
+                           r->vi, r->d_ip.p, r->d_ieps.p, (const float *)nullptr, r->d_istats.p, r->d_ig.p, r->d_iacc.p,
+                           r->d_ismall.p);
+        hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, r->vi, r->d_ip.p, r->d_ieps.p, r->d_ismall.p,
+                           r->d_istats.p, r->d_iacc.p, r->d_ig.p, r->d_iloss.p, (const float *)nullptr);
+    }
     hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p,
-                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p);
+                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p, r->iso_reg ? r->d_iloss.p : (const float *)nullptr);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -923,6 +959,54 @@ polee_status polee_regression_set_gene_likelihood(polee_regression *r, polee_app
     POLEE_TRY(r->d_xi.alloc(ctx, snt));
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_im.p, 0, sizeof(float) * np, ctx->stream));
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iv.p, 0, sizeof(float) * np, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return POLEE_OK;
+}
+
+polee_status polee_regression_set_gene_isoform_likelihood(polee_regression *r, polee_approx *ap, const int32_t *gene_of,
+                                                          const float *x_isoform_init, const float *design_isoform,
+                                                          int32_t num_isoform_factors)
+{
+    if (!r || !design_isoform) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    if (num_isoform_factors < 1 || num_isoform_factors > REG_MAXF)
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "1..%d isoform factors (got %d)", REG_MAXF, num_isoform_factors);
+    POLEE_TRY(polee_regression_set_gene_likelihood(r, ap, gene_of, x_isoform_init));
+    const int S = r->v.S, nt = r->nt, Fi = num_isoform_factors;
+    RegView &vi = r->vi;
+    vi = RegView{S, Fi, nt, 0, 0, 0, 0.0f, 2.0f, 1.0f};
+    vi.fixed_ab = 0.001f;
+    const int64_t P = vi.num_params(), Fn = vi.Fn(), snt = (int64_t)S * nt;
+    // initial values (models/polee_regression.py:740-775)
+    std::vector<float> p((size_t)P, 0.0f);
+    p[1] = p[3] = -1.0f;
+    for (int a = 1; a < 10; a += 2) std::fill_n(p.begin() + vi.o_cols() + a * Fn, Fn, -1.0f);
+    for (int i = 0; i < nt; ++i) {
+        double m = 0.0;
+        for (int s = 0; s < S; ++s) m += x_isoform_init[(size_t)s * nt + i];
+        p[(size_t)(vi.o_bias_loc() + i)] = (float)(m / S);
+        p[(size_t)(vi.o_bias_s() + i)] = -1.0f;
+        p[(size_t)(vi.o_xs_loc() + i)] = 1.0f;
+        p[(size_t)(vi.o_xs_s() + i)] = -1.0f;
+    }
+    std::copy_n(x_isoform_init, snt, p.begin() + vi.o_qx_loc());
+    std::fill_n(p.begin() + vi.o_qx_s(), snt, -2.0f);
+    r->iso_reg = true;
+    POLEE_TRY(r->d_ip.upload(ctx, p));
+    POLEE_TRY(r->d_idesign.upload(ctx, design_isoform, (size_t)S * Fi));
+    POLEE_TRY(r->d_ig.alloc(ctx, (size_t)P));
+    POLEE_TRY(r->d_im.alloc(ctx, (size_t)P));
+    POLEE_TRY(r->d_iv.alloc(ctx, (size_t)P));
+    POLEE_TRY(r->d_ieps.alloc(ctx, (size_t)vi.num_noise()));
+    POLEE_TRY(r->d_istats.alloc(ctx, (size_t)r->num_iso_stats()));
+    POLEE_TRY(r->d_ismall.alloc(ctx, (size_t)REG_SLOTS * vi.num_red()));
+    POLEE_TRY(r->d_iacc.alloc(ctx, REG_SLOTS));
+    POLEE_TRY(r->d_iloss.alloc(ctx, 1));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_im.p, 0, sizeof(float) * P, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iv.p, 0, sizeof(float) * P, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_istats.p, 0, sizeof(float) * r->num_iso_stats(), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_ismall.p, 0, sizeof(float) * REG_SLOTS * vi.num_red(), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iacc.p, 0, sizeof(double) * REG_SLOTS, ctx->stream));
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return POLEE_OK;
 }

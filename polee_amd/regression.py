@@ -57,6 +57,7 @@ class RNASeqLinearRegression:
         x0 = arr(np.atleast_2d(x_init), np.float32)
         ss = arr(np.asarray(sample_scales).reshape(-1), np.float32)
         self.num_samples, self.num_factors = Fm.shape
+        self.design = Fm
         self.num_features = x0.shape[1]
         if x0.shape[0] != self.num_samples or ss.size != self.num_samples:
             raise ValueError("F [S,F], x_init [S,n] and sample_scales [S] disagree on S")
@@ -95,14 +96,23 @@ class RNASeqLinearRegression:
                 raise ValueError("the Normal likelihood's loc and scale must be [S, n]")
             check(lib.polee_regression_set_normal_likelihood(self._h, ptr(loc, f32p), ptr(scale, f32p)), self.ctx._h)
         self.num_isoform_params = 0
-        if gene_likelihood is not None:  # (RNASeqApproxLikelihood over the transcripts, 0-based gene of each, init)
-            lik, gene_of, xi0 = gene_likelihood
+        if gene_likelihood is not None:  # (RNASeqApproxLikelihood over the transcripts, 0-based gene of each, init
+            # [, isoform design: the gene-isoform model])
+            lik, gene_of, xi0 = gene_likelihood[:3]
+            Fi = arr(np.atleast_2d(gene_likelihood[3]), np.float32) if len(gene_likelihood) > 3 else None
             gene_of, xi0 = arr(gene_of, np.int32).reshape(-1), arr(np.atleast_2d(xi0), np.float32)
             if gene_of.size != lik.n or xi0.shape != (self.num_samples, lik.n):
                 raise ValueError("gene_of must be [nt] and x_isoform_init [S, nt]")
             self.likelihood_model = lik
-            check(lib.polee_regression_set_gene_likelihood(self._h, lik._h, ptr(gene_of, L.i32p), ptr(xi0, f32p)),
-                  self.ctx._h)
+            if Fi is not None:
+                if Fi.shape[0] != self.num_samples:
+                    raise ValueError("F_isoform must be [S, Fi]")
+                self.num_isoform_factors = Fi.shape[1]
+                check(lib.polee_regression_set_gene_isoform_likelihood(
+                    self._h, lik._h, ptr(gene_of, L.i32p), ptr(xi0, f32p), ptr(Fi, f32p), Fi.shape[1]), self.ctx._h)
+            else:
+                check(lib.polee_regression_set_gene_likelihood(self._h, lik._h, ptr(gene_of, L.i32p), ptr(xi0, f32p)),
+                      self.ctx._h)
             lib.polee_regression_num_isoform_params.restype = C.c_int64
             lib.polee_regression_num_isoform_params.argtypes = [C.c_void_p]
             self.num_isoform_params = int(lib.polee_regression_num_isoform_params(self._h))
@@ -265,6 +275,75 @@ class RNASeqGeneLinearRegression(RNASeqLinearRegression):
         return dict(qx_isoform_mean_loc=v[:nt], qx_isoform_mean_softplus_scale=v[nt:2 * nt],
                     qx_isoform_loc=v[2 * nt:2 * nt + S * nt].reshape(S, nt),
                     qx_isoform_softplus_scale=v[2 * nt + S * nt:].reshape(S, nt))
+
+
+class RNASeqGeneIsoformLinearRegression(RNASeqLinearRegression):
+    """RNASeqGeneIsoformLinearRegression (models/polee_regression.py:656-877): regression over gene expression AND over
+    the within-gene isoform mixtures (own design matrix F_isoform_arr, horseshoe+ coefficients).  Argument order and
+    fit()'s return follow the reference.  Built without point estimates only."""
+
+    # the isoform block in the order of the flat vector (include/polee_hip.h); shapes: 1, [Fi, nt], [nt], [S, nt]
+    ISOFORM_PARAMS = [
+        ("qw_isoform_global_scale_variance_loc", "1"), ("qw_isoform_global_scale_variance_softplus_scale", "1"),
+        ("qw_isoform_global_scale_noncentered_loc", "1"), ("qw_isoform_global_scale_noncentered_softplus_scale", "1"),
+        ("qw_isoform_local1_scale_variance_loc", "Ft"), ("qw_isoform_local1_scale_variance_softplus_scale", "Ft"),
+        ("qw_isoform_local1_scale_noncentered_loc", "Ft"), ("qw_isoform_local1_scale_noncentered_softplus_scale", "Ft"),
+        ("qw_isoform_local2_scale_variance_loc", "Ft"), ("qw_isoform_local2_scale_variance_softplus_scale", "Ft"),
+        ("qw_isoform_local2_scale_noncentered_loc", "Ft"), ("qw_isoform_local2_scale_noncentered_softplus_scale", "Ft"),
+        ("qw_isoform_loc", "Ft"), ("qw_isoform_softplus_scale", "Ft"),
+        ("qx_isoform_bias_loc", "t"), ("qx_isoform_bias_softplus_scale", "t"),
+        ("qx_isoform_scale_loc", "t"), ("qx_isoform_scale_softplus_scale", "t"),
+        ("qx_isoform_loc", "St"), ("qx_isoform_softplus_scale", "St"),
+    ]
+
+    def __init__(self, vars, feature_idxs, transcript_idxs, x_gene_init, x_isoform_init, feature_sizes, F_gene_arr,
+                 F_isoform_arr, sample_scales, use_distortion, scale_penalty, use_point_estimates,
+                 kernel_regression_degree=15, kernel_regression_bandwidth=1.0, ctx=None):
+        if use_point_estimates:
+            raise NotImplementedError("the gene-isoform model is built without point estimates only")
+        x_gene_init = np.asarray(x_gene_init, np.float32)
+        lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=ctx)
+        fi = np.asarray(feature_idxs, np.int64).reshape(-1) - 1
+        ti = np.asarray(transcript_idxs, np.int64).reshape(-1) - 1
+        gene_of = np.full(lik.n, -1, np.int64)
+        gene_of[ti] = fi
+        if (gene_of < 0).any():
+            raise ValueError("every transcript must belong to a gene")
+        super().__init__(F_gene_arr, x_gene_init, None, math.log(1.0 / x_gene_init.shape[1]), 12.0, None, sample_scales,
+                         use_distortion, scale_penalty, False, kernel_regression_degree, kernel_regression_bandwidth,
+                         ctx=ctx or lik.ctx, gene_likelihood=(lik, gene_of, x_isoform_init, F_isoform_arr))
+
+    def isoform_variables(self):
+        v, S, nt, Fi = self.get_isoform_params(), self.num_samples, self.likelihood_model.n, self.num_isoform_factors
+        shapes = {"1": (), "Ft": (Fi, nt), "t": (nt,), "St": (S, nt)}
+        out, o = {}, 0
+        for name, code in self.ISOFORM_PARAMS:
+            k = int(np.prod(shapes[code], dtype=np.int64))
+            out[name] = v[o:o + k].reshape(shapes[code])
+            o += k
+        assert o == v.size
+        return out
+
+    def fit(self, niter, seed=123456789, noise=None, return_trace=False):
+        """fit (models/polee_regression.py:833-857): (qw_gene_loc, qw_gene_scale, qw_isoform_loc, qw_isoform_scale,
+        qx_isoform_bias_loc, qx_isoform_bias_scale, qx_isoform_scale, qx_gene_bias_loc, qx_gene_scale,
+        qx_gene_loc_factor_est)."""
+        base = super().fit(niter, seed=seed, noise=noise, return_trace=True)
+        _, qw_gene_loc, qw_gene_scale, qx_gene_bias_loc, qx_gene_scale, trace = base
+        iv = self.isoform_variables()
+        out = (qw_gene_loc, qw_gene_scale, iv["qw_isoform_loc"], _softplus(iv["qw_isoform_softplus_scale"]),
+               iv["qx_isoform_bias_loc"], _softplus(iv["qx_isoform_bias_softplus_scale"]),
+               _softplus(iv["qx_isoform_scale_loc"]), qx_gene_bias_loc, qx_gene_scale,
+               self.design @ qw_gene_loc)
+        return out + (trace,) if return_trace else out
+
+    def write_other_params(self, output_filename):
+        """write_other_params (models/polee_regression.py:859-875)"""
+        iv = self.isoform_variables()
+        with open(output_filename, "w") as output:
+            for name in ("global_scale_variance_loc", "global_scale_variance_softplus_scale",
+                         "global_scale_noncentered_loc", "global_scale_noncentered_softplus_scale"):
+                output.write("qw_isoform_{}_var: {}\n".format(name, iv["qw_isoform_" + name]))
 
 
 class RNASeqNormalTranscriptLinearRegression(RNASeqLinearRegression):

@@ -401,3 +401,99 @@ def test_gene_level_model_matches_restatement(P, ctx):
     out = reg.fit(60, seed=4, return_trace=True)
     assert np.all(np.isfinite(out[-1])) and out[-1][-10:].mean() < out[-1][:10].mean()
     assert not np.allclose(reg.get_isoform_params(), itheta)
+
+
+def test_gene_isoform_model_matches_restatement(P, ctx):
+    """RNASeqGeneIsoformLinearRegression (models/polee_regression.py:656-877): loss against the float64 restatement
+    (gene block + isoform regression block) with the C oracle's gene-level likelihood; EVERY gradient of the isoform
+    block's shared parameters and samples of its per-sample ones against central differences of the restatement + the
+    oracle's analytic likelihood gradients; initial values and fit()'s outputs as the reference's."""
+    rng = np.random.default_rng(41)
+    S, F, Fi, nt, G, deg, pen = 4, 2, 3, 120, 30, 5, 0.8
+    vars_, design, _ = _problem(rng, S, F, nt)
+    design_iso = np.concatenate([np.ones((S, 1)), rng.normal(0, 1, size=(S, Fi - 1))], axis=1).astype(np.float32)
+    gene_of = np.concatenate([np.arange(G), rng.integers(0, G, nt - G)])
+    rng.shuffle(gene_of)
+    x_gene_init = (rng.normal(-np.log(G), 1.2, size=(1, G)) + rng.normal(0, 0.3, size=(S, G))).astype(np.float32)
+    x_iso_init = rng.normal(0, 1.0, size=(S, nt)).astype(np.float32)
+    ss = P.estimate_sample_scales(x_gene_init, upper_quantile=0.7)
+    reg = P.RNASeqGeneIsoformLinearRegression(vars_, gene_of + 1, np.arange(1, nt + 1), x_gene_init, x_iso_init, None,
+                                              design, design_iso, ss, True, pen, False, kernel_regression_degree=deg,
+                                              ctx=ctx)
+    n_ip = 4 + 10 * Fi * nt + 4 * nt + 2 * S * nt
+    n_ie = 2 + 5 * Fi * nt + 2 * nt + S * nt
+    assert reg.num_isoform_params == n_ip and reg.num_noise == 2 + 5 * F * G + 2 * G + S * G + n_ie
+    iv = reg.isoform_variables()
+    # initial values (models/polee_regression.py:736-775)
+    np.testing.assert_allclose(iv["qx_isoform_bias_loc"], x_iso_init.mean(axis=0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(iv["qx_isoform_loc"], x_iso_init)
+    assert np.all(iv["qx_isoform_softplus_scale"] == -2.0) and np.all(iv["qx_isoform_scale_loc"] == 1.0)
+    assert np.all(iv["qw_isoform_loc"] == 0.0) and np.all(iv["qw_isoform_softplus_scale"] == -1.0)
+    for k, val in iv.items():
+        if k.endswith("softplus_scale") and k != "qx_isoform_softplus_scale":
+            assert np.all(val == -1.0), k
+        elif "scale_variance_loc" in k or "scale_noncentered_loc" in k:
+            assert np.all(val == 0.0), k
+    theta = (reg.get_flat_params() + rng.normal(0, 0.2, size=reg.num_params)).astype(np.float32)
+    itheta = (reg.get_isoform_params() + rng.normal(0, 0.2, size=n_ip)).astype(np.float32)
+    reg.set_flat_params(theta)
+    reg.set_isoform_params(itheta)
+    eps = rng.normal(size=reg.num_noise).astype(np.float32)
+    loss, g = reg.loss_and_gradients(noise=eps)
+    gi = reg.isoform_gradients()
+    assert np.all(np.isfinite(gi)) and np.all(np.isfinite(g))
+    W = _oracle_setup(reg, design, x_gene_init, ss, deg, 1.0)
+    e = RR.unflatten(eps[:-n_ie].astype(np.float64), RR.NOISE, S, F, G, deg)
+    ie = RR.unflatten(eps[-n_ie:].astype(np.float64), RR.NOISE, S, Fi, nt, 0)
+    a = (vars_["efflen"], vars_["la_mu"], vars_["la_sigma"], vars_["la_alpha"], vars_["left_index"],
+         vars_["right_index"], vars_["leaf_index"])
+    common = dict(design=design.astype(np.float64), W=W, sample_scales=ss, x_bias_loc0=np.log(1.0 / G),
+                  x_bias_scale0=12.0, use_distortion=True, scale_penalty=pen, use_point_estimates=False)
+
+    def base(vec):
+        return RR.regression_loss(RR.unflatten(vec, RR.PARAMS, S, F, G, deg), e, lik=None, **common)
+
+    def iso(ivec, x_gene, with_lik):
+        lik = (lambda xg, xi: O.approx_gene_log_prob(xg.astype(np.float32), xi.astype(np.float32), gene_of, *a)) \
+            if with_lik else None
+        return RR.isoform_regression_terms(RR.unflatten(ivec, RR.PARAMS, S, Fi, nt, 0), ie, design_iso, x_gene, lik)
+
+    t64, i64 = theta.astype(np.float64), itheta.astype(np.float64)
+    lb, z = base(t64)
+    li, xi = iso(i64, z["x"], True)
+    assert abs(loss - (lb + li)) <= 1e-4 * abs(lb + li) + 1e-2, (loss, lb + li)
+    _, gg, gxi = O.approx_gene_log_prob(z["x"].astype(np.float32), xi.astype(np.float32), gene_of, *a, want_grad=True)
+    # The likelihood reaches the isoform block through x_isoform alone: d loss / d theta = d(restatement without the
+    # likelihood) / d theta - <d lp / d x_isoform, d x_isoform / d theta>, the second factor by differences too.
+    o_loc, o_s = n_ip - 2 * S * nt, n_ip - S * nt
+    scale = np.abs(gi[:o_loc]).max()
+    shared = np.concatenate([np.arange(4), 4 + rng.choice(10 * Fi * nt + 4 * nt, 60, replace=False)])
+    own = np.concatenate([o_loc + rng.choice(S * nt, 15, replace=False), o_s + rng.choice(S * nt, 15, replace=False)])
+    worst = 0.0
+    for i in np.concatenate([shared, own]):
+        h = 1e-4 * max(1.0, abs(i64[i]))
+        tp, tm = i64.copy(), i64.copy()
+        tp[i] += h
+        tm[i] -= h
+        (lp_, xp), (lm_, xm) = iso(tp, z["x"], False), iso(tm, z["x"], False)
+        fd = (lp_ - lm_) / (2 * h) - float(np.sum(gxi * (xp - xm))) / (2 * h)
+        err = abs(gi[i] - fd) / (abs(fd) + 2e-3 * (scale if i < o_loc else np.abs(gi[o_loc:]).max()))
+        worst = max(worst, err)
+        assert err < 1e-2, (i, gi[i], fd)
+    # gene-level qx_loc sees the likelihood through d lp / d x_gene
+    table = RR.unflatten(np.arange(t64.size), RR.PARAMS, S, F, G, deg)
+    o_qx = int(table["qx_loc"].reshape(-1)[0])
+    gs = np.abs(g).max()
+    for k in rng.choice(S * G, 12, replace=False):
+        i = o_qx + k
+        h = 1e-4 * max(1.0, abs(t64[i]))
+        tp, tm = t64.copy(), t64.copy()
+        tp[i] += h
+        tm[i] -= h
+        fd = (base(tp)[0] - base(tm)[0]) / (2 * h) - gg.reshape(-1)[k]
+        assert abs(g[i] - fd) / (abs(fd) + 2e-3 * gs) < 1e-2, (i, g[i], fd)
+    out = reg.fit(60, seed=4, return_trace=True)
+    assert len(out) == 11 and np.all(np.isfinite(out[-1])) and out[-1][-10:].mean() < out[-1][:10].mean()
+    assert out[2].shape == (Fi, nt) and out[3].shape == (Fi, nt) and out[4].shape == (nt,) and out[6].shape == (nt,)
+    assert out[9].shape == (S, G)
+    assert not np.allclose(reg.get_isoform_params(), itheta)
