@@ -294,6 +294,15 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
  * HDF5 stores.  Runs on the CPU (as the reference's does); no context needed. */
 polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
                           int32_t *node_parent_idxs, int32_t *node_js);
+/* The same rule -- join the subtrees that share the most reads first -- in parallel rounds: every round merges each edge
+ * that is the best edge (similarity, then a hash of the endpoints: a total order) of both its endpoints, on all host
+ * threads; new nodes are numbered by their edges' priorities, so the tree does not depend on the thread count.  Not the
+ * reference's tree node for node (its order depends on heap positions among equal similarities, which no parallel
+ * schedule reproduces, and a locally best edge is merged before a better one can appear at an endpoint): a documented
+ * variant for sample preparation at scale (polee_amd/csrc/hclust.cpp; the exact mode above stays the default).  Same
+ * arguments, same output arrays. */
+polee_status polee_hclust_parallel(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                   int32_t *node_parent_idxs, int32_t *node_js);
 
 /* ---- one sample over several GPUs -----------------------------------
  * X's rows (fragments) are sharded over the ranks in contiguous blocks; every rank creates its

@@ -385,17 +385,20 @@ def kumaraswamy_transform_gradients(zs, as_, bs, y_grad, a_grad=None, b_grad=Non
     return ag, bg
 
 
-def hclust(m, n, colptr, rowval):
+def hclust(m, n, colptr, rowval, parallel=False):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],
-    i.e. what the prep HDF5 stores and PolyaTreeTransform(...) takes.  Runs on the host, as in the reference."""
+    i.e. what the prep HDF5 stores and PolyaTreeTransform(...) takes.  Runs on the host, as in the reference.
+    parallel=True: the same joining rule in rounds of mutually-best merges on all host threads (polee_hclust_parallel;
+    a documented variant, not the reference's tree node for node)."""
     colptr = np.ascontiguousarray(colptr)
     if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
         colptr = colptr.astype(np.uint64)
     rowval = arr(rowval, np.uint32)
     parents, js = np.empty(2 * int(n) - 1, np.int32), np.empty(2 * int(n) - 1, np.int32)
-    check(L.lib().polee_hclust(C.c_int64(int(m)), C.c_int64(int(n)), colptr.ctypes.data_as(C.c_void_p),
-                               int(colptr.dtype.itemsize), ptr(rowval, u32p), ptr(parents, L.i32p), ptr(js, L.i32p)))
+    f = L.lib().polee_hclust_parallel if parallel else L.lib().polee_hclust
+    check(f(C.c_int64(int(m)), C.c_int64(int(n)), colptr.ctypes.data_as(C.c_void_p), int(colptr.dtype.itemsize),
+            ptr(rowval, u32p), ptr(parents, L.i32p), ptr(js, L.i32p)))
     return parents, js
 
 
@@ -584,6 +587,10 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
                 raise ValueError("tree construction needs the sample's CSC arrays (create it from colptr/rowval/nzval) "
                                  "or pass a PolyaTreeTransform")
             parents, js = hclust(sample.m, sample.n, *sample._csc)
+        elif approx.treemethod == "cluster_parallel":  # (the rounds variant of the same rule, polee_hclust_parallel)
+            if getattr(sample, "_csc", None) is None:
+                raise ValueError("tree construction needs the sample's CSC arrays")
+            parents, js = hclust(sample.m, sample.n, *sample._csc, parallel=True)
         elif approx.treemethod == "sequential":
             parents, js = list_nodes(sample.n)
         else:

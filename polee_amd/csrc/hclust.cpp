@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <string>
 #include <unordered_set>
@@ -125,6 +126,14 @@ double relative_intersection(const ReadSet &a, const ReadSet &b)
     const size_t is = intersection_size(a, b);
     return (double)is / (double)(a.size() + b.size() - is);
 }
+// the same quotient with the reads of the other set (ks_size of them) marked in `bits`
+inline double bitmap_similarity(const ReadSet &a, size_t ks_size, const std::vector<uint64_t> &bits)
+{
+    if (a.empty()) return 0.0;
+    size_t is = 0;
+    for (uint32_t v : a) is += (size_t)((bits[v >> 6] >> (v & 63u)) & 1ull);
+    return (double)is / (double)(a.size() + ks_size - is);
+}
 // hclust.jl:150-190
 ReadSet merge_sets(const ReadSet &a, const ReadSet &b)
 {
@@ -133,10 +142,188 @@ ReadSet merge_sets(const ReadSet &a, const ReadSet &b)
     return out;
 }
 
+// Large sets (the top of the tree: millions of reads per node, one or two merges per round) are cut into disjoint value
+// ranges at evenly spaced elements of the larger set; the ranges are independent for counting and for merging.
+struct RangeCut {
+    std::vector<size_t> pa, pb;  // part p covers a[pa[p] .. pa[p+1]) and b[pb[p] .. pb[p+1])
+    size_t parts() const { return pa.size() - 1; }
+};
+RangeCut cut_ranges(const ReadSet &a, const ReadSet &b, size_t parts)
+{
+    RangeCut c;
+    const ReadSet &big = a.size() >= b.size() ? a : b;
+    c.pa.push_back(0);
+    c.pb.push_back(0);
+    for (size_t p = 1; p < parts; ++p) {
+        const uint32_t v = big[big.size() * p / parts];
+        c.pa.push_back((size_t)(std::lower_bound(a.begin(), a.end(), v) - a.begin()));
+        c.pb.push_back((size_t)(std::lower_bound(b.begin(), b.end(), v) - b.begin()));
+    }
+    c.pa.push_back(a.size());
+    c.pb.push_back(b.size());
+    return c;
+}
+inline size_t intersection_size_range(const uint32_t *a, const uint32_t *ae, const uint32_t *b, const uint32_t *be)
+{
+    size_t c = 0;
+    while (a < ae && b < be) {
+        const uint32_t x = *a, y = *b;
+        c += x == y;
+        a += x <= y;
+        b += y <= x;
+    }
+    return c;
+}
+// |a n b| on all host threads (the counts are integers: the same number whatever the cut)
+size_t intersection_size_parallel(const ReadSet &a, const ReadSet &b, size_t grain = (size_t)1 << 20)
+{
+    if (a.empty() || b.empty() || a.front() > b.back() || a.back() < b.front()) return 0;
+    const size_t parts = std::min<size_t>(4 * host_threads(), (a.size() + b.size()) / grain + 1);
+    if (parts <= 1) return intersection_size(a, b);
+    const RangeCut c = cut_ranges(a, b, parts);
+    std::vector<size_t> cnt(parts, 0);
+    parallel_chunks(parts, 1, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t p = lo; p < hi; ++p)
+            cnt[p] = intersection_size_range(a.data() + c.pa[p], a.data() + c.pa[p + 1], b.data() + c.pb[p], b.data() + c.pb[p + 1]);
+    });
+    size_t t = 0;
+    for (size_t v : cnt) t += v;
+    return t;
+}
+// a u b on all host threads: count per range, then every range merges into its place
+ReadSet merge_sets_parallel(const ReadSet &a, const ReadSet &b, size_t grain = (size_t)1 << 20)
+{
+    const size_t parts = std::min<size_t>(4 * host_threads(), (a.size() + b.size()) / grain + 1);
+    if (parts <= 1 || a.empty() || b.empty()) return merge_sets(a, b);
+    const RangeCut c = cut_ranges(a, b, parts);
+    std::vector<size_t> off(parts + 1, 0);
+    parallel_chunks(parts, 1, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t p = lo; p < hi; ++p)
+            off[p + 1] = (c.pa[p + 1] - c.pa[p]) + (c.pb[p + 1] - c.pb[p]) -
+                         intersection_size_range(a.data() + c.pa[p], a.data() + c.pa[p + 1], b.data() + c.pb[p], b.data() + c.pb[p + 1]);
+    });
+    for (size_t p = 0; p < parts; ++p) off[p + 1] += off[p];
+    ReadSet out(off[parts]);
+    parallel_chunks(parts, 1, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t p = lo; p < hi; ++p)
+            std::set_union(a.begin() + c.pa[p], a.begin() + c.pa[p + 1], b.begin() + c.pb[p], b.begin() + c.pb[p + 1],
+                           out.begin() + off[p]);
+    });
+    return out;
+}
+
 struct TreeNode {
     uint32_t j = 0;           // transcript (1-based), 0 = internal
     int32_t left = -1, right = -1;
 };
+
+// What both variants start from: the leaves in the order of their median compatible read (:204-222) as nodes 1..n with
+// their read sets, and the similarities of every leaf to its K successors (:225-236), sims[(j1 - 1) K + (j2 - j1 - 1)].
+template <class ColPtr>
+std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, int K, std::vector<TreeNode> &nodes,
+                       std::vector<ReadSet> &read_sets, std::vector<float> &sims)
+{
+    // order transcripts by the median compatible read (:204-212); sortperm is stable
+    std::vector<uint32_t> med((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        if (cp(j + 1) < cp(j)) return "colptr is not monotone";
+        if (cp(j) == cp(j + 1))
+            med[(size_t)j] = 0;
+        else
+            med[(size_t)j] = rowval[(cp(j) + cp(j + 1)) / 2 - 1];  // 1-based position div(a + b, 2)
+    }
+    std::vector<uint32_t> idxs((size_t)n);
+    for (int64_t j = 0; j < n; ++j) idxs[(size_t)j] = (uint32_t)j;
+    std::stable_sort(idxs.begin(), idxs.end(), [&](uint32_t a, uint32_t b) { return med[a] < med[b]; });
+
+    // nodes 1..n are the leaves in that order; internal nodes are appended (:215-222)
+    nodes.assign((size_t)n + 1, TreeNode());  // [0] unused: ids are 1-based like the reference's keys
+    read_sets.assign((size_t)n + 1, ReadSet());
+    nodes.reserve(2 * (size_t)n);
+    read_sets.reserve(2 * (size_t)n);
+    {
+        std::atomic<int> bad{0};
+        parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t q = lo; q < hi; ++q) {
+                const size_t j = q + 1;
+                const uint32_t t = idxs[q];
+                nodes[j].j = t + 1;
+                read_sets[j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
+                for (size_t e = 1; e < read_sets[j].size(); ++e)
+                    if (read_sets[j][e] <= read_sets[j][e - 1]) bad = 1;
+                if (!read_sets[j].empty() && (read_sets[j].front() < 1 || (int64_t)read_sets[j].back() > m)) bad = 2;
+            }
+        });
+        if (bad == 1) return "row indexes of a column are not ascending";
+        if (bad == 2) return "row index out of range";
+    }
+    // (the n x K similarities are independent: computed by a few threads; a leaf's reads are marked in the thread's bitmap
+    // once, each of its K successors is then |successor| look-ups instead of a branchy walk over both sets -- the counts,
+    // hence the similarities, are the same)
+    sims.assign((size_t)n * K, 0.0f);
+    std::vector<std::vector<uint64_t>> bitmaps(host_threads());
+    parallel_chunks((size_t)n, 256, [&](size_t lo, size_t hi, unsigned th) {
+        std::vector<uint64_t> &bits = bitmaps[th];
+        if (bits.empty()) bits.assign(((size_t)m >> 6) + 2, 0);
+        for (int64_t j1 = (int64_t)lo + 1; j1 <= (int64_t)hi; ++j1) {
+            const ReadSet &a = read_sets[(size_t)j1];
+            if (a.empty()) continue;
+            bool marked = false;
+            for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
+                const ReadSet &b = read_sets[(size_t)j2];
+                if (b.empty() || a.front() > b.back() || a.back() < b.front()) continue;
+                if (!marked) {
+                    for (uint32_t v : a) bits[v >> 6] |= 1ull << (v & 63u);
+                    marked = true;
+                }
+                sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)] = (float)bitmap_similarity(b, a.size(), bits);
+            }
+            if (marked)
+                for (uint32_t v : a) bits[v >> 6] = 0;
+        }
+    });
+    return "";
+}
+
+// The stages both variants share: the components left without a common read are joined smallest first (:244-258), then
+// order_nodes (:361-389).  set_size(j) = number of reads of live node j.
+template <class SetSize>
+std::string finish_tree(int64_t n, std::vector<TreeNode> &nodes, const std::vector<char> &alive, SetSize set_size,
+                        int32_t *node_parent_idxs, int32_t *node_js)
+{
+    BinHeap<NodeWithSize, SizeBefore> rest;
+    for (uint32_t j = 1; j < nodes.size(); ++j)
+        if (alive[j]) rest.push(NodeWithSize{j, (uint32_t)(1 + set_size(j))});
+    while (rest.size() > 1) {
+        const NodeWithSize a = rest.pop(), b = rest.pop();
+        const uint32_t k = (uint32_t)nodes.size();
+        nodes.push_back(TreeNode{0, (int32_t)a.j, (int32_t)b.j});
+        rest.push(NodeWithSize{k, a.size + b.size});
+    }
+    if (rest.size() != 1) return "internal error: no root";
+    const uint32_t root = rest.pop().j;
+    if (nodes.size() != 2 * (size_t)n) return "internal error: node count";
+
+    // order_nodes (:361-389): DFS, left pushed first so that the right child is visited first
+    std::vector<uint32_t> stack{root};
+    std::vector<int32_t> parent_of(nodes.size(), 0);
+    int64_t pos = 0;
+    while (!stack.empty()) {
+        const uint32_t v = stack.back();
+        stack.pop_back();
+        node_parent_idxs[pos] = parent_of[v];
+        node_js[pos] = (int32_t)nodes[v].j;
+        ++pos;
+        if (nodes[v].j == 0) {
+            parent_of[(size_t)nodes[v].left] = (int32_t)pos;
+            parent_of[(size_t)nodes[v].right] = (int32_t)pos;
+            stack.push_back((uint32_t)nodes[v].left);
+            stack.push_back((uint32_t)nodes[v].right);
+        }
+    }
+    if (pos != 2 * n - 1) return "internal error: tree size";
+    return "";
+}
 
 }  // namespace
 
@@ -172,62 +359,20 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         t_prev = now();
     };
 
-    // order transcripts by the median compatible read (:204-212); sortperm is stable
-    std::vector<uint32_t> med((size_t)n);
-    for (int64_t j = 0; j < n; ++j) {
-        if (cp(j + 1) < cp(j)) return "colptr is not monotone";
-        if (cp(j) == cp(j + 1))
-            med[(size_t)j] = 0;
-        else
-            med[(size_t)j] = rowval[(cp(j) + cp(j + 1)) / 2 - 1];  // 1-based position div(a + b, 2)
-    }
-    std::vector<uint32_t> idxs((size_t)n);
-    for (int64_t j = 0; j < n; ++j) idxs[(size_t)j] = (uint32_t)j;
-    std::stable_sort(idxs.begin(), idxs.end(), [&](uint32_t a, uint32_t b) { return med[a] < med[b]; });
-
-    // nodes 1..n are the leaves in that order; internal nodes are appended (:215-222)
-    std::vector<TreeNode> nodes((size_t)n + 1);  // [0] unused: ids are 1-based like the reference's keys
-    std::vector<ReadSet> read_sets((size_t)n + 1);
-    std::vector<char> alive((size_t)n + 1, 1), deleted((size_t)n + 1, 0);
-    nodes.reserve(2 * (size_t)n);
-    read_sets.reserve(2 * (size_t)n);
+    std::vector<TreeNode> nodes;
+    std::vector<ReadSet> read_sets;
+    std::vector<float> sims;
     {
-        std::atomic<int> bad{0};
-        parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
-            for (size_t q = lo; q < hi; ++q) {
-                const size_t j = q + 1;
-                const uint32_t t = idxs[q];
-                nodes[j].j = t + 1;
-                read_sets[j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
-                for (size_t e = 1; e < read_sets[j].size(); ++e)
-                    if (read_sets[j][e] <= read_sets[j][e - 1]) bad = 1;
-                if (!read_sets[j].empty() && (read_sets[j].front() < 1 || (int64_t)read_sets[j].back() > m)) bad = 2;
-            }
-        });
-        if (bad == 1) return "row indexes of a column are not ascending";
-        if (bad == 2) return "row index out of range";
+        const std::string err = leaf_setup(m, n, cp, rowval, K, nodes, read_sets, sims);
+        if (!err.empty()) return err;
     }
+    std::vector<char> alive((size_t)n + 1, 1), deleted((size_t)n + 1, 0);
+    lap("read sets + similarities");
 
     // initial edges (:225-236)
     BinHeap<Edge, EdgeBefore> queue;
     std::vector<std::vector<uint32_t>> neighbors((size_t)n + 1);
     neighbors.reserve(2 * (size_t)n);
-    lap("read sets");
-    // (the n x 25 similarities are independent: computed by a few threads, then pushed in the reference's order)
-    std::vector<float> sims((size_t)n * K, 0.0f);
-    {
-        const unsigned hw = host_threads();
-        std::vector<std::thread> pool;
-        for (unsigned th = 0; th < hw; ++th)
-            pool.emplace_back([&, th]() {
-                for (int64_t j1 = 1 + th; j1 <= n; j1 += hw)
-                    for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2)
-                        sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)] =
-                            (float)relative_intersection(read_sets[(size_t)j1], read_sets[(size_t)j2]);
-            });
-        for (auto &t : pool) t.join();
-    }
-    lap("initial similarities");
     for (int64_t j1 = 1; j1 <= n; ++j1)
         for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
             const float sim = sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)];
@@ -344,39 +489,289 @@ std::string hclust_build(int64_t m, int64_t n, const void *colptr, int colptr_by
         fprintf(stderr, "[hclust]   pops %zu (%.3f s), merge_sets %.3f s, similarities %.3f s light + %.3f s in %zu heavy merges, "
                         "candidates %zu, distinct %zu\n", n_pops, t_pop, t_merge, t_eval, t_eval_heavy, n_heavy, n_cand, n_uniq);
     lap("greedy joining");
-    // remaining components: smallest first (:244-258)
-    BinHeap<NodeWithSize, SizeBefore> rest;
-    for (uint32_t j = 1; j < nodes.size(); ++j)
-        if (alive[j]) rest.push(NodeWithSize{j, (uint32_t)(1 + read_sets[j].size())});
-    while (rest.size() > 1) {
-        const NodeWithSize a = rest.pop(), b = rest.pop();
-        const uint32_t k = (uint32_t)nodes.size();
-        nodes.push_back(TreeNode{0, (int32_t)a.j, (int32_t)b.j});
-        rest.push(NodeWithSize{k, a.size + b.size});
-    }
-    if (rest.size() != 1) return "internal error: no root";
-    const uint32_t root = rest.pop().j;
-    if (nodes.size() != 2 * (size_t)n) return "internal error: node count";
+    return finish_tree(n, nodes, alive, [&](uint32_t j) { return read_sets[j].size(); }, node_parent_idxs, node_js);
+}
 
-    // order_nodes (:361-389): DFS, left pushed first so that the right child is visited first
-    std::vector<uint32_t> stack{root};
-    std::vector<int32_t> parent_of(nodes.size(), 0);
-    int64_t pos = 0;
-    while (!stack.empty()) {
-        const uint32_t v = stack.back();
-        stack.pop_back();
-        node_parent_idxs[pos] = parent_of[v];
-        node_js[pos] = (int32_t)nodes[v].j;
-        ++pos;
-        if (nodes[v].j == 0) {
-            parent_of[(size_t)nodes[v].left] = (int32_t)pos;
-            parent_of[(size_t)nodes[v].right] = (int32_t)pos;
-            stack.push_back((uint32_t)nodes[v].left);
-            stack.push_back((uint32_t)nodes[v].right);
-        }
+// ---- the parallel variant: rounds of mutually-best merges ---------------------------------------------------------------
+// The reference's greedy joining pops ONE edge at a time from a heap of millions (5.3 M pops at BASELINE's C2, every one a
+// cache-missing percolate-down) and its result depends on heap positions among equal similarities -- node-for-node
+// equality forbids any reordering, so the exact mode above is sequential by construction (3.8 s at C2, 20x the fit it
+// feeds).  This variant keeps the rule -- join the subtrees that share the most reads first, similarities of a merged
+// node recomputed against the neighbours of both halves (:262-308), same +-25 starting window, same Jaccard similarity,
+// same smallest-first joining of what is left -- and replaces the global order by a local one:
+//   * every edge has a priority (similarity, then a hash of its endpoints, then the endpoints): a TOTAL order;
+//   * a round merges every edge that is the best edge of BOTH its endpoints (the globally best edge always is, so every
+//     round makes progress; the hash breaks the long chains that equal similarities -- small rationals: the rule, not
+//     the exception -- would form under an id tie-break);
+//   * the merges of a round are independent: unions, candidate lists and similarities run on all host threads;
+//   * new nodes are numbered in the order of their edges' priorities: the tree does not depend on the thread count.
+// Neighbours without a common read are not listed (a node sharing no read with either half shares none with the union;
+// it can only become similar again through a LATER merge of its own neighbours, which lists it then).
+// Where it differs from the exact mode: an edge is merged as soon as nothing better touches either endpoint, although a
+// better edge may exist elsewhere (irrelevant for the tree: disjoint subtrees) or may APPEAR at an endpoint later through
+// a neighbour's merge (Jaccard similarity is not reducible, so this changes some joins).  The tree is a heuristic
+// parameterisation either way (the reference ships two others, polee.jl: random and sequential trees); validated by the
+// fit it gives (tests/test_gpu_hclust.py: E[lp] of the fit on the parallel tree against the exact tree's).
+namespace {
+
+struct Nbr {
+    uint32_t id;
+    float sim;
+};
+struct EdgePri {  // larger = merged first
+    uint64_t key;  // similarity bits (positive floats order like their bit patterns) << 32 | hash
+    uint32_t lo, hi;
+    bool operator<(const EdgePri &o) const
+    {
+        if (key != o.key) return key < o.key;
+        if (lo != o.lo) return lo > o.lo;
+        return hi > o.hi;
     }
-    if (pos != 2 * n - 1) return "internal error: tree size";
-    return "";
+    bool operator==(const EdgePri &o) const { return lo == o.lo && hi == o.hi; }
+};
+inline EdgePri edge_pri(uint32_t a, uint32_t b, float sim)
+{
+    const uint32_t lo = std::min(a, b), hi = std::max(a, b);
+    uint64_t h = (uint64_t)lo * 0x9E3779B97F4A7C15ull ^ ((uint64_t)hi * 0xC2B2AE3D27D4EB4Full + 0x165667B19E3779F9ull);
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    uint32_t sb;
+    memcpy(&sb, &sim, 4);
+    return EdgePri{((uint64_t)sb << 32) | (uint32_t)h, lo, hi};
+}
+
+}  // namespace
+
+std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                int32_t *node_parent_idxs, int32_t *node_js)
+{
+    if (n < 1 || m < 0 || !colptr || !node_parent_idxs || !node_js) return "bad argument";
+    if (colptr_bytes != 4 && colptr_bytes != 8) return "colptr_bytes must be 4 or 8";
+    auto cp = [&](int64_t j) -> uint64_t {
+        return colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j]
+                                 : reinterpret_cast<const uint64_t *>(colptr)[j];
+    };
+    if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
+    const int K = 25;
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[hclust/rounds] %-24s %.3f s\n", what, now() - t_prev);
+        t_prev = now();
+    };
+    std::vector<TreeNode> nodes;
+    std::vector<ReadSet> read_sets;
+    std::vector<float> sims;
+    {
+        const std::string err = leaf_setup(m, n, cp, rowval, K, nodes, read_sets, sims);
+        if (!err.empty()) return err;
+    }
+    lap("read sets + similarities");
+    const size_t cap = 2 * (size_t)n + 1;
+    nodes.resize(cap);
+    read_sets.resize(cap);
+    std::vector<std::vector<Nbr>> adj(cap);
+    std::vector<char> alive(cap, 0);
+    std::vector<uint32_t> best(cap, 0), into(cap, 0), stamp(cap, 0);
+    std::vector<uint32_t> set_size(cap, 0);
+    for (int64_t j = 1; j <= n; ++j) alive[(size_t)j] = 1, set_size[(size_t)j] = (uint32_t)read_sets[(size_t)j].size();
+    for (int64_t j1 = 1; j1 <= n; ++j1)
+        for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
+            const float sim = sims[(size_t)(j1 - 1) * K + (size_t)(j2 - j1 - 1)];
+            if (sim > 0) {
+                adj[(size_t)j1].push_back(Nbr{(uint32_t)j2, sim});
+                adj[(size_t)j2].push_back(Nbr{(uint32_t)j1, sim});
+            }
+        }
+    std::vector<float>().swap(sims);
+    std::vector<uint32_t> dirty;
+    for (int64_t j = 1; j <= n; ++j)
+        if (!adj[(size_t)j].empty()) dirty.push_back((uint32_t)j);
+    lap("initial edges");
+
+    uint32_t next_id = (uint32_t)n + 1;
+    struct Pair {
+        EdgePri pri;
+        uint32_t k;
+    };
+    std::vector<Pair> pairs;
+    std::vector<std::vector<uint32_t>> cands;  // per pair: the distinct live neighbours of both halves (new ids applied)
+    std::vector<size_t> task_ptr;
+    std::vector<uint32_t> next_dirty;
+    std::vector<float> tsim;
+    std::vector<ReadSet> heavy_sets;
+    // a merge is "heavy" when its sets are large AND its work exceeds a thread's fair share of the round: then it is cut
+    // into value ranges over all threads instead of being one task (POLEE_HCLUST_HEAVY: the size threshold, for tests)
+    const size_t HEAVY = getenv("POLEE_HCLUST_HEAVY") ? (size_t)atol(getenv("POLEE_HCLUST_HEAVY")) : (size_t)1 << 22;
+    std::vector<char> is_heavy;
+    // (a range per ~1 M elements: starting a host thread costs about what merging 50 k elements does)
+    const size_t grain = std::max<size_t>(1, std::min<size_t>((size_t)1 << 20, HEAVY));
+    std::vector<std::vector<uint64_t>> bitmaps(host_threads());
+    size_t rounds = 0, n_eval = 0;
+    double t_best = 0, t_union = 0, t_eval = 0, t_apply = 0;
+    while (!dirty.empty()) {
+        ++rounds;
+        double t0 = timing ? now() : 0.0;
+        // A: the best live edge of every node whose neighbourhood changed (dead neighbours leave the list here)
+        parallel_chunks(dirty.size(), 2048, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t q = lo; q < hi; ++q) {
+                const uint32_t a = dirty[q];
+                std::vector<Nbr> &L = adj[a];
+                size_t w = 0;
+                EdgePri bp{0, 0, 0};
+                uint32_t b = 0;
+                for (size_t e = 0; e < L.size(); ++e) {
+                    if (!alive[L[e].id]) continue;
+                    L[w++] = L[e];
+                    const EdgePri pr = edge_pri(a, L[e].id, L[e].sim);
+                    if (b == 0 || bp < pr) bp = pr, b = L[e].id;
+                }
+                L.resize(w);
+                best[a] = b;
+            }
+        });
+        // B: the edges that are the best of both endpoints, in the order of their priorities
+        pairs.clear();
+        for (uint32_t a : dirty) {
+            const uint32_t b = best[a];
+            if (!b || best[b] != a) continue;
+            float sim = 0.0f;
+            for (const Nbr &e : adj[a])
+                if (e.id == b) sim = e.sim;
+            pairs.push_back(Pair{edge_pri(a, b, sim), 0});
+        }
+        std::sort(pairs.begin(), pairs.end(), [](const Pair &x, const Pair &y) { return y.pri < x.pri; });
+        pairs.erase(std::unique(pairs.begin(), pairs.end(), [](const Pair &x, const Pair &y) { return x.pri == y.pri; }),
+                    pairs.end());
+        if (pairs.empty()) break;  // (cannot happen while an edge is left: the best edge overall is mutual)
+        const uint32_t base = next_id;  // ids below are the old nodes
+        for (Pair &pr : pairs) {
+            pr.k = next_id++;
+            into[pr.pri.lo] = into[pr.pri.hi] = pr.k;
+            nodes[pr.k] = TreeNode{0, (int32_t)pr.pri.lo, (int32_t)pr.pri.hi};
+        }
+        if (timing) t_best += now() - t0, t0 = now();
+        // C1: unions and candidate lists (independent per merge)
+        cands.resize(pairs.size());
+        // (the few merges of millions of reads first, one at a time on all threads; the rest one merge per task)
+        heavy_sets.clear();
+        heavy_sets.resize(pairs.size());
+        size_t round_work = 0;
+        for (const Pair &pr : pairs) round_work += read_sets[pr.pri.lo].size() + read_sets[pr.pri.hi].size();
+        is_heavy.assign(pairs.size(), 0);
+        for (size_t q = 0; q < pairs.size(); ++q) {
+            const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi;
+            const size_t w = read_sets[a].size() + read_sets[b].size();
+            if (w < HEAVY || w * host_threads() < round_work) continue;
+            is_heavy[q] = 1;
+            heavy_sets[q] = merge_sets_parallel(read_sets[a], read_sets[b], grain);
+            set_size[pairs[q].k] = 1;  // (marks the pair for the loop below)
+            ReadSet().swap(read_sets[a]);
+            ReadSet().swap(read_sets[b]);
+        }
+        parallel_chunks(pairs.size(), 8, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t q = lo; q < hi; ++q) {
+                const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
+                read_sets[k] = merge_sets(read_sets[a], read_sets[b]);  // (a heavy pair's halves are empty by now)
+                if (read_sets[k].empty() && set_size[k]) read_sets[k].swap(heavy_sets[q]);
+                set_size[k] = (uint32_t)read_sets[k].size();
+                std::vector<uint32_t> &c = cands[q];
+                c.clear();
+                for (uint32_t half : {a, b})
+                    for (const Nbr &e : adj[half]) {
+                        if (e.id == a || e.id == b) continue;
+                        c.push_back(into[e.id] ? into[e.id] : e.id);
+                    }
+                std::sort(c.begin(), c.end());
+                c.erase(std::unique(c.begin(), c.end()), c.end());
+                // the halves retire here, on this thread: nobody else reads their sets or lists (other merges see them
+                // through `into` only), and releasing 400 k vectors one after the other was a third of the sequential part
+                ReadSet().swap(read_sets[a]);
+                ReadSet().swap(read_sets[b]);
+                std::vector<Nbr>().swap(adj[a]);
+                std::vector<Nbr>().swap(adj[b]);
+            }
+        });
+        if (timing) t_union += now() - t0, t0 = now();
+        // C2: similarities of the new nodes to their candidates.  A new node's reads are marked in a bitmap once and
+        // every candidate is |candidate| look-ups (as in the exact mode).  Light merges: one merge per task, the thread's
+        // own bitmap.  Heavy merges (the top of the tree: few per round, millions of reads): one at a time, one shared
+        // bitmap, the candidates spread over the threads.
+        task_ptr.assign(pairs.size() + 1, 0);
+        for (size_t q = 0; q < pairs.size(); ++q) task_ptr[q + 1] = task_ptr[q] + cands[q].size();
+        const size_t ntasks = task_ptr.back();
+        n_eval += ntasks;
+        tsim.resize(ntasks);
+        auto range_hit = [&](const ReadSet &a, const ReadSet &ks) {
+            return !a.empty() && !ks.empty() && a.front() <= ks.back() && a.back() >= ks.front();
+        };
+        parallel_chunks(pairs.size(), 4, [&](size_t lo, size_t hi, unsigned th) {
+            std::vector<uint64_t> &bits = bitmaps[th];
+            for (size_t q = lo; q < hi; ++q) {
+                const ReadSet &ks = read_sets[pairs[q].k];
+                const size_t nc = cands[q].size();
+                if (is_heavy[q]) continue;  // (below)
+                const bool use_bits = nc >= 3;
+                if (use_bits) {
+                    if (bits.empty()) bits.assign(((size_t)m >> 6) + 2, 0);
+                    for (uint32_t v : ks) bits[v >> 6] |= 1ull << (v & 63u);
+                }
+                for (size_t c = 0; c < nc; ++c) {
+                    const ReadSet &a = read_sets[cands[q][c]];
+                    tsim[task_ptr[q] + c] = !range_hit(a, ks) ? 0.0f
+                                            : (float)(use_bits ? bitmap_similarity(a, ks.size(), bits) : relative_intersection(a, ks));
+                }
+                if (use_bits)
+                    for (uint32_t v : ks) bits[v >> 6] = 0;
+            }
+        });
+        for (size_t q = 0; q < pairs.size(); ++q) {
+            const ReadSet &ks = read_sets[pairs[q].k];
+            const size_t nc = cands[q].size();
+            if (!is_heavy[q]) continue;
+            for (size_t c = 0; c < nc; ++c) {  // every evaluation on all threads, cut into value ranges
+                const ReadSet &a = read_sets[cands[q][c]];
+                const size_t is = intersection_size_parallel(a, ks, grain);
+                tsim[task_ptr[q] + c] = a.empty() ? 0.0f : (float)((double)is / (double)(a.size() + ks.size() - is));
+            }
+        }
+        if (timing) t_eval += now() - t0, t0 = now();
+        // D: the new nodes' lists, their entries in the old neighbours' lists, the halves retire
+        next_dirty.clear();
+        for (size_t q = 0; q < pairs.size(); ++q) {
+            const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
+            std::vector<Nbr> &L = adj[k];
+            L.reserve(task_ptr[q + 1] - task_ptr[q]);
+            for (size_t t = task_ptr[q]; t < task_ptr[q + 1]; ++t) {
+                const uint32_t l = cands[q][t - task_ptr[q]];
+                if (!(tsim[t] > 0)) continue;
+                L.push_back(Nbr{l, tsim[t]});
+                if (l < base) {  // an old node: it learns about k (a new one lists k itself)
+                    adj[l].push_back(Nbr{k, tsim[t]});
+                    if (stamp[l] != (uint32_t)rounds) stamp[l] = (uint32_t)rounds, next_dirty.push_back(l);
+                }
+            }
+            alive[a] = alive[b] = 0;
+            alive[k] = 1;
+            if (!L.empty()) next_dirty.push_back(k);
+        }
+        for (const Pair &pr : pairs) into[pr.pri.lo] = into[pr.pri.hi] = 0;
+        // (an old node that was listed but merged in this very round is dead now; step A skips nothing for it: drop it)
+        dirty.clear();
+        for (uint32_t l : next_dirty)
+            if (alive[l]) dirty.push_back(l);
+        std::sort(dirty.begin(), dirty.end());
+        if (timing) t_apply += now() - t0;
+    }
+    if (timing)
+        fprintf(stderr, "[hclust/rounds]   %zu rounds, %zu similarity evaluations; best/pairs %.3f s, unions %.3f s, "
+                        "similarities %.3f s, apply %.3f s\n", rounds, n_eval, t_best, t_union, t_eval, t_apply);
+    lap("joining in rounds");
+    nodes.resize(next_id);
+    alive.resize(next_id);
+    return finish_tree(n, nodes, alive, [&](uint32_t j) { return (size_t)set_size[j]; }, node_parent_idxs, node_js);
 }
 
 }  // namespace polee
@@ -385,6 +780,14 @@ extern "C" polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, i
                                      int32_t *node_parent_idxs, int32_t *node_js)
 {
     const std::string err = polee::hclust_build(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js);
+    if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
+    return POLEE_OK;
+}
+
+extern "C" polee_status polee_hclust_parallel(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                              const uint32_t *rowval, int32_t *node_parent_idxs, int32_t *node_js)
+{
+    const std::string err = polee::hclust_build_rounds(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js);
     if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
     return POLEE_OK;
 }

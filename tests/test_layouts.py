@@ -389,6 +389,57 @@ def test_hclust_on_the_reference_fixture(lm_fixture, prep_fixture):
     np.testing.assert_array_equal(j, j2)
 
 
+def test_hclust_parallel_matches_its_restatement_and_does_not_depend_on_threads(lm_fixture):
+    """polee_hclust_parallel (rounds of mutually-best merges, csrc/hclust.cpp) against the sequential, dict-and-set
+    restatement of its definition (oracle/hclust_ref.py::hclust_rounds): node for node, on random matrices with many
+    ties and disconnected components and on the reference's real-data fixture; the same tree from 1 and from many host
+    threads; most clades shared with the exact (reference-order) tree."""
+    import subprocess
+    import sys
+    from oracle import hclust_ref
+    import polee_amd as P
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    cases = []
+    for trial, (m, n) in enumerate([(60, 9), (300, 40), (500, 80), (40, 30), (3000, 300), (5, 1), (9, 2)]):
+        dens = [0.3, 0.08, 0.05, 0.02, 0.012, 0.5, 0.5][trial]
+        X = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        X.sort_indices()
+        cases.append((m, n, (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32)))
+    f = lm_fixture
+    cases.append((f["m"], f["n"], f["colptr"], f["rowval"]))
+    for m, n, colptr, rowval in cases:
+        pc, jc = P.hclust(m, n, colptr, rowval, parallel=True)
+        pr, jr = hclust_ref.hclust_rounds(m, n, colptr, rowval)
+        _valid_tree(pc, jc, n)
+        np.testing.assert_array_equal(pc, pr)
+        np.testing.assert_array_equal(jc, jr)
+
+    def clades(parents, js):
+        sets = [frozenset([int(j)]) if j > 0 else frozenset() for j in js]
+        for i in range(len(js) - 1, 0, -1):
+            sets[parents[i] - 1] = sets[parents[i] - 1] | sets[i]
+        return {c for c, j in zip(sets, js) if j == 0}
+    pe, je = P.hclust(f["m"], f["n"], f["colptr"], f["rowval"])
+    pp, jp = P.hclust(f["m"], f["n"], f["colptr"], f["rowval"], parallel=True)
+    shared = len(clades(pe, je) & clades(pp, jp))
+    assert shared >= 0.7 * (f["n"] - 1), shared  # (256 of 312: the joins differ where a better edge appears later)
+    # one host thread against the default: a sample large enough for several chunks per phase
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import polee_amd as P; from tools import synth;"
+            "s = synth.make_sample(3000, 200000, 6.0, 5); c, r, _ = synth.to_csc(s);"
+            "p, j = P.hclust(200000, 3000, c, r, parallel=True); sys.stdout.write(str(hash((p.tobytes(), j.tobytes()))))"
+            % os.path.join(os.path.dirname(__file__), ".."))
+    outs = []
+    # (POLEE_HCLUST_HEAVY=1: every merge above a thread's share of its round is cut into value ranges over all threads --
+    # the path the top of a large tree takes)
+    for threads, heavy in (("1", None), ("3", None), ("8", None), ("8", "1"), ("3", "40")):
+        env = dict(os.environ, POLEE_HOST_THREADS=threads, PYTHONHASHSEED="0")
+        if heavy:
+            env["POLEE_HCLUST_HEAVY"] = heavy
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
+    assert len(set(outs)) == 1 and outs[0], outs
+
+
 def test_psell_layout_with_multiplicities_on_equivalence_classes():
     """Uniform slices carry the row multiplicities as their last row; the emulated pass equals the factored oracle."""
     import scipy.sparse as sp

@@ -17,7 +17,9 @@ for s in range(3):
     distinct.append((m, n, colptr, rowval, nzval, smp["effective_lengths"]))
     del smp
 print("3 distinct samples generated in %.1f s" % (time.time() - t0), flush=True)
-approx = P.LogitSkewNormalPTTApprox("cluster")
+# POLEE_PREP_TREE=cluster_parallel: the rounds variant of the tree heuristic (polee_hclust_parallel)
+approx = P.LogitSkewNormalPTTApprox(os.environ.get("POLEE_PREP_TREE", "cluster"))
+print("tree method:", approx.treemethod, flush=True)
 for w in workers_list:
     t0 = time.time()
     out = P.approximate_likelihood_cohort(approx, [distinct[i % 3] for i in range(jobs)], workers=w, num_steps=500)
