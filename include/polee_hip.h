@@ -65,6 +65,10 @@ void *polee_ctx_stream(polee_ctx *ctx); /* the context's hipStream_t */
 polee_status polee_ctx_timer_start(polee_ctx *ctx);
 polee_status polee_ctx_timer_stop(polee_ctx *ctx, double *elapsed_ms);
 const char *polee_version(void);
+/* The host-side builders (polee_loglik_create, polee_hclust*) keep the large scratch blocks they used -- up to
+ * POLEE_HOST_CACHE_MB megabytes, default 8192 -- for the next sample: mapping and unmapping gigabytes per sample was a
+ * third of a sample's preparation.  This releases them. */
+void polee_host_cache_trim(void);
 
 /* ---- Polya tree transform ---------------------------------------------------------
  * Replaces PolyaTreeTransform (src/ptt.jl:6-27) and the three TF custom ops of

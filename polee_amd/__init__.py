@@ -17,7 +17,7 @@ would use).  Names, argument meaning and error behaviour follow the reference:
 All numerics run in libpolee_hip.so on the GPU; nothing here computes on the CPU.
 """
 from ._lib import PoleeError, NonFiniteError, lib, LIB_PATH  # noqa: F401
-from .core import (Context, Comm, HostComm, hclust, PolyaTreeTransform, make_inverse_ptt_params, hsb, inv_hsb, inv_hsb_grad,  # noqa: F401
+from .core import (Context, Comm, HostComm, hclust, host_cache_trim, PolyaTreeTransform, make_inverse_ptt_params, hsb, inv_hsb, inv_hsb_grad,  # noqa: F401
                    RNASeqSample, log_likelihood, factored_log_likelihood,
                    effective_length_jacobian_adjustment, gene_noninformative_prior, LogitSkewNormalPTTApprox, approximate_likelihood,
                    LikelihoodApproximationFit, ApproxLikelihoodSampler, RNASeqApproxLikelihood,
@@ -31,5 +31,5 @@ from .estimate import LoadedSamples, load_samples_from_specification, load_sampl
 from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegression, RNASeqNormalTranscriptLinearRegression, RNASeqGeneLinearRegression, RNASeqGeneIsoformLinearRegression, estimate_sample_scales,  # noqa: F401,E402
                          find_minimum_effect_size, write_regression_effects)
 from .salmon import load_salmon_likelihood, SalmonLikelihood  # noqa: F401,E402
-from .cohort import approximate_likelihood_cohort  # noqa: F401,E402
+from .cohort import approximate_likelihood_cohort, approximate_likelihood_cohort_processes  # noqa: F401,E402
 from .xbuild import build_likelihood_matrix  # noqa: F401,E402

@@ -385,6 +385,13 @@ def kumaraswamy_transform_gradients(zs, as_, bs, y_grad, a_grad=None, b_grad=Non
     return ag, bg
 
 
+def host_cache_trim():
+    """Release the scratch blocks the host-side builders keep between samples (polee_host_cache_trim)."""
+    f = L.lib().polee_host_cache_trim
+    f.restype, f.argtypes = None, []
+    f()
+
+
 def hclust(m, n, colptr, rowval, parallel=False):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],

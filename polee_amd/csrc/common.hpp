@@ -1,5 +1,7 @@
 // Shared host-side plumbing of libpolee_hip: context, error state, device buffers.
 #pragma once
+#include <mutex>
+#include <sys/mman.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -133,15 +135,136 @@ inline unsigned host_threads()
     return n;
 }
 
+// Large blocks (>= 8 MiB) come straight from mmap with MADV_HUGEPAGE: the one-off host builders fill gigabytes of fresh
+// memory once, and with 4 KiB pages that is a million page faults in (and a million page frees out) per gigabyte-sized
+// buffer -- measured at BASELINE's C2: the two passes of the CSC -> rows transposition 0.36 -> 0.05 s.
+// Freed blocks are kept (up to POLEE_HOST_CACHE_MB, default 8192) and handed out again: unmapping a 3 GB staging buffer
+// costs 0.14 s of kernel time, and doing it on a helper thread only moves the cost (the unmap holds the address-space
+// lock that every page fault of the next phase needs: measured, the next phase got 0.14 s slower).  A reused block is
+// already resident, so the second use does not fault either -- within one build (the sort's buffers reuse the
+// transposition's) and from one sample of a cohort to the next.  polee_host_cache_trim() releases everything.
+struct HugeBlockCache {
+    static constexpr size_t HUGE_PAGE = (size_t)2 << 20;
+    struct Blk {
+        void *p;
+        size_t len;
+    };
+    std::mutex mu;
+    std::vector<Blk> free_;             // oldest first
+    std::vector<Blk> live_;             // blocks handed out (a dozen at a time: linear search)
+    size_t cached = 0, cap;
+    HugeBlockCache()
+    {
+        const char *e = getenv("POLEE_HOST_CACHE_MB");
+        cap = (size_t)(e ? std::max(0L, atol(e)) : 8192L) << 20;
+    }
+    ~HugeBlockCache() { trim(); }
+    static HugeBlockCache &get()
+    {
+        static HugeBlockCache c;
+        return c;
+    }
+    void *take(size_t bytes)
+    {
+        const size_t len = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)  // smallest block that fits without wasting more than half of it
+                if (free_[i].len >= len && free_[i].len <= 2 * len && (best == free_.size() || free_[i].len < free_[best].len))
+                    best = i;
+            if (best != free_.size()) {
+                const Blk b = free_[best];
+                free_.erase(free_.begin() + (ptrdiff_t)best);
+                cached -= b.len;
+                live_.push_back(b);
+                return b.p;
+            }
+        }
+        void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return nullptr;
+        (void)madvise(p, len, MADV_HUGEPAGE);
+        std::lock_guard<std::mutex> g(mu);
+        live_.push_back(Blk{p, len});
+        return p;
+    }
+    void give(void *p)
+    {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            Blk b{p, 0};
+            for (size_t i = 0; i < live_.size(); ++i)
+                if (live_[i].p == p) {
+                    b = live_[i];
+                    live_[i] = live_.back();
+                    live_.pop_back();
+                    break;
+                }
+            if (b.len == 0) return;  // (not ours: cannot happen)
+            if (b.len > cap)
+                drop.push_back(b);
+            else {
+                while (cached + b.len > cap) {
+                    drop.push_back(free_.front());
+                    cached -= free_.front().len;
+                    free_.erase(free_.begin());
+                }
+                free_.push_back(b);
+                cached += b.len;
+            }
+        }
+        for (const Blk &d : drop) (void)munmap(d.p, d.len);
+    }
+    void trim()
+    {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            drop.swap(free_);
+            cached = 0;
+        }
+        for (const Blk &d : drop) (void)munmap(d.p, d.len);
+    }
+};
+
+template <class T>
+struct huge_allocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = huge_allocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    static constexpr size_t HUGE_MIN = (size_t)8 << 20;
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < HUGE_MIN) return std::allocator<T>::allocate(n);
+        void *p = HugeBlockCache::get().take(bytes);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t n)
+    {
+        if (n * sizeof(T) < HUGE_MIN)
+            std::allocator<T>::deallocate(p, n);
+        else
+            HugeBlockCache::get().give(p);
+    }
+};
+// a std::vector that behaves like one (value-initialises) on that allocator
+template <class T>
+using BVec = std::vector<T, huge_allocator<T>>;
+
 // std::vector allocator that leaves trivially constructible elements uninitialised on resize (a 1 GB resize otherwise
 // spends its time writing zeros that are overwritten at once)
 template <class T>
-struct default_init_allocator : std::allocator<T> {
+struct default_init_allocator : huge_allocator<T> {
     template <class U>
     struct rebind {
         using other = default_init_allocator<U>;
     };
-    using std::allocator<T>::allocator;
+    using huge_allocator<T>::huge_allocator;
     template <class U>
     void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
     {
@@ -153,6 +276,9 @@ struct default_init_allocator : std::allocator<T> {
         ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
     }
 };
+
+template <class T>
+using RawVec = std::vector<T, default_init_allocator<T>>;
 
 // f(lo, hi, thread) over [0, count) in chunks of `grain` on a few host threads (dynamic assignment)
 template <class F>

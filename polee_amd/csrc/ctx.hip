@@ -33,6 +33,9 @@ extern "C" {
 // (the build records the hipcc version and the backend tuning flags loglik.hip was compiled with: csrc/Makefile)
 const char *polee_version(void) { return "polee_hip 0.3 (gfx950); " POLEE_BUILD_INFO; }
 
+// the host builders keep their large scratch blocks for the next sample (common.hpp HugeBlockCache)
+void polee_host_cache_trim(void) { polee::HugeBlockCache::get().trim(); }
+
 polee_status polee_ctx_create(int device, polee_ctx **out)
 {
     if (!out) return fail(nullptr, POLEE_ERR_BAD_ARG, "polee_ctx_create: null out pointer");

@@ -7,8 +7,7 @@
 
 namespace polee {
 std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
-                       const float *nzval, std::vector<uint64_t> &rowptr, std::vector<uint32_t> &col,
-                       std::vector<float> &val);
+                       const float *nzval, BVec<uint64_t> &rowptr, RawVec<uint32_t> &col, RawVec<float> &val);
 }
 using namespace polee;
 
@@ -43,9 +42,9 @@ polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, i
                                      polee_psell_debug **out)
 {
     if (!colptr || !out) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
-    std::vector<uint64_t> rowptr;
-    std::vector<uint32_t> col;
-    std::vector<float> val;
+    BVec<uint64_t> rowptr;
+    RawVec<uint32_t> col;  // (resize leaves them uninitialised: 1.9 GB of zeros would be written by one thread)
+    RawVec<float> val;
     std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
     if (!err.empty()) return fail(nullptr, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());
     polee_psell_debug *p = new polee_psell_debug();

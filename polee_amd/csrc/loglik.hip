@@ -2433,8 +2433,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
 namespace polee {
 // CSC (1-based, as in the HDF5) -> CSR (0-based).  Columns stay ascending within a row.
 std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
-                       const float *nzval, std::vector<uint64_t> &rowptr, std::vector<uint32_t> &col,
-                       std::vector<float> &val)
+                       const float *nzval, BVec<uint64_t> &rowptr, RawVec<uint32_t> &col, RawVec<float> &val)
 {
     auto cp = [&](int64_t j) -> uint64_t {
         return colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j]
@@ -2442,55 +2441,115 @@ std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_byte
     };
     if (colptr_bytes != 4 && colptr_bytes != 8) return "colptr_bytes must be 4 or 8";
     if (cp(0) != 1) return "colptr[0] must be 1 (1-based)";
+    const double t_enter = wall_now();
     const uint64_t nnz = cp(n) - 1;
-    rowptr.assign(m + 1, 0);
     for (int64_t j = 0; j < n; ++j)
         if (cp(j + 1) < cp(j)) return "colptr is not monotone";
-    // On several host threads: count per row (atomic increments), prefix sum, scatter through atomic cursors
-    // (arbitrary order inside a row), then sort every row by transcript -- the result is the same as a
-    // sequential transposition because a row holds every transcript at most once.
+    rowptr.assign(m + 1, 0);
+    // Transposition in two partitioned passes on the host threads, without atomics and without a sort:
+    //   the columns are cut into chunks of equal nnz, the rows into buckets of 2^sh consecutive rows (a bucket's cursors
+    //   stay in a core's L2);
+    //   pass 1: every chunk counts its entries per bucket; a prefix over (bucket, chunk) gives every (chunk, bucket) pair
+    //           its own contiguous piece of a staging array, bucket-major, chunks in column order inside a bucket;
+    //   pass 2: every chunk writes (row, column, value) records into its pieces -- a few hundred sequential write
+    //           streams per thread instead of 240 M random ones;
+    //   pass 3: every bucket counts its rows, prefixes (that IS its part of rowptr) and places its records: they arrive
+    //           in ascending column order, so every row comes out sorted by transcript, as a sequential transposition
+    //           would leave it.
+    col.clear();
+    val.clear();
+    if (nnz == 0) return "";
+    if (m < 1) return "rowval out of range";
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    double t_prev = t_enter;
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[CSC -> rows] %-30s %.3f s\n", what, wall_now() - t_prev);
+        t_prev = wall_now();
+    };
+    int sh = 0;
+    while (((uint64_t)m >> sh) > 512) ++sh;  // <= 512 buckets (+1)
+    if (sh < 12) sh = 12;
+    const size_t B = (size_t)(((uint64_t)m - 1) >> sh) + 1;
+    const size_t NC = std::max<size_t>(1, std::min<size_t>(4 * host_threads(), (size_t)(nnz >> 16) + 1));
+    std::vector<int64_t> cstart(NC + 1, n);  // chunk c = columns [cstart[c], cstart[c+1])
+    for (size_t c = 0; c <= NC; ++c) {
+        const uint64_t target = 1 + nnz * c / NC;  // first column whose start is >= target
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (cp(mid) < target) lo = mid + 1; else hi = mid;
+        }
+        cstart[c] = c == NC ? n : lo;
+    }
+    cstart[0] = 0;
+    std::vector<uint64_t> cnt(NC * B, 0);
     std::atomic<int> err{0};
-    parallel_chunks((size_t)nnz, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
-        for (size_t k = lo; k < hi; ++k) {
-            const uint32_t r = rowval[k];
-            if (r < 1 || (int64_t)r > m) {
-                err = 1;
-                continue;
+    parallel_chunks(NC, 1, [&](size_t clo, size_t chi, unsigned) {
+        for (size_t c = clo; c < chi; ++c) {
+            uint64_t *cc = cnt.data() + c * B;
+            for (uint64_t k = cp(cstart[c]) - 1; k < cp(cstart[c + 1]) - 1; ++k) {
+                const uint32_t r = rowval[k];
+                if (r < 1 || (int64_t)r > m) {
+                    err = 1;
+                    continue;
+                }
+                ++cc[(r - 1) >> sh];
             }
-            __atomic_fetch_add(&rowptr[r], (uint64_t)1, __ATOMIC_RELAXED);
         }
     });
     if (err) return "rowval out of range";
-    for (int64_t i = 0; i < m; ++i) rowptr[i + 1] += rowptr[i];
+    lap("checks + count per (chunk, bucket)");
+    std::vector<uint64_t> bstart(B + 1, 0);
+    {
+        uint64_t run = 0;
+        for (size_t b = 0; b < B; ++b) {
+            bstart[b] = run;
+            for (size_t c = 0; c < NC; ++c) {
+                const uint64_t t = cnt[c * B + b];
+                cnt[c * B + b] = run;  // becomes the write cursor of (chunk, bucket)
+                run += t;
+            }
+        }
+        bstart[B] = run;
+    }
+    struct Rec {
+        uint32_t row, col;
+        float val;
+    };
+    std::vector<Rec, default_init_allocator<Rec>> stage((size_t)nnz);
+    lap("allocate staging");
+    parallel_chunks(NC, 1, [&](size_t clo, size_t chi, unsigned) {
+        for (size_t c = clo; c < chi; ++c) {
+            uint64_t *cur = cnt.data() + c * B;
+            for (int64_t j = cstart[c]; j < cstart[c + 1]; ++j)
+                for (uint64_t k = cp(j) - 1; k < cp(j + 1) - 1; ++k) {
+                    const uint32_t r = rowval[k] - 1;
+                    stage[cur[r >> sh]++] = Rec{r, (uint32_t)j, nzval[k]};
+                }
+        }
+    });
+    lap("scatter into buckets");
     col.resize(nnz);
     val.resize(nnz);
-    std::vector<uint64_t> cursor(rowptr.begin(), rowptr.end() - 1);
-    parallel_chunks((size_t)n, 1024, [&](size_t jlo, size_t jhi, unsigned) {
-        for (size_t j = jlo; j < jhi; ++j)
-            for (uint64_t k = cp((int64_t)j) - 1; k < cp((int64_t)j + 1) - 1; ++k) {
-                const uint64_t p = __atomic_fetch_add(&cursor[rowval[k] - 1], (uint64_t)1, __ATOMIC_RELAXED);
-                col[p] = (uint32_t)j;
-                val[p] = nzval[k];
-            }
-    });
-    std::vector<uint64_t>().swap(cursor);
-    parallel_chunks((size_t)m, (size_t)1 << 16, [&](size_t ilo, size_t ihi, unsigned) {
-        for (size_t i = ilo; i < ihi; ++i) {
-            const uint64_t b = rowptr[i], e = rowptr[i + 1];
-            for (uint64_t p = b + 1; p < e; ++p) {  // insertion sort: rows are short
-                const uint32_t c = col[p];
-                const float v = val[p];
-                uint64_t q = p;
-                while (q > b && col[q - 1] > c) {
-                    col[q] = col[q - 1];
-                    val[q] = val[q - 1];
-                    --q;
-                }
-                col[q] = c;
-                val[q] = v;
+    lap("allocate rows");
+    parallel_chunks(B, 1, [&](size_t blo, size_t bhi, unsigned) {
+        std::vector<uint32_t> local;
+        for (size_t b = blo; b < bhi; ++b) {
+            const uint64_t r0 = (uint64_t)b << sh, r1 = std::min<uint64_t>((uint64_t)m, r0 + ((uint64_t)1 << sh));
+            local.assign((size_t)(r1 - r0) + 1, 0);
+            for (uint64_t p = bstart[b]; p < bstart[b + 1]; ++p) ++local[stage[p].row - r0 + 1];
+            for (size_t i = 1; i < local.size(); ++i) local[i] += local[i - 1];
+            for (uint64_t i = 0; i < r1 - r0; ++i) rowptr[r0 + i + 1] = bstart[b] + local[i + 1];
+            for (uint64_t p = bstart[b]; p < bstart[b + 1]; ++p) {
+                const Rec &e = stage[p];
+                const uint64_t q = bstart[b] + local[e.row - r0]++;
+                col[q] = e.col;
+                val[q] = e.val;
             }
         }
     });
+    rowptr[0] = 0;
+    lap("place within buckets");
     return "";
 }
 }  // namespace polee
@@ -2560,10 +2619,13 @@ polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const voi
 {
     POLEE_TRY(use_device(ctx));
     if (!colptr || !out || m < 0 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create: bad argument");
-    std::vector<uint64_t> rowptr;
-    std::vector<uint32_t> col;
-    std::vector<float> val;
+    BVec<uint64_t> rowptr;
+    RawVec<uint32_t> col;  // (resize leaves them uninitialised: 1.9 GB of zeros would be written by one thread)
+    RawVec<float> val;
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    const double t_begin = wall_now();
     std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
+    if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "CSC -> rows", wall_now() - t_begin);
     if (!err.empty()) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());
     polee_loglik *ll = new (std::nothrow) polee_loglik();
     if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
@@ -2579,7 +2641,9 @@ polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const voi
         return fail(ctx, err.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG,
                     "likelihood matrix: %s", err.c_str());
     }
-    return loglik_finish_create(ctx, ll, out);
+    const polee_status st = loglik_finish_create(ctx, ll, out);
+    if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "total", wall_now() - t_begin);
+    return st;
 }
 
 void polee_loglik_destroy(polee_loglik *ll) { loglik_release(ll); }

@@ -22,14 +22,14 @@ static inline uint32_t mix32(uint32_t h, uint32_t v)
 
 // LSD radix sort of (key, value) pairs by 64-bit key, 16 bits per pass, skipping passes whose digit is
 // constant; stable; histogram and scatter run on several host threads (fixed contiguous chunk per thread).
-static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> &vals)
+static void radix_sort_pairs(BVec<uint64_t> &keys, BVec<uint32_t> &vals)
 {
     const size_t N = keys.size();
     if (N < 2) return;
-    std::vector<uint64_t> k2(N);
-    std::vector<uint32_t> v2(N);
+    BVec<uint64_t> k2(N);
+    BVec<uint32_t> v2(N);
     const unsigned T = N < ((size_t)1 << 16) ? 1u : std::min(host_threads(), 32u);
-    std::vector<std::vector<size_t>> hist(T, std::vector<size_t>(65536));
+    std::vector<BVec<size_t>> hist(T, BVec<size_t>(65536));
     auto run = [&](auto &&f) {
         if (T == 1) {
             f(0u);
@@ -43,7 +43,7 @@ static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> 
     for (int pass = 0; pass < 4; ++pass) {
         const int sh = pass * 16;
         run([&](unsigned t) {
-            std::vector<size_t> &h = hist[t];
+            BVec<size_t> &h = hist[t];
             std::fill(h.begin(), h.end(), 0);
             for (size_t i = N * t / T, e = N * (t + 1) / T; i < e; ++i) h[(keys[i] >> sh) & 0xffff]++;
         });
@@ -59,7 +59,7 @@ static void radix_sort_pairs(std::vector<uint64_t> &keys, std::vector<uint32_t> 
                 sum += c;
             }
         run([&](unsigned t) {
-            std::vector<size_t> &h = hist[t];
+            BVec<size_t> &h = hist[t];
             for (size_t i = N * t / T, e = N * (t + 1) / T; i < e; ++i) {
                 const size_t p = h[(keys[i] >> sh) & 0xffff]++;
                 k2[p] = keys[i];
@@ -92,8 +92,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         t_prev = now();
     };
     // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards)
-    std::vector<uint64_t> keys((size_t)m);
-    std::vector<uint32_t> rows((size_t)m);
+    BVec<uint64_t> keys((size_t)m);
+    BVec<uint32_t> rows((size_t)m);
     {
         std::atomic<int> err{0};
         std::atomic<int64_t> empties{0};
@@ -153,35 +153,35 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     //            stored in the cheapest form: a dense union slice (A1 / A2), a masked slice (A1M; narrow class only) --
     //            or, when neither is below what its rows cost in the mixed stream, not as a group at all;
     //   B:       rows of more than 32 transcripts and the leftover rows of rejected groups.
-    std::vector<uint32_t> run_end;   // for the uniform streams' rows: 1 = the row's slice ends after it
-    std::vector<uint8_t> row_form;   // for the uniform streams' rows: 0 exact run, 1 dense union, 2 masked
-    std::vector<uint32_t> row_gid;   // ... forms 1, 2: the row's group (index into `patterns`)
-    std::vector<std::vector<uint32_t>> patterns;  // transcript set (union) of every group of leftover rows
+    BVec<uint32_t> run_end;   // for the uniform streams' rows: 1 = the row's slice ends after it
+    BVec<uint8_t> row_form;   // for the uniform streams' rows: 0 exact run, 1 dense union, 2 masked
+    BVec<uint32_t> row_gid;   // ... forms 1, 2: the row's group (index into `patterns`)
+    std::vector<BVec<uint32_t>> patterns;  // transcript set (union) of every group of leftover rows
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
             return l1 == l2 && std::equal(col + rowptr[r1], col + rowptr[r1] + l1, col + rowptr[r2]);
         };
         // head[i]: row i starts a new run (comparisons in parallel)
-        std::vector<uint8_t> head(rows.size() + 1, 1);
+        BVec<uint8_t> head(rows.size() + 1, 1);
         parallel_chunks(rows.size(), (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
             for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
         });
         struct RowList {
-            std::vector<uint32_t> rows, ends;
-            std::vector<uint8_t> form;
-            std::vector<uint32_t> gid;  // union / masked rows: index of the group's transcript set in `patterns`
+            BVec<uint32_t> rows, ends;
+            BVec<uint8_t> form;
+            BVec<uint32_t> gid;  // union / masked rows: index of the group's transcript set in `patterns`
         };
         RowList S1, S1M, S2, S2M;  // A1, A1M, A2, A2M
-        std::vector<uint32_t> rb;
+        BVec<uint32_t> rb;
         // (on several host threads: chunks of rows that start at a run's head, each with its own output lists, which are
         // then joined in chunk order -- the result does not depend on the number of threads)
         struct Part {
-            std::vector<uint32_t> ra1, ra2, rb, e1, e2;
+            BVec<uint32_t> ra1, ra2, rb, e1, e2;
         };
         const size_t CH = (size_t)1 << 20;
         const size_t nparts = std::max<size_t>(1, (rows.size() + CH - 1) / CH);
-        std::vector<size_t> pstart(nparts + 1, rows.size());
+        BVec<size_t> pstart(nparts + 1, rows.size());
         for (size_t p = 0; p < nparts; ++p) {
             size_t a = p * CH;
             while (a < rows.size() && !head[a]) ++a;  // (head[0] = 1)
@@ -203,8 +203,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     size_t take = (r / PSELL_LANES) * PSELL_LANES;
                     if (r - take >= (size_t)min_uniform) take = r;
                     if (len > (uint64_t)PSELL_WIDE_MAX || no_runs) take = 0;
-                    std::vector<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? P.ra1 : P.ra2;
-                    std::vector<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? P.e1 : P.e2;
+                    BVec<uint32_t> &dst = len <= (uint64_t)PSELL_NARROW_MAX ? P.ra1 : P.ra2;
+                    BVec<uint32_t> &de = len <= (uint64_t)PSELL_NARROW_MAX ? P.e1 : P.e2;
                     for (size_t q = 0; q < take; ++q) {
                         dst.push_back(rows[i + q]);
                         // slice boundary inside the run: after every 64 rows, and at the end of the taken part
@@ -256,14 +256,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
-            std::vector<uint64_t> k2(rb.size());
+            BVec<uint64_t> k2(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;  // (columns ascend within a row)
-            std::vector<uint32_t> idx(rb.size());
+            BVec<uint32_t> idx(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) idx[q] = (uint32_t)q;
             radix_sort_pairs(k2, idx);
-            std::vector<uint32_t> cand(rb.size());
+            BVec<uint32_t> cand(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) cand[q] = rb[idx[q]];
-            std::vector<uint32_t> keep_b, pool, next_pool;
+            BVec<uint32_t> keep_b, pool, next_pool;
             // pass 0: unions of <= 16; pass 1: unions of <= 32 over what is left.  What finds no company in either goes to
             // the mixed streams: rows of <= 16 transcripts to BN, inside the persistent launch.  Rows of 17..32 would need
             // the per-tile kernel's extra launch (30 us for a handful of rows), so the second pass keeps their groups even
@@ -280,9 +280,9 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     }
                 } else {
                     // the previous pass's rejects (pass 1: and the rows of 17..32), merged back into first-transcript order
-                    std::vector<uint64_t> k3(next_pool.size());
+                    BVec<uint64_t> k3(next_pool.size());
                     for (size_t q = 0; q < next_pool.size(); ++q) k3[q] = ((uint64_t)col[rowptr[next_pool[q]]] << 32) | q;
-                    std::vector<uint32_t> i3(next_pool.size());
+                    BVec<uint32_t> i3(next_pool.size());
                     for (size_t q = 0; q < next_pool.size(); ++q) i3[q] = (uint32_t)q;
                     radix_sort_pairs(k3, i3);
                     pool.resize(next_pool.size());
@@ -296,14 +296,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 const double matrix_csr_bytes = 8.0 * (double)rowptr[m] + 4.0 * (double)m;
                 struct UPart {
                     RowList dense1, masked1, dense2, masked2;
-                    std::vector<uint32_t> left;
-                    std::vector<std::vector<uint32_t>> pats;  // the sets of this part's groups (RowList::gid is local to the part)
+                    BVec<uint32_t> left;
+                    std::vector<BVec<uint32_t>> pats;  // the sets of this part's groups (RowList::gid is local to the part)
                 };
                 const size_t UCH = (size_t)1 << 15;
                 const size_t nup = std::max<size_t>(1, (pool.size() + UCH - 1) / UCH);
                 std::vector<UPart> uparts(nup);
                 parallel_chunks(nup, 1, [&](size_t ulo, size_t uhi, unsigned) {
-                    std::vector<uint32_t> deferred, group, uni, tmp;
+                    BVec<uint32_t> deferred, group, uni, tmp;
                     for (size_t up = ulo; up < uhi; ++up) {
                         UPart &U = uparts[up];
                         const size_t p0 = up * UCH, p1 = std::min(pool.size(), p0 + UCH);
@@ -364,7 +364,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                         for (int pass = 0; pass < 2; ++pass) {
                             const uint32_t *src = pass == 0 ? pool.data() + p0 : deferred.data();
                             const size_t cnt = pass == 0 ? p1 - p0 : deferred.size();
-                            std::vector<uint32_t> next_deferred;
+                            BVec<uint32_t> next_deferred;
                             for (size_t qi = 0; qi < cnt; ++qi) {
                                 const uint32_t r = src[qi];
                                 const uint32_t *cb = col + rowptr[r], *ce = col + rowptr[r + 1];
@@ -405,7 +405,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                     append(S1M, U.masked1);
                     append(S2, U.dense2);
                     append(S2M, U.masked2);
-                    std::vector<uint32_t> &left = pass_w == 0 ? next_pool : keep_b;
+                    BVec<uint32_t> &left = pass_w == 0 ? next_pool : keep_b;
                     left.insert(left.end(), U.left.begin(), U.left.end());
                 }
             }
@@ -414,14 +414,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // the mixed streams -- BN: rows of <= 16 transcripts, B: the others -- each in the order of the rows' first
         // transcripts (small tile dictionaries), and inside every block of 1024 rows -- a tile's worth -- by descending
         // length (little padding inside a slice)
-        std::vector<uint32_t> rbn;
+        BVec<uint32_t> rbn;
         if (!rb.empty()) {
-            std::vector<uint64_t> k2(rb.size());
+            BVec<uint64_t> k2(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) k2[q] = ((uint64_t)col[rowptr[rb[q]]] << 32) | q;
-            std::vector<uint32_t> idx(rb.size());
+            BVec<uint32_t> idx(rb.size());
             for (size_t q = 0; q < rb.size(); ++q) idx[q] = (uint32_t)q;
             radix_sort_pairs(k2, idx);
-            std::vector<uint32_t> wide;
+            BVec<uint32_t> wide;
             static const bool no_bn = getenv("POLEE_PSELL_NO_BN") != nullptr;  // (experiments: every mixed row to the per-tile kernel)
             for (size_t q = 0; q < rb.size(); ++q) {
                 const uint32_t r = rb[idx[q]];
@@ -429,7 +429,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
             rb.swap(wide);
             const size_t BL = (size_t)PSELL_LANES * PSELL_TILE_SLICES_B;
-            for (std::vector<uint32_t> *lst : {&rbn, &rb})
+            for (BVec<uint32_t> *lst : {&rbn, &rb})
                 parallel_chunks((lst->size() + BL - 1) / BL, 16, [&](size_t lo, size_t hi, unsigned) {
                     for (size_t blk = lo; blk < hi; ++blk)
                         std::stable_sort(lst->begin() + blk * BL, lst->begin() + std::min(lst->size(), (blk + 1) * BL), [&](uint32_t r1, uint32_t r2) {
@@ -448,14 +448,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // of their own.)
         static const bool no_csr = getenv("POLEE_PSELL_NO_CSR") != nullptr;
         static const double csr_min_share = getenv("POLEE_PSELL_CSR_MIN_SHARE") ? atof(getenv("POLEE_PSELL_CSR_MIN_SHARE")) : 0.10;
-        std::vector<uint32_t> rcsr;
-        const std::vector<uint32_t> rbn_all(rbn), rb_all(rb);
+        BVec<uint32_t> rcsr;
+        const BVec<uint32_t> rbn_all(rbn), rb_all(rb);
         if (!no_csr) {
-            std::vector<uint32_t> stamp((size_t)n, 0);
+            BVec<uint32_t> stamp((size_t)n, 0);
             uint32_t tile_stamp = 0;
-            for (std::vector<uint32_t> *lst : {&rbn, &rb}) {
+            for (BVec<uint32_t> *lst : {&rbn, &rb}) {
                 const size_t cap_slices = lst == &rbn ? (size_t)PSELL_TILE_SLICES_BN : (size_t)PSELL_TILE_SLICES_B;
-                std::vector<uint32_t> kept;
+                BVec<uint32_t> kept;
                 size_t i = 0;
                 while (i < lst->size()) {
                     // one simulated tile: rows i .. j-1
@@ -507,7 +507,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 out.csr_rowptr.push_back((uint32_t)out.csr_col.size());
                 if (ks) out.csr_ks.push_back((float)ks[r]);
             }
-            out.csr_rows = rcsr;
+            out.csr_rows.assign(rcsr.begin(), rcsr.end());
             out.stream_rows[PSELL_C] = (int64_t)rcsr.size();
             out.stream_nnz[PSELL_C] = (int64_t)out.csr_col.size();
             out.stream_bytes[PSELL_C] = (int64_t)(8 * out.csr_col.size() + 4 * (rcsr.size() + 1));
@@ -572,17 +572,17 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     static const int a2cap = getenv("POLEE_TILE_A2") ? atoi(getenv("POLEE_TILE_A2")) : PSELL_TILE_SLICES_A2;
     static const int a2mcap = getenv("POLEE_TILE_A2M") ? std::min(atoi(getenv("POLEE_TILE_A2M")), 126) : PSELL_TILE_SLICES_A2M;
     const unsigned nthreads = host_threads();
-    std::vector<std::vector<uint32_t>> stamps(nthreads);
-    std::vector<std::vector<uint16_t>> locals(nthreads);
-    std::vector<uint32_t> next_tile_id(nthreads, 1);
+    std::vector<BVec<uint32_t>> stamps(nthreads);
+    std::vector<BVec<uint16_t>> locals(nthreads);
+    BVec<uint32_t> next_tile_id(nthreads, 1);
     auto emit_segment = [&](Segment &sg, unsigned th) {
     PsellHost &out = sg.frag;  // (shadows the result: a segment fills its own fragment)
     if (stamps[th].empty()) {
         stamps[th].assign((size_t)n, 0);
         locals[th].assign((size_t)n, 0);
     }
-    std::vector<uint32_t> &col_stamp = stamps[th];   // tile id in which the column was last registered
-    std::vector<uint16_t> &col_local = locals[th];
+    BVec<uint32_t> &col_stamp = stamps[th];   // tile id in which the column was last registered
+    BVec<uint16_t> &col_local = locals[th];
     const int cur_stream = sg.stream;
     out.data.reserve((size_t)((double)(rowptr[m] / std::max<size_t>(rows.size(), 1)) * 6.6 * (double)(sg.rb - sg.ra)) + 4096);
     out.slice_off.push_back(0);
@@ -594,10 +594,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     uint32_t &tile_id = next_tile_id[th];  // stamp of the current tile (unique per thread)
     uint32_t tile_cols = 0;      // dictionary size of the current tile
     uint32_t tile_nslices = 0;
-    std::vector<uint32_t> slice_rows;  // original row ids of the slice being formed
+    BVec<uint32_t> slice_rows;  // original row ids of the slice being formed
     slice_rows.reserve(PSELL_LANES);
-    std::vector<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
-    std::vector<uint32_t> pattern;  // transcript set of the slice being closed (uniform streams)
+    BVec<uint32_t> prev_pattern;  // transcript ids of the previous slice if it was uniform
+    BVec<uint32_t> pattern;  // transcript set of the slice being closed (uniform streams)
     bool prev_uniform = false;
     int slice_form = 0;  // the slice being formed: 0 rows of one set, 1 dense union, 2 masked
     uint32_t slice_gid = 0;  // ... forms 1, 2: its group
@@ -827,7 +827,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.slice_w.reserve(tot_slices);
         out.row_order.reserve(tot_slices * 64);
         if (ks) out.slice_ks.reserve(tot_slices * 64);
-        std::vector<size_t> data_base(segs.size());
+        BVec<size_t> data_base(segs.size());
         size_t dbase = 0;
         int last_stream = 0;
         auto stream_ends = [&](int st) {  // stream `st` ends at the current tile / slice count
