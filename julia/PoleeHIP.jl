@@ -307,13 +307,23 @@ set_comm!(f::LikelihoodApproximationFit, c) =
 
 # ---- tree construction: hclust + order_nodes (src/hclust.jl:193-319, 361-389) -----------------------------------
 "X in CSC, 1-based (colptr UInt32 or UInt64), as in the likelihood-matrix HDF5 -> (node_parent_idxs, node_js)"
-function hclust(m::Integer, n::Integer, colptr::Union{Vector{UInt32},Vector{UInt64}}, rowval::Vector{UInt32})
+function hclust(m::Integer, n::Integer, colptr::Union{Vector{UInt32},Vector{UInt64}}, rowval::Vector{UInt32};
+                parallel::Bool=false)
     parents, js = Vector{Int32}(undef, 2n - 1), Vector{Int32}(undef, 2n - 1)
-    GC.@preserve colptr rowval parents js check(
-        ccall((:polee_hclust, LIB), Cint, (Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
-              m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js))
+    if parallel   # rounds of mutually-best merges on all host threads: a variant, not hclust.jl's tree node for node
+        GC.@preserve colptr rowval parents js check(
+            ccall((:polee_hclust_parallel, LIB), Cint, (Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+                  m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js))
+    else
+        GC.@preserve colptr rowval parents js check(
+            ccall((:polee_hclust, LIB), Cint, (Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+                  m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js))
+    end
     return parents, js
 end
+
+"release the scratch blocks the host-side builders keep between samples"
+host_cache_trim() = ccall((:polee_host_cache_trim, LIB), Cvoid, ())
 
 # ---- density of the fitted approximations: replaces create_tensorflow_variables! (src/estimate.jl:502-556) +
 #      RNASeqApproxLikelihoodDist (src/polee_approx_likelihood.py:367-450) -------------------------------------------
