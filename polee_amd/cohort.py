@@ -145,10 +145,12 @@ def _process_init(host_threads):
 def _process_job(args):
     idx, src, treemethod, device, kwargs = args
     from . import core
+    import numpy as np
     lm = src() if callable(src) else src
-    if isinstance(lm, dict):
+    if hasattr(lm, "keys"):  # the dict of h5io.read_likelihood_matrix, or an .npz of the same arrays
         lm = tuple(lm[key] for key in ("m", "n", "colptr", "rowval", "nzval", "effective_lengths"))
     m, n, colptr, rowval, nzval, efflens = lm
+    m, n = int(np.ravel(m)[0]), int(np.ravel(n)[0])
     ctx = core.Context(device)
     sample = core.RNASeqSample(m, n, colptr, rowval, nzval, efflens, ctx=ctx)
     params = core.approximate_likelihood(core.LogitSkewNormalPTTApprox(treemethod), sample, **kwargs)

@@ -962,3 +962,29 @@ def test_cohort_pipeline_matches_sequential_fits(P, lm_fixture):
     as_dicts = [dict(zip(("m", "n", "colptr", "rowval", "nzval", "effective_lengths"), s)) for s in samples[:2]]  # (h5io.read_likelihood_matrix)
     assert P.approximate_likelihood_cohort(approx, as_dicts, workers=2, on_result=lambda i, p: got.__setitem__(i, p), **kw) == [None, None]
     assert sorted(got) == [0, 1] and np.isfinite(got[1]["mu"]).all()
+
+
+def test_cohort_of_worker_processes_matches_sequential_fits(P, lm_fixture, tmp_path):
+    """approximate_likelihood_cohort_processes: one worker PROCESS per sample in flight (`spawn`; each its own HIP context
+    on the one GPU), samples read inside the workers from their files; the parallel tree variant; the same trees and --
+    up to the float32 summation order of the likelihood's atomics -- the same fitted parameters as one-at-a-time calls."""
+    import functools
+    f = lm_fixture
+    rng = np.random.default_rng(12)
+    paths, samples = [], []
+    for i in range(3):
+        nz = (f["nzval"] * rng.uniform(0.5, 1.5, size=f["nzval"].shape)).astype(np.float32)
+        samples.append((f["m"], f["n"], f["colptr"], f["rowval"], nz, f["effective_lengths"]))
+        paths.append(str(tmp_path / ("sample%d.npz" % i)))
+        np.savez(paths[-1], m=np.array([f["m"]]), n=np.array([f["n"]]), colptr=f["colptr"], rowval=f["rowval"], nzval=nz,
+                 effective_lengths=f["effective_lengths"])
+    approx = P.LogitSkewNormalPTTApprox("cluster_parallel")
+    kw = dict(num_steps=30, num_mc_samples=6, seed=5)
+    seq = [P.approximate_likelihood(approx, P.RNASeqSample(*s, ctx=P.Context(0)), **kw) for s in samples]
+    par = P.approximate_likelihood_cohort_processes(approx, [functools.partial(np.load, p) for p in paths], processes=2,
+                                                    host_threads=2, **kw)
+    assert len(par) == 3
+    for a, b in zip(seq, par):
+        assert (a["node_parent_idxs"] == b["node_parent_idxs"]).all() and (a["node_js"] == b["node_js"]).all()
+        for key in ("mu", "omega", "alpha"):
+            np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-3)
