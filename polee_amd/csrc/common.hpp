@@ -135,7 +135,7 @@ inline unsigned host_threads()
     return n;
 }
 
-// Large blocks (>= 8 MiB) come straight from mmap with MADV_HUGEPAGE: the one-off host builders fill gigabytes of fresh
+// Large blocks (>= 1 MiB) come straight from mmap with MADV_HUGEPAGE: the one-off host builders fill gigabytes of fresh
 // memory once, and with 4 KiB pages that is a million page faults in (and a million page frees out) per gigabyte-sized
 // buffer -- measured at BASELINE's C2: the two passes of the CSC -> rows transposition 0.36 -> 0.05 s.
 // Freed blocks are kept (up to POLEE_HOST_CACHE_MB, default 8192) and handed out again: unmapping a 3 GB staging buffer
@@ -158,11 +158,10 @@ struct HugeBlockCache {
         const char *e = getenv("POLEE_HOST_CACHE_MB");
         cap = (size_t)(e ? std::max(0L, atol(e)) : 8192L) << 20;
     }
-    ~HugeBlockCache() { trim(); }
     static HugeBlockCache &get()
     {
-        static HugeBlockCache c;
-        return c;
+        static HugeBlockCache *c = new HugeBlockCache();  // (never destroyed: handles may be released after static destructors ran)
+        return *c;
     }
     void *take(size_t bytes)
     {
@@ -235,7 +234,7 @@ struct huge_allocator : std::allocator<T> {
         using other = huge_allocator<U>;
     };
     using std::allocator<T>::allocator;
-    static constexpr size_t HUGE_MIN = (size_t)8 << 20;
+    static constexpr size_t HUGE_MIN = (size_t)1 << 20;
     T *allocate(size_t n)
     {
         const size_t bytes = n * sizeof(T);
