@@ -124,9 +124,9 @@ def approximate_likelihood_cohort(approx, samples, workers=4, device=0, on_resul
             lm = tuple(lm[key] for key in ("m", "n", "colptr", "rowval", "nzval", "effective_lengths"))
         m, n, colptr, rowval, nzval, efflens = lm
         ctx = core.Context(device)
-        sample = core.RNASeqSample(m, n, colptr, rowval, nzval, efflens, ctx=ctx)
-        params = core.approximate_likelihood(approx, sample, **kwargs)
-        del sample
+        sample, tree = core.sample_and_tree(approx, m, n, colptr, rowval, nzval, efflens, ctx=ctx)  # (side by side)
+        params = core.approximate_likelihood(approx, sample, tree, **kwargs)
+        del sample, tree
         if on_result is not None:
             on_result(idx, params)
             return None
@@ -152,9 +152,10 @@ def _process_job(args):
     m, n, colptr, rowval, nzval, efflens = lm
     m, n = int(np.ravel(m)[0]), int(np.ravel(n)[0])
     ctx = core.Context(device)
-    sample = core.RNASeqSample(m, n, colptr, rowval, nzval, efflens, ctx=ctx)
-    params = core.approximate_likelihood(core.LogitSkewNormalPTTApprox(treemethod), sample, **kwargs)
-    del sample
+    approx = core.LogitSkewNormalPTTApprox(treemethod)
+    sample, tree = core.sample_and_tree(approx, m, n, colptr, rowval, nzval, efflens, ctx=ctx)
+    params = core.approximate_likelihood(approx, sample, tree, **kwargs)
+    del sample, tree
     return idx, params
 
 

@@ -576,6 +576,28 @@ class LikelihoodApproximationFit:
         return out
 
 
+def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=None, ks=None):
+    """The two host-side stages of preparing a sample side by side: the tree heuristic (hclust*) on a helper thread while
+    this thread builds the sample's device layout (RNASeqSample); both are C calls that release the GIL, and neither
+    needs the other.  Returns (sample, PolyaTreeTransform) -- what `approximate_likelihood(approx, sample, t)` takes.
+    (`approximate_likelihood(approx, sample)` alone does the same two stages one after the other.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    ctx = ctx or default_context()
+    tm = approx.treemethod
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = None
+        if tm in ("cluster", "cluster_parallel"):
+            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel")
+        sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx)
+        if fut is not None:
+            parents, js = fut.result()
+        elif tm == "sequential":
+            parents, js = list_nodes(int(n))
+        else:
+            raise ValueError("%r is not a supported Polya tree transform heuristic" % (tm,))
+    return sample, PolyaTreeTransform(parents, js, ctx=ctx)
+
+
 def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, use_efflen_jacobian=True,
                            num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES, gradonly=True,
                            seed=123456789, z0=None, gene_transcripts=None):
