@@ -36,7 +36,7 @@ struct NodeWithSize {
 // DataStructures.jl BinaryHeap: `before(a, b)` = a must be nearer the root than b (strict)
 template <class T, class Before>
 struct BinHeap {
-    std::vector<T> xs;
+    BVec<T> xs;  // (millions of edges visited at random: on huge pages the percolate-down misses the cache, not the TLB too)
     Before before;
     bool empty() const { return xs.empty(); }
     size_t size() const { return xs.size(); }
