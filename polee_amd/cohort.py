@@ -159,7 +159,28 @@ def _process_job(args):
     return idx, params
 
 
-def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_threads=16, device=0, on_result=None,
+def usable_cpus():
+    """CPUs this process may use: the affinity mask, cut to the cgroup's CFS quota when there is one (a container often
+    shows every core of the host and throttles beyond its quota)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_threads=None, device=0, on_result=None,
                                             **kwargs):
     """As `approximate_likelihood_cohort`, with one worker PROCESS per sample in flight instead of a thread.  The host
     stages of a sample (tree construction, device layout build) fill and release gigabytes of memory; threads of one
@@ -167,11 +188,14 @@ def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_t
     prepare hardly more samples per second than one (measured on a 256-core host: 0.65 -> 0.76 samples/s).  Separate
     processes do not meet there; they share the GPU (every process its own HIP context, one fit = 1.2 GB).
     samples: picklable zero-argument callables (e.g. functools.partial(h5io.read_likelihood_matrix, path)) or tuples.
-    host_threads: threads every process gives its builders (POLEE_HOST_THREADS).  The pool is started with `spawn`."""
+    host_threads: threads every process gives its builders (POLEE_HOST_THREADS; default: the usable CPUs -- affinity mask
+    and cgroup quota -- divided by `processes`).  The pool is started with `spawn`."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     samples = list(samples)
     out = [None] * len(samples)
+    if host_threads is None:  # share the usable CPUs out (two host stages run side by side in every process)
+        host_threads = max(2, usable_cpus() // max(1, int(processes)))
     with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mp.get_context("spawn"),
                              initializer=_process_init, initargs=(host_threads,)) as ex:
         jobs = [(i, s, approx.treemethod, device, kwargs) for i, s in enumerate(samples)]

@@ -125,11 +125,37 @@ struct DevBuf {
 };
 
 // host threads for the one-off layout work (bounded: the loops are memory-bound well before 64 threads)
+// CPUs this process may actually use: a container often shows every core of the host but runs under a CFS bandwidth
+// quota (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- threads beyond it only get
+// throttled in bursts.  0 = no quota found.
+inline unsigned cgroup_cpu_quota()
+{
+    long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+        }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(g, "%ld", &period) != 1) period = -1;
+            fclose(g);
+        }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (unsigned)std::max(1L, (quota + period - 1) / period);
+}
 inline unsigned host_threads()
 {
     static const unsigned n = [] {
         unsigned cap = 48;
-        if (const char *e = getenv("POLEE_HOST_THREADS")) cap = (unsigned)std::max(1, atoi(e));
+        if (const char *e = getenv("POLEE_HOST_THREADS"))
+            cap = (unsigned)std::max(1, atoi(e));
+        else if (const unsigned q = cgroup_cpu_quota())
+            cap = std::min(cap, q);
         return std::max(1u, std::min(cap, std::thread::hardware_concurrency()));
     }();
     return n;

@@ -42,8 +42,8 @@ def main():
     print("3 distinct samples ready in %.1f s" % (time.time() - t0), flush=True)
     approx = P.LogitSkewNormalPTTApprox(os.environ.get("POLEE_PREP_TREE", "cluster"))
     procs = bool(os.environ.get("POLEE_PREP_PROCESSES"))
-    ht = int(os.environ.get("POLEE_PREP_HOST_THREADS", "16"))
-    print("tree method:", approx.treemethod, "| workers are", ("processes, %d host threads each" % ht) if procs else "threads",
+    ht = int(os.environ["POLEE_PREP_HOST_THREADS"]) if os.environ.get("POLEE_PREP_HOST_THREADS") else None
+    print("tree method:", approx.treemethod, "| workers are", ("processes, %s host threads each" % (ht or "usable CPUs / processes")) if procs else "threads",
           flush=True)
     loaders = [functools.partial(load_one, i) for i in range(jobs)]
     for w in workers_list:
