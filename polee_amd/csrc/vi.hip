@@ -277,6 +277,8 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         a.eps = o.adam_eps;
         a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
         a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
+        a.inv_m_denom = 1.0 / a.m_denom;
+        a.inv_v_denom = 1.0 / a.v_denom;
         a.max_mu = o.max_mu_step;
         a.max_omega = o.max_omega_step;
         a.max_alpha = o.max_alpha_step;
@@ -842,6 +844,8 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         a.eps = o.adam_eps;
         a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
         a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
+        a.inv_m_denom = 1.0 / a.m_denom;
+        a.inv_v_denom = 1.0 / a.v_denom;
         a.max_mu = 1e-1;  // ss_max_z_step (likelihood-approximation.jl:166)
         a.max_omega = a.max_alpha = 0.0;
         a.first = step_num == 1;
