@@ -1,5 +1,5 @@
 """Exact (reference-order) tree against the parallel-rounds tree: construction time and the fit each gives.
-usage: hclust_quality.py [fixture] [small] [c1] [c2]   (ELBO / E[lp]: mean over the last 100 of 500 steps, 3 seeds)"""
+usage: hclust_quality.py [fixture] [small] [c1] [c2] [tiled]   (ELBO / E[lp]: mean over the last 100 of 500 steps, 3 seeds)"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, ROOT)
@@ -11,6 +11,10 @@ def load(which):
     if which == "fixture":
         a = np.load(os.path.join(ROOT, "tests", "golden", "mBr_M_6w_1.likelihood-matrix.npz"))
         return int(a["m"][0]), int(a["n"][0]), a["colptr"], a["rowval"], a["nzval"], a["effective_lengths"]
+    if which == "tiled":  # the reference fixture x639: 639 disconnected blocks with the real set structure
+        smp = synth.tile_fixture(639)
+        colptr, rowval, nzval = synth.to_csc(smp)
+        return int(smp["m"]), int(smp["n"]), colptr, rowval, nzval, smp["effective_lengths"]
     n, m = {"small": (20000, 3000000), "c1": (2000, 300000), "c2": (200000, 30000000)}[which]
     smp = synth.make_sample(n, m, 8.0, 123456789)
     colptr, rowval, nzval = synth.to_csc(smp)
