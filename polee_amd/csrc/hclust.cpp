@@ -88,13 +88,27 @@ struct SizeBefore {
 };
 
 typedef std::vector<uint32_t, default_init_allocator<uint32_t>> ReadSet;  // (resize does not zero-fill)
+// a read set that lives somewhere else (a column of X, a slice of a round's arena): the parallel variant's sets
+struct SetRef {
+    const uint32_t *p = nullptr;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    uint32_t front() const { return p[0]; }
+    uint32_t back() const { return p[n - 1]; }
+    const uint32_t *begin() const { return p; }
+    const uint32_t *end() const { return p + n; }
+    const uint32_t *data() const { return p; }
+    uint32_t operator[](size_t i) const { return p[i]; }
+};
 
 // hclust.jl:116-135
-size_t intersection_size(const ReadSet &a, const ReadSet &b)
+template <class Set>
+size_t intersection_size(const Set &a, const Set &b)
 {
     if (a.empty() || b.empty() || a.front() > b.back() || a.back() < b.front()) return 0;
     // one set much smaller than the other: look its elements up (galloping) instead of walking both
-    const ReadSet &sm = a.size() <= b.size() ? a : b, &lg = a.size() <= b.size() ? b : a;
+    const Set &sm = a.size() <= b.size() ? a : b, &lg = a.size() <= b.size() ? b : a;
     if (sm.size() * 24 < lg.size()) {
         size_t c = 0;
         auto from = lg.begin();
@@ -120,14 +134,16 @@ size_t intersection_size(const ReadSet &a, const ReadSet &b)
     return c;
 }
 // hclust.jl:143-152 (Float64 quotient, stored as Float32 in the edge)
-double relative_intersection(const ReadSet &a, const ReadSet &b)
+template <class Set>
+double relative_intersection(const Set &a, const Set &b)
 {
     if (a.empty() && b.empty()) return 0.0;
     const size_t is = intersection_size(a, b);
     return (double)is / (double)(a.size() + b.size() - is);
 }
 // the same quotient with the reads of the other set (ks_size of them) marked in `bits`
-inline double bitmap_similarity(const ReadSet &a, size_t ks_size, const std::vector<uint64_t> &bits)
+template <class Set>
+inline double bitmap_similarity(const Set &a, size_t ks_size, const std::vector<uint64_t> &bits)
 {
     if (a.empty()) return 0.0;
     size_t is = 0;
@@ -148,10 +164,11 @@ struct RangeCut {
     std::vector<size_t> pa, pb;  // part p covers a[pa[p] .. pa[p+1]) and b[pb[p] .. pb[p+1])
     size_t parts() const { return pa.size() - 1; }
 };
-RangeCut cut_ranges(const ReadSet &a, const ReadSet &b, size_t parts)
+template <class Set>
+RangeCut cut_ranges(const Set &a, const Set &b, size_t parts)
 {
     RangeCut c;
-    const ReadSet &big = a.size() >= b.size() ? a : b;
+    const Set &big = a.size() >= b.size() ? a : b;
     c.pa.push_back(0);
     c.pb.push_back(0);
     for (size_t p = 1; p < parts; ++p) {
@@ -175,7 +192,8 @@ inline size_t intersection_size_range(const uint32_t *a, const uint32_t *ae, con
     return c;
 }
 // |a n b| on all host threads (the counts are integers: the same number whatever the cut)
-size_t intersection_size_parallel(const ReadSet &a, const ReadSet &b, size_t grain = (size_t)1 << 20)
+template <class Set>
+size_t intersection_size_parallel(const Set &a, const Set &b, size_t grain = (size_t)1 << 20)
 {
     if (a.empty() || b.empty() || a.front() > b.back() || a.back() < b.front()) return 0;
     const size_t parts = std::min<size_t>(4 * host_threads(), (a.size() + b.size()) / grain + 1);
@@ -190,11 +208,39 @@ size_t intersection_size_parallel(const ReadSet &a, const ReadSet &b, size_t gra
     for (size_t v : cnt) t += v;
     return t;
 }
-// a u b on all host threads: count per range, then every range merges into its place
-ReadSet merge_sets_parallel(const ReadSet &a, const ReadSet &b, size_t grain = (size_t)1 << 20)
+// [a, ae) u [b, be) into `out` (room for both); returns the size of the union.  The loop body has no data-dependent
+// branch (std::set_union's three-way branch mispredicts on every other element of interleaved sets).
+inline size_t union_range(const uint32_t *a, const uint32_t *ae, const uint32_t *b, const uint32_t *be, uint32_t *out)
+{
+    uint32_t *o = out;
+    while (a < ae && b < be) {
+        const uint32_t x = *a, y = *b;
+        *o++ = x < y ? x : y;
+        a += x <= y;
+        b += y <= x;
+    }
+    if (a < ae) {
+        std::memcpy(o, a, (size_t)(ae - a) * sizeof(uint32_t));
+        o += ae - a;
+    }
+    if (b < be) {
+        std::memcpy(o, b, (size_t)(be - b) * sizeof(uint32_t));
+        o += be - b;
+    }
+    return (size_t)(o - out);
+}
+// a u b into `out` (room for |a| + |b|); returns |a u b|
+template <class Set>
+size_t merge_into(const Set &a, const Set &b, uint32_t *out)
+{
+    return union_range(a.data(), a.data() + a.size(), b.data(), b.data() + b.size(), out);
+}
+// the same on all host threads: count per range, then every range merges into its place
+template <class Set>
+size_t merge_into_parallel(const Set &a, const Set &b, uint32_t *out, size_t grain = (size_t)1 << 20)
 {
     const size_t parts = std::min<size_t>(4 * host_threads(), (a.size() + b.size()) / grain + 1);
-    if (parts <= 1 || a.empty() || b.empty()) return merge_sets(a, b);
+    if (parts <= 1 || a.empty() || b.empty()) return merge_into(a, b, out);
     const RangeCut c = cut_ranges(a, b, parts);
     std::vector<size_t> off(parts + 1, 0);
     parallel_chunks(parts, 1, [&](size_t lo, size_t hi, unsigned) {
@@ -203,13 +249,11 @@ ReadSet merge_sets_parallel(const ReadSet &a, const ReadSet &b, size_t grain = (
                          intersection_size_range(a.data() + c.pa[p], a.data() + c.pa[p + 1], b.data() + c.pb[p], b.data() + c.pb[p + 1]);
     });
     for (size_t p = 0; p < parts; ++p) off[p + 1] += off[p];
-    ReadSet out(off[parts]);
     parallel_chunks(parts, 1, [&](size_t lo, size_t hi, unsigned) {
         for (size_t p = lo; p < hi; ++p)
-            std::set_union(a.begin() + c.pa[p], a.begin() + c.pa[p + 1], b.begin() + c.pb[p], b.begin() + c.pb[p + 1],
-                           out.begin() + off[p]);
+            (void)union_range(a.data() + c.pa[p], a.data() + c.pa[p + 1], b.data() + c.pb[p], b.data() + c.pb[p + 1], out + off[p]);
     });
-    return out;
+    return off[parts];
 }
 
 struct TreeNode {
@@ -217,11 +261,10 @@ struct TreeNode {
     int32_t left = -1, right = -1;
 };
 
-// What both variants start from: the leaves in the order of their median compatible read (:204-222) as nodes 1..n with
-// their read sets, and the similarities of every leaf to its K successors (:225-236), sims[(j1 - 1) K + (j2 - j1 - 1)].
+// What both variants start from: the leaves in the order of their median compatible read (:204-222), idxs[j - 1] = the
+// transcript (0-based) of node j; the columns of X are validated on the way.
 template <class ColPtr>
-std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, int K, std::vector<TreeNode> &nodes,
-                       std::vector<ReadSet> &read_sets, std::vector<float> &sims)
+std::string leaf_order(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, std::vector<uint32_t> &idxs)
 {
     // order transcripts by the median compatible read (:204-212); sortperm is stable
     std::vector<uint32_t> med((size_t)n);
@@ -232,31 +275,26 @@ std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, 
         else
             med[(size_t)j] = rowval[(cp(j) + cp(j + 1)) / 2 - 1];  // 1-based position div(a + b, 2)
     }
-    std::vector<uint32_t> idxs((size_t)n);
+    idxs.resize((size_t)n);
     for (int64_t j = 0; j < n; ++j) idxs[(size_t)j] = (uint32_t)j;
     std::stable_sort(idxs.begin(), idxs.end(), [&](uint32_t a, uint32_t b) { return med[a] < med[b]; });
-
-    // nodes 1..n are the leaves in that order; internal nodes are appended (:215-222)
-    nodes.assign((size_t)n + 1, TreeNode());  // [0] unused: ids are 1-based like the reference's keys
-    read_sets.assign((size_t)n + 1, ReadSet());
-    nodes.reserve(2 * (size_t)n);
-    read_sets.reserve(2 * (size_t)n);
-    {
-        std::atomic<int> bad{0};
-        parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
-            for (size_t q = lo; q < hi; ++q) {
-                const size_t j = q + 1;
-                const uint32_t t = idxs[q];
-                nodes[j].j = t + 1;
-                read_sets[j].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
-                for (size_t e = 1; e < read_sets[j].size(); ++e)
-                    if (read_sets[j][e] <= read_sets[j][e - 1]) bad = 1;
-                if (!read_sets[j].empty() && (read_sets[j].front() < 1 || (int64_t)read_sets[j].back() > m)) bad = 2;
-            }
-        });
-        if (bad == 1) return "row indexes of a column are not ascending";
-        if (bad == 2) return "row index out of range";
-    }
+    std::atomic<int> bad{0};
+    parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t t = lo; t < hi; ++t) {
+            const uint32_t *b = rowval + (cp((int64_t)t) - 1), *e = rowval + (cp((int64_t)t + 1) - 1);
+            for (const uint32_t *q = b + 1; q < e; ++q)
+                if (*q <= q[-1]) bad = 1;
+            if (b < e && (*b < 1 || (int64_t)e[-1] > m)) bad = 2;
+        }
+    });
+    if (bad == 1) return "row indexes of a column are not ascending";
+    if (bad == 2) return "row index out of range";
+    return "";
+}
+// the similarities of every leaf to its K successors (:225-236), sims[(j1 - 1) K + (j2 - j1 - 1)]; set(j) = node j's reads
+template <class GetSet>
+void leaf_similarities(int64_t m, int64_t n, int K, GetSet set, std::vector<float> &sims)
+{
     // (the n x K similarities are independent: computed by a few threads; a leaf's reads are marked in the thread's bitmap
     // once, each of its K successors is then |successor| look-ups instead of a branchy walk over both sets -- the counts,
     // hence the similarities, are the same)
@@ -266,11 +304,11 @@ std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, 
         std::vector<uint64_t> &bits = bitmaps[th];
         if (bits.empty()) bits.assign(((size_t)m >> 6) + 2, 0);
         for (int64_t j1 = (int64_t)lo + 1; j1 <= (int64_t)hi; ++j1) {
-            const ReadSet &a = read_sets[(size_t)j1];
+            const auto &a = set((size_t)j1);
             if (a.empty()) continue;
             bool marked = false;
             for (int64_t j2 = j1 + 1; j2 <= std::min<int64_t>(j1 + K, n); ++j2) {
-                const ReadSet &b = read_sets[(size_t)j2];
+                const auto &b = set((size_t)j2);
                 if (b.empty() || a.front() > b.back() || a.back() < b.front()) continue;
                 if (!marked) {
                     for (uint32_t v : a) bits[v >> 6] |= 1ull << (v & 63u);
@@ -282,6 +320,27 @@ std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, 
                 for (uint32_t v : a) bits[v >> 6] = 0;
         }
     });
+}
+// the exact mode's leaves: nodes 1..n with their own copies of the read sets (:215-222)
+template <class ColPtr>
+std::string leaf_setup(int64_t m, int64_t n, ColPtr cp, const uint32_t *rowval, int K, std::vector<TreeNode> &nodes,
+                       std::vector<ReadSet> &read_sets, std::vector<float> &sims)
+{
+    std::vector<uint32_t> idxs;
+    const std::string err = leaf_order(m, n, cp, rowval, idxs);
+    if (!err.empty()) return err;
+    nodes.assign((size_t)n + 1, TreeNode());  // [0] unused: ids are 1-based like the reference's keys
+    read_sets.assign((size_t)n + 1, ReadSet());
+    nodes.reserve(2 * (size_t)n);
+    read_sets.reserve(2 * (size_t)n);
+    parallel_chunks((size_t)n, 4096, [&](size_t lo, size_t hi, unsigned) {
+        for (size_t q = lo; q < hi; ++q) {
+            const uint32_t t = idxs[q];
+            nodes[q + 1].j = t + 1;
+            read_sets[q + 1].assign(rowval + (cp(t) - 1), rowval + (cp(t + 1) - 1));
+        }
+    });
+    leaf_similarities(m, n, K, [&](size_t j) -> const ReadSet & { return read_sets[j]; }, sims);
     return "";
 }
 
@@ -561,17 +620,28 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
         if (timing) fprintf(stderr, "[hclust/rounds] %-24s %.3f s\n", what, now() - t_prev);
         t_prev = now();
     };
-    std::vector<TreeNode> nodes;
-    std::vector<ReadSet> read_sets;
+    // Read sets are views: a leaf's is its column of X where it lies; a merged node's is a slice of its round's arena (one
+    // block per round, room for |a| + |b| per merge, from the block cache: no allocation per merge, and the next round --
+    // and the next sample -- write into memory that is already resident).  An arena goes back when its last set retires.
+    const size_t cap = 2 * (size_t)n + 1;
+    std::vector<TreeNode> nodes(cap);
+    std::vector<SetRef> read_sets(cap);
+    std::vector<int32_t> arena_of(cap, -1);
+    std::vector<RawVec<uint32_t>> arenas;
+    std::vector<int> arena_live;
     std::vector<float> sims;
     {
-        const std::string err = leaf_setup(m, n, cp, rowval, K, nodes, read_sets, sims);
+        std::vector<uint32_t> idxs;
+        const std::string err = leaf_order(m, n, cp, rowval, idxs);
         if (!err.empty()) return err;
+        for (int64_t q = 0; q < n; ++q) {
+            const uint32_t t = idxs[(size_t)q];
+            nodes[(size_t)q + 1].j = t + 1;
+            read_sets[(size_t)q + 1] = SetRef{rowval + (cp(t) - 1), (size_t)(cp(t + 1) - cp(t))};
+        }
+        leaf_similarities(m, n, K, [&](size_t j) -> const SetRef & { return read_sets[j]; }, sims);
     }
-    lap("read sets + similarities");
-    const size_t cap = 2 * (size_t)n + 1;
-    nodes.resize(cap);
-    read_sets.resize(cap);
+    lap("leaves + similarities");
     std::vector<std::vector<Nbr>> adj(cap);
     std::vector<char> alive(cap, 0);
     std::vector<uint32_t> best(cap, 0), into(cap, 0), stamp(cap, 0);
@@ -601,7 +671,7 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
     std::vector<size_t> task_ptr;
     std::vector<uint32_t> next_dirty;
     std::vector<float> tsim;
-    std::vector<ReadSet> heavy_sets;
+    std::vector<size_t> slot;  // a merge's place in the round's arena
     // a merge is "heavy" when its sets are large AND its work exceeds a thread's fair share of the round: then it is cut
     // into value ranges over all threads instead of being one task (POLEE_HCLUST_HEAVY: the size threshold, for tests)
     const size_t HEAVY = getenv("POLEE_HCLUST_HEAVY") ? (size_t)atol(getenv("POLEE_HCLUST_HEAVY")) : (size_t)1 << 22;
@@ -653,29 +723,38 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
             nodes[pr.k] = TreeNode{0, (int32_t)pr.pri.lo, (int32_t)pr.pri.hi};
         }
         if (timing) t_best += now() - t0, t0 = now();
-        // C1: unions and candidate lists (independent per merge)
+        // C1: unions (into this round's arena) and candidate lists (independent per merge)
         cands.resize(pairs.size());
+        slot.assign(pairs.size() + 1, 0);
+        for (size_t q = 0; q < pairs.size(); ++q)
+            slot[q + 1] = slot[q] + read_sets[pairs[q].pri.lo].size() + read_sets[pairs[q].pri.hi].size();
+        const size_t round_work = slot.back();
+        const int32_t arena_id = (int32_t)arenas.size();
+        arenas.emplace_back();
+        arenas.back().resize(round_work);
+        arena_live.push_back((int)pairs.size());
+        uint32_t *const arena = arenas.back().data();
+        // a set retires: its arena goes back to the block cache with its last set (called from the parallel loop below:
+        // only the thread that brings the count to zero touches the arena)
+        auto retire = [&](uint32_t x) {
+            const int32_t id = arena_of[x];
+            read_sets[x] = SetRef{};
+            if (id >= 0 && __atomic_sub_fetch(&arena_live[(size_t)id], 1, __ATOMIC_ACQ_REL) == 0) RawVec<uint32_t>().swap(arenas[(size_t)id]);
+        };
         // (the few merges of millions of reads first, one at a time on all threads; the rest one merge per task)
-        heavy_sets.clear();
-        heavy_sets.resize(pairs.size());
-        size_t round_work = 0;
-        for (const Pair &pr : pairs) round_work += read_sets[pr.pri.lo].size() + read_sets[pr.pri.hi].size();
         is_heavy.assign(pairs.size(), 0);
         for (size_t q = 0; q < pairs.size(); ++q) {
-            const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi;
-            const size_t w = read_sets[a].size() + read_sets[b].size();
+            const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
+            const size_t w = slot[q + 1] - slot[q];
             if (w < HEAVY || w * host_threads() < round_work) continue;
             is_heavy[q] = 1;
-            heavy_sets[q] = merge_sets_parallel(read_sets[a], read_sets[b], grain);
-            set_size[pairs[q].k] = 1;  // (marks the pair for the loop below)
-            ReadSet().swap(read_sets[a]);
-            ReadSet().swap(read_sets[b]);
+            read_sets[k] = SetRef{arena + slot[q], merge_into_parallel(read_sets[a], read_sets[b], arena + slot[q], grain)};
         }
         parallel_chunks(pairs.size(), 8, [&](size_t lo, size_t hi, unsigned) {
             for (size_t q = lo; q < hi; ++q) {
                 const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
-                read_sets[k] = merge_sets(read_sets[a], read_sets[b]);  // (a heavy pair's halves are empty by now)
-                if (read_sets[k].empty() && set_size[k]) read_sets[k].swap(heavy_sets[q]);
+                if (!is_heavy[q]) read_sets[k] = SetRef{arena + slot[q], merge_into(read_sets[a], read_sets[b], arena + slot[q])};
+                arena_of[k] = arena_id;
                 set_size[k] = (uint32_t)read_sets[k].size();
                 std::vector<uint32_t> &c = cands[q];
                 c.clear();
@@ -687,9 +766,9 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
                 std::sort(c.begin(), c.end());
                 c.erase(std::unique(c.begin(), c.end()), c.end());
                 // the halves retire here, on this thread: nobody else reads their sets or lists (other merges see them
-                // through `into` only), and releasing 400 k vectors one after the other was a third of the sequential part
-                ReadSet().swap(read_sets[a]);
-                ReadSet().swap(read_sets[b]);
+                // through `into` only)
+                retire(a);
+                retire(b);
                 std::vector<Nbr>().swap(adj[a]);
                 std::vector<Nbr>().swap(adj[b]);
             }
@@ -704,13 +783,13 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
         const size_t ntasks = task_ptr.back();
         n_eval += ntasks;
         tsim.resize(ntasks);
-        auto range_hit = [&](const ReadSet &a, const ReadSet &ks) {
+        auto range_hit = [&](const SetRef &a, const SetRef &ks) {
             return !a.empty() && !ks.empty() && a.front() <= ks.back() && a.back() >= ks.front();
         };
         parallel_chunks(pairs.size(), 4, [&](size_t lo, size_t hi, unsigned th) {
             std::vector<uint64_t> &bits = bitmaps[th];
             for (size_t q = lo; q < hi; ++q) {
-                const ReadSet &ks = read_sets[pairs[q].k];
+                const SetRef &ks = read_sets[pairs[q].k];
                 const size_t nc = cands[q].size();
                 if (is_heavy[q]) continue;  // (below)
                 const bool use_bits = nc >= 3;
@@ -719,7 +798,7 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
                     for (uint32_t v : ks) bits[v >> 6] |= 1ull << (v & 63u);
                 }
                 for (size_t c = 0; c < nc; ++c) {
-                    const ReadSet &a = read_sets[cands[q][c]];
+                    const SetRef &a = read_sets[cands[q][c]];
                     tsim[task_ptr[q] + c] = !range_hit(a, ks) ? 0.0f
                                             : (float)(use_bits ? bitmap_similarity(a, ks.size(), bits) : relative_intersection(a, ks));
                 }
@@ -728,11 +807,11 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
             }
         });
         for (size_t q = 0; q < pairs.size(); ++q) {
-            const ReadSet &ks = read_sets[pairs[q].k];
+            const SetRef &ks = read_sets[pairs[q].k];
             const size_t nc = cands[q].size();
             if (!is_heavy[q]) continue;
             for (size_t c = 0; c < nc; ++c) {  // every evaluation on all threads, cut into value ranges
-                const ReadSet &a = read_sets[cands[q][c]];
+                const SetRef &a = read_sets[cands[q][c]];
                 const size_t is = intersection_size_parallel(a, ks, grain);
                 tsim[task_ptr[q] + c] = a.empty() ? 0.0f : (float)((double)is / (double)(a.size() + ks.size() - is));
             }
