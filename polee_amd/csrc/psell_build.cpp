@@ -91,6 +91,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (timing) fprintf(stderr, "[psell build] %-28s %.3f s\n", what, now() - t_prev);
         t_prev = now();
     };
+    double t_sub = now();
+    auto sublap = [&](const char *what) {  // (finer marks inside a phase; the phase's own line still covers all of it)
+        if (timing) fprintf(stderr, "[psell build]   . %-24s %.3f s\n", what, now() - t_sub);
+        t_sub = now();
+    };
     // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards)
     BVec<uint64_t> keys((size_t)m);
     BVec<uint32_t> rows((size_t)m);
@@ -142,6 +147,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     lap("keys");
     radix_sort_pairs(keys, rows);
     lap("radix sort");
+    t_sub = now();
     keys.clear();
     keys.shrink_to_fit();
 
@@ -167,6 +173,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         parallel_chunks(rows.size(), (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
             for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
         });
+        sublap("run heads");
         struct RowList {
             BVec<uint32_t> rows, ends;
             BVec<uint8_t> form;
@@ -236,6 +243,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             S1.gid.assign(S1.rows.size(), 0);
             S2.gid.assign(S2.rows.size(), 0);
         }
+        sublap("exact runs -> streams");
         // Packing of the leftover rows.  Rows are visited in the order of their first transcript (then length, then set:
         // equal sets stay neighbours); a row joins the open group while the union stays within the pass's width and the
         // group has fewer than 64 rows, a misfit is deferred once.  Two passes: unions of <= 16 over the rows of <= 16
@@ -411,6 +419,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
             rb.swap(keep_b);
         }
+        sublap("packing of leftover rows");
         // the mixed streams -- BN: rows of <= 16 transcripts, B: the others -- each in the order of the rows' first
         // transcripts (small tile dictionaries), and inside every block of 1024 rows -- a tile's worth -- by descending
         // length (little padding inside a slice)
@@ -446,6 +455,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // (Only when that concerns a real share of the matrix -- more than `csr_min_share` (a tenth) of its non-zeros: a handful of
         // fragments without company stay in stream BN, inside the persistent launch, rather than cost every pass a launch
         // of their own.)
+        sublap("mixed streams");
         static const bool no_csr = getenv("POLEE_PSELL_NO_CSR") != nullptr;
         static const double csr_min_share = getenv("POLEE_PSELL_CSR_MIN_SHARE") ? atof(getenv("POLEE_PSELL_CSR_MIN_SHARE")) : 0.10;
         BVec<uint32_t> rcsr;
@@ -537,6 +547,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         row_gid.insert(row_gid.end(), S2M.gid.begin(), S2M.gid.end());
     }
 
+    sublap("CSR last resort + totals");
     lap("runs / stream split");
     // 2. greedy slices and tiles.  The three streams are cut into SEGMENTS of about a million rows (at slice
     // boundaries; every segment starts a fresh tile) which are laid out independently, on several host threads, and
