@@ -988,3 +988,26 @@ def test_cohort_of_worker_processes_matches_sequential_fits(P, lm_fixture, tmp_p
         assert (a["node_parent_idxs"] == b["node_parent_idxs"]).all() and (a["node_js"] == b["node_js"]).all()
         for key in ("mu", "omega", "alpha"):
             np.testing.assert_allclose(b[key], a[key], rtol=0, atol=2e-3)
+
+
+def test_sample_and_tree_side_by_side_equals_one_after_the_other(P, ctx, lm_fixture):
+    """core.sample_and_tree builds the tree on a helper thread while the device layout is built: the same tree arrays as
+    hclust() alone (both modes) and a sample handle that evaluates like one built on its own."""
+    f = lm_fixture
+    args = (f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], f["effective_lengths"])
+    x = np.random.default_rng(3).dirichlet(np.ones(f["n"])).astype(np.float32)
+    ref = P.RNASeqSample(*args, ctx=ctx)
+    lp0, g0 = ref.log_likelihood(x)
+    for method, par in (("cluster", False), ("cluster_parallel", True)):
+        s, t = P.sample_and_tree(P.LogitSkewNormalPTTApprox(method), *args, ctx=ctx)
+        pe, je = P.hclust(f["m"], f["n"], f["colptr"], f["rowval"], parallel=par)
+        params = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(method), s, t, num_steps=5, seed=1)
+        np.testing.assert_array_equal(params["node_parent_idxs"], pe)
+        np.testing.assert_array_equal(params["node_js"], je)
+        lp, g = s.log_likelihood(x)
+        np.testing.assert_allclose(lp, lp0, rtol=1e-6)
+        np.testing.assert_allclose(g, g0, rtol=1e-4, atol=1e-3 * np.abs(g0).max())
+    s, t = P.sample_and_tree(P.LogitSkewNormalPTTApprox("sequential"), *args, ctx=ctx)
+    assert len(P.approximate_likelihood(P.LogitSkewNormalPTTApprox("sequential"), s, t, num_steps=2)["mu"]) == f["n"] - 1
+    with pytest.raises(ValueError):
+        P.sample_and_tree(P.LogitSkewNormalPTTApprox("random"), *args, ctx=ctx)

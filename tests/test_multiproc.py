@@ -226,3 +226,10 @@ def test_bench_gpus_2_launches_two_ranks():
     d = json.loads(last)
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
     assert abs(d["slowest_rank_s"] - 0.002) < 1e-12  # the max over ranks, not rank 0's own time
+
+
+def test_usable_cpus_is_positive_and_within_the_affinity_mask():
+    import os
+    from polee_amd.cohort import usable_cpus
+    n = usable_cpus()
+    assert 1 <= n <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
