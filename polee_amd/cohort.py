@@ -99,14 +99,16 @@ def shard_regression_inputs(vars, x_init, F_arr, sample_scales, world_size, rank
                 x_init_mean=x_init.astype(np.float64).mean(axis=0).astype(np.float32))
 
 
-def approximate_likelihood_cohort(approx, samples, workers=4, device=0, on_result=None, **kwargs):
+def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_result=None, **kwargs):
     """`approximate_likelihood` (likelihood-approximation.jl:395-624) for the samples of a cohort, `workers` of them in
     flight on ONE GPU.  Per sample the reference's `prep-sample` (main.jl:560-660) builds the tree from X on the CPU
     (hclust.jl), then fits; here a fit occupies the GPU for a fraction of a second while the host side of the same sample
     -- tree construction, device layout build -- takes seconds, so the samples are pipelined: every worker thread takes
     one sample through all stages on its own `Context` (= HIP stream); the C library releases the GIL, the host stages of
     some samples run under the device stage of others, and two fits that meet on the device share it (one's sparse pass
-    under the other's tree kernels, like `bench.py --samples-per-gpu`).
+    under the other's tree kernels, like `bench.py --samples-per-gpu`).  Two workers are the measured optimum (threads of
+    one process share the address space the builders fill and release; more samples in flight: worker PROCESSES,
+    `approximate_likelihood_cohort_processes`).
 
     samples: iterable of zero-argument callables, each returning `(m, n, colptr, rowval, nzval, effective_lengths)`
              or the dict of `h5io.read_likelihood_matrix` (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
