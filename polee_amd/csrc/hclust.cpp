@@ -670,6 +670,9 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
     std::vector<std::vector<uint32_t>> cands;  // per pair: the distinct live neighbours of both halves (new ids applied)
     std::vector<size_t> task_ptr;
     std::vector<uint32_t> next_dirty;
+    std::vector<std::vector<uint32_t>> dirty_parts(host_threads());
+    std::vector<std::atomic_flag> locks(4096);
+    for (auto &f : locks) f.clear();
     std::vector<float> tsim;
     std::vector<size_t> slot;  // a merge's place in the round's arena
     // a merge is "heavy" when its sets are large AND its work exceeds a thread's fair share of the round: then it is cut
@@ -817,25 +820,39 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
             }
         }
         if (timing) t_eval += now() - t0, t0 = now();
-        // D: the new nodes' lists, their entries in the old neighbours' lists, the halves retire
-        next_dirty.clear();
-        for (size_t q = 0; q < pairs.size(); ++q) {
-            const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
-            std::vector<Nbr> &L = adj[k];
-            L.reserve(task_ptr[q + 1] - task_ptr[q]);
-            for (size_t t = task_ptr[q]; t < task_ptr[q + 1]; ++t) {
-                const uint32_t l = cands[q][t - task_ptr[q]];
-                if (!(tsim[t] > 0)) continue;
-                L.push_back(Nbr{l, tsim[t]});
-                if (l < base) {  // an old node: it learns about k (a new one lists k itself)
-                    adj[l].push_back(Nbr{k, tsim[t]});
-                    if (stamp[l] != (uint32_t)rounds) stamp[l] = (uint32_t)rounds, next_dirty.push_back(l);
+        // D: the new nodes' lists, their entries in the old neighbours' lists, the halves retire.  In parallel over the
+        // merges: an old neighbour's list (and its dirty stamp) is taken under one of 4096 striped spin locks.  The order
+        // of a list's entries then depends on timing, but nothing reads a list by position: the best edge is a maximum
+        // over a total order, candidate lists are sorted, similarities are looked up by neighbour id.
+        for (auto &v : dirty_parts) v.clear();
+        parallel_chunks(pairs.size(), 64, [&](size_t lo, size_t hi, unsigned th) {
+            std::vector<uint32_t> &nd = dirty_parts[th];
+            for (size_t q = lo; q < hi; ++q) {
+                const uint32_t a = pairs[q].pri.lo, b = pairs[q].pri.hi, k = pairs[q].k;
+                std::vector<Nbr> &L = adj[k];
+                L.reserve(task_ptr[q + 1] - task_ptr[q]);
+                for (size_t t = task_ptr[q]; t < task_ptr[q + 1]; ++t) {
+                    const uint32_t l = cands[q][t - task_ptr[q]];
+                    if (!(tsim[t] > 0)) continue;
+                    L.push_back(Nbr{l, tsim[t]});
+                    if (l < base) {  // an old node: it learns about k (a new one lists k itself)
+                        std::atomic_flag &lk = locks[l & 4095u];
+                        while (lk.test_and_set(std::memory_order_acquire)) {
+                        }
+                        adj[l].push_back(Nbr{k, tsim[t]});
+                        const bool first = stamp[l] != (uint32_t)rounds;
+                        stamp[l] = (uint32_t)rounds;
+                        lk.clear(std::memory_order_release);
+                        if (first) nd.push_back(l);
+                    }
                 }
+                alive[a] = alive[b] = 0;
+                alive[k] = 1;
+                if (!L.empty()) nd.push_back(k);
             }
-            alive[a] = alive[b] = 0;
-            alive[k] = 1;
-            if (!L.empty()) next_dirty.push_back(k);
-        }
+        });
+        next_dirty.clear();
+        for (const auto &v : dirty_parts) next_dirty.insert(next_dirty.end(), v.begin(), v.end());
         for (const Pair &pr : pairs) into[pr.pri.lo] = into[pr.pri.hi] = 0;
         // (an old node that was listed but merged in this very round is dead now; step A skips nothing for it: drop it)
         dirty.clear();
