@@ -81,8 +81,12 @@ def launch_ranks(args):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    env.setdefault("POLEE_HOST_THREADS", str(max(4, (os.cpu_count() or 8) // args.gpus)))  # (layout build threads per rank)
+    # host threads per rank: the CPUs this job may USE (affinity mask cut to the cgroup's CFS quota -- the GPU boxes show
+    # 256 cores under a quota of 16) shared out over the ranks; never os.cpu_count()
+    from polee_amd.cohort import usable_cpus
+    per_rank = max(1, usable_cpus() // args.gpus)
+    env.setdefault("OMP_NUM_THREADS", str(per_rank))
+    env.setdefault("POLEE_HOST_THREADS", str(per_rank))  # (layout build threads per rank)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -265,7 +269,7 @@ def main():
         if rank == 0:
             emit({"metric": "approx-lik VI iters/sec", "value": None, "unit": "VI iters/s", "n_gpus": world,
                   "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": seen,
-                  "slowest_rank_s": t})
+                  "slowest_rank_s": t, "host_threads_per_rank": int(os.environ.get("POLEE_HOST_THREADS", "0"))})
         if dist is not None:
             dist.destroy_process_group()
         return

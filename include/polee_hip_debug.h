@@ -55,6 +55,10 @@ typedef struct {
     const uint32_t *csr_col;     /* 0-based transcript ids                                         */
     const float *csr_val;
     const uint32_t *csr_rows;    /* [csr_num_rows] original 0-based fragment of every row          */
+    int64_t single_num_rows;     /* stream S: fragments with ONE compatible transcript, collapsed at build time    */
+    const uint32_t *single_rows; /* [single_num_rows] their original 0-based fragment ids, ascending               */
+    const float *single_cnt;     /* [n] sum of their multiplicities per transcript, or NULL (none)                 */
+    double single_logsum;        /* sum of ks_i log X_ij over them                                                 */
 } polee_psell_view;
 /* Same arguments as polee_loglik_create, minus the context. */
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,

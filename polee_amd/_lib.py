@@ -67,7 +67,8 @@ class PsellView(C.Structure):
                 ("tile_dict", u32p), ("dict", u32p), ("row_order", u32p), ("slice_ks", f32p), ("slice_flags", u8p),
                 ("num_tiles_a", C.c_int64), ("num_tiles_a1", C.c_int64), ("num_tiles_a1m", C.c_int64), ("num_tiles_a2", C.c_int64), ("slice_w", u8p), ("num_tiles_s", C.c_int64),
                 ("stream_rows", C.c_int64 * 8), ("stream_nnz", C.c_int64 * 8), ("stream_bytes", C.c_int64 * 8),
-                ("csr_num_rows", C.c_int64), ("csr_rowptr", u32p), ("csr_col", u32p), ("csr_val", f32p), ("csr_rows", u32p)]
+                ("csr_num_rows", C.c_int64), ("csr_rowptr", u32p), ("csr_col", u32p), ("csr_val", f32p), ("csr_rows", u32p),
+                ("single_num_rows", C.c_int64), ("single_rows", u32p), ("single_cnt", f32p), ("single_logsum", C.c_double)]
 
 
 def lib():

@@ -83,6 +83,10 @@ polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view
     v->csr_col = h.csr_col.data();
     v->csr_val = h.csr_val.data();
     v->csr_rows = h.csr_rows.data();
+    v->single_num_rows = (int64_t)h.single_rows.size();
+    v->single_rows = h.single_rows.data();
+    v->single_cnt = h.single_cnt.empty() ? nullptr : h.single_cnt.data();
+    v->single_logsum = h.single_logsum;
     for (int i = 0; i < PSELL_NSTREAMS; ++i) {
         v->stream_rows[i] = h.stream_rows[i];
         v->stream_nnz[i] = h.stream_nnz[i];

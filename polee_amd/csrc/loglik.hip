@@ -1664,6 +1664,53 @@ __global__ __launch_bounds__(64) void gwin_reduce_heavy_kernel(const uint32_t *_
     }
 }
 
+// Stream S (loglik_internal.hpp): fragments with ONE compatible transcript were collapsed at build time into cnt[j] (the
+// sum of their multiplicities) and a constant; a pass adds cnt_j / x_j[k] to the gradient (the reference's
+// X_ij / (X_ij x_j), sparse.jl:36 after likelihood.jl:41) and cnt_j log x_j[k] (+ the constant sum of log X_ij) to lp.
+// A thread per transcript; lp: per-block partial sums, added in block order by single_lp_finish_kernel (a fixed order:
+// the deterministic mode stays bitwise reproducible).
+constexpr int SINGLE_THREADS = 256;
+__global__ __launch_bounds__(SINGLE_THREADS) void single_rows_kernel(const float *__restrict__ cnt, const float *__restrict__ x,
+                                                                    int K, int64_t n, float *__restrict__ g,
+                                                                    double *__restrict__ part)
+{
+    __shared__ double sm[SINGLE_THREADS / 64][PSELL_MAX_K];
+    const int64_t j = (int64_t)blockIdx.x * SINGLE_THREADS + threadIdx.x;
+    const float c = j < n ? cnt[j] : 0.0f;
+    double ls[PSELL_MAX_K];
+#pragma unroll
+    for (int k = 0; k < PSELL_MAX_K; ++k) ls[k] = 0.0;
+    if (c != 0.0f) {
+        const float *xr = x + (size_t)j * K;
+        float *gr = g + (size_t)j * K;
+#pragma unroll
+        for (int k = 0; k < PSELL_MAX_K; ++k)
+            if (k < K) {
+                const float xv = xr[k];
+                gr[k] += c / xv;
+                if (part) ls[k] = (double)c * log((double)xv);
+            }
+    }
+    if (!part) return;
+#pragma unroll
+    for (int k = 0; k < PSELL_MAX_K; ++k) {
+        double v = ls[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) part[(size_t)blockIdx.x * K + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+__global__ void single_lp_finish_kernel(const double *__restrict__ part, int nblocks, int K, double logsum, double *__restrict__ lp)
+{
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    double s = logsum;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * K + k];
+    lp[k] += s;
+}
+
 // LDS layout of the streaming kernel:
 //   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
@@ -2220,6 +2267,15 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         case 7: st = launch_k<7>(ll, d_x, d_g, d_lp); break;
         default: st = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
+    if (st == POLEE_OK && ll->has_singles) {
+        const int nb = (int)ceil_div(ll->n, SINGLE_THREADS);
+        hipLaunchKernelGGL(single_rows_kernel, dim3((unsigned)nb), dim3(SINGLE_THREADS), 0, ctx->stream, ll->d_single_cnt.p, d_x, K,
+                           ll->n, d_g, d_lp ? ll->d_single_part.p : nullptr);
+        if (d_lp)
+            hipLaunchKernelGGL(single_lp_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ll->d_single_part.p, nb, K,
+                               ll->host.single_logsum, d_lp);
+        POLEE_KERNEL_CHECK(ctx);
+    }
     if (p1) (void)hipEventRecord(p1, ctx->stream);
     return st;
 }
@@ -2329,6 +2385,15 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     }
     ll->csr_rows = (int64_t)h.csr_rows.size();
     ll->csr_nnz = (int64_t)h.csr_col.size();
+    if (!h.single_cnt.empty()) {
+        if ((s = ll->d_single_cnt.upload(ctx, h.single_cnt)) ||
+            (s = ll->d_single_part.alloc(ctx, (size_t)ceil_div(ll->n, SINGLE_THREADS) * PSELL_MAX_K))) {
+            loglik_release(ll);
+            return s;
+        }
+        ll->has_singles = true;
+        std::vector<float>().swap(h.single_cnt);
+    }
     if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "upload", wall_now() - t_begin);
     // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
     // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule

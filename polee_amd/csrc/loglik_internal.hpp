@@ -49,6 +49,12 @@
 //       C     = rows kept in CSR (u32 ids, f32 values, u32 row offsets: 8 B per non-zero + 4 B per row): fragments with no structure at all,
 //              whose mixed tiles would close on the dictionary before a slice is full -- the last resort that keeps
 //              the layout below CSR's size for ANY matrix; loglik_csr_kernel (lane = row, global gathers / atomics).
+//       S     = fragments compatible with ONE transcript (54 % of the rows of the reference's real-data fixture): not stored at
+//              all.  Such a fragment adds log(X_ij) + log(x_j) to the log-likelihood and 1 / x_j to transcript j's
+//              gradient (X_ij cancels: X_ij / (X_ij x_j)), ks_i times with multiplicities -- so the build keeps c_j = the
+//              number of such fragments per transcript (single_cnt) and the constant sum of log X_ij (single_logsum), and
+//              a pass adds c_j / x_j[k] and c_j log x_j[k] + const (single_rows_kernel): 4 B per TRANSCRIPT instead of
+//              8 B + a slice lane per fragment.
 //   * Each slice carries two flag bits (in the top bits of its offset word): "uniform" (its rows
 //     are stored under one transcript set) and "continues" (the same set as the previous slice).  Runs of such
 //     slices -- the bulk of real and synthetic data, where many fragments fall into the same
@@ -73,7 +79,7 @@ constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
 // A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
-enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_C = 6, PSELL_NSTREAMS = 7 };  // streams, in tile order (C has no tiles)
+enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_C = 6, PSELL_S = 7, PSELL_NSTREAMS = 8 };  // streams, in tile order (C and S have no tiles)
 constexpr int PSELL_MIXED_NARROW_MAX = 15;  // longest row of stream BN (its slices pass through the narrow streams' 7 KiB rings)
 constexpr int PSELL_TILE_SLICES_A2M = 16;
 constexpr int PSELL_TILE_SLICES_BN = 64;
@@ -121,6 +127,10 @@ struct PsellHost {
     std::vector<uint32_t> csr_rowptr;
     std::vector<uint32_t> csr_col, csr_rows;  // csr_rows: original row ids
     std::vector<float> csr_val, csr_ks;
+    // stream S: fragments with exactly one compatible transcript, collapsed at build time
+    std::vector<float> single_cnt;  // [n] (empty: none) sum of the multiplicities of transcript j's single-transcript fragments
+    double single_logsum = 0.0;     // sum of ks_i log X_ij over them
+    std::vector<uint32_t> single_rows;  // their original row ids, ascending (debug view / tests)
 };
 
 // Builds the layout from X in CSR form (0-based): rowptr [m+1], col [nnz], val [nnz].
@@ -145,6 +155,9 @@ struct polee_loglik {
     polee::DevBuf<uint32_t> d_csr_col;
     polee::DevBuf<float> d_csr_val, d_csr_ks;
     int64_t csr_rows = 0, csr_nnz = 0;
+    polee::DevBuf<float> d_single_cnt;    // stream S: [n] multiplicity-weighted count of single-transcript fragments
+    polee::DevBuf<double> d_single_part;  // per-block partial sums of c_j log x_j[k] (lp only)
+    bool has_singles = false;
     // the streaming kernel: per-pass x windows, static schedule (built for the grid of the first launch)
     polee::DevBuf<float> d_xwin;
     polee::DevBuf<polee::PosDesc> d_sched;

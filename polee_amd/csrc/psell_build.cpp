@@ -3,6 +3,7 @@
 // (src/likelihood-approximation.jl:407): a one-off re-layout of X for the hot loop.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <atomic>
 #include <numeric>
@@ -96,16 +97,24 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (timing) fprintf(stderr, "[psell build]   . %-24s %.3f s\n", what, now() - t_sub);
         t_sub = now();
     };
-    // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards)
+    // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards).  Fragments with ONE compatible
+    // transcript are collapsed here (stream S, loglik_internal.hpp): counted per transcript, their log X_ij summed per chunk
+    // (the chunks' sums are added in chunk order: the constant does not depend on the number of threads), key ~0 too.
     BVec<uint64_t> keys((size_t)m);
     BVec<uint32_t> rows((size_t)m);
     {
+        static const bool no_singles = getenv("POLEE_PSELL_NO_SINGLES") != nullptr;  // (A/B, tests: such rows stay in the slices)
         std::atomic<int> err{0};
-        std::atomic<int64_t> empties{0};
+        std::atomic<int64_t> empties{0}, singles{0};
         std::atomic<int32_t> max_row{0};
-        parallel_chunks((size_t)m, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
-            int64_t em = 0;
+        const size_t KCH = (size_t)1 << 18;
+        BVec<int64_t> scnt;
+        if (!no_singles) scnt.assign((size_t)n, 0);
+        BVec<double> chunk_log((size_t)((m + (int64_t)KCH - 1) / (int64_t)KCH) + 1, 0.0);
+        parallel_chunks((size_t)m, KCH, [&](size_t lo, size_t hi, unsigned) {
+            int64_t em = 0, sg = 0;
             int32_t mr = 0;
+            double lsum = 0.0;
             for (size_t i = lo; i < hi; ++i) {
                 const uint64_t b = rowptr[i], e = rowptr[i + 1];
                 rows[i] = (uint32_t)i;
@@ -113,6 +122,16 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 const uint64_t len = e - b;
                 if (len == 0) { ++em; keys[i] = ~0ull; continue; }
                 if (len > (uint64_t)PSELL_MAX_TILE_COLS) { err = 2; keys[i] = ~0ull; continue; }
+                if (len == 1 && !no_singles && col[b] < (uint64_t)n && val[b] > 0.0f && (!ks || ks[i] >= 0)) {
+                    // (a non-positive X_ij stays a stored row: its log is the reference's -Inf / NaN, not ours to hide)
+                    const int64_t k = ks ? ks[i] : 1;
+                    __atomic_fetch_add(&scnt[col[b]], k, __ATOMIC_RELAXED);
+                    lsum += (double)k * log((double)val[b]);
+                    ++sg;
+                    mr = std::max(mr, 1);
+                    keys[i] = ~0ull;
+                    continue;
+                }
                 uint32_t h = 0x12345u, first = col[b];
                 for (uint64_t k = b; k < e; ++k) {
                     if (col[k] >= (uint64_t)n) err = 3;
@@ -123,6 +142,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 keys[i] = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)std::min<uint64_t>(len, 255) << 32) | h;
             }
             empties += em;
+            singles += sg;
+            chunk_log[lo / KCH] = lsum;
             int32_t cur = max_row.load();
             while (mr > cur && !max_row.compare_exchange_weak(cur, mr)) {}
         });
@@ -132,7 +153,18 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (err == 4) return "the transcript ids of a fragment must be strictly ascending (sorted, no duplicates)";
         out.empty_rows = empties;
         out.max_row = max_row;
-        if (out.empty_rows > 0) {  // drop the empty rows (stable)
+        if (singles > 0) {
+            out.single_cnt.resize((size_t)n);
+            for (size_t j = 0; j < (size_t)n; ++j) out.single_cnt[j] = (float)scnt[j];
+            for (double v : chunk_log) out.single_logsum += v;
+            out.single_rows.reserve((size_t)singles);
+            for (size_t i = 0; i < (size_t)m; ++i)
+                if (keys[i] == ~0ull && rowptr[i + 1] - rowptr[i] == 1) out.single_rows.push_back((uint32_t)i);
+            out.stream_rows[PSELL_S] = singles;
+            out.stream_nnz[PSELL_S] = singles;
+            out.stream_bytes[PSELL_S] = 4 * n;
+        }
+        if (out.empty_rows > 0 || singles > 0) {  // drop the empty and the collapsed rows (stable)
             size_t w = 0;
             for (size_t i = 0; i < (size_t)m; ++i)
                 if (keys[i] != ~0ull) {

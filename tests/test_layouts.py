@@ -151,6 +151,10 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
     out["csr_col"] = np.ctypeslib.as_array(v.csr_col, shape=(nz,)).copy() if nz else np.zeros(0, np.uint32)
     out["csr_val"] = np.ctypeslib.as_array(v.csr_val, shape=(nz,)).copy() if nz else np.zeros(0, np.float32)
     out["csr_ks"] = None if ks is None else np.asarray(ks)[out["csr_rows"]].astype(np.float64)
+    ns = int(v.single_num_rows)  # stream S: fragments with one compatible transcript, collapsed at build time
+    out["single_rows"] = np.ctypeslib.as_array(v.single_rows, shape=(ns,)).copy() if ns else np.zeros(0, np.uint32)
+    out["single_cnt"] = np.ctypeslib.as_array(v.single_cnt, shape=(int(v.n),)).copy() if ns else np.zeros(int(v.n), np.float32)
+    out["single_logsum"] = float(v.single_logsum)
     def arr_of(ptr, count, dt):  # (an empty vector's data() may be NULL)
         return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count and ptr else np.zeros(count, dt)
     out["data"] = arr_of(v.data, v.data_bytes, np.uint8)
@@ -255,6 +259,14 @@ def _emulate_psell(ps, x, n):
             if sacc > 0:
                 lp[k] += kq * np.log(sacc)
                 np.add.at(g[k], c, v * kq / sacc)
+    # stream S: collapsed single-transcript fragments (single_rows_kernel)
+    c = ps["single_cnt"].astype(np.float64)
+    if c.any():
+        live = c != 0
+        for k in range(K):
+            xk = x[k].astype(np.float64)
+            g[k][live] += c[live] / xk[live]
+            lp[k] += (c[live] * np.log(xk[live])).sum() + ps["single_logsum"]
     return lp, g
 
 
@@ -263,8 +275,11 @@ def test_psell_layout_reproduces_oracle_on_fixture(lm_fixture):
     ps = _psell(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
     assert ps["nnz"] == 42775 and ps["empty"] == 0 and ps["max_row"] == 15
     ro = ps["row_order"]
-    assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["csr_rows"].tolist()) == list(range(f["m"]))  # every fragment exactly once
+    assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["csr_rows"].tolist() + ps["single_rows"].tolist()) == list(range(f["m"]))  # every fragment exactly once
     assert len(ps["csr_rows"]) == 0 and ps["num_tiles"] == ps["num_tiles_s"]  # real data: one launch
+    # 54 % of the real fixture's fragments are compatible with one transcript only: collapsed into per-transcript counts
+    assert len(ps["single_rows"]) == 10740 and ps["single_cnt"].sum() == 10740 and ps["stream_nnz"][7] == 10740
+    assert sum(ps["stream_nnz"]) == 42775
     assert ps["max_tile_cols"] <= 1024
     # (stored entries / non-zeros: zero lanes of partial slices and the zeros of union slices, on a sample of only 19 743
     # fragments in ~1 300 distinct transcript sets; 1.02 at BASELINE's C2)
@@ -309,7 +324,9 @@ def test_psell_ragged_and_empty_rows(structured):
     if structured:
         assert ps["num_tiles"] > ps["num_tiles_s"] >= 1 and len(ps["csr_rows"]) == 0  # the long row: stream B
     else:
-        assert len(ps["csr_rows"]) == m - m // 50 and ps["num_tiles"] == 0  # no structure: everything stays in CSR
+        # no structure: everything stays in CSR -- but for the fragments of one transcript, which are collapsed (stream S)
+        assert len(ps["csr_rows"]) + len(ps["single_rows"]) == m - m // 50 and ps["num_tiles"] == 0 and len(ps["single_rows"]) > 100
+        assert ps["single_cnt"].sum() == ks[ps["single_rows"]].sum()  # (weighted by the multiplicities)
     x = rng.dirichlet(np.ones(n), size=2).astype(np.float32)
     lp, g = _emulate_psell(ps, x, n)
     # reference semantics with numpy
@@ -477,8 +494,8 @@ def test_psell_layout_built_in_many_segments(lm_fixture):
         m, n = int(d["m"].item()), int(d["n"].item())
         ps = _psell(m, n, d["colptr"], d["rowval"], d["nzval"])
         ro = ps["row_order"]
-        assert sorted(ro[ro != 0xFFFFFFFF].tolist()) == list(range(m))
-        assert ps["num_tiles"] > 20, ps["num_tiles"]
+        assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["single_rows"].tolist()) == list(range(m))
+        assert ps["num_tiles"] > 10, ps["num_tiles"]
         x = np.random.default_rng(0).dirichlet(np.ones(n), size=2).astype(np.float32)
         lp, g = _emulate_psell(ps, x, n)
         s = O.Sample(m, n, d["colptr"], d["rowval"], d["nzval"])
@@ -521,9 +538,11 @@ def test_layout_bytes_stay_below_csr_whatever_the_sets_look_like(case, lm_fixtur
     colptr, rowval, nzval = synth.to_csc(smp)
     ps = _psell(m, n, colptr, rowval, nzval)
     ro = ps["row_order"]
-    assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["csr_rows"].tolist()) == list(range(m))  # every fragment exactly once
+    assert sorted(ro[ro != 0xFFFFFFFF].tolist() + ps["csr_rows"].tolist() + ps["single_rows"].tolist()) == list(range(m))  # every fragment exactly once
+    if case == "tiled fixture":
+        assert len(ps["single_rows"]) == 3 * 10740  # 54 % of the real fixture's fragments have one compatible transcript
     stored = (len(ps["data"]) + 4 * (ps["num_slices"] + 1) + 4 * len(ps["dict"])
-              + 8 * len(ps["csr_col"]) + 4 * len(ps["csr_rowptr"]))
+              + 8 * len(ps["csr_col"]) + 4 * len(ps["csr_rowptr"]) + (4 * n if len(ps["single_rows"]) else 0))
     csr = 8 * smp["nnz"] + 4 * (m + 1)
     print(case, "stored bytes / nnz %.2f, CSR %.2f, stream shares" % (stored / smp["nnz"], csr / smp["nnz"]),
           [round(v / smp["nnz"], 3) for v in ps["stream_nnz"][:6]])
@@ -532,7 +551,7 @@ def test_layout_bytes_stay_below_csr_whatever_the_sets_look_like(case, lm_fixtur
     if case != "random sparse":
         assert ps["num_tiles"] == ps["num_tiles_s"] and len(ps["csr_rows"]) == 0  # one launch
     else:
-        assert len(ps["csr_rows"]) > 0.9 * m  # no structure to exploit: kept in CSR
+        assert len(ps["csr_rows"]) + len(ps["single_rows"]) > 0.9 * m  # no structure to exploit: kept in CSR
     rng = np.random.default_rng(1)
     x = rng.dirichlet(np.ones(n), size=2).astype(np.float32)
     lp, g = _emulate_psell(ps, x, n)

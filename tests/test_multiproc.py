@@ -210,8 +210,9 @@ def test_shard_regression_inputs_partitions_the_samples():
         shard_regression_inputs(vars_, x_init, design, ss, 8, 7)
 
 
-def test_bench_gpus_2_launches_two_ranks():
-    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) starts two ranks as a child torch.distributed.run
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gpus_n_launches_n_ranks(world):
+    """`python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N ranks as a child torch.distributed.run
     and relays rank 0's JSON line as the last line of stdout.  No GPU here: POLEE_BENCH_DRY=1 stops after the
     rendezvous / barrier / max-over-ranks bookkeeping (the fits themselves are covered by the -m gpu twin in
     tests/test_gpu_multiproc.py)."""
@@ -219,13 +220,18 @@ def test_bench_gpus_2_launches_two_ranks():
     env = dict(os.environ, POLEE_BENCH_BACKEND="gloo", POLEE_BENCH_DRY="1", OMP_NUM_THREADS="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1",
-                          "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    for k in ("POLEE_HOST_THREADS",):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "c1",
+                          "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1]
     d = json.loads(last)
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
-    assert abs(d["slowest_rank_s"] - 0.002) < 1e-12  # the max over ranks, not rank 0's own time
+    assert d["n_gpus"] == world and d["ranks_seen"] == world and d["steps"] == 3 and d["warmup"] == 1
+    assert abs(d["slowest_rank_s"] - 0.001 * world) < 1e-12  # the max over ranks, not rank 0's own time
+    # the ranks share the CPUs this job may use (cgroup quota respected), not os.cpu_count() each
+    from polee_amd.cohort import usable_cpus
+    assert d["host_threads_per_rank"] == max(1, usable_cpus() // world)
 
 
 def test_usable_cpus_is_positive_and_within_the_affinity_mask():

@@ -9,15 +9,22 @@ import polee_amd as P
 from polee_amd import _lib as L
 from tools import synth
 n, m = 200000, 30000000
-drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
-smp = synth.make_sample(n, m, 8.0, 123456789, dropout=drop)
+# argument: a per-entry dropout probability, "literal" (every fragment its own subset) or "fixture" (the real fixture tiled x639)
+mode = sys.argv[1] if len(sys.argv) > 1 else "0"
+if mode == "fixture":
+    smp = synth.tile_fixture(639)
+    n, m = smp["n"], smp["m"]
+elif mode == "literal":
+    smp = synth.make_sample(n, m, 8.0, 123456789, literal=True)
+else:
+    smp = synth.make_sample(n, m, 8.0, 123456789, dropout=float(mode))
 parents, js = synth.make_tree(smp["gene"], 123456789)
 ctx = P.Context(0)
 sample = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ctx,
                         xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
 info = sample.info
 tree = P.PolyaTreeTransform(parents, js, ctx=ctx)
-fit = P.LikelihoodApproximationFit(sample, tree, num_steps=80, num_mc_samples=6, seed=1)
+fit = P.LikelihoodApproximationFit(sample, tree, num_steps=80, num_mc_samples=6, seed=1, profile=True)
 fit.run(20); fit.sync()
 NT = sum(info["stream_tiles"][:5])
 tiles = (C.c_ulonglong * NT)(); wgs = (C.c_ulonglong * 1024)()
@@ -37,9 +44,15 @@ for i, name in enumerate(["A1", "A1M", "A2", "A2M", "BN"]):
     if b <= a:
         continue
     tt = t[a:b]
-    print("%-4s tiles %6d  cycles/tile mean %8.0f (p5 %6.0f p95 %6.0f)  total %5.1f %% of tile time  cycles per KiB %.1f" % (
-        name, b - a, tt.mean(), np.percentile(tt, 5), np.percentile(tt, 95), 100 * tt.sum() / t.sum(), tt.sum() / (bytes_[i] / 1024)))
+    print("%-4s tiles %6d  cycles/tile mean %8.0f (p5 %6.0f p95 %6.0f)  total %5.1f %% of tile time  cycles per KiB %.1f  share of nnz %.3f  cycles per nnz %.2f" % (
+        name, b - a, tt.mean(), np.percentile(tt, 5), np.percentile(tt, 95), 100 * tt.sum() / t.sum(), tt.sum() / (bytes_[i] / 1024),
+        info["stream_nnz"][i] / info["nnz"], tt.sum() / max(info["stream_nnz"][i], 1)))
 
+st = fit.stats()
+print("mode %s: kernel ms %.4f  pass ms %.4f  single-transcript rows %d (%.3f of nnz)" % (
+    mode, st["loglik_kernel_ms_avg"], st["loglik_pass_ms_avg"], info["stream_rows"][7], info["stream_nnz"][7] / info["nnz"]))
+if os.environ.get("TILE_FEATURES") != "1":
+    sys.exit(0)
 # per-tile features of the layout (host build of the same matrix), saved beside the cycles for an offline fit of the
 # schedule's cost model
 colptr, rowval, nzval = synth.to_csc(smp)
