@@ -65,10 +65,15 @@ void *polee_ctx_stream(polee_ctx *ctx); /* the context's hipStream_t */
 polee_status polee_ctx_timer_start(polee_ctx *ctx);
 polee_status polee_ctx_timer_stop(polee_ctx *ctx, double *elapsed_ms);
 const char *polee_version(void);
-/* The host-side builders (polee_loglik_create, polee_hclust*) keep the large scratch blocks they used -- up to
- * POLEE_HOST_CACHE_MB megabytes, default 8192 -- for the next sample: mapping and unmapping gigabytes per sample was a
- * third of a sample's preparation.  This releases them. */
+/* The host-side builders (polee_loglik_create, polee_hclust*) keep the large scratch blocks they used for the next sample
+ * (mapping and unmapping gigabytes per sample was a third of a sample's preparation): up to POLEE_HOST_CACHE_MB
+ * megabytes; default = a quarter of the memory available to the process (MemAvailable, cut to the cgroup's
+ * memory.max - memory.current), at most 8192.  A long-lived process therefore keeps up to that much resident after a
+ * sample's preparation.  polee_host_cache_trim releases the blocks; polee_host_cache_configure sets a new cap in MB
+ * (freeing what no longer fits; < 0: only query) and returns the cap in force; polee_host_cache_bytes = bytes cached now. */
 void polee_host_cache_trim(void);
+int64_t polee_host_cache_configure(int64_t cap_mb);
+int64_t polee_host_cache_bytes(void);
 
 /* ---- Polya tree transform ---------------------------------------------------------
  * Replaces PolyaTreeTransform (src/ptt.jl:6-27) and the three TF custom ops of

@@ -369,6 +369,23 @@ def vi_draw_gradients(sample, ptt, efflens, mu, omega, alpha, zs0, use_efflen_ja
                 lp=lp.value, ladj=ladj.value)
 
 
+def set_debug_scale(term, scale):
+    """Scale one of the six additive gradient terms of the ELBO (see polee_oracle.c: oracle_debug_scale); 1.0 = off."""
+    lib().oracle_set_debug_scale(int(term), C.c_double(scale))
+
+
+def vi_pin_stats(sample, ptt, efflens, mu, omega, alpha, seed0, ndraws):
+    """(mean, standard error) [3, n-1] of the per-draw gradients of vi_draw_gradients over draws seed0 .. seed0+ndraws-1."""
+    efflens, mu, omega, alpha = map(_f32, (efflens, mu, omega, alpha))
+    nm1 = sample.n - 1
+    gsum, gsq = np.empty((3, nm1), np.float64), np.empty((3, nm1), np.float64)
+    lib().oracle_vi_pin_stats(sample.h, ptt.h, _p(efflens, c_f32p), _p(mu, c_f32p), _p(omega, c_f32p), _p(alpha, c_f32p),
+                              C.c_uint64(seed0), C.c_int64(ndraws), _p(gsum, c_f64p), _p(gsq, c_f64p))
+    mean = gsum / ndraws
+    var = np.maximum(gsq / ndraws - mean ** 2, 0.0)
+    return mean, np.sqrt(var / max(ndraws - 1, 1))
+
+
 def sampler_draw(ptt, mu, sigma, alpha, zs0):
     mu, sigma, alpha, zs0 = map(_f32, (mu, sigma, alpha, zs0))
     xs = np.empty(ptt.n, np.float32)

@@ -33,6 +33,17 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+/* Debug scales of the six additive gradient terms of the ELBO (all 1.0 = the reference's arithmetic, bit for bit:
+ * a multiplication by 1.0 is exact).  tests/test_oracle_pin.py uses them (a) to measure every term's expected
+ * contribution to the parameter gradients and (b) for its power check: a term biased by 3 % must make the
+ * stationarity test fail.  0 logitnormal.jl:50 (mu), 1 logitnormal.jl:51-52 (sigma), 2 logitnormal.jl:53 (z),
+ * 3 sinh_arcsinh.jl:36, 4 ptt.jl:203-204 (the ladj part of transform_gradients!), 5 likelihood.jl:102-104. */
+static double oracle_debug_scale[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+void oracle_set_debug_scale(int term, double scale)
+{
+    if (term >= 0 && term < 6) oracle_debug_scale[term] = scale;
+}
 #endif
 
 /* ------------------------------------------------------------------------- */
@@ -152,7 +163,7 @@ void oracle_ptt_transform_gradients(oracle_ptt *t, const double *ys, float *y_gr
         y_grad[k] = (float)(t->us[i] * (double)inner);          /* f64 * f32 -> f32 store */
         t->gradients[0 + 2 * (size_t)i] = (float)(ys[k] * (double)lg + (1 - ys[k]) * (double)rg);
         t->gradients[1 + 2 * (size_t)i] =
-            (float)(1 / t->us[i] + ys[k] * (double)llg + (1 - ys[k]) * (double)rlg);
+            (float)(oracle_debug_scale[4] * (1 / t->us[i]) + ys[k] * (double)llg + (1 - ys[k]) * (double)rlg);
         --k;
     }
 }
@@ -460,7 +471,7 @@ double oracle_effective_length_jacobian_adjustment(const float *efflens, const f
     }
     for (int64_t i = 0; i < n; ++i) xls[i] = (float)((double)xls[i] / x_scaled_sum);
     for (int64_t i = 0; i < n; ++i)
-        x_grad[i] -= (double)((float)n * (1 / efflens[i])) / x_scaled_sum; /* Int64 * Float32 -> Float32 */
+        x_grad[i] -= oracle_debug_scale[5] * ((double)((float)n * (1 / efflens[i])) / x_scaled_sum); /* Int64 * Float32 -> Float32 */
     return 0.0;
 }
 
@@ -529,10 +540,10 @@ void oracle_logit_normal_transform_gradients(const float *zs, const double *ys, 
         double dy_dz = ys[i] * (1 - ys[i]) * (double)sigma[i];
         z_grad[i] = (float)((double)z_grad[i] + dy_dz * (double)y_grad[i]);
         /* ladj gradients, added unconditionally (logitnormal.jl:50-53) */
-        mu_grad[i] = (float)((double)mu_grad[i] + (1 - 2 * ys[i]));
+        mu_grad[i] = (float)((double)mu_grad[i] + oracle_debug_scale[0] * (1 - 2 * ys[i]));
         sigma_grad[i] =
-            (float)((double)sigma_grad[i] + ((double)(1 / sigma[i]) + (double)zs[i] * (1 - 2 * ys[i])));
-        z_grad[i] = (float)((double)z_grad[i] + (double)sigma[i] * (1 - 2 * ys[i]));
+            (float)((double)sigma_grad[i] + oracle_debug_scale[1] * ((double)(1 / sigma[i]) + (double)zs[i] * (1 - 2 * ys[i])));
+        z_grad[i] = (float)((double)z_grad[i] + oracle_debug_scale[2] * ((double)sigma[i] * (1 - 2 * ys[i])));
     }
 }
 
@@ -574,7 +585,7 @@ void oracle_sinh_asinh_transform_gradients(const float *zs0, const float *alpha,
     for (int64_t i = 0; i < nm1; ++i) {
         float c = alpha[i] + asinhf(zs0[i]);
         alpha_grad[i] += coshf(c) * z_grad[i];
-        alpha_grad[i] += tanhf(c);
+        alpha_grad[i] += (float)oracle_debug_scale[3] * tanhf(c);
     }
 }
 
@@ -874,6 +885,30 @@ void oracle_vi_draw_gradients(oracle_sample *s, oracle_ptt *t, const float *effl
     if (ladj_out) *ladj_out = (double)skew_ladj + (double)ln_ladj + hsb_ladj;
     if (ys_out) memcpy(ys_out, ys, nm1 * 8);
     free(zs); free(sigma); free(xls); free(sigma_grad); free(z_grad); free(ys);
+}
+
+/* Sums over `ndraws` draws (noise of draw d = oracle_randn_fill(., n-1, seed0 + d)) of the per-draw parameter
+ * gradients of oracle_vi_draw_gradients and of their squares: gsum, gsq [3][n-1] (mu, omega, alpha), in double.
+ * The stationarity pin (tests/test_oracle_pin.py) needs 10^5 draws: a loop in C instead of 10^5 ctypes calls. */
+void oracle_vi_pin_stats(oracle_sample *s, oracle_ptt *t, const float *efflens, const float *mu, const float *omega,
+                         const float *alpha, uint64_t seed0, int64_t ndraws, double *gsum, double *gsq)
+{
+    int64_t n = s->n, nm1 = n - 1;
+    float *z0 = calloc(nm1, 4), *xs = calloc(n, 4), *yg = calloc(nm1, 4);
+    float *mg = calloc(nm1, 4), *og = calloc(nm1, 4), *ag = calloc(nm1, 4);
+    double *xg = calloc(n, 8);
+    memset(gsum, 0, sizeof(double) * 3 * nm1);
+    memset(gsq, 0, sizeof(double) * 3 * nm1);
+    for (int64_t d = 0; d < ndraws; ++d) {
+        oracle_randn_fill(z0, nm1, seed0 + (uint64_t)d);
+        oracle_vi_draw_gradients(s, t, efflens, 1, mu, omega, alpha, z0, xs, xg, yg, mg, og, ag, NULL, NULL, NULL);
+        for (int64_t i = 0; i < nm1; ++i) {
+            gsum[i] += mg[i]; gsq[i] += (double)mg[i] * mg[i];
+            gsum[nm1 + i] += og[i]; gsq[nm1 + i] += (double)og[i] * og[i];
+            gsum[2 * nm1 + i] += ag[i]; gsq[2 * nm1 + i] += (double)ag[i] * ag[i];
+        }
+    }
+    free(z0); free(xs); free(yg); free(mg); free(og); free(ag); free(xg);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -138,10 +138,15 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
         return list(ex.map(job, enumerate(samples)))
 
 
-def _process_init(host_threads):
+def _process_init(host_threads, cache_mb=None):
     import os
     if host_threads:
         os.environ["POLEE_HOST_THREADS"] = str(int(host_threads))  # (read once, when the library first needs it)
+    if cache_mb is not None:
+        # every worker process has its own scratch-block cache: the cohort's share of memory is divided between them
+        # (four workers at the 8 GiB default pinned 32 GiB)
+        from . import core
+        core.host_cache_configure(int(cache_mb))
 
 
 def _process_job(args):
@@ -191,15 +196,19 @@ def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_t
     processes do not meet there; they share the GPU (every process its own HIP context, one fit = 1.2 GB).
     samples: picklable zero-argument callables (e.g. functools.partial(h5io.read_likelihood_matrix, path)) or tuples.
     host_threads: threads every process gives its builders (POLEE_HOST_THREADS; default: the usable CPUs -- affinity mask
-    and cgroup quota -- divided by `processes`).  The pool is started with `spawn`."""
+    and cgroup quota -- divided by `processes`).  The pool is started with `spawn`.  Every worker keeps its builders'
+    scratch blocks between samples (core.host_cache_configure): the single-process cap is divided by `processes`, so the
+    cohort as a whole holds no more resident scratch than one process would."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     samples = list(samples)
     out = [None] * len(samples)
     if host_threads is None:  # share the usable CPUs out (two host stages run side by side in every process)
         host_threads = max(2, usable_cpus() // max(1, int(processes)))
+    from . import core
+    cache_mb = max(256, core.host_cache_configure(-1) // max(1, int(processes)))
     with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mp.get_context("spawn"),
-                             initializer=_process_init, initargs=(host_threads,)) as ex:
+                             initializer=_process_init, initargs=(host_threads, cache_mb)) as ex:
         jobs = [(i, s, approx.treemethod, device, kwargs) for i, s in enumerate(samples)]
         for idx, params in ex.map(_process_job, jobs):
             if on_result is not None:

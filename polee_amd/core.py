@@ -392,6 +392,21 @@ def host_cache_trim():
     f()
 
 
+def host_cache_configure(cap_mb=-1):
+    """Cap (MB) of the builders' scratch-block cache; frees what no longer fits.  cap_mb < 0: query only.  Returns the cap
+    in force.  (Default: a quarter of the memory available to the process, at most 8 GiB -- a process keeps up to that
+    much resident between samples.)"""
+    f = L.lib().polee_host_cache_configure
+    f.restype, f.argtypes = C.c_int64, [C.c_int64]
+    return int(f(int(cap_mb)))
+
+
+def host_cache_bytes():
+    f = L.lib().polee_host_cache_bytes
+    f.restype, f.argtypes = C.c_int64, []
+    return int(f())
+
+
 def hclust(m, n, colptr, rowval, parallel=False):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],

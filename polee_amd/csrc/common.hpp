@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <algorithm>
 #include <atomic>
@@ -164,7 +165,7 @@ inline unsigned host_threads()
 // Large blocks (>= 1 MiB) come straight from mmap with MADV_HUGEPAGE: the one-off host builders fill gigabytes of fresh
 // memory once, and with 4 KiB pages that is a million page faults in (and a million page frees out) per gigabyte-sized
 // buffer -- measured at BASELINE's C2: the two passes of the CSC -> rows transposition 0.36 -> 0.05 s.
-// Freed blocks are kept (up to POLEE_HOST_CACHE_MB, default 8192) and handed out again: unmapping a 3 GB staging buffer
+// Freed blocks are kept (up to POLEE_HOST_CACHE_MB; default: a quarter of the available memory, at most 8192) and handed out again: unmapping a 3 GB staging buffer
 // costs 0.14 s of kernel time, and doing it on a helper thread only moves the cost (the unmap holds the address-space
 // lock that every page fault of the next phase needs: measured, the next phase got 0.14 s slower).  A reused block is
 // already resident, so the second use does not fault either -- within one build (the sort's buffers reuse the
@@ -179,10 +180,68 @@ struct HugeBlockCache {
     std::vector<Blk> free_;             // oldest first
     std::vector<Blk> live_;             // blocks handed out (a dozen at a time: linear search)
     size_t cached = 0, cap;
+    // Default cap: a quarter of the memory this process can still get -- MemAvailable, cut to what the cgroup
+    // leaves (memory.max - memory.current) -- and never more than 8 GiB; POLEE_HOST_CACHE_MB or polee_host_cache_configure()
+    // override it (a cohort's worker processes each get their share, polee_amd/cohort.py).
+    static size_t default_cap()
+    {
+        long long avail = -1;
+        if (FILE *f = fopen("/proc/meminfo", "r")) {
+            char line[128];
+            while (fgets(line, sizeof line, f))
+                if (sscanf(line, "MemAvailable: %lld kB", &avail) == 1) {
+                    avail <<= 10;
+                    break;
+                }
+            fclose(f);
+        }
+        long long mx = -1, cur = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/memory.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s", q) == 1 && strcmp(q, "max") != 0) mx = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/memory/memory.limit_in_bytes", "r")) {
+            if (fscanf(g, "%lld", &mx) != 1 || mx > (1LL << 60)) mx = -1;
+            fclose(g);
+        }
+        if (mx > 0) {
+            if (FILE *f = fopen("/sys/fs/cgroup/memory.current", "r")) {
+                if (fscanf(f, "%lld", &cur) != 1) cur = 0;
+                fclose(f);
+            } else if (FILE *g = fopen("/sys/fs/cgroup/memory/memory.usage_in_bytes", "r")) {
+                if (fscanf(g, "%lld", &cur) != 1) cur = 0;
+                fclose(g);
+            }
+            const long long left = std::max(0LL, mx - cur);
+            avail = avail < 0 ? left : std::min(avail, left);
+        }
+        const size_t hard = (size_t)8192 << 20;
+        return avail < 0 ? hard : std::min(hard, (size_t)(avail / 4));
+    }
     HugeBlockCache()
     {
         const char *e = getenv("POLEE_HOST_CACHE_MB");
-        cap = (size_t)(e ? std::max(0L, atol(e)) : 8192L) << 20;
+        cap = e ? (size_t)std::max(0L, atol(e)) << 20 : default_cap();
+    }
+    // new cap (bytes); frees cached blocks, oldest first, until the cache fits
+    void set_cap(size_t bytes)
+    {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            cap = bytes;
+            while (cached > cap && !free_.empty()) {
+                drop.push_back(free_.front());
+                cached -= free_.front().len;
+                free_.erase(free_.begin());
+            }
+        }
+        for (const Blk &d : drop) (void)munmap(d.p, d.len);
+    }
+    size_t cached_bytes()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        return cached;
     }
     static HugeBlockCache &get()
     {
@@ -317,11 +376,24 @@ inline void parallel_chunks(size_t count, size_t grain, F &&f)
     }
     std::atomic<size_t> next{0};
     std::vector<std::thread> pool;
+    // an exception in a worker (std::bad_alloc from a builder's vector) must not reach std::terminate: the first one is
+    // kept, the other workers stop taking chunks, and it is rethrown on the calling thread after the join
+    std::exception_ptr first;
+    std::mutex first_mu;
+    std::atomic<bool> stop{false};
     for (unsigned th = 0; th < std::min<size_t>(hw, nchunks); ++th)
         pool.emplace_back([&, th]() {
-            for (size_t c = next++; c < nchunks; c = next++) f(c * grain, std::min(count, (c + 1) * grain), th);
+            try {
+                for (size_t c = next++; c < nchunks && !stop.load(std::memory_order_relaxed); c = next++)
+                    f(c * grain, std::min(count, (c + 1) * grain), th);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(first_mu);
+                if (!first) first = std::current_exception();
+                stop = true;
+            }
         });
     for (auto &t : pool) t.join();
+    if (first) std::rethrow_exception(first);
 }
 
 
@@ -339,6 +411,22 @@ void ctx_retain(polee_ctx *ctx);
 void ctx_release(polee_ctx *ctx);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Nothing may unwind through the C ABI: the host-side builders allocate gigabytes through std::vector, on
+// the calling thread and in parallel_chunks workers (which hand their first exception back to the caller).
+template <class F>
+inline polee_status guarded(polee_ctx *ctx, const char *what, F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, POLEE_ERR_OOM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "%s: unknown exception", what);
+    }
+}
 
 // accessors of the approximation handle (approx.hip) for its consumers
 polee_ctx *approx_ctx(const polee_approx *ap);

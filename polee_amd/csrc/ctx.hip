@@ -35,6 +35,13 @@ const char *polee_version(void) { return "polee_hip 0.3 (gfx950); " POLEE_BUILD_
 
 // the host builders keep their large scratch blocks for the next sample (common.hpp HugeBlockCache)
 void polee_host_cache_trim(void) { polee::HugeBlockCache::get().trim(); }
+int64_t polee_host_cache_configure(int64_t cap_mb)
+{
+    polee::HugeBlockCache &c = polee::HugeBlockCache::get();
+    if (cap_mb >= 0) c.set_cap((size_t)cap_mb << 20);
+    return (int64_t)(c.cap >> 20);
+}
+int64_t polee_host_cache_bytes(void) { return (int64_t)polee::HugeBlockCache::get().cached_bytes(); }
 
 polee_status polee_ctx_create(int device, polee_ctx **out)
 {

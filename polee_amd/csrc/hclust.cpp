@@ -872,18 +872,32 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
 
 }  // namespace polee
 
+//  nothing may unwind through the C ABI: the builders allocate on the calling thread and inside
+// parallel_chunks workers (which hand the first exception back to the caller, common.hpp)
+template <class F>
+static polee_status hclust_guarded(F &&f)
+{
+    try {
+        const std::string err = f();
+        if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
+        return POLEE_OK;
+    } catch (const std::bad_alloc &) {
+        return polee::fail(nullptr, POLEE_ERR_OOM, "hclust: out of host memory");
+    } catch (const std::exception &e) {
+        return polee::fail(nullptr, POLEE_ERR_UNSUPPORTED, "hclust: %s", e.what());
+    } catch (...) {
+        return polee::fail(nullptr, POLEE_ERR_UNSUPPORTED, "hclust: unknown exception");
+    }
+}
+
 extern "C" polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
                                      int32_t *node_parent_idxs, int32_t *node_js)
 {
-    const std::string err = polee::hclust_build(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js);
-    if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
-    return POLEE_OK;
+    return hclust_guarded([&] { return polee::hclust_build(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js); });
 }
 
 extern "C" polee_status polee_hclust_parallel(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
                                               const uint32_t *rowval, int32_t *node_parent_idxs, int32_t *node_js)
 {
-    const std::string err = polee::hclust_build_rounds(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js);
-    if (!err.empty()) return polee::fail(nullptr, POLEE_ERR_BAD_ARG, "hclust: %s", err.c_str());
-    return POLEE_OK;
+    return hclust_guarded([&] { return polee::hclust_build_rounds(m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js); });
 }

@@ -1997,8 +1997,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
     }
     if (dyn && threadIdx.x == 0) {
-        // (every draw of this launch has been made before the last workgroup arrives here)
-        if (__hip_atomic_fetch_add(A.dyn_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
+        // Every draw of this launch has been made before the last workgroup arrives here: the draws are this thread's own
+        // earlier atomics, ordered before its arrival by the RELEASE half of the increment; the workgroup that sees G - 1
+        // ACQUIRES all of them before it resets the counters for the next launch (the ordering is now stated,
+        // not implied by the per-tile s_waitcnt).  Should a launch fail, the host zeroes the counters (loglik_eval_device).
+        if (__hip_atomic_fetch_add(A.dyn_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
             __hip_atomic_store(A.dyn_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.dyn_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -2267,6 +2270,8 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         case 7: st = launch_k<7>(ll, d_x, d_g, d_lp); break;
         default: st = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
+    if (st != POLEE_OK && ll->d_dyn_ctr.p)  // a failed launch may have left draws behind: the next pass must start at position 0
+        (void)hipMemsetAsync(ll->d_dyn_ctr.p, 0, 2 * sizeof(unsigned int), ctx->stream);
     if (st == POLEE_OK && ll->has_singles) {
         const int nb = (int)ceil_div(ll->n, SINGLE_THREADS);
         hipLaunchKernelGGL(single_rows_kernel, dim3((unsigned)nb), dim3(SINGLE_THREADS), 0, ctx->stream, ll->d_single_cnt.p, d_x, K,
@@ -2635,7 +2640,7 @@ polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on)
     return POLEE_OK;
 }
 
-polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
+static polee_status polee_loglik_create_from_xt_impl(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
                                          const uint32_t *trowval, const float *tnzval, const int64_t *ks,
                                          polee_loglik **out)
 {
@@ -2679,7 +2684,14 @@ polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, c
     return loglik_finish_create(ctx, ll, out);
 }
 
-polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
+                                         const uint32_t *trowval, const float *tnzval, const int64_t *ks,
+                                         polee_loglik **out)
+{
+    return guarded(ctx, "polee_loglik_create_from_xt", [&] { return polee_loglik_create_from_xt_impl(ctx, m, n, tcolptr, trowval, tnzval, ks, out); });
+}
+
+static polee_status polee_loglik_create_impl(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
                                  const uint32_t *rowval, const float *nzval, const int64_t *ks, polee_loglik **out)
 {
     POLEE_TRY(use_device(ctx));
@@ -2709,6 +2721,12 @@ polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const voi
     const polee_status st = loglik_finish_create(ctx, ll, out);
     if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "total", wall_now() - t_begin);
     return st;
+}
+
+polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                 const uint32_t *rowval, const float *nzval, const int64_t *ks, polee_loglik **out)
+{
+    return guarded(ctx, "polee_loglik_create", [&] { return polee_loglik_create_impl(ctx, m, n, colptr, colptr_bytes, rowval, nzval, ks, out); });
 }
 
 void polee_loglik_destroy(polee_loglik *ll) { loglik_release(ll); }

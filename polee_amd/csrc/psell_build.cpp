@@ -293,6 +293,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.15;
         static const double over_budget = getenv("POLEE_PSELL_OVER_BUDGET") ? atof(getenv("POLEE_PSELL_OVER_BUDGET")) : 0.02;
         static const double relax = getenv("POLEE_PSELL_RELAX") ? atof(getenv("POLEE_PSELL_RELAX")) : 2.0;
+        static const double relax0 = getenv("POLEE_PSELL_RELAX0") ? atof(getenv("POLEE_PSELL_RELAX0")) : 1.0;  // (first pass)
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
@@ -351,7 +352,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                         // few fragments without company do not cost a pass the mixed stream's extra launch
                         // (over_budget of the whole matrix's CSR bytes, shared out by the parts' candidate rows)
                         double allowance = 0.0;
-                        if (pass_w == 1) {
+                        if (pass_w == 1 || relax0 > 1.0) {
                             for (size_t q = p0; q < p1; ++q) allowance += 8.0 * (double)(rowptr[pool[q] + 1] - rowptr[pool[q]]) + 4.0;
                             allowance *= over_budget * matrix_csr_bytes / std::max(pool_csr_bytes, 1.0);
                         }
@@ -378,7 +379,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                                 // (second pass: a slice up to `relax` times CSR's cost is still better than what is left
                                 // for its rows -- mixed tiles of some twenty unrelated fragments each --, and rows too long
                                 // for stream BN are kept at any cost; both within the allowance)
-                                if (!worth && pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX) && cost - budget <= allowance) {
+                                if (!worth && ((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
+                                               (pass_w == 0 && cost <= relax0 * budget)) && cost - budget <= allowance) {
                                     allowance -= cost - budget;
                                     worth = true;
                                 }
@@ -611,9 +613,20 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             }
         }
     }
-    static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
+    static const int a1cap_env = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
     static const int a2cap = getenv("POLEE_TILE_A2") ? atoi(getenv("POLEE_TILE_A2")) : PSELL_TILE_SLICES_A2;
     static const int a2mcap = getenv("POLEE_TILE_A2M") ? std::min(atoi(getenv("POLEE_TILE_A2M")), 126) : PSELL_TILE_SLICES_A2M;
+    // A small sample gives the persistent launch's ~1000 workgroups only a few tiles each, and the dynamic schedule can
+    // balance no finer than a tile (measured on the tiled real fixture, 3 500 tiles: slowest workgroup 1.29 x the mean).
+    // So the narrow streams' tiles shrink -- never below 16 slices, four per wave -- until there are about
+    // `tiles_per_wg` x 1024 of them.
+    static const int tiles_per_wg = getenv("POLEE_TILE_PER_WG") ? atoi(getenv("POLEE_TILE_PER_WG")) : 0;
+    int a1cap = a1cap_env;
+    if (tiles_per_wg > 0) {
+        const size_t slices_est = (rows.size() + PSELL_LANES - 1) / PSELL_LANES;
+        const size_t want = (size_t)tiles_per_wg * 1024;
+        a1cap = (int)std::max<size_t>(16, std::min<size_t>((size_t)a1cap_env, (slices_est + want - 1) / want));
+    }
     const unsigned nthreads = host_threads();
     std::vector<BVec<uint32_t>> stamps(nthreads);
     std::vector<BVec<uint16_t>> locals(nthreads);

@@ -419,7 +419,7 @@ struct polee_xbuild {
 
 extern "C" {
 
-polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
+static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
                               polee_xbuild **out)
 {
     POLEE_TRY(use_device(ctx));
@@ -428,6 +428,51 @@ polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, con
         return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run: bad argument");
     const int32_t n = T->n;
     const int64_t m = F->m, nex = T->exon_ptr[n];
+    // fragments: every array present, mates ordered as the reference orders them itself (a1 = the leftmost mate,
+    // transcripts.jl:288-297 -- a caller holding them in BAM order swaps first, polee_amd/xbuild.py does), intervals and
+    // CIGAR ranges well formed -- the kernels index with them
+    if (m > 0 && (!F->seq || !F->strand || !F->m1_left || !F->m1_right || !F->m2_left || !F->m2_right || !F->m1_is_flag16 || !F->cig1_ptr))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run: a fragment array is null (only cig2_ptr may be: all single-end)");
+    std::vector<int64_t> cig2_zero;  // cig2_ptr == NULL: no second mate has CIGAR operations
+    const int64_t *cig2 = F->cig2_ptr;
+    if (m > 0 && !cig2) {
+        cig2_zero.assign((size_t)m + 1, 0);
+        cig2 = cig2_zero.data();
+    }
+    const int64_t ncig = m > 0 ? std::max(F->cig1_ptr[m], cig2[m]) : 0;
+    if (m > 0 && (F->cig1_ptr[0] < 0 || cig2[0] < 0 || (ncig > 0 && (!F->cig_op || !F->cig_len))))
+        return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run: bad CIGAR offsets");
+    {
+        std::atomic<int> bad{0};
+        std::atomic<int64_t> where{-1};
+        parallel_chunks((size_t)m, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
+            for (size_t i = lo; i < hi; ++i) {
+                int why = 0;
+                if (F->seq[i] < 0) why = 1;
+                else if (F->m1_left[i] < 1 || F->m1_right[i] < F->m1_left[i]) why = 2;
+                else if (F->m2_left[i] != 0 && (F->m2_left[i] < 1 || F->m2_right[i] < F->m2_left[i])) why = 2;
+                else if (F->m2_left[i] != 0 && F->m2_left[i] < F->m1_left[i]) why = 3;
+                else if (F->cig1_ptr[i + 1] < F->cig1_ptr[i] || cig2[i + 1] < cig2[i]) why = 4;
+                else if (F->m2_left[i] == 0 && cig2[i + 1] != cig2[i]) why = 4;
+                else {
+                    for (int64_t k = F->cig1_ptr[i]; k < F->cig1_ptr[i + 1] && !why; ++k)
+                        if (F->cig_len[k] < 0 || F->cig_op[k] > 8) why = 5;
+                    for (int64_t k = cig2[i]; k < cig2[i + 1] && !why; ++k)
+                        if (F->cig_len[k] < 0 || F->cig_op[k] > 8) why = 5;
+                }
+                if (why) {
+                    int z = 0;
+                    if (bad.compare_exchange_strong(z, why)) where = (int64_t)i;
+                    return;
+                }
+            }
+        });
+        static const char *const msg[] = {"", "negative sequence id", "mate interval is not 1-based with left <= right",
+                                          "m1 must be the LEFTMOST mate (the reference orders the mates by leftpos, transcripts.jl:288-297)",
+                                          "CIGAR offsets are not monotone (or a single-end fragment has operations for a second mate)",
+                                          "CIGAR operation out of range or negative length"};
+        if (bad) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run: fragment %lld: %s", (long long)where.load(), msg[bad.load()]);
+    }
     // transcripts: every one needs exons, ascending and disjoint
     int32_t num_seq = 0;
     for (int32_t j = 0; j < n; ++j) {
@@ -467,7 +512,6 @@ polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, con
     DevBuf<int64_t> d_eptr, d_ef, d_el, d_ofirst, d_omax, d_seqptr, d_m1l, d_m1r, d_m2l, d_m2r, d_c1, d_c2, d_counts, d_off, d_rowid, d_tmp;
     DevBuf<uint8_t> d_flag16, d_cigop;
     DevBuf<float> d_pmf, d_cdf;
-    const int64_t ncig = m > 0 ? std::max(F->cig1_ptr[m], F->cig2_ptr ? F->cig2_ptr[m] : 0) : 0;
     polee_status s = POLEE_OK;
     auto A = [&](polee_status r) {
         if (s == POLEE_OK) s = r;
@@ -479,7 +523,7 @@ polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, con
     A(d_m1l.upload(ctx, F->m1_left, (size_t)m)); A(d_m1r.upload(ctx, F->m1_right, (size_t)m));
     A(d_m2l.upload(ctx, F->m2_left, (size_t)m)); A(d_m2r.upload(ctx, F->m2_right, (size_t)m));
     A(d_flag16.upload(ctx, F->m1_is_flag16, (size_t)m));
-    A(d_c1.upload(ctx, F->cig1_ptr, (size_t)m + 1)); A(d_c2.upload(ctx, F->cig2_ptr, (size_t)m + 1));
+    A(d_c1.upload(ctx, F->cig1_ptr, (size_t)m + 1)); A(d_c2.upload(ctx, cig2, (size_t)m + 1));
     A(d_cigop.upload(ctx, F->cig_op, (size_t)ncig)); A(d_ciglen.upload(ctx, F->cig_len, (size_t)ncig));
     A(d_pmf.upload(ctx, M->fraglen_pmf, (size_t)XB_MAX_FRAG_LEN)); A(d_cdf.upload(ctx, M->fraglen_cdf, (size_t)XB_MAX_FRAG_LEN));
     A(xb->d_efflens.alloc(ctx, (size_t)n)); A(d_counts.alloc(ctx, (size_t)m + 1)); A(d_off.alloc(ctx, (size_t)m + 2)); A(d_rowid.alloc(ctx, (size_t)m + 2));
@@ -521,6 +565,12 @@ polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, con
     xb->rows = rows;
     *out = xb;
     return POLEE_OK;
+}
+
+polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
+                              polee_xbuild **out)
+{
+    return guarded(ctx, "polee_xbuild_run", [&] { return polee_xbuild_run_impl(ctx, T, F, M, out); });
 }
 
 void polee_xbuild_destroy(polee_xbuild *xb)

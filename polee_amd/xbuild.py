@@ -45,12 +45,44 @@ def pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, stran
     return T, F, M, keep
 
 
+def order_mates(fragments):
+    """The reference orders the mates of a pair itself -- a1 = the mate with the smaller leftpos (src/transcripts.jl:288-297)
+    -- and polee_xbuild_run REQUIRES m1 to be that mate (POLEE_ERR_BAD_ARG otherwise).  A caller holding the mates in BAM
+    order (mate1_idx / mate2_idx) passes through here: pairs with m2_left < m1_left are swapped, intervals and CIGAR
+    ranges alike; cig2_ptr == None stands for "no second mate has operations".  Returns a new dict (arrays shared where
+    nothing changes)."""
+    F = dict(fragments)
+    m = int(F["m"])
+    c1 = np.asarray(F["cig1_ptr"], np.int64)
+    c2 = np.zeros(m + 1, np.int64) if F.get("cig2_ptr") is None else np.asarray(F["cig2_ptr"], np.int64)
+    F["cig2_ptr"] = c2
+    m1l, m2l = np.asarray(F["m1_left"], np.int64), np.asarray(F["m2_left"], np.int64)
+    swap = (m2l != 0) & (m2l < m1l)
+    if not swap.any():
+        return F
+    for a, b in (("m1_left", "m2_left"), ("m1_right", "m2_right")):
+        x, y = np.asarray(F[a], np.int64), np.asarray(F[b], np.int64)
+        F[a], F[b] = np.where(swap, y, x), np.where(swap, x, y)
+    l1, l2 = np.diff(c1), np.diff(c2)
+    n1, n2 = np.where(swap, l2, l1), np.where(swap, l1, l2)
+    s1, s2 = np.where(swap, c2[:-1], c1[:-1]), np.where(swap, c1[:-1], c2[:-1])
+    p1 = np.concatenate([[0], np.cumsum(n1)])
+    p2 = p1[-1] + np.concatenate([[0], np.cumsum(n2)])  # (all first mates' operations, then all second mates')
+    src = np.concatenate([np.repeat(s1 - p1[:-1], n1) + np.arange(p1[-1]), np.repeat(s2 - p2[:-1], n2) + np.arange(p1[-1], p2[-1])])
+    F["cig_op"] = np.asarray(F["cig_op"], np.uint8)[src] if src.size else np.zeros(1, np.uint8)
+    F["cig_len"] = np.asarray(F["cig_len"], np.int32)[src] if src.size else np.zeros(1, np.int32)
+    F["cig1_ptr"], F["cig2_ptr"] = p1.astype(np.int64), p2.astype(np.int64)
+    return F
+
+
 def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity=0.9,
                             alt_frag_model=False, ctx=None):
     """-> dict(m, n, nnz, tcolptr u64 [m+1], trowval u32, tnzval f32 (the rows of X, 1-based, what RNASeqSample(xt=...)
-    takes), effective_lengths f32 [n], row_fragment i64 [m], kernel_ms)."""
+    takes), effective_lengths f32 [n], row_fragment i64 [m], kernel_ms).  The mates of a pair may come in any order
+    (order_mates)."""
     from .core import default_context
     ctx = ctx or default_context()
+    fragments = order_mates(fragments)
     T, F, M, keep = pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity, alt_frag_model)
     h = C.c_void_p()
     check(L.lib().polee_xbuild_run(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(h)), ctx._h)

@@ -128,3 +128,86 @@ def test_device_matches_oracle(n, m, alt, seed):
         lpo, go = so.log_likelihood(x[k])
         assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo)
         np.testing.assert_allclose(grad[k], go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
+
+
+def _bam_order(F, rng):
+    """The same fragments with the mates of half of the pairs exchanged (what a caller holding mate1 / mate2 in BAM order
+    has): intervals and CIGAR ranges swapped, offsets rebuilt (first mates' operations, then second mates')."""
+    m = F["m"]
+    c1, c2 = np.asarray(F["cig1_ptr"]), np.asarray(F["cig2_ptr"])
+    sw = (np.asarray(F["m2_left"]) != 0) & (rng.random(m) < 0.5)
+    G = dict(F)
+    for a, b in (("m1_left", "m2_left"), ("m1_right", "m2_right")):
+        x, y = np.asarray(F[a]), np.asarray(F[b])
+        G[a], G[b] = np.where(sw, y, x), np.where(sw, x, y)
+    ops1, ops2 = [], []
+    for i in range(m):
+        r1, r2 = (c1[i], c1[i + 1]), (c2[i], c2[i + 1])
+        if sw[i]:
+            r1, r2 = r2, r1
+        ops1.append(r1); ops2.append(r2)
+    src, p1, p2 = [], [0], []
+    for a, b in ops1:
+        src += range(a, b); p1.append(len(src))
+    p2.append(len(src))
+    for a, b in ops2:
+        src += range(a, b); p2.append(len(src))
+    src = np.array(src, np.int64)
+    G["cig_op"] = np.asarray(F["cig_op"])[src] if src.size else np.zeros(1, np.uint8)
+    G["cig_len"] = np.asarray(F["cig_len"])[src] if src.size else np.zeros(1, np.int32)
+    G["cig1_ptr"], G["cig2_ptr"] = np.array(p1, np.int64), np.array(p2, np.int64)
+    return G, sw
+
+
+def test_order_mates_restores_the_leftmost_first_contract():
+    """the reference orders a pair's mates by leftpos itself (transcripts.jl:288-297); the C ABI requires that
+    order and the host wrapper establishes it.  Mates shuffled into 'BAM order' and passed through order_mates give the
+    oracle the same matrix as the original fragments."""
+    d = synth_aln.make(150, 4000, seed=9, p_single=0.2)
+    pmf, cdf, med = synth_aln.fraglen_model()
+    F = d["fragments"]
+    G, sw = _bam_order(F, np.random.default_rng(2))
+    assert sw.sum() > 1000 and (np.asarray(G["m2_left"])[sw] < np.asarray(G["m1_left"])[sw]).any()
+    H = XB.order_mates(G)
+    lft = np.asarray(H["m2_left"])
+    assert ((lft == 0) | (lft >= np.asarray(H["m1_left"]))).all()
+    outs = []
+    for frag in (F, H):
+        Ts, Fs, Ms, keep = XB.pack(d["transcripts"], frag, pmf, cdf, med, 0.9, False)
+        outs.append(OX.build(Ts, Fs, Ms, 150))
+    for k in ("tcolptr", "trowval", "tnzval", "row_fragment"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    # all single-end, cig2_ptr omitted
+    S = dict(F, m2_left=np.zeros(F["m"], np.int64), m2_right=np.zeros(F["m"], np.int64), cig2_ptr=None)
+    assert (XB.order_mates(S)["cig2_ptr"] == 0).all()
+
+
+@pytest.mark.gpu
+def test_device_validates_fragments_and_accepts_any_mate_order():
+    import polee_amd as P
+    from polee_amd import _lib as L
+    import ctypes as C
+    ctx = P.Context(0)
+    d = synth_aln.make(300, 20000, seed=3, p_single=0.15)
+    pmf, cdf, med = synth_aln.fraglen_model(180.0, 60.0)
+    ref = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, False, ctx=ctx)
+    G, sw = _bam_order(d["fragments"], np.random.default_rng(5))
+    got = XB.build_likelihood_matrix(d["transcripts"], G, pmf, cdf, med, 0.85, False, ctx=ctx)  # (wrapper orders the mates)
+    for k in ("tcolptr", "trowval", "tnzval", "row_fragment"):
+        np.testing.assert_array_equal(ref[k], got[k])
+
+    def raw(F):
+        Ts, Fs, Ms, keep = XB.pack(d["transcripts"], F, pmf, cdf, med, 0.85, False)
+        h = C.c_void_p()
+        rc = L.lib().polee_xbuild_run(ctx._h, C.byref(Ts), C.byref(Fs), C.byref(Ms), C.byref(h))
+        if rc == 0:
+            L.lib().polee_xbuild_destroy(h)
+        return rc
+    assert raw(d["fragments"]) == 0
+    assert raw(G) != 0  # mates not ordered: rejected, not silently a different X
+    bad = dict(d["fragments"]); c = np.array(bad["cig1_ptr"]); c[5] = c[4] - 1; bad["cig1_ptr"] = c
+    assert raw(bad) != 0  # offsets not monotone
+    bad = dict(d["fragments"]); r = np.array(bad["m1_right"]); r[7] = np.asarray(bad["m1_left"])[7] - 1; bad["m1_right"] = r
+    assert raw(bad) != 0  # right < left
+    bad = dict(d["fragments"]); ln = np.array(bad["cig_len"]); ln[0] = -3; bad["cig_len"] = ln
+    assert raw(bad) != 0 or np.diff(np.asarray(bad["cig1_ptr"]))[0] == 0  # negative operation length
