@@ -1631,7 +1631,8 @@ __global__ __launch_bounds__(256) void xwin_gather_kernel(const uint32_t *__rest
 constexpr uint32_t GWIN_HEAVY = 32;
 __global__ void gwin_reduce_kernel(const uint32_t *__restrict__ tslot_ptr, const uint32_t *__restrict__ tslot,
                                    const float *__restrict__ gwin, int K, int64_t n, float *__restrict__ g,
-                                   const double *__restrict__ lpwin, int nwg, double *__restrict__ lp)
+                                   const double *__restrict__ lpwin, int nwg, double *__restrict__ lp,
+                                   const uint32_t *__restrict__ gmap)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lp && blockIdx.x == 0 && threadIdx.x < K) {
@@ -1646,12 +1647,13 @@ __global__ void gwin_reduce_kernel(const uint32_t *__restrict__ tslot_ptr, const
     if (e1 - b > GWIN_HEAVY) return;
     float s = 0.0f;
     for (uint32_t e = b; e < e1; ++e) s += gwin[(size_t)tslot[e] * K + k];
-    g[i] += s;
+    g[gmap ? (size_t)gmap[j] * K + k : (size_t)i] += s;
 }
 __global__ __launch_bounds__(64) void gwin_reduce_heavy_kernel(const uint32_t *__restrict__ heavy,
                                                              const uint32_t *__restrict__ tslot_ptr,
                                                              const uint32_t *__restrict__ tslot,
-                                                             const float *__restrict__ gwin, int K, float *__restrict__ g)
+                                                             const float *__restrict__ gwin, int K, float *__restrict__ g,
+                                                             const uint32_t *__restrict__ gmap)
 {
     const uint32_t j = heavy[blockIdx.x];
     const uint32_t b = tslot_ptr[j], e1 = tslot_ptr[j + 1];
@@ -1660,7 +1662,7 @@ __global__ __launch_bounds__(64) void gwin_reduce_heavy_kernel(const uint32_t *_
         for (uint32_t e = b + threadIdx.x; e < e1; e += 64) s += gwin[(size_t)tslot[e] * K + k];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-        if (threadIdx.x == 0) g[(size_t)j * K + k] += s;
+        if (threadIdx.x == 0) g[(size_t)(gmap ? gmap[j] : j) * K + k] += s;
     }
 }
 
@@ -1687,7 +1689,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void single_rows_kernel(const float
         for (int k = 0; k < PSELL_MAX_K; ++k)
             if (k < K) {
                 const float xv = xr[k];
-                gr[k] += c / xv;
+                if (g) gr[k] += c / xv;
                 if (part) ls[k] = (double)c * log((double)xv);
             }
     }
@@ -2157,17 +2159,18 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         A.lpwin = ll->d_lpwin.p;
     }
     if (!ll->xwin_ready)
-        hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, ll->d_dict.p,
+        hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, A.dict,
                            A.x, ll->dict_len, ll->d_xwin.p);
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
     if (DET) {
+        const uint32_t *gmap = ll->cur_remap ? ll->cur_remap->index_of : nullptr;
         hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
-                           ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, G, A.lp);
+                           ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, G, A.lp, gmap);
         if (ll->d_theavy.n > 0)
             hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n), dim3(64), 0, st, ll->d_theavy.p,
-                               ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g);
+                               ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g, gmap);
     }
     return POLEE_OK;
 }
@@ -2182,7 +2185,9 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     static const bool no_ring_env = getenv("POLEE_NO_RING") != nullptr;
     const bool no_ring = no_ring_env || ll->force_mixed;
     static const int dbg = getenv("POLEE_DBG_ABLATE") ? atoi(getenv("POLEE_DBG_ABLATE")) : 0;
-    PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, ll->d_dict.p,
+    const LoglikRemap *rm = ll->cur_remap;
+    const uint32_t *csr_col = rm && rm->csr_col ? rm->csr_col : ll->d_csr_col.p;
+    PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, rm ? rm->dict : ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
                 (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
@@ -2207,11 +2212,11 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
         }
         if (ll->csr_rows > 0)  // stream C: rows kept in CSR (float atomics: like stream B, outside the deterministic guarantee)
             hipLaunchKernelGGL((loglik_csr_kernel<K, LP, KS>), dim3((unsigned)ceil_div(ll->csr_rows, 256)), dim3(256), 0, st,
-                               ll->d_csr_rowptr.p, ll->d_csr_col.p, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
+                               ll->d_csr_rowptr.p, csr_col, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
     } else {
         if (ll->csr_rows > 0)
             hipLaunchKernelGGL((loglik_csr_kernel<K, LP, KS>), dim3((unsigned)ceil_div(ll->csr_rows, 256)), dim3(256), 0, st,
-                               ll->d_csr_rowptr.p, ll->d_csr_col.p, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
+                               ll->d_csr_rowptr.p, csr_col, ll->d_csr_val.p, ll->d_csr_ks.p, ll->csr_rows, d_x, d_g, d_lp);
         // the cross-check switch: every tile as mixed slices with the per-run DPP kernel
         if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
         hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)h.num_tiles), dim3(256), lds_psell, st, A, 0,
@@ -2232,9 +2237,11 @@ static polee_status launch_k(polee_loglik *ll, const float *d_x, float *d_g, dou
                       : launch_variant<K, false, false>(ll, d_x, d_g, d_lp);
 }
 
-polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready)
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready,
+                                const LoglikRemap *remap)
 {
     ll->xwin_ready = xwin_ready;
+    ll->cur_remap = remap;
     polee_ctx *ctx = ll->ctx;
     if (K < 1 || K > PSELL_MAX_K) return fail(ctx, POLEE_ERR_BAD_ARG, "K must be in 1..8 (got %d)", K);
     // (the pass is a single launch: one pair of events brackets both the kernel and the pass)
@@ -2272,10 +2279,13 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
     }
     if (st != POLEE_OK && ll->d_dyn_ctr.p)  // a failed launch may have left draws behind: the next pass must start at position 0
         (void)hipMemsetAsync(ll->d_dyn_ctr.p, 0, 2 * sizeof(unsigned int), ctx->stream);
-    if (st == POLEE_OK && ll->has_singles) {
+    ll->cur_remap = nullptr;
+    // stream S; a caller whose forward kernel has already written cnt / x into g only needs the log-likelihood's share
+    if (st == POLEE_OK && ll->has_singles && !(remap && remap->singles_in_g && !d_lp)) {
         const int nb = (int)ceil_div(ll->n, SINGLE_THREADS);
-        hipLaunchKernelGGL(single_rows_kernel, dim3((unsigned)nb), dim3(SINGLE_THREADS), 0, ctx->stream, ll->d_single_cnt.p, d_x, K,
-                           ll->n, d_g, d_lp ? ll->d_single_part.p : nullptr);
+        hipLaunchKernelGGL(single_rows_kernel, dim3((unsigned)nb), dim3(SINGLE_THREADS), 0, ctx->stream,
+                           remap && remap->single_cnt ? remap->single_cnt : ll->d_single_cnt.p, d_x, K,
+                           ll->n, remap && remap->singles_in_g ? nullptr : d_g, d_lp ? ll->d_single_part.p : nullptr);
         if (d_lp)
             hipLaunchKernelGGL(single_lp_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ll->d_single_part.p, nb, K,
                                ll->host.single_logsum, d_lp);

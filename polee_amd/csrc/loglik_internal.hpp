@@ -140,6 +140,19 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
 
 }  // namespace polee
 
+namespace polee {
+// A caller that numbers the transcripts differently from X's columns (the VI loop numbers them in the tree's leaf order, so
+// that its x / gradient vectors are contiguous in the tree kernels) hands the pass the tables that name transcripts,
+// translated into its numbering; x and g are then indexed by that numbering.
+struct LoglikRemap {
+    const uint32_t *dict;       // [dict_len] the tile dictionaries
+    const float *single_cnt;    // [n] stream S's counts, or null
+    const uint32_t *csr_col;    // [csr_nnz] stream C's column ids, or null
+    const uint32_t *index_of;   // [n] transcript -> the caller's index (deterministic mode's per-transcript reduction)
+    bool singles_in_g;          // the caller has already put cnt / x into g (the VI loop's forward kernel does)
+};
+}  // namespace polee
+
 struct polee_loglik {
     polee_ctx *ctx = nullptr;
     int refs = 1;
@@ -158,6 +171,7 @@ struct polee_loglik {
     polee::DevBuf<float> d_single_cnt;    // stream S: [n] multiplicity-weighted count of single-transcript fragments
     polee::DevBuf<double> d_single_part;  // per-block partial sums of c_j log x_j[k] (lp only)
     bool has_singles = false;
+    const polee::LoglikRemap *cur_remap = nullptr;  // (per call) the caller's transcript numbering, see loglik_eval_device
     // the streaming kernel: per-pass x windows, static schedule (built for the grid of the first launch)
     polee::DevBuf<float> d_xwin;
     polee::DevBuf<polee::PosDesc> d_sched;
@@ -197,5 +211,6 @@ void loglik_retain(polee_loglik *ll);
 void loglik_release(polee_loglik *ll);
 // xwin_ready: the caller has already written the tiles' x windows (ll->d_xwin, through the slot lists d_tslot_ptr / d_tslot:
 // the VI loop's forward kernel does, saving the gather launch)
-polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready = false);
+polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float *d_g, double *d_lp, bool xwin_ready = false,
+                                const LoglikRemap *remap = nullptr);
 }  // namespace polee

@@ -78,23 +78,38 @@ __global__ void vi_init_mu_kernel(const double *ys, int64_t nm1, float *mu, floa
     alpha[k] = 0.0f;
 }
 
-__global__ void aos_to_rows_f32_kernel(const float *in, int K, int64_t n, float *out)
+// (index_of: leaf-order mode -- transcript j's values live at index_of[j])
+__global__ void aos_to_rows_f32_kernel(const float *in, int K, int64_t n, float *out, const uint32_t *index_of)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * K) return;
     const int k = (int)(i / n);
     const int64_t j = i - (int64_t)k * n;
-    out[i] = in[j * K + k];
+    out[i] = in[(index_of ? (int64_t)index_of[j] : j) * K + k];
+}
+
+// dst[i] = map[src[i]] / dst[i] = src[idx[i]]: the sparse pass's tables translated into the fit's leaf-order numbering
+__global__ void remap_u32_kernel(const uint32_t *src, const uint32_t *map, int64_t count, uint32_t *dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = map[src[i]];
+}
+template <typename T>
+__global__ void gather_kernel(const T *src, const int32_t *idx, int64_t count, T *dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[idx[i]];
 }
 
 // x_grad after the effective length adjustment, as rows [K][n] f64 (test hook output).
 __global__ void vi_xgrad_rows_kernel(const float *g, const float *efflens, const double *csum, GenePrior gp, int K,
-                                     int64_t n, double *out)
+                                     int64_t n, double *out, const uint32_t *index_of)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * K) return;
     const int k = (int)(i / n);
-    const int64_t tid = i - (int64_t)k * n;
+    // (leaf-order mode: g, efflens and gene_of are indexed by leaf position; the output stays in transcript order)
+    const int64_t tid = index_of ? (int64_t)index_of[i - (int64_t)k * n] : i - (int64_t)k * n;
     double xg = (double)g[tid * K + k];
     if (efflens) xg -= (double)((float)n * (1.0f / efflens[tid])) / csum[k];
     if (gp.gene_of) {  // (as bwd_values)
@@ -161,6 +176,14 @@ struct polee_vi {
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<float> d_zcur;  // [n-1][K] the current iteration's N(0,1) draws
     DevBuf<uint32_t> d_open_ptr, d_open_code;  // per forward-scan chunk: the tour's ENTER entries still open at its start
+    // Leaf-order mode (round 4): this fit numbers the transcripts by their position among the tree's leaves.  d_x, d_g,
+    // d_efflens and d_gene_of are indexed by leaf position -- the tree kernels' accesses to them are contiguous where
+    // they were gathers through leaf_tid -- and the sparse pass gets its transcript-naming tables translated once, here
+    // (LoglikRemap).  Results leave the handle in transcript order (index_of).
+    bool leaf_order = false;
+    DevBuf<uint32_t> d_index_of, d_dict_leaf, d_csr_col_leaf;
+    DevBuf<float> d_single_leaf;
+    LoglikRemap remap{nullptr, nullptr, nullptr, nullptr, false};
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
     DevBuf<int> d_flag;
@@ -189,6 +212,10 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     const int step_num = vi->step + 1;
     hipStream_t st = ctx->stream;
     const PttView view = t->view();
+    PttView lview = view;  // the view of the kernels that touch x / g: in leaf-order mode without the leaf -> transcript table
+    if (vi->leaf_order) lview.leaf_tid = nullptr;
+    const LoglikRemap *remap = vi->leaf_order ? &vi->remap : nullptr;
+    const uint32_t *index_of = vi->leaf_order ? vi->d_index_of.p : nullptr;
     const int nch_f = scan_num_chunks(t->TL), nch_b = scan_num_chunks(n);
     const float *eff = o.use_efflen_jacobian ? vi->d_efflens.p : nullptr;
     VK<K> *chunk_f = reinterpret_cast<VK<K> *>(t->d_chunk.p);
@@ -212,7 +239,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // so that the gather launch in front of the pass goes.  Measured at C2: the pass loses its 6.9 us gather, the forward
     // kernel gains ~17 us of scattered 24-byte stores behind two dependent loads -- 2 570 against 2 695 iterations/s.  Off.)
     static const bool xwin_fold = getenv("POLEE_VI_XWIN_FOLD") != nullptr && getenv("POLEE_NO_RING") == nullptr;
-    const bool xwin_here = xwin_fold && !vi->ll->force_mixed && vi->ll->d_xwin.p && vi->ll->d_tslot_ptr.p && vi->ll->host.num_tiles_s > 0;
+    const bool xwin_here = xwin_fold && !vi->leaf_order && !vi->ll->force_mixed && vi->ll->d_xwin.p && vi->ll->d_tslot_ptr.p && vi->ll->host.num_tiles_s > 0;
     if (open_lists) {
         // (the chunks' offsets come from the tree's open-edge lists: no reduce launch)
     } else if (nch_f > 1) {
@@ -221,19 +248,20 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     } else {
         POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
     }
-    hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
+    hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, vi->d_lyy.p, chunk_f,
                        vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
                        eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
                        (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
                        xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
-                       xwin_here ? vi->ll->d_xwin.p : nullptr);
+                       xwin_here ? vi->ll->d_xwin.p : nullptr,
+                       remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
     {
         const bool det_saved = vi->ll->deterministic;
         if (o.deterministic) vi->ll->deterministic = true;
-        const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr, xwin_here);
+        const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr, xwin_here, remap);
         vi->ll->deterministic = det_saved;
         POLEE_TRY(ls);
     }
@@ -250,10 +278,10 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
                            vi->d_efflens.p, vi->d_part_c.p, nch_f, (int64_t)n, gp, vi->d_gene_c.p);
     }
     // backward: double-double prefix over leaves of u * (g - efflen term)
-    hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
+    hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
                        eff, vi->d_part_c.p, nch_f, vi->d_csum.p, gp, chunk_b);
     if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
-    hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, view, vi->d_uleaf.p, vi->d_g.p,
+    hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
                        eff, vi->d_csum.p, gp, chunk_b, vi->d_C.p, own_b);
     POLEE_KERNEL_CHECK(ctx);
     if (want_values) {
@@ -263,7 +291,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     }
     if (hook_outputs) {
         hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st,
-                           vi->d_g.p, eff, vi->d_csum.p, gp, K, (int64_t)n, vi->d_xgrad_rows.p);
+                           vi->d_g.p, eff, vi->d_csum.p, gp, K, (int64_t)n, vi->d_xgrad_rows.p, index_of);
         POLEE_KERNEL_CHECK(ctx);
     }
     // update
@@ -458,6 +486,9 @@ void polee_vi_default_opts(polee_vi_opts *o)
     o->gene_of = nullptr;
 }
 
+// (polee_optimize_ptt drives the K = 1 kernels itself, in transcript order)
+static thread_local bool g_vi_plain_order = false;
+
 polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflens, const polee_vi_opts *opts,
                              polee_vi **out)
 {
@@ -574,6 +605,42 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         A(vi->d_gene_of.upload(ctx, o.gene_of, n));
         A(vi->d_gene_k.upload(ctx, gene_k));
         A(vi->d_gene_c.alloc(ctx, gene_k.size() * K));
+    }
+    // Leaf-order mode: the transcripts renumbered by leaf position for this fit (polee_vi::leaf_order)
+    static const bool no_leaf_env = getenv("POLEE_VI_NO_LEAF_ORDER") != nullptr;  // (A/B)
+    if (!no_leaf_env && !g_vi_plain_order && n > 1 && t->plans.size() == 1 && t->plans[0].tid_pos.size() == n) {
+        const PttPlan &pl = t->plans[0];
+        std::vector<uint32_t> index_of(n);
+        std::vector<float> eff_leaf(n);
+        for (size_t j = 0; j < n; ++j) index_of[j] = (uint32_t)pl.tid_pos[j];
+        for (size_t pos = 0; pos < n; ++pos) eff_leaf[pos] = efflens[pl.leaf_tid[pos]];
+        A(vi->d_index_of.upload(ctx, index_of));
+        A(vi->d_efflens.upload(ctx, eff_leaf));
+        if (!gene_k.empty()) {
+            std::vector<int32_t> gene_leaf(n);
+            for (size_t pos = 0; pos < n; ++pos) gene_leaf[pos] = o.gene_of[pl.leaf_tid[pos]];
+            A(vi->d_gene_of.upload(ctx, gene_leaf));
+        }
+        A(vi->d_dict_leaf.alloc(ctx, (size_t)std::max<int64_t>(ll->dict_len, 1)));
+        if (ll->csr_nnz > 0) A(vi->d_csr_col_leaf.alloc(ctx, (size_t)ll->csr_nnz));
+        if (ll->has_singles) A(vi->d_single_leaf.alloc(ctx, n));
+        if (s == POLEE_OK) {
+            hipStream_t st0 = ctx->stream;
+            if (ll->dict_len > 0)
+                hipLaunchKernelGGL(remap_u32_kernel, dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st0,
+                                   (const uint32_t *)ll->d_dict.p, (const uint32_t *)vi->d_index_of.p, ll->dict_len, vi->d_dict_leaf.p);
+            if (ll->csr_nnz > 0)
+                hipLaunchKernelGGL(remap_u32_kernel, dim3((unsigned)ceil_div(ll->csr_nnz, 256)), dim3(256), 0, st0,
+                                   (const uint32_t *)ll->d_csr_col.p, (const uint32_t *)vi->d_index_of.p, ll->csr_nnz, vi->d_csr_col_leaf.p);
+            if (ll->has_singles)
+                hipLaunchKernelGGL(gather_kernel<float>, dim3((unsigned)ceil_div((int64_t)n, 256)), dim3(256), 0, st0,
+                                   (const float *)ll->d_single_cnt.p, (const int32_t *)t->d_leaf_tid.p, (int64_t)n, vi->d_single_leaf.p);
+            if (hipGetLastError() != hipSuccess) A(fail(ctx, POLEE_ERR_HIP, "leaf-order tables: kernel launch failed"));
+            vi->leaf_order = true;
+            // (the singles' cnt / x goes into g in the forward kernel: one launch and one pass over g less per iteration)
+            vi->remap = LoglikRemap{vi->d_dict_leaf.p, ll->has_singles ? vi->d_single_leaf.p : nullptr,
+                                    ll->csr_nnz > 0 ? vi->d_csr_col_leaf.p : nullptr, vi->d_index_of.p, ll->has_singles};
+        }
     }
     vi->o.gene_of = nullptr;  // (host memory is borrowed for the call only)
     vi->trace_cap = o.gradonly ? 0 : std::max(o.num_steps, 1);
@@ -758,7 +825,7 @@ polee_status polee_vi_eval_gradients(polee_vi *vi, float *xs, double *x_grad, do
     POLEE_TRY(vi->one_step(false, true, true));
     if (xs) {
         hipLaunchKernelGGL(aos_to_rows_f32_kernel, dim3((unsigned)ceil_div(n * K, 256)), dim3(256), 0, ctx->stream,
-                           vi->d_x.p, (int)K, (int64_t)n, vi->d_x_rows.p);
+                           vi->d_x.p, (int)K, (int64_t)n, vi->d_x_rows.p, vi->leaf_order ? (const uint32_t *)vi->d_index_of.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
         POLEE_TRY(vi->d_x_rows.download(ctx, xs, n * K));
     }
@@ -799,7 +866,10 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
     o.num_steps = num_steps;
     o.num_mc_samples = 1;
     polee_vi *vi = nullptr;
-    POLEE_TRY(polee_vi_create(ll, t, efflens, &o, &vi));  // initial z = logit(inverse_transform(1/n)) lands in d_mu
+    g_vi_plain_order = true;
+    const polee_status cs = polee_vi_create(ll, t, efflens, &o, &vi);  // initial z = logit(inverse_transform(1/n)) lands in d_mu
+    g_vi_plain_order = false;
+    POLEE_TRY(cs);
     polee_ctx *ctx = vi->ctx;
     hipStream_t st = ctx->stream;
     const int32_t n = vi->n;
@@ -821,7 +891,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
                            vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr, (const float *)nullptr);
         POLEE_KERNEL_CHECK(ctx);
         return POLEE_OK;
     };

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                                                                    const uint32_t *__restrict__ open_code,
                                                                    const uint32_t *__restrict__ tslot_ptr,
                                                                    const uint32_t *__restrict__ tslot,
-                                                                   float *__restrict__ xwin)
+                                                                   float *__restrict__ xwin,
+                                                                   const float *__restrict__ single_cnt)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
@@ -274,8 +275,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
             const uint32_t type = code[j] & 3u;
             if (type == TOUR_LEAF) {
                 const int pos = v.tour_tgt[base + j];
-                const int tid = v.leaf_tid[pos];
+                // (leaf-order mode, v.leaf_tid == null: the fit numbers the transcripts by leaf position, so xs, g, efflens
+                // and single_cnt are indexed by pos and a chunk's leaves write one contiguous piece of each)
+                const int tid = v.leaf_tid ? v.leaf_tid[pos] : pos;
                 const float inv_l = efflens ? 1.0f / efflens[tid] : 0.0f;
+                // stream S of the sparse pass (loglik_internal.hpp): the fragments compatible with this transcript alone
+                // add cnt / x to its gradient -- g starts from that instead of 0
+                const float sc = single_cnt ? single_cnt[tid] : 0.0f;
 #pragma unroll
                 for (int d = 0; d < K; ++d) {
                     const double u = exp(inc.v[d] + edge[j].v[d]);
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
                     x = (float)fmax((double)x, 1e-16);
                     x = fminf(fmaxf(x, clamp_lo), clamp_hi);
                     xs[(size_t)tid * K + d] = x;
-                    g[(size_t)tid * K + d] = 0.0f;
+                    g[(size_t)tid * K + d] = sc != 0.0f ? sc / x : 0.0f;
                     pc[d] += (double)(x * inv_l);  // xls[i] = xs[i] / efflens[i] in f32 (likelihood.jl:97)
                 }
                 if (xwin) {
@@ -349,7 +355,7 @@ __device__ inline void bwd_values(const PttView &v, int64_t pos, const double *_
                                   const float *__restrict__ g, const float *__restrict__ efflens,
                                   const double *csum, const GenePrior &gp, VD<K> &a)
 {
-    const int tid = v.leaf_tid[pos];
+    const int tid = v.leaf_tid ? v.leaf_tid[pos] : (int)pos;  // (leaf-order mode: see vi_fwd_apply_kernel)
     const float inv_lf = efflens ? 1.0f / efflens[tid] : 0.0f;
     const float nl = (float)v.n * inv_lf;  // Int * Float32 -> Float32 in the reference
     int gene = -1, kg = 0;

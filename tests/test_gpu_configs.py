@@ -72,6 +72,41 @@ def test_c2_loglik_and_gradient_match_oracle(P, c2):
     assert rel_long.max() < 1e-4
 
 
+@pytest.mark.parametrize("case", ["literal", "dropout 0.3"])
+def test_c2_size_set_diverse_inputs_match_oracle(P, case):
+    """the C2-size oracle comparison on the inputs the generator does not flatter -- every fragment its
+    own random subset of its gene's isoforms (SURVEY 8(d) read literally) and per-entry dropout 0.3 -- which route a large
+    share of X through the dense-union, masked and wide streams.  Same tolerances as the C2 test above."""
+    from tools import synth
+    kw = dict(literal=True) if case == "literal" else dict(dropout=0.3)
+    smp = synth.make_sample(N, M, NNZ_PER_FRAG, seed=123456789, **kw)
+    ctx = P.Context(0)
+    s = P.RNASeqSample(M, N, None, None, None, smp["effective_lengths"], ctx=ctx,
+                       xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
+    info = s.info
+    assert sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == M and info["stream_tiles"][5] == 0
+    assert info["stream_nnz"][1] + info["stream_nnz"][2] + info["stream_nnz"][3] > 0.25 * smp["nnz"]  # not the A1 stream's show
+    colptr, rowval, nzval = synth.to_csc(smp)
+    so = O.Sample(M, N, colptr, rowval, nzval)
+    del colptr, rowval, nzval
+    O.set_num_threads(O.physical_cores())
+    rng = np.random.default_rng(1)
+    K = 6
+    x = rng.gamma(0.3, size=(K, N)).astype(np.float32) + np.float32(1e-7)
+    x /= x.sum(axis=1, keepdims=True)
+    x = np.clip(x, np.float32(1e-10), 1)
+    lp, g = s.log_likelihood(x)
+    worst = 0.0
+    for k in range(K):
+        lpo, go = so.log_likelihood(x[k])
+        assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo), (case, k, lp[k], lpo)
+        scale = np.abs(go).max()
+        worst = max(worst, float((np.abs(g[k] - go) / (np.abs(go) + 1e-2 * scale)).max()))
+        np.testing.assert_allclose(g[k], go, rtol=1e-4, atol=1e-6 * scale)
+    print("C2-size %s: shares of nnz %s, worst weighted gradient error %.3g" % (
+        case, [round(v / smp["nnz"], 3) for v in info["stream_nnz"]], worst))
+
+
 def test_c2_three_vi_iterations_match_oracle(P, c2):
     """Three whole iterations (sampling, tree transform, likelihood over the 240 M non-zeros, backward, ADAM) with the
     same z0 on both sides (likelihood-approximation.jl:496-572)."""

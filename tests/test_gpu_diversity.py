@@ -49,7 +49,9 @@ def test_diverse_sets_match_oracle(P, ctx, case, K):
     info = s.info
     assert sum(info["stream_nnz"]) == smp["nnz"] and sum(info["stream_rows"]) == m
     assert info["stream_nnz"][1] > 0.02 * smp["nnz"], info["stream_nnz"]  # the masked streams are in use
-    assert info["stream_nnz"][3] > 0.01 * smp["nnz"], info["stream_nnz"]
+    # (round 4: a leftover slice is stored dense unless masking HALVES it -- the wide masked stream keeps 8 % of the
+    # non-zeros at dropout 0.3 and a few tenths of a per cent in the other two cases)
+    assert info["stream_nnz"][3] > (0.05 if case == "dropout 0.3" else 0.002) * smp["nnz"], info["stream_nnz"]
     assert info["stream_nnz"][4] < 0.05 * smp["nnz"], info["stream_nnz"]  # ... and little is left to the mixed one
     assert info["stream_tiles"][5] == 0  # one launch
     # never more bytes than CSR, whatever the sets look like

@@ -16,7 +16,7 @@ for input in $INPUTS; do
   esac
   for i in "${!ARR[@]}"; do
     set_=${ARR[$i]}
-    env $set_ timeout 600 python3 bench.py $ARGS --steps 20 --warmup 5 --cpu-steps 0 --prewarm 150 2> $OUT/${input}_$i.err | tail -1 > $OUT/${input}_$i.json
+    env $set_ timeout 600 python3 bench.py $ARGS --steps ${STEPS:-50} --warmup 5 --cpu-steps 0 --prewarm ${PREWARM:-300} 2> $OUT/${input}_$i.err | tail -1 > $OUT/${input}_$i.json
     python3 - "$input" "$set_" $OUT/${input}_$i.json <<'PY'
 import sys, json
 try:
