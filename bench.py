@@ -216,13 +216,94 @@ def regression_bench(args):
             "config": {"workload": "%s: regression step, S=%d samples x F=%d factors x n=%d transcripts, 15 hinges, "
                                    "likelihood on, device RNG" % (args.workload.upper(), S, F, n),
                        "parallelism": "samples sharded over %d GPU(s), %d on rank 0, one all-reduce of (F+2) n f32 "
-                                      "statistics per step" % (world, reg.num_samples) if world > 1 else "1 GPU"},
+                                      "statistics per step" % (world, reg.num_samples) if world > 1 else "1 GPU",
+                       "comm": comm.info() if comm is not None else None},
             "detail": {"loss_first": float(trace[0]), "loss_last": float(trace[-1]),
                        "finite": bool(np.all(np.isfinite(trace))), "parameters": reg.num_params,
                        "note": "latency / gather bound (SURVEY.md 8(d)): no roofline claim for this step"},
         }))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def roofline_of(info, st0, st1, m, n, K, deterministic=False):
+    """The `roofline` object of one measured input (stats of the fit before / after the timed steps).
+    ALGORITHMIC bytes of a pass (CSR with u32 ids) and the bytes the device layout PHYSICALLY moves: the slice
+    streams read once + the x windows read and the gradient windows added (dictionary entries x K x 4 B each way).  The
+    layout stores a slice's transcript ids once (or as a 16-bit mask per fragment) and collapses single-transcript
+    fragments, so physical < algorithmic and "algorithmic bytes / time" can exceed the HBM peak without the memory system
+    being saturated: `frac` is therefore the PHYSICAL fraction -- bytes that really move / kernel time / peak -- and the
+    contract's CSR-equivalent figure is reported beside it as `effective_*`.  The dominant kernel is the persistent launch
+    over the sliced streams; the x-window gather, stream S's per-transcript kernel and (rare) the mixed stream's second
+    launch are inside `pass_ms`."""
+    launches = st1["loglik_kernel_launches"] - st0["loglik_kernel_launches"]
+
+    def avg(key):
+        return ((st1[key] * st1["loglik_kernel_launches"] - st0[key] * st0["loglik_kernel_launches"])
+                / max(launches, 1))
+
+    kern_ms, pass_ms = avg("loglik_kernel_ms_avg"), avg("loglik_pass_ms_avg")
+    bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
+    sb = info["stream_bytes_hbm"]
+    win_bytes = 2 * 4 * K * info.get("dict_entries", 0)
+    phys_bytes_pass = sum(sb) + win_bytes
+    uniform_share = sum(info["stream_nnz"][:5]) / max(info["nnz"], 1)  # (streams 0..4: the persistent launch)
+    phys_bytes_dom = sum(sb[:5]) + win_bytes * (sum(info["stream_tiles"][:5]) / max(sum(info["stream_tiles"]), 1))
+    bytes_dom = bytes_pass * uniform_share
+    achieved = phys_bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    effective = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "definition": "achieved = bytes the device layout moves per launch (slice streams + x / gradient windows) / "
+                      "kernel time; effective_* = SURVEY 8(d)'s CSR-equivalent bytes of the same rows / the same time",
+        "kernel": "loglik_stream_kernel<%d, false, false, %s>" % (K, "true" if deterministic else "false"),
+        "kernel_ms_avg": kern_ms, "pass_ms_avg": pass_ms, "launches": int(launches),
+        "physical_bytes_per_launch": phys_bytes_dom,
+        "algorithmic_bytes_per_launch": bytes_dom,
+        "effective_GBs": effective, "effective_frac": effective / HBM_PEAK_GBS,
+        "physical_over_algorithmic": phys_bytes_dom / max(bytes_dom, 1),
+        # the whole pass, same two definitions
+        "pass_physical_GBs": phys_bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
+        "pass_effective_GBs": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
+        "stream_share_of_nnz": [v / max(info["nnz"], 1) for v in info["stream_nnz"]],
+        "stream_bytes_per_nnz": [b / max(v, 1) for b, v in zip(sb, info["stream_nnz"])],
+        "layout_bytes_per_nnz": sum(sb) / max(info["nnz"], 1), "csr_bytes_per_nnz": (8 * info["nnz"] + 4 * (m + 1)) / max(info["nnz"], 1),
+        "accumulate": "f32 row sums and gradient sums (MFMA + f32 atomics); the reference multiplies in f32 and accumulates in "
+                      "f64 (sparse.jl:13-17,32-36): within 1e-4 of it at C2 / C5 (tests/test_gpu_configs.py)",
+    }
+
+
+def measure_other_input(P, synth, ctx, name, smp, args, K):
+    """roofline.by_input: the same measurement (prewarm, warmup, timed steps; the fit's own HIP events) on another input of
+    the same size class, after the headline's handles are gone.  Returns a compact dict."""
+    parents, js = synth.make_tree(smp["gene"], seed=args.seed, kind=args.tree)
+    m, n = smp["m"], smp["n"]
+    sample = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ctx,
+                            xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
+    tree = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    if args.prewarm > 0:
+        pre = P.LikelihoodApproximationFit(sample, tree, num_steps=args.prewarm, num_mc_samples=K, seed=args.seed + 1)
+        pre.run(args.prewarm)
+        pre.sync()
+        del pre
+    fit = P.LikelihoodApproximationFit(sample, tree, num_steps=args.warmup + args.steps, num_mc_samples=K, seed=args.seed,
+                                       profile=True, deterministic=args.deterministic)
+    fit.run(args.warmup)
+    fit.sync()
+    st0 = fit.stats()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    fit.run(args.steps)
+    fit.sync()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    r = roofline_of(sample.info, st0, fit.stats(), m, n, K, args.deterministic)
+    return {"input": name, "n": n, "m": m, "nnz": sample.info["nnz"], "value": args.steps / elapsed, "unit": "VI iters/s",
+            "ms_per_step": 1e3 * elapsed / args.steps, "kernel_ms_avg": r["kernel_ms_avg"], "pass_ms_avg": r["pass_ms_avg"],
+            "frac": r["frac"], "achieved": r["achieved"], "effective_frac": r["effective_frac"],
+            "physical_bytes_per_launch": r["physical_bytes_per_launch"], "layout_bytes_per_nnz": r["layout_bytes_per_nnz"],
+            "stream_share_of_nnz": r["stream_share_of_nnz"]}
 
 
 def main():
@@ -247,12 +328,20 @@ def main():
     ap.add_argument("--set-diversity", type=float, default=0.0, metavar="P",
                     help="per-entry dropout probability of the generator (first entry of a fragment kept): fragments of a "
                          "gene stop sharing a handful of transcript sets; 0 = the generator as built")
-    ap.add_argument("--literal-subsets", action="store_true",
-                    help="every fragment draws its own random subset of its gene's isoforms (SURVEY 8(d)'s literal wording) "
-                         "instead of one of the gene's <= 12 compatibility patterns")
+    ap.add_argument("--generator", default="literal", choices=["literal", "patterns"],
+                    help="set structure of the synthetic sample.  literal (default since round 4, the headline): every fragment "
+                         "draws its OWN random non-empty subset of its gene's isoforms -- SURVEY 8(d)'s wording.  patterns: "
+                         "the generator of rounds 1-3, a fragment draws one of its gene's <= 12 compatibility patterns (what "
+                         "exon structure induces in real data: few distinct sets per gene); reported under roofline.by_input")
+    ap.add_argument("--literal-subsets", action="store_true", help="(kept for scripts) same as --generator literal")
+    ap.add_argument("--no-by-input", action="store_true",
+                    help="skip the two extra inputs of roofline.by_input (the other generator and the tiled real fixture)")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
+    if args.literal_subsets:
+        args.generator = "literal"
+    args.literal_subsets = args.generator == "literal"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)  # nothing above this line touches the GPU
     if args.workload in ("c3", "c4"):
@@ -354,29 +443,7 @@ def main():
 
     elapsed = ranks.max(elapsed)  # slowest rank
 
-    launches = st1["loglik_kernel_launches"] - st0["loglik_kernel_launches"]
-
-    def avg(key):
-        return ((st1[key] * st1["loglik_kernel_launches"] - st0[key] * st0["loglik_kernel_launches"])
-                / max(launches, 1))
-
-    kern_ms, pass_ms = avg("loglik_kernel_ms_avg"), avg("loglik_pass_ms_avg")
-    # ALGORITHMIC bytes of a pass (CSR with u32 ids) and the bytes the device layout PHYSICALLY moves: the
-    # slice streams read once + the x windows read and the gradient windows added (dictionary entries x K x 4 B each
-    # way).  The layout stores a slice's transcript ids once (or as a 16-bit mask per fragment), so physical < algorithmic
-    # and "algorithmic bytes / time" can exceed the HBM peak without the memory system being saturated: `frac` is therefore
-    # the PHYSICAL fraction -- bytes that really move / kernel time / peak -- and the CSR-equivalent figure is reported
-    # beside it as `effective_*`.  The dominant kernel is the persistent launch over the uniform streams; the mixed
-    # stream's tiles (rows that fit no uniform slice) run in a second launch, inside `pass_ms`.
-    bytes_pass = algorithmic_bytes_per_pass(info["nnz"], m, n, K)
-    sb = info["stream_bytes_hbm"]
-    win_bytes = 2 * 4 * K * info.get("dict_entries", 0)
-    phys_bytes_pass = sum(sb) + win_bytes
-    uniform_share = sum(info["stream_nnz"][:5]) / max(info["nnz"], 1)  # (streams 0..4: the persistent launch; 5: the per-tile kernel's)
-    phys_bytes_dom = sum(sb[:5]) + win_bytes * (sum(info["stream_tiles"][:5]) / max(sum(info["stream_tiles"]), 1))
-    bytes_dom = bytes_pass * uniform_share
-    achieved = phys_bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    effective = bytes_dom / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    roof = roofline_of(info, st0, st1, m, n, K, args.deterministic)
     sid = source_id()
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile.sh): a capture is
     # valid for the build and the workload it was taken with -- otherwise null
@@ -390,6 +457,9 @@ def main():
                 traffic = cap.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    roof["traffic"] = traffic
+    input_name = ("tiled_real_fixture_x639" if args.workload == "fixture" else
+                  ("literal_subsets" if args.literal_subsets else "gene_patterns") + ("_dropout_%g" % args.set_diversity if args.set_diversity else ""))
 
     out = {
         "metric": "approx-lik VI iters/sec",
@@ -406,32 +476,20 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s: one sample per GPU, n=%d transcripts x m=%d fragments, nnz=%d (%.2f/fragment), "
-                        "K=%d draws per VI iteration, %s tree" % (args.workload.upper(), n, m, info["nnz"],
-                                                                  info["nnz"] / m, K, args.tree),
+                        "K=%d draws per VI iteration, %s tree; set structure: %s" % (
+                            args.workload.upper(), n, m, info["nnz"], info["nnz"] / m, K, args.tree,
+                            "the reference's real fixture tiled x639" if args.workload == "fixture" else
+                            ("every fragment its own random subset of its gene's isoforms (SURVEY 8(d) literally)"
+                             if args.literal_subsets else "one of <= 12 compatibility patterns per gene (generator of rounds 1-3)")
+                            + (", per-entry dropout %g" % args.set_diversity if args.set_diversity else "")),
+            "input": input_name, "comm": comm.info() if comm is not None else None,
             "samples_per_gpu": S, "draws": K, "tree": args.tree, "nnz": info["nnz"], "deterministic": bool(args.deterministic),
             "set_diversity": args.set_diversity, "literal_subsets": bool(args.literal_subsets),
             "parallelism": "one sample row-sharded over %d GPU(s), 1 all-reduce of K*n f32 per pass" % world
                            if args.row_shard else "sample-per-GPU x%d, no collective" % world if S == 1 else
                            "%d concurrent samples per GPU x%d GPUs, no collective" % (S, world),
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "definition": "achieved = bytes the device layout moves per launch (slice streams + x / gradient windows) / "
-                          "kernel time; effective_* = SURVEY 8(d)'s CSR-equivalent bytes of the same rows / the same time",
-            "kernel": "loglik_stream_kernel<%d, false, false, %s>" % (K, "true" if args.deterministic else "false"),
-            "kernel_ms_avg": kern_ms, "pass_ms_avg": pass_ms, "launches": int(launches),
-            "physical_bytes_per_launch": phys_bytes_dom,
-            "algorithmic_bytes_per_launch": bytes_dom,
-            "effective_GBs": effective, "effective_frac": effective / HBM_PEAK_GBS,
-            "physical_over_algorithmic": phys_bytes_dom / max(bytes_dom, 1),
-            # the whole pass (gather + persistent launch + the mixed stream's launch), same two definitions
-            "pass_physical_GBs": phys_bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
-            "pass_effective_GBs": bytes_pass / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0,
-            "stream_share_of_nnz": [v / max(info["nnz"], 1) for v in info["stream_nnz"]],
-            "stream_bytes_per_nnz": [b / max(v, 1) for b, v in zip(sb, info["stream_nnz"])],
-            "layout_bytes_per_nnz": sum(sb) / max(info["nnz"], 1), "csr_bytes_per_nnz": (8 * info["nnz"] + 4 * (m + 1)) / max(info["nnz"], 1),
-        },
+        "roofline": roof,
         "detail": {
             "source_id": sid, "hip_event_ms_per_step": ev_ms / args.steps, "prewarm_steps": args.prewarm, "gen_s": t_gen, "device_layout_build_s": t_build,
             "padded_nnz_ratio": info["padded_nnz"] / max(info["nnz"], 1), "num_tiles": info["num_tiles"],
@@ -439,7 +497,38 @@ def main():
         },
     }
 
+    main_entry = {"input": input_name, "n": n, "m": m, "nnz": info["nnz"], "value": out["value"], "unit": "VI iters/s",
+                  "ms_per_step": out["ms_per_step"], "kernel_ms_avg": roof["kernel_ms_avg"], "pass_ms_avg": roof["pass_ms_avg"],
+                  "frac": roof["frac"], "achieved": roof["achieved"], "effective_frac": roof["effective_frac"],
+                  "physical_bytes_per_launch": roof["physical_bytes_per_launch"],
+                  "layout_bytes_per_nnz": roof["layout_bytes_per_nnz"], "stream_share_of_nnz": roof["stream_share_of_nnz"]}
+    roof["by_input"] = {input_name: main_entry}
+
+    cpu_inputs = None
     if rank == 0 and world == 1 and args.cpu_steps > 0 and S == 1:
+        cpu_inputs = (smp, parents, js)
+    by_input_wanted = (rank == 0 and world == 1 and S == 1 and not args.row_shard and not args.no_by_input
+                       and args.workload == "c2" and not args.set_diversity)
+    if by_input_wanted:
+        # The same measurement on the inputs the headline's generator is not: the other generator at the same size, and
+        # the reference's real fixture tiled to n = 200 k (real set structure: 54 % single-transcript fragments, 2.2
+        # non-zeros per fragment).  The headline's device handles are released first.
+        del fits, fit, sample, tree, extra, sample_i, tree_i, xt_i, smp_i  # (smp stays for the CPU baseline)
+        import gc
+        gc.collect()
+        for name, make in (("gene_patterns" if args.literal_subsets else "literal_subsets",
+                            lambda: synth.make_sample(n, m, mean_nnz, seed=sample_seed(args.seed, 0), literal=not args.literal_subsets)),
+                           ("tiled_real_fixture_x639", lambda: synth.tile_fixture(639))):
+            try:
+                smp_o = make()
+                roof["by_input"][name] = measure_other_input(P, synth, ctx, name, smp_o, args, K)
+                del smp_o
+                gc.collect()
+            except Exception as e:  # (never lose the headline line to a by-product)
+                roof["by_input"][name] = {"input": name, "error": repr(e)}
+
+    if cpu_inputs is not None:
+        smp, parents, js = cpu_inputs
         # CPU baseline: the oracle (a port that keeps the reference's loop structure: CSR pass
         # threaded over fragments, CSC pass threaded over transcripts, serial tree walks) on the host cores.
         from oracle import oracle as O

@@ -334,6 +334,9 @@ polee_status polee_comm_create_host(polee_ctx *ctx, int32_t nranks, int32_t rank
 void polee_comm_destroy(polee_comm *comm);
 int32_t polee_comm_rank(const polee_comm *comm);
 int32_t polee_comm_size(const polee_comm *comm);
+/* what the transport itself reports: *transport = 1 RCCL / 2 host-staged; *count, *user_rank = ncclCommCount,
+ * ncclCommUserRank of the RCCL communicator (the creation arguments for a host communicator); any pointer may be NULL */
+polee_status polee_comm_info(const polee_comm *comm, int32_t *transport, int32_t *count, int32_t *user_rank);
 /* sum over ranks of a host buffer (convenience; the VI loop reduces device buffers in place) */
 polee_status polee_allreduce_sum_f32(polee_comm *comm, float *buf, int64_t count);
 /* make `vi` a row-sharded fit: its likelihood handle holds this rank's block of rows */

@@ -460,6 +460,13 @@ class Comm:
         except Exception:
             pass
 
+    def info(self):
+        """What the transport reports (polee_comm_info): dict(transport "rccl" | "host", count, rank) -- for RCCL the
+        communicator's own ncclCommCount / ncclCommUserRank."""
+        t, n, r = C.c_int32(), C.c_int32(), C.c_int32()
+        check(L.lib().polee_comm_info(self._h, C.byref(t), C.byref(n), C.byref(r)), self.ctx._h)
+        return dict(transport={1: "rccl", 2: "host"}.get(t.value, "?"), count=n.value, rank=r.value)
+
     def allreduce_sum(self, values):
         """Sum of a float32 array over the ranks (polee_allreduce_sum_f32)."""
         v = arr(values, np.float32).copy()

@@ -18,6 +18,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
 };
 
 Rccl *rccl(std::string &err)
@@ -53,6 +55,8 @@ Rccl *rccl(std::string &err)
             r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
             r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+            r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+            r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
         }
     }
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
@@ -181,6 +185,28 @@ polee_status polee_allreduce_sum_f32(polee_comm *c, float *buf, int64_t count)
     POLEE_TRY(d.upload(ctx, buf, (size_t)count));
     POLEE_TRY(comm_allreduce_device(c, d.p, (size_t)count, false));
     return d.download(ctx, buf, (size_t)count);
+}
+
+// What the TRANSPORT says (first-contact evidence for the multi-GPU runs nobody could make yet):
+// *transport = 1 RCCL, 2 host-staged callback; *count / *user_rank = ncclCommCount / ncclCommUserRank of the RCCL
+// communicator (the creation arguments for a host communicator).
+polee_status polee_comm_info(const polee_comm *c, int32_t *transport, int32_t *count, int32_t *user_rank)
+{
+    if (!c) return fail(nullptr, POLEE_ERR_BAD_ARG, "null communicator");
+    int t = c->host_allreduce ? 2 : 1, n = c->nranks, rk = c->rank;
+    if (!c->host_allreduce && c->comm) {
+        std::string err;
+        Rccl *r = rccl(err);
+        if (r && r->CommCount && r->CommUserRank) {
+            if (r->CommCount(static_cast<ncclComm_t>(c->comm), &n) != ncclSuccess ||
+                r->CommUserRank(static_cast<ncclComm_t>(c->comm), &rk) != ncclSuccess)
+                return fail(c->ctx, POLEE_ERR_COMM, "ncclCommCount / ncclCommUserRank failed");
+        }
+    }
+    if (transport) *transport = t;
+    if (count) *count = n;
+    if (user_rank) *user_rank = rk;
+    return POLEE_OK;
 }
 
 int32_t polee_comm_rank(const polee_comm *c) { return c ? c->rank : -1; }

@@ -6,10 +6,10 @@ TAG=${1:-run}; WL=${2:-c2}; shift; shift
 OUT=gpurun_out/diversity_$TAG
 mkdir -p $OUT
 COMMON="--steps 20 --warmup 5 --cpu-steps 0 $*"
-python3 bench.py --workload $WL $COMMON > $OUT/p0.json 2> $OUT/p0.err
-python3 bench.py --workload $WL --set-diversity 0.1 $COMMON > $OUT/p0.1.json 2> $OUT/p0.1.err
-python3 bench.py --workload $WL --set-diversity 0.3 $COMMON > $OUT/p0.3.json 2> $OUT/p0.3.err
-python3 bench.py --workload $WL --literal-subsets $COMMON > $OUT/literal.json 2> $OUT/literal.err
+python3 bench.py --workload $WL --generator patterns --no-by-input $COMMON > $OUT/p0.json 2> $OUT/p0.err
+python3 bench.py --workload $WL --generator patterns --set-diversity 0.1 $COMMON > $OUT/p0.1.json 2> $OUT/p0.1.err
+python3 bench.py --workload $WL --generator patterns --set-diversity 0.3 $COMMON > $OUT/p0.3.json 2> $OUT/p0.3.err
+python3 bench.py --workload $WL --generator literal --no-by-input $COMMON > $OUT/literal.json 2> $OUT/literal.err
 python3 bench.py --workload fixture $COMMON > $OUT/fixture.json 2> $OUT/fixture.err
 python3 - $OUT <<'PY'
 import json, sys, os

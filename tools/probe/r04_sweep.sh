@@ -8,10 +8,10 @@ OUT=gpurun_out/sweep_$TAG; mkdir -p $OUT
 IFS='|' read -ra ARR <<< "$SETS"
 for input in $INPUTS; do
   case $input in
-    p0) ARGS="--workload c2" ;;
-    p0.1) ARGS="--workload c2 --set-diversity 0.1" ;;
-    p0.3) ARGS="--workload c2 --set-diversity 0.3" ;;
-    literal) ARGS="--workload c2 --literal-subsets" ;;
+    p0) ARGS="--workload c2 --generator patterns --no-by-input" ;;
+    p0.1) ARGS="--workload c2 --generator patterns --set-diversity 0.1" ;;
+    p0.3) ARGS="--workload c2 --generator patterns --set-diversity 0.3" ;;
+    literal) ARGS="--workload c2 --generator literal --no-by-input" ;;
     fixture) ARGS="--workload fixture" ;;
   esac
   for i in "${!ARR[@]}"; do

@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5  # (scratch of earlier runs would mix into the summary)
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --cpu-steps 0 --prewarm 100 $*"
+ARGS="--steps 10 --warmup 2 --cpu-steps 0 --prewarm 100 --no-by-input $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc1 -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc2 -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc2.err
@@ -22,6 +22,19 @@ out = {}
 for f in glob.glob('trace/**/*kernel_stats.csv', recursive=True):
     rows = list(csv.DictReader(open(f)))
     out['kernel_stats'] = rows[:15]
+# per-kernel MEDIAN duration from the dispatch trace (the stats CSV only has the mean, which one slow first launch shifts)
+for f in glob.glob('trace/**/*kernel_trace.csv', recursive=True):
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        try:
+            dur[r['Kernel_Name']].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+        except (KeyError, ValueError):
+            pass
+    med = {}
+    for k, v in dur.items():
+        v.sort()
+        med[k] = {'calls': len(v), 'median_ns': v[len(v) // 2], 'mean_ns': sum(v) / len(v), 'min_ns': v[0], 'max_ns': v[-1]}
+    out['kernel_medians'] = med
 for d in ('pmc1','pmc2','pmc3','pmc4','pmc5'):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))

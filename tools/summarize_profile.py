@@ -25,11 +25,17 @@ except Exception:
     pass
 dom = [k for k in s.get("pmc", {}) if "loglik_stream_kernel<6" in k]
 lines = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), "",
-         "Command: `tools/profile.sh %s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-steps 0`" % tag,
+         "Command: `tools/profile.sh %s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-steps 0 --prewarm 100 --no-by-input`" % tag,
+         "(mean from rocprofv3's stats CSV; median from the dispatch trace of the same run: the mean carries the first launches' outliers)",
          "plus separate `--pmc` passes (SQ / LDS / MFMA / FETCH_SIZE / WRITE_SIZE).", "",
-         "| kernel | calls | avg µs | % of GPU time |", "|---|---|---|---|"]
+         "| kernel | calls | avg µs | median µs | % of GPU time |", "|---|---|---|---|---|"]
+med = s.get("kernel_medians", {})
 for r in s.get("kernel_stats", []):
-    lines.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    mk = med.get(r["Name"], {})
+    lines.append("| `%s` | %s | %.1f | %s | %s |" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                    "%.1f" % (mk["median_ns"] / 1e3) if mk else "-", r["Percentage"]))
+if med:
+    json.dump(med, open(os.path.join(dst, tag + "_kernel_medians.json"), "w"), indent=1, sort_keys=True)
 if dom:
     c = s["pmc"][dom[0]]
     hbm = (c.get("FETCH_SIZE", 0) * 2 + c.get("WRITE_SIZE", 0)) * 1024
