@@ -147,13 +147,15 @@ typedef struct {
     int64_t num_empty_rows;  /* fragments with no compatible transcript (skipped)       */
     int32_t max_row_nnz;
     int32_t max_tile_cols;   /* largest per-tile column dictionary                      */
-    /* the six row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp; entries 6, 7   */
-    /* are reserved): [0] dense uniform slices, sets of <= 16 transcripts; [1] masked uniform slices,   */
+    /* the row streams of the device layout (see polee_amd/csrc/loglik_internal.hpp):                     */
+    /* [0] dense uniform slices, sets of <= 16 transcripts; [1] masked uniform slices,   */
     /* unions of <= 16 (fragments whose sets differ); [2] dense uniform, 17..32; [3] masked uniform,    */
     /* unions of 17..32; [4] mixed slices of unrelated fragments of <= 15 transcripts -- [0..4] are one */
     /* persistent launch; [5] mixed slices of longer fragments (more than 32 transcripts, as a rule): a */
     /* second launch; [6] rows kept in CSR (fragments without any structure, whose sliced forms would   */
-    /* cost more than CSR: a random sparse matrix): a launch of their own, no tiles                      */
+    /* cost more than CSR: a random sparse matrix): a launch of their own, no tiles; [7] fragments       */
+    /* compatible with ONE transcript: collapsed at build time into a count per transcript (each adds    */
+    /* log X_ij + log x_j to lp and 1 / x_j to the gradient): stream_bytes_hbm[7] = 4 n, no tiles        */
     int64_t stream_rows[8];  /* fragments                                               */
     int64_t stream_nnz[8];   /* non-zeros of X                                          */
     int64_t stream_tiles[8]; /* tiles (workgroup-sized units of work)                   */

@@ -3,8 +3,10 @@
 # This is the reference-side binding a Polee maintainer would add: it keeps the Julia
 # function API of the hot path (names and argument order of src/ptt.jl, src/likelihood.jl,
 # src/likelihood-approximation.jl, src/approx-sampler.jl) and routes it to the MI355X
-# kernels, replacing PyCall + TensorFlow + hsb_ops.so.  NOT TESTED in the build container
-# (no Julia there); the Python mirror polee_amd/core.py exercises the same C entry points.
+# kernels, replacing PyCall + TensorFlow + hsb_ops.so.  NOT EXECUTED in the build container
+# (no Julia there); the Python mirror polee_amd/core.py exercises the same C entry points, and
+# julia/runtests.jl is the test-suite a box with Julia + an MI355X runs (it reads the reference's own
+# HDF5 fixtures, test/dataset/mBr_M_6w_1.*.h5).
 module PoleeHIP
 
 const LIB = get(ENV, "POLEE_HIP_LIB", joinpath(@__DIR__, "..", "polee_amd", "csrc", "libpolee_hip.so"))
@@ -519,6 +521,354 @@ mutable struct HostComm
         finalizer(x -> ccall((:polee_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
         return c
     end
+end
+
+
+# =====================================================================================================================
+# Round 4: the rest of the C ABI (every export of libpolee_hip.so now has a wrapper; julia/runtests.jl exercises them
+# against the golden fixtures).  Reference call sites in the docstrings.
+# =====================================================================================================================
+
+version() = unsafe_string(ccall((:polee_version, LIB), Cstring, ()))
+synchronize(ctx::Context) = check(ccall((:polee_ctx_synchronize, LIB), Cint, (Ptr{Cvoid},), ctx.h), ctx.h)
+"the context's hipStream_t (for callers that enqueue their own HIP work behind the library's)"
+stream(ctx::Context) = ccall((:polee_ctx_stream, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), ctx.h)
+"(free, total) bytes of the context's GPU"
+function mem_info(ctx::Context)
+    f, t = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:polee_ctx_mem_info, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), ctx.h, f, t), ctx.h)
+    return f[], t[]
+end
+"HIP-event stopwatch on the context's stream"
+timer_start(ctx::Context) = check(ccall((:polee_ctx_timer_start, LIB), Cint, (Ptr{Cvoid},), ctx.h), ctx.h)
+function timer_stop(ctx::Context)
+    ms = Ref{Float64}(0.0)
+    check(ccall((:polee_ctx_timer_stop, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), ctx.h, ms), ctx.h)
+    return ms[]
+end
+"cap (MB) of the host builders' scratch-block cache; cap_mb < 0 only queries.  Returns the cap in force."
+host_cache_configure(cap_mb::Integer=-1) = ccall((:polee_host_cache_configure, LIB), Int64, (Int64,), cap_mb)
+host_cache_bytes() = ccall((:polee_host_cache_bytes, LIB), Int64, ())
+
+# ---- trees from the TF-side index arrays; the three TF custom ops (src/tensorflow_ext/hsb_ops.cpp) -------------------
+"make_inverse_ptt_params(t) -- src/estimate.jl:461-500: (left_index, right_index, leaf_index), 0-based, -1 = none"
+function make_inverse_ptt_params(parent_idxs::Vector{Int32}, output_idxs::Vector{Int32})
+    N = length(parent_idxs)
+    l, r, f = (Vector{Int32}(undef, N) for _ in 1:3)
+    GC.@preserve parent_idxs output_idxs l r f check(
+        ccall((:polee_make_inverse_ptt_params, LIB), Cint, (Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+              parent_idxs, output_idxs, N, l, r, f))
+    return l, r, f
+end
+
+"a tree handle from the index arrays the TF ops take (hsb_ops.cpp:17-60)"
+function tree_from_index(ctx::Context, left_index::Vector{Int32}, right_index::Vector{Int32}, leaf_index::Vector{Int32})
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve left_index right_index leaf_index check(
+        ccall((:polee_ptt_create_from_index, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int32, Ref{Ptr{Cvoid}}),
+              ctx.h, left_index, right_index, leaf_index, length(left_index), out), ctx.h)
+    t = PolyaTreeTransformHandle(out[], ctx)
+    return t
+end
+"a bare tree handle (trees created from index arrays have no parent / js arrays on the Julia side)"
+mutable struct PolyaTreeTransformHandle
+    h::Ptr{Cvoid}
+    ctx::Context
+    function PolyaTreeTransformHandle(h::Ptr{Cvoid}, ctx::Context)
+        t = new(h, ctx)
+        finalizer(x -> ccall((:polee_ptt_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), t)
+        return t
+    end
+end
+const AnyTree = Union{PolyaTreeTransform,PolyaTreeTransformHandle}
+num_leaves(t::AnyTree) = Int(ccall((:polee_ptt_n, LIB), Int32, (Ptr{Cvoid},), t.h))
+
+"TF op HSB (hsb_ops.cpp:62-121): y_logit Float32 [B*(n-1)] row-major -> x Float32 [B*n]"
+function hsb(t::AnyTree, y_logit::Vector{Float32}, B::Integer=1)
+    x = Vector{Float32}(undef, B * num_leaves(t))
+    GC.@preserve y_logit x check(ccall((:polee_hsb, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int32, Ptr{Float32}), t.h, y_logit, B, x), t.ctx.h)
+    return x
+end
+"TF op InvHSB (hsb_ops.cpp:123-250): x [B*n] -> (y Float64 [B*(n-1)], ladj Float32 [B])"
+function inv_hsb(t::AnyTree, x::Vector{Float32}, B::Integer=1)
+    y, ladj = Vector{Float64}(undef, B * (num_leaves(t) - 1)), Vector{Float32}(undef, B)
+    GC.@preserve x y ladj check(ccall((:polee_inv_hsb, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int32, Ptr{Float64}, Ptr{Float32}),
+                                      t.h, x, B, y, ladj), t.ctx.h)
+    return y, ladj
+end
+"TF op InvHSBGrad (hsb_ops.cpp:252-402): -> backprops Float32 [B*n]"
+function inv_hsb_grad(t::AnyTree, y_grad::Vector{Float64}, ladj_grad::Vector{Float32}, y::Vector{Float64}, B::Integer=1)
+    bp = Vector{Float32}(undef, B * num_leaves(t))
+    GC.@preserve y_grad ladj_grad y bp check(
+        ccall((:polee_inv_hsb_grad, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float32}, Ptr{Float64}, Int32, Ptr{Float32}),
+              t.h, y_grad, ladj_grad, y, B, bp), t.ctx.h)
+    return bp
+end
+
+# ---- the reparameterisations as standalone calls (src/logitnormal.jl, src/sinh_arcsinh.jl, src/kumaraswamy.jl) -------
+"logit_normal_transform!(mu, sigma, zs, ys, Val(compute_ladj)) -- src/logitnormal.jl:8-20"
+function logit_normal_transform!(ctx::Context, mu::Vector{Float32}, sigma::Vector{Float32}, zs::Vector{Float32},
+                                 ys::Vector{Float64}, ::Val{compute_ladj}=Val(false)) where {compute_ladj}
+    ladj = Ref{Float64}(0.0)
+    GC.@preserve mu sigma zs ys check(
+        ccall((:polee_logit_normal_transform, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Float64}),
+              ctx.h, mu, sigma, zs, length(zs), ys, compute_ladj ? ladj : C_NULL), ctx.h)
+    return ladj[]
+end
+"logit_normal_transform_gradients!(zs, ys, mu, sigma, y_grad, z_grad, mu_grad, sigma_grad) -- src/logitnormal.jl:38-55 (accumulates)"
+function logit_normal_transform_gradients!(ctx::Context, zs::Vector{Float32}, ys::Vector{Float64}, sigma::Vector{Float32},
+                                           y_grad::Vector{Float32}, z_grad::Union{Nothing,Vector{Float32}},
+                                           mu_grad::Vector{Float32}, sigma_grad::Vector{Float32})
+    GC.@preserve zs ys sigma y_grad z_grad mu_grad sigma_grad check(
+        ccall((:polee_logit_normal_transform_gradients, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float64}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+              ctx.h, zs, ys, sigma, y_grad, length(zs), z_grad === nothing ? C_NULL : pointer(z_grad), mu_grad, sigma_grad), ctx.h)
+    return nothing
+end
+"sinh_asinh_transform!(alpha, zs0, zs, Val(compute_ladj)) -- src/sinh_arcsinh.jl:10-23"
+function sinh_asinh_transform!(ctx::Context, alpha::Vector{Float32}, zs0::Vector{Float32}, zs::Vector{Float32},
+                               ::Val{compute_ladj}=Val(false)) where {compute_ladj}
+    ladj = Ref{Float64}(0.0)
+    GC.@preserve alpha zs0 zs check(
+        ccall((:polee_sinh_asinh_transform, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float64}),
+              ctx.h, alpha, zs0, length(zs0), zs, compute_ladj ? ladj : C_NULL), ctx.h)
+    return ladj[]
+end
+"sinh_asinh_transform_gradients!(zs0, alpha, z_grad, alpha_grad) -- src/sinh_arcsinh.jl:29-38 (accumulates)"
+function sinh_asinh_transform_gradients!(ctx::Context, zs0::Vector{Float32}, alpha::Vector{Float32}, z_grad::Vector{Float32},
+                                         alpha_grad::Vector{Float32})
+    GC.@preserve zs0 alpha z_grad alpha_grad check(
+        ccall((:polee_sinh_asinh_transform_gradients, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float32}),
+              ctx.h, zs0, alpha, z_grad, length(zs0), alpha_grad), ctx.h)
+    return nothing
+end
+"kumaraswamy_transform!(as, bs, zs, ys, Val(compute_ladj)) -- src/kumaraswamy.jl:9-36"
+function kumaraswamy_transform!(ctx::Context, as::Vector{Float32}, bs::Vector{Float32}, zs::Vector{Float32},
+                                ys::Vector{Float64}, ::Val{compute_ladj}=Val(false)) where {compute_ladj}
+    ladj = Ref{Float64}(0.0)
+    GC.@preserve as bs zs ys check(
+        ccall((:polee_kumaraswamy_transform, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Float64}),
+              ctx.h, as, bs, zs, length(zs), ys, compute_ladj ? ladj : C_NULL), ctx.h)
+    return ladj[]
+end
+"kumaraswamy_transform_gradients!(zs, as, bs, y_grad, a_grad, b_grad) -- src/kumaraswamy.jl:39-71 (accumulates)"
+function kumaraswamy_transform_gradients!(ctx::Context, zs::Vector{Float32}, as::Vector{Float32}, bs::Vector{Float32},
+                                          y_grad::Vector{Float32}, a_grad::Vector{Float32}, b_grad::Vector{Float32})
+    GC.@preserve zs as bs y_grad a_grad b_grad check(
+        ccall((:polee_kumaraswamy_transform_gradients, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float32}),
+              ctx.h, zs, as, bs, y_grad, length(zs), a_grad, b_grad), ctx.h)
+    return nothing
+end
+
+# ---- the sample from the rows of X; layout information; deterministic mode ------------------------------------------
+"X given by rows (Xt = SparseMatrixCSC(transpose(X)), likelihood-approximation.jl:407): tcolptr UInt64 [m+1] 1-based"
+function DeviceSampleFromXt(ctx::Context, m, n, tcolptr::Vector{UInt64}, trowval::Vector{UInt32}, tnzval::Vector{Float32};
+                            ks::Union{Nothing,Vector{Int64}}=nothing)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve tcolptr trowval tnzval ks check(
+        ccall((:polee_loglik_create_from_xt, LIB), Cint,
+              (Ptr{Cvoid}, Int64, Int64, Ptr{UInt64}, Ptr{UInt32}, Ptr{Float32}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+              ctx.h, m, n, tcolptr, trowval, tnzval, ks === nothing ? C_NULL : pointer(ks), r), ctx.h)
+    return wrap_sample(r[], ctx, m, n)
+end
+"adopts a polee_loglik handle (DeviceSample's inner constructor always builds from CSC)"
+function wrap_sample(h::Ptr{Cvoid}, ctx::Context, m, n)
+    s = DeviceSampleHandle(h, ctx, Int(m), Int(n))
+    finalizer(x -> ccall((:polee_loglik_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), s)
+    return s
+end
+mutable struct DeviceSampleHandle
+    h::Ptr{Cvoid}
+    ctx::Context
+    m::Int
+    n::Int
+end
+const AnySample = Union{DeviceSample,DeviceSampleHandle}
+
+"mirror of `polee_loglik_info` (include/polee_hip.h): field order and types must stay in step with the header"
+mutable struct LoglikInfo
+    m::Int64; n::Int64; nnz::Int64; num_slices::Int64; num_tiles::Int64; padded_nnz::Int64
+    device_bytes::Int64; stream_bytes::Int64; num_empty_rows::Int64; max_row_nnz::Int32; max_tile_cols::Int32
+    stream_rows::NTuple{8,Int64}; stream_nnz::NTuple{8,Int64}; stream_tiles::NTuple{8,Int64}; stream_bytes_hbm::NTuple{8,Int64}
+    dict_entries::Int64
+    LoglikInfo() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> 0, 8), ntuple(_ -> 0, 8), ntuple(_ -> 0, 8), ntuple(_ -> 0, 8), 0)
+end
+function info(s::AnySample)
+    i = LoglikInfo()
+    check(ccall((:polee_loglik_get_info, LIB), Cint, (Ptr{Cvoid}, Ref{LoglikInfo}), s.h, i), s.ctx.h)
+    return i
+end
+"bitwise reproducible gradient sums (fixed reduction order instead of float atomics)"
+set_deterministic!(s::AnySample, on::Bool=true) =
+    check(ccall((:polee_loglik_set_deterministic, LIB), Cint, (Ptr{Cvoid}, Cint), s.h, on), s.ctx.h)
+"debug: every slice through the per-tile kernel (the second algorithm of the cross-check tests)"
+debug_force_mixed!(s::AnySample, on::Bool=true) =
+    check(ccall((:polee_debug_loglik_force_mixed, LIB), Cint, (Ptr{Cvoid}, Cint), s.h, on), s.ctx.h)
+
+"K expression vectors at once: xs Float32 [n, K] (a column per draw) -> (lp [K], x_grad Float64 [n, K])"
+function log_likelihood_batch(s::AnySample, xs::Matrix{Float32}; gradonly::Bool=false)
+    K = size(xs, 2)
+    g, lp = Matrix{Float64}(undef, size(xs, 1), K), Vector{Float64}(undef, K)
+    GC.@preserve xs g lp check(
+        ccall((:polee_loglik_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int32, Ptr{Float64}, Ptr{Float64}),
+              s.h, xs, K, g, gradonly ? C_NULL : pointer(lp)), s.ctx.h)
+    return lp, g
+end
+
+"OptimizePTTApprox (likelihood-approximation.jl:149-242): maximum-likelihood point estimate -> (xs, zs)"
+function optimize_ptt(s::AnySample, t::AnyTree, efflens::Vector{Float32}, num_steps::Integer=500)
+    xs, zs = Vector{Float32}(undef, s.n), Vector{Float32}(undef, s.n - 1)
+    GC.@preserve efflens xs zs check(
+        ccall((:polee_optimize_ptt, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Int32, Ptr{Float32}, Ptr{Float32}),
+              s.h, t.h, efflens, num_steps, xs, zs), s.ctx.h)
+    return xs, zs
+end
+
+# ---- the VI handle's test hooks ---------------------------------------------------------------------------------------
+"""
+One iteration's quantities WITHOUT applying the update (the parity tests' hook): K draws of the current parameters ->
+(xs [n,K], x_grad [n,K], y_grad [n-1,K], mu_grad, omega_grad, alpha_grad [n-1], lp [K], ladj [K]).
+"""
+function eval_gradients(f::LikelihoodApproximationFit, K::Integer)
+    n = f.t.n
+    xs, xg, yg = Matrix{Float32}(undef, n, K), Matrix{Float64}(undef, n, K), Matrix{Float64}(undef, n - 1, K)
+    mg, og, ag = (Vector{Float32}(undef, n - 1) for _ in 1:3)
+    lp, ladj = Vector{Float64}(undef, K), Vector{Float64}(undef, K)
+    GC.@preserve xs xg yg mg og ag lp ladj check(
+        ccall((:polee_vi_eval_gradients, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}),
+              f.h, xs, xg, yg, mg, og, ag, lp, ladj), f.t.ctx.h)
+    return xs, xg, yg, mg, og, ag, lp, ladj
+end
+"the N(0,1) draws iteration `step` uses (device RNG or the caller's table): Float32 [n-1, K]"
+function export_noise(f::LikelihoodApproximationFit, step::Integer, K::Integer)
+    z = Matrix{Float32}(undef, f.t.n - 1, K)
+    GC.@preserve z check(ccall((:polee_vi_export_noise, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Float32}), f.h, step, z), f.t.ctx.h)
+    return z
+end
+
+# ---- communicators: what the transport reports; a host-side all-reduce through it ------------------------------------
+const AnyComm = Union{Comm,HostComm}
+comm_rank(c::AnyComm) = Int(ccall((:polee_comm_rank, LIB), Int32, (Ptr{Cvoid},), c.h))
+comm_size(c::AnyComm) = Int(ccall((:polee_comm_size, LIB), Int32, (Ptr{Cvoid},), c.h))
+"(transport, count, rank): transport 1 = RCCL (count / rank = ncclCommCount / ncclCommUserRank), 2 = host-staged"
+function comm_info(c::AnyComm)
+    t, n, r = Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:polee_comm_info, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), c.h, t, n, r), c.ctx.h)
+    return Int(t[]), Int(n[]), Int(r[])
+end
+"sum of a Float32 vector over the ranks, in place"
+function allreduce_sum!(c::AnyComm, buf::Vector{Float32})
+    GC.@preserve buf check(ccall((:polee_allreduce_sum_f32, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), c.h, buf, length(buf)), c.ctx.h)
+    return buf
+end
+
+# ---- density of the approximations on device buffers; splicing moments ------------------------------------------------
+"as log_prob with DEVICE pointers (Ptr{Float32} into memory of the context's GPU): for callers with their own HIP code"
+log_prob_device(ap::ApproxLikelihood, d_x::Ptr{Float32}, d_lp::Ptr{Float32}, d_x_grad::Ptr{Float32}=Ptr{Float32}(C_NULL)) =
+    check(ccall((:polee_approx_logprob_device, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), ap.h, d_x, d_lp, d_x_grad), ap.ctx.h)
+
+"approximate_splicing_likelihood (polee_splicing.py:14-113): (loc, scale) Float32 [S*F]; index pairs (feature, transcript), 1-based, flattened"
+function splicing_moments(ap::ApproxLikelihood, feature_indices::Vector{Int32}, antifeature_indices::Vector{Int32}, F::Integer;
+                          num_mean_draws::Integer=1000, num_var_draws::Integer=1000, seed::Integer=0)
+    loc, scale = Vector{Float32}(undef, ap.S * F), Vector{Float32}(undef, ap.S * F)
+    GC.@preserve feature_indices antifeature_indices loc scale check(
+        ccall((:polee_approx_splicing_moments, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Int32}, Int64, Ptr{Int32}, Int64, Int32, Int32, Int32, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+              ap.h, feature_indices, div(length(feature_indices), 2), antifeature_indices, div(length(antifeature_indices), 2), F,
+              num_mean_draws, num_var_draws, seed, C_NULL, loc, scale), ap.ctx.h)
+    return loc, scale
+end
+
+# ---- regression model: evaluation hook, parameter access, the Normal-likelihood variant --------------------------------
+num_noise(r::Regression) = Int(ccall((:polee_regression_num_noise, LIB), Int64, (Ptr{Cvoid},), r.h))
+"loss (and gradient with respect to the flat parameter vector) at one draw of the latents: the tests' hook"
+function eval_loss(r::Regression; noise::Union{Nothing,Vector{Float32}}=nothing, seed::Integer=0, grad::Bool=false)
+    loss = Ref{Float32}(0f0)
+    g = grad ? Vector{Float32}(undef, num_params(r)) : Float32[]
+    GC.@preserve noise g check(
+        ccall((:polee_regression_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, UInt64, Ref{Float32}, Ptr{Float32}),
+              r.h, noise === nothing ? C_NULL : pointer(noise), seed, loss, grad ? pointer(g) : C_NULL), r.ctx.h)
+    return grad ? (loss[], g) : loss[]
+end
+function set_flat_params!(r::Regression, p::Vector{Float32})
+    @assert length(p) == num_params(r)
+    GC.@preserve p check(ccall((:polee_regression_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, p), r.ctx.h)
+end
+function set_isoform_params!(r::Regression, p::Vector{Float32})
+    GC.@preserve p check(ccall((:polee_regression_set_isoform_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, p), r.ctx.h)
+end
+function isoform_grad(r::Regression)
+    n = Int(ccall((:polee_regression_num_isoform_params, LIB), Int64, (Ptr{Cvoid},), r.h))
+    g = Vector{Float32}(undef, n)
+    GC.@preserve g check(ccall((:polee_regression_get_isoform_grad, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, g), r.ctx.h)
+    return g
+end
+"RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): x ~ Normal(loc, scale) per sample, [S*n] row-major"
+function set_normal_likelihood!(r::Regression, loc::Vector{Float32}, scale::Vector{Float32})
+    GC.@preserve loc scale check(ccall((:polee_regression_set_normal_likelihood, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), r.h, loc, scale), r.ctx.h)
+end
+"the kernel-regression weights of the mean-variance prior, Float32 [degree*n] (models/polee_regression.py:436-460)"
+function regression_weights(r::Regression, degree::Integer=15)
+    w = Vector{Float32}(undef, degree * r.n)
+    GC.@preserve w check(ccall((:polee_regression_weights, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, w), r.ctx.h)
+    return w
+end
+
+# ---- X construction (src/rnaseq_sample.jl:390-524 with the SimplisticFragModel, src/fragmodel.jl:23-169) --------------
+struct XbTranscripts
+    n::Int32; seq::Ptr{Int32}; strand::Ptr{Int8}; exon_ptr::Ptr{Int64}; exon_first::Ptr{Int64}; exon_last::Ptr{Int64}
+end
+struct XbFragments
+    m::Int64; seq::Ptr{Int32}; strand::Ptr{Int8}
+    m1_left::Ptr{Int64}; m1_right::Ptr{Int64}; m2_left::Ptr{Int64}; m2_right::Ptr{Int64}
+    m1_is_flag16::Ptr{UInt8}; cig1_ptr::Ptr{Int64}; cig2_ptr::Ptr{Int64}; cig_op::Ptr{UInt8}; cig_len::Ptr{Int32}
+end
+struct XbFragModel
+    fraglen_pmf::Ptr{Float32}; fraglen_cdf::Ptr{Float32}; fraglen_median::Int32; strand_specificity::Float32; alt_frag_model::Int32
+end
+"""
+    build_likelihood_matrix(ctx, T, F, pmf, cdf, median; strand_specificity, alt_frag_model)
+
+T: NamedTuple (seq, strand, exon_ptr, exon_first, exon_last), F: NamedTuple (seq, strand, m1_left, m1_right, m2_left,
+m2_right, m1_is_flag16, cig1_ptr, cig2_ptr, cig_op, cig_len) in the layout of include/polee_hip.h (m1 = the LEFTMOST mate,
+as transcripts.jl:288-297 orders them).  Returns (tcolptr, trowval, tnzval, effective_lengths, row_fragment): the rows of X.
+"""
+function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::Vector{Float32}, median::Integer;
+                                 strand_specificity::Real=0.9, alt_frag_model::Bool=false)
+    n = length(T.seq); m = length(F.seq)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve T F pmf cdf begin
+        ts = XbTranscripts(n, pointer(T.seq), pointer(T.strand), pointer(T.exon_ptr), pointer(T.exon_first), pointer(T.exon_last))
+        fs = XbFragments(m, pointer(F.seq), pointer(F.strand), pointer(F.m1_left), pointer(F.m1_right), pointer(F.m2_left),
+                         pointer(F.m2_right), pointer(F.m1_is_flag16), pointer(F.cig1_ptr), pointer(F.cig2_ptr), pointer(F.cig_op),
+                         pointer(F.cig_len))
+        ms = XbFragModel(pointer(pmf), pointer(cdf), median, strand_specificity, alt_frag_model)
+        check(ccall((:polee_xbuild_run, LIB), Cint, (Ptr{Cvoid}, Ref{XbTranscripts}, Ref{XbFragments}, Ref{XbFragModel}, Ref{Ptr{Cvoid}}),
+                    ctx.h, ts, fs, ms, out), ctx.h)
+    end
+    h = out[]
+    try
+        rows, nnz = Ref{Int64}(0), Ref{Int64}(0)
+        check(ccall((:polee_xbuild_sizes, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    h, rows, nnz, C_NULL, C_NULL, C_NULL), ctx.h)
+        tcolptr, trowval, tnzval = Vector{UInt64}(undef, rows[] + 1), Vector{UInt32}(undef, nnz[]), Vector{Float32}(undef, nnz[])
+        efflens, rowfrag = Vector{Float32}(undef, n), Vector{Int64}(undef, rows[])
+        GC.@preserve tcolptr trowval tnzval efflens rowfrag check(
+            ccall((:polee_xbuild_get, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int64}),
+                  h, tcolptr, trowval, tnzval, efflens, rowfrag), ctx.h)
+        return tcolptr, trowval, tnzval, efflens, rowfrag
+    finally
+        ccall((:polee_xbuild_destroy, LIB), Cvoid, (Ptr{Cvoid},), h)
+    end
+end
+
+"fast_log of the tree kernels (csrc/scan.hpp), element-wise on the device: the tests compare it with Base.log"
+function debug_fast_log(ctx::Context, x::Vector{Float64})
+    out = similar(x)
+    GC.@preserve x out check(ccall((:polee_debug_fast_log, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}), ctx.h, x, length(x), out), ctx.h)
+    return out
 end
 
 end # module
