@@ -542,9 +542,41 @@ typedef struct {
     float strand_specificity;
     int32_t alt_frag_model;
 } polee_xb_fragmodel;
+/* A TRAINED bias model for the reference's default BiasedFragModel (src/fragmodel.jl:174-445; training, src/bias.jl:266-786,
+ * stays upstream).  tseq: the transcripts' spliced sequences in transcript orientation (t.metadata.seq), one code per base:
+ * 0 A, 1 C, 2 G, 3 T, 4 anything else; tseq_ptr [n+1] (tseq_ptr[0] = 0, lengths = exonic lengths).  Sequence bias
+ * (SeqBiasModel{:left} / {:right}, bias.jl:157-160, 419-456): seqbias_len = 20 positions, orders [20] (-1: position not in
+ * the model), ps [20][4][ps_ctx] row-major (the reference's ps[i, c+1, ctx+1]), ps_ctx >= 4^(largest order).  gc_bins: the
+ * SimpleHistogramModel's bins (bias.jl:459-521).  pos_terms [pos_maxtlen] + pos_p: PositionalBiasModel (bias.jl:523-659) or
+ * NULL (use_pos_bias = false, the default).  high_prob_fraglens: the BIAS_EFFLEN_NUM_FRAGLENS most probable fragment lengths
+ * in descending probability (fragmodel.jl:358-359).  m1_reverse [m]: the lone mate of a single-end fragment has
+ * FLAG_REVERSE set (transcripts.jl:486); may be NULL when every fragment is paired.
+ * Not reproducible: context positions beyond a transcript's ends are RANDOM nucleotides in the reference (bias.jl:83-85,
+ * 424-429); here they read as A. */
+typedef struct {
+    const int64_t *tseq_ptr;
+    const uint8_t *tseq;
+    int32_t seqbias_len, ps_ctx;
+    const int32_t *orders_left, *orders_right;
+    const float *ps_left, *ps_right;
+    int32_t gc_nbins;
+    const float *gc_bins;
+    double pos_p;
+    const double *pos_terms;
+    int32_t pos_maxtlen;
+    int32_t num_fraglens;
+    const int32_t *high_prob_fraglens;
+    const uint8_t *m1_reverse;
+} polee_xb_biasmodel;
 typedef struct polee_xbuild polee_xbuild;
 polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *transcripts, const polee_xb_fragments *fragments,
                               const polee_xb_fragmodel *fragmodel, polee_xbuild **out);
+/* The same under the BiasedFragModel: compute_transcript_bias! (bias.jl:834-858), effective_length (fragmodel.jl:372-410),
+ * condfragprob with genomic_to_transcriptomic (fragmodel.jl:413-445, transcripts.jl:452-538).  polee_xbuild_get_bias
+ * returns the transcripts' bias vectors (left / right f32 [tseq_ptr[n]], laid out like tseq) and the kernel's time. */
+polee_status polee_xbuild_run_biased(polee_ctx *ctx, const polee_xb_transcripts *transcripts, const polee_xb_fragments *fragments,
+                                     const polee_xb_fragmodel *fragmodel, const polee_xb_biasmodel *biasmodel, polee_xbuild **out);
+polee_status polee_xbuild_get_bias(const polee_xbuild *xb, float *left_bias_or_null, float *right_bias_or_null, double *ms_bias_or_null);
 void polee_xbuild_destroy(polee_xbuild *xb);
 /* rows and non-zeros of the result; kernel times (ms): effective lengths, counting pass, filling pass */
 polee_status polee_xbuild_sizes(const polee_xbuild *xb, int64_t *rows, int64_t *nnz, double *ms_efflen, double *ms_count,

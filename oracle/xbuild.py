@@ -41,3 +41,27 @@ def build(T, F, M, n):
     for q in (ptr, cols, vals, rf):
         L.xb_oracle_free(q)
     return out
+
+
+def build_biased(T, F, M, B, n, total_bases):
+    """BiasedFragModel (second half of xbuild_oracle.c): B = the ctypes struct of polee_amd.xbuild.pack_bias.  -> the dict of
+    `build` plus left_bias / right_bias f32 [total_bases]."""
+    L = lib()
+    eff = np.empty(n, np.float32)
+    left, right = np.empty(max(total_bases, 1), np.float32), np.empty(max(total_bases, 1), np.float32)
+    rows = C.c_int64()
+    ptr, cols, vals, rf = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)(), C.POINTER(C.c_int64)()
+    L.xb_oracle_build_biased(C.byref(T), C.byref(F), C.byref(M), C.byref(B), eff.ctypes.data_as(C.c_void_p),
+                             left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), C.byref(rows), C.byref(ptr),
+                             C.byref(cols), C.byref(vals), C.byref(rf))
+    r = rows.value
+    tcolptr = np.ctypeslib.as_array(ptr, shape=(r + 1,)).copy()
+    nnz = int(tcolptr[-1] - 1)
+    out = dict(m=r, n=n, nnz=nnz, tcolptr=tcolptr,
+               trowval=np.ctypeslib.as_array(cols, shape=(max(nnz, 1),))[:nnz].copy(),
+               tnzval=np.ctypeslib.as_array(vals, shape=(max(nnz, 1),))[:nnz].copy(), effective_lengths=eff,
+               row_fragment=np.ctypeslib.as_array(rf, shape=(max(r, 1),))[:r].copy(),
+               left_bias=left[:total_bases], right_bias=right[:total_bases])
+    for q in (ptr, cols, vals, rf):
+        L.xb_oracle_free(q)
+    return out

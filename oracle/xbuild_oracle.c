@@ -1,7 +1,8 @@
 /*
  * xbuild_oracle.c -- CPU restatement of the construction of the likelihood matrix X (first
  * slice): which fragments are compatible with which transcripts, and with what conditional probability, under the
- * reference's SimplisticFragModel (bias terms = 1).
+ * reference's SimplisticFragModel (bias terms = 1) and, since round 4, its default BiasedFragModel given a trained bias
+ * model (second half of this file).
  *
  * TEST INFRASTRUCTURE ONLY: only tests/ may call this (the product path is polee_amd/csrc/xbuild.hip).
  * Parity: UNPINNED -- the reference holds no fixture for this step (its test dataset starts at the likelihood matrix)
@@ -256,6 +257,223 @@ int xb_oracle_build(const xb_transcripts *T, const xb_fragments *F, const xb_fra
         }
         if (nnz > start) { rf[rows] = i; ptr[++rows] = (uint64_t)nnz + 1; }
     }
+    *rows_out = rows; *tcolptr = ptr; *trowval = cols; *tnzval = vals; *row_fragment = rf;
+    return 0;
+}
+
+/* ===================================================================================================================
+ * BiasedFragModel (round 4; the reference's DEFAULT model, main.jl:689,703): evaluation of a TRAINED bias model during the
+ * construction of X.  Training (bias.jl:266-400, 464-515, 532-648, 677-786) stays upstream, like BAM parsing.
+ *
+ *   evaluate(::SeqBiasModel{:left / :right}, seq, pos)   src/bias.jl:419-456
+ *   evaluate(::SimpleHistogramModel, x)                  src/bias.jl:517-520
+ *   evaluate(::PositionalBiasModel, tlen, pos)           src/bias.jl:649-663
+ *   compute_transcript_bias!                             src/bias.jl:834-858
+ *   effective_length(::BiasedFragModel, t)               src/fragmodel.jl:372-410
+ *   genomic_to_transcriptomic                            src/transcripts.jl:452-538
+ *   condfragprob(::BiasedFragModel, ...)                 src/fragmodel.jl:413-445
+ *
+ * Quirk NOT reproducible: context positions beyond a transcript's ends are random nucleotides in the reference
+ * (randdna(), bias.jl:83-85 in :424-429,444-449) -- a run-to-run random quantity; here they read as A (code 0).
+ * Quirks kept: Float32 running GC proportion of the effective length's sliding window (+= / -= in sequence), Float32
+ * products left to right, `round(Int, x * nbins)` to even, the single-end position arithmetic as written (:486-501),
+ * the overhang nudges (:505-512), `1.0 - strand_specificity` in Float64.
+ */
+#define BIAS_SEQ_INNER_CTX 15 /* src/constants.jl:77 */
+#define BIAS_SEQ_OUTER_CTX 5  /* src/constants.jl:78 */
+typedef struct {
+    const int64_t *tseq_ptr;  /* [n+1] into tseq */
+    const uint8_t *tseq;      /* spliced sequence in transcript orientation: 0 A, 1 C, 2 G, 3 T, 4 anything else */
+    int32_t seqbias_len;      /* BIAS_SEQ_OUTER_CTX + BIAS_SEQ_INNER_CTX */
+    int32_t ps_ctx;           /* 4^(largest order) */
+    const int32_t *orders_left, *orders_right; /* [seqbias_len], -1 = position not in the model */
+    const float *ps_left, *ps_right;           /* [seqbias_len][4][ps_ctx] */
+    int32_t gc_nbins;
+    const float *gc_bins;
+    double pos_p;
+    const double *pos_terms;  /* [pos_maxtlen] or NULL (pos_model === nothing) */
+    int32_t pos_maxtlen;
+    int32_t num_fraglens;
+    const int32_t *high_prob_fraglens;
+    const uint8_t *m1_reverse; /* [m] the lone mate's flag has FLAG_REVERSE set (transcripts.jl:486) */
+} xb_biasmodel;
+
+static int code_at(const uint8_t *seq, int64_t len, int64_t j) /* 1-based; off the ends: A (see header) */
+{
+    if (j < 1 || j > len) return 0;
+    return seq[j - 1] < 4 ? seq[j - 1] : 0; /* nt2bit: N -> 0 (bias.jl:176-181) */
+}
+static int is_gc(uint8_t c) { return c == 1 || c == 2; }
+
+/* evaluate(sb, seq, pos): first = pos - OUTER (left) / pos - INNER + 1 (right) */
+static float seqbias_eval(const xb_biasmodel *B, int right, const uint8_t *seq, int64_t len, int64_t pos)
+{
+    const int32_t *orders = right ? B->orders_right : B->orders_left;
+    const float *ps = right ? B->ps_right : B->ps_left;
+    const int64_t first = right ? pos - BIAS_SEQ_INNER_CTX + 1 : pos - BIAS_SEQ_OUTER_CTX;
+    float bias = 1.0f;
+    for (int32_t i = 0; i < B->seqbias_len; ++i) {
+        if (orders[i] < 0) continue;
+        const int64_t j = first + i;
+        const int c = code_at(seq, len, j);
+        int ctx = 0;
+        for (int l = 1; l <= orders[i]; ++l) ctx = (ctx << 2) | code_at(seq, len, j + l);
+        bias *= ps[((size_t)i * 4 + (size_t)c) * (size_t)B->ps_ctx + (size_t)ctx];
+    }
+    return bias;
+}
+static float hist_eval_f32(const xb_biasmodel *B, float x)
+{
+    long i = lrintf(x * (float)B->gc_nbins); /* round(Int, x * length(bins)): Float32 product, ties to even */
+    if (i < 1) i = 1;
+    if (i > B->gc_nbins) i = B->gc_nbins;
+    return B->gc_bins[i - 1];
+}
+static float hist_eval_f64(const xb_biasmodel *B, double x)
+{
+    long i = lrint(x * (double)B->gc_nbins);
+    if (i < 1) i = 1;
+    if (i > B->gc_nbins) i = B->gc_nbins;
+    return B->gc_bins[i - 1];
+}
+/* compute_transcript_bias! (bias.jl:834-858): left / right [tlen] */
+void xb_oracle_transcript_bias(const xb_biasmodel *B, int32_t j, float *left, float *right)
+{
+    const uint8_t *seq = B->tseq + B->tseq_ptr[j];
+    const int64_t tlen = B->tseq_ptr[j + 1] - B->tseq_ptr[j];
+    for (int64_t pos = 1; pos <= tlen; ++pos) {
+        const float sb = seqbias_eval(B, 0, seq, tlen, pos);
+        if (B->pos_terms) { /* evaluate(posmodel, tlen, tlen - pos + 1), Float64 (bias.jl:649-658) */
+            const double base = (1.0 / (double)tlen) * pow(1.0 - B->pos_p, (double)tlen) + B->pos_terms[tlen - 1];
+            const double prob = base - B->pos_terms[(tlen - pos + 1) - 1];
+            left[pos - 1] = (float)((prob / base) * (double)sb);
+        } else {
+            left[pos - 1] = 1.0f * sb;
+        }
+        right[pos - 1] = seqbias_eval(B, 1, seq, tlen, pos);
+    }
+}
+/* effective_length(::BiasedFragModel, t) (fragmodel.jl:372-410) */
+float xb_oracle_effective_length_biased(const xb_fragmodel *M, const xb_biasmodel *B, int32_t j, const float *left, const float *right)
+{
+    const uint8_t *seq = B->tseq + B->tseq_ptr[j];
+    const int64_t tlen = B->tseq_ptr[j + 1] - B->tseq_ptr[j];
+    float efflen = 0.0f;
+    for (int32_t f = 0; f < B->num_fraglens; ++f) {
+        const int64_t fraglen = B->high_prob_fraglens[f];
+        if (fraglen > tlen) continue;
+        const float fraglenpr = fraglen <= MAX_FRAG_LEN ? M->fraglen_pmf[fraglen - 1] : 0.0f;
+        const float gc_c = 1.0f / (float)fraglen;
+        float frag_gc_prop = 0.0f;
+        for (int64_t pos = 1; pos <= fraglen; ++pos) frag_gc_prop += gc_c * (float)is_gc(seq[pos - 1]);
+        float c = 0.0f;
+        for (int64_t pos = 1; pos <= tlen - fraglen + 1; ++pos) {
+            if (pos > 1) {
+                frag_gc_prop -= gc_c * (float)is_gc(seq[pos - 2]);
+                frag_gc_prop += gc_c * (float)is_gc(seq[pos + fraglen - 2]);
+            }
+            c += left[pos - 1] * right[pos + fraglen - 2] * hist_eval_f32(B, frag_gc_prop);
+        }
+        efflen += c * fraglenpr;
+    }
+    return efflen > MIN_EFFECTIVE_LENGTH ? efflen : MIN_EFFECTIVE_LENGTH;
+}
+/* genomic_to_transcriptomic(t, position) (transcripts.jl:520-538): 0 = not in an exon */
+static int64_t g2t_pos(const xb_transcripts *T, int32_t j, int64_t position)
+{
+    const int64_t e0 = T->exon_ptr[j], ne = T->exon_ptr[j + 1] - e0;
+    const int64_t *ef = T->exon_first + e0, *el = T->exon_last + e0;
+    int64_t i = 0; /* searchsortedlast(exons, Exon(position, position)): exons <= (position, position) lexicographically */
+    for (int64_t k = 0; k < ne; ++k)
+        if (ef[k] < position || (ef[k] == position && el[k] <= position)) i = k + 1; else break;
+    if (i == 0 || el[i - 1] < position) return 0;
+    int64_t tpos = 1;
+    for (int64_t k = 0; k < i - 1; ++k) tpos += el[k] - ef[k] + 1;
+    tpos += position - ef[i - 1];
+    if (T->strand[j] < 0) tpos = exonic_length(T, j) - tpos + 1;
+    return tpos;
+}
+/* genomic_to_transcriptomic(t, rs, alnpr, fraglen_median) (transcripts.jl:452-517): the fragment's interval on the
+ * transcript, [*start, *stop]; returns its length (0 = incompatible / empty) */
+static int64_t g2t_fragment(const xb_transcripts *T, const xb_fragments *F, const xb_biasmodel *B, int32_t j, int64_t i,
+                            int64_t fraglen_median, int64_t tlen, int64_t *start, int64_t *stop)
+{
+    int64_t fraglen = fragmentlength(T, F, j, i);
+    if (fraglen < 0) return 0;          /* nothing: incompatible */
+    if (fraglen <= 0) {
+        fraglen = fraglen_median;
+        if (fraglen <= 0) return 0;
+    }
+    int64_t tpos;
+    if (F->m2_left[i] > 0) {            /* both mates */
+        const int64_t lmin = F->m1_left[i] < F->m2_left[i] ? F->m1_left[i] : F->m2_left[i];
+        const int64_t rmax = F->m1_right[i] > F->m2_right[i] ? F->m1_right[i] : F->m2_right[i];
+        tpos = g2t_pos(T, j, T->strand[j] > 0 ? lmin : rmax);
+    } else {                            /* single-end: guess (:481-501) */
+        const int aln_neg = B->m1_reverse[i] != 0;
+        if (T->strand[j] > 0) tpos = !aln_neg ? g2t_pos(T, j, F->m1_left[i]) : g2t_pos(T, j, F->m1_right[i]) - fraglen;
+        else tpos = !aln_neg ? g2t_pos(T, j, F->m1_left[i]) - fraglen : g2t_pos(T, j, F->m1_right[i]);
+    }
+    if (tpos <= 0) { fraglen += tpos - 1; tpos = 1; }               /* :505-508 */
+    if (tpos + fraglen - 1 > tlen) fraglen = tlen - tpos + 1;       /* :510-512 */
+    *start = tpos; *stop = tpos + fraglen - 1;
+    return fraglen > 0 ? fraglen : 0;
+}
+/* condfragprob(::BiasedFragModel, ...) (fragmodel.jl:413-445) as the Float32 pushed into V */
+float xb_oracle_condfragprob_biased(const xb_transcripts *T, const xb_fragments *F, const xb_fragmodel *M, const xb_biasmodel *B,
+                                    int32_t j, int64_t i, float efflen, const float *left, const float *right)
+{
+    const uint8_t *seq = B->tseq + B->tseq_ptr[j];
+    const int64_t tlen = B->tseq_ptr[j + 1] - B->tseq_ptr[j];
+    int64_t a, b;
+    const int64_t fraglen = g2t_fragment(T, F, B, j, i, M->fraglen_median, tlen, &a, &b);
+    if (fraglen == 0) return 0.0f;
+    const float fraglenpr = fraglen <= MAX_FRAG_LEN ? M->fraglen_pmf[fraglen - 1] : 0.0f;
+    int64_t gc = 0;
+    for (int64_t pos = a; pos <= b; ++pos) gc += is_gc(seq[pos - 1]);
+    const double frag_gc = (double)gc / (double)fraglen;
+    const float fragbias = left[a - 1] * right[b - 1] * hist_eval_f64(B, frag_gc);
+    if (F->strand[i] == T->strand[j]) return M->strand_specificity * fraglenpr * fragbias / efflen;  /* Float32 chain */
+    return (float)((1.0 - (double)M->strand_specificity) * (double)fraglenpr * (double)fragbias / (double)efflen);
+}
+/* the whole step under the BiasedFragModel; also returns the bias vectors (left / right, concatenated like tseq) when
+ * the pointers are non-NULL (caller-allocated, tseq_ptr[n] floats each) */
+int xb_oracle_build_biased(const xb_transcripts *T, const xb_fragments *F, const xb_fragmodel *M, const xb_biasmodel *B,
+                           float *efflens, float *left_out, float *right_out, int64_t *rows_out, uint64_t **tcolptr,
+                           uint32_t **trowval, float **tnzval, int64_t **row_fragment)
+{
+    const int64_t total = B->tseq_ptr[T->n];
+    float *left = left_out ? left_out : malloc((size_t)(total > 0 ? total : 1) * sizeof(float));
+    float *right = right_out ? right_out : malloc((size_t)(total > 0 ? total : 1) * sizeof(float));
+    for (int32_t j = 0; j < T->n; ++j) {
+        xb_oracle_transcript_bias(B, j, left + B->tseq_ptr[j], right + B->tseq_ptr[j]);
+        efflens[j] = xb_oracle_effective_length_biased(M, B, j, left + B->tseq_ptr[j], right + B->tseq_ptr[j]);
+    }
+    size_t cap = 1024, nnz = 0;
+    uint32_t *cols = malloc(cap * sizeof(uint32_t));
+    float *vals = malloc(cap * sizeof(float));
+    uint64_t *ptr = malloc(((size_t)F->m + 2) * sizeof(uint64_t));
+    int64_t *rf = malloc(((size_t)F->m + 1) * sizeof(int64_t));
+    int64_t rows = 0;
+    ptr[0] = 1;
+    for (int64_t i = 0; i < F->m; ++i) {
+        const size_t start = nnz;
+        int64_t a_last = F->m1_right[i];
+        if (F->m2_left[i] > 0 && F->m2_right[i] > a_last) a_last = F->m2_right[i];
+        for (int32_t j = 0; j < T->n; ++j) {
+            if (T->seq[j] != F->seq[i]) continue;
+            const int64_t tf = T->exon_first[T->exon_ptr[j]], tl = T->exon_last[T->exon_ptr[j + 1] - 1];
+            if (!(tf <= F->m1_left[i] && a_last <= tl)) continue;
+            const float p = xb_oracle_condfragprob_biased(T, F, M, B, j, i, efflens[j], left + B->tseq_ptr[j], right + B->tseq_ptr[j]);
+            if (isfinite(p) && (double)p > MIN_FRAG_PROB) {
+                if (nnz == cap) { cap *= 2; cols = realloc(cols, cap * sizeof(uint32_t)); vals = realloc(vals, cap * sizeof(float)); }
+                cols[nnz] = (uint32_t)j + 1; vals[nnz] = p; ++nnz;
+            }
+        }
+        if (nnz > start) { rf[rows] = i; ptr[++rows] = (uint64_t)nnz + 1; }
+    }
+    if (!left_out) free(left);
+    if (!right_out) free(right);
     *rows_out = rows; *tcolptr = ptr; *trowval = cols; *tnzval = vals; *row_fragment = rf;
     return 0;
 }

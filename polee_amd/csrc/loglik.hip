@@ -366,6 +366,24 @@ __device__ inline const void *uniform_ptr(const void *p)
 // cannot be declared clobbered: hipcc treats M0 as a reserved register and warns that such a clobber is not honoured.
 // Nothing else in these kernels uses it -- LDS instructions on gfx9 do not, there is no movrel / sendmsg -- and the base /
 // offset registers are not rewritten per piece.)
+#ifdef POLEE_DMA_BUILTIN
+// A/B build (`make dmabuiltin`): the LDS-DMA through the compiler's builtin, which models M0 (no
+// unmodelled write) but takes a per-lane 64-bit global address instead of SGPR base + 32-bit lane offset.
+__device__ inline void dma_builtin(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any, int bytes16)
+{
+    typedef __attribute__((address_space(3))) void *lds_vp;
+    typedef const __attribute__((address_space(1))) void *glb_vp;
+    const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
+    glb_vp src = (glb_vp)(reinterpret_cast<const char *>(base_uniform) + voff);
+    if (bytes16)
+        __builtin_amdgcn_global_load_lds(src, (lds_vp)(uintptr_t)lds_dst, 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds(src, (lds_vp)(uintptr_t)lds_dst, 4, 0, 0);
+}
+__device__ inline void dma_1k(const void *b, uint32_t v, uint32_t l) { dma_builtin(b, v, l, 1); }
+__device__ inline void dma_1k_keep(const void *b, uint32_t v, uint32_t l) { dma_builtin(b, v, l, 1); }
+__device__ inline void dma_256(const void *b, uint32_t v, uint32_t l) { dma_builtin(b, v, l, 0); }
+#else
 __device__ inline void dma_1k(const void *base_uniform, uint32_t voff, uint32_t lds_dst_any)
 {
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
@@ -386,6 +404,7 @@ __device__ inline void dma_256(const void *base_uniform, uint32_t voff, uint32_t
     const uint32_t lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst_any);
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" : : "s"(base_uniform), "v"(voff), "s"(lds_dst) : "memory");
 }
+#endif
 __device__ inline uint32_t lds_addr(const void *p)
 {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const char *)p);
@@ -2144,7 +2163,9 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
             fprintf(stderr, "[loglik] stream kernel K=%d%s: %d workgroups per CU by the occupancy query, LDS %zu B, grid %d x %d\n",
                     K, DET ? " (deterministic)" : "", nb, lds, occ, ctx->num_cus);
     }
-    const int G = (int)std::min<int64_t>((int64_t)occ * ctx->num_cus, std::max<int64_t>(h.num_tiles_s, 1));
+    static const int wg_env = getenv("POLEE_STREAM_WGS_PER_CU") ? atoi(getenv("POLEE_STREAM_WGS_PER_CU")) : 0;  // (A/B)
+    const int per_cu = wg_env > 0 ? std::min(wg_env, occ) : occ;
+    const int G = (int)std::min<int64_t>((int64_t)per_cu * ctx->num_cus, std::max<int64_t>(h.num_tiles_s, 1));
     POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
     A.sched = ll->d_sched.p;
     static const bool static_sched = getenv("POLEE_STATIC_SCHED") != nullptr;  // (A/B)

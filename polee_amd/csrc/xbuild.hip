@@ -8,7 +8,10 @@
 //   fragmentlength                      src/transcripts.jl:273-446    (CIGAR intervals against exons / introns)
 //   effective_length, condfragprob      src/fragmodel.jl:119-169      (SimplisticFragModel)
 //   sortperm / compact_indexes! / sparse  src/rnaseq_sample.jl:126-157, 470-489
-// BAM / GFF parsing, bias models and read assignment stay upstream (out of scope).
+// Round 4: the same with the reference's DEFAULT BiasedFragModel given a TRAINED bias model (polee_xbuild_run_biased): the
+// transcripts' bias vectors (compute_transcript_bias!, bias.jl:834-858), the biased effective lengths (fragmodel.jl:372-410)
+// and condfragprob with the fragment's interval on the transcript (fragmodel.jl:413-445, transcripts.jl:452-538).
+// BAM / GFF parsing, TRAINING of the bias model and read assignment stay upstream (out of scope).
 //
 // Formulation: the reference joins two interval trees per sequence on threads.  Here a thread owns a FRAGMENT: the
 // transcripts of its sequence are sorted by first base (once, on the host: a few hundred thousand of them) with a running
@@ -64,6 +67,21 @@ struct XbView {
     float strand_specificity;
     int32_t alt_frag_model;
     const float *efflens;
+    // BiasedFragModel (null tseq: the SimplisticFragModel): sequences, the trained bias model's tables, the transcripts'
+    // bias vectors (compute_transcript_bias!, filled by xb_bias_kernel)
+    const int64_t *tseq_ptr;
+    const uint8_t *tseq;
+    int32_t seqbias_len, ps_ctx;
+    const int32_t *orders_left, *orders_right;
+    const float *ps_left, *ps_right;
+    int32_t gc_nbins;
+    const float *gc_bins;
+    double pos_p;
+    const double *pos_terms;
+    int32_t num_fraglens;
+    const int32_t *high_prob_fraglens;
+    const uint8_t *m1_reverse;
+    float *left_bias, *right_bias;
 };
 
 struct CigIter {
@@ -246,6 +264,170 @@ __device__ inline float condfragprob(const XbView &v, int32_t j, int64_t i)
     return (float)fragpr;
 }
 
+// ---- BiasedFragModel (src/fragmodel.jl:174-445 with a TRAINED bias model, src/bias.jl:402-456, 517-520, 649-663, 834-858) ---
+constexpr int XB_BIAS_SEQ_INNER_CTX = 15, XB_BIAS_SEQ_OUTER_CTX = 5;  // src/constants.jl:77-78
+__device__ inline int xb_code_at(const uint8_t *seq, int64_t len, int64_t j)  // 1-based; off the ends: A (the reference draws a random
+{                                                                             // nucleotide there, bias.jl:424-429: not reproducible)
+    if (j < 1 || j > len) return 0;
+    const uint8_t c = seq[j - 1];
+    return c < 4 ? c : 0;  // nt2bit: N -> 0 (bias.jl:176-181)
+}
+__device__ inline int xb_is_gc(uint8_t c) { return c == 1 || c == 2; }
+template <bool RIGHT>
+__device__ inline float xb_seqbias_eval(const XbView &v, const uint8_t *seq, int64_t len, int64_t pos)
+{
+    const int32_t *orders = RIGHT ? v.orders_right : v.orders_left;
+    const float *ps = RIGHT ? v.ps_right : v.ps_left;
+    const int64_t first = RIGHT ? pos - XB_BIAS_SEQ_INNER_CTX + 1 : pos - XB_BIAS_SEQ_OUTER_CTX;
+    float bias = 1.0f;
+    for (int32_t i = 0; i < v.seqbias_len; ++i) {
+        const int32_t order = orders[i];
+        if (order < 0) continue;
+        const int64_t j = first + i;
+        const int c = xb_code_at(seq, len, j);
+        int ctx = 0;
+        for (int l = 1; l <= order; ++l) ctx = (ctx << 2) | xb_code_at(seq, len, j + l);
+        bias = __fmul_rn(bias, ps[((size_t)i * 4 + (size_t)c) * (size_t)v.ps_ctx + (size_t)ctx]);
+    }
+    return bias;
+}
+__device__ inline float xb_hist_f32(const XbView &v, float x)  // evaluate(::SimpleHistogramModel, x): round(Int, x * nbins) to even
+{
+    long long i = __float2ll_rn(__fmul_rn(x, (float)v.gc_nbins));
+    i = i < 1 ? 1 : (i > v.gc_nbins ? v.gc_nbins : i);
+    return v.gc_bins[i - 1];
+}
+__device__ inline float xb_hist_f64(const XbView &v, double x)
+{
+    long long i = __double2ll_rn(__dmul_rn(x, (double)v.gc_nbins));
+    i = i < 1 ? 1 : (i > v.gc_nbins ? v.gc_nbins : i);
+    return v.gc_bins[i - 1];
+}
+// compute_transcript_bias! (bias.jl:834-858): a thread per base of every transcript
+__global__ void xb_bias_kernel(XbView v, int64_t total)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int32_t lo = 0, hi = v.n;  // transcript of base g: last j with tseq_ptr[j] <= g
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (v.tseq_ptr[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int32_t j = lo;
+    const int64_t off = v.tseq_ptr[j], tlen = v.tseq_ptr[j + 1] - off, pos = g - off + 1;
+    const uint8_t *seq = v.tseq + off;
+    const float sb = xb_seqbias_eval<false>(v, seq, tlen, pos);
+    float l;
+    if (v.pos_terms) {  // evaluate(posmodel, tlen, tlen - pos + 1) in Float64 (bias.jl:649-658), times the Float32 sequence bias
+        const double base = __dadd_rn(__dmul_rn(__ddiv_rn(1.0, (double)tlen), pow(1.0 - v.pos_p, (double)tlen)), v.pos_terms[tlen - 1]);
+        const double prob = __dsub_rn(base, v.pos_terms[(tlen - pos + 1) - 1]);
+        l = (float)__dmul_rn(__ddiv_rn(prob, base), (double)sb);
+    } else {
+        l = sb;
+    }
+    v.left_bias[g] = l;
+    v.right_bias[g] = xb_seqbias_eval<true>(v, seq, tlen, pos);
+}
+// effective_length(::BiasedFragModel, t) (fragmodel.jl:372-410), the inner sum c of one (transcript, fragment length): a
+// Float32 sum in sequence over the positions, the GC proportion of the sliding window updated in sequence like the
+// reference's.  A thread per pair; csum [n][num_fraglens].
+__global__ void xb_efflen_biased_c_kernel(XbView v, float *__restrict__ csum)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)v.n * v.num_fraglens) return;
+    const int32_t j = (int32_t)(t / v.num_fraglens), f = (int32_t)(t - (int64_t)j * v.num_fraglens);
+    const int64_t off = v.tseq_ptr[j], tlen = v.tseq_ptr[j + 1] - off;
+    const int64_t fraglen = v.high_prob_fraglens[f];
+    if (fraglen > tlen) {
+        csum[t] = 0.0f;
+        return;
+    }
+    const uint8_t *seq = v.tseq + off;
+    const float *left = v.left_bias + off, *right = v.right_bias + off;
+    const float gc_c = __fdiv_rn(1.0f, (float)fraglen);
+    float frag_gc_prop = 0.0f;
+    for (int64_t pos = 1; pos <= fraglen; ++pos) frag_gc_prop = __fadd_rn(frag_gc_prop, xb_is_gc(seq[pos - 1]) ? gc_c : 0.0f);
+    float c = 0.0f;
+    for (int64_t pos = 1; pos <= tlen - fraglen + 1; ++pos) {
+        if (pos > 1) {
+            frag_gc_prop = __fsub_rn(frag_gc_prop, xb_is_gc(seq[pos - 2]) ? gc_c : 0.0f);
+            frag_gc_prop = __fadd_rn(frag_gc_prop, xb_is_gc(seq[pos + fraglen - 2]) ? gc_c : 0.0f);
+        }
+        c = __fadd_rn(c, __fmul_rn(__fmul_rn(left[pos - 1], right[pos + fraglen - 2]), xb_hist_f32(v, frag_gc_prop)));
+    }
+    csum[t] = c;
+}
+// ... and the sum over the fragment lengths, in the list's order (a thread per transcript)
+__global__ void xb_efflen_biased_sum_kernel(XbView v, const float *__restrict__ csum, float *__restrict__ efflens)
+{
+    const int32_t j = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= v.n) return;
+    const int64_t tlen = v.tseq_ptr[j + 1] - v.tseq_ptr[j];
+    float efflen = 0.0f;
+    for (int32_t f = 0; f < v.num_fraglens; ++f) {
+        const int64_t fraglen = v.high_prob_fraglens[f];
+        if (fraglen > tlen) continue;
+        const float fraglenpr = fraglen <= XB_MAX_FRAG_LEN ? v.pmf[fraglen - 1] : 0.0f;
+        efflen = __fadd_rn(efflen, __fmul_rn(csum[(int64_t)j * v.num_fraglens + f], fraglenpr));
+    }
+    efflens[j] = fmaxf(efflen, XB_MIN_EFFECTIVE_LENGTH);
+}
+// genomic_to_transcriptomic(t, position) (transcripts.jl:520-538): 0 = not in an exon
+__device__ inline int64_t xb_g2t_pos(const XbView &v, int32_t j, int64_t position)
+{
+    const int64_t e0 = v.exon_ptr[j], ne = v.exon_ptr[j + 1] - e0;
+    const int64_t *ef = v.exon_first + e0, *el = v.exon_last + e0;
+    int64_t lo = 0, hi = ne;  // searchsortedlast(exons, Exon(position, position))
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ef[mid] < position || (ef[mid] == position && el[mid] <= position)) lo = mid + 1; else hi = mid;
+    }
+    const int64_t i = lo;
+    if (i == 0 || el[i - 1] < position) return 0;
+    int64_t tpos = 1;
+    for (int64_t k = 0; k < i - 1; ++k) tpos += el[k] - ef[k] + 1;
+    tpos += position - ef[i - 1];
+    if (v.t_strand[j] < 0) tpos = exonic_length(v, j) - tpos + 1;
+    return tpos;
+}
+// condfragprob(::BiasedFragModel, ...) (fragmodel.jl:413-445) with genomic_to_transcriptomic (transcripts.jl:452-517)
+__device__ inline float condfragprob_biased(const XbView &v, int32_t j, int64_t i)
+{
+    int64_t fraglen = fragmentlength(v, j, i);
+    if (fraglen < 0) return 0.0f;
+    if (fraglen <= 0) {
+        fraglen = v.fraglen_median;
+        if (fraglen <= 0) return 0.0f;
+    }
+    const int64_t off = v.tseq_ptr[j], tlen = v.tseq_ptr[j + 1] - off;
+    int64_t tpos;
+    if (v.m2_left[i] > 0) {
+        const int64_t lmin = min(v.m1_left[i], v.m2_left[i]), rmax = max(v.m1_right[i], v.m2_right[i]);
+        tpos = xb_g2t_pos(v, j, v.t_strand[j] > 0 ? lmin : rmax);
+    } else {
+        const bool aln_neg = v.m1_reverse[i] != 0;
+        if (v.t_strand[j] > 0) tpos = !aln_neg ? xb_g2t_pos(v, j, v.m1_left[i]) : xb_g2t_pos(v, j, v.m1_right[i]) - fraglen;
+        else tpos = !aln_neg ? xb_g2t_pos(v, j, v.m1_left[i]) - fraglen : xb_g2t_pos(v, j, v.m1_right[i]);
+    }
+    if (tpos <= 0) {
+        fraglen += tpos - 1;
+        tpos = 1;
+    }
+    if (tpos + fraglen - 1 > tlen) fraglen = tlen - tpos + 1;
+    if (fraglen <= 0) return 0.0f;
+    const int64_t a = tpos, b = tpos + fraglen - 1;
+    const float fraglenpr = fraglen <= XB_MAX_FRAG_LEN ? v.pmf[fraglen - 1] : 0.0f;
+    const uint8_t *seq = v.tseq + off;
+    int64_t gc = 0;
+    for (int64_t pos = a; pos <= b; ++pos) gc += xb_is_gc(seq[pos - 1]);
+    const double frag_gc = __ddiv_rn((double)gc, (double)fraglen);
+    const float fragbias = __fmul_rn(__fmul_rn(v.left_bias[off + a - 1], v.right_bias[off + b - 1]), xb_hist_f64(v, frag_gc));
+    const float efflen = v.efflens[j];
+    if (v.f_strand[i] == v.t_strand[j])
+        return __fdiv_rn(__fmul_rn(__fmul_rn(v.strand_specificity, fraglenpr), fragbias), efflen);
+    return (float)__ddiv_rn(__dmul_rn(__dmul_rn(1.0 - (double)v.strand_specificity, (double)fraglenpr), (double)fragbias), (double)efflen);
+}
+
 // Transcripts containing fragment i, in descending order of their position in the sorted list; f(j, fragpr) for the kept
 // ones (finite, > MIN_FRAG_PROB: rnaseq_sample.jl:99)
 template <typename F>
@@ -266,7 +448,7 @@ __device__ inline void for_each_entry(const XbView &v, int64_t i, F &&f)
         if (v.ord_maxlast[k] < a_last) break;  // no transcript at or before k reaches the fragment's end
         const int32_t j = v.ord[k];
         if (v.exon_last[v.exon_ptr[j + 1] - 1] < a_last) continue;  // intersect_contains (rnaseq_sample.jl:77-79)
-        const float p = condfragprob(v, j, i);
+        const float p = v.tseq ? condfragprob_biased(v, j, i) : condfragprob(v, j, i);
         if (isfinite(p) && (double)p > XB_MIN_FRAG_PROB) f(j, p);
     }
 }
@@ -410,7 +592,9 @@ struct polee_xbuild {
     polee_ctx *ctx = nullptr;
     int64_t rows = 0, nnz = 0, m = 0;
     int32_t n = 0;
-    DevBuf<float> d_efflens, d_vals;
+    DevBuf<float> d_efflens, d_vals, d_left_bias, d_right_bias;  // (bias vectors: BiasedFragModel only)
+    int64_t total_bases = 0;
+    double ms_bias = 0;
     DevBuf<uint32_t> d_cols;
     DevBuf<uint64_t> d_tcolptr;
     DevBuf<int64_t> d_row_fragment;
@@ -420,7 +604,7 @@ struct polee_xbuild {
 extern "C" {
 
 static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
-                              polee_xbuild **out)
+                              const polee_xb_biasmodel *B, polee_xbuild **out)
 {
     POLEE_TRY(use_device(ctx));
     if (!T || !F || !M || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run: null argument");
@@ -501,8 +685,40 @@ static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcr
     }
     for (int32_t s = 0; s < num_seq; ++s) seq_ptr[(size_t)s + 1] += seq_ptr[(size_t)s];
 
+    // the trained bias model (BiasedFragModel): tables present and consistent with the transcripts
+    int64_t total_bases = 0;
+    if (B) {
+        if (!B->tseq_ptr || !B->tseq || !B->orders_left || !B->orders_right || !B->ps_left || !B->ps_right || !B->gc_bins ||
+            !B->high_prob_fraglens)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run_biased: a bias-model array is null");
+        if (B->seqbias_len != XB_BIAS_SEQ_INNER_CTX + XB_BIAS_SEQ_OUTER_CTX)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "seqbias_len must be %d (BIAS_SEQ_OUTER_CTX + BIAS_SEQ_INNER_CTX)", XB_BIAS_SEQ_INNER_CTX + XB_BIAS_SEQ_OUTER_CTX);
+        if (B->gc_nbins < 1 || B->num_fraglens < 1 || B->ps_ctx < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bias model: empty table");
+        int max_order = 0;
+        for (int32_t i = 0; i < B->seqbias_len; ++i) max_order = std::max(max_order, std::max(B->orders_left[i], B->orders_right[i]));
+        if (max_order > 8 || (int64_t)B->ps_ctx < ((int64_t)1 << (2 * max_order)))
+            return fail(ctx, POLEE_ERR_BAD_ARG, "bias model: ps_ctx = %d is smaller than 4^(largest order %d)", B->ps_ctx, max_order);
+        if (B->tseq_ptr[0] != 0) return fail(ctx, POLEE_ERR_BAD_ARG, "tseq_ptr[0] must be 0");
+        int64_t max_tlen = 0;
+        for (int32_t j = 0; j < n; ++j) {
+            const int64_t tlen = B->tseq_ptr[j + 1] - B->tseq_ptr[j];
+            int64_t ex = 0;
+            for (int64_t k = T->exon_ptr[j]; k < T->exon_ptr[j + 1]; ++k) ex += T->exon_last[k] - T->exon_first[k] + 1;
+            if (tlen != ex) return fail(ctx, POLEE_ERR_BAD_ARG, "transcript %d: sequence of %lld bases, exons of %lld", j, (long long)tlen, (long long)ex);
+            max_tlen = std::max(max_tlen, tlen);
+        }
+        total_bases = B->tseq_ptr[n];
+        if (B->pos_terms && B->pos_maxtlen < max_tlen)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "positional bias terms cover transcripts up to %d bases, the longest has %lld", B->pos_maxtlen, (long long)max_tlen);
+        for (int32_t f = 0; f < B->num_fraglens; ++f)
+            if (B->high_prob_fraglens[f] < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "high_prob_fraglens[%d] = %d", f, B->high_prob_fraglens[f]);
+        bool any_single = false;
+        for (int64_t i = 0; i < m && !any_single; ++i) any_single = F->m2_left[i] == 0;
+        if (any_single && !B->m1_reverse) return fail(ctx, POLEE_ERR_BAD_ARG, "single-end fragments need m1_reverse (transcripts.jl:486)");
+    }
     polee_xbuild *xb = new (std::nothrow) polee_xbuild();
     if (!xb) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    xb->total_bases = total_bases;
     xb->ctx = ctx;
     xb->n = n;
     xb->m = m;
@@ -531,9 +747,38 @@ static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcr
         polee_xbuild_destroy(xb);
         return s;
     }
+    DevBuf<int64_t> d_tsp;
+    DevBuf<uint8_t> d_tsq, d_m1rev;
+    DevBuf<int32_t> d_ol, d_or, d_hpf;
+    DevBuf<float> d_psl, d_psr, d_gcb, d_csum;
+    DevBuf<double> d_pterms;
+    if (B) {
+        const size_t psn = (size_t)B->seqbias_len * 4 * (size_t)B->ps_ctx;
+        std::vector<uint8_t> rev_zero;
+        const uint8_t *rev = B->m1_reverse;
+        if (!rev) {  // (no single-end fragment: never read)
+            rev_zero.assign((size_t)std::max<int64_t>(m, 1), 0);
+            rev = rev_zero.data();
+        }
+        A(d_tsp.upload(ctx, B->tseq_ptr, (size_t)n + 1)); A(d_tsq.upload(ctx, B->tseq, (size_t)std::max<int64_t>(total_bases, 1)));
+        A(d_ol.upload(ctx, B->orders_left, (size_t)B->seqbias_len)); A(d_or.upload(ctx, B->orders_right, (size_t)B->seqbias_len));
+        A(d_psl.upload(ctx, B->ps_left, psn)); A(d_psr.upload(ctx, B->ps_right, psn));
+        A(d_gcb.upload(ctx, B->gc_bins, (size_t)B->gc_nbins)); A(d_hpf.upload(ctx, B->high_prob_fraglens, (size_t)B->num_fraglens));
+        if (B->pos_terms) A(d_pterms.upload(ctx, B->pos_terms, (size_t)B->pos_maxtlen));
+        A(d_m1rev.upload(ctx, rev, (size_t)std::max<int64_t>(m, 1)));
+        A(xb->d_left_bias.alloc(ctx, (size_t)std::max<int64_t>(total_bases, 1))); A(xb->d_right_bias.alloc(ctx, (size_t)std::max<int64_t>(total_bases, 1)));
+        A(d_csum.alloc(ctx, (size_t)n * (size_t)B->num_fraglens));
+        if (s != POLEE_OK) {
+            polee_xbuild_destroy(xb);
+            return s;
+        }
+    }
     XbView v{n, d_tseq.p, d_tstrand.p, d_eptr.p, d_ef.p, d_el.p, d_ord.p, d_ofirst.p, d_omax.p, d_seqptr.p, num_seq, m, d_fseq.p, d_fstrand.p,
              d_m1l.p, d_m1r.p, d_m2l.p, d_m2r.p, d_flag16.p, d_c1.p, d_c2.p, d_cigop.p, d_ciglen.p, d_pmf.p, d_cdf.p, M->fraglen_median,
-             M->strand_specificity, M->alt_frag_model, xb->d_efflens.p};
+             M->strand_specificity, M->alt_frag_model, xb->d_efflens.p,
+             B ? d_tsp.p : nullptr, B ? d_tsq.p : nullptr, B ? B->seqbias_len : 0, B ? B->ps_ctx : 0, d_ol.p, d_or.p, d_psl.p, d_psr.p,
+             B ? B->gc_nbins : 0, d_gcb.p, B ? B->pos_p : 0.0, B && B->pos_terms ? d_pterms.p : nullptr, B ? B->num_fraglens : 0, d_hpf.p,
+             d_m1rev.p, xb->d_left_bias.p, xb->d_right_bias.p};
     hipStream_t st = ctx->stream;
     auto timed = [&](double &ms, auto &&launch) -> polee_status {
         (void)hipEventRecord(ctx->ev0, st);
@@ -548,7 +793,20 @@ static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcr
     };
     const unsigned nbm = (unsigned)std::max<int64_t>(1, ceil_div(m, 256));
     int64_t nnz = 0, rows = 0;
-    if ((s = timed(xb->ms_efflen, [&] { hipLaunchKernelGGL(xb_efflen_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, st, v, xb->d_efflens.p); })) ||
+    if (B && (s = timed(xb->ms_bias, [&] {
+            if (total_bases > 0) hipLaunchKernelGGL(xb_bias_kernel, dim3((unsigned)ceil_div(total_bases, 256)), dim3(256), 0, st, v, total_bases);
+        }))) {
+        polee_xbuild_destroy(xb);
+        return s;
+    }
+    if ((s = timed(xb->ms_efflen, [&] {
+            if (B) {
+                hipLaunchKernelGGL(xb_efflen_biased_c_kernel, dim3((unsigned)ceil_div((int64_t)n * B->num_fraglens, 64)), dim3(64), 0, st, v, d_csum.p);
+                hipLaunchKernelGGL(xb_efflen_biased_sum_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, st, v, (const float *)d_csum.p, xb->d_efflens.p);
+            } else {
+                hipLaunchKernelGGL(xb_efflen_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, st, v, xb->d_efflens.p);
+            }
+        })) ||
         (s = timed(xb->ms_count, [&] { hipLaunchKernelGGL(xb_count_kernel, dim3(nbm), dim3(256), 0, st, v, d_counts.p); })) ||
         (s = exclusive_scan_i64<false>(ctx, d_counts.p, m, d_off.p, d_tmp, &nnz)) ||
         (s = exclusive_scan_i64<true>(ctx, d_counts.p, m, d_rowid.p, d_tmp, &rows)) ||
@@ -570,7 +828,26 @@ static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcr
 polee_status polee_xbuild_run(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
                               polee_xbuild **out)
 {
-    return guarded(ctx, "polee_xbuild_run", [&] { return polee_xbuild_run_impl(ctx, T, F, M, out); });
+    return guarded(ctx, "polee_xbuild_run", [&] { return polee_xbuild_run_impl(ctx, T, F, M, nullptr, out); });
+}
+
+polee_status polee_xbuild_run_biased(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,
+                                     const polee_xb_biasmodel *B, polee_xbuild **out)
+{
+    if (!B) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_xbuild_run_biased: null bias model");
+    return guarded(ctx, "polee_xbuild_run_biased", [&] { return polee_xbuild_run_impl(ctx, T, F, M, B, out); });
+}
+
+polee_status polee_xbuild_get_bias(const polee_xbuild *xb, float *left_bias, float *right_bias, double *ms_bias)
+{
+    if (!xb) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
+    polee_ctx *ctx = xb->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!xb->d_left_bias.p) return fail(ctx, POLEE_ERR_BAD_ARG, "this matrix was built without a bias model");
+    if (left_bias) POLEE_TRY(xb->d_left_bias.download(ctx, left_bias, (size_t)xb->total_bases));
+    if (right_bias) POLEE_TRY(xb->d_right_bias.download(ctx, right_bias, (size_t)xb->total_bases));
+    if (ms_bias) *ms_bias = xb->ms_bias;
+    return POLEE_OK;
 }
 
 void polee_xbuild_destroy(polee_xbuild *xb)

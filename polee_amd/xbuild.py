@@ -25,6 +25,39 @@ class _FragModel(C.Structure):
                 ("strand_specificity", C.c_float), ("alt_frag_model", C.c_int32)]
 
 
+class _BiasModel(C.Structure):
+    _fields_ = [("tseq_ptr", C.c_void_p), ("tseq", C.c_void_p), ("seqbias_len", C.c_int32), ("ps_ctx", C.c_int32),
+                ("orders_left", C.c_void_p), ("orders_right", C.c_void_p), ("ps_left", C.c_void_p), ("ps_right", C.c_void_p),
+                ("gc_nbins", C.c_int32), ("gc_bins", C.c_void_p), ("pos_p", C.c_double), ("pos_terms", C.c_void_p),
+                ("pos_maxtlen", C.c_int32), ("num_fraglens", C.c_int32), ("high_prob_fraglens", C.c_void_p),
+                ("m1_reverse", C.c_void_p)]
+
+
+def pack_bias(bias):
+    """ctypes struct (+ the arrays it borrows) of a TRAINED bias model (polee_xb_biasmodel, include/polee_hip.h): dict with
+    tseq_ptr i64 [n+1], tseq u8 (0 A, 1 C, 2 G, 3 T, 4 other; transcript orientation), orders_left / orders_right i32 [20],
+    ps_left / ps_right f32 [20, 4, ps_ctx], gc_bins f32, high_prob_fraglens i32 [200], optional pos_p + pos_terms f64,
+    optional m1_reverse u8 [m]."""
+    keep = []
+
+    def ptr(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+    psl = np.ascontiguousarray(bias["ps_left"], np.float32)
+    psr = np.ascontiguousarray(bias["ps_right"], np.float32)
+    assert psl.ndim == 3 and psl.shape == psr.shape and psl.shape[1] == 4
+    pt = bias.get("pos_terms")
+    B = _BiasModel(ptr(bias["tseq_ptr"], np.int64), ptr(bias["tseq"], np.uint8), psl.shape[0], psl.shape[2],
+                   ptr(bias["orders_left"], np.int32), ptr(bias["orders_right"], np.int32), ptr(psl, np.float32), ptr(psr, np.float32),
+                   len(bias["gc_bins"]), ptr(bias["gc_bins"], np.float32), float(bias.get("pos_p", 0.0)), ptr(pt, np.float64),
+                   0 if pt is None else len(pt), len(bias["high_prob_fraglens"]), ptr(bias["high_prob_fraglens"], np.int32),
+                   ptr(bias.get("m1_reverse"), np.uint8))
+    return B, keep
+
+
 _T_TYPES = dict(seq=np.int32, strand=np.int8, exon_ptr=np.int64, exon_first=np.int64, exon_last=np.int64)
 _F_TYPES = dict(seq=np.int32, strand=np.int8, m1_left=np.int64, m1_right=np.int64, m2_left=np.int64, m2_right=np.int64,
                 m1_is_flag16=np.uint8, cig1_ptr=np.int64, cig2_ptr=np.int64, cig_op=np.uint8, cig_len=np.int32)
@@ -76,16 +109,24 @@ def order_mates(fragments):
 
 
 def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity=0.9,
-                            alt_frag_model=False, ctx=None):
+                            alt_frag_model=False, ctx=None, bias=None, return_bias=False):
     """-> dict(m, n, nnz, tcolptr u64 [m+1], trowval u32, tnzval f32 (the rows of X, 1-based, what RNASeqSample(xt=...)
     takes), effective_lengths f32 [n], row_fragment i64 [m], kernel_ms).  The mates of a pair may come in any order
-    (order_mates)."""
+    (order_mates).  bias: a trained bias model (pack_bias) -> the reference's default BiasedFragModel
+    (src/fragmodel.jl:174-445) instead of the SimplisticFragModel; return_bias adds left_bias / right_bias (the
+    transcripts' bias vectors, compute_transcript_bias!)."""
     from .core import default_context
     ctx = ctx or default_context()
     fragments = order_mates(fragments)
     T, F, M, keep = pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity, alt_frag_model)
     h = C.c_void_p()
-    check(L.lib().polee_xbuild_run(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(h)), ctx._h)
+    if bias is not None:
+        if bias.get("m1_reverse") is not None and "_mate_swap" in fragments:
+            raise ValueError("order the mates (order_mates) before deriving m1_reverse")
+        Bs, keep_b = pack_bias(bias)
+        check(L.lib().polee_xbuild_run_biased(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(Bs), C.byref(h)), ctx._h)
+    else:
+        check(L.lib().polee_xbuild_run(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(h)), ctx._h)
     try:
         rows, nnz = C.c_int64(), C.c_int64()
         ms = [C.c_double(), C.c_double(), C.c_double()]
@@ -97,6 +138,12 @@ def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fr
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(L.lib().polee_xbuild_get(h, p(out["tcolptr"]), p(out["trowval"]), p(out["tnzval"]), p(out["effective_lengths"]),
                                        p(out["row_fragment"])), ctx._h)
+        if bias is not None and return_bias:
+            total = int(np.asarray(bias["tseq_ptr"])[-1])
+            out["left_bias"], out["right_bias"] = np.empty(total, np.float32), np.empty(total, np.float32)
+            msb = C.c_double()
+            check(L.lib().polee_xbuild_get_bias(h, p(out["left_bias"]), p(out["right_bias"]), C.byref(msb)), ctx._h)
+            out["kernel_ms"]["bias"] = msb.value
     finally:
         L.lib().polee_xbuild_destroy(h)
     del keep

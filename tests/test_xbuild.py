@@ -211,3 +211,104 @@ def test_device_validates_fragments_and_accepts_any_mate_order():
     assert raw(bad) != 0  # right < left
     bad = dict(d["fragments"]); ln = np.array(bad["cig_len"]); ln[0] = -3; bad["cig_len"] = ln
     assert raw(bad) != 0 or np.diff(np.asarray(bad["cig1_ptr"]))[0] == 0  # negative operation length
+
+
+# ---- BiasedFragModel (the reference's default; src/fragmodel.jl:174-445 with a trained bias model, src/bias.jl) ------------
+
+def _toy_bias(T, F, pmf, **kw):
+    b = synth_aln.make_bias_model(T, F, pmf, **kw)
+    return b
+
+
+def test_oracle_biased_model_on_a_hand_computed_case():
+    """One transcript on the + strand (exons 101..160 and 201..260: 120 bases), a trained model with ONE position in each
+    sequence-bias table, two GC bins, no positional model; a paired fragment.  Every number is recomputed in NumPy from
+    the reference's formulas: compute_transcript_bias! (bias.jl:834-858), effective_length (fragmodel.jl:372-410),
+    genomic_to_transcriptomic (transcripts.jl:452-538) and condfragprob (fragmodel.jl:413-445)."""
+    T = _one_transcript([(101, 160), (201, 260)])
+    M_, N_ = 0, 3
+    F = _frags([(1, (111, 150, [(M_, 40)]), (211, 250, [(M_, 40)]), 0)])   # fragment 111..250 minus the 40-base intron: 100 bases
+    pmf, cdf, med = synth_aln.fraglen_model(100.0, 10.0)
+    rng = np.random.default_rng(0)
+    tseq = rng.integers(0, 4, 120).astype(np.uint8)
+    orders_l = np.full(20, -1, np.int32); orders_l[5] = 0      # the fragment's first base itself (pos - 5 + 5)
+    orders_r = np.full(20, -1, np.int32); orders_r[14] = 1     # the fragment's last base with one base of context
+    ps_l = np.ones((20, 4, 4), np.float32); ps_l[5, :, 0] = [0.5, 1.0, 1.5, 2.0]
+    ps_r = np.ones((20, 4, 4), np.float32); ps_r[14] = rng.uniform(0.5, 2.0, (4, 4)).astype(np.float32)
+    bias = dict(tseq_ptr=np.array([0, 120], np.int64), tseq=tseq, orders_left=orders_l, orders_right=orders_r, ps_left=ps_l,
+                ps_right=ps_r, gc_bins=np.array([0.8, 1.25], np.float32),
+                high_prob_fraglens=np.array([100, 99, 101, 130], np.int32), m1_reverse=np.zeros(1, np.uint8))
+    Ts, Fs, Ms, keep = XB.pack(T, F, pmf, cdf, med, 0.9, False)
+    Bs, kb = XB.pack_bias(bias)
+    o = OX.build_biased(Ts, Fs, Ms, Bs, 1, 120)
+    code = lambda j: int(tseq[j - 1]) if 1 <= j <= 120 else 0          # off the ends: A
+    left = np.array([ps_l[5, code(p), 0] for p in range(1, 121)], np.float32)
+    right = np.array([ps_r[14, code(p), code(p + 1)] for p in range(1, 121)], np.float32)
+    np.testing.assert_array_equal(o["left_bias"], left)
+    np.testing.assert_array_equal(o["right_bias"], right)
+    gcb = lambda x: bias["gc_bins"][int(np.clip(np.round(x * 2), 1, 2)) - 1]  # round half to even, like Julia's round(Int, .)
+    isgc = (tseq == 1) | (tseq == 2)
+    el = np.float32(0)
+    for fl in (100, 99, 101):                                             # 130 > tlen: skipped
+        c = np.float32(0)
+        for pos in range(1, 120 - fl + 2):
+            prop = np.float32(isgc[pos - 1:pos - 1 + fl].sum() / fl)        # (the oracle slides the window in Float32: <= 1e-5 apart)
+            c = np.float32(c + np.float32(np.float32(left[pos - 1] * right[pos + fl - 2]) * gcb(prop)))
+        el = np.float32(el + np.float32(c * pmf[fl - 1]))
+    np.testing.assert_allclose(o["effective_lengths"][0], el, rtol=1e-5)
+    # the fragment: positions 11 .. 110 of the transcript (111 - 101 + 1 = 11; 100 bases)
+    gc = isgc[10:110].mean()
+    expect = np.float32(0.9) * pmf[99] * np.float32(left[10] * right[109]) * gcb(gc) / o["effective_lengths"][0]
+    assert o["m"] == 1 and o["trowval"].tolist() == [1]
+    np.testing.assert_allclose(o["tnzval"][0], expect, rtol=1e-6)
+
+
+def test_oracle_biased_single_end_and_negative_strand():
+    """genomic_to_transcriptomic for a transcript on the - strand and single-end reads (transcripts.jl:471-512): the position
+    arithmetic as written, the overhang nudges; all entries finite, probabilities scale with 1 / effective length."""
+    d = synth_aln.make(40, 1500, seed=8, p_single=0.5)
+    pmf, cdf, med = synth_aln.fraglen_model()
+    bias = _toy_bias(d["transcripts"], d["fragments"], pmf, seed=4, use_pos_bias=True)
+    Ts, Fs, Ms, keep = XB.pack(d["transcripts"], d["fragments"], pmf, cdf, med, 0.9, False)
+    Bs, kb = XB.pack_bias(bias)
+    o = OX.build_biased(Ts, Fs, Ms, Bs, 40, int(bias["tseq_ptr"][-1]))
+    assert np.isfinite(o["tnzval"]).all() and (o["tnzval"] > 1e-12).all() and (o["effective_lengths"] >= 1).all()
+    assert (np.asarray(d["transcripts"]["strand"]) < 0).any() and (np.asarray(d["fragments"]["m2_left"]) == 0).sum() > 300
+    tt = d["true_transcript"]
+    ptr = o["tcolptr"].astype(np.int64) - 1
+    hit = [tt[i] + 1 in o["trowval"][ptr[r]:ptr[r + 1]] for r, i in enumerate(o["row_fragment"]) if tt[i] >= 0]
+    assert np.mean(hit) > 0.98  # (a handful of single-end guesses fall off the transcript's end and are dropped)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,pos,seed", [(200, 15000, False, 3), (1500, 80000, True, 4)])
+def test_device_biased_model_matches_oracle(n, m, pos, seed):
+    """polee_xbuild_run_biased against the restatement: bit-identical bias vectors and effective lengths (the same Float32
+    operations in the same order), identical sparsity pattern, values to 1e-6."""
+    import polee_amd as P
+    ctx = P.Context(0)
+    d = synth_aln.make(n, m, seed=seed, p_single=0.2, p_noise=0.05)
+    pmf, cdf, med = synth_aln.fraglen_model(180.0, 60.0)
+    bias = _toy_bias(d["transcripts"], d["fragments"], pmf, seed=seed + 10, use_pos_bias=pos)
+    Ts, Fs, Ms, keep = XB.pack(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, False)
+    Bs, kb = XB.pack_bias(bias)
+    total = int(bias["tseq_ptr"][-1])
+    o = OX.build_biased(Ts, Fs, Ms, Bs, n, total)
+    g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, False, ctx=ctx, bias=bias, return_bias=True)
+    np.testing.assert_array_equal(g["right_bias"], o["right_bias"])
+    if pos:  # (the positional term is Float64 arithmetic with a pow(): device and host libm may differ in the last place)
+        np.testing.assert_allclose(g["left_bias"], o["left_bias"], rtol=2e-7)
+        np.testing.assert_allclose(g["effective_lengths"], o["effective_lengths"], rtol=1e-5)
+    else:
+        np.testing.assert_array_equal(g["left_bias"], o["left_bias"])
+        np.testing.assert_array_equal(g["effective_lengths"], o["effective_lengths"])
+    assert g["m"] == o["m"] and g["nnz"] == o["nnz"] and g["m"] > 0.8 * m
+    np.testing.assert_array_equal(g["row_fragment"], o["row_fragment"])
+    np.testing.assert_array_equal(g["trowval"], o["trowval"])
+    np.testing.assert_allclose(g["tnzval"], o["tnzval"], rtol=1e-6 if not pos else 2e-5)
+    print("biased X construction n=%d m=%d: %d rows, %d non-zeros, %d bases; kernels %s ms" % (n, m, g["m"], g["nnz"], total, g["kernel_ms"]))
+    # a malformed model is rejected
+    bad = dict(bias); bad["tseq_ptr"] = bias["tseq_ptr"].copy(); bad["tseq_ptr"][-1] += 5
+    bad["tseq"] = np.concatenate([bias["tseq"], np.zeros(5, np.uint8)])
+    with pytest.raises(P.PoleeError):
+        XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, False, ctx=ctx, bias=bad)

@@ -59,3 +59,34 @@ def make(n, m, num_seq=4, seed=1, read_len=75, p_single=0.1, p_noise=0.05, stran
     F["cig_op"], F["cig_len"] = cop[:max(nc, 1)].copy(), clen[:max(nc, 1)].copy()
     L.aln_model_free(h)
     return dict(transcripts=T, fragments=F, true_transcript=tt)
+
+
+def make_bias_model(transcripts, fragments, pmf, seed=1, use_pos_bias=False, num_fraglens=200, max_order=2, gc_nbins=20):
+    """A synthetic TRAINED bias model in the layout of polee_xb_biasmodel (include/polee_hip.h): random transcript sequences
+    (codes 0..3, a few N = 4), sequence-bias tables of the reference's shape (20 positions, orders in -1..max_order,
+    probability ratios in [0.8, 1.25]), GC histogram bins, optionally a positional model, the `num_fraglens` most probable
+    fragment lengths (fragmodel.jl:358-359), and m1_reverse for the single-end fragments."""
+    rng = np.random.default_rng(seed)
+    ep, ef, el = (np.asarray(transcripts[k], np.int64) for k in ("exon_ptr", "exon_first", "exon_last"))
+    n = int(transcripts["n"])
+    lens = np.array([int((el[ep[j]:ep[j + 1]] - ef[ep[j]:ep[j + 1]] + 1).sum()) for j in range(n)], np.int64)
+    tseq_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gc_rate = rng.uniform(0.35, 0.65, n)
+    tseq = np.empty(int(tseq_ptr[-1]), np.uint8)
+    for j in range(n):
+        g = rng.random(lens[j]) < gc_rate[j]
+        tseq[tseq_ptr[j]:tseq_ptr[j + 1]] = np.where(g, rng.integers(1, 3, lens[j]), rng.integers(0, 2, lens[j]) * 3)
+    tseq[rng.random(tseq.size) < 0.001] = 4
+    L, ctx = 20, 4 ** max_order
+    orders = lambda: rng.choice(np.arange(-1, max_order + 1), L).astype(np.int32)
+    ps = lambda: rng.uniform(0.8, 1.25, (L, 4, ctx)).astype(np.float32)
+    out = dict(tseq_ptr=tseq_ptr, tseq=tseq, orders_left=orders(), orders_right=orders(), ps_left=ps(), ps_right=ps(),
+               gc_bins=rng.uniform(0.5, 1.5, gc_nbins).astype(np.float32),
+               high_prob_fraglens=(np.argsort(-np.asarray(pmf), kind="stable")[:num_fraglens] + 1).astype(np.int32),
+               m1_reverse=(rng.random(int(fragments["m"])) < 0.5).astype(np.uint8))
+    if use_pos_bias:
+        p = 2e-4
+        maxt = int(lens.max())
+        out["pos_p"] = p
+        out["pos_terms"] = np.cumsum(p * (1 - p) ** np.arange(maxt) / np.arange(1, maxt + 1)).astype(np.float64)
+    return out
