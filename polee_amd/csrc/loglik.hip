@@ -196,7 +196,7 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
         // masked slices: one (A1M) or two (A2M) rows of uint32 hw[64] (low half: 16 bits of the lane's mask, high half:
         // transcript ids), then float val[i][64] = the lane's i-th non-zero;
         // mixed slices: float val[w][64]; uint16 lcol[w][64]
-        const bool masked = stream == PSELL_A1M || stream == PSELL_A2M;
+        const bool masked = stream == PSELL_A1M || stream == PSELL_A2M || ((slice_off[s] >> PSELL_FLAG_MASKED_BIT) & 1u) != 0;
         const int hrows = stream == PSELL_A2M ? 2 : 1;
         const int nrows = compact ? (int)(units / 2u) - hrows - (HAS_KS ? 1 : 0)  // (+ a ks row when factored: uniform streams and BN)
                                   : (int)((units - (HAS_KS && stream == PSELL_BN ? 2u : 0u)) / 3u);
@@ -869,7 +869,10 @@ __device__ inline void quad_transpose(float &a0, float &a1, float &a2, float &a3
 // transcript, conflict free because every lane reads its own column -- and phase 2's operands V[4 g + j][4 b + i] are
 // exactly the quad transposes of the phase-1 registers: no second LDS pass, and the slice's ring bytes are free before
 // the first matrix instruction.
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, bool MASKED>
+// (round 4: dense AND masked narrow slices in one loop -- the kind is a flag of the slice (bit 29 of its offset word), so
+// that leftover fragments' masked slices ride in the A1 tiles of their genomic neighbourhood instead of closing tiles of
+// their own after a handful of slices)
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
 __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
@@ -972,9 +975,10 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
+        const bool masked = ((e0 >> PSELL_FLAG_MASKED_BIT) & 1u) != 0;  // (wave-uniform: e0 comes out of v_readlane)
         const uint32_t units = off_next - off;
-        const int nrows = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // rows of 64 values: the set's transcripts / (MASKED) the longest fragment
-        int w = MASKED ? run_w : nrows;
+        const int nrows = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // rows of 64 values: the set's transcripts / (masked) the longest fragment
+        int w = masked ? run_w : nrows;
         const uint32_t bytes = units * 128u;
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
         STAMP(1);  // slice bookkeeping
@@ -989,12 +993,11 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             // a new run: lane t < 16 reads transcript t's tile-local id from the slice's header and turns it into the
             // addresses of its x row and its gradient row; then the x values of the run, four transcripts at a time
             const uint32_t cid = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
-                (uintptr_t)(ring_lds + pos_r + (MASKED ? 4u * (uint32_t)(lane & 15) + 2u : 2u * (uint32_t)(lane & 15))));
-            const bool live = MASKED ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < w;
-            if (MASKED) {
-                run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
-                w = run_w;
-            }
+                (uintptr_t)(ring_lds + pos_r + (masked ? 4u * (uint32_t)(lane & 15) + 2u : 2u * (uint32_t)(lane & 15))));
+            const bool live = masked ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < nrows;
+            // (a dense slice: nrows; a masked one: the union's size from its header -- the same expression gives both)
+            run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
+            w = run_w;
             xav = live ? xw_lds + cid * (uint32_t)(K * 4) : aux_lds;
             gav = live ? gw_lds + cid * (uint32_t)(K * 4) : aux_lds + 32u;
             load_x_group(0, xq);
@@ -1020,9 +1023,10 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
         };
         // NG = groups of four transcripts of the slice; FAST = its bytes do not wrap around the ring's end
-        auto body = [&](auto NGc, auto FASTc) {
+        auto body = [&](auto NGc, auto FASTc, auto MASKEDc) {
             constexpr int NG = decltype(NGc)::value;
             constexpr bool FAST = decltype(FASTc)::value;
+            constexpr bool MASKED = decltype(MASKEDc)::value;
             float pv[8], qv[2][4];  // the operands of two groups at a time
             uint32_t bp[4];
             if (FAST) {
@@ -1172,17 +1176,21 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         };
         using std::integral_constant;
         const bool fast = pos_r + bytes <= RB;
-        if (fast) {
-            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, true>());
-            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, true>());
-            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, true>());
-            else body(integral_constant<int, 4>(), integral_constant<bool, true>());
-        } else {
-            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, false>());
-            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, false>());
-            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, false>());
-            else body(integral_constant<int, 4>(), integral_constant<bool, false>());
-        }
+        auto dispatch = [&](auto MASKEDc) {
+            if (fast) {
+                if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, true>(), MASKEDc);
+                else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, true>(), MASKEDc);
+                else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, true>(), MASKEDc);
+                else body(integral_constant<int, 4>(), integral_constant<bool, true>(), MASKEDc);
+            } else {
+                if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, false>(), MASKEDc);
+                else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, false>(), MASKEDc);
+                else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, false>(), MASKEDc);
+                else body(integral_constant<int, 4>(), integral_constant<bool, false>(), MASKEDc);
+            }
+        };
+        if (masked) dispatch(integral_constant<bool, true>());
+        else dispatch(integral_constant<bool, false>());
         pend_w = w;
         STAMP(5);  // phase 2
     }
@@ -1896,14 +1904,8 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             }
         }
         STAMP(0);  // between tiles: prefetch issue
-        if (kind == 0) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
-#ifdef POLEE_STAMPS
-                                                                             , st_acc, st_last
-#endif
-            );
-        } else if (kind == 2) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+        if (kind == 0 || kind == 2) {  // (dense and masked narrow slices: one loop, the kind is per slice)
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif

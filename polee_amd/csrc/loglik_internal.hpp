@@ -73,7 +73,9 @@ constexpr int PSELL_TILE_SLICES_A1 = 64;      // slices per tile (= per workgrou
 constexpr int PSELL_TILE_SLICES_A2 = 8;
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
-constexpr uint32_t PSELL_OFF_MASK = 0x3fffffffu;  // slice_off entries carry the slice flags in bits 30..31
+constexpr uint32_t PSELL_OFF_MASK = 0x1fffffffu;  // slice_off entries carry the slice flags in bits 29..31
+constexpr uint32_t PSELL_FLAG_MASKED_BIT = 29;    // bit 29: a MASKED slice (round 4: masked narrow slices ride in the A1 tiles of their
+                                                  // genomic neighbourhood -- shared dictionaries, no tiles of their own; the kind is per slice)
 constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, four groups of four transcripts: narrow_stream)
 constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two 16-row MFMA tiles: uniform_stream)
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
@@ -119,7 +121,7 @@ struct PsellHost {
     std::vector<uint32_t> tile_cols;   // [num_tiles] dictionary entries in use (the rest, up to tile_dict[t+1], is padding)
     std::vector<uint32_t> dict;        // transcript ids (0-based)
     std::vector<uint32_t> big_tiles;   // tiles whose dictionary exceeds PSELL_TILE_COLS_TARGET (a fragment with > 256 transcripts)
-    std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set
+    std::vector<uint8_t> slice_flags;  // [num_slices] bit0 uniform, bit1 continues the previous slice's set, bit2 masked
     std::vector<uint8_t> slice_w;      // [num_slices] transcripts of the slice's set (uniform streams) / longest row (mixed)
     std::vector<float> slice_ks;       // optional [num_slices*64] row multiplicities
     std::vector<uint32_t> row_order;   // [stored rows] original 0-based row id per (slice, lane); ~0u = empty lane

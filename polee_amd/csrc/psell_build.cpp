@@ -301,6 +301,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // slice, 4 - 10 x the cycles -- within the same global allowance; tiled real fixture -3 % kernel time, others +-0.7 %)
         static const double relax0 = getenv("POLEE_PSELL_RELAX0") ? atof(getenv("POLEE_PSELL_RELAX0")) : 2.0;
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
+        static const bool split_masked = getenv("POLEE_PSELL_SPLIT_MASKED") != nullptr;  // (A/B)
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
             BVec<uint64_t> k2(rb.size());
@@ -392,7 +393,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                                 }
                                 if (worth) {
                                     const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
-                                    RowList &dst = narrow ? (masked ? U.masked1 : U.dense1) : (masked ? U.masked2 : U.dense2);
+                                    // (narrow groups, dense and masked alike, stay in ONE list in the order they were formed: their
+                                    // slices share the tiles -- and the dictionaries -- of their genomic neighbourhood; the kind is
+                                    // per slice.  POLEE_PSELL_SPLIT_MASKED=1: masked narrow slices in tiles of their own, as in round 3)
+                                    RowList &dst = narrow ? (masked && split_masked ? U.masked1 : U.dense1) : (masked ? U.masked2 : U.dense2);
                                     for (size_t q = c0; q < c1; ++q) {
                                         dst.rows.push_back(group[q]);
                                         dst.ends.push_back(q + 1 == c1 ? 1u : 0u);
@@ -562,6 +566,42 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.stream_nnz[PSELL_C] = (int64_t)out.csr_col.size();
             out.stream_bytes[PSELL_C] = (int64_t)(8 * out.csr_col.size() + 4 * (rcsr.size() + 1));
         }
+        // Round 4: the slices of leftover groups (dense unions and masked slices) used to FOLLOW all the run slices of their
+        // stream, in tiles of their own -- which close on the 128-entry dictionary after ~10 slices of 12 - 16 transcripts
+        // each, and a tile's fixed cost (~9 k cycles: barriers, flush, ring start) then weighs 3 - 10 x what it does in a tile
+        // of 64 run slices.  Now they follow the runs OF THEIR GENOMIC BIN (first transcript / 256, the runs' own sort key):
+        // the runs' dictionary already holds most of a leftover group's transcripts (the same genes), so the group's slices
+        // ride in those tiles.  A stable sort of the stream's rows by (bin, run before group); a group's rows share one key
+        // (the bin of its union's first transcript), so slices stay intact.
+        static const bool no_interleave = getenv("POLEE_PSELL_NO_INTERLEAVE") != nullptr;  // (A/B)
+        auto interleave = [&](RowList &L) {
+            const size_t N = L.rows.size();
+            if (N == 0 || no_interleave) return;
+            bool any_run = false, any_group = false;
+            for (size_t q = 0; q < N && !(any_run && any_group); ++q) (L.form[q] == 0 ? any_run : any_group) = true;
+            if (!any_run || !any_group) return;
+            BVec<uint64_t> key(N);
+            BVec<uint32_t> idx(N);
+            parallel_chunks(N, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t q = lo; q < hi; ++q) {
+                    const uint32_t first = L.form[q] == 0 ? col[rowptr[L.rows[q]]] : patterns[L.gid[q]][0];
+                    key[q] = ((uint64_t)(first >> binsh) << 1) | (L.form[q] == 0 ? 0u : 1u);
+                    idx[q] = (uint32_t)q;
+                }
+            });
+            radix_sort_pairs(key, idx);
+            RowList R;
+            R.rows.resize(N); R.ends.resize(N); R.form.resize(N); R.gid.resize(N);
+            parallel_chunks(N, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t q = lo; q < hi; ++q) {
+                    const uint32_t o = idx[q];
+                    R.rows[q] = L.rows[o]; R.ends[q] = L.ends[o]; R.form[q] = L.form[o]; R.gid[q] = L.gid[o];
+                }
+            });
+            L.rows.swap(R.rows); L.ends.swap(R.ends); L.form.swap(R.form); L.gid.swap(R.gid);
+        };
+        interleave(S1);
+        interleave(S2);
         out.rows_a1 = (int64_t)S1.rows.size();
         out.rows_a1m = out.rows_a1 + (int64_t)S1M.rows.size();
         out.rows_a2 = out.rows_a1m + (int64_t)S2.rows.size();
@@ -679,12 +719,14 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         }
         const size_t base = out.data.size();
         uint32_t stored_rows = w;  // rows of 64 values the slice stores
-        if (cur_stream == PSELL_A1M || cur_stream == PSELL_A2M) {
+        const bool masked_slice = cur_stream == PSELL_A1M || cur_stream == PSELL_A2M || (cur_stream == PSELL_A1 && slice_form == 2);
+        const int stat_stream = masked_slice && cur_stream == PSELL_A1 ? PSELL_A1M : cur_stream;  // (accounting: by slice kind)
+        if (masked_slice) {
             // masked slice: header rows of uint32 hw[64] -- one for unions of <= 16, two for 17..32: low half = bits
             // 0..15 (16..31) of the mask of the fragment in lane r; high half, r < 16: tile-local id of transcript r
             // (16 + r) of the union, PSELL_NO_COL past it -- then float val[i][64] = the i-th non-zero of the fragment in
             // lane r, i < longest row (+ the ks row)
-            const size_t hrows = cur_stream == PSELL_A1M ? 1 : 2;
+            const size_t hrows = cur_stream == PSELL_A2M ? 2 : 1;
             stored_rows = longest;
             out.data.resize(base + 256 * hrows + (size_t)longest * 256 + (ks ? 256 : 0), 0);
             uint32_t *hw = reinterpret_cast<uint32_t *>(out.data.data() + base);
@@ -762,7 +804,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         }
         // flags: bit0 = all 64 lanes are stored under one transcript set ("uniform"),
         //        bit1 = uniform and the same set as the previous slice of this tile ("continues")
-        uint8_t flags = 0;
+        uint8_t flags = masked_slice ? 4 : 0;
         if (uniform_stream) {
             flags |= 1;
             if (prev_uniform && tile_nslices > 0 && prev_pattern == pattern) flags |= 2;
@@ -786,7 +828,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         out.slice_flags.push_back(flags);
         out.slice_w.push_back((uint8_t)std::min<uint32_t>(w, 255));
         {
-            const int st = cur_stream;
+            const int st = stat_stream;
             out.stream_rows[st] += (int64_t)slice_rows.size();
             for (uint32_t r : slice_rows) out.stream_nnz[st] += (int64_t)(rowptr[r + 1] - rowptr[r]);
             out.stream_bytes[st] += (int64_t)(out.data.size() - base);
@@ -910,7 +952,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             data_base[si] = dbase;
             const uint32_t unit_base = (uint32_t)(dbase / 128), slice_base = (uint32_t)out.num_slices,
                            dict_base = (uint32_t)out.dict.size(), tile_base = (uint32_t)out.num_tiles;
-            if (dbase / 128 + f.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
+            if (dbase / 128 + f.data.size() / 128 >= (1ull << 29)) return "matrix too large (the slice stream is limited to 64 GiB)";
             for (size_t q = 1; q < f.slice_off.size(); ++q) out.slice_off.push_back(f.slice_off[q] + unit_base);
             for (size_t q = 1; q < f.tile_slice.size(); ++q) out.tile_slice.push_back(f.tile_slice[q] + slice_base);
             for (size_t q = 1; q < f.tile_dict.size(); ++q) out.tile_dict.push_back(f.tile_dict[q] + dict_base);
@@ -946,9 +988,10 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     lap("slices and tiles");
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return "internal error: non-uniform slice in the uniform stream";
-    if (out.data.size() / 128 >= (1ull << 30)) return "matrix too large (the slice stream is limited to 128 GiB)";
+    if (out.data.size() / 128 >= (1ull << 29)) return "matrix too large (the slice stream is limited to 64 GiB)";
     // the two flag bits of slice s ride in the top bits of slice_off[s] (one scalar/lane load per slice)
-    for (int64_t s = 0; s < out.num_slices; ++s) out.slice_off[s] |= (uint32_t)(out.slice_flags[s] & 3u) << 30;
+    for (int64_t s = 0; s < out.num_slices; ++s)
+        out.slice_off[s] |= ((uint32_t)(out.slice_flags[s] & 3u) << 30) | ((uint32_t)((out.slice_flags[s] >> 2) & 1u) << PSELL_FLAG_MASKED_BIT);
     return "";
 }
 

@@ -159,8 +159,9 @@ def _psell(m, n, colptr, rowval, nzval, ks=None):
         return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count and ptr else np.zeros(count, dt)
     out["data"] = arr_of(v.data, v.data_bytes, np.uint8)
     raw = arr_of(v.slice_off, v.num_slices + 1, np.uint32)
-    out["slice_off"] = raw & np.uint32(0x3FFFFFFF)  # bits 30..31 carry the slice flags
+    out["slice_off"] = raw & np.uint32(0x1FFFFFFF)  # bits 29..31 carry the slice flags
     out["slice_flags"] = (raw >> np.uint32(30))[:-1]
+    out["slice_masked"] = ((raw >> np.uint32(29)) & np.uint32(1))[:-1].astype(bool)  # (round 4: the kind of a narrow slice is per slice)
     out["tile_slice"] = arr_of(v.tile_slice, v.num_tiles + 1, np.uint32)
     out["tile_dict"] = arr_of(v.tile_dict, v.num_tiles + 1, np.uint32)
     out["dict"] = arr_of(v.dict, v.dict_len, np.uint32)
@@ -183,11 +184,12 @@ def _emulate_psell(ps, x, n):
         for s in range(ps["tile_slice"][t], ps["tile_slice"][t + 1]):
             off = int(ps["slice_off"][s]) * 128
             nbytes = int(ps["slice_off"][s + 1]) * 128 - off
-            if ps["num_tiles_a1"] <= t < ps["num_tiles_a1m"] or ps["num_tiles_a2"] <= t < ps["num_tiles_a"]:
+            if ps["slice_masked"][s] or ps["num_tiles_a1"] <= t < ps["num_tiles_a1m"] or ps["num_tiles_a2"] <= t < ps["num_tiles_a"]:
                 # masked uniform slice: one (unions of <= 16) or two (17..32) header rows of uint32 hw[64] (low half: 16
                 # bits of the mask of the fragment in lane r; high half of a row's hw[t], t < 16: tile-local id of that
                 # transcript of the union, 0x8000 past it), then val[i][r] = the i-th non-zero of the fragment in lane r
                 hrows = 1 if t < ps["num_tiles_a1m"] else 2
+                assert ps["slice_masked"][s]  # the flag travels with every masked slice, whatever tile holds it
                 nrows = nbytes // 256 - hrows - (0 if ps["ks"] is None else 1)
                 assert ps["slice_flags"][s] & 1
                 hw = data[off:off + 256 * hrows].view(np.uint32).astype(np.int64).reshape(hrows, 64)

@@ -25,7 +25,7 @@ print("build %.1f s" % (time.time() - t0))
 v = L.PsellView()
 L.check(L.lib().polee_debug_psell_view(h, C.byref(v)))
 raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,))
-off = (raw & np.uint32(0x3FFFFFFF)).astype(np.int64)
+off = (raw & np.uint32(0x1FFFFFFF)).astype(np.int64)
 flags = (raw >> np.uint32(30))[:-1]
 ts = np.ctypeslib.as_array(v.tile_slice, shape=(v.num_tiles + 1,)).astype(np.int64)
 td = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).astype(np.int64)

@@ -65,7 +65,7 @@ ts = np.ctypeslib.as_array(v.tile_slice, shape=(v.num_tiles + 1,)).astype(np.int
 td = np.ctypeslib.as_array(v.tile_dict, shape=(v.num_tiles + 1,)).astype(np.int64)
 sw = np.ctypeslib.as_array(v.slice_w, shape=(v.num_slices,)).astype(np.int64)
 raw = np.ctypeslib.as_array(v.slice_off, shape=(v.num_slices + 1,))
-off = (raw & np.uint32(0x3FFFFFFF)).astype(np.int64)
+off = (raw & np.uint32(0x1FFFFFFF)).astype(np.int64)
 cont = ((raw >> np.uint32(30)) & 2)[:-1] != 0
 ro = np.ctypeslib.as_array(v.row_order, shape=(v.num_slices * 64,)).reshape(-1, 64)
 rows = (ro != 0xFFFFFFFF).sum(1)
