@@ -489,6 +489,10 @@ struct WaveStream {
     int issued, islot;    // pieces requested so far; ring slot of the next one
     int primed;           // pieces requested before the tile's loop started
     const uint8_t *gsrc;  // start of the byte range (wave-uniform)
+    // (round 4) an A1 tile holds its dense slices first and its masked ones behind them: the wave runs the dense loop over
+    // slices [0, ndense) of its share and the masked loop over [ndense, nsl), the ring position carried from one to the other
+    uint32_t pos, pos_r;
+    int ndense;
 };
 
 template <uint32_t RB>
@@ -869,11 +873,8 @@ __device__ inline void quad_transpose(float &a0, float &a1, float &a2, float &a3
 // transcript, conflict free because every lane reads its own column -- and phase 2's operands V[4 g + j][4 b + i] are
 // exactly the quad transposes of the phase-1 registers: no second LDS pass, and the slice's ring bytes are free before
 // the first matrix instruction.
-// (round 4: dense AND masked narrow slices in one loop -- the kind is a flag of the slice (bit 29 of its offset word), so
-// that leftover fragments' masked slices ride in the A1 tiles of their genomic neighbourhood instead of closing tiles of
-// their own after a handful of slices)
-template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
-__device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, bool MASKED>
+__device__ inline void narrow_stream(WaveStream &ws, int si0, int si1, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
@@ -968,17 +969,16 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         }
     };
 
-    uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
-    uint32_t pos_r = 0;  // pos modulo the ring size
-    for (int si = 0; si < ws.nsl; ++si) {
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws.pos);      // byte offset of the current slice inside this wave's range
+    uint32_t pos_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws.pos_r);  // pos modulo the ring size
+    for (int si = si0; si < si1; ++si) {
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
         const int flags = (int)(e0 >> 30);
-        const bool masked = ((e0 >> PSELL_FLAG_MASKED_BIT) & 1u) != 0;  // (wave-uniform: e0 comes out of v_readlane)
         const uint32_t units = off_next - off;
-        const int nrows = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // rows of 64 values: the set's transcripts / (masked) the longest fragment
-        int w = masked ? run_w : nrows;
+        const int nrows = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // rows of 64 values: the set's transcripts / (MASKED) the longest fragment
+        int w = MASKED ? run_w : nrows;
         const uint32_t bytes = units * 128u;
         if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
         STAMP(1);  // slice bookkeeping
@@ -993,11 +993,12 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             // a new run: lane t < 16 reads transcript t's tile-local id from the slice's header and turns it into the
             // addresses of its x row and its gradient row; then the x values of the run, four transcripts at a time
             const uint32_t cid = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(
-                (uintptr_t)(ring_lds + pos_r + (masked ? 4u * (uint32_t)(lane & 15) + 2u : 2u * (uint32_t)(lane & 15))));
-            const bool live = masked ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < nrows;
-            // (a dense slice: nrows; a masked one: the union's size from its header -- the same expression gives both)
-            run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
-            w = run_w;
+                (uintptr_t)(ring_lds + pos_r + (MASKED ? 4u * (uint32_t)(lane & 15) + 2u : 2u * (uint32_t)(lane & 15))));
+            const bool live = MASKED ? cid != (uint32_t)PSELL_NO_COL : (lane & 15) < w;
+            if (MASKED) {
+                run_w = __builtin_popcount((uint32_t)__ballot(live) & 0xffffu);
+                w = run_w;
+            }
             xav = live ? xw_lds + cid * (uint32_t)(K * 4) : aux_lds;
             gav = live ? gw_lds + cid * (uint32_t)(K * 4) : aux_lds + 32u;
             load_x_group(0, xq);
@@ -1023,10 +1024,9 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
             if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
         };
         // NG = groups of four transcripts of the slice; FAST = its bytes do not wrap around the ring's end
-        auto body = [&](auto NGc, auto FASTc, auto MASKEDc) {
+        auto body = [&](auto NGc, auto FASTc) {
             constexpr int NG = decltype(NGc)::value;
             constexpr bool FAST = decltype(FASTc)::value;
-            constexpr bool MASKED = decltype(MASKEDc)::value;
             float pv[8], qv[2][4];  // the operands of two groups at a time
             uint32_t bp[4];
             if (FAST) {
@@ -1176,25 +1176,23 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
         };
         using std::integral_constant;
         const bool fast = pos_r + bytes <= RB;
-        auto dispatch = [&](auto MASKEDc) {
-            if (fast) {
-                if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, true>(), MASKEDc);
-                else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, true>(), MASKEDc);
-                else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, true>(), MASKEDc);
-                else body(integral_constant<int, 4>(), integral_constant<bool, true>(), MASKEDc);
-            } else {
-                if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, false>(), MASKEDc);
-                else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, false>(), MASKEDc);
-                else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, false>(), MASKEDc);
-                else body(integral_constant<int, 4>(), integral_constant<bool, false>(), MASKEDc);
-            }
-        };
-        if (masked) dispatch(integral_constant<bool, true>());
-        else dispatch(integral_constant<bool, false>());
+        if (fast) {
+            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, true>());
+            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, true>());
+            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, true>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, true>());
+        } else {
+            if (w <= 4) body(integral_constant<int, 1>(), integral_constant<bool, false>());
+            else if (w <= 8) body(integral_constant<int, 2>(), integral_constant<bool, false>());
+            else if (w <= 12) body(integral_constant<int, 3>(), integral_constant<bool, false>());
+            else body(integral_constant<int, 4>(), integral_constant<bool, false>());
+        }
         pend_w = w;
         STAMP(5);  // phase 2
     }
     if (pend_w != 0) flush();
+    ws.pos = pos;
+    ws.pos_r = pos_r;
     if (WANT_LP) {
         // into the caller's accumulator, whose lane l < 16 collects draw l: the sixteen blocks' sums of draw 4 kg + j
 #pragma unroll
@@ -1849,11 +1847,17 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     const int ahead = (dbg >> 8) & 15;  // (experiment: pieces requested ahead; 0 = the whole ring)
     auto start_ring = [&](const PosDesc &t) {
         const int kind = kind_of(t.tile);
-        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
+        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data; ws.pos = 0u; ws.pos_r = 0u; ws.ndense = 0;
         uint32_t sb, se;
         share(kind, t, sb, se);
         ws.ent = entb[wave * 64 + wave_lane()];
         ws.nsl = (int)(se - sb);
+        ws.pos = 0u;
+        ws.pos_r = 0u;
+        {   // dense slices of the share (they come first): lanes [0, nsl) whose offset word has the MASKED bit clear
+            const bool dense = wave_lane() < ws.nsl && ((ws.ent >> PSELL_FLAG_MASKED_BIT) & 1u) == 0u;
+            ws.ndense = __builtin_popcountll(__ballot(dense));
+        }
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
@@ -1904,8 +1908,23 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             }
         }
         STAMP(0);  // between tiles: prefetch issue
-        if (kind == 0 || kind == 2) {  // (dense and masked narrow slices: one loop, the kind is per slice)
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+        if (kind == 0) {
+            // an A1 tile: this wave's dense slices, then (round 4) the masked slices of leftover fragments that ride in the
+            // tile -- the same two loops as before, one after the other over the same ring, dictionary and windows
+            const int nd = __builtin_amdgcn_readfirstlane(ws.ndense);
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, 0, nd, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                                             , st_acc, st_last
+#endif
+            );
+            if (nd < ws.nsl)
+                narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, nd, ws.nsl, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+#ifdef POLEE_STAMPS
+                                                                                 , st_acc, st_last
+#endif
+                );
+        } else if (kind == 2) {
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, 0, ws.nsl, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif

@@ -704,7 +704,16 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     int slice_form = 0;  // the slice being formed: 0 rows of one set, 1 dense union, 2 masked
     uint32_t slice_gid = 0;  // ... forms 1, 2: its group
     const bool uniform_stream = cur_stream != PSELL_B && cur_stream != PSELL_BN;
-    auto close_slice = [&]() {
+    // (round 4) the slices of a tile are QUEUED and emitted when the tile closes: in stream A1 the dense slices first, the
+    // masked ones (leftover fragments riding in the tile) behind them -- the kernel runs its dense loop, then its masked
+    // loop, over every wave's share of the tile
+    struct PendingSlice {
+        BVec<uint32_t> rows;
+        int form;
+        uint32_t gid;
+    };
+    std::vector<PendingSlice> pending;
+    auto emit_slice = [&]() {
         if (slice_rows.empty()) return;
         uint32_t w = 0, longest = 0;
         for (uint32_t r : slice_rows) longest = std::max<uint32_t>(longest, (uint32_t)(rowptr[r + 1] - rowptr[r]));
@@ -840,8 +849,24 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         slice_rows.clear();
         slice_form = 0;
     };
+    auto close_slice = [&]() {
+        if (slice_rows.empty()) return;
+        pending.push_back(PendingSlice{slice_rows, slice_form, slice_gid});
+        slice_rows.clear();
+        slice_form = 0;
+    };
     auto close_tile = [&]() {
-        if (tile_nslices == 0) return;
+        if (pending.empty()) return;
+        for (int pass = 0; pass < 2; ++pass)  // (stable: runs of slices with one set stay together)
+            for (PendingSlice &ps : pending) {
+                const bool masked_narrow = cur_stream == PSELL_A1 && ps.form == 2;
+                if ((int)masked_narrow != pass) continue;
+                slice_rows.swap(ps.rows);
+                slice_form = ps.form;
+                slice_gid = ps.gid;
+                emit_slice();
+            }
+        pending.clear();
         out.tile_slice.push_back((uint32_t)out.num_slices);
         out.tile_cols.push_back(tile_cols);
         while (out.dict.size() % PSELL_DICT_ALIGN) out.dict.push_back(0u);  // (never referenced by a slice)
@@ -865,7 +890,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         for (;;) {
             uint32_t fresh = 0;
             for (const uint32_t *c = cb; c < ce; ++c) fresh += col_stamp[*c] != tile_id;
-            if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && slice_rows.empty())) break;
+            if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && slice_rows.empty() && pending.empty())) break;
             // does not fit into the current tile: finish it (possibly with a partial slice)
             close_slice();
             close_tile();
@@ -890,7 +915,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             const uint32_t cap = cur_stream == PSELL_A1 || cur_stream == PSELL_A1M ? (uint32_t)std::min(a1cap, 252)  // <= 63 slices per wave
                                  : cur_stream == PSELL_A2 ? (uint32_t)std::min(a2cap, 126) : cur_stream == PSELL_A2M ? (uint32_t)a2mcap
                                  : cur_stream == PSELL_BN ? (uint32_t)PSELL_TILE_SLICES_BN : (uint32_t)PSELL_TILE_SLICES_B;
-            if (tile_nslices >= cap) close_tile();
+            if (pending.size() >= (size_t)cap) close_tile();
         }
     }
     close_slice();
