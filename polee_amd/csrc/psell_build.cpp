@@ -301,7 +301,13 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // slice, 4 - 10 x the cycles -- within the same global allowance; tiled real fixture -3 % kernel time, others +-0.7 %)
         static const double relax0 = getenv("POLEE_PSELL_RELAX0") ? atof(getenv("POLEE_PSELL_RELAX0")) : 2.0;
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
-        static const bool split_masked = getenv("POLEE_PSELL_SPLIT_MASKED") != nullptr;  // (A/B)
+        // Round 4 experiment, OFF by default: POLEE_PSELL_MERGE_MASKED=1 lets the masked narrow slices
+        // of leftover fragments ride in the A1 tiles of their genomic bin (kind flag per slice; the kernel runs its dense
+        // loop, then its masked loop over a wave's share) instead of closing tiles of their own after ~10 slices.
+        // Measured at C2 size, same box (profiles/r04_mixed_tiles_ab.txt): tiled real fixture -2.3 % kernel time, every
+        // fragment its own subset +1.5 %, dropout 0.3 +2.6 %, generator patterns +-0: the saved tile overhead is paid back
+        // by the second loop's start in every wave of every tile.  (ONE loop over both kinds compiled 17 % slower.)
+        static const bool split_masked = getenv("POLEE_PSELL_MERGE_MASKED") == nullptr;
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
             BVec<uint64_t> k2(rb.size());
@@ -566,14 +572,15 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             out.stream_nnz[PSELL_C] = (int64_t)out.csr_col.size();
             out.stream_bytes[PSELL_C] = (int64_t)(8 * out.csr_col.size() + 4 * (rcsr.size() + 1));
         }
-        // Round 4: the slices of leftover groups (dense unions and masked slices) used to FOLLOW all the run slices of their
+        // Round 4 experiment: the slices of leftover groups (dense unions and masked slices) FOLLOW all the run slices of their
         // stream, in tiles of their own -- which close on the 128-entry dictionary after ~10 slices of 12 - 16 transcripts
         // each, and a tile's fixed cost (~9 k cycles: barriers, flush, ring start) then weighs 3 - 10 x what it does in a tile
         // of 64 run slices.  Now they follow the runs OF THEIR GENOMIC BIN (first transcript / 256, the runs' own sort key):
         // the runs' dictionary already holds most of a leftover group's transcripts (the same genes), so the group's slices
         // ride in those tiles.  A stable sort of the stream's rows by (bin, run before group); a group's rows share one key
         // (the bin of its union's first transcript), so slices stay intact.
-        static const bool no_interleave = getenv("POLEE_PSELL_NO_INTERLEAVE") != nullptr;  // (A/B)
+        // (the same experiment's second half, POLEE_PSELL_INTERLEAVE=1; off by default: no measurable gain on its own)
+        static const bool no_interleave = getenv("POLEE_PSELL_INTERLEAVE") == nullptr;
         auto interleave = [&](RowList &L) {
             const size_t N = L.rows.size();
             if (N == 0 || no_interleave) return;
