@@ -2483,10 +2483,20 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         cut[0] = cut[1] = cut[2] = s1;
         if (t >= h.num_tiles_s) continue;
         const int nw = h.stream_of_tile(t) != PSELL_A2 && h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
+        // (experiment, POLEE_CUT_MODEL="a,b,c": cost = a + b x groups of four transcripts + c x (1 + groups) when the slice
+        // starts a new run -- the flush of the previous set and the column lookup of the new one)
+        static const char *cut_env = getenv("POLEE_CUT_MODEL");
+        static double cm[3] = {0, 0, 0};
+        static const bool cut_custom = cut_env && sscanf(cut_env, "%lf,%lf,%lf", &cm[0], &cm[1], &cm[2]) == 3;
         auto cost = [&](uint32_t sl) {
             const int w = h.slice_w[sl];
             if (bytes_cut) return 512.0 + 128.0 * (double)((h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK));
             if (h.stream_of_tile(t) == PSELL_BN) return 6.0 * w + 4.0;  // (instructions per entry, not matrix-core work)
+            if (cut_custom) {
+                const double ng = (double)((w + 3) / 4);
+                const bool cont = (h.slice_flags[sl] & 2) != 0 && sl > s0;
+                return cm[0] + cm[1] * ng + (cont ? 0.0 : cm[2] * (1.0 + ng));
+            }
             return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
         };
         double total = 0.0;
