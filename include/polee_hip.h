@@ -479,6 +479,25 @@ polee_status polee_regression_set_gene_likelihood(polee_regression *reg, polee_a
 polee_status polee_regression_set_gene_isoform_likelihood(polee_regression *reg, polee_approx *ap,
                                                           const int32_t *gene_of, const float *x_isoform_init,
                                                           const float *design_isoform, int32_t num_isoform_factors);
+/* RNASeqJointLinearRegression (models/polee_regression.py:879-1283; driven by models/joint-regression.jl): gene-level
+ * regression + a regression over SPLICE FEATURES whose predictor reaches the transcripts through the 0/1 feature matrix.
+ * Create the model over the gene features with ap = NULL, use_distortion = 0, scale_penalty = 5e-4 (:1052-1054), then
+ * attach: ap over the nt transcripts, gene_of int32 [nt], x_isoform_init f32 [S][nt], the number of splice features P and
+ * the matrix's non-zeros as (transcript, feature) pairs, 0-based.  The gene block becomes the joint model's: a horseshoe
+ * prior (ONE local scale level: the local2 arrays of the flat vector stay, unused), kernel-regression weights that follow
+ * the SAMPLED bias (:1034-1035), HalfCauchy(0, 10) on the mean-variance coefficients (:1037-1041),
+ * qw_softplus_scale = -2, Adam(1e-3) (:1215).  The isoform block then holds: the splice block in the model's own order
+ * with P columns and no hinges -- global scale variance loc / s, noncentered loc / s; [F][P] arrays local variance loc / s,
+ * local noncentered loc / s, (local2: four unused arrays), w_splice loc / s; [P] arrays bias loc / s, (x_scale: two
+ * unused arrays) -- then x_iso_scale loc / s [nt] (SoftplusNormal; prior HalfCauchy(0, 1), :1110-1112) and x_iso loc / s
+ * [S][nt] (prior Normal(x_iso_loc, x_iso_scale), :1114-1116).  Noise appended to the noise vector: 2 globals, five [F][P]
+ * arrays, bias [P], (unused [P]), x_iso_scale [nt], x_iso [S][nt].  One GPU only. */
+polee_status polee_regression_set_joint_likelihood(polee_regression *reg, polee_approx *ap, const int32_t *gene_of,
+                                                   const float *x_isoform_init, int32_t num_splice_features,
+                                                   const int32_t *pair_transcript, const int32_t *pair_feature,
+                                                   int64_t num_pairs);
+/* Adam's learning rate of polee_regression_fit (default 2e-3: models/polee_regression.py:326; the joint model sets 1e-3) */
+polee_status polee_regression_set_learning_rate(polee_regression *reg, float learning_rate);
 int64_t polee_regression_num_isoform_params(const polee_regression *reg);
 polee_status polee_regression_get_isoform_params(polee_regression *reg, float *params);
 polee_status polee_regression_set_isoform_params(polee_regression *reg, const float *params);

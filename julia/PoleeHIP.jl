@@ -489,6 +489,30 @@ function set_gene_likelihood!(r::Regression, ap::ApproxLikelihood, gene_of::Abst
     return r
 end
 
+"""
+RNASeqJointLinearRegression (models/polee_regression.py:879-1283) on a model created over the genes (ap = nothing, no
+distortion, scale penalty 5e-4): gene block with a one-level horseshoe prior and kernel-regression weights of the sampled
+bias, plus a regression over `num_splice_features` splice features that reaches the transcripts through the 0/1 matrix given
+by the 1-based pairs (`feature_is`, `feature_js`) -- the arguments of models/joint-regression.jl.
+"""
+function set_joint_likelihood!(r::Regression, ap::ApproxLikelihood, gene_of::AbstractVector{<:Integer},
+                               x_isoform_init::AbstractMatrix, num_splice_features::Integer,
+                               feature_is::AbstractVector{<:Integer}, feature_js::AbstractVector{<:Integer})
+    length(feature_is) == length(feature_js) || throw(ArgumentError("feature_is and feature_js must pair up"))
+    g = Int32.(gene_of .- 1)
+    xi = Matrix{Float32}(x_isoform_init')            # row-major [S][nt]
+    pt = Int32.(feature_is .- 1)
+    pf = Int32.(feature_js .- 1)
+    GC.@preserve g xi pt pf check(ccall((:polee_regression_set_joint_likelihood, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Float32}, Int32, Ptr{Int32}, Ptr{Int32}, Int64),
+        r.h, ap.h, g, xi, Int32(num_splice_features), pt, pf, Int64(length(pt))), r.ctx.h)
+    return r
+end
+
+"Adam step size of fit (2e-3 as created; the joint model sets 1e-3, models/polee_regression.py:1222)"
+set_learning_rate!(r::Regression, lr::Real) =
+    check(ccall((:polee_regression_set_learning_rate, LIB), Cint, (Ptr{Cvoid}, Cfloat), r.h, Float32(lr)), r.ctx.h)
+
 "the isoform block of a gene-level / gene-isoform model as a flat vector (order: include/polee_hip.h)"
 function isoform_params(r::Regression)
     n = Int(ccall((:polee_regression_num_isoform_params, LIB), Int64, (Ptr{Cvoid},), r.h))

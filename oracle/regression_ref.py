@@ -298,3 +298,84 @@ def adam_step(theta, g, m, v, t, lr=2e-3, b1=0.9, b2=0.999, eps=1e-7):
     m[:] = b1 * m + (1 - b1) * g
     v[:] = b2 * v + (1 - b2) * g * g
     theta -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps)
+
+
+# ---- RNASeqJointLinearRegression (models/polee_regression.py:879-1283) ------------------------------------------------------
+JOINT_TRANSCRIPT_PARAMS = [("qx_iso_scale_loc", "t"), ("qx_iso_scale_softplus_scale", "t"), ("qx_iso_loc", "St"),
+                           ("qx_iso_softplus_scale", "St")]
+JOINT_TRANSCRIPT_NOISE = [("x_iso_scale", "t"), ("x_iso", "St")]
+
+
+def _halfcauchy_lp(x, scale):
+    return np.log(2.0) - np.log(np.pi * scale) - np.log1p(np.square(x / scale))
+
+
+def joint_regression_loss(p, eps, sp, se, tp, te, design, hinges, bandwidth, sample_scales, num_gene_features,
+                          pair_transcript, pair_feature, gene_lik=None, frozen_weights=None):
+    """loss = log q - log p of the joint model at one draw.
+    p / eps: the GENE block (PARAMS / NOISE with n = gene features; the local2 and distortion entries are unused);
+    sp / se: the SPLICE block (PARAMS / NOISE with n = P splice features, deg = 0, S = 0; local2 and x_scale unused);
+    tp / te: the transcripts' part (JOINT_TRANSCRIPT_PARAMS / _NOISE).  pair_*: the feature matrix's non-zeros (0-based).
+    model_fn :1007-1121, variational_model_fn :1124-1203.  Returns (loss, draws)."""
+    design = np.asarray(design, np.float64)
+    logq = 0.0
+
+    def sp_normal(d, loc, sraw, e):
+        nonlocal logq
+        s = softplus(d[sraw])
+        u = d[loc] + s * e
+        logq += np.sum(_normal_lp(u, d[loc], s) - log_sigmoid(u))
+        return softplus(u)
+
+    def normal(d, loc, sraw, e):
+        nonlocal logq
+        s = softplus(d[sraw])
+        v = d[loc] + s * e
+        logq += np.sum(_normal_lp(v, d[loc], s))
+        return v
+
+    def horseshoe(d, e):
+        gv = sp_normal(d, "qw_global_scale_variance_loc", "qw_global_scale_variance_softplus_scale", e["w_global_scale_variance"])
+        gn = sp_normal(d, "qw_global_scale_noncentered_loc", "qw_global_scale_noncentered_softplus_scale", e["w_global_scale_noncentered"])
+        lv = sp_normal(d, "qw_local1_scale_variance_loc", "qw_local1_scale_variance_softplus_scale", e["w_local1_scale_variance"])
+        ln = sp_normal(d, "qw_local1_scale_noncentered_loc", "qw_local1_scale_noncentered_softplus_scale", e["w_local1_scale_noncentered"])
+        w = normal(d, "qw_loc", "qw_softplus_scale", e["w"])
+        lp = np.sum(_invgamma_lp(gv, 0.5, 0.5)) + np.sum(_halfnormal_lp(gn)) + np.sum(_invgamma_lp(lv, 0.5, 0.5)) + np.sum(_halfnormal_lp(ln))
+        lp += np.sum(_normal_lp(w, 0.0, (ln * np.sqrt(lv)) * (gn * np.sqrt(gv))))
+        return w, lp
+
+    # ---- gene block
+    w_gene, logp = horseshoe(p, eps)
+    x_gene_bias = normal(p, "qx_bias_loc", "qx_bias_softplus_scale", eps["x_bias"])
+    conc_c = softplus(p["qx_scale_concentration_c_loc"])
+    scale_c = softplus(p["qx_scale_scale_c_loc"])
+    x_scale = sp_normal(p, "qx_scale_loc", "qx_scale_softplus_scale", eps["x_scale"])
+    x_gene = normal(p, "qx_loc", "qx_softplus_scale", eps["x"])
+    logp += np.sum(_normal_lp(x_gene_bias, np.log(1.0 / num_gene_features), 12.0))
+    W = kernel_regression_weights(bandwidth, x_gene_bias, np.asarray(hinges, np.float64))   # of the SAMPLED bias (:1034-1035)
+    if frozen_weights is not None:     # (tests: what the gradient would be if the weights did not depend on the bias)
+        W = frozen_weights
+    logp += np.sum(_halfcauchy_lp(conc_c, 10.0)) + np.sum(_halfcauchy_lp(scale_c, 10.0))
+    logp += np.sum(_invgamma_lp(x_scale, (conc_c[:, None] * W).sum(axis=0), (scale_c[:, None] * W).sum(axis=0)))
+    x_gene_loc = design @ w_gene + x_gene_bias
+    logp += np.sum(_normal_lp(x_gene, x_gene_loc - np.asarray(sample_scales, np.float64).reshape(-1, 1), x_scale))
+    m = p["qx_loc"].max(axis=1)
+    t = m + np.log(np.exp(p["qx_loc"] - m[:, None]).sum(axis=1))
+    logp += np.sum(_normal_lp(t, 0.0, 5e-4))
+    # ---- splice block
+    w_splice, lp_s = horseshoe(sp, se)
+    logp += lp_s
+    x_splice_bias = normal(sp, "qx_bias_loc", "qx_bias_softplus_scale", se["x_bias"])
+    logp += np.sum(_normal_lp(x_splice_bias, 0.0, 10.0))
+    mu = design @ w_splice + x_splice_bias                       # [S, P]
+    nt = tp["qx_iso_scale_loc"].shape[0]
+    A = np.zeros((nt, mu.shape[1]))
+    np.add.at(A, (np.asarray(pair_transcript), np.asarray(pair_feature)), 1.0)
+    x_iso_loc = mu @ A.T                                          # [S, nt]
+    x_iso_scale = sp_normal(tp, "qx_iso_scale_loc", "qx_iso_scale_softplus_scale", te["x_iso_scale"])
+    x_iso = normal(tp, "qx_iso_loc", "qx_iso_softplus_scale", te["x_iso"])
+    logp += np.sum(_halfcauchy_lp(x_iso_scale, 1.0))
+    logp += np.sum(_normal_lp(x_iso, x_iso_loc, x_iso_scale[None, :]))
+    if gene_lik is not None:
+        logp += float(np.sum(gene_lik(x_gene, x_iso)))
+    return float(logq - logp), dict(x_gene=x_gene, x_iso=x_iso, x_iso_loc=x_iso_loc, W=W, x_gene_bias=x_gene_bias)

@@ -28,7 +28,7 @@ from .core import (Context, Comm, HostComm, hclust, host_cache_trim, sample_and_
 
 from . import h5io, estimate  # noqa: F401,E402
 from .estimate import LoadedSamples, load_samples_from_specification, load_samples_hdf5, read_specification  # noqa: F401,E402
-from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegression, RNASeqNormalTranscriptLinearRegression, RNASeqGeneLinearRegression, RNASeqGeneIsoformLinearRegression, estimate_sample_scales,  # noqa: F401,E402
+from .regression import (RNASeqLinearRegression, RNASeqTranscriptLinearRegression, RNASeqNormalTranscriptLinearRegression, RNASeqGeneLinearRegression, RNASeqGeneIsoformLinearRegression, RNASeqJointLinearRegression, estimate_sample_scales,  # noqa: F401,E402
                          find_minimum_effect_size, write_regression_effects)
 from .salmon import load_salmon_likelihood, SalmonLikelihood  # noqa: F401,E402
 from .cohort import approximate_likelihood_cohort, approximate_likelihood_cohort_processes  # noqa: F401,E402

@@ -44,6 +44,14 @@ struct RegView {
     // observation model stands alone (no sample scales, no scale-drift penalty, no likelihood term of its own): the
     // isoform block of the gene-isoform model (models/polee_regression.py:727-733), run with deg = 0
     float fixed_ab = 0.0f;
+    // --- the joint model's variants (RNASeqJointLinearRegression, models/polee_regression.py:879-1283) ---
+    int32_t levels = 2;       // 1: a horseshoe prior (one local scale level, :1009-1024) instead of horseshoe+; the local2 arrays stay in
+                              //    the vector, unused (gradient 0)
+    int32_t no_xs = 0;        // 1: no x_scale in this block (the splice-feature block: its observation lives on the transcripts)
+    int32_t w_from_bias = 0;  // 1: the kernel-regression weights are functions of the SAMPLED bias (:1034-1035), not of x_bias_init
+    float hc_scale = 1.0f;    // scale of the HalfCauchy prior on the mean-variance coefficients (10 in the joint model, :1037-1041)
+    float bandwidth = 1.0f;
+    const float *hinges = nullptr;  // (w_from_bias) device pointer, deg values
     __host__ __device__ int64_t Fn() const { return (int64_t)F * n; }
     __host__ __device__ int64_t o_dist() const { return 4; }
     __host__ __device__ int64_t o_conc() const { return 4 + (int64_t)F * deg; }
@@ -303,6 +311,104 @@ __global__ __launch_bounds__(256) void reg_iso_grad_kernel(int S, int nt, const 
     if ((threadIdx.x & 63) == 63) atomicAdd(&loss_slots[blockIdx.x % REG_SLOTS], loss);
 }
 
+// ---- joint model (RNASeqJointLinearRegression, models/polee_regression.py:879-1283): beside the gene block a SPLICE block --
+// horseshoe coefficients w_splice [F][P] and a bias ~ Normal(0, 10) over P splice features (:1062-1087), whose linear
+// predictor reaches the transcripts through the 0/1 feature matrix (:1089-1108): x_iso_loc[s][t] = sum of (F w + b)[s][p] over
+// the features p of transcript t; x_iso_scale ~ HalfCauchy(0, 1) [nt] (:1110-1112), x_iso ~ Normal(x_iso_loc, x_iso_scale)
+// (:1114-1116), and the gene-level likelihood of (x_gene, x_iso) (:1118-1121).  The splice features' coefficients are a
+// RegView over P "columns" (levels = 1, no_xs) run through the column / finish kernels; the transcripts' part -- x_iso_scale
+// (SoftplusNormal surrogate) and x_iso (Normal surrogate) -- is the kernel below.  Transcript part of the parameter block:
+// x_iso_scale_loc [nt], x_iso_scale_softplus_scale [nt], x_iso_loc [S][nt], x_iso_softplus_scale [S][nt]; noise: scale [nt],
+// x_iso [S][nt].
+__global__ void reg_joint_sample_kernel(int S, int nt, const float *jp, const float *jeps, float *xi)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, snt = (int64_t)S * nt;
+    if (i >= snt) return;
+    xi[i] = jp[2 * (int64_t)nt + i] + softplusf(jp[2 * (int64_t)nt + snt + i]) * jeps[nt + i];
+}
+// mu[s][p] = x_splice_bias[p] + sum_f F[s][f] w_splice[f][p] at the block's draw (thread per feature)
+__global__ void reg_joint_mean_kernel(RegView vs, int S, const float *__restrict__ sp, const float *__restrict__ seps,
+                                      const float *__restrict__ design, float *__restrict__ mu)
+{
+    const int64_t pidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= vs.n) return;
+    const int64_t Fn = vs.Fn();
+    const float b = sp[vs.o_bias_loc() + pidx] + softplusf(sp[vs.o_bias_s() + pidx]) * seps[vs.e_bias() + pidx];
+    float w[REG_MAXF];
+    for (int f = 0; f < vs.F; ++f) {
+        const int64_t idx = (int64_t)f * vs.n + pidx;
+        w[f] = sp[vs.o_cols() + 8 * Fn + idx] + softplusf(sp[vs.o_cols() + 9 * Fn + idx]) * seps[vs.e_cols() + 4 * Fn + idx];
+    }
+    for (int s = 0; s < S; ++s) {
+        float m = b;
+        for (int f = 0; f < vs.F; ++f) m += design[s * vs.F + f] * w[f];
+        mu[(int64_t)s * vs.n + pidx] = m;
+    }
+}
+// thread per transcript: x_iso_scale's draw, the observation term of its S values, log q of both, their gradients (gi = d lp /
+// d x_iso from the gene-level likelihood); resid[s][t] = (x_iso - x_iso_loc) / x_iso_scale^2 goes on to the features
+__global__ __launch_bounds__(256) void reg_joint_iso_kernel(int S, int nt, int P, const float *__restrict__ jp,
+                                                            const float *__restrict__ jeps, const float *__restrict__ gi,
+                                                            const float *__restrict__ mu, const int32_t *__restrict__ t_ptr,
+                                                            const int32_t *__restrict__ t_feat, float *__restrict__ jg,
+                                                            float *__restrict__ resid, float *loss_slots)
+{
+    const int64_t ii = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, snt = (int64_t)S * nt;
+    const bool live = ii < nt;
+    const int64_t i = live ? ii : nt - 1;
+    const float *loc = jp + 2 * (int64_t)nt, *sr = loc + snt;
+    const SpDraw xs = sp_draw(jp[i], jp[nt + i], jeps[i]);
+    const float z = xs.z, iz = frcp(z), iz2 = iz * iz, lz = flog(z);
+    float loss = xs.logq + 0.45158270528945486473f + log1pf(z * z);  // log q - log HalfCauchy(0, 1)
+    float Gz = 2.0f * z / (1.0f + z * z);
+    const int32_t f0 = t_ptr[i], f1 = t_ptr[i + 1];
+    for (int s = 0; s < S; ++s) {
+        const int64_t o = (int64_t)s * nt + i;
+        float m = 0.0f;
+        for (int32_t q = f0; q < f1; ++q) m += mu[(int64_t)s * P + t_feat[q]];
+        const float sraw = sr[o], sx = softplusf(sraw), e = jeps[nt + o];
+        const float d = loc[o] + sx * e - m;
+        const float a = d * iz2;
+        loss += 0.5f * d * a + lz + HALF_LOG2PI;              // -log Normal(x_iso_loc, x_iso_scale)(x_iso)
+        loss += -0.5f * e * e - flog(sx) - HALF_LOG2PI;       // log q(x_iso)
+        Gz += iz - d * a * iz;
+        const float Gx = a - gi[o];
+        if (live) {
+            jg[2 * (int64_t)nt + o] = Gx;
+            jg[2 * (int64_t)nt + snt + o] = (Gx * e - frcp(sx)) * sigmoidf(sraw);
+            resid[o] = a;
+        }
+    }
+    if (live) {
+        float a, c;
+        sp_grad(xs, Gz, a, c);
+        jg[i] = a;
+        jg[nt + i] = c;
+    }
+    loss = wave_sum_to_lane63(live ? loss : 0.0f);
+    if ((threadIdx.x & 63) == 63) atomicAdd(&loss_slots[blockIdx.x % REG_SLOTS], loss);
+}
+// thread per splice feature: what the transcripts say about its column (the `stats` rows the column kernel reads)
+__global__ void reg_joint_agg_kernel(int S, int nt, int P, int F, const float *__restrict__ resid,
+                                     const float *__restrict__ design, const int32_t *__restrict__ p_ptr,
+                                     const int32_t *__restrict__ p_trans, float *__restrict__ stats)
+{
+    const int64_t pidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pidx >= P) return;
+    float gacc[REG_MAXF], sum_a = 0.0f;
+    for (int f = 0; f < F; ++f) gacc[f] = 0.0f;
+    const int32_t q0 = p_ptr[pidx], q1 = p_ptr[pidx + 1];
+    for (int s = 0; s < S; ++s) {
+        float a = 0.0f;
+        for (int32_t q = q0; q < q1; ++q) a += resid[(int64_t)s * nt + p_trans[q]];
+        sum_a += a;
+        for (int f = 0; f < F; ++f) gacc[f] -= design[s * F + f] * a;
+    }
+    for (int f = 0; f < F; ++f) stats[(int64_t)f * P + pidx] = gacc[f];
+    stats[(int64_t)F * P + pidx] = sum_a;
+    stats[(int64_t)(F + 1) * P + pidx] = 0.0f;
+}
+
 // ---- data pass: what the S (local) samples say about each column ------------------------------------------
 // stats [F+2][n] + REG_SLOTS:  rows 0..F-1  sum_s design[s][f] d(-log p_x)/d x_loc[s][j];  row F  sum_s (x - mu)/x_scale^2;
 // row F+1  sum_s d(-log p_x)/d x_scale;  last REG_SLOTS values (summed by the reader)  loss terms of the samples (observation model, log q of x,
@@ -427,15 +533,20 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         float *gc = g + v.o_cols() + idx;
         const SpDraw l1v = sp_draw(pc[0 * Fn], pc[1 * Fn], ec[0 * Fn]);
         const SpDraw l1n = sp_draw(pc[2 * Fn], pc[3 * Fn], ec[1 * Fn]);
-        const SpDraw l2v = sp_draw(pc[4 * Fn], pc[5 * Fn], ec[2 * Fn]);
-        const SpDraw l2n = sp_draw(pc[6 * Fn], pc[7 * Fn], ec[3 * Fn]);
+        SpDraw l2v = sp_draw(pc[4 * Fn], pc[5 * Fn], ec[2 * Fn]);
+        SpDraw l2n = sp_draw(pc[6 * Fn], pc[7 * Fn], ec[3 * Fn]);
+        const bool two = v.levels > 1;
+        if (!two) {  // horseshoe: no second local scale
+            l2v.z = l2n.z = 1.0f;
+            l2v.logq = l2n.logq = 0.0f;
+        }
         const float sraw_w = pc[9 * Fn], s_w = softplusf(sraw_w), e_w = ec[4 * Fn];
         const float w = pc[8 * Fn] + s_w * e_w;
         const float sw = (l1n.z * fsqrt(l1v.z)) * (l2n.z * fsqrt(l2v.z)) * gscale;
         const float isw = frcp(sw), r = w * isw, q = 1.0f - r * r;
         S1 += q;
         loss += l1v.logq + l1n.logq + l2v.logq + l2n.logq + (-0.5f * e_w * e_w - flog(s_w) - HALF_LOG2PI);
-        loss += nlp_ig_half(l1v.z) + nlp_halfnormal(l1n.z) + nlp_ig_half(l2v.z) + nlp_halfnormal(l2n.z);
+        loss += nlp_ig_half(l1v.z) + nlp_halfnormal(l1n.z) + (two ? nlp_ig_half(l2v.z) + nlp_halfnormal(l2n.z) : 0.0f);
         loss += 0.5f * r * r + flog(sw) + HALF_LOG2PI;
         float a, b;
         float iz = frcp(l1v.z);
@@ -445,9 +556,9 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
         if (live) gc[2 * Fn] = a, gc[3 * Fn] = b;
         iz = frcp(l2v.z);
         sp_grad(l2v, iz * (1.5f + 0.5f * q - 0.5f * iz), a, b);
-        if (live) gc[4 * Fn] = a, gc[5 * Fn] = b;
+        if (live) gc[4 * Fn] = two ? a : 0.0f, gc[5 * Fn] = two ? b : 0.0f;
         sp_grad(l2n, l2n.z + q * frcp(l2n.z), a, b);
-        if (live) gc[6 * Fn] = a, gc[7 * Fn] = b;
+        if (live) gc[6 * Fn] = two ? a : 0.0f, gc[7 * Fn] = two ? b : 0.0f;
         const float gacc = stats[idx];
         const float Gw = r * isw + gacc;
         if (live) {
@@ -467,39 +578,84 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
     const float s_b = softplusf(p[v.o_bias_s() + j]), e_b = eps[v.e_bias() + j];
     const float b = p[v.o_bias_loc() + j] + s_b * e_b;
     loss += -0.5f * e_b * e_b - flog(s_b) - HALF_LOG2PI;
-    const SpDraw xs = sp_draw(p[v.o_xs_loc() + j], p[v.o_xs_s() + j], eps[v.e_xs() + j]);
-    loss += xs.logq;
-    float alpha = 0.0f, beta = 0.0f;
-#pragma unroll UD
-    for (int d = 0; d < deg; ++d) {
-        const float wdj = W[(int64_t)d * n + j];
-        alpha += s_cc[d] * wdj;
-        beta += s_sc[d] * wdj;
-    }
-    if (v.fixed_ab > 0.0f) alpha = beta = v.fixed_ab;
-    const float inv = frcp(xs.z), inv2 = inv * inv, lxs = flog(xs.z);
-    const float Gxs = (alpha + 1.0f) * inv - beta * inv2 + stats[(int64_t)(F + 1) * n + j];
     const float db = (b - v.bias_loc0) / v.bias_scale0;
-    const float Gb = db / v.bias_scale0 - stats[(int64_t)F * n + j];
+    float Gb = db / v.bias_scale0 - stats[(int64_t)F * n + j];
     loss += 0.5f * db * db + logf(v.bias_scale0) + HALF_LOG2PI;
-    const float lbeta = flog(beta);
-    float lg_alpha, psi_alpha;
-    lgamma_digamma(alpha, lg_alpha, psi_alpha);
-    loss += -(alpha * lbeta - lg_alpha - (alpha + 1.0f) * lxs - beta * inv);
-    const float g_alpha = -lbeta + psi_alpha + lxs, g_beta = -alpha * frcp(beta) + inv;
+    float g_alpha = 0.0f, g_beta = 0.0f;
+    // the kernel-regression weights of this column: precomputed from x_bias_init (W), or -- the joint model -- functions of
+    // the sampled bias b (src/polee.py:36-47): k_d = clip(exp(-((b - h_d) / bw)^2), 1e-10, 1), w_d = k_d / sum k
+    // (only the run-time-shape instance <0, 0> carries this variant: the fixed-shape instances of the transcript model keep
+    // their register budget; the host launches <0, 0> for a view with w_from_bias)
+    constexpr bool WB = FT == 0 && DT == 0;
+    float wcol[WB ? REG_MAXDEG : 1], dl[WB ? REG_MAXDEG : 1];
+    const bool wfb = WB && v.w_from_bias;
+    if (wfb) {
+        float tot = 0.0f;
+        for (int d = 0; d < deg; ++d) {
+            const float u = (b - v.hinges[d]) / v.bandwidth;
+            const float k0 = fexp(-u * u);
+            const bool clipped = k0 < 1e-10f;  // (the upper clip at 1 is never active: exp(-u^2) <= 1)
+            wcol[d] = clipped ? 1e-10f : k0;
+            dl[d] = clipped ? 0.0f : -2.0f * u / v.bandwidth;  // d log k_d / d b
+            tot += wcol[d];
+        }
+        const float it = frcp(tot);
+        for (int d = 0; d < deg; ++d) wcol[d] *= it;
+    }
+    if (!v.no_xs) {
+        const SpDraw xs = sp_draw(p[v.o_xs_loc() + j], p[v.o_xs_s() + j], eps[v.e_xs() + j]);
+        loss += xs.logq;
+        float alpha = 0.0f, beta = 0.0f;
+        if (wfb) {
+            for (int d = 0; d < deg; ++d) {
+                alpha += s_cc[d] * wcol[d];
+                beta += s_sc[d] * wcol[d];
+            }
+        } else {
+#pragma unroll UD
+            for (int d = 0; d < deg; ++d) {
+                const float wdj = W[(int64_t)d * n + j];
+                alpha += s_cc[d] * wdj;
+                beta += s_sc[d] * wdj;
+            }
+        }
+        if (v.fixed_ab > 0.0f) alpha = beta = v.fixed_ab;
+        const float inv = frcp(xs.z), inv2 = inv * inv, lxs = flog(xs.z);
+        const float Gxs = (alpha + 1.0f) * inv - beta * inv2 + stats[(int64_t)(F + 1) * n + j];
+        const float lbeta = flog(beta);
+        float lg_alpha, psi_alpha;
+        lgamma_digamma(alpha, lg_alpha, psi_alpha);
+        loss += -(alpha * lbeta - lg_alpha - (alpha + 1.0f) * lxs - beta * inv);
+        g_alpha = -lbeta + psi_alpha + lxs;
+        g_beta = -alpha * frcp(beta) + inv;
+        if (wfb) {  // d alpha / d b = sum_d cc_d w_d (l_d - lbar), lbar = sum_e w_e l_e; the same for beta
+            float lbar = 0.0f, da = 0.0f, dbt = 0.0f;
+            for (int d = 0; d < deg; ++d) lbar += wcol[d] * dl[d];
+            for (int d = 0; d < deg; ++d) {
+                da += s_cc[d] * wcol[d] * (dl[d] - lbar);
+                dbt += s_sc[d] * wcol[d] * (dl[d] - lbar);
+            }
+            Gb += g_alpha * da + g_beta * dbt;
+        }
+        if (live) {
+            float a, c;
+            sp_grad(xs, Gxs, a, c);
+            g[v.o_xs_loc() + j] = a;
+            g[v.o_xs_s() + j] = c;
+        }
+    } else if (live) {
+        g[v.o_xs_loc() + j] = 0.0f;
+        g[v.o_xs_s() + j] = 0.0f;
+    }
     if (live) {
         g[v.o_bias_loc() + j] = Gb;
         g[v.o_bias_s() + j] = (Gb * e_b - frcp(s_b)) * sigmoidf(p[v.o_bias_s() + j]);
-        float a, c;
-        sp_grad(xs, Gxs, a, c);
-        g[v.o_xs_loc() + j] = a;
-        g[v.o_xs_s() + j] = c;
     }
 
     // ---- block sums of what the columns share
 #pragma unroll UD
     for (int d = 0; d < deg; ++d) {
-        const float wdj = lv * W[(int64_t)d * n + j];
+        const float wdj = lv * (wfb ? wcol[WB ? d : 0] : W[(int64_t)d * n + j]);
         const float ta = wave_sum_to_lane63(wdj * g_alpha), tb = wave_sum_to_lane63(wdj * g_beta);
         if (lane == 63) {
             atomicAdd(&s_red[1 + F * deg + d], ta);
@@ -555,9 +711,9 @@ __global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *
     }
     for (int i = lane; i < 2 * v.deg; i += 64) {  // concentration_c then scale_c (adjacent in the vector)
         const int64_t o = v.o_conc() + i;
-        const float c = softplusf(p[o]);
-        g[o] = (2.0f * c / (1.0f + c * c) + slots(1 + v.F * v.deg + i)) * sigmoidf(p[o]);
-        loss += 0.45158270528945486473f + log1pf(c * c);  // -log(2/pi)
+        const float c = softplusf(p[o]), hs = v.hc_scale;  // HalfCauchy(0, hs): -log p = -log(2 / (pi hs)) + log1p((c / hs)^2)
+        g[o] = (2.0f * c / (hs * hs + c * c) + slots(1 + v.F * v.deg + i)) * sigmoidf(p[o]);
+        loss += 0.45158270528945486473f + logf(hs) + log1pf((c / hs) * (c / hs));  // (0.4515... = -log(2/pi))
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, 64);
@@ -612,14 +768,27 @@ struct polee_regression {
     // ~ Normal(0, 2), x_isoform_scale ~ InverseGamma(0.001, 0.001) -- laid out as a second RegView (vi, deg = 0) and
     // run through the same data / column / finish kernels
     bool iso_reg = false;
+    // joint model (RNASeqJointLinearRegression): vi = the splice-feature block (P columns), the transcripts' part of the
+    // block behind it in d_ip; the feature matrix both ways
+    bool joint = false;
+    int32_t P = 0;
+    DevBuf<int32_t> d_tptr, d_tfeat, d_pptr, d_ptrans;
+    DevBuf<float> d_mu, d_resid, d_hinges;
+    std::vector<float> h_hinges;  // (kept from create: the joint model's weights follow the sampled bias)
+    float bandwidth = 1.0f;
     RegView vi{};
     DevBuf<float> d_idesign, d_istats, d_ismall, d_iloss;
     DevBuf<double> d_iacc;
     int64_t num_iso_params() const
     {
+        if (joint) return vi.num_params() + 2 * (int64_t)nt + 2 * (int64_t)v.S * nt;
         return !gene_ap ? 0 : (iso_reg ? vi.num_params() : 2 * (int64_t)nt + 2 * (int64_t)v.S * nt);
     }
-    int64_t num_iso_noise() const { return !gene_ap ? 0 : (iso_reg ? vi.num_noise() : (int64_t)nt + (int64_t)v.S * nt); }
+    int64_t num_iso_noise() const
+    {
+        if (joint) return vi.num_noise() + (int64_t)nt + (int64_t)v.S * nt;
+        return !gene_ap ? 0 : (iso_reg ? vi.num_noise() : (int64_t)nt + (int64_t)v.S * nt);
+    }
     int64_t num_iso_stats() const { return (int64_t)(vi.F + 2) * vi.n + REG_SLOTS; }
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
     int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + REG_SLOTS; }
@@ -647,7 +816,11 @@ polee_status reg_data_pass(polee_regression *r)
                            r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
         if (r->gene_ap) {
-            if (r->iso_reg)
+            if (r->joint)
+                hipLaunchKernelGGL(reg_joint_sample_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256), 0,
+                                   st, v.S, r->nt, (const float *)(r->d_ip.p + r->vi.num_params()),
+                                   (const float *)(r->d_ieps.p + r->vi.num_noise()), r->d_xi.p);
+            else if (r->iso_reg)
                 hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div((int64_t)v.S * r->nt, 256)), dim3(256), 0,
                                    st, r->vi, r->d_ip.p, r->d_ieps.p, r->d_xi.p);
             else
@@ -675,7 +848,17 @@ polee_status reg_data_pass(polee_regression *r)
     else if (v.deg == 15 && v.F == 4) POLEE_REG_DATA(4, 15);
     else POLEE_REG_DATA(0, 0);
 #undef POLEE_REG_DATA
-    if (r->gene_ap && r->iso_reg)  // (d_xi now holds d lp / d x_isoform): the isoform block's own data pass
+    if (r->gene_ap && r->joint) {  // (d_xi now holds d lp / d x_iso): the splice block's predictor, the transcripts, back to the features
+        const RegView &vs = r->vi;
+        hipLaunchKernelGGL(reg_joint_mean_kernel, dim3((unsigned)ceil_div(vs.n, 128)), dim3(128), 0, st, vs, v.S, r->d_ip.p,
+                           r->d_ieps.p, r->d_design.p, r->d_mu.p);
+        hipLaunchKernelGGL(reg_joint_iso_kernel, dim3((unsigned)ceil_div(r->nt, 256)), dim3(256), 0, st, v.S, r->nt, r->P,
+                           (const float *)(r->d_ip.p + vs.num_params()), (const float *)(r->d_ieps.p + vs.num_noise()),
+                           (const float *)r->d_xi.p, (const float *)r->d_mu.p, r->d_tptr.p, r->d_tfeat.p,
+                           r->d_ig.p + vs.num_params(), r->d_resid.p, r->d_stats.p + r->num_stats() - REG_SLOTS);
+        hipLaunchKernelGGL(reg_joint_agg_kernel, dim3((unsigned)ceil_div(r->P, 128)), dim3(128), 0, st, v.S, r->nt, r->P, vs.F,
+                           (const float *)r->d_resid.p, r->d_design.p, r->d_pptr.p, r->d_ptrans.p, r->d_istats.p);
+    } else if (r->gene_ap && r->iso_reg)  // (d_xi now holds d lp / d x_isoform): the isoform block's own data pass
         hipLaunchKernelGGL((reg_data_kernel<0, 0>), dim3((unsigned)ceil_div(r->nt, REG_BLOCK)), dim3(REG_BLOCK), 0, st,
                            r->vi, r->d_ip.p, r->d_ieps.p, r->d_idesign.p, (const float *)nullptr, (const float *)nullptr,
                            (const float *)nullptr, r->d_xi.p, (const float *)nullptr, (const float *)nullptr, r->d_ig.p,
@@ -697,21 +880,22 @@ polee_status reg_prior_pass(polee_regression *r)
 #define POLEE_REG_COLS(FT, DT)                                                                                     \
     hipLaunchKernelGGL((reg_cols_kernel<FT, DT>), grid, dim3(REG_BLOCK), 0, st, v, r->d_p.p, r->d_eps.p, r->d_W.p, \
                        r->d_stats.p, r->d_g.p, r->d_acc.p, r->d_small.p)
-    if (v.deg == 15 && v.F == 1) POLEE_REG_COLS(1, 15);
+    if (v.w_from_bias) POLEE_REG_COLS(0, 0);
+    else if (v.deg == 15 && v.F == 1) POLEE_REG_COLS(1, 15);
     else if (v.deg == 15 && v.F == 2) POLEE_REG_COLS(2, 15);
     else if (v.deg == 15 && v.F == 3) POLEE_REG_COLS(3, 15);
     else if (v.deg == 15 && v.F == 4) POLEE_REG_COLS(4, 15);
     else POLEE_REG_COLS(0, 0);
 #undef POLEE_REG_COLS
-    if (r->iso_reg) {  // the isoform block's columns and its global scale; its loss joins the model's below
-        hipLaunchKernelGGL((reg_cols_kernel<0, 0>), dim3((unsigned)ceil_div(r->nt, REG_BLOCK)), dim3(REG_BLOCK), 0, st,
+    if (r->iso_reg || r->joint) {  // the isoform / splice block's columns and its global scale; its loss joins the model's below
+        hipLaunchKernelGGL((reg_cols_kernel<0, 0>), dim3((unsigned)ceil_div(r->vi.n, REG_BLOCK)), dim3(REG_BLOCK), 0, st,
                            r->vi, r->d_ip.p, r->d_ieps.p, (const float *)nullptr, r->d_istats.p, r->d_ig.p, r->d_iacc.p,
                            r->d_ismall.p);
         hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, r->vi, r->d_ip.p, r->d_ieps.p, r->d_ismall.p,
                            r->d_istats.p, r->d_iacc.p, r->d_ig.p, r->d_iloss.p, (const float *)nullptr);
     }
     hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p,
-                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p, r->iso_reg ? r->d_iloss.p : (const float *)nullptr);
+                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p, (r->iso_reg || r->joint) ? r->d_iloss.p : (const float *)nullptr);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -832,6 +1016,8 @@ polee_status polee_regression_create(polee_ctx *ctx, polee_approx *ap, int32_t S
         const double step = (hi - lo) / (degree + 1);
         for (int d = 0; d < degree; ++d) hg[(size_t)d] = lo + (d + 1) * step;
     }
+    r->h_hinges.assign(hg.begin(), hg.end());
+    r->bandwidth = bandwidth;
     std::vector<float> W((size_t)degree * n);
     for (int j = 0; j < n; ++j) {
         double tot = 0.0, col[REG_MAXDEG];
@@ -1008,6 +1194,107 @@ polee_status polee_regression_set_gene_isoform_likelihood(polee_regression *r, p
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_ismall.p, 0, sizeof(float) * REG_SLOTS * vi.num_red(), ctx->stream));
     POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iacc.p, 0, sizeof(double) * REG_SLOTS, ctx->stream));
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return POLEE_OK;
+}
+
+polee_status polee_regression_set_joint_likelihood(polee_regression *r, polee_approx *ap, const int32_t *gene_of,
+                                                   const float *x_isoform_init, int32_t num_splice_features,
+                                                   const int32_t *pair_transcript, const int32_t *pair_feature, int64_t num_pairs)
+{
+    if (!r || !pair_transcript || !pair_feature) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    if (num_splice_features < 1 || num_pairs < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "bad splice-feature matrix");
+    if (r->v.use_distortion) return fail(ctx, POLEE_ERR_BAD_ARG, "the joint model has no distortion term: create the gene block with use_distortion = 0");
+    POLEE_TRY(polee_regression_set_gene_likelihood(r, ap, gene_of, x_isoform_init));  // (gene_ap, nt, d_xi; its isoform block is replaced below)
+    const int S = r->v.S, nt = r->nt, P = num_splice_features, F = r->v.F;
+    for (int64_t q = 0; q < num_pairs; ++q)
+        if (pair_transcript[q] < 0 || pair_transcript[q] >= nt || pair_feature[q] < 0 || pair_feature[q] >= P)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "splice-feature pair %lld out of range", (long long)q);
+    // the feature matrix both ways (CSR by transcript, CSR by feature)
+    std::vector<int32_t> tptr((size_t)nt + 1, 0), tfeat((size_t)num_pairs), pptr((size_t)P + 1, 0), ptrans((size_t)num_pairs);
+    for (int64_t q = 0; q < num_pairs; ++q) {
+        ++tptr[(size_t)pair_transcript[q] + 1];
+        ++pptr[(size_t)pair_feature[q] + 1];
+    }
+    for (int i = 0; i < nt; ++i) tptr[(size_t)i + 1] += tptr[(size_t)i];
+    for (int i = 0; i < P; ++i) pptr[(size_t)i + 1] += pptr[(size_t)i];
+    {
+        std::vector<int32_t> ct(tptr.begin(), tptr.end() - 1), cp(pptr.begin(), pptr.end() - 1);
+        for (int64_t q = 0; q < num_pairs; ++q) {
+            tfeat[(size_t)ct[(size_t)pair_transcript[q]]++] = pair_feature[q];
+            ptrans[(size_t)cp[(size_t)pair_feature[q]]++] = pair_transcript[q];
+        }
+    }
+    // the gene block becomes the joint model's: a horseshoe (one local level), weights from the sampled bias, HalfCauchy(0, 10)
+    // on the mean-variance coefficients, qw_gene_softplus_scale = -2 (:1009-1041, :936-937), Adam(1e-3) (:1215)
+    RegView &v = r->v;
+    v.levels = 1;
+    v.w_from_bias = 1;
+    v.hc_scale = 10.0f;
+    v.bandwidth = r->bandwidth;
+    POLEE_TRY(r->d_hinges.upload(ctx, r->h_hinges));
+    v.hinges = r->d_hinges.p;
+    r->lr = 1e-3f;
+    {
+        std::vector<float> qs((size_t)v.Fn(), -2.0f);
+        POLEE_HIP_TRY(ctx, hipMemcpy(r->d_p.p + v.o_cols() + 9 * v.Fn(), qs.data(), sizeof(float) * qs.size(), hipMemcpyHostToDevice));
+    }
+    // the splice block: P columns, horseshoe, bias ~ Normal(0, 10), no x_scale of its own (:1062-1087, surrogates :1172-1203)
+    RegView &vs = r->vi;
+    vs = RegView{0, F, P, 0, 0, 0, 0.0f, 10.0f, 1.0f};
+    vs.levels = 1;
+    vs.no_xs = 1;
+    const int64_t PS = vs.num_params(), Fp = vs.Fn(), snt = (int64_t)S * nt, PJ = PS + 2 * (int64_t)nt + 2 * snt;
+    std::vector<float> p((size_t)PJ, 0.0f);
+    p[1] = p[3] = -1.0f;
+    for (int a = 1; a < 8; a += 2) std::fill_n(p.begin() + vs.o_cols() + a * Fp, Fp, -1.0f);
+    std::fill_n(p.begin() + vs.o_cols() + 9 * Fp, Fp, -2.0f);           // qw_splice_softplus_scale
+    for (int i = 0; i < P; ++i) p[(size_t)(vs.o_bias_s() + i)] = -1.0f;  // qx_splice_bias: loc 0, softplus scale -1
+    for (int i = 0; i < nt; ++i) {
+        p[(size_t)(PS + i)] = 3.0f;        // qx_iso_scale_loc (:1004-1005)
+        p[(size_t)(PS + nt + i)] = -1.0f;  // qx_iso_scale_softplus_scale
+    }
+    std::copy_n(x_isoform_init, snt, p.begin() + PS + 2 * (int64_t)nt);
+    std::fill_n(p.begin() + PS + 2 * (int64_t)nt + snt, snt, -3.0f);  // qx_iso_softplus_scale (:1009-1010)
+    r->joint = true;
+    r->iso_reg = false;
+    r->P = P;
+    r->drop_graph();
+    POLEE_TRY(r->d_ip.upload(ctx, p));
+    POLEE_TRY(r->d_ig.alloc(ctx, (size_t)PJ));
+    POLEE_TRY(r->d_im.alloc(ctx, (size_t)PJ));
+    POLEE_TRY(r->d_iv.alloc(ctx, (size_t)PJ));
+    POLEE_TRY(r->d_ieps.alloc(ctx, (size_t)r->num_iso_noise()));
+    POLEE_TRY(r->d_istats.alloc(ctx, (size_t)r->num_iso_stats()));
+    POLEE_TRY(r->d_ismall.alloc(ctx, (size_t)REG_SLOTS * vs.num_red()));
+    POLEE_TRY(r->d_iacc.alloc(ctx, REG_SLOTS));
+    POLEE_TRY(r->d_iloss.alloc(ctx, 1));
+    POLEE_TRY(r->d_mu.alloc(ctx, (size_t)S * P));
+    POLEE_TRY(r->d_resid.alloc(ctx, (size_t)snt));
+    POLEE_TRY(r->d_tptr.upload(ctx, tptr));
+    POLEE_TRY(r->d_pptr.upload(ctx, pptr));
+    if (num_pairs > 0) {
+        POLEE_TRY(r->d_tfeat.upload(ctx, tfeat));
+        POLEE_TRY(r->d_ptrans.upload(ctx, ptrans));
+    } else {
+        POLEE_TRY(r->d_tfeat.alloc(ctx, 1));
+        POLEE_TRY(r->d_ptrans.alloc(ctx, 1));
+    }
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_ig.p, 0, sizeof(float) * PJ, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_im.p, 0, sizeof(float) * PJ, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iv.p, 0, sizeof(float) * PJ, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_istats.p, 0, sizeof(float) * r->num_iso_stats(), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_ismall.p, 0, sizeof(float) * REG_SLOTS * vs.num_red(), ctx->stream));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(r->d_iacc.p, 0, sizeof(double) * REG_SLOTS, ctx->stream));
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return POLEE_OK;
+}
+
+polee_status polee_regression_set_learning_rate(polee_regression *r, float lr)
+{
+    if (!r || !(lr > 0.0f)) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "bad learning rate");
+    r->lr = lr;
+    r->drop_graph();  // (the step size is an argument of the captured tick kernel)
     return POLEE_OK;
 }
 

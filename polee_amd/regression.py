@@ -346,6 +346,87 @@ class RNASeqGeneIsoformLinearRegression(RNASeqLinearRegression):
                 output.write("qw_isoform_{}_var: {}\n".format(name, iv["qw_isoform_" + name]))
 
 
+class RNASeqJointLinearRegression(RNASeqLinearRegression):
+    """RNASeqJointLinearRegression (models/polee_regression.py:879-1283, driven by models/joint-regression.jl): regression
+    over gene (TSS-group) expression AND over splice-feature usage, whose predictor reaches the transcripts through the 0/1
+    feature matrix.  Argument order follows the reference: tss_is / tss_js = 1-based (transcript, gene) pairs,
+    feature_is / feature_js = 1-based (transcript, splice feature) pairs.  fit() returns (qw_gene_loc, qw_gene_scale,
+    qw_splice_loc, qw_splice_scale) (:1230-1234).  Built without point estimates only."""
+
+    # the splice block of the isoform-parameter vector (include/polee_hip.h); shapes: 1, [F, P], [P]; then [nt], [S, nt]
+    SPLICE_PARAMS = [
+        ("qw_splice_global_scale_variance_loc", "1"), ("qw_splice_global_scale_variance_softplus_scale", "1"),
+        ("qw_splice_global_scale_noncentered_loc", "1"), ("qw_splice_global_scale_noncentered_softplus_scale", "1"),
+        ("qw_splice_local_scale_variance_loc", "FP"), ("qw_splice_local_scale_variance_softplus_scale", "FP"),
+        ("qw_splice_local_scale_noncentered_loc", "FP"), ("qw_splice_local_scale_noncentered_softplus_scale", "FP"),
+        ("_unused_local2_a", "FP"), ("_unused_local2_b", "FP"), ("_unused_local2_c", "FP"), ("_unused_local2_d", "FP"),
+        ("qw_splice_loc", "FP"), ("qw_splice_softplus_scale", "FP"),
+        ("qx_splice_bias_loc", "P"), ("qx_splice_bias_softplus_scale", "P"),
+        ("_unused_scale_a", "P"), ("_unused_scale_b", "P"),
+        ("qx_iso_scale_loc", "t"), ("qx_iso_scale_softplus_scale", "t"),
+        ("qx_iso_loc", "St"), ("qx_iso_softplus_scale", "St"),
+    ]
+
+    def __init__(self, vars, tss_is, tss_js, num_gene_features, feature_is, feature_js, num_splice_features, gene_sizes,
+                 x_gene_init, x_isoform_init, F_arr, sample_scales, use_point_estimates, kernel_regression_degree=15,
+                 kernel_regression_bandwidth=1.0, ctx=None):
+        if use_point_estimates:
+            raise NotImplementedError("the joint model is built without point estimates only")
+        x_gene_init = np.asarray(x_gene_init, np.float32)
+        if x_gene_init.shape[1] != int(num_gene_features):
+            raise ValueError("x_gene_init must be [S, num_gene_features]")
+        lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=ctx)
+        ti = np.asarray(tss_is, np.int64).reshape(-1) - 1
+        gi = np.asarray(tss_js, np.int64).reshape(-1) - 1
+        gene_of = np.full(lik.n, -1, np.int64)
+        gene_of[ti] = gi
+        if (gene_of < 0).any():
+            raise ValueError("every transcript must belong to a gene feature")
+        # the gene block: no distortion (:1029), scale-drift penalty Normal(0, 5e-4) (:1052-1054)
+        super().__init__(F_arr, x_gene_init, None, math.log(1.0 / int(num_gene_features)), 12.0, None, sample_scales, False,
+                         5e-4, False, kernel_regression_degree, kernel_regression_bandwidth, ctx=ctx or lik.ctx,
+                         gene_likelihood=(lik, gene_of, x_isoform_init))
+        # (the base constructor attaches the plain gene-level likelihood; polee_regression_set_joint_likelihood below
+        # re-attaches it and replaces its isoform block by the joint model's splice block)
+        xi0 = arr(np.atleast_2d(x_isoform_init), np.float32)
+        if xi0.shape != (self.num_samples, lik.n):
+            raise ValueError("x_isoform_init must be [S, nt]")
+        pt = arr(np.asarray(feature_is, np.int64).reshape(-1) - 1, np.int32)
+        pf = arr(np.asarray(feature_js, np.int64).reshape(-1) - 1, np.int32)
+        if pt.size != pf.size:
+            raise ValueError("feature_is and feature_js must pair up")
+        self.num_splice_features = int(num_splice_features)
+        self.likelihood_model = lik
+        lib = L.lib()
+        check(lib.polee_regression_set_joint_likelihood(self._h, lik._h, ptr(arr(gene_of, np.int32), L.i32p), ptr(xi0, f32p),
+                                                        self.num_splice_features, ptr(pt, L.i32p), ptr(pf, L.i32p),
+                                                        C.c_int64(pt.size)), self.ctx._h)
+        lib.polee_regression_num_isoform_params.restype = C.c_int64
+        lib.polee_regression_num_isoform_params.argtypes = [C.c_void_p]
+        self.num_isoform_params = int(lib.polee_regression_num_isoform_params(self._h))
+        self.num_noise = int(lib.polee_regression_num_noise(self._h))
+
+    def splice_variables(self):
+        v, S, nt, F, P = (self.get_isoform_params(), self.num_samples, self.likelihood_model.n, self.num_factors,
+                          self.num_splice_features)
+        shapes = {"1": (), "FP": (F, P), "P": (P,), "t": (nt,), "St": (S, nt)}
+        out, o = {}, 0
+        for name, code in self.SPLICE_PARAMS:
+            k = int(np.prod(shapes[code], dtype=np.int64))
+            out[name] = v[o:o + k].reshape(shapes[code])
+            o += k
+        assert o == v.size
+        return out
+
+    def fit(self, niter, seed=123456789, noise=None, return_trace=False):
+        """fit (models/polee_regression.py:1204-1234): (qw_gene_loc, qw_gene_scale, qw_splice_loc, qw_splice_scale)."""
+        base = super().fit(niter, seed=seed, noise=noise, return_trace=True)
+        _, qw_gene_loc, qw_gene_scale, _, _, trace = base
+        sv = self.splice_variables()
+        out = (qw_gene_loc, qw_gene_scale, sv["qw_splice_loc"], _softplus(sv["qw_splice_softplus_scale"]))
+        return out + (trace,) if return_trace else out
+
+
 class RNASeqNormalTranscriptLinearRegression(RNASeqLinearRegression):
     """RNASeqNormalTranscriptLinearRegression (models/polee_regression.py:490-531): point estimates and their standard
     deviation in place of the approximate likelihood.  `vars` is unused, as in the reference."""

@@ -497,3 +497,124 @@ def test_gene_isoform_model_matches_restatement(P, ctx):
     assert out[2].shape == (Fi, nt) and out[3].shape == (Fi, nt) and out[4].shape == (nt,) and out[6].shape == (nt,)
     assert out[9].shape == (S, G)
     assert not np.allclose(reg.get_isoform_params(), itheta)
+
+
+def test_joint_model_matches_restatement(P, ctx):
+    """RNASeqJointLinearRegression (models/polee_regression.py:879-1283): the loss against the float64 restatement (gene
+    block with a horseshoe prior, kernel-regression weights of the SAMPLED bias and HalfCauchy(0, 10) coefficients; splice
+    block over P features aggregated to the transcripts; HalfCauchy x_iso_scale) with the C oracle's gene-level likelihood,
+    and gradients of every kind of parameter against central differences of the restatement (+ the oracle's analytic
+    likelihood gradients); initial values; fit()'s outputs."""
+    rng = np.random.default_rng(53)
+    S, F, nt, G, Pf, deg = 4, 2, 90, 25, 30, 5
+    vars_, design, _ = _problem(rng, S, F, nt)
+    gene_of = np.concatenate([np.arange(G), rng.integers(0, G, nt - G)])
+    rng.shuffle(gene_of)
+    # splice features: every transcript takes part in 0..3 of them, every feature has at least one transcript
+    pt, pf = [], []
+    for t in range(nt):
+        for f in rng.choice(Pf, rng.integers(0, 4), replace=False):
+            pt.append(t); pf.append(int(f))
+    for f in range(Pf):
+        if f not in pf:
+            pt.append(int(rng.integers(0, nt))); pf.append(f)
+    pt, pf = np.array(pt), np.array(pf)
+    x_gene_init = (rng.normal(-np.log(G), 1.2, size=(1, G)) + rng.normal(0, 0.3, size=(S, G))).astype(np.float32)
+    x_iso_init = rng.normal(0, 1.0, size=(S, nt)).astype(np.float32)
+    ss = P.estimate_sample_scales(x_gene_init, upper_quantile=0.7)
+    reg = P.RNASeqJointLinearRegression(vars_, np.arange(1, nt + 1), gene_of + 1, G, pt + 1, pf + 1, Pf, None, x_gene_init,
+                                        x_iso_init, design, ss, False, kernel_regression_degree=deg, ctx=ctx)
+    n_sp = 4 + 10 * F * Pf + 4 * Pf
+    n_ip = n_sp + 2 * nt + 2 * S * nt
+    n_se = 2 + 5 * F * Pf + 2 * Pf
+    n_ie = n_se + nt + S * nt
+    assert reg.num_isoform_params == n_ip and reg.num_noise == 2 + 5 * F * G + 2 * G + S * G + n_ie
+    sv, gv = reg.splice_variables(), reg.variables()
+    # initial values (:925-1010)
+    assert np.all(sv["qx_iso_scale_loc"] == 3.0) and np.all(sv["qx_iso_scale_softplus_scale"] == -1.0)
+    np.testing.assert_array_equal(sv["qx_iso_loc"], x_iso_init)
+    assert np.all(sv["qx_iso_softplus_scale"] == -3.0) and np.all(sv["qw_splice_softplus_scale"] == -2.0)
+    assert np.all(sv["qw_splice_loc"] == 0.0) and np.all(sv["qx_splice_bias_loc"] == 0.0) and np.all(sv["qx_splice_bias_softplus_scale"] == -1.0)
+    assert np.all(gv["qw_softplus_scale"] == -2.0) and np.all(gv["qx_scale_loc"] == -0.5)
+    np.testing.assert_allclose(gv["qx_bias_loc"], x_gene_init.mean(axis=0), rtol=1e-5, atol=1e-6)
+    theta = (reg.get_flat_params() + rng.normal(0, 0.2, size=reg.num_params)).astype(np.float32)
+    itheta = (reg.get_isoform_params() + rng.normal(0, 0.2, size=n_ip)).astype(np.float32)
+    reg.set_flat_params(theta)
+    reg.set_isoform_params(itheta)
+    eps = rng.normal(size=reg.num_noise).astype(np.float32)
+    loss, g = reg.loss_and_gradients(noise=eps)
+    gi = reg.isoform_gradients()
+    assert np.all(np.isfinite(gi)) and np.all(np.isfinite(g))
+    mean0 = x_gene_init.astype(np.float64).mean(axis=0).astype(np.float32).astype(np.float64)
+    hinges = RR.choose_knots(mean0.min(), mean0.max(), deg)
+    e = RR.unflatten(eps[:-n_ie].astype(np.float64), RR.NOISE, S, F, G, deg)
+    se = RR.unflatten(eps[-n_ie:-n_ie + n_se].astype(np.float64), RR.NOISE, 0, F, Pf, 0)
+    te = RR.unflatten_iso(eps[-n_ie + n_se:].astype(np.float64), RR.JOINT_TRANSCRIPT_NOISE, S, nt)
+    a = (vars_["efflen"], vars_["la_mu"], vars_["la_sigma"], vars_["la_alpha"], vars_["left_index"],
+         vars_["right_index"], vars_["leaf_index"])
+
+    def model(tvec, ivec, with_lik, frozen=None):
+        lik = (lambda xg, xi: O.approx_gene_log_prob(xg.astype(np.float32), xi.astype(np.float32), gene_of, *a)) if with_lik else None
+        return RR.joint_regression_loss(RR.unflatten(tvec, RR.PARAMS, S, F, G, deg), e,
+                                        RR.unflatten(ivec[:n_sp], RR.PARAMS, 0, F, Pf, 0), se,
+                                        RR.unflatten_iso(ivec[n_sp:], RR.JOINT_TRANSCRIPT_PARAMS, S, nt), te,
+                                        design, hinges, 1.0, ss, G, pt, pf, lik, frozen)
+
+    t64, i64 = theta.astype(np.float64), itheta.astype(np.float64)
+    lref, z = model(t64, i64, True)
+    assert abs(loss - lref) <= 1e-4 * abs(lref) + 1e-2, (loss, lref)
+    _, gg, gxi = O.approx_gene_log_prob(z["x_gene"].astype(np.float32), z["x_iso"].astype(np.float32), gene_of, *a, want_grad=True)
+
+    def fd(tvec, ivec, which, i, frozen=None):
+        h = 1e-4 * max(1.0, abs((tvec if which == 0 else ivec)[i]))
+        vp, vm = (tvec.copy(), ivec.copy()), (tvec.copy(), ivec.copy())
+        vp[which][i] += h
+        vm[which][i] -= h
+        (lp_, zp), (lm_, zm) = model(vp[0], vp[1], False, frozen), model(vm[0], vm[1], False, frozen)
+        # the likelihood reaches the parameters through x_gene and x_iso alone
+        return ((lp_ - lm_) - float(np.sum(gg * (zp["x_gene"] - zm["x_gene"]))) - float(np.sum(gxi * (zp["x_iso"] - zm["x_iso"])))) / (2 * h)
+
+    # gene block: globals, mean-variance coefficients, per-column arrays (local1, w, bias -- the bias also through the
+    # weights --, x_scale), per-sample qx; the local2 and distortion entries are unused: gradient 0
+    table = RR.unflatten(np.arange(t64.size), RR.PARAMS, S, F, G, deg)
+    pick = lambda name, k: rng.choice(table[name].reshape(-1).astype(int), min(k, table[name].size), replace=False)
+    # (tolerances scale with the gradients of the SAME array: the 5e-4 drift penalty makes qx_loc's far larger than the rest)
+    groups = [("globals", np.arange(4)), ("qx_scale_concentration_c_loc", table["qx_scale_concentration_c_loc"].astype(int)),
+              ("qx_scale_scale_c_loc", table["qx_scale_scale_c_loc"].astype(int))]
+    groups += [(nm, pick(nm, 6)) for nm in ("qw_local1_scale_variance_loc", "qw_local1_scale_noncentered_softplus_scale", "qw_loc",
+                                            "qw_softplus_scale", "qx_bias_loc", "qx_bias_softplus_scale", "qx_scale_loc",
+                                            "qx_scale_softplus_scale", "qx_loc", "qx_softplus_scale")]
+    for nm, idx in groups:
+        gs = np.abs(g[idx]).max()
+        for i in idx:
+            f_ = fd(t64, i64, 0, int(i))
+            assert abs(g[i] - f_) / (abs(f_) + 2e-3 * gs) < 1e-2, ("gene block", nm, int(i), g[i], f_)
+    for nm in ("qw_local2_scale_variance_loc", "qw_local2_scale_noncentered_loc", "qw_distortion_c_loc"):
+        assert np.all(g[table[nm].reshape(-1).astype(int)] == 0.0), nm
+    # the weights are a function of the SAMPLED bias (:1034-1035): the check above has the power to see that path --
+    # with the weights frozen the restatement's bias gradients differ from the device's by far more than the tolerance
+    idx = table["qx_bias_loc"].astype(int)
+    gs = np.abs(g[idx]).max()
+    frozen_err = [abs(g[i] - fd(t64, i64, 0, int(i), z["W"])) / (abs(g[i]) + 2e-3 * gs) for i in idx]
+    assert np.sum(np.array(frozen_err) > 5e-2) >= 3, sorted(frozen_err)[-5:]
+    # splice block + transcripts
+    stab = RR.unflatten(np.arange(n_sp), RR.PARAMS, 0, F, Pf, 0)
+    spick = lambda name, k: rng.choice(stab[name].reshape(-1).astype(int), k, replace=False)
+    o_t = n_sp
+    groups = [("globals", np.arange(4))]
+    groups += [(nm, spick(nm, 6)) for nm in ("qw_local1_scale_variance_loc", "qw_local1_scale_noncentered_loc", "qw_loc",
+                                             "qw_softplus_scale", "qx_bias_loc", "qx_bias_softplus_scale")]
+    groups += [("x_iso_scale loc", o_t + rng.choice(nt, 6, replace=False)), ("x_iso_scale s", o_t + nt + rng.choice(nt, 6, replace=False)),
+               ("x_iso loc", o_t + 2 * nt + rng.choice(S * nt, 8, replace=False)),
+               ("x_iso s", o_t + 2 * nt + S * nt + rng.choice(S * nt, 8, replace=False))]
+    for nm, idx in groups:
+        gis = np.abs(gi[idx]).max()
+        for i in idx:
+            f_ = fd(t64, i64, 1, int(i))
+            assert abs(gi[i] - f_) / (abs(f_) + 2e-3 * gis) < 1e-2, ("splice block", nm, int(i), gi[i], f_)
+    for nm in ("qw_local2_scale_variance_loc", "qx_scale_loc", "qx_scale_softplus_scale"):
+        assert np.all(gi[stab[nm].reshape(-1).astype(int)] == 0.0), nm
+    out = reg.fit(80, seed=4, return_trace=True)
+    assert len(out) == 5 and np.all(np.isfinite(out[-1])) and out[-1][-10:].mean() < out[-1][:10].mean()
+    assert out[0].shape == (F, G) and out[1].shape == (F, G) and out[2].shape == (F, Pf) and out[3].shape == (F, Pf)
+    assert not np.allclose(reg.get_isoform_params(), itheta)

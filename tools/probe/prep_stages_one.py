@@ -6,7 +6,7 @@ import numpy as np
 import polee_amd as P
 from tools import synth
 n, m = 200000, 30000000
-smp = synth.make_sample(n, m, 8.0, 123456789)
+smp = synth.make_sample(n, m, 8.0, 123456789, literal=bool(os.environ.get("POLEE_PREP_LITERAL")))
 colptr, rowval, nzval = synth.to_csc(smp)
 eff = smp["effective_lengths"]
 ctx = P.Context(0)

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import numpy as np
 
 n, m = 200000, 30000000
-DIR = os.environ.get("POLEE_PREP_DIR", "/tmp/polee_prep_samples")
+LITERAL = bool(os.environ.get("POLEE_PREP_LITERAL"))  # every fragment its own subset (the bench's headline input) instead of gene patterns
+DIR = os.environ.get("POLEE_PREP_DIR", "/tmp/polee_prep_samples" + ("_literal" if LITERAL else ""))
 
 
 def load_one(s):
@@ -34,7 +35,7 @@ def main():
         if os.path.exists(os.path.join(d, "efflen.npy")):
             continue
         os.makedirs(d, exist_ok=True)
-        smp = synth.make_sample(n, m, 8.0, 123456789 + 7919 * s)
+        smp = synth.make_sample(n, m, 8.0, 123456789 + 7919 * s, literal=LITERAL)
         colptr, rowval, nzval = synth.to_csc(smp)
         for k, v in (("colptr", colptr), ("rowval", rowval), ("nzval", nzval), ("efflen", smp["effective_lengths"])):
             np.save(os.path.join(d, k + ".npy"), v)
