@@ -135,6 +135,22 @@ struct PsellHost {
     std::vector<uint32_t> single_rows;  // their original row ids, ascending (debug view / tests)
 };
 
+// The builder's stages (psell_build.cpp; psell_device.hip builds the same on the device and is checked against these):
+struct PsellRuns {  // stage 1 -> 2: rows of the exact runs (with their slice ends) and the leftover rows, in sort-key order
+    BVec<uint32_t> a1_rows, a1_ends, a2_rows, a2_ends, rb;
+};
+struct PsellRows {  // stage 2 -> 3: the ordered rows of the sliced streams (bounds: PsellHost::rows_a1 .. rows_s)
+    BVec<uint32_t> rows, run_end, row_gid;  // run_end: 1 = the row's slice ends after it; row_gid: its group (forms 1, 2)
+    BVec<uint8_t> row_form;                 // 0 exact run, 1 dense union, 2 masked
+    BVec<uint32_t> pat_ptr, pat_col;        // the groups' transcript sets (unions)
+};
+int psell_bin_shift();
+std::string psell_stage1(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, PsellHost &out, PsellRuns &R);
+std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, PsellRuns &R, PsellHost &out, PsellRows &W);
+std::string psell_stage3(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, const PsellRows &W, PsellHost &out);
 // Builds the layout from X in CSR form (0-based): rowptr [m+1], col [nnz], val [nnz].
 // Returns "" or an error message.
 std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,

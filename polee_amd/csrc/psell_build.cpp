@@ -72,8 +72,37 @@ static void radix_sort_pairs(BVec<uint64_t> &keys, BVec<uint32_t> &vals)
     }
 }
 
-std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
-                        const int64_t *ks, PsellHost &out)
+namespace {
+struct BuildClock {  // POLEE_BUILD_TIMING=1: wall time of every phase on stderr
+    bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    double t_prev = now(), t_sub = now();
+    void lap(const char *what)
+    {
+        if (timing) fprintf(stderr, "[psell build] %-28s %.3f s\n", what, now() - t_prev);
+        t_prev = now();
+    }
+    void sublap(const char *what)  // (finer marks inside a phase; the phase's own line still covers all of it)
+    {
+        if (timing) fprintf(stderr, "[psell build]   . %-24s %.3f s\n", what, now() - t_sub);
+        t_sub = now();
+    }
+};
+}  // namespace
+
+int psell_bin_shift()
+{
+    int binsh = 8;
+    if (const char *e = getenv("POLEE_PSELL_BINSH")) binsh = std::max(0, std::min(24, atoi(e)));
+    return binsh;
+}
+
+// The builder runs in three stages with explicit interfaces (loglik_internal.hpp), so that the device builder
+// (psell_device.hip) can be checked against it stage by stage: any stage of either builder continues from the other's output.
+//
+// STAGE 1: sort keys, rows with one transcript collapsed (stream S), runs of rows with the same transcript set.
+std::string psell_stage1(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, PsellHost &out, PsellRuns &R)
 {
     if (m < 0 || n < 1) return "bad matrix dimensions";
     if (n > (int64_t)1 << 31) return "more than 2^31 transcripts is not supported";
@@ -81,22 +110,11 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     out.m = m;
     out.n = n;
     out.nnz = (int64_t)rowptr[m];
-
-    int binsh = 8;
-    if (const char *e = getenv("POLEE_PSELL_BINSH")) binsh = std::max(0, std::min(24, atoi(e)));
-
-    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now();
-    auto lap = [&](const char *what) {
-        if (timing) fprintf(stderr, "[psell build] %-28s %.3f s\n", what, now() - t_prev);
-        t_prev = now();
-    };
-    double t_sub = now();
-    auto sublap = [&](const char *what) {  // (finer marks inside a phase; the phase's own line still covers all of it)
-        if (timing) fprintf(stderr, "[psell build]   . %-24s %.3f s\n", what, now() - t_sub);
-        t_sub = now();
-    };
+    R = PsellRuns();
+    const int binsh = psell_bin_shift();
+    BuildClock clk;
+    auto lap = [&](const char *w) { clk.lap(w); };
+    auto sublap = [&](const char *w) { clk.sublap(w); };
     // 1. sort keys (rows in parallel; empty rows get the key ~0 and are dropped afterwards).  Fragments with ONE compatible
     // transcript are collapsed here (stream S, loglik_internal.hpp): counted per transcript, their log X_ij summed per chunk
     // (the chunks' sums are added in chunk order: the constant does not depend on the number of threads), key ~0 too.
@@ -179,7 +197,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     lap("keys");
     radix_sort_pairs(keys, rows);
     lap("radix sort");
-    t_sub = now();
+    clk.t_sub = BuildClock::now();
     keys.clear();
     keys.shrink_to_fit();
 
@@ -191,10 +209,6 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     //            stored in the cheapest form: a dense union slice (A1 / A2), a masked slice (A1M; narrow class only) --
     //            or, when neither is below what its rows cost in the mixed stream, not as a group at all;
     //   B:       rows of more than 32 transcripts and the leftover rows of rejected groups.
-    BVec<uint32_t> run_end;   // for the uniform streams' rows: 1 = the row's slice ends after it
-    BVec<uint8_t> row_form;   // for the uniform streams' rows: 0 exact run, 1 dense union, 2 masked
-    BVec<uint32_t> row_gid;   // ... forms 1, 2: the row's group (index into `patterns`)
-    std::vector<BVec<uint32_t>> patterns;  // transcript set (union) of every group of leftover rows
     {
         auto same_set = [&](uint32_t r1, uint32_t r2) {
             const uint64_t l1 = rowptr[r1 + 1] - rowptr[r1], l2 = rowptr[r2 + 1] - rowptr[r2];
@@ -206,13 +220,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
             for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) head[i] = same_set(rows[i - 1], rows[i]) ? 0 : 1;
         });
         sublap("run heads");
-        struct RowList {
-            BVec<uint32_t> rows, ends;
-            BVec<uint8_t> form;
-            BVec<uint32_t> gid;  // union / masked rows: index of the group's transcript set in `patterns`
-        };
-        RowList S1, S1M, S2, S2M;  // A1, A1M, A2, A2M
-        BVec<uint32_t> rb;
+        BVec<uint32_t> &rb = R.rb;
         // (on several host threads: chunks of rows that start at a run's head, each with its own output lists, which are
         // then joined in chunk order -- the result does not depend on the number of threads)
         struct Part {
@@ -261,21 +269,49 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
                 n2 += P.ra2.size();
                 nb += P.rb.size();
             }
-            S1.rows.reserve(n1); S1.ends.reserve(n1); S2.rows.reserve(n2); S2.ends.reserve(n2); rb.reserve(nb);
+            R.a1_rows.reserve(n1); R.a1_ends.reserve(n1); R.a2_rows.reserve(n2); R.a2_ends.reserve(n2); rb.reserve(nb);
             for (Part &P : parts) {
-                S1.rows.insert(S1.rows.end(), P.ra1.begin(), P.ra1.end());
-                S1.ends.insert(S1.ends.end(), P.e1.begin(), P.e1.end());
-                S2.rows.insert(S2.rows.end(), P.ra2.begin(), P.ra2.end());
-                S2.ends.insert(S2.ends.end(), P.e2.begin(), P.e2.end());
+                R.a1_rows.insert(R.a1_rows.end(), P.ra1.begin(), P.ra1.end());
+                R.a1_ends.insert(R.a1_ends.end(), P.e1.begin(), P.e1.end());
+                R.a2_rows.insert(R.a2_rows.end(), P.ra2.begin(), P.ra2.end());
+                R.a2_ends.insert(R.a2_ends.end(), P.e2.begin(), P.e2.end());
                 rb.insert(rb.end(), P.rb.begin(), P.rb.end());
                 Part().ra1.swap(P.ra1);
             }
-            S1.form.assign(S1.rows.size(), 0);
-            S2.form.assign(S2.rows.size(), 0);
-            S1.gid.assign(S1.rows.size(), 0);
-            S2.gid.assign(S2.rows.size(), 0);
         }
         sublap("exact runs -> streams");
+    }
+    return "";
+}
+
+// STAGE 2: packing of the leftover rows, the mixed streams, the CSR last resort; the ordered row list of every sliced stream.
+std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, PsellRuns &R, PsellHost &out, PsellRows &W)
+{
+    W = PsellRows();
+    const int binsh = psell_bin_shift();
+    BuildClock clk;
+    auto sublap = [&](const char *w) { clk.sublap(w); };
+    BVec<uint32_t> &rows = W.rows, &run_end = W.run_end, &row_gid = W.row_gid;
+    BVec<uint8_t> &row_form = W.row_form;
+    std::vector<BVec<uint32_t>> patterns;  // transcript set (union) of every group of leftover rows
+    {
+        struct RowList {
+            BVec<uint32_t> rows, ends;
+            BVec<uint8_t> form;
+            BVec<uint32_t> gid;  // union / masked rows: index of the group's transcript set in `patterns`
+        };
+        RowList S1, S1M, S2, S2M;  // A1, A1M, A2, A2M
+        S1.rows.swap(R.a1_rows);
+        S1.ends.swap(R.a1_ends);
+        S2.rows.swap(R.a2_rows);
+        S2.ends.swap(R.a2_ends);
+        S1.form.assign(S1.rows.size(), 0);
+        S2.form.assign(S2.rows.size(), 0);
+        S1.gid.assign(S1.rows.size(), 0);
+        S2.gid.assign(S2.rows.size(), 0);
+        BVec<uint32_t> rb;
+        rb.swap(R.rb);
         // Packing of the leftover rows.  Rows are visited in the order of their first transcript (then length, then set:
         // equal sets stay neighbours); a row joins the open group while the union stays within the pass's width and the
         // group has fewer than 64 rows, a misfit is deferred once.  Two passes: unions of <= 16 over the rows of <= 16
@@ -635,7 +671,31 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     }
 
     sublap("CSR last resort + totals");
-    lap("runs / stream split");
+    // the groups' transcript sets, flattened
+    W.pat_ptr.assign(1, 0);
+    {
+        size_t tot = 0;
+        for (const auto &pt : patterns) tot += pt.size();
+        W.pat_col.reserve(tot);
+        W.pat_ptr.reserve(patterns.size() + 1);
+        for (const auto &pt : patterns) {
+            W.pat_col.insert(W.pat_col.end(), pt.begin(), pt.end());
+            W.pat_ptr.push_back((uint32_t)W.pat_col.size());
+        }
+    }
+    clk.lap("packing / stream split");
+    return "";
+}
+
+// STAGE 3: slices and tiles.
+std::string psell_stage3(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                         const int64_t *ks, const PsellRows &W, PsellHost &out)
+{
+    BuildClock clk;
+    auto lap = [&](const char *w) { clk.lap(w); };
+    const BVec<uint32_t> &rows = W.rows, &run_end = W.run_end, &row_gid = W.row_gid;
+    const BVec<uint8_t> &row_form = W.row_form;
+    const uint32_t *pat_ptr = W.pat_ptr.data(), *pat_col = W.pat_col.data();
     // 2. greedy slices and tiles.  The three streams are cut into SEGMENTS of about a million rows (at slice
     // boundaries; every segment starts a fresh tile) which are laid out independently, on several host threads, and
     // concatenated afterwards.  The cut points depend on the data only, not on the number of threads.
@@ -728,7 +788,7 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         if (uniform_stream) {  // the slice's transcript set: its rows' common set, or their union
             const uint32_t r0 = slice_rows[0];
             if (slice_form != 0)
-                pattern = patterns[slice_gid];  // the union of the slice's GROUP (a superset of its rows' sets)
+                pattern.assign(pat_col + pat_ptr[slice_gid], pat_col + pat_ptr[slice_gid + 1]);  // the union of the slice's GROUP (a superset of its rows' sets)
             else
                 pattern.assign(col + rowptr[r0], col + rowptr[r0 + 1]);
             w = (uint32_t)pattern.size();
@@ -892,8 +952,8 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
         // the transcripts this row needs in the tile's dictionary: its own, or -- a row of a union / masked group -- the
         // whole set of its group (the slice's header lists every one of them)
         const bool grouped = uniform_stream && row_form[ri] != 0;
-        const uint32_t *cb = grouped ? patterns[row_gid[ri]].data() : col + rowptr[r];
-        const uint32_t *ce = grouped ? cb + patterns[row_gid[ri]].size() : col + rowptr[r + 1];
+        const uint32_t *cb = grouped ? pat_col + pat_ptr[row_gid[ri]] : col + rowptr[r];
+        const uint32_t *ce = grouped ? pat_col + pat_ptr[row_gid[ri] + 1] : col + rowptr[r + 1];
         for (;;) {
             uint32_t fresh = 0;
             for (const uint32_t *c = cb; c < ce; ++c) fresh += col_stamp[*c] != tile_id;
@@ -1025,6 +1085,17 @@ std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint
     for (int64_t s = 0; s < out.num_slices; ++s)
         out.slice_off[s] |= ((uint32_t)(out.slice_flags[s] & 3u) << 30) | ((uint32_t)((out.slice_flags[s] >> 2) & 1u) << PSELL_FLAG_MASKED_BIT);
     return "";
+}
+
+std::string build_psell(int64_t m, int64_t n, const uint64_t *rowptr, const uint32_t *col, const float *val,
+                        const int64_t *ks, PsellHost &out)
+{
+    PsellRuns R;
+    PsellRows W;
+    std::string err = psell_stage1(m, n, rowptr, col, val, ks, out, R);
+    if (err.empty()) err = psell_stage2(m, n, rowptr, col, val, ks, R, out, W);
+    if (err.empty()) err = psell_stage3(m, n, rowptr, col, val, ks, W, out);
+    return err;
 }
 
 }  // namespace polee
