@@ -64,6 +64,12 @@ typedef struct {
 polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
                                      const uint32_t *rowval, const float *nzval,
                                      const int64_t *ks_or_null, polee_psell_debug **out);
+/* The same layout with some of the builder's stages run on the DEVICE (csrc/psell_device.hip; bit 0: keys / sort / runs,
+ * bit 1: packing of leftover rows, bit 2: slices and tiles) and the others on the host, each continuing from the other's
+ * output.  Every mix gives the bytes polee_debug_psell_build gives (tests/test_gpu_device_build.py). */
+polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                            const uint32_t *rowval, const float *nzval, const int64_t *ks_or_null,
+                                            int device_stages, polee_psell_debug **out);
 polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *view);
 void polee_debug_psell_free(polee_psell_debug *p);
 

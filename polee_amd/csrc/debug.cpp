@@ -1,9 +1,11 @@
 // Host-only introspection entry points (include/polee_hip_debug.h).
 #include <algorithm>
+#include <memory>
 
 #include "../../include/polee_hip_debug.h"
 #include "loglik_internal.hpp"
 #include "ptt_internal.hpp"
+#include "psell_device.hpp"
 
 namespace polee {
 std::string csc_to_csr(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
@@ -55,6 +57,60 @@ polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, i
                     "likelihood matrix: %s", err.c_str());
     }
     *out = p;
+    return POLEE_OK;
+}
+
+// The layout with some of the builder's stages run on the device (bit 0: stage 1, bit 1: stage 2, bit 2: stage 3) and the rest
+// on the host, each continuing from the other's output: every mix must give the bytes polee_debug_psell_build gives.
+polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                            const uint32_t *rowval, const float *nzval, const int64_t *ks, int device_stages,
+                                            polee_psell_debug **out)
+{
+    if (!ctx || !colptr || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
+    POLEE_TRY(use_device(ctx));
+    BVec<uint64_t> rowptr;
+    RawVec<uint32_t> col;
+    RawVec<float> val;
+    std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
+    if (!err.empty()) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());
+    std::unique_ptr<polee_psell_debug> p(new polee_psell_debug());
+    auto bad = [&](const std::string &e) {
+        return fail(ctx, e.find("more than") != std::string::npos ? POLEE_ERR_UNSUPPORTED : POLEE_ERR_BAD_ARG, "likelihood matrix: %s", e.c_str());
+    };
+    DevBuf<uint64_t> d_rowptr;
+    DevBuf<uint32_t> d_col;
+    DevBuf<float> d_val;
+    DevBuf<int64_t> d_ks;
+    POLEE_TRY(d_rowptr.upload(ctx, rowptr.data(), rowptr.size()));
+    POLEE_TRY(d_col.upload(ctx, col.data(), col.size()));
+    POLEE_TRY(d_val.upload(ctx, val.data(), val.size()));
+    if (ks) POLEE_TRY(d_ks.upload(ctx, ks, (size_t)m));
+    PsellDevIn X;
+    X.rowptr = d_rowptr.p; X.col = d_col.p; X.val = d_val.p; X.ks = ks ? d_ks.p : nullptr; X.m = m; X.n = n;
+    PsellRuns R;
+    PsellRows W;
+    if ((err = psell_stage1(m, n, rowptr.data(), col.data(), val.data(), ks, p->h, R)) != "") return bad(err);
+    if ((err = psell_stage2(m, n, rowptr.data(), col.data(), val.data(), ks, R, p->h, W)) != "") return bad(err);
+    if (device_stages & 4) {
+        DevBuf<uint32_t> d_rows, d_end, d_gid, d_pp, d_pc;
+        DevBuf<uint8_t> d_form;
+        POLEE_TRY(d_rows.upload(ctx, W.rows.data(), W.rows.size()));
+        POLEE_TRY(d_end.upload(ctx, W.run_end.data(), W.run_end.size()));
+        POLEE_TRY(d_gid.upload(ctx, W.row_gid.data(), W.row_gid.size()));
+        POLEE_TRY(d_form.upload(ctx, W.row_form.data(), W.row_form.size()));
+        POLEE_TRY(d_pp.upload(ctx, W.pat_ptr.data(), W.pat_ptr.size()));
+        POLEE_TRY(d_pc.upload(ctx, W.pat_col.data(), W.pat_col.size()));
+        PsellDevRows DW;
+        DW.rows = d_rows.p; DW.run_end = d_end.p; DW.gid = d_gid.p; DW.form = d_form.p; DW.pat_ptr = d_pp.p; DW.pat_col = d_pc.p;
+        DW.Nr = W.rows.size();
+        const size_t b[7] = {0, (size_t)p->h.rows_a1, (size_t)p->h.rows_a1m, (size_t)p->h.rows_a2, (size_t)p->h.rows_a, (size_t)p->h.rows_s, W.rows.size()};
+        for (int q = 0; q < 7; ++q) DW.bounds[q] = b[q];
+        PsellDevOut D;
+        POLEE_TRY(psell_device_stage3(ctx, X, DW, p->h, D, true));
+    } else if ((err = psell_stage3(m, n, rowptr.data(), col.data(), val.data(), ks, W, p->h)) != "") {
+        return bad(err);
+    }
+    *out = p.release();
     return POLEE_OK;
 }
 

@@ -1,0 +1,856 @@
+// Device-side construction of the PSELL layout (loglik_internal.hpp): the stages of psell_build.cpp as HIP kernels, byte for
+// byte the same layout -- the host builder is the checker (polee_debug_psell_build_device runs any mix of host and device
+// stages and hands the result to the same debug view; tests/test_gpu_device_build.py).
+// Plays the role of `Xt = SparseMatrixCSC(transpose(X))` in the reference (src/likelihood-approximation.jl:406-408).
+//
+// What is sequential in the host builder stays sequential here, one WAVE per independent piece (a segment of a stream in
+// stage 3), with the 64 lanes spread over the transcripts of a set; everything per row, per slice and per byte is parallel.
+#include <cstring>
+#include <cstdio>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "loglik_internal.hpp"
+#include "psell_device.hpp"
+
+namespace polee {
+namespace {
+
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ inline uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
+template <typename T>
+__device__ inline T bcast0(T v) { return __shfl(v, 0); }
+
+struct SegDesc {
+    uint32_t ra, rb, stream, pad;
+};
+struct SegAux {
+    uint32_t st0, st1;  // stretches (maximal runs of rows under one transcript set) of the segment
+    uint32_t sl0;       // uniform streams: index of its first slice in the numbering of the slice ends
+    uint32_t tbase;     // scratch: tiles
+    uint64_t dbase;     // scratch: dictionary entries
+};
+struct SegOut {
+    uint32_t ntiles, nslices, ndict, pad;
+};
+
+struct S3In {
+    const uint64_t *rowptr;
+    const uint32_t *col;
+    const float *val;
+    const int64_t *ks;
+    const uint32_t *rows, *run_end, *gid;
+    const uint8_t *form;
+    const uint32_t *pat_ptr, *pat_col;
+    uint32_t Nr, n;
+    uint32_t bounds[7];  // rows of stream st: [bounds[st], bounds[st + 1])
+};
+
+__device__ inline int stream_of_row(const S3In &A, uint32_t ri)
+{
+    int st = 0;
+    while (st < 5 && ri >= A.bounds[st + 1]) ++st;
+    return st;
+}
+
+// per ordered row: its length; head = it starts a new STRETCH (a segment or stream starts, or its transcript set -- its own, or
+// its group's union -- differs from the previous row's); endflag = a slice of a uniform stream ends after it
+__global__ void s3_rowinfo_kernel(S3In A, uint32_t *rlen, uint32_t *head, uint32_t *endflag)
+{
+    const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= A.Nr) return;
+    const uint32_t r = A.rows[ri];
+    const uint64_t b = A.rowptr[r];
+    const uint32_t len = (uint32_t)(A.rowptr[r + 1] - b);
+    rlen[ri] = len;
+    const int st = stream_of_row(A, ri);
+    const bool uniform = st <= PSELL_A2M;
+    endflag[ri] = uniform && A.run_end[ri] != 0 ? 1u : 0u;
+    uint32_t h = 1;
+    if (uniform && ri > A.bounds[st]) {
+        const bool g = A.form[ri] != 0, gp = A.form[ri - 1] != 0;
+        if (g == gp) {
+            if (g) {
+                h = A.gid[ri] != A.gid[ri - 1];
+            } else {
+                const uint32_t rp = A.rows[ri - 1];
+                const uint64_t bp = A.rowptr[rp];
+                bool same = (uint32_t)(A.rowptr[rp + 1] - bp) == len;
+                for (uint32_t k = 0; same && k < len; ++k) same = A.col[b + k] == A.col[bp + k];
+                h = same ? 0u : 1u;
+            }
+        }
+    }
+    head[ri] = h;
+}
+
+// the streams cut into segments (psell_build.cpp, stage 3: "SEGMENTS of about a million rows", same cut points)
+__global__ void s3_segments_kernel(S3In A, uint32_t seg_rows, SegDesc *segs, uint32_t *nseg, uint32_t *head, uint32_t max_segs)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t k = 0;
+    for (int st = 0; st < 6; ++st) {
+        uint64_t a = A.bounds[st];
+        const uint64_t end = A.bounds[st + 1];
+        while (a < end) {
+            uint64_t e = a + seg_rows < end ? a + seg_rows : end;
+            if (e < end) {
+                if (st != PSELL_B && st != PSELL_BN) {
+                    while (e < end && !A.run_end[e - 1]) ++e;
+                } else {
+                    const uint64_t tile_rows = (uint64_t)PSELL_LANES * PSELL_TILE_SLICES_B;
+                    const uint64_t e2 = a + ((e - a + tile_rows - 1) / tile_rows) * tile_rows;
+                    e = e2 < end ? e2 : end;
+                }
+            }
+            if (k < max_segs) segs[k] = SegDesc{(uint32_t)a, (uint32_t)e, (uint32_t)st, 0u};
+            head[a] = 1;
+            ++k;
+            a = e;
+        }
+    }
+    *nseg = k;
+}
+
+__global__ void s3_scatter_kernel(uint32_t Nr, const uint32_t *head, const uint32_t *hscan, const uint32_t *endflag,
+                                  const uint32_t *escan, uint32_t *st_start, uint32_t *endpos)
+{
+    const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri > Nr) return;
+    if (ri == Nr) {
+        st_start[hscan[Nr]] = Nr;
+        return;
+    }
+    if (head[ri]) st_start[hscan[ri]] = ri;
+    if (endflag[ri]) endpos[escan[ri]] = ri;
+}
+
+// per segment: its stretches, its first slice, and room in the scratch arrays (tiles: at most one per slice / per row;
+// dictionary entries: at most 32 + padding per (stretch, tile) pair in the uniform streams, the rows' own entries + padding in
+// the mixed ones)
+__global__ void s3_segaux_kernel(S3In A, const SegDesc *segs, uint32_t nseg, const uint32_t *hscan, const uint32_t *escan,
+                                 const uint64_t *lenps, SegAux *aux, uint64_t *totals)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t tb = 0, db = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+        const SegDesc s = segs[k];
+        SegAux x;
+        x.st0 = hscan[s.ra];
+        x.st1 = hscan[s.rb];
+        x.sl0 = escan[s.ra];
+        x.tbase = (uint32_t)tb;
+        x.dbase = db;
+        aux[k] = x;
+        if (s.stream <= PSELL_A2M) {
+            const uint64_t nsl = escan[s.rb] - escan[s.ra];
+            tb += nsl;
+            db += (uint64_t)(PSELL_WIDE_MAX + PSELL_DICT_ALIGN) * (nsl + (x.st1 - x.st0));
+        } else {
+            tb += s.rb - s.ra;
+            db += (lenps[s.rb] - lenps[s.ra]) + (uint64_t)PSELL_DICT_ALIGN * (s.rb - s.ra);
+        }
+    }
+    totals[0] = tb;
+    totals[1] = db;
+}
+
+struct S3Seq {
+    S3In A;
+    const SegDesc *segs;
+    const SegAux *aux;
+    uint32_t nseg;
+    const uint32_t *rlen, *st_start, *escan;
+    uint32_t *stamps;  // [waves][n]: the tile in which a transcript was last registered (the tile ids of a wave never repeat)
+    uint32_t *t_s0, *t_cols, *t_dstart;
+    uint32_t *dict_s;
+    uint32_t *srec_ri, *srec_n;  // mixed streams: first row and number of rows of every slice, at (ra - bounds[BN]) + slice
+    SegOut *outs;
+    uint32_t *next_seg;
+    uint32_t caps[6];
+};
+
+// TILES AND DICTIONARIES: the one sequential part of stage 3 (psell_build.cpp, emit_segment: a row joins the current tile
+// while the tile's dictionary holds its transcripts or has room for them; a tile closes on its slice count).  One wave per
+// segment.  In the uniform streams the slices are known beforehand (they end where run_end says), and all rows of a stretch
+// ask the same question of the dictionary -- so the wave steps from stretch to stretch, not from row to row.
+__global__ __launch_bounds__(64) void s3_tiles_kernel(S3Seq P)
+{
+    const uint32_t lane = lane_id();
+    uint32_t *stamp = P.stamps + (size_t)blockIdx.x * P.A.n;
+    uint32_t tile_id = 1;
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(P.next_seg, 1u);
+        k = bcast0(k);
+        if (k >= P.nseg) break;
+        const SegDesc seg = P.segs[k];
+        const SegAux aux = P.aux[k];
+        const int st = (int)seg.stream;
+        const uint32_t cap = P.caps[st];
+        uint32_t ntile = 0, nsl = 0, dict_n = 0, tile_cols = 0, pending = 0, tile_d0 = 0, tile_s0 = 0;
+        uint32_t *dict_out = P.dict_s + aux.dbase;
+        auto close_tile = [&]() {
+            if (!pending) return;
+            if (lane == 0) {
+                P.t_s0[aux.tbase + ntile] = tile_s0;
+                P.t_cols[aux.tbase + ntile] = tile_cols;
+                P.t_dstart[aux.tbase + ntile] = tile_d0;
+            }
+            ++ntile;
+            dict_n = (dict_n + PSELL_DICT_ALIGN - 1) & ~(uint32_t)(PSELL_DICT_ALIGN - 1);
+            tile_d0 = dict_n;
+            tile_s0 = nsl;
+            ++tile_id;
+            tile_cols = 0;
+            pending = 0;
+        };
+        if (st <= PSELL_A2M) {
+            for (uint32_t s = aux.st0; s < aux.st1; ++s) {
+                const uint32_t a = P.st_start[s], b = P.st_start[s + 1];
+                uint32_t j = P.escan[a];
+                const uint32_t j1 = P.escan[b];
+                const uint32_t *set;
+                uint32_t w;
+                if (P.A.form[a]) {
+                    const uint32_t g = P.A.gid[a];
+                    set = P.A.pat_col + P.A.pat_ptr[g];
+                    w = P.A.pat_ptr[g + 1] - P.A.pat_ptr[g];
+                } else {
+                    set = P.A.col + P.A.rowptr[P.A.rows[a]];
+                    w = P.rlen[a];
+                }
+                const uint32_t c = lane < w ? set[lane] : 0u;  // (w <= 32 in the uniform streams)
+                while (j < j1) {
+                    const bool fr = lane < w && stamp[c] != tile_id;
+                    const uint64_t bal = __ballot(fr);
+                    const uint32_t fresh = (uint32_t)__popcll(bal);
+                    if (!(tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && pending == 0))) {
+                        close_tile();
+                        continue;
+                    }
+                    if (fr) {
+                        stamp[c] = tile_id;
+                        dict_out[dict_n + (uint32_t)__popcll(bal & lanes_below())] = c;
+                    }
+                    dict_n += fresh;
+                    tile_cols += fresh;
+                    const uint32_t take = min(j1 - j, cap - pending);
+                    pending += take;
+                    nsl += take;
+                    j += take;
+                    if (pending >= cap) close_tile();
+                    __threadfence_block();
+                }
+            }
+            close_tile();
+        } else {
+            const uint32_t sbase = seg.ra - P.A.bounds[PSELL_BN];
+            uint32_t in_slice = 0, slice_start = seg.ra;
+            auto close_slice = [&]() {
+                if (!in_slice) return;
+                if (lane == 0) {
+                    P.srec_ri[sbase + nsl] = slice_start;
+                    P.srec_n[sbase + nsl] = in_slice;
+                }
+                ++nsl;
+                ++pending;
+                in_slice = 0;
+            };
+            for (uint32_t ri = seg.ra; ri < seg.rb; ++ri) {
+                const uint32_t *set = P.A.col + P.A.rowptr[P.A.rows[ri]];
+                const uint32_t w = P.rlen[ri];
+                for (;;) {
+                    uint32_t fresh = 0;
+                    for (uint32_t base = 0; base < w; base += 64) {
+                        const uint32_t i = base + lane;
+                        fresh += (uint32_t)__popcll(__ballot(i < w && stamp[set[i < w ? i : 0]] != tile_id));
+                    }
+                    if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && in_slice == 0 && pending == 0)) break;
+                    close_slice();
+                    close_tile();
+                }
+                for (uint32_t base = 0; base < w; base += 64) {
+                    const uint32_t i = base + lane;
+                    const uint32_t c = i < w ? set[i] : 0u;
+                    const bool fr = i < w && stamp[c] != tile_id;
+                    const uint64_t bal = __ballot(fr);
+                    if (fr) {
+                        stamp[c] = tile_id;
+                        dict_out[dict_n + (uint32_t)__popcll(bal & lanes_below())] = c;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(bal);
+                    dict_n += cnt;
+                    tile_cols += cnt;
+                }
+                __threadfence_block();
+                if (in_slice == 0) slice_start = ri;
+                ++in_slice;
+                if (in_slice == (uint32_t)PSELL_LANES) {
+                    close_slice();
+                    if (pending >= cap) close_tile();
+                }
+            }
+            close_slice();
+            close_tile();
+        }
+        if (lane == 0) P.outs[k] = SegOut{ntile, nsl, dict_n, 0u};
+    }
+}
+
+struct SegFinal {
+    uint32_t tile_base, slice_base, dict_base, pad;
+};
+
+// the tiles of every segment into the final numbering; the dictionaries copied (padding entries stay 0)
+__global__ void s3_tiles_final_kernel(const SegDesc *segs, const SegAux *aux, const SegOut *outs, const SegFinal *fin, uint32_t nseg,
+                                      const uint32_t *t_s0, const uint32_t *t_cols, const uint32_t *t_dstart, const uint32_t *dict_s,
+                                      uint32_t *tile_slice, uint32_t *tile_dict, uint32_t *tile_cols, uint32_t *tile_seg, uint32_t *dict)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= nseg) return;
+    const SegAux x = aux[k];
+    const SegFinal f = fin[k];
+    const uint32_t nt = outs[k].ntiles;
+    for (uint32_t t = threadIdx.x >> 6; t < nt; t += blockDim.x >> 6) {  // one wave per tile
+        const uint32_t d0 = t_dstart[x.tbase + t], L = t_cols[x.tbase + t];
+        if (lane_id() == 0) {
+            tile_slice[f.tile_base + t] = f.slice_base + t_s0[x.tbase + t];
+            tile_dict[f.tile_base + t] = f.dict_base + d0;
+            tile_cols[f.tile_base + t] = L;
+            tile_seg[f.tile_base + t] = k;
+        }
+        for (uint32_t l = lane_id(); l < L; l += 64) dict[f.dict_base + d0 + l] = dict_s[x.dbase + d0 + l];
+    }
+}
+
+struct S3Size {
+    S3In A;
+    const SegDesc *segs;
+    const SegAux *aux;
+    const SegFinal *fin;
+    const uint32_t *rlen, *endpos, *srec_ri, *srec_n;
+    const uint32_t *tile_slice, *tile_seg;
+    uint32_t num_tiles;
+    int has_ks;
+    uint32_t *sl_ri, *sl_n, *sl_units, *sl_tile, *sl_long;
+    uint8_t *slice_flags, *slice_w;
+    unsigned long long *stats;  // [3][8] rows, nnz, bytes per stream; [24] padded_nnz
+};
+
+struct SliceSet {
+    const uint32_t *set;
+    uint32_t w;
+};
+__device__ inline void slice_rows_of(const S3Size &P, const SegDesc &seg, const SegAux &x, const SegFinal &f, uint32_t s, uint32_t &rs, uint32_t &nr)
+{
+    const uint32_t ls = s - f.slice_base;
+    if (seg.stream <= PSELL_A2M) {
+        const uint32_t j = x.sl0 + ls;
+        rs = j == 0 ? 0u : P.endpos[j - 1] + 1u;
+        nr = P.endpos[j] + 1u - rs;
+    } else {
+        const uint32_t sb = seg.ra - P.A.bounds[PSELL_BN];
+        rs = P.srec_ri[sb + ls];
+        nr = P.srec_n[sb + ls];
+    }
+}
+__device__ inline SliceSet uniform_set(const S3In &A, const uint32_t *rlen, uint32_t rs)
+{
+    SliceSet q;
+    if (A.form[rs]) {
+        const uint32_t g = A.gid[rs];
+        q.set = A.pat_col + A.pat_ptr[g];
+        q.w = A.pat_ptr[g + 1] - A.pat_ptr[g];
+    } else {
+        q.set = A.col + A.rowptr[A.rows[rs]];
+        q.w = rlen[rs];
+    }
+    return q;
+}
+
+// per slice (one wave per tile, a lane per slice): its rows, width, bytes and flags
+__global__ __launch_bounds__(64) void s3_size_kernel(S3Size P)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= P.num_tiles) return;
+    const uint32_t k = P.tile_seg[t];
+    const SegDesc seg = P.segs[k];
+    const SegAux x = P.aux[k];
+    const SegFinal f = P.fin[k];
+    const int st = (int)seg.stream;
+    const bool uniform = st <= PSELL_A2M;
+    const uint32_t s0 = P.tile_slice[t], s1 = P.tile_slice[t + 1];
+    for (uint32_t s = s0 + lane_id(); s < s1; s += 64) {
+        uint32_t rs, nr;
+        slice_rows_of(P, seg, x, f, s, rs, nr);
+        uint32_t longest = 0;
+        unsigned long long nnz = 0;
+        for (uint32_t q = 0; q < nr; ++q) {
+            const uint32_t l = P.rlen[rs + q];
+            longest = max(longest, l);
+            nnz += l;
+        }
+        uint32_t w = longest, form = 0;
+        uint8_t flags = 0;
+        if (uniform) {
+            form = P.A.form[rs];
+            const SliceSet q = uniform_set(P.A, P.rlen, rs);
+            w = q.w;
+            flags |= 1;
+            if (s > s0) {  // the same set as the previous slice of this tile?
+                uint32_t prs, pnr;
+                slice_rows_of(P, seg, x, f, s - 1, prs, pnr);
+                const SliceSet p = uniform_set(P.A, P.rlen, prs);
+                bool same = p.w == q.w;
+                for (uint32_t i = 0; same && i < q.w; ++i) same = p.set[i] == q.set[i];
+                if (same) flags |= 2;
+            }
+        } else {
+            const uint32_t r0 = P.A.rows[rs];
+            const uint64_t b0 = P.A.rowptr[r0];
+            const uint32_t len0 = P.rlen[rs];
+            bool uni = true;
+            for (uint32_t q = 1; uni && q < nr; ++q) {
+                const uint64_t b = P.A.rowptr[P.A.rows[rs + q]];
+                uni = P.rlen[rs + q] == len0;
+                for (uint32_t i = 0; uni && i < len0; ++i) uni = P.A.col[b + i] == P.A.col[b0 + i];
+            }
+            if (uni) flags |= 1;
+        }
+        const bool masked = st == PSELL_A1M || st == PSELL_A2M || (st == PSELL_A1 && form == 2);
+        if (masked) flags |= 4;
+        uint32_t bytes, stored = w;
+        if (masked) {
+            stored = longest;
+            bytes = 256u * (st == PSELL_A2M ? 2u : 1u) + longest * 256u + (P.has_ks ? 256u : 0u);
+        } else if (uniform) {
+            bytes = 256u + w * 256u + (P.has_ks ? 256u : 0u);
+        } else {
+            bytes = ((w * 384u + 255u) & ~255u) + (P.has_ks && st == PSELL_BN ? 256u : 0u);
+        }
+        P.sl_ri[s] = rs;
+        P.sl_n[s] = nr;
+        P.sl_units[s] = bytes / 128u;
+        P.sl_tile[s] = t;
+        P.sl_long[s] = longest;
+        P.slice_flags[s] = flags;
+        P.slice_w[s] = (uint8_t)min(w, 255u);
+        const int ss = masked && st == PSELL_A1 ? PSELL_A1M : st;
+        atomicAdd(&P.stats[ss], (unsigned long long)nr);
+        atomicAdd(&P.stats[8 + ss], nnz);
+        atomicAdd(&P.stats[16 + ss], (unsigned long long)bytes);
+        atomicAdd(&P.stats[24], (unsigned long long)stored * 64ull);
+    }
+}
+
+struct S3Emit {
+    S3In A;
+    const SegDesc *segs;
+    const uint32_t *tile_seg, *tile_dict, *tile_cols, *dict;
+    const uint32_t *sl_ri, *sl_n, *sl_tile, *sl_long, *slice_off;
+    uint32_t num_slices;
+    uint8_t *data;
+    uint32_t *row_order;  // or null
+    float *slice_ks;      // or null
+};
+
+__device__ inline uint32_t local_id(const uint32_t *sdict, uint32_t L, uint32_t c)
+{
+    uint32_t i = 0;
+    while (i < L && sdict[i] != c) ++i;
+    return i;
+}
+
+// THE BYTES: one wave per slice, a lane per fragment (psell_build.cpp, emit_slice; `data` arrives zeroed)
+__global__ __launch_bounds__(64) void s3_emit_kernel(S3Emit E)
+{
+    __shared__ uint32_t sdict[PSELL_MAX_TILE_COLS];
+    __shared__ uint32_t spat[PSELL_WIDE_MAX];
+    __shared__ uint32_t spat_local[PSELL_WIDE_MAX];
+    const uint32_t s = blockIdx.x;
+    if (s >= E.num_slices) return;
+    const uint32_t lane = lane_id();
+    const uint32_t t = E.sl_tile[s];
+    const int st = (int)E.segs[E.tile_seg[t]].stream;
+    const uint32_t d0 = E.tile_dict[t], L = E.tile_cols[t];
+    for (uint32_t i = lane; i < L && i < (uint32_t)PSELL_MAX_TILE_COLS; i += 64) sdict[i] = E.dict[d0 + i];
+    const uint32_t rs = E.sl_ri[s], nr = E.sl_n[s], longest = E.sl_long[s];
+    const bool uniform = st <= PSELL_A2M;
+    const uint32_t form = uniform ? E.A.form[rs] : 0u;
+    const bool masked = st == PSELL_A1M || st == PSELL_A2M || (st == PSELL_A1 && form == 2);
+    uint8_t *base = E.data + (size_t)E.slice_off[s] * 128u;
+    const bool valid = lane < nr;
+    const uint32_t r = valid ? E.A.rows[rs + lane] : 0u;
+    const uint64_t b = valid ? E.A.rowptr[r] : 0ull;
+    const uint32_t len = valid ? (uint32_t)(E.A.rowptr[r + 1] - b) : 0u;
+    uint32_t w = longest;
+    if (uniform) {
+        const uint32_t *set;
+        if (form) {
+            const uint32_t g = E.A.gid[rs];
+            set = E.A.pat_col + E.A.pat_ptr[g];
+            w = E.A.pat_ptr[g + 1] - E.A.pat_ptr[g];
+        } else {
+            set = E.A.col + E.A.rowptr[E.A.rows[rs]];
+            w = (uint32_t)(E.A.rowptr[E.A.rows[rs] + 1] - E.A.rowptr[E.A.rows[rs]]);
+        }
+        __syncthreads();
+        if (lane < w) {
+            spat[lane] = set[lane];
+            spat_local[lane] = local_id(sdict, L, set[lane]);
+        }
+    }
+    __syncthreads();
+    const float ksv = E.A.ks && valid ? (float)E.A.ks[r] : 0.0f;
+    if (masked) {
+        const uint32_t hrows = st == PSELL_A2M ? 2u : 1u;
+        uint32_t *hw = reinterpret_cast<uint32_t *>(base);
+        float *vals = reinterpret_cast<float *>(base + 256u * hrows);
+        uint32_t mk = 0, tpos = 0;
+        for (uint32_t k = 0; k < len; ++k) {
+            const uint32_t c = E.A.col[b + k];
+            while (spat[tpos] != c) ++tpos;
+            mk |= 1u << tpos;
+            vals[(size_t)k * 64 + lane] = E.A.val[b + k];
+        }
+        for (uint32_t h = 0; h < hrows; ++h) {
+            uint32_t word = 0;
+            if (lane < 16) {
+                const uint32_t tt = 16u * h + lane;
+                word = (uint32_t)(tt < w ? spat_local[tt] : (uint32_t)PSELL_NO_COL) << 16;
+            }
+            if (valid) word |= h == 0 ? (mk & 0xffffu) : (mk >> 16);
+            hw[h * 64 + lane] = word;
+        }
+        if (E.A.ks && valid) reinterpret_cast<float *>(base + 256u * hrows + (size_t)longest * 256u)[lane] = ksv;
+    } else if (uniform) {
+        uint16_t *hdr = reinterpret_cast<uint16_t *>(base);
+        float *vals = reinterpret_cast<float *>(base + 256);
+        if (lane < w) hdr[lane] = (uint16_t)spat_local[lane];
+        if (valid) {
+            if (form == 0) {
+                for (uint32_t tt = 0; tt < w; ++tt) vals[(size_t)tt * 64 + psell_row_pos(st, tt, lane)] = E.A.val[b + tt];
+            } else {
+                uint32_t tpos = 0;
+                for (uint32_t k = 0; k < len; ++k) {
+                    const uint32_t c = E.A.col[b + k];
+                    while (spat[tpos] != c) ++tpos;
+                    vals[(size_t)tpos * 64 + psell_row_pos(st, tpos, lane)] = E.A.val[b + k];
+                }
+            }
+            if (E.A.ks) reinterpret_cast<float *>(base + 256 + (size_t)w * 256u)[lane] = ksv;
+        }
+    } else {
+        const size_t body = ((size_t)w * 384 + 255) & ~(size_t)255;
+        float *vals = reinterpret_cast<float *>(base);
+        uint16_t *lcols = reinterpret_cast<uint16_t *>(base + (size_t)w * 256);
+        if (valid) {
+            uint16_t last = 0;
+            for (uint32_t tt = 0; tt < w; ++tt) {
+                if (tt < len) {
+                    vals[(size_t)tt * 64 + lane] = E.A.val[b + tt];
+                    last = (uint16_t)local_id(sdict, L, E.A.col[b + tt]);
+                }
+                lcols[(size_t)tt * 64 + lane] = last;
+            }
+            if (E.A.ks && st == PSELL_BN) reinterpret_cast<float *>(base + body)[lane] = ksv;
+        }
+    }
+    if (E.row_order) E.row_order[(size_t)s * 64 + lane] = valid ? r : 0xffffffffu;
+    if (E.slice_ks) E.slice_ks[(size_t)s * 64 + lane] = ksv;
+}
+
+__global__ void s3_flags_kernel(uint32_t S, const uint8_t *slice_flags, uint32_t *slice_off)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    slice_off[s] |= ((uint32_t)(slice_flags[s] & 3u) << 30) | ((uint32_t)((slice_flags[s] >> 2) & 1u) << PSELL_FLAG_MASKED_BIT);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+struct Scratch {  // rocPRIM's temporary storage, grown on demand
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~Scratch()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t need(size_t b)
+    {
+        if (b <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+};
+
+template <typename In, typename Out, typename T>
+hipError_t exclusive_sum(Scratch &tmp, In in, Out out, T init, size_t count, hipStream_t stream)
+{
+    size_t bytes = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, init, count, rocprim::plus<T>(), stream);
+    if (e != hipSuccess) return e;
+    if ((e = tmp.need(bytes)) != hipSuccess) return e;
+    return rocprim::exclusive_scan(tmp.p, bytes, in, out, init, count, rocprim::plus<T>(), stream);
+}
+
+struct ToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+
+}  // namespace
+
+#define PD_HIP(expr) POLEE_HIP_TRY(ctx, expr)
+
+polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
+                                 bool want_debug)
+{
+    hipStream_t stream = ctx->stream;
+    const uint32_t Nr = (uint32_t)W.Nr;
+    out.rows_a1 = (int64_t)W.bounds[1];
+    out.rows_a1m = (int64_t)W.bounds[2];
+    out.rows_a2 = (int64_t)W.bounds[3];
+    out.rows_a = (int64_t)W.bounds[4];
+    out.rows_s = (int64_t)W.bounds[5];
+    out.slice_off.assign(1, 0);
+    out.tile_slice.assign(1, 0);
+    out.tile_dict.assign(1, 0);
+    if (Nr == 0) {
+        POLEE_TRY(D.data.alloc(ctx, 2048));
+        PD_HIP(hipMemsetAsync(D.data.p, 0, 2048, stream));
+        D.data_bytes = 0;
+        return POLEE_OK;
+    }
+    S3In A;
+    A.rowptr = X.rowptr; A.col = X.col; A.val = X.val; A.ks = X.ks;
+    A.rows = W.rows; A.run_end = W.run_end; A.gid = W.gid; A.form = W.form; A.pat_ptr = W.pat_ptr; A.pat_col = W.pat_col;
+    A.Nr = Nr;
+    A.n = (uint32_t)X.n;
+    for (int q = 0; q < 7; ++q) A.bounds[q] = (uint32_t)W.bounds[q];
+    static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
+    const uint32_t seg_rows = (uint32_t)(seg_env >= 64 ? seg_env : (size_t)1 << 18);
+    const uint32_t max_segs = Nr / seg_rows + 8;
+    Scratch tmp;
+    DevBuf<uint32_t> rlen, head, endflag, hscan, escan, st_start, endpos, nseg_d;
+    DevBuf<uint64_t> lenps, totals;
+    DevBuf<SegDesc> segs;
+    DevBuf<SegAux> aux;
+    POLEE_TRY(rlen.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(head.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(endflag.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(hscan.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(escan.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(lenps.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(segs.alloc(ctx, max_segs));
+    POLEE_TRY(aux.alloc(ctx, max_segs));
+    POLEE_TRY(nseg_d.alloc(ctx, 2));
+    POLEE_TRY(totals.alloc(ctx, 2));
+    PD_HIP(hipMemsetAsync(rlen.p + Nr, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(head.p + Nr, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(endflag.p + Nr, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(nseg_d.p, 0, 8, stream));
+    const unsigned TB = 256;
+    hipLaunchKernelGGL(s3_rowinfo_kernel, dim3((Nr + TB - 1) / TB), dim3(TB), 0, stream, A, rlen.p, head.p, endflag.p);
+    POLEE_KERNEL_CHECK(ctx);
+    hipLaunchKernelGGL(s3_segments_kernel, dim3(1), dim3(1), 0, stream, A, seg_rows, segs.p, nseg_d.p, head.p, max_segs);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, head.p, hscan.p, 0u, (size_t)Nr + 1, stream));
+    PD_HIP(exclusive_sum(tmp, endflag.p, escan.p, 0u, (size_t)Nr + 1, stream));
+    PD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(rlen.p, ToU64()), lenps.p, (uint64_t)0, (size_t)Nr + 1, stream));
+    uint32_t nseg = 0, nstretch = 0, nends = 0;
+    PD_HIP(hipMemcpyAsync(&nseg, nseg_d.p, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&nstretch, hscan.p + Nr, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&nends, escan.p + Nr, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (nseg > max_segs) return fail(ctx, POLEE_ERR_HIP, "device layout build: %u segments, room for %u", nseg, max_segs);
+    POLEE_TRY(st_start.alloc(ctx, (size_t)nstretch + 1));
+    POLEE_TRY(endpos.alloc(ctx, (size_t)nends + 1));
+    hipLaunchKernelGGL(s3_scatter_kernel, dim3((Nr + 1 + TB - 1) / TB), dim3(TB), 0, stream, Nr, head.p, hscan.p, endflag.p, escan.p,
+                       st_start.p, endpos.p);
+    POLEE_KERNEL_CHECK(ctx);
+    hipLaunchKernelGGL(s3_segaux_kernel, dim3(1), dim3(1), 0, stream, A, segs.p, nseg, hscan.p, escan.p, lenps.p, aux.p, totals.p);
+    POLEE_KERNEL_CHECK(ctx);
+    std::vector<SegDesc> h_segs(nseg);
+    std::vector<SegAux> h_aux(nseg);
+    uint64_t h_tot[2] = {0, 0};
+    PD_HIP(hipMemcpyAsync(h_segs.data(), segs.p, sizeof(SegDesc) * nseg, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(h_aux.data(), aux.p, sizeof(SegAux) * nseg, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (h_tot[0] >= (1ull << 32)) return fail(ctx, POLEE_ERR_UNSUPPORTED, "device layout build: too many tiles");
+
+    // ---- tiles and dictionaries
+    const uint32_t nwaves = std::min<uint32_t>(nseg, (uint32_t)std::max(1, 2 * ctx->num_cus));
+    const uint32_t mixed_rows = (uint32_t)(W.bounds[6] - W.bounds[4]);
+    DevBuf<uint32_t> stamps, t_s0, t_cols, t_dstart, dict_s, srec_ri, srec_n;
+    DevBuf<SegOut> outs;
+    POLEE_TRY(stamps.alloc(ctx, (size_t)nwaves * A.n));
+    POLEE_TRY(t_s0.alloc(ctx, (size_t)h_tot[0] + 1));
+    POLEE_TRY(t_cols.alloc(ctx, (size_t)h_tot[0] + 1));
+    POLEE_TRY(t_dstart.alloc(ctx, (size_t)h_tot[0] + 1));
+    POLEE_TRY(dict_s.alloc(ctx, (size_t)h_tot[1] + 1));
+    POLEE_TRY(srec_ri.alloc(ctx, (size_t)mixed_rows + 1));
+    POLEE_TRY(srec_n.alloc(ctx, (size_t)mixed_rows + 1));
+    POLEE_TRY(outs.alloc(ctx, nseg));
+    PD_HIP(hipMemsetAsync(stamps.p, 0, (size_t)nwaves * A.n * 4, stream));
+    PD_HIP(hipMemsetAsync(nseg_d.p + 1, 0, 4, stream));
+    S3Seq Q;
+    Q.A = A; Q.segs = segs.p; Q.aux = aux.p; Q.nseg = nseg; Q.rlen = rlen.p; Q.st_start = st_start.p; Q.escan = escan.p;
+    Q.stamps = stamps.p; Q.t_s0 = t_s0.p; Q.t_cols = t_cols.p; Q.t_dstart = t_dstart.p; Q.dict_s = dict_s.p;
+    Q.srec_ri = srec_ri.p; Q.srec_n = srec_n.p; Q.outs = outs.p; Q.next_seg = nseg_d.p + 1;
+    {
+        static const int a1cap = getenv("POLEE_TILE_A1") ? atoi(getenv("POLEE_TILE_A1")) : PSELL_TILE_SLICES_A1;
+        static const int a2cap = getenv("POLEE_TILE_A2") ? atoi(getenv("POLEE_TILE_A2")) : PSELL_TILE_SLICES_A2;
+        static const int a2mcap = getenv("POLEE_TILE_A2M") ? std::min(atoi(getenv("POLEE_TILE_A2M")), 126) : PSELL_TILE_SLICES_A2M;
+        Q.caps[PSELL_A1] = Q.caps[PSELL_A1M] = (uint32_t)std::min(a1cap, 252);
+        Q.caps[PSELL_A2] = (uint32_t)std::min(a2cap, 126);
+        Q.caps[PSELL_A2M] = (uint32_t)a2mcap;
+        Q.caps[PSELL_BN] = (uint32_t)PSELL_TILE_SLICES_BN;
+        Q.caps[PSELL_B] = (uint32_t)PSELL_TILE_SLICES_B;
+    }
+    hipLaunchKernelGGL(s3_tiles_kernel, dim3(nwaves), dim3(64), 0, stream, Q);
+    POLEE_KERNEL_CHECK(ctx);
+    std::vector<SegOut> h_outs(nseg);
+    PD_HIP(hipMemcpyAsync(h_outs.data(), outs.p, sizeof(SegOut) * nseg, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+
+    // ---- the final numbering: segments concatenated in order (psell_build.cpp, "concatenate the fragments")
+    std::vector<SegFinal> h_fin(nseg);
+    uint64_t T = 0, S = 0, Dn = 0;
+    {
+        int last_stream = 0;
+        auto stream_ends = [&](int st) {
+            if (st == PSELL_A1) out.num_tiles_a1 = (int64_t)T;
+            if (st == PSELL_A1M) out.num_tiles_a1m = (int64_t)T;
+            if (st == PSELL_A2) out.num_tiles_a2 = (int64_t)T;
+            if (st == PSELL_A2M) {
+                out.num_tiles_a = (int64_t)T;
+                out.num_slices_a = (int64_t)S;
+            }
+            if (st == PSELL_BN) out.num_tiles_s = (int64_t)T;
+        };
+        for (uint32_t k = 0; k < nseg; ++k) {
+            for (; last_stream < (int)h_segs[k].stream; ++last_stream) stream_ends(last_stream);
+            h_fin[k] = SegFinal{(uint32_t)T, (uint32_t)S, (uint32_t)Dn, 0u};
+            T += h_outs[k].ntiles;
+            S += h_outs[k].nslices;
+            Dn += h_outs[k].ndict;
+        }
+        for (; last_stream < PSELL_B; ++last_stream) stream_ends(last_stream);
+    }
+    if (T >= (1ull << 32) || S >= (1ull << 32) || Dn >= (1ull << 32)) return fail(ctx, POLEE_ERR_UNSUPPORTED, "device layout build: index overflow");
+    out.num_tiles = (int64_t)T;
+    out.num_slices = (int64_t)S;
+    DevBuf<SegFinal> fin;
+    POLEE_TRY(fin.upload(ctx, h_fin.data(), nseg));
+    DevBuf<uint32_t> tile_slice, tile_dict, tile_cols, tile_seg, dict, sl_ri, sl_n, sl_units, sl_tile, sl_long, slice_off;
+    DevBuf<uint8_t> slice_flags, slice_w;
+    DevBuf<unsigned long long> stats;
+    POLEE_TRY(tile_slice.alloc(ctx, T + 1));
+    POLEE_TRY(tile_dict.alloc(ctx, T + 1));
+    POLEE_TRY(tile_cols.alloc(ctx, T + 1));
+    POLEE_TRY(tile_seg.alloc(ctx, T + 1));
+    POLEE_TRY(dict.alloc(ctx, Dn + 1));
+    POLEE_TRY(sl_ri.alloc(ctx, S + 1));
+    POLEE_TRY(sl_n.alloc(ctx, S + 1));
+    POLEE_TRY(sl_units.alloc(ctx, S + 1));
+    POLEE_TRY(sl_tile.alloc(ctx, S + 1));
+    POLEE_TRY(sl_long.alloc(ctx, S + 1));
+    POLEE_TRY(slice_off.alloc(ctx, S + 1));
+    POLEE_TRY(slice_flags.alloc(ctx, S + 1));
+    POLEE_TRY(slice_w.alloc(ctx, S + 1));
+    POLEE_TRY(stats.alloc(ctx, 32));
+    PD_HIP(hipMemsetAsync(dict.p, 0, (Dn + 1) * 4, stream));
+    PD_HIP(hipMemsetAsync(stats.p, 0, 32 * 8, stream));
+    PD_HIP(hipMemsetAsync(sl_units.p + S, 0, 4, stream));
+    {
+        const uint32_t tails[2] = {(uint32_t)S, (uint32_t)Dn};
+        PD_HIP(hipMemcpyAsync(tile_slice.p + T, &tails[0], 4, hipMemcpyHostToDevice, stream));
+        PD_HIP(hipMemcpyAsync(tile_dict.p + T, &tails[1], 4, hipMemcpyHostToDevice, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+    }
+    hipLaunchKernelGGL(s3_tiles_final_kernel, dim3(nseg), dim3(256), 0, stream, segs.p, aux.p, outs.p, fin.p, nseg, t_s0.p, t_cols.p,
+                       t_dstart.p, dict_s.p, tile_slice.p, tile_dict.p, tile_cols.p, tile_seg.p, dict.p);
+    POLEE_KERNEL_CHECK(ctx);
+    S3Size Z;
+    Z.A = A; Z.segs = segs.p; Z.aux = aux.p; Z.fin = fin.p; Z.rlen = rlen.p; Z.endpos = endpos.p; Z.srec_ri = srec_ri.p; Z.srec_n = srec_n.p;
+    Z.tile_slice = tile_slice.p; Z.tile_seg = tile_seg.p; Z.num_tiles = (uint32_t)T; Z.has_ks = X.ks != nullptr;
+    Z.sl_ri = sl_ri.p; Z.sl_n = sl_n.p; Z.sl_units = sl_units.p; Z.sl_tile = sl_tile.p; Z.sl_long = sl_long.p;
+    Z.slice_flags = slice_flags.p; Z.slice_w = slice_w.p; Z.stats = stats.p;
+    if (T) {
+        hipLaunchKernelGGL(s3_size_kernel, dim3((uint32_t)T), dim3(64), 0, stream, Z);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    // slice offsets in 128-byte units (64-bit sum first: the stream is limited to 2^29 units)
+    DevBuf<uint64_t> off64;
+    POLEE_TRY(off64.alloc(ctx, S + 1));
+    PD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(sl_units.p, ToU64()), off64.p, (uint64_t)0, (size_t)S + 1, stream));
+    uint64_t total_units = 0;
+    PD_HIP(hipMemcpyAsync(&total_units, off64.p + S, 8, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (total_units >= (1ull << 29)) return fail(ctx, POLEE_ERR_UNSUPPORTED, "likelihood matrix: matrix too large (the slice stream is limited to 64 GiB)");
+    PD_HIP(exclusive_sum(tmp, sl_units.p, slice_off.p, 0u, (size_t)S + 1, stream));
+    D.data_bytes = (size_t)total_units * 128;
+    POLEE_TRY(D.data.alloc(ctx, D.data_bytes + 2048));  // slack: the LDS-DMA stream reads whole 1 KiB pieces
+    PD_HIP(hipMemsetAsync(D.data.p, 0, D.data_bytes + 2048, stream));
+    if (X.ks) POLEE_TRY(D.slice_ks.alloc(ctx, (size_t)S * 64 + 1));
+    DevBuf<uint32_t> row_order;
+    if (want_debug) POLEE_TRY(row_order.alloc(ctx, (size_t)S * 64 + 1));
+    S3Emit E;
+    E.A = A; E.segs = segs.p; E.tile_seg = tile_seg.p; E.tile_dict = tile_dict.p; E.tile_cols = tile_cols.p; E.dict = dict.p;
+    E.sl_ri = sl_ri.p; E.sl_n = sl_n.p; E.sl_tile = sl_tile.p; E.sl_long = sl_long.p; E.slice_off = slice_off.p;
+    E.num_slices = (uint32_t)S; E.data = D.data.p; E.row_order = want_debug ? row_order.p : nullptr; E.slice_ks = X.ks ? D.slice_ks.p : nullptr;
+    if (S) {
+        hipLaunchKernelGGL(s3_emit_kernel, dim3((uint32_t)S), dim3(64), 0, stream, E);
+        POLEE_KERNEL_CHECK(ctx);
+        hipLaunchKernelGGL(s3_flags_kernel, dim3(((uint32_t)S + TB - 1) / TB), dim3(TB), 0, stream, (uint32_t)S, slice_flags.p, slice_off.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    // ---- the metadata back to the host (schedule, cost model, slot lists: loglik_finish_create)
+    out.slice_off.resize(S + 1);
+    out.tile_slice.resize(T + 1);
+    out.tile_dict.resize(T + 1);
+    out.tile_cols.resize(T);
+    out.dict.resize(Dn);
+    out.slice_flags.resize(S);
+    out.slice_w.resize(S);
+    unsigned long long h_stats[32];
+    PD_HIP(hipMemcpyAsync(out.slice_off.data(), slice_off.p, (S + 1) * 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(out.tile_slice.data(), tile_slice.p, (T + 1) * 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(out.tile_dict.data(), tile_dict.p, (T + 1) * 4, hipMemcpyDeviceToHost, stream));
+    if (T) PD_HIP(hipMemcpyAsync(out.tile_cols.data(), tile_cols.p, T * 4, hipMemcpyDeviceToHost, stream));
+    if (Dn) PD_HIP(hipMemcpyAsync(out.dict.data(), dict.p, Dn * 4, hipMemcpyDeviceToHost, stream));
+    if (S) PD_HIP(hipMemcpyAsync(out.slice_flags.data(), slice_flags.p, S, hipMemcpyDeviceToHost, stream));
+    if (S) PD_HIP(hipMemcpyAsync(out.slice_w.data(), slice_w.p, S, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(h_stats, stats.p, sizeof h_stats, hipMemcpyDeviceToHost, stream));
+    if (want_debug) {
+        out.data.resize(D.data_bytes);
+        out.row_order.resize(S * 64);
+        if (D.data_bytes) PD_HIP(hipMemcpyAsync(out.data.data(), D.data.p, D.data_bytes, hipMemcpyDeviceToHost, stream));
+        if (S) PD_HIP(hipMemcpyAsync(out.row_order.data(), row_order.p, S * 64 * 4, hipMemcpyDeviceToHost, stream));
+        if (X.ks) {
+            out.slice_ks.resize(S * 64);
+            if (S) PD_HIP(hipMemcpyAsync(out.slice_ks.data(), D.slice_ks.p, S * 64 * 4, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    PD_HIP(hipStreamSynchronize(stream));
+    for (int q = 0; q < 6; ++q) {
+        out.stream_rows[q] += (int64_t)h_stats[q];
+        out.stream_nnz[q] += (int64_t)h_stats[8 + q];
+        out.stream_bytes[q] += (int64_t)h_stats[16 + q];
+    }
+    out.padded_nnz += (int64_t)h_stats[24];
+    for (uint64_t t = 0; t < T; ++t) {
+        out.max_tile_cols = std::max<int32_t>(out.max_tile_cols, (int32_t)(out.tile_dict[t + 1] - out.tile_dict[t]));
+        if (out.tile_cols[t] > (uint32_t)PSELL_TILE_COLS_TARGET) out.big_tiles.push_back((uint32_t)t);
+    }
+    for (int64_t s = 0; s < out.num_slices_a; ++s)
+        if (!(out.slice_flags[s] & 1)) return fail(ctx, POLEE_ERR_HIP, "internal error: non-uniform slice in the uniform stream");
+    return POLEE_OK;
+}
+
+}  // namespace polee

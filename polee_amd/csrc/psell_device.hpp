@@ -1,0 +1,32 @@
+// Device-side layout builder (psell_device.hip): interfaces of its stages, mirroring psell_build.cpp's.
+#pragma once
+#include "loglik_internal.hpp"
+
+namespace polee {
+
+struct PsellDevIn {  // X by rows (CSR, 0-based) in device memory
+    const uint64_t *rowptr = nullptr;
+    const uint32_t *col = nullptr;
+    const float *val = nullptr;
+    const int64_t *ks = nullptr;  // or null
+    int64_t m = 0, n = 0;
+};
+struct PsellDevRows {  // PsellRows in device memory
+    const uint32_t *rows = nullptr, *run_end = nullptr, *gid = nullptr;
+    const uint8_t *form = nullptr;
+    const uint32_t *pat_ptr = nullptr, *pat_col = nullptr;
+    size_t Nr = 0;
+    size_t bounds[7] = {};  // rows of stream st: [bounds[st], bounds[st + 1])
+};
+struct PsellDevOut {  // what stays on the device
+    DevBuf<uint8_t> data;  // the slice stream (+ 2 KiB of slack)
+    size_t data_bytes = 0;
+    DevBuf<float> slice_ks;
+};
+
+// stage 3 on the device: slices and tiles.  Fills `out`'s metadata (offsets, tiles, dictionaries, flags, totals); the bytes stay
+// in D -- and are copied into out.data / row_order / slice_ks as well with want_debug.
+polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
+                                 bool want_debug);
+
+}  // namespace polee
