@@ -89,7 +89,13 @@ polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n
     X.rowptr = d_rowptr.p; X.col = d_col.p; X.val = d_val.p; X.ks = ks ? d_ks.p : nullptr; X.m = m; X.n = n;
     PsellRuns R;
     PsellRows W;
-    if ((err = psell_stage1(m, n, rowptr.data(), col.data(), val.data(), ks, p->h, R)) != "") return bad(err);
+    if (device_stages & 1) {
+        PsellDevRuns DR;
+        POLEE_TRY(psell_device_stage1(ctx, X, p->h, DR, true));
+        POLEE_TRY(psell_device_runs_to_host(ctx, DR, R));
+    } else if ((err = psell_stage1(m, n, rowptr.data(), col.data(), val.data(), ks, p->h, R)) != "") {
+        return bad(err);
+    }
     if ((err = psell_stage2(m, n, rowptr.data(), col.data(), val.data(), ks, R, p->h, W)) != "") return bad(err);
     if (device_stages & 4) {
         DevBuf<uint32_t> d_rows, d_end, d_gid, d_pp, d_pc;

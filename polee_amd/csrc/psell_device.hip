@@ -604,7 +604,315 @@ struct ToU64 {
 
 }  // namespace
 
+
+// ================================================================= STAGE 1 ==================================================
+namespace {
+
+__device__ inline uint32_t mix32_dev(uint32_t h, uint32_t v)  // (psell_build.cpp, mix32)
+{
+    h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    return h;
+}
+
+struct S1Counters {
+    unsigned long long empties, singles;
+    uint32_t err, max_row;
+};
+
+// sort key of every row (first transcript's bin, length, hash of the set); empty rows and rows with ONE transcript drop out --
+// the latter counted per transcript (stream S), their k log X_ij left in `term`
+__global__ void s1_keys_kernel(PsellDevIn X, int binsh, uint64_t *keys, uint32_t *keep, uint32_t *is_single, double *term,
+                               unsigned long long *scnt, S1Counters *ctr)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)X.m) return;
+    const uint64_t b = X.rowptr[i], e = X.rowptr[i + 1];
+    uint64_t key = ~0ull;
+    uint32_t single = 0;
+    double tm = 0.0;
+    if (e < b) {
+        atomicMax(&ctr->err, 1u);
+    } else if (e == b) {
+        atomicAdd(&ctr->empties, 1ull);
+    } else if (e - b > (uint64_t)PSELL_MAX_TILE_COLS) {
+        atomicMax(&ctr->err, 2u);
+    } else if (e - b == 1 && X.col[b] < (uint64_t)X.n && X.val[b] > 0.0f && (!X.ks || X.ks[i] >= 0)) {
+        const long long k = X.ks ? X.ks[i] : 1;
+        atomicAdd(&scnt[X.col[b]], (unsigned long long)k);
+        tm = (double)k * log((double)X.val[b]);
+        single = 1;
+        atomicAdd(&ctr->singles, 1ull);
+        atomicMax(&ctr->max_row, 1u);
+    } else {
+        const uint64_t len = e - b;
+        uint32_t h = 0x12345u;
+        const uint32_t first = X.col[b];
+        for (uint64_t k = b; k < e; ++k) {
+            const uint32_t c = X.col[k];
+            if (c >= (uint64_t)X.n) atomicMax(&ctr->err, 3u);
+            if (k > b && c <= X.col[k - 1]) atomicMax(&ctr->err, 4u);
+            h = mix32_dev(h, c);
+        }
+        atomicMax(&ctr->max_row, (uint32_t)len);
+        key = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)(len < 255 ? len : 255) << 32) | h;
+    }
+    keys[i] = key;
+    keep[i] = key != ~0ull;
+    is_single[i] = single;
+    term[i] = tm;
+}
+
+__global__ void s1_compact_kernel(uint64_t m, const uint64_t *keys, const uint32_t *keep, const uint32_t *kscan, const uint32_t *is_single,
+                                  const uint32_t *sscan, uint64_t *keys_c, uint32_t *rows_c, uint32_t *single_rows)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (keep[i]) {
+        keys_c[kscan[i]] = keys[i];
+        rows_c[kscan[i]] = (uint32_t)i;
+    }
+    if (is_single[i]) single_rows[sscan[i]] = (uint32_t)i;
+}
+
+__global__ void s1_heads_kernel(PsellDevIn X, uint32_t N, const uint32_t *rows, uint32_t *head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint32_t h = 1;
+    if (i > 0) {
+        const uint32_t r1 = rows[i - 1], r2 = rows[i];
+        const uint64_t b1 = X.rowptr[r1], b2 = X.rowptr[r2];
+        const uint64_t l1 = X.rowptr[r1 + 1] - b1, l2 = X.rowptr[r2 + 1] - b2;
+        bool same = l1 == l2;
+        for (uint64_t k = 0; same && k < l1; ++k) same = X.col[b1 + k] == X.col[b2 + k];
+        h = same ? 0u : 1u;
+    }
+    head[i] = h;
+}
+
+__global__ void s1_runstart_kernel(uint32_t N, const uint32_t *head, const uint32_t *hscan, uint32_t *run_start)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    if (i == N) {
+        run_start[hscan[N]] = N;
+        return;
+    }
+    if (head[i]) run_start[hscan[i]] = i;
+}
+
+// a run of r identical rows gives floor(r / 64) whole slices and its remainder as one more when that is >= 32 rows
+// (psell_build.cpp, "exact runs -> streams"); the other rows are leftover
+__global__ void s1_classify_kernel(PsellDevIn X, uint32_t N, const uint32_t *rows, const uint32_t *head, const uint32_t *hscan,
+                                   const uint32_t *run_start, uint32_t *f1, uint32_t *f2, uint32_t *fb, uint8_t *endf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t rid = hscan[i] + head[i] - 1u;
+    const uint32_t s = run_start[rid], e = run_start[rid + 1];
+    const uint32_t r = e - s, q = i - s;
+    const uint32_t row = rows[i];
+    const uint64_t len = X.rowptr[row + 1] - X.rowptr[row];
+    uint32_t take = (r / PSELL_LANES) * PSELL_LANES;
+    if (r - take >= (uint32_t)PSELL_MIN_UNIFORM_ROWS) take = r;
+    if (len > (uint64_t)PSELL_WIDE_MAX) take = 0;
+    const bool taken = q < take;
+    const bool narrow = len <= (uint64_t)PSELL_NARROW_MAX;
+    f1[i] = taken && narrow;
+    f2[i] = taken && !narrow;
+    fb[i] = !taken;
+    endf[i] = taken && ((q + 1) % PSELL_LANES == 0 || q + 1 == take) ? 1 : 0;
+}
+
+__global__ void s1_split_kernel(uint32_t N, const uint32_t *rows, const uint32_t *f1, const uint32_t *f2, const uint32_t *fb,
+                                const uint32_t *p1, const uint32_t *p2, const uint32_t *pb, const uint8_t *endf, uint32_t *a1_rows,
+                                uint32_t *a1_ends, uint32_t *a2_rows, uint32_t *a2_ends, uint32_t *rb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t row = rows[i];
+    if (f1[i]) {
+        a1_rows[p1[i]] = row;
+        a1_ends[p1[i]] = endf[i];
+    } else if (f2[i]) {
+        a2_rows[p2[i]] = row;
+        a2_ends[p2[i]] = endf[i];
+    } else if (fb[i]) {
+        rb[pb[i]] = row;
+    }
+}
+
+__global__ void s1_cnt_to_float_kernel(uint32_t n, const unsigned long long *scnt, float *out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = (float)(long long)scnt[j];
+}
+
+}  // namespace
+
 #define PD_HIP(expr) POLEE_HIP_TRY(ctx, expr)
+
+polee_status psell_device_stage1(polee_ctx *ctx, const PsellDevIn &X, PsellHost &out, PsellDevRuns &R, bool want_debug)
+{
+    hipStream_t stream = ctx->stream;
+    const int64_t m = X.m, n = X.n;
+    if (m < 0 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: bad matrix dimensions");
+    if (n > (int64_t)1 << 31) return fail(ctx, POLEE_ERR_UNSUPPORTED, "likelihood matrix: more than 2^31 transcripts is not supported");
+    if (m >= ((int64_t)1 << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "likelihood matrix: more than 2^32 fragments is not supported");
+    out = PsellHost();
+    out.m = m;
+    out.n = n;
+    R.n_a1 = R.n_a2 = R.n_rb = 0;
+    uint64_t nnz = 0;
+    PD_HIP(hipMemcpyAsync(&nnz, X.rowptr + m, 8, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    out.nnz = (int64_t)nnz;
+    if (m == 0) return POLEE_OK;
+    const int binsh = psell_bin_shift();
+    const unsigned TB = 256;
+    Scratch tmp;
+    DevBuf<uint64_t> keys, keys_c, keys_s;
+    DevBuf<uint32_t> keep, is_single, kscan, sscan, rows_c, rows_s, single_rows;
+    DevBuf<double> term, lsum;
+    DevBuf<unsigned long long> scnt;
+    DevBuf<S1Counters> ctr;
+    POLEE_TRY(keys.alloc(ctx, (size_t)m));
+    POLEE_TRY(keep.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(is_single.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(kscan.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(sscan.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(term.alloc(ctx, (size_t)m));
+    POLEE_TRY(lsum.alloc(ctx, 1));
+    POLEE_TRY(scnt.alloc(ctx, (size_t)n));
+    POLEE_TRY(ctr.alloc(ctx, 1));
+    PD_HIP(hipMemsetAsync(scnt.p, 0, (size_t)n * 8, stream));
+    PD_HIP(hipMemsetAsync(ctr.p, 0, sizeof(S1Counters), stream));
+    PD_HIP(hipMemsetAsync(keep.p + m, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(is_single.p + m, 0, 4, stream));
+    hipLaunchKernelGGL(s1_keys_kernel, dim3((unsigned)((m + TB - 1) / TB)), dim3(TB), 0, stream, X, binsh, keys.p, keep.p, is_single.p, term.p,
+                       scnt.p, ctr.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, keep.p, kscan.p, 0u, (size_t)m + 1, stream));
+    PD_HIP(exclusive_sum(tmp, is_single.p, sscan.p, 0u, (size_t)m + 1, stream));
+    {
+        size_t bytes = 0;
+        PD_HIP(rocprim::reduce(nullptr, bytes, term.p, lsum.p, 0.0, (size_t)m, rocprim::plus<double>(), stream));
+        PD_HIP(tmp.need(bytes));
+        PD_HIP(rocprim::reduce(tmp.p, bytes, term.p, lsum.p, 0.0, (size_t)m, rocprim::plus<double>(), stream));
+    }
+    S1Counters h_ctr;
+    uint32_t N = 0, nsingle = 0;
+    double h_lsum = 0.0;
+    PD_HIP(hipMemcpyAsync(&h_ctr, ctr.p, sizeof h_ctr, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&N, kscan.p + m, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&nsingle, sscan.p + m, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&h_lsum, lsum.p, 8, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (h_ctr.err == 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: row offsets are not monotone");
+    if (h_ctr.err == 2) return fail(ctx, POLEE_ERR_UNSUPPORTED, "likelihood matrix: a fragment is compatible with more than 1024 transcripts");
+    if (h_ctr.err == 3) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: transcript index out of range");
+    if (h_ctr.err == 4) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: the transcript ids of a fragment must be strictly ascending (sorted, no duplicates)");
+    out.empty_rows = (int64_t)h_ctr.empties;
+    out.max_row = (int32_t)h_ctr.max_row;
+    POLEE_TRY(keys_c.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(rows_c.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(single_rows.alloc(ctx, (size_t)nsingle + 1));
+    hipLaunchKernelGGL(s1_compact_kernel, dim3((unsigned)((m + TB - 1) / TB)), dim3(TB), 0, stream, (uint64_t)m, keys.p, keep.p, kscan.p, is_single.p,
+                       sscan.p, keys_c.p, rows_c.p, single_rows.p);
+    POLEE_KERNEL_CHECK(ctx);
+    if (nsingle > 0) {
+        POLEE_TRY(R.single_cnt.alloc(ctx, (size_t)n));
+        hipLaunchKernelGGL(s1_cnt_to_float_kernel, dim3((unsigned)((n + TB - 1) / TB)), dim3(TB), 0, stream, (uint32_t)n, scnt.p, R.single_cnt.p);
+        POLEE_KERNEL_CHECK(ctx);
+        out.single_cnt.resize((size_t)n);
+        PD_HIP(hipMemcpyAsync(out.single_cnt.data(), R.single_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        out.single_logsum = h_lsum;
+        out.stream_rows[PSELL_S] = nsingle;
+        out.stream_nnz[PSELL_S] = nsingle;
+        out.stream_bytes[PSELL_S] = 4 * n;
+        if (want_debug) {
+            out.single_rows.resize(nsingle);
+            PD_HIP(hipMemcpyAsync(out.single_rows.data(), single_rows.p, (size_t)nsingle * 4, hipMemcpyDeviceToHost, stream));
+        }
+        PD_HIP(hipStreamSynchronize(stream));
+    }
+    keys.release();
+    term.release();
+    if (N == 0) return POLEE_OK;
+    // stable sort by key (the host's LSD radix sort is stable too: the same order)
+    POLEE_TRY(keys_s.alloc(ctx, N));
+    POLEE_TRY(rows_s.alloc(ctx, (size_t)N + 1));
+    {
+        size_t bytes = 0;
+        PD_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_c.p, keys_s.p, rows_c.p, rows_s.p, (size_t)N, 0, 64, stream));
+        PD_HIP(tmp.need(bytes));
+        PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, keys_c.p, keys_s.p, rows_c.p, rows_s.p, (size_t)N, 0, 64, stream));
+    }
+    keys_c.release();
+    keys_s.release();
+    DevBuf<uint32_t> head, hscan, run_start, f1, f2, fb, p1, p2, pb;
+    DevBuf<uint8_t> endf;
+    POLEE_TRY(head.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(hscan.alloc(ctx, (size_t)N + 1));
+    PD_HIP(hipMemsetAsync(head.p + N, 0, 4, stream));
+    hipLaunchKernelGGL(s1_heads_kernel, dim3((N + TB - 1) / TB), dim3(TB), 0, stream, X, N, rows_s.p, head.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, head.p, hscan.p, 0u, (size_t)N + 1, stream));
+    uint32_t nruns = 0;
+    PD_HIP(hipMemcpyAsync(&nruns, hscan.p + N, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    POLEE_TRY(run_start.alloc(ctx, (size_t)nruns + 1));
+    hipLaunchKernelGGL(s1_runstart_kernel, dim3((N + 1 + TB - 1) / TB), dim3(TB), 0, stream, N, head.p, hscan.p, run_start.p);
+    POLEE_KERNEL_CHECK(ctx);
+    POLEE_TRY(f1.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(f2.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(fb.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(p1.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(p2.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(pb.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(endf.alloc(ctx, (size_t)N + 1));
+    PD_HIP(hipMemsetAsync(f1.p + N, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(f2.p + N, 0, 4, stream));
+    PD_HIP(hipMemsetAsync(fb.p + N, 0, 4, stream));
+    hipLaunchKernelGGL(s1_classify_kernel, dim3((N + TB - 1) / TB), dim3(TB), 0, stream, X, N, rows_s.p, head.p, hscan.p, run_start.p, f1.p, f2.p,
+                       fb.p, endf.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, f1.p, p1.p, 0u, (size_t)N + 1, stream));
+    PD_HIP(exclusive_sum(tmp, f2.p, p2.p, 0u, (size_t)N + 1, stream));
+    PD_HIP(exclusive_sum(tmp, fb.p, pb.p, 0u, (size_t)N + 1, stream));
+    uint32_t c1 = 0, c2 = 0, cb = 0;
+    PD_HIP(hipMemcpyAsync(&c1, p1.p + N, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&c2, p2.p + N, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipMemcpyAsync(&cb, pb.p + N, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    R.n_a1 = c1;
+    R.n_a2 = c2;
+    R.n_rb = cb;
+    POLEE_TRY(R.a1_rows.alloc(ctx, (size_t)c1 + 1));
+    POLEE_TRY(R.a1_ends.alloc(ctx, (size_t)c1 + 1));
+    POLEE_TRY(R.a2_rows.alloc(ctx, (size_t)c2 + 1));
+    POLEE_TRY(R.a2_ends.alloc(ctx, (size_t)c2 + 1));
+    POLEE_TRY(R.rb.alloc(ctx, (size_t)cb + 1));
+    hipLaunchKernelGGL(s1_split_kernel, dim3((N + TB - 1) / TB), dim3(TB), 0, stream, N, rows_s.p, f1.p, f2.p, fb.p, p1.p, p2.p, pb.p, endf.p,
+                       R.a1_rows.p, R.a1_ends.p, R.a2_rows.p, R.a2_ends.p, R.rb.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(hipStreamSynchronize(stream));
+    return POLEE_OK;
+}
+
+polee_status psell_device_runs_to_host(polee_ctx *ctx, const PsellDevRuns &R, PsellRuns &H)
+{
+    H = PsellRuns();
+    H.a1_rows.resize(R.n_a1); H.a1_ends.resize(R.n_a1); H.a2_rows.resize(R.n_a2); H.a2_ends.resize(R.n_a2); H.rb.resize(R.n_rb);
+    POLEE_TRY(R.a1_rows.download(ctx, H.a1_rows.data(), R.n_a1));
+    POLEE_TRY(R.a1_ends.download(ctx, H.a1_ends.data(), R.n_a1));
+    POLEE_TRY(R.a2_rows.download(ctx, H.a2_rows.data(), R.n_a2));
+    POLEE_TRY(R.a2_ends.download(ctx, H.a2_ends.data(), R.n_a2));
+    POLEE_TRY(R.rb.download(ctx, H.rb.data(), R.n_rb));
+    return POLEE_OK;
+}
 
 polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
                                  bool want_debug)

@@ -24,6 +24,16 @@ struct PsellDevOut {  // what stays on the device
     DevBuf<float> slice_ks;
 };
 
+struct PsellDevRuns {  // PsellRuns in device memory (+ stream S's counts)
+    DevBuf<uint32_t> a1_rows, a1_ends, a2_rows, a2_ends, rb;
+    size_t n_a1 = 0, n_a2 = 0, n_rb = 0;
+    DevBuf<float> single_cnt;  // [n], allocated when there are such rows
+};
+
+// stage 1 on the device: keys, stable sort, runs.  Fills `out` as psell_stage1 does (single_rows only with want_debug).
+polee_status psell_device_stage1(polee_ctx *ctx, const PsellDevIn &X, PsellHost &out, PsellDevRuns &R, bool want_debug);
+polee_status psell_device_runs_to_host(polee_ctx *ctx, const PsellDevRuns &R, PsellRuns &H);
+
 // stage 3 on the device: slices and tiles.  Fills `out`'s metadata (offsets, tiles, dictionaries, flags, totals); the bytes stay
 // in D -- and are copied into out.data / row_order / slice_ks as well with want_debug.
 polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
