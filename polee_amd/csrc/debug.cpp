@@ -89,32 +89,54 @@ polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n
     X.rowptr = d_rowptr.p; X.col = d_col.p; X.val = d_val.p; X.ks = ks ? d_ks.p : nullptr; X.m = m; X.n = n;
     PsellRuns R;
     PsellRows W;
+    PsellDevRuns DR;
+    PsellDevRowsOwned DW;
+    bool runs_on_device = false, rows_on_device = false;
     if (device_stages & 1) {
-        PsellDevRuns DR;
         POLEE_TRY(psell_device_stage1(ctx, X, p->h, DR, true));
-        POLEE_TRY(psell_device_runs_to_host(ctx, DR, R));
+        runs_on_device = true;
     } else if ((err = psell_stage1(m, n, rowptr.data(), col.data(), val.data(), ks, p->h, R)) != "") {
         return bad(err);
     }
-    if ((err = psell_stage2(m, n, rowptr.data(), col.data(), val.data(), ks, R, p->h, W)) != "") return bad(err);
+    if (device_stages & 2) {
+        if (!runs_on_device) {
+            DR.n_a1 = R.a1_rows.size(); DR.n_a2 = R.a2_rows.size(); DR.n_rb = R.rb.size();
+            POLEE_TRY(DR.a1_rows.upload(ctx, R.a1_rows.data(), R.a1_rows.size()));
+            POLEE_TRY(DR.a1_ends.upload(ctx, R.a1_ends.data(), R.a1_ends.size()));
+            POLEE_TRY(DR.a2_rows.upload(ctx, R.a2_rows.data(), R.a2_rows.size()));
+            POLEE_TRY(DR.a2_ends.upload(ctx, R.a2_ends.data(), R.a2_ends.size()));
+            POLEE_TRY(DR.rb.upload(ctx, R.rb.data(), R.rb.size()));
+        }
+        bool needs_host = false;
+        POLEE_TRY(psell_device_stage2(ctx, X, DR, p->h, DW, needs_host));
+        if (needs_host) {  // (a matrix without structure: the host builder's case)
+            if (runs_on_device) POLEE_TRY(psell_device_runs_to_host(ctx, DR, R));
+            if ((err = psell_stage2(m, n, rowptr.data(), col.data(), val.data(), ks, R, p->h, W)) != "") return bad(err);
+        } else {
+            rows_on_device = true;
+        }
+    } else {
+        if (runs_on_device) POLEE_TRY(psell_device_runs_to_host(ctx, DR, R));
+        if ((err = psell_stage2(m, n, rowptr.data(), col.data(), val.data(), ks, R, p->h, W)) != "") return bad(err);
+    }
     if (device_stages & 4) {
-        DevBuf<uint32_t> d_rows, d_end, d_gid, d_pp, d_pc;
-        DevBuf<uint8_t> d_form;
-        POLEE_TRY(d_rows.upload(ctx, W.rows.data(), W.rows.size()));
-        POLEE_TRY(d_end.upload(ctx, W.run_end.data(), W.run_end.size()));
-        POLEE_TRY(d_gid.upload(ctx, W.row_gid.data(), W.row_gid.size()));
-        POLEE_TRY(d_form.upload(ctx, W.row_form.data(), W.row_form.size()));
-        POLEE_TRY(d_pp.upload(ctx, W.pat_ptr.data(), W.pat_ptr.size()));
-        POLEE_TRY(d_pc.upload(ctx, W.pat_col.data(), W.pat_col.size()));
-        PsellDevRows DW;
-        DW.rows = d_rows.p; DW.run_end = d_end.p; DW.gid = d_gid.p; DW.form = d_form.p; DW.pat_ptr = d_pp.p; DW.pat_col = d_pc.p;
-        DW.Nr = W.rows.size();
-        const size_t b[7] = {0, (size_t)p->h.rows_a1, (size_t)p->h.rows_a1m, (size_t)p->h.rows_a2, (size_t)p->h.rows_a, (size_t)p->h.rows_s, W.rows.size()};
-        for (int q = 0; q < 7; ++q) DW.bounds[q] = b[q];
+        if (!rows_on_device) {
+            DW.Nr = W.rows.size();
+            DW.npat = W.pat_ptr.size() - 1;
+            const size_t b[7] = {0, (size_t)p->h.rows_a1, (size_t)p->h.rows_a1m, (size_t)p->h.rows_a2, (size_t)p->h.rows_a, (size_t)p->h.rows_s, W.rows.size()};
+            for (int q = 0; q < 7; ++q) DW.bounds[q] = b[q];
+            POLEE_TRY(DW.rows.upload(ctx, W.rows.data(), W.rows.size()));
+            POLEE_TRY(DW.run_end.upload(ctx, W.run_end.data(), W.run_end.size()));
+            POLEE_TRY(DW.gid.upload(ctx, W.row_gid.data(), W.row_gid.size()));
+            POLEE_TRY(DW.form.upload(ctx, W.row_form.data(), W.row_form.size()));
+            POLEE_TRY(DW.pat_ptr.upload(ctx, W.pat_ptr.data(), W.pat_ptr.size()));
+            POLEE_TRY(DW.pat_col.upload(ctx, W.pat_col.data(), W.pat_col.size()));
+        }
         PsellDevOut D;
-        POLEE_TRY(psell_device_stage3(ctx, X, DW, p->h, D, true));
-    } else if ((err = psell_stage3(m, n, rowptr.data(), col.data(), val.data(), ks, W, p->h)) != "") {
-        return bad(err);
+        POLEE_TRY(psell_device_stage3(ctx, X, DW.view(), p->h, D, true));
+    } else {
+        if (rows_on_device) POLEE_TRY(psell_device_rows_to_host(ctx, DW, p->h, W));
+        if ((err = psell_stage3(m, n, rowptr.data(), col.data(), val.data(), ks, W, p->h)) != "") return bad(err);
     }
     *out = p.release();
     return POLEE_OK;

@@ -914,6 +914,592 @@ polee_status psell_device_runs_to_host(polee_ctx *ctx, const PsellDevRuns &R, Ps
     return POLEE_OK;
 }
 
+// ================================================================= STAGE 2 ==================================================
+namespace {
+
+constexpr uint32_t S2_CHUNK = 1u << 15;  // candidate rows packed independently (psell_build.cpp: UCH)
+constexpr uint32_t S2_MAX_GROUP = 1u << 14;
+
+__device__ inline uint32_t wave_sum_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline uint32_t wave_max_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ void s2_firstcol_kernel(PsellDevIn X, uint32_t N, const uint32_t *rows, uint32_t *key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) key[i] = X.col[X.rowptr[rows[i]]];
+}
+
+// class of a row by its length: 0 (<= t0), 1 (<= t1), 2
+__global__ void s2_lenclass_kernel(PsellDevIn X, uint32_t N, const uint32_t *rows, uint32_t t0, uint32_t t1, uint8_t *cls)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint64_t len = X.rowptr[rows[i] + 1] - X.rowptr[rows[i]];
+    cls[i] = len <= t0 ? 0 : (len <= t1 ? 1 : 2);
+}
+__global__ void s2_flag_kernel(uint32_t N, const uint8_t *cls, uint8_t k, uint32_t mask, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = (cls[i] & mask) == k;
+}
+__global__ void s2_scatter_rows_kernel(uint32_t N, const uint32_t *flag, const uint32_t *pos, const uint32_t *rows, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && flag[i]) out[pos[i]] = rows[i];
+}
+
+__global__ void s2_poolinfo_kernel(PsellDevIn X, uint32_t N, const uint32_t *prow, uint32_t *plen, uint64_t *pbeg)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint64_t b = X.rowptr[prow[i]];
+    pbeg[i] = b;
+    plen[i] = (uint32_t)(X.rowptr[prow[i] + 1] - b);
+}
+
+struct S2Pack {
+    const uint32_t *col;
+    const uint32_t *prow, *plen;
+    const uint64_t *pbeg, *plps;
+    uint32_t Np, cap;
+    int pass_w, ks_rows;
+    double factor;
+    uint32_t *rec_row, *rec_gid, *chunk_npats, *psize, *poff, *pcols, *gbuf, *dbuf;
+    uint8_t *rec_meta;  // dest (bits 0..2: 0 dense narrow, 1 masked narrow, 2 dense wide, 3 masked wide, 4 left) | end << 3 | form << 4
+};
+
+// PACKING OF THE LEFTOVER ROWS (psell_build.cpp, stage 2: "Rows are visited in the order of their first transcript ... a row
+// joins the open group while the union stays within the pass's width ... a misfit is deferred once"): the same greedy walk,
+// one wave per chunk of 32 768 candidates, the union held sorted in LDS, a lane per transcript of the row.
+__global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
+{
+#pragma clang fp contract(off)
+    __shared__ uint32_t sA[PSELL_WIDE_MAX], sB[PSELL_WIDE_MAX], srow[PSELL_WIDE_MAX], snew[PSELL_WIDE_MAX];
+    const uint32_t lane = lane_id();
+    const uint32_t p0 = blockIdx.x * S2_CHUNK, p1 = min(P.Np, p0 + S2_CHUNK);
+    uint32_t *uni = sA, *tmp = sB;
+    uint32_t nu = 0, gs = 0, emitted = 0, npat = 0, pat_off = 0, nd = 0;
+    const double relax = 2.0, relax0 = 2.0, mask_gain = 0.5;
+    double allowance = (8.0 * (double)(P.plps[p1] - P.plps[p0]) + 4.0 * (double)(p1 - p0)) * P.factor;
+    const uint64_t pat_base = P.plps[p0];
+    auto close_group = [&]() {
+        if (gs == 0) return;
+        __syncthreads();  // (the group's rows, written by lane 0, to every lane)
+        const bool narrow = nu <= (uint32_t)PSELL_NARROW_MAX;
+        const uint32_t pid = npat;
+        bool any = false;
+        for (uint32_t c0 = 0; c0 < gs; c0 += PSELL_LANES) {
+            const uint32_t nrow = min(gs - c0, (uint32_t)PSELL_LANES);
+            const uint32_t q = lane < nrow ? P.gbuf[p0 + c0 + lane] : 0u;
+            const uint32_t l = lane < nrow ? P.plen[q] : 0u;
+            const uint32_t total = wave_sum_u32(l), longest = wave_max_u32(l);
+            const double dense_bytes = 256.0 * (double)(nu + 1 + (uint32_t)P.ks_rows);
+            const double masked_bytes = 256.0 * (double)(longest + (narrow ? 1u : 2u) + (uint32_t)P.ks_rows);
+            const double budget = 8.0 * (double)total + 4.0 * (double)nrow;
+            const double cost = fmin(dense_bytes, masked_bytes);
+            bool worth = cost <= budget;
+            if (!worth && ((P.pass_w == 1 && (cost <= relax * budget || longest > (uint32_t)PSELL_MIXED_NARROW_MAX)) || (P.pass_w == 0 && cost <= relax0 * budget)) &&
+                cost - budget <= allowance) {
+                allowance -= cost - budget;
+                worth = true;
+            }
+            if (worth) {
+                const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
+                const uint32_t dest = narrow ? (masked ? 1u : 0u) : (masked ? 3u : 2u);
+                if (lane < nrow) {
+                    P.rec_row[p0 + emitted + lane] = P.prow[q];
+                    P.rec_meta[p0 + emitted + lane] = (uint8_t)(dest | ((lane + 1 == nrow ? 1u : 0u) << 3) | ((masked ? 2u : 1u) << 4));
+                    P.rec_gid[p0 + emitted + lane] = pid;
+                }
+                any = true;
+            } else if (lane < nrow) {
+                P.rec_row[p0 + emitted + lane] = P.prow[q];
+                P.rec_meta[p0 + emitted + lane] = 4;
+                P.rec_gid[p0 + emitted + lane] = 0;
+            }
+            emitted += nrow;
+        }
+        if (any) {
+            if (lane < nu) P.pcols[pat_base + pat_off + lane] = uni[lane];
+            if (lane == 0) {
+                P.psize[p0 + pid] = nu;
+                P.poff[p0 + pid] = pat_off;
+            }
+            pat_off += nu;
+            ++npat;
+        }
+        gs = 0;
+        nu = 0;
+        __syncthreads();
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t cnt = pass == 0 ? p1 - p0 : nd;
+        uint32_t ndn = 0;
+        for (uint32_t qi = 0; qi < cnt; ++qi) {
+            const uint32_t q = pass == 0 ? p0 + qi : P.dbuf[p0 + qi];
+            const uint32_t len = P.plen[q];
+            const uint64_t beg = P.pbeg[q];
+            const uint32_t c = lane < len ? P.col[beg + lane] : 0u;
+            bool found = false;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nu; ++j) {
+                const uint32_t u = uni[j];
+                found |= u == c;
+                rank += u < c;
+            }
+            const bool isnew = lane < len && !found;
+            const uint64_t bal = __ballot(isnew);
+            const uint32_t nnew = (uint32_t)__popcll(bal), nt = nu + nnew;
+            if (nt <= P.cap && (gs < (uint32_t)PSELL_LANES || (nt + 3) / 4 == (nu + 3) / 4) && gs < S2_MAX_GROUP) {
+                if (nnew) {
+                    if (lane < PSELL_WIDE_MAX) {
+                        srow[lane] = c;
+                        snew[lane] = isnew;
+                    }
+                    __syncthreads();
+                    if (lane < nu) {
+                        const uint32_t u = uni[lane];
+                        uint32_t before = 0;
+                        for (uint32_t i = 0; i < len; ++i) before += snew[i] && srow[i] < u;
+                        tmp[lane + before] = u;
+                    }
+                    if (isnew) tmp[rank + (uint32_t)__popcll(bal & lanes_below())] = c;
+                    __syncthreads();
+                    uint32_t *sw = uni;
+                    uni = tmp;
+                    tmp = sw;
+                    nu = nt;
+                }
+                if (lane == 0) P.gbuf[p0 + gs] = q;
+                ++gs;
+                continue;
+            }
+            if (pass == 0 && gs < 48 && nu + 1 < P.cap) {
+                if (lane == 0) P.dbuf[p0 + ndn] = q;  // an outlier (a neighbouring gene's isoform): second pass
+                ++ndn;
+                continue;
+            }
+            close_group();
+            if (lane < len) uni[lane] = c;
+            nu = len;
+            if (lane == 0) P.gbuf[p0] = q;
+            gs = 1;
+            __syncthreads();
+        }
+        close_group();
+        if (pass == 0) nd = ndn;
+        __syncthreads();
+    }
+    if (lane == 0) P.chunk_npats[blockIdx.x] = npat;
+}
+
+// the records of a pass into the four lists and the rows left over (each in record order: chunk by chunk, group by group)
+__global__ void s2_recflag_kernel(uint32_t N, const uint8_t *meta, uint32_t *f0, uint32_t *f1, uint32_t *f2, uint32_t *f3, uint32_t *f4)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t d = meta[i] & 7u;
+    f0[i] = d == 0; f1[i] = d == 1; f2[i] = d == 2; f3[i] = d == 3; f4[i] = d == 4;
+}
+struct ListPtrs {
+    uint32_t *rows[4], *ends[4], *gid[4];
+    uint8_t *form[4];
+    uint32_t *left;
+};
+__global__ void s2_recscatter_kernel(uint32_t N, const uint32_t *rec_row, const uint8_t *meta, const uint32_t *rec_gid, const uint32_t *gbase,
+                                     const uint32_t *p0, const uint32_t *p1, const uint32_t *p2, const uint32_t *p3, const uint32_t *p4, ListPtrs L)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t d = meta[i] & 7u;
+    if (d == 4) {
+        L.left[p4[i]] = rec_row[i];
+        return;
+    }
+    const uint32_t pos = d == 0 ? p0[i] : (d == 1 ? p1[i] : (d == 2 ? p2[i] : p3[i]));
+    L.rows[d][pos] = rec_row[i];
+    L.ends[d][pos] = (meta[i] >> 3) & 1u;
+    L.form[d][pos] = (uint8_t)(meta[i] >> 4);
+    L.gid[d][pos] = rec_gid[i] + gbase[i / S2_CHUNK];
+}
+// the patterns of a pass, chunk by chunk: sizes, then the transcript ids
+__global__ void s2_patflag_kernel(uint32_t N, const uint32_t *chunk_npats, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = (i % S2_CHUNK) < chunk_npats[i / S2_CHUNK];
+}
+__global__ void s2_patsize_kernel(uint32_t N, const uint32_t *flag, const uint32_t *pos, const uint32_t *psize, uint32_t *sizes, uint32_t *src)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && flag[i]) {
+        sizes[pos[i]] = psize[i];
+        src[pos[i]] = i;
+    }
+}
+__global__ void s2_patcopy_kernel(uint32_t npat, const uint32_t *src, const uint32_t *sizes, const uint32_t *ptr, const uint32_t *poff,
+                                  const uint64_t *plps, const uint32_t *pcols, uint32_t *pat_col, uint32_t col_base)
+{
+    const uint32_t k = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (k >= npat) return;
+    const uint32_t i = src[k], t = threadIdx.x & 31u;
+    const uint32_t p0 = (i / S2_CHUNK) * S2_CHUNK;
+    if (t < sizes[k]) pat_col[col_base + ptr[k] + t] = pcols[plps[p0] + poff[i] + t];
+}
+__global__ void s2_blockkey_kernel(PsellDevIn X, uint32_t N, const uint32_t *rows, uint32_t block_rows, uint32_t *key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t len = (uint32_t)(X.rowptr[rows[i] + 1] - X.rowptr[rows[i]]);
+    key[i] = ((i / block_rows) << 11) | (2047u - len);  // (len <= 1024): blocks in order, longest rows first, ties in order
+}
+__global__ void s2_fill_u32_kernel(uint32_t N, uint32_t *p, uint32_t v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) p[i] = v;
+}
+
+struct PackLists {
+    DevBuf<uint32_t> rows[4], ends[4], gid[4], left;
+    DevBuf<uint8_t> form[4];
+    uint32_t count[4] = {0, 0, 0, 0}, nleft = 0;
+    DevBuf<uint32_t> pat_sizes, pat_src, pat_ptr, poff, pcols;
+    DevBuf<uint64_t> plps;
+    uint32_t npat = 0, pat_cols = 0;
+};
+
+polee_status sort_by_first_col(polee_ctx *ctx, Scratch &tmp, const PsellDevIn &X, const uint32_t *rows, uint32_t N, DevBuf<uint32_t> &out)
+{
+    hipStream_t stream = ctx->stream;
+    POLEE_TRY(out.alloc(ctx, (size_t)N + 1));
+    if (N == 0) return POLEE_OK;
+    DevBuf<uint32_t> key, key_s;
+    POLEE_TRY(key.alloc(ctx, N));
+    POLEE_TRY(key_s.alloc(ctx, N));
+    hipLaunchKernelGGL(s2_firstcol_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, X, N, rows, key.p);
+    POLEE_KERNEL_CHECK(ctx);
+    size_t bytes = 0;
+    PD_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, rows, out.p, (size_t)N, 0, 32, stream));
+    PD_HIP(tmp.need(bytes));
+    PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, rows, out.p, (size_t)N, 0, 32, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    return POLEE_OK;
+}
+
+// out = the rows whose class (masked) equals k, in order
+polee_status select_class(polee_ctx *ctx, Scratch &tmp, const uint32_t *rows, const uint8_t *cls, uint32_t N, uint8_t k, uint32_t mask,
+                          DevBuf<uint32_t> &flag, DevBuf<uint32_t> &pos, DevBuf<uint32_t> &out, uint32_t &count)
+{
+    hipStream_t stream = ctx->stream;
+    count = 0;
+    POLEE_TRY(out.alloc(ctx, 1));
+    if (N == 0) return POLEE_OK;
+    POLEE_TRY(flag.alloc(ctx, (size_t)N + 1));
+    POLEE_TRY(pos.alloc(ctx, (size_t)N + 1));
+    PD_HIP(hipMemsetAsync(flag.p + N, 0, 4, stream));
+    hipLaunchKernelGGL(s2_flag_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, cls, k, mask, flag.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, flag.p, pos.p, 0u, (size_t)N + 1, stream));
+    PD_HIP(hipMemcpyAsync(&count, pos.p + N, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    POLEE_TRY(out.alloc(ctx, (size_t)count + 1));
+    hipLaunchKernelGGL(s2_scatter_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, flag.p, pos.p, rows, out.p);
+    POLEE_KERNEL_CHECK(ctx);
+    return POLEE_OK;
+}
+
+polee_status concat2(polee_ctx *ctx, const DevBuf<uint32_t> &a, uint32_t na, const DevBuf<uint32_t> &b, uint32_t nb, DevBuf<uint32_t> &out)
+{
+    POLEE_TRY(out.alloc(ctx, (size_t)na + nb + 1));
+    if (na) PD_HIP(hipMemcpyAsync(out.p, a.p, (size_t)na * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (nb) PD_HIP(hipMemcpyAsync(out.p + na, b.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return POLEE_OK;
+}
+
+// one pass of the packing over `pool` (already in first-transcript order)
+polee_status run_pack(polee_ctx *ctx, Scratch &tmp, const PsellDevIn &X, uint64_t nnz_total, const DevBuf<uint32_t> &pool, uint32_t Np, uint32_t cap,
+                      int pass_w, uint32_t gid_base, PackLists &L)
+{
+    hipStream_t stream = ctx->stream;
+    for (int d = 0; d < 4; ++d) L.count[d] = 0;
+    L.nleft = 0;
+    L.npat = 0;
+    L.pat_cols = 0;
+    if (Np == 0) return POLEE_OK;
+    const unsigned TB = 256;
+    const uint32_t nch = (Np + S2_CHUNK - 1) / S2_CHUNK;
+    DevBuf<uint32_t> plen, rec_row, rec_gid, chunk_npats, gbase, psize, gbuf, dbuf, f[5], p[5], pflag, ppos;
+    DevBuf<uint64_t> pbeg;
+    DevBuf<uint8_t> rec_meta;
+    POLEE_TRY(plen.alloc(ctx, (size_t)Np + 1));
+    POLEE_TRY(pbeg.alloc(ctx, (size_t)Np + 1));
+    POLEE_TRY(L.plps.alloc(ctx, (size_t)Np + 1));
+    PD_HIP(hipMemsetAsync(plen.p + Np, 0, 4, stream));
+    hipLaunchKernelGGL(s2_poolinfo_kernel, dim3((Np + TB - 1) / TB), dim3(TB), 0, stream, X, Np, pool.p, plen.p, pbeg.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(plen.p, ToU64()), L.plps.p, (uint64_t)0, (size_t)Np + 1, stream));
+    uint64_t pool_nnz = 0;
+    PD_HIP(hipMemcpyAsync(&pool_nnz, L.plps.p + Np, 8, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (pool_nnz >= (1ull << 32)) return fail(ctx, POLEE_ERR_UNSUPPORTED, "device layout build: more than 2^32 non-zeros in leftover rows");
+    const double over_budget = 0.02;
+    const double pool_csr_bytes = 8.0 * (double)pool_nnz + 4.0 * (double)Np;
+    const double matrix_csr_bytes = 8.0 * (double)nnz_total + 4.0 * (double)X.m;
+    S2Pack P;
+    P.col = X.col; P.prow = pool.p; P.plen = plen.p; P.pbeg = pbeg.p; P.plps = L.plps.p; P.Np = Np; P.cap = cap; P.pass_w = pass_w;
+    P.ks_rows = X.ks ? 1 : 0;
+    P.factor = over_budget * matrix_csr_bytes / std::max(pool_csr_bytes, 1.0);
+    POLEE_TRY(rec_row.alloc(ctx, Np));
+    POLEE_TRY(rec_gid.alloc(ctx, Np));
+    POLEE_TRY(rec_meta.alloc(ctx, Np));
+    POLEE_TRY(chunk_npats.alloc(ctx, (size_t)nch + 1));
+    POLEE_TRY(gbase.alloc(ctx, (size_t)nch + 1));
+    POLEE_TRY(psize.alloc(ctx, Np));
+    POLEE_TRY(L.poff.alloc(ctx, Np));
+    POLEE_TRY(L.pcols.alloc(ctx, (size_t)pool_nnz + 1));
+    POLEE_TRY(gbuf.alloc(ctx, Np));
+    POLEE_TRY(dbuf.alloc(ctx, Np));
+    P.rec_row = rec_row.p; P.rec_gid = rec_gid.p; P.rec_meta = rec_meta.p; P.chunk_npats = chunk_npats.p; P.psize = psize.p; P.poff = L.poff.p;
+    P.pcols = L.pcols.p; P.gbuf = gbuf.p; P.dbuf = dbuf.p;
+    PD_HIP(hipMemsetAsync(chunk_npats.p + nch, 0, 4, stream));
+    hipLaunchKernelGGL(s2_pack_kernel, dim3(nch), dim3(64), 0, stream, P);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, chunk_npats.p, gbase.p, gid_base, (size_t)nch + 1, stream));
+    // the four lists + the rows left
+    uint32_t cnt[5];
+    for (int d = 0; d < 5; ++d) {
+        POLEE_TRY(f[d].alloc(ctx, (size_t)Np + 1));
+        POLEE_TRY(p[d].alloc(ctx, (size_t)Np + 1));
+        PD_HIP(hipMemsetAsync(f[d].p + Np, 0, 4, stream));
+    }
+    hipLaunchKernelGGL(s2_recflag_kernel, dim3((Np + TB - 1) / TB), dim3(TB), 0, stream, Np, rec_meta.p, f[0].p, f[1].p, f[2].p, f[3].p, f[4].p);
+    POLEE_KERNEL_CHECK(ctx);
+    for (int d = 0; d < 5; ++d) {
+        PD_HIP(exclusive_sum(tmp, f[d].p, p[d].p, 0u, (size_t)Np + 1, stream));
+        PD_HIP(hipMemcpyAsync(&cnt[d], p[d].p + Np, 4, hipMemcpyDeviceToHost, stream));
+    }
+    uint32_t gend = 0;
+    PD_HIP(hipMemcpyAsync(&gend, gbase.p + nch, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    L.npat = gend - gid_base;
+    ListPtrs LP;
+    for (int d = 0; d < 4; ++d) {
+        L.count[d] = cnt[d];
+        POLEE_TRY(L.rows[d].alloc(ctx, (size_t)cnt[d] + 1));
+        POLEE_TRY(L.ends[d].alloc(ctx, (size_t)cnt[d] + 1));
+        POLEE_TRY(L.gid[d].alloc(ctx, (size_t)cnt[d] + 1));
+        POLEE_TRY(L.form[d].alloc(ctx, (size_t)cnt[d] + 1));
+        LP.rows[d] = L.rows[d].p; LP.ends[d] = L.ends[d].p; LP.gid[d] = L.gid[d].p; LP.form[d] = L.form[d].p;
+    }
+    L.nleft = cnt[4];
+    POLEE_TRY(L.left.alloc(ctx, (size_t)cnt[4] + 1));
+    LP.left = L.left.p;
+    hipLaunchKernelGGL(s2_recscatter_kernel, dim3((Np + TB - 1) / TB), dim3(TB), 0, stream, Np, rec_row.p, rec_meta.p, rec_gid.p, gbase.p, p[0].p, p[1].p,
+                       p[2].p, p[3].p, p[4].p, LP);
+    POLEE_KERNEL_CHECK(ctx);
+    // the patterns: sizes in (chunk, group) order, offsets, where each one's ids lie
+    POLEE_TRY(pflag.alloc(ctx, (size_t)Np + 1));
+    POLEE_TRY(ppos.alloc(ctx, (size_t)Np + 1));
+    PD_HIP(hipMemsetAsync(pflag.p + Np, 0, 4, stream));
+    hipLaunchKernelGGL(s2_patflag_kernel, dim3((Np + TB - 1) / TB), dim3(TB), 0, stream, Np, chunk_npats.p, pflag.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, pflag.p, ppos.p, 0u, (size_t)Np + 1, stream));
+    POLEE_TRY(L.pat_sizes.alloc(ctx, (size_t)L.npat + 1));
+    POLEE_TRY(L.pat_src.alloc(ctx, (size_t)L.npat + 1));
+    POLEE_TRY(L.pat_ptr.alloc(ctx, (size_t)L.npat + 1));
+    PD_HIP(hipMemsetAsync(L.pat_sizes.p + L.npat, 0, 4, stream));
+    hipLaunchKernelGGL(s2_patsize_kernel, dim3((Np + TB - 1) / TB), dim3(TB), 0, stream, Np, pflag.p, ppos.p, psize.p, L.pat_sizes.p, L.pat_src.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(exclusive_sum(tmp, L.pat_sizes.p, L.pat_ptr.p, 0u, (size_t)L.npat + 1, stream));
+    PD_HIP(hipMemcpyAsync(&L.pat_cols, L.pat_ptr.p + L.npat, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    return POLEE_OK;
+}
+
+}  // namespace
+
+polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRuns &R, PsellHost &out, PsellDevRowsOwned &W, bool &needs_host)
+{
+    hipStream_t stream = ctx->stream;
+    needs_host = false;
+    Scratch tmp;
+    const unsigned TB = 256;
+    const uint64_t nnz_total = (uint64_t)out.nnz;
+    // candidates in the order of their first transcript; by length: <= 16 first pass, 17..32 second pass, longer: mixed streams
+    DevBuf<uint32_t> cand, flag, pos, pool0, l1, l2;
+    DevBuf<uint8_t> cls;
+    const uint32_t nrb = (uint32_t)R.n_rb;
+    POLEE_TRY(sort_by_first_col(ctx, tmp, X, R.rb.p, nrb, cand));
+    uint32_t n0 = 0, n1 = 0, n2 = 0;
+    POLEE_TRY(cls.alloc(ctx, (size_t)nrb + 1));
+    if (nrb) {
+        hipLaunchKernelGGL(s2_lenclass_kernel, dim3((nrb + TB - 1) / TB), dim3(TB), 0, stream, X, nrb, cand.p, (uint32_t)PSELL_NARROW_MAX, (uint32_t)PSELL_WIDE_MAX, cls.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 0, 0xffu, flag, pos, pool0, n0));
+    POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 1, 0xffu, flag, pos, l1, n1));
+    POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 2, 0xffu, flag, pos, l2, n2));
+    PackLists P0, P1;
+    POLEE_TRY(run_pack(ctx, tmp, X, nnz_total, pool0, n0, (uint32_t)PSELL_NARROW_MAX, 0, 0u, P0));
+    DevBuf<uint32_t> np_unsorted, pool1;
+    POLEE_TRY(concat2(ctx, l1, n1, P0.left, P0.nleft, np_unsorted));
+    const uint32_t np1 = n1 + P0.nleft;
+    POLEE_TRY(sort_by_first_col(ctx, tmp, X, np_unsorted.p, np1, pool1));
+    POLEE_TRY(run_pack(ctx, tmp, X, nnz_total, pool1, np1, (uint32_t)PSELL_WIDE_MAX, 1, P0.npat, P1));
+    // the mixed streams: what found no company, in first-transcript order; BN: rows of <= 15 transcripts, B: the others; inside every
+    // block of 1024 rows by descending length
+    DevBuf<uint32_t> kb_unsorted, kb, rbn, wide;
+    POLEE_TRY(concat2(ctx, l2, n2, P1.left, P1.nleft, kb_unsorted));
+    const uint32_t nkb = n2 + P1.nleft;
+    POLEE_TRY(sort_by_first_col(ctx, tmp, X, kb_unsorted.p, nkb, kb));
+    uint32_t nbn = 0, nwide = 0;
+    DevBuf<uint8_t> cls2;
+    POLEE_TRY(cls2.alloc(ctx, (size_t)nkb + 1));
+    if (nkb) {
+        hipLaunchKernelGGL(s2_lenclass_kernel, dim3((nkb + TB - 1) / TB), dim3(TB), 0, stream, X, nkb, kb.p, (uint32_t)PSELL_MIXED_NARROW_MAX, 0xffffffffu, cls2.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    POLEE_TRY(select_class(ctx, tmp, kb.p, cls2.p, nkb, 0, 0xffu, flag, pos, rbn, nbn));
+    POLEE_TRY(select_class(ctx, tmp, kb.p, cls2.p, nkb, 1, 0xffu, flag, pos, wide, nwide));
+    DevBuf<uint32_t> rbn_s, wide_s;
+    uint64_t mixed_nnz = 0;
+    for (int which = 0; which < 2; ++which) {
+        DevBuf<uint32_t> &src = which == 0 ? rbn : wide, &dst = which == 0 ? rbn_s : wide_s;
+        const uint32_t N = which == 0 ? nbn : nwide;
+        POLEE_TRY(dst.alloc(ctx, (size_t)N + 1));
+        if (N == 0) continue;
+        DevBuf<uint32_t> key, key_s, lens;
+        DevBuf<uint64_t> lsum;
+        POLEE_TRY(key.alloc(ctx, N));
+        POLEE_TRY(key_s.alloc(ctx, N));
+        hipLaunchKernelGGL(s2_blockkey_kernel, dim3((N + TB - 1) / TB), dim3(TB), 0, stream, X, N, src.p, (uint32_t)(PSELL_LANES * PSELL_TILE_SLICES_B), key.p);
+        POLEE_KERNEL_CHECK(ctx);
+        size_t bytes = 0;
+        PD_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, src.p, dst.p, (size_t)N, 0, 32, stream));
+        PD_HIP(tmp.need(bytes));
+        PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, src.p, dst.p, (size_t)N, 0, 32, stream));
+        // their non-zeros (for the CSR question below): 2047 - (key & 2047) summed
+        std::vector<uint32_t> hk(N);
+        PD_HIP(hipMemcpyAsync(hk.data(), key.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+        for (uint32_t v : hk) mixed_nnz += 2047u - (v & 2047u);
+    }
+    // Stream C (rows kept in CSR): the host builder simulates the mixed streams' tiles row by row and keeps rows in CSR only when
+    // they are more than a tenth of the matrix -- which they cannot be when ALL the mixed rows are less.  Otherwise (a matrix
+    // without structure) the layout is the host builder's to make.
+    if ((double)mixed_nnz >= 0.10 * (double)nnz_total && mixed_nnz > 0) {
+        needs_host = true;
+        return POLEE_OK;
+    }
+    // ---- the ordered rows of the sliced streams: A1 = exact runs, first-pass unions, second-pass narrow unions; A1M; A2; A2M; BN; B
+    const uint32_t nA1 = (uint32_t)R.n_a1 + P0.count[0] + P1.count[0], nA1M = P0.count[1] + P1.count[1];
+    const uint32_t nA2 = (uint32_t)R.n_a2 + P0.count[2] + P1.count[2], nA2M = P0.count[3] + P1.count[3];
+    const uint64_t Nr64 = (uint64_t)nA1 + nA1M + nA2 + nA2M + nbn + nwide;
+    if (Nr64 >= (1ull << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "device layout build: too many rows");
+    const uint32_t Nr = (uint32_t)Nr64;
+    W.Nr = Nr;
+    W.bounds[0] = 0; W.bounds[1] = nA1; W.bounds[2] = W.bounds[1] + nA1M; W.bounds[3] = W.bounds[2] + nA2; W.bounds[4] = W.bounds[3] + nA2M;
+    W.bounds[5] = W.bounds[4] + nbn; W.bounds[6] = Nr;
+    POLEE_TRY(W.rows.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(W.run_end.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(W.gid.alloc(ctx, (size_t)Nr + 1));
+    POLEE_TRY(W.form.alloc(ctx, (size_t)Nr + 1));
+    PD_HIP(hipMemsetAsync(W.run_end.p, 0, ((size_t)Nr + 1) * 4, stream));
+    PD_HIP(hipMemsetAsync(W.gid.p, 0, ((size_t)Nr + 1) * 4, stream));
+    PD_HIP(hipMemsetAsync(W.form.p, 0, (size_t)Nr + 1, stream));
+    size_t at = 0;
+    auto put_u32 = [&](uint32_t *dst, const uint32_t *src, size_t cnt) -> polee_status {
+        if (cnt) PD_HIP(hipMemcpyAsync(dst + at, src, cnt * 4, hipMemcpyDeviceToDevice, stream));
+        return POLEE_OK;
+    };
+    auto put_list = [&](const PackLists &L, int d) -> polee_status {
+        const size_t cnt = L.count[d];
+        POLEE_TRY(put_u32(W.rows.p, L.rows[d].p, cnt));
+        POLEE_TRY(put_u32(W.run_end.p, L.ends[d].p, cnt));
+        POLEE_TRY(put_u32(W.gid.p, L.gid[d].p, cnt));
+        if (cnt) PD_HIP(hipMemcpyAsync(W.form.p + at, L.form[d].p, cnt, hipMemcpyDeviceToDevice, stream));
+        at += cnt;
+        return POLEE_OK;
+    };
+    POLEE_TRY(put_u32(W.rows.p, R.a1_rows.p, R.n_a1));
+    POLEE_TRY(put_u32(W.run_end.p, R.a1_ends.p, R.n_a1));
+    at += R.n_a1;
+    POLEE_TRY(put_list(P0, 0));
+    POLEE_TRY(put_list(P1, 0));
+    POLEE_TRY(put_list(P0, 1));
+    POLEE_TRY(put_list(P1, 1));
+    POLEE_TRY(put_u32(W.rows.p, R.a2_rows.p, R.n_a2));
+    POLEE_TRY(put_u32(W.run_end.p, R.a2_ends.p, R.n_a2));
+    at += R.n_a2;
+    POLEE_TRY(put_list(P0, 2));
+    POLEE_TRY(put_list(P1, 2));
+    POLEE_TRY(put_list(P0, 3));
+    POLEE_TRY(put_list(P1, 3));
+    POLEE_TRY(put_u32(W.rows.p, rbn_s.p, nbn));
+    at += nbn;
+    POLEE_TRY(put_u32(W.rows.p, wide_s.p, nwide));
+    at += nwide;
+    // the groups' transcript sets: first pass's, then second pass's
+    W.npat = (size_t)P0.npat + P1.npat;
+    const uint32_t ncols = P0.pat_cols + P1.pat_cols;
+    POLEE_TRY(W.pat_ptr.alloc(ctx, W.npat + 1));
+    POLEE_TRY(W.pat_col.alloc(ctx, (size_t)ncols + 1));
+    {
+        // pat_ptr = [P0.ptr ..., P0.cols + P1.ptr ...]
+        if (P0.npat) PD_HIP(hipMemcpyAsync(W.pat_ptr.p, P0.pat_ptr.p, (size_t)P0.npat * 4, hipMemcpyDeviceToDevice, stream));
+        std::vector<uint32_t> h1((size_t)P1.npat + 1, 0);
+        if (P1.npat) PD_HIP(hipMemcpyAsync(h1.data(), P1.pat_ptr.p, ((size_t)P1.npat + 1) * 4, hipMemcpyDeviceToHost, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+        for (auto &v : h1) v += P0.pat_cols;
+        if (P1.npat == 0) h1[0] = P0.pat_cols;
+        PD_HIP(hipMemcpyAsync(W.pat_ptr.p + P0.npat, h1.data(), ((size_t)P1.npat + 1) * 4, hipMemcpyHostToDevice, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+        if (P0.npat) {
+            hipLaunchKernelGGL(s2_patcopy_kernel, dim3((P0.npat + 7) / 8), dim3(256), 0, stream, P0.npat, P0.pat_src.p, P0.pat_sizes.p, P0.pat_ptr.p,
+                               P0.poff.p, P0.plps.p, P0.pcols.p, W.pat_col.p, 0u);
+            POLEE_KERNEL_CHECK(ctx);
+        }
+        if (P1.npat) {
+            hipLaunchKernelGGL(s2_patcopy_kernel, dim3((P1.npat + 7) / 8), dim3(256), 0, stream, P1.npat, P1.pat_src.p, P1.pat_sizes.p, P1.pat_ptr.p,
+                               P1.poff.p, P1.plps.p, P1.pcols.p, W.pat_col.p, P0.pat_cols);
+            POLEE_KERNEL_CHECK(ctx);
+        }
+    }
+    PD_HIP(hipStreamSynchronize(stream));
+    return POLEE_OK;
+}
+
+polee_status psell_device_rows_to_host(polee_ctx *ctx, const PsellDevRowsOwned &W, PsellHost &out, PsellRows &H)
+{
+    H = PsellRows();
+    const size_t nu = W.bounds[4];  // rows of the uniform streams: run_end / form / gid cover these
+    H.rows.resize(W.Nr);
+    H.run_end.resize(nu);
+    H.row_gid.resize(nu);
+    H.row_form.resize(nu);
+    H.pat_ptr.resize(W.npat + 1);
+    POLEE_TRY(W.rows.download(ctx, H.rows.data(), W.Nr));
+    POLEE_TRY(W.run_end.download(ctx, H.run_end.data(), nu));
+    POLEE_TRY(W.gid.download(ctx, H.row_gid.data(), nu));
+    POLEE_TRY(W.form.download(ctx, H.row_form.data(), nu));
+    POLEE_TRY(W.pat_ptr.download(ctx, H.pat_ptr.data(), W.npat + 1));
+    H.pat_col.resize(H.pat_ptr.back());
+    POLEE_TRY(W.pat_col.download(ctx, H.pat_col.data(), H.pat_col.size()));
+    out.rows_a1 = (int64_t)W.bounds[1];
+    out.rows_a1m = (int64_t)W.bounds[2];
+    out.rows_a2 = (int64_t)W.bounds[3];
+    out.rows_a = (int64_t)W.bounds[4];
+    out.rows_s = (int64_t)W.bounds[5];
+    return POLEE_OK;
+}
+
 polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
                                  bool want_debug)
 {

@@ -34,6 +34,26 @@ struct PsellDevRuns {  // PsellRuns in device memory (+ stream S's counts)
 polee_status psell_device_stage1(polee_ctx *ctx, const PsellDevIn &X, PsellHost &out, PsellDevRuns &R, bool want_debug);
 polee_status psell_device_runs_to_host(polee_ctx *ctx, const PsellDevRuns &R, PsellRuns &H);
 
+struct PsellDevRowsOwned {  // stage 2's result in device memory
+    DevBuf<uint32_t> rows, run_end, gid, pat_ptr, pat_col;
+    DevBuf<uint8_t> form;
+    size_t Nr = 0, npat = 0;
+    size_t bounds[7] = {};
+    PsellDevRows view() const
+    {
+        PsellDevRows v;
+        v.rows = rows.p; v.run_end = run_end.p; v.gid = gid.p; v.form = form.p; v.pat_ptr = pat_ptr.p; v.pat_col = pat_col.p;
+        v.Nr = Nr;
+        for (int q = 0; q < 7; ++q) v.bounds[q] = bounds[q];
+        return v;
+    }
+};
+
+// stage 2 on the device: packing of the leftover rows, mixed streams, the ordered rows.  needs_host: the matrix has a real share
+// of rows without any structure (stream C's question, sequential over all of them): the layout is the host builder's to make.
+polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRuns &R, PsellHost &out, PsellDevRowsOwned &W, bool &needs_host);
+polee_status psell_device_rows_to_host(polee_ctx *ctx, const PsellDevRowsOwned &W, PsellHost &out, PsellRows &H);
+
 // stage 3 on the device: slices and tiles.  Fills `out`'s metadata (offsets, tiles, dictionaries, flags, totals); the bytes stay
 // in D -- and are copied into out.data / row_order / slice_ks as well with want_debug.
 polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
