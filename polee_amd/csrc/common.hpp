@@ -104,6 +104,14 @@ struct DevBuf {
         n = count;
         return POLEE_OK;
     }
+    void take(DevBuf &other)  // (ownership moves here)
+    {
+        release();
+        p = other.p;
+        n = other.n;
+        other.p = nullptr;
+        other.n = 0;
+    }
     polee_status upload(polee_ctx *ctx, const T *host, size_t count)
     {
         POLEE_TRY(alloc(ctx, count));

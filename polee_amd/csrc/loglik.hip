@@ -11,6 +11,7 @@
 // Roofline: HBM-bound by bytes (0.25 flop/B); the two small dense products per slice run on the
 // exact-f32 matrix instruction because that removes the cross-lane sums, not for flops.
 #include "loglik_internal.hpp"
+#include "psell_device.hpp"
 #include "wave.hpp"
 
 #include <algorithm>
@@ -2430,11 +2431,12 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     polee_status s;
     static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
     const double t_begin = wall_now();
-    h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
-    if ((s = ll->d_data.upload(ctx, h.data.data(), h.data.size())) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
+    if (!ll->device_built) h.data.resize(h.data.size() + 2048, 0);  // slack: the LDS-DMA stream reads whole 1 KiB pieces
+    // (device_built: the slice stream and the multiplicities were laid out on the device, psell_device.hip, and are in place)
+    if ((!ll->device_built && (s = ll->d_data.upload(ctx, h.data.data(), h.data.size()))) || (s = ll->d_slice_off.upload(ctx, h.slice_off)) ||
         (s = ll->d_tile_slice.upload(ctx, h.tile_slice)) || (s = ll->d_tile_dict.upload(ctx, h.tile_dict)) ||
         (s = ll->d_dict.upload(ctx, h.dict)) ||
-        (ll->has_ks && (s = ll->d_slice_ks.upload(ctx, h.slice_ks))) ||
+        (ll->has_ks && !ll->device_built && (s = ll->d_slice_ks.upload(ctx, h.slice_ks))) ||
         (!h.csr_rows.empty() && ((s = ll->d_csr_rowptr.upload(ctx, h.csr_rowptr)) || (s = ll->d_csr_col.upload(ctx, h.csr_col)) ||
                                  (s = ll->d_csr_val.upload(ctx, h.csr_val)) || (ll->has_ks && (s = ll->d_csr_ks.upload(ctx, h.csr_ks)))))) {
         loglik_release(ll);
@@ -2702,6 +2704,33 @@ polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on)
     return POLEE_OK;
 }
 
+// The layout built on the device from X by rows in device memory (psell_device.hip).  done = false (and POLEE_OK): the matrix
+// is the host builder's case -- a real share of fragments without any structure.
+static polee_status loglik_create_on_device(polee_ctx *ctx, const PsellDevIn &X, bool has_ks, polee_loglik **out, bool &done)
+{
+    done = false;
+    polee_loglik *ll = new (std::nothrow) polee_loglik();
+    if (!ll) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+    ll->ctx = ctx;
+    ctx_retain(ctx);
+    ll->m = X.m;
+    ll->n = X.n;
+    ll->has_ks = has_ks;
+    PsellDevOut D;
+    bool needs_host = false;
+    polee_status st = psell_device_build(ctx, X, ll->host, D, false, needs_host);
+    if (st != POLEE_OK || needs_host) {
+        loglik_release(ll);
+        return st;
+    }
+    ll->nnz = ll->host.nnz;
+    ll->device_built = true;
+    ll->d_data.take(D.data);
+    if (has_ks) ll->d_slice_ks.take(D.slice_ks);
+    done = true;
+    return loglik_finish_create(ctx, ll, out);
+}
+
 static polee_status polee_loglik_create_from_xt_impl(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
                                          const uint32_t *trowval, const float *tnzval, const int64_t *ks,
                                          polee_loglik **out)
@@ -2712,6 +2741,16 @@ static polee_status polee_loglik_create_from_xt_impl(polee_ctx *ctx, int64_t m, 
     if (tcolptr[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "tcolptr[0] must be 1 (1-based)");
     const uint64_t nnz = tcolptr[m] - 1;
     const double t_begin = wall_now();
+    if (psell_device_enabled() && nnz < (1ull << 32) - 1 && m < ((int64_t)1 << 32) - 1) {
+        polee_status st = POLEE_OK;
+        bool done = false;
+        {
+            PsellDevCSR C;
+            if ((st = psell_device_rows_from_xt(ctx, m, n, tcolptr, trowval, tnzval, ks, false, C)) != POLEE_OK) return st;
+            st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+        }
+        if (st != POLEE_OK || done) return st;
+    }
     // (0-based copies; vectors that do not zero-fill a gigabyte first, filled on several threads)
     std::vector<uint64_t, default_init_allocator<uint64_t>> rowptr(m + 1);
     parallel_chunks((size_t)m + 1, (size_t)1 << 20, [&](size_t lo, size_t hi, unsigned) {
@@ -2763,6 +2802,19 @@ static polee_status polee_loglik_create_impl(polee_ctx *ctx, int64_t m, int64_t 
     RawVec<float> val;
     static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
     const double t_begin = wall_now();
+    if (psell_device_enabled()) {
+        polee_status st = POLEE_OK;
+        bool done = false;
+        {
+            PsellDevCSR C;
+            bool needs_host = false;
+            if ((st = psell_device_rows_from_csc(ctx, m, n, colptr, colptr_bytes, rowval, nzval, ks, C, needs_host)) != POLEE_OK) return st;
+            if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "X onto the device, by rows", wall_now() - t_begin);
+            if (!needs_host) st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+        }
+        if (timing && done) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "total (device build)", wall_now() - t_begin);
+        if (st != POLEE_OK || done) return st;
+    }
     std::string err = csc_to_csr(m, n, colptr, colptr_bytes, rowval, nzval, rowptr, col, val);
     if (timing) fprintf(stderr, "[loglik create] %-28s %.3f s\n", "CSC -> rows", wall_now() - t_begin);
     if (!err.empty()) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: %s", err.c_str());

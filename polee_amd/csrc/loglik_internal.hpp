@@ -176,6 +176,7 @@ struct polee_loglik {
     int refs = 1;
     int64_t m = 0, n = 0, nnz = 0;
     bool has_ks = false;
+    bool device_built = false;  // the slice stream was laid out on the device (psell_device.hip)
     bool force_mixed = false;  // debug: process every slice with the mixed-slice kernel
     bool xwin_ready = false;   // (per call) the x windows are already filled
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging

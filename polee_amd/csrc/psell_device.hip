@@ -6,6 +6,7 @@
 // What is sequential in the host builder stays sequential here, one WAVE per independent piece (a segment of a stream in
 // stage 3), with the 64 lanes spread over the transcripts of a set; everything per row, per slice and per byte is parallel.
 #include <cstring>
+#include <chrono>
 #include <cstdio>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -1744,6 +1745,216 @@ polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const Psel
     }
     for (int64_t s = 0; s < out.num_slices_a; ++s)
         if (!(out.slice_flags[s] & 1)) return fail(ctx, POLEE_ERR_HIP, "internal error: non-uniform slice in the uniform stream");
+    return POLEE_OK;
+}
+
+// ================================================================= INPUT ====================================================
+namespace {
+
+__global__ void s0_minus1_u64_kernel(uint64_t N, const uint64_t *in, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = in[i] - 1u;
+}
+__global__ void s0_minus1_u32_kernel(uint64_t N, const uint32_t *in, uint32_t *out, uint32_t *err)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (in[i] < 1) atomicMax(err, 1u);
+    out[i] = in[i] - 1u;
+}
+// X by columns (CSC, 1-based) -> by rows: entries counted per row, a STABLE sort by row keeps a row's transcripts ascending
+__global__ void s0_rowkeys_kernel(uint64_t nnz, uint64_t m, const uint32_t *rowval, uint32_t *key, uint32_t *idx, uint32_t *counts, uint32_t *err)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const uint32_t r = rowval[k];
+    if (r < 1 || (uint64_t)r > m) {
+        atomicMax(err, 1u);
+        key[k] = 0;
+        idx[k] = (uint32_t)k;
+        return;
+    }
+    key[k] = r - 1u;
+    idx[k] = (uint32_t)k;
+    atomicAdd(&counts[r - 1u], 1u);
+}
+__global__ void s0_gather_kernel(uint64_t nnz, int64_t n, const uint64_t *colptr, const uint32_t *idx, const float *nzval, uint32_t *col, float *val)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    const uint32_t k = idx[i];
+    // the transcript j with colptr[j] - 1 <= k < colptr[j + 1] - 1
+    int64_t lo = 0, hi = n;  // first j with colptr[j] - 1 > k, minus one
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (colptr[mid] - 1u <= (uint64_t)k) lo = mid + 1; else hi = mid;
+    }
+    col[i] = (uint32_t)(lo - 1);
+    val[i] = nzval[k];
+}
+
+}  // namespace
+
+bool psell_device_enabled()
+{
+    static const bool on = [] {
+        if (const char *e = getenv("POLEE_DEVICE_BUILD")) return atoi(e) != 0;
+        // the host builder's experiment knobs are the host builder's
+        for (const char *k : {"POLEE_PSELL_BINSH", "POLEE_PSELL_NO_SINGLES", "POLEE_PSELL_NO_RUNS", "POLEE_PSELL_MIN_UNIFORM", "POLEE_PSELL_NO_UNION",
+                              "POLEE_PSELL_NO_MASK", "POLEE_PSELL_MASK_GAIN", "POLEE_PSELL_OVER_BUDGET", "POLEE_PSELL_RELAX", "POLEE_PSELL_RELAX0",
+                              "POLEE_PSELL_MAX_GROUP", "POLEE_PSELL_MERGE_MASKED", "POLEE_PSELL_INTERLEAVE", "POLEE_PSELL_NO_BN", "POLEE_PSELL_NO_CSR",
+                              "POLEE_PSELL_CSR_MIN_SHARE", "POLEE_TILE_PER_WG"})
+            if (getenv(k)) return false;
+        return true;
+    }();
+    return on;
+}
+
+polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr, const uint32_t *trowval, const float *tnzval,
+                                       const int64_t *ks, bool on_device, PsellDevCSR &C)
+{
+    hipStream_t stream = ctx->stream;
+    C.m = m;
+    C.n = n;
+    uint64_t last = 0;
+    if (on_device) {
+        PD_HIP(hipMemcpyAsync(&last, tcolptr + m, 8, hipMemcpyDeviceToHost, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+    } else {
+        last = tcolptr[m];
+    }
+    const uint64_t nnz = last - 1;
+    DevBuf<uint64_t> up_ptr;
+    DevBuf<uint32_t> up_col, err;
+    const uint64_t *d_ptr = tcolptr;
+    const uint32_t *d_col = trowval;
+    if (!on_device) {
+        POLEE_TRY(up_ptr.upload(ctx, tcolptr, (size_t)m + 1));
+        POLEE_TRY(up_col.upload(ctx, trowval, (size_t)nnz));
+        POLEE_TRY(C.val.upload(ctx, tnzval, (size_t)nnz));
+        C.val_ptr = C.val.p;
+        d_ptr = up_ptr.p;
+        d_col = up_col.p;
+    } else {
+        C.val_ptr = tnzval;
+    }
+    if (ks) {
+        if (on_device) C.ks_ptr = ks;
+        else {
+            POLEE_TRY(C.ks.upload(ctx, ks, (size_t)m));
+            C.ks_ptr = C.ks.p;
+        }
+    }
+    POLEE_TRY(C.rowptr.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(C.col.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(err.alloc(ctx, 1));
+    PD_HIP(hipMemsetAsync(err.p, 0, 4, stream));
+    hipLaunchKernelGGL(s0_minus1_u64_kernel, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, stream, (uint64_t)m + 1, d_ptr, C.rowptr.p);
+    POLEE_KERNEL_CHECK(ctx);
+    if (nnz) {
+        hipLaunchKernelGGL(s0_minus1_u32_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, d_col, C.col.p, err.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    uint32_t h_err = 0;
+    PD_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (h_err) return fail(ctx, POLEE_ERR_BAD_ARG, "trowval must be 1-based");
+    return POLEE_OK;
+}
+
+polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                        const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host)
+{
+    hipStream_t stream = ctx->stream;
+    needs_host = false;
+    C.m = m;
+    C.n = n;
+    if (colptr_bytes != 4 && colptr_bytes != 8) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr_bytes must be 4 or 8");
+    std::vector<uint64_t> cp((size_t)n + 1);
+    for (int64_t j = 0; j <= n; ++j)
+        cp[(size_t)j] = colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j] : reinterpret_cast<const uint64_t *>(colptr)[j];
+    if (cp[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr[0] must be 1 (1-based)");
+    for (int64_t j = 0; j < n; ++j)
+        if (cp[(size_t)j + 1] < cp[(size_t)j]) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr is not monotone");
+    const uint64_t nnz = cp[(size_t)n] - 1;
+    if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1) {
+        needs_host = true;
+        return POLEE_OK;
+    }
+    if (nnz > 0 && m < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: rowval out of range");
+    if (ks) {
+        POLEE_TRY(C.ks.upload(ctx, ks, (size_t)m));
+        C.ks_ptr = C.ks.p;
+    }
+    POLEE_TRY(C.rowptr.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(C.col.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(C.val.alloc(ctx, (size_t)nnz + 1));
+    C.val_ptr = C.val.p;
+    if (nnz == 0) {
+        PD_HIP(hipMemsetAsync(C.rowptr.p, 0, ((size_t)m + 1) * 8, stream));
+        PD_HIP(hipStreamSynchronize(stream));
+        return POLEE_OK;
+    }
+    Scratch tmp;
+    DevBuf<uint64_t> d_cp;
+    DevBuf<uint32_t> d_rowval, key, key_s, idx, idx_s, counts, err;
+    DevBuf<float> d_nzval;
+    POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
+    POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
+    POLEE_TRY(d_nzval.upload(ctx, nzval, (size_t)nnz));
+    POLEE_TRY(key.alloc(ctx, (size_t)nnz));
+    POLEE_TRY(idx.alloc(ctx, (size_t)nnz));
+    POLEE_TRY(counts.alloc(ctx, (size_t)m + 1));
+    POLEE_TRY(err.alloc(ctx, 1));
+    PD_HIP(hipMemsetAsync(counts.p, 0, ((size_t)m + 1) * 4, stream));
+    PD_HIP(hipMemsetAsync(err.p, 0, 4, stream));
+    hipLaunchKernelGGL(s0_rowkeys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, (uint64_t)m, d_rowval.p, key.p, idx.p, counts.p,
+                       err.p);
+    POLEE_KERNEL_CHECK(ctx);
+    uint32_t h_err = 0;
+    PD_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, stream));
+    PD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(counts.p, ToU64()), C.rowptr.p, (uint64_t)0, (size_t)m + 1, stream));
+    PD_HIP(hipStreamSynchronize(stream));
+    if (h_err) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: rowval out of range");
+    d_rowval.release();
+    counts.release();
+    POLEE_TRY(key_s.alloc(ctx, (size_t)nnz));
+    POLEE_TRY(idx_s.alloc(ctx, (size_t)nnz));
+    unsigned bits = 1;
+    while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)m) ++bits;
+    {
+        size_t bytes = 0;
+        PD_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, idx.p, idx_s.p, (size_t)nnz, 0, bits, stream));
+        PD_HIP(tmp.need(bytes));
+        PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, idx.p, idx_s.p, (size_t)nnz, 0, bits, stream));
+    }
+    hipLaunchKernelGGL(s0_gather_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, n, d_cp.p, idx_s.p, d_nzval.p, C.col.p, C.val.p);
+    POLEE_KERNEL_CHECK(ctx);
+    PD_HIP(hipStreamSynchronize(stream));
+    return POLEE_OK;
+}
+
+// all three stages on the device.  needs_host: the layout is the host builder's to make (see psell_device_stage2).
+polee_status psell_device_build(polee_ctx *ctx, const PsellDevIn &X, PsellHost &out, PsellDevOut &D, bool want_debug, bool &needs_host)
+{
+    static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[psell device build] %-22s %.3f s\n", what, now() - t0);
+        t0 = now();
+    };
+    PsellDevRuns R;
+    PsellDevRowsOwned W;
+    POLEE_TRY(psell_device_stage1(ctx, X, out, R, want_debug));
+    lap("keys / sort / runs");
+    POLEE_TRY(psell_device_stage2(ctx, X, R, out, W, needs_host));
+    lap("packing");
+    if (needs_host) return POLEE_OK;
+    R.a1_rows.release(); R.a1_ends.release(); R.a2_rows.release(); R.a2_ends.release(); R.rb.release();
+    POLEE_TRY(psell_device_stage3(ctx, X, W.view(), out, D, want_debug));
+    lap("slices and tiles");
     return POLEE_OK;
 }
 

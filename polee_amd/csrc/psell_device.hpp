@@ -11,6 +11,21 @@ struct PsellDevIn {  // X by rows (CSR, 0-based) in device memory
     const int64_t *ks = nullptr;  // or null
     int64_t m = 0, n = 0;
 };
+struct PsellDevCSR {  // X by rows, owned (val / ks may be borrowed from the caller's device arrays)
+    DevBuf<uint64_t> rowptr;
+    DevBuf<uint32_t> col;
+    DevBuf<float> val;
+    DevBuf<int64_t> ks;
+    const float *val_ptr = nullptr;
+    const int64_t *ks_ptr = nullptr;
+    int64_t m = 0, n = 0;
+    PsellDevIn view() const
+    {
+        PsellDevIn v;
+        v.rowptr = rowptr.p; v.col = col.p; v.val = val_ptr; v.ks = ks_ptr; v.m = m; v.n = n;
+        return v;
+    }
+};
 struct PsellDevRows {  // PsellRows in device memory
     const uint32_t *rows = nullptr, *run_end = nullptr, *gid = nullptr;
     const uint8_t *form = nullptr;
@@ -58,5 +73,15 @@ polee_status psell_device_rows_to_host(polee_ctx *ctx, const PsellDevRowsOwned &
 // in D -- and are copied into out.data / row_order / slice_ks as well with want_debug.
 polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const PsellDevRows &W, PsellHost &out, PsellDevOut &D,
                                  bool want_debug);
+
+// the input onto the device, by rows: from X by columns (host arrays, 1-based: polee_loglik_create's arguments; a stable sort by
+// row on the device) or from Xt (1-based; host arrays, or device arrays: an xbuild result)
+polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                        const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host);
+polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr, const uint32_t *trowval, const float *tnzval,
+                                       const int64_t *ks, bool on_device, PsellDevCSR &C);
+// POLEE_DEVICE_BUILD=0 turns the device builder off; so does any of the host builder's experiment knobs
+bool psell_device_enabled();
+polee_status psell_device_build(polee_ctx *ctx, const PsellDevIn &X, PsellHost &out, PsellDevOut &D, bool want_debug, bool &needs_host);
 
 }  // namespace polee
