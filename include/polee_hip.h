@@ -128,6 +128,14 @@ polee_status polee_inv_hsb_grad(polee_ptt *t, const double *y_grad, const float 
 polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr,
                                  int colptr_bytes, const uint32_t *rowval, const float *nzval,
                                  const int64_t *ks_or_null, polee_loglik **out);
+/* WHERE the device layout is built.  By default on the DEVICE (csrc/psell_device.hip): X is uploaded as given, transposed there
+ * (a stable sort by fragment) and laid out by kernels that follow the host builder (csrc/psell_build.cpp) stage by stage -- byte
+ * for byte the same layout (tests/test_gpu_device_build.py; 0.21 s at 20 M fragments x 200 k transcripts, against 0.73 s for the
+ * host builder + upload).  The host builder takes over for a matrix without structure (a tenth of its non-zeros or more in
+ * fragments that share no transcript set with their neighbours: stream C's question is sequential over all of them), for more
+ * than 2^32 - 2 non-zeros, and when POLEE_DEVICE_BUILD=0 or one of its own experiment knobs (POLEE_PSELL_*) is set.
+ * polee_loglik_built_on_device: 1 / 0 for a handle. */
+int polee_loglik_built_on_device(const polee_loglik *ll);
 /* Same sample given as Xt (n x m CSC == X in CSR), which the reference materialises
  * anyway (likelihood-approximation.jl:407): tcolptr [m+1] uint64 1-based row offsets,
  * trowval [nnz] 1-based transcript ids. */
@@ -603,6 +611,9 @@ polee_status polee_xbuild_sizes(const polee_xbuild *xb, int64_t *rows, int64_t *
 /* copies the result to host arrays (any pointer may be NULL) */
 polee_status polee_xbuild_get(const polee_xbuild *xb, uint64_t *tcolptr, uint32_t *trowval, float *tnzval,
                               float *effective_lengths, int64_t *row_fragment);
+/* The likelihood handle straight from an xbuild result, without X leaving the device: rows_to_device -> layout kernels
+ * (as polee_loglik_create_from_xt on polee_xbuild_get's arrays; ks_or_null: host array [rows]).  The xbuild handle stays valid. */
+polee_status polee_loglik_create_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, const int64_t *ks_or_null, polee_loglik **out);
 
 #ifdef __cplusplus
 }

@@ -696,6 +696,8 @@ function DeviceSampleFromXt(ctx::Context, m, n, tcolptr::Vector{UInt64}, trowval
               ctx.h, m, n, tcolptr, trowval, tnzval, ks === nothing ? C_NULL : pointer(ks), r), ctx.h)
     return wrap_sample(r[], ctx, m, n)
 end
+"true: the device layout of this sample was built by the device builder (csrc/psell_device.hip); false: by the host builder"
+built_on_device(s) = ccall((:polee_loglik_built_on_device, LIB), Cint, (Ptr{Cvoid},), s.h) != 0
 "adopts a polee_loglik handle (DeviceSample's inner constructor always builds from CSC)"
 function wrap_sample(h::Ptr{Cvoid}, ctx::Context, m, n)
     s = DeviceSampleHandle(h, ctx, Int(m), Int(n))
@@ -860,7 +862,7 @@ m2_right, m1_is_flag16, cig1_ptr, cig2_ptr, cig_op, cig_len) in the layout of in
 as transcripts.jl:288-297 orders them).  Returns (tcolptr, trowval, tnzval, effective_lengths, row_fragment): the rows of X.
 """
 function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::Vector{Float32}, median::Integer;
-                                 strand_specificity::Real=0.9, alt_frag_model::Bool=false)
+                                 strand_specificity::Real=0.9, alt_frag_model::Bool=false, return_sample::Bool=false)
     n = length(T.seq); m = length(F.seq)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve T F pmf cdf begin
@@ -882,6 +884,11 @@ function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::
         GC.@preserve tcolptr trowval tnzval efflens rowfrag check(
             ccall((:polee_xbuild_get, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int64}),
                   h, tcolptr, trowval, tnzval, efflens, rowfrag), ctx.h)
+        if return_sample  # the likelihood handle straight from the result on the device (X never visits the host on its way in)
+            r = Ref{Ptr{Cvoid}}(C_NULL)
+            check(ccall((:polee_loglik_create_from_xbuild, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ref{Ptr{Cvoid}}), ctx.h, h, C_NULL, r), ctx.h)
+            return tcolptr, trowval, tnzval, efflens, rowfrag, wrap_sample(r[], ctx, rows[], n)
+        end
         return tcolptr, trowval, tnzval, efflens, rowfrag
     finally
         ccall((:polee_xbuild_destroy, LIB), Cvoid, (Ptr{Cvoid},), h)

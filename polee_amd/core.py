@@ -187,14 +187,16 @@ class RNASeqSample:
     colptr/rowval exactly as in the likelihood-matrix HDF5, :505-519) + effective_lengths,
     resident on the GPU.  `ks` = row multiplicities for the factored likelihood."""
 
-    def __init__(self, m, n, colptr, rowval, nzval, effective_lengths=None, ks=None, ctx=None, xt=None):
+    def __init__(self, m, n, colptr, rowval, nzval, effective_lengths=None, ks=None, ctx=None, xt=None, _xbuild=None):
         self.ctx = ctx or default_context()
         self.m, self.n = int(m), int(n)
         self.effective_lengths = None if effective_lengths is None else arr(effective_lengths, np.float32)
         self._h = C.c_void_p()
         self._csc = None
         ks_a = None if ks is None else arr(ks, np.int64)
-        if xt is not None:
+        if _xbuild is not None:  # an xbuild result, still on the device (polee_amd.xbuild.build_likelihood_matrix(return_sample=True))
+            check(L.lib().polee_loglik_create_from_xbuild(self.ctx._h, _xbuild, ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
+        elif xt is not None:
             tp, tr, tv = arr(xt[0], np.uint64), arr(xt[1], np.uint32), arr(xt[2], np.float32)
             check(L.lib().polee_loglik_create_from_xt(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n), ptr(tp, u64p),
                                                       ptr(tr, u32p), ptr(tv, f32p), ptr(ks_a, i64p),
@@ -218,6 +220,11 @@ class RNASeqSample:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+    @property
+    def built_on_device(self):
+        """True when the device layout was built by the device builder (csrc/psell_device.hip), False: by the host builder."""
+        return bool(L.lib().polee_loglik_built_on_device(self._h))
 
     def set_deterministic(self, on=True):
         """Fixed-order (bitwise reproducible) gradient sums instead of float atomics (polee_loglik_set_deterministic)."""

@@ -2785,6 +2785,48 @@ static polee_status polee_loglik_create_from_xt_impl(polee_ctx *ctx, int64_t m, 
     return loglik_finish_create(ctx, ll, out);
 }
 
+int polee_loglik_built_on_device(const polee_loglik *ll) { return ll && ll->device_built ? 1 : 0; }
+
+static polee_status polee_loglik_create_from_xbuild_impl(polee_ctx *ctx, const polee_xbuild *xb, const int64_t *ks, polee_loglik **out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!xb || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_xbuild: null argument");
+    polee_ctx *xctx = nullptr;
+    int64_t m = 0, n = 0;
+    const uint64_t *tcolptr = nullptr;
+    const uint32_t *trowval = nullptr;
+    const float *tnzval = nullptr;
+    POLEE_TRY(xbuild_device_view(xb, &xctx, &m, &n, &tcolptr, &trowval, &tnzval));
+    if (xctx->device != ctx->device) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_xbuild: the xbuild result lives on another device");
+    POLEE_HIP_TRY(ctx, hipStreamSynchronize(xctx->stream));
+    bool done = false;
+    polee_status st = POLEE_OK;
+    if (psell_device_enabled() && m < ((int64_t)1 << 32) - 1) {
+        PsellDevCSR C;
+        DevBuf<int64_t> d_ks;
+        if (ks) POLEE_TRY(d_ks.upload(ctx, ks, (size_t)m));
+        if ((st = psell_device_rows_from_xt(ctx, m, n, tcolptr, trowval, tnzval, ks ? d_ks.p : nullptr, true, C)) != POLEE_OK) return st;
+        st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+        if (st != POLEE_OK || done) return st;
+    }
+    // the host builder's case: through the host arrays
+    std::vector<uint64_t> h_ptr((size_t)m + 1);
+    POLEE_HIP_TRY(ctx, hipMemcpy(h_ptr.data(), tcolptr, ((size_t)m + 1) * 8, hipMemcpyDeviceToHost));
+    const size_t nnz = (size_t)(h_ptr[(size_t)m] - 1);
+    std::vector<uint32_t> h_col(nnz);
+    std::vector<float> h_val(nnz);
+    if (nnz) {
+        POLEE_HIP_TRY(ctx, hipMemcpy(h_col.data(), trowval, nnz * 4, hipMemcpyDeviceToHost));
+        POLEE_HIP_TRY(ctx, hipMemcpy(h_val.data(), tnzval, nnz * 4, hipMemcpyDeviceToHost));
+    }
+    return polee_loglik_create_from_xt(ctx, m, n, h_ptr.data(), h_col.data(), h_val.data(), ks, out);
+}
+
+polee_status polee_loglik_create_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, const int64_t *ks, polee_loglik **out)
+{
+    return guarded(ctx, "polee_loglik_create_from_xbuild", [&] { return polee_loglik_create_from_xbuild_impl(ctx, xb, ks, out); });
+}
+
 polee_status polee_loglik_create_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr,
                                          const uint32_t *trowval, const float *tnzval, const int64_t *ks,
                                          polee_loglik **out)

@@ -171,6 +171,13 @@ struct LoglikRemap {
 };
 }  // namespace polee
 
+struct polee_xbuild;
+namespace polee {
+// xbuild.hip: the result of an xbuild run where it lies (Xt, 1-based, device memory)
+polee_status xbuild_device_view(const polee_xbuild *xb, polee_ctx **ctx, int64_t *rows, int64_t *n, const uint64_t **tcolptr,
+                                const uint32_t **trowval, const float **tnzval);
+}  // namespace polee
+
 struct polee_loglik {
     polee_ctx *ctx = nullptr;
     int refs = 1;

@@ -601,6 +601,21 @@ struct polee_xbuild {
     double ms_efflen = 0, ms_count = 0, ms_fill = 0;
 };
 
+namespace polee {
+polee_status xbuild_device_view(const polee_xbuild *xb, polee_ctx **ctx, int64_t *rows, int64_t *n, const uint64_t **tcolptr,
+                                const uint32_t **trowval, const float **tnzval)
+{
+    if (!xb) return fail(nullptr, POLEE_ERR_BAD_ARG, "null xbuild handle");
+    *ctx = xb->ctx;
+    *rows = xb->rows;
+    *n = xb->n;
+    *tcolptr = xb->d_tcolptr.p;
+    *trowval = xb->d_cols.p;
+    *tnzval = xb->d_vals.p;
+    return POLEE_OK;
+}
+}  // namespace polee
+
 extern "C" {
 
 static polee_status polee_xbuild_run_impl(polee_ctx *ctx, const polee_xb_transcripts *T, const polee_xb_fragments *F, const polee_xb_fragmodel *M,

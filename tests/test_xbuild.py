@@ -107,7 +107,7 @@ def test_device_matches_oracle(n, m, alt, seed):
     pmf, cdf, med = synth_aln.fraglen_model(180.0, 60.0)
     Ts, Fs, Ms, keep = XB.pack(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt)
     o = OX.build(Ts, Fs, Ms, n)
-    g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt, ctx=ctx)
+    g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt, ctx=ctx, return_sample=True)
     assert g["m"] == o["m"] and g["nnz"] == o["nnz"] and g["m"] > 0.8 * m
     np.testing.assert_array_equal(g["row_fragment"], o["row_fragment"])
     np.testing.assert_array_equal(g["tcolptr"], o["tcolptr"])
@@ -124,10 +124,15 @@ def test_device_matches_oracle(n, m, alt, seed):
     so = O.Sample(g["m"], n, (X.indptr + 1).astype(np.uint64), (X.indices + 1).astype(np.uint32), X.data.astype(np.float32))
     x = np.clip(np.random.default_rng(0).dirichlet(np.ones(n), size=2), 1e-10, 1).astype(np.float32)
     lp, grad = s.log_likelihood(x)
+    # (... without visiting the host: polee_loglik_create_from_xbuild lays the result out where xbuild left it)
+    sd = g["sample"]
+    assert sd.built_on_device and sd.info["nnz"] == g["nnz"]
+    lpd, gradd = sd.log_likelihood(x)
     for k in range(2):
         lpo, go = so.log_likelihood(x[k])
-        assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo)
+        assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo) and abs(lpd[k] - lpo) <= 1e-6 * abs(lpo)
         np.testing.assert_allclose(grad[k], go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
+        np.testing.assert_allclose(gradd[k], go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
 
 
 def _bam_order(F, rng):
