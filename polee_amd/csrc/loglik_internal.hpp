@@ -87,6 +87,9 @@ constexpr int PSELL_TILE_SLICES_A2M = 16;
 constexpr int PSELL_TILE_SLICES_BN = 64;
 constexpr uint32_t psell_row_pos(int stream, uint32_t t, uint32_t r) { return stream == PSELL_A1 ? (r ^ (t & 3u)) : (stream == PSELL_A2 ? ((r + 4u * t) & 63u) : r); }
 constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice past its union (0x8000xxxx is a finite float)
+// leftover rows are packed in independent chunks of this many candidates (host: a thread each; device: a WAVE each, whose walk is
+// bound by instruction latency -- 4 096 rows give BASELINE's C2 a few thousand waves; a group is cut once per chunk: 0.02 % of them)
+constexpr uint32_t PSELL_PACK_CHUNK = 1u << 12;
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 

@@ -379,8 +379,9 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                     for (size_t q = 0; q < next_pool.size(); ++q) pool[q] = next_pool[i3[q]];
                     next_pool.clear();
                 }
-                // (chunks of 32 768 candidate rows are packed independently on several threads and joined in order: a
-                // group never spans two chunks, and the result does not depend on the number of threads)
+                // (chunks of PSELL_PACK_CHUNK candidate rows are packed independently on several threads -- on the device: one
+                // wave each, psell_device.hip -- and joined in order: a group never spans two chunks, and the result does not
+                // depend on the number of threads)
                 double pool_csr_bytes = 0.0;
                 for (uint32_t r : pool) pool_csr_bytes += 8.0 * (double)(rowptr[r + 1] - rowptr[r]) + 4.0;
                 const double matrix_csr_bytes = 8.0 * (double)rowptr[m] + 4.0 * (double)m;
@@ -389,7 +390,7 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                     BVec<uint32_t> left;
                     std::vector<BVec<uint32_t>> pats;  // the sets of this part's groups (RowList::gid is local to the part)
                 };
-                const size_t UCH = (size_t)1 << 15;
+                const size_t UCH = (size_t)PSELL_PACK_CHUNK;
                 const size_t nup = std::max<size_t>(1, (pool.size() + UCH - 1) / UCH);
                 std::vector<UPart> uparts(nup);
                 parallel_chunks(nup, 1, [&](size_t ulo, size_t uhi, unsigned) {

@@ -918,7 +918,7 @@ polee_status psell_device_runs_to_host(polee_ctx *ctx, const PsellDevRuns &R, Ps
 // ================================================================= STAGE 2 ==================================================
 namespace {
 
-constexpr uint32_t S2_CHUNK = 1u << 15;  // candidate rows packed independently (psell_build.cpp: UCH)
+constexpr uint32_t S2_CHUNK = PSELL_PACK_CHUNK;  // candidate rows packed independently (psell_build.cpp: UCH)
 constexpr uint32_t S2_MAX_GROUP = 1u << 14;
 
 __device__ inline uint32_t wave_sum_u32(uint32_t v)
@@ -966,6 +966,18 @@ __global__ void s2_poolinfo_kernel(PsellDevIn X, uint32_t N, const uint32_t *pro
     plen[i] = (uint32_t)(X.rowptr[prow[i] + 1] - b);
 }
 
+// LDS hand-over between the lanes of ONE wave (the block is one wave): DS operations of a wave execute in order, so only the
+// compiler has to be kept from moving them -- no wait on the vector-memory counter, which would also wait for the row that is
+// being prefetched
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
 struct S2Pack {
     const uint32_t *col;
     const uint32_t *prow, *plen;
@@ -983,24 +995,36 @@ struct S2Pack {
 __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
 {
 #pragma clang fp contract(off)
-    __shared__ uint32_t sA[PSELL_WIDE_MAX], sB[PSELL_WIDE_MAX], srow[PSELL_WIDE_MAX], snew[PSELL_WIDE_MAX];
+    __shared__ uint32_t smerge[PSELL_LANES];
+    constexpr uint32_t GL = 256;  // rows of the open group held in LDS (id and length); longer groups continue in global memory
+    __shared__ uint32_t g_row[GL], g_len[GL];
     const uint32_t lane = lane_id();
     const uint32_t p0 = blockIdx.x * S2_CHUNK, p1 = min(P.Np, p0 + S2_CHUNK);
-    uint32_t *uni = sA, *tmp = sB;
+    uint32_t u_reg = 0xffffffffu;  // the open group's union, ascending: lane j holds its j-th transcript (j < nu)
     uint32_t nu = 0, gs = 0, emitted = 0, npat = 0, pat_off = 0, nd = 0;
     const double relax = 2.0, relax0 = 2.0, mask_gain = 0.5;
     double allowance = (8.0 * (double)(P.plps[p1] - P.plps[p0]) + 4.0 * (double)(p1 - p0)) * P.factor;
     const uint64_t pat_base = P.plps[p0];
     auto close_group = [&]() {
         if (gs == 0) return;
-        __syncthreads();  // (the group's rows, written by lane 0, to every lane)
+        if (gs > GL) __syncthreads();  // (the group's rows, written by lane 0, to every lane)
+        else WAVE_LDS_SYNC();
         const bool narrow = nu <= (uint32_t)PSELL_NARROW_MAX;
         const uint32_t pid = npat;
         bool any = false;
         for (uint32_t c0 = 0; c0 < gs; c0 += PSELL_LANES) {
             const uint32_t nrow = min(gs - c0, (uint32_t)PSELL_LANES);
-            const uint32_t q = lane < nrow ? P.gbuf[p0 + c0 + lane] : 0u;
-            const uint32_t l = lane < nrow ? P.plen[q] : 0u;
+            uint32_t l = 0, row = 0;
+            if (lane < nrow) {
+                if (c0 < GL) {
+                    l = g_len[c0 + lane];
+                    row = g_row[c0 + lane];
+                } else {
+                    const uint32_t q = P.gbuf[p0 + c0 + lane];
+                    l = P.plen[q];
+                    row = P.prow[q];
+                }
+            }
             const uint32_t total = wave_sum_u32(l), longest = wave_max_u32(l);
             const double dense_bytes = 256.0 * (double)(nu + 1 + (uint32_t)P.ks_rows);
             const double masked_bytes = 256.0 * (double)(longest + (narrow ? 1u : 2u) + (uint32_t)P.ks_rows);
@@ -1016,20 +1040,20 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
                 const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
                 const uint32_t dest = narrow ? (masked ? 1u : 0u) : (masked ? 3u : 2u);
                 if (lane < nrow) {
-                    P.rec_row[p0 + emitted + lane] = P.prow[q];
+                    P.rec_row[p0 + emitted + lane] = row;
                     P.rec_meta[p0 + emitted + lane] = (uint8_t)(dest | ((lane + 1 == nrow ? 1u : 0u) << 3) | ((masked ? 2u : 1u) << 4));
                     P.rec_gid[p0 + emitted + lane] = pid;
                 }
                 any = true;
             } else if (lane < nrow) {
-                P.rec_row[p0 + emitted + lane] = P.prow[q];
+                P.rec_row[p0 + emitted + lane] = row;
                 P.rec_meta[p0 + emitted + lane] = 4;
                 P.rec_gid[p0 + emitted + lane] = 0;
             }
             emitted += nrow;
         }
         if (any) {
-            if (lane < nu) P.pcols[pat_base + pat_off + lane] = uni[lane];
+            if (lane < nu) P.pcols[pat_base + pat_off + lane] = u_reg;
             if (lane == 0) {
                 P.psize[p0 + pid] = nu;
                 P.poff[p0 + pid] = pat_off;
@@ -1039,61 +1063,90 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
         }
         gs = 0;
         nu = 0;
-        __syncthreads();
+        u_reg = 0xffffffffu;
+        WAVE_LDS_SYNC();
     };
     for (int pass = 0; pass < 2; ++pass) {
         const uint32_t cnt = pass == 0 ? p1 - p0 : nd;
         uint32_t ndn = 0;
-        for (uint32_t qi = 0; qi < cnt; ++qi) {
-            const uint32_t q = pass == 0 ? p0 + qi : P.dbuf[p0 + qi];
-            const uint32_t len = P.plen[q];
-            const uint64_t beg = P.pbeg[q];
-            const uint32_t c = lane < len ? P.col[beg + lane] : 0u;
-            bool found = false;
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < nu; ++j) {
-                const uint32_t u = uni[j];
-                found |= u == c;
-                rank += u < c;
+        // (a block of 64 rows' positions, lengths and offsets sits in the lanes.  The union and the row are compared through
+        // v_readlane with a uniform lane index -- no LDS round trip per element.)
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t nb = min(64u, cnt - base);
+            uint32_t myq = 0, mylen = 0, mybeg_lo = 0, mybeg_hi = 0, myrow = 0;
+            if (lane < nb) {
+                myq = pass == 0 ? p0 + base + lane : P.dbuf[p0 + base + lane];
+                mylen = P.plen[myq];
+                myrow = P.prow[myq];
+                const uint64_t bg = P.pbeg[myq];
+                mybeg_lo = (uint32_t)bg;
+                mybeg_hi = (uint32_t)(bg >> 32);
             }
-            const bool isnew = lane < len && !found;
-            const uint64_t bal = __ballot(isnew);
-            const uint32_t nnew = (uint32_t)__popcll(bal), nt = nu + nnew;
-            if (nt <= P.cap && (gs < (uint32_t)PSELL_LANES || (nt + 3) / 4 == (nu + 3) / 4) && gs < S2_MAX_GROUP) {
-                if (nnew) {
-                    if (lane < PSELL_WIDE_MAX) {
-                        srow[lane] = c;
-                        snew[lane] = isnew;
-                    }
-                    __syncthreads();
-                    if (lane < nu) {
-                        const uint32_t u = uni[lane];
-                        uint32_t before = 0;
-                        for (uint32_t i = 0; i < len; ++i) before += snew[i] && srow[i] < u;
-                        tmp[lane + before] = u;
-                    }
-                    if (isnew) tmp[rank + (uint32_t)__popcll(bal & lanes_below())] = c;
-                    __syncthreads();
-                    uint32_t *sw = uni;
-                    uni = tmp;
-                    tmp = sw;
-                    nu = nt;
+            uint32_t c_next;  // (the NEXT row's transcripts are on their way while the current row is merged)
+            {
+                const uint32_t len0 = rdlane(mylen, 0);
+                const uint64_t beg0 = ((uint64_t)rdlane(mybeg_hi, 0) << 32) | rdlane(mybeg_lo, 0);
+                c_next = lane < len0 ? P.col[beg0 + lane] : 0xffffffffu;
+            }
+            for (uint32_t t = 0; t < nb; ++t) {
+                const uint32_t q = rdlane(myq, t);
+                const uint32_t len = rdlane(mylen, t);
+                const uint32_t row = rdlane(myrow, t);
+                const uint32_t c = c_next;  // lane i < len: the row's i-th transcript
+                if (t + 1 < nb) {
+                    const uint32_t len2 = rdlane(mylen, t + 1);
+                    const uint64_t beg2 = ((uint64_t)rdlane(mybeg_hi, t + 1) << 32) | rdlane(mybeg_lo, t + 1);
+                    c_next = lane < len2 ? P.col[beg2 + lane] : 0xffffffffu;
                 }
-                if (lane == 0) P.gbuf[p0 + gs] = q;
-                ++gs;
-                continue;
+                bool found = false;
+                uint32_t rank = 0;  // transcripts of the union below this lane's
+                for (uint32_t j = 0; j < nu; ++j) {
+                    const uint32_t u = rdlane(u_reg, j);
+                    found |= u == c;
+                    rank += u < c;
+                }
+                const bool isnew = lane < len && !found;
+                const uint64_t bal = __ballot(isnew);
+                const uint32_t nnew = (uint32_t)__popcll(bal), nt = nu + nnew;
+                if (nt <= P.cap && (gs < (uint32_t)PSELL_LANES || (nt + 3) / 4 == (nu + 3) / 4) && gs < S2_MAX_GROUP) {
+                    if (nnew) {
+                        uint32_t before = 0;  // new transcripts below this lane's member of the union
+                        for (uint64_t rest = bal; rest; rest &= rest - 1) {
+                            const uint32_t i = (uint32_t)__builtin_ctzll(rest);
+                            before += rdlane(c, i) < u_reg;
+                        }
+                        if (lane < nu) smerge[lane + before] = u_reg;
+                        if (isnew) smerge[rank + (uint32_t)__popcll(bal & lanes_below())] = c;
+                        WAVE_LDS_SYNC();
+                        u_reg = lane < nt ? smerge[lane] : 0xffffffffu;
+                        WAVE_LDS_SYNC();
+                        nu = nt;
+                    }
+                    if (lane == 0) {
+                        if (gs < GL) {
+                            g_row[gs] = row;
+                            g_len[gs] = len;
+                        } else {
+                            P.gbuf[p0 + gs] = q;
+                        }
+                    }
+                    ++gs;
+                    continue;
+                }
+                if (pass == 0 && gs < 48 && nu + 1 < P.cap) {
+                    if (lane == 0) P.dbuf[p0 + ndn] = q;  // an outlier (a neighbouring gene's isoform): second pass
+                    ++ndn;
+                    continue;
+                }
+                close_group();
+                u_reg = lane < len ? c : 0xffffffffu;
+                nu = len;
+                if (lane == 0) {
+                    g_row[0] = row;
+                    g_len[0] = len;
+                }
+                gs = 1;
             }
-            if (pass == 0 && gs < 48 && nu + 1 < P.cap) {
-                if (lane == 0) P.dbuf[p0 + ndn] = q;  // an outlier (a neighbouring gene's isoform): second pass
-                ++ndn;
-                continue;
-            }
-            close_group();
-            if (lane < len) uni[lane] = c;
-            nu = len;
-            if (lane == 0) P.gbuf[p0] = q;
-            gs = 1;
-            __syncthreads();
         }
         close_group();
         if (pass == 0) nd = ndn;
@@ -1166,6 +1219,21 @@ __global__ void s2_fill_u32_kernel(uint32_t N, uint32_t *p, uint32_t v)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) p[i] = v;
 }
+
+struct DevClock {  // POLEE_BUILD_TIMING=1: phases of the device builder on stderr (each mark waits for the stream)
+    bool on = getenv("POLEE_BUILD_TIMING") != nullptr;
+    hipStream_t stream;
+    double t0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit DevClock(hipStream_t s) : stream(s), t0(now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        (void)hipStreamSynchronize(stream);
+        fprintf(stderr, "[psell device build]   . %-26s %.4f s\n", what, now() - t0);
+        t0 = now();
+    }
+};
 
 struct PackLists {
     DevBuf<uint32_t> rows[4], ends[4], gid[4], left;
@@ -1270,8 +1338,11 @@ polee_status run_pack(polee_ctx *ctx, Scratch &tmp, const PsellDevIn &X, uint64_
     P.rec_row = rec_row.p; P.rec_gid = rec_gid.p; P.rec_meta = rec_meta.p; P.chunk_npats = chunk_npats.p; P.psize = psize.p; P.poff = L.poff.p;
     P.pcols = L.pcols.p; P.gbuf = gbuf.p; P.dbuf = dbuf.p;
     PD_HIP(hipMemsetAsync(chunk_npats.p + nch, 0, 4, stream));
+    DevClock clk(stream);
+    clk.lap("pack: pool info, buffers");
     hipLaunchKernelGGL(s2_pack_kernel, dim3(nch), dim3(64), 0, stream, P);
     POLEE_KERNEL_CHECK(ctx);
+    clk.lap("pack: greedy walk");
     PD_HIP(exclusive_sum(tmp, chunk_npats.p, gbase.p, gid_base, (size_t)nch + 1, stream));
     // the four lists + the rows left
     uint32_t cnt[5];
@@ -1321,6 +1392,7 @@ polee_status run_pack(polee_ctx *ctx, Scratch &tmp, const PsellDevIn &X, uint64_
     PD_HIP(exclusive_sum(tmp, L.pat_sizes.p, L.pat_ptr.p, 0u, (size_t)L.npat + 1, stream));
     PD_HIP(hipMemcpyAsync(&L.pat_cols, L.pat_ptr.p + L.npat, 4, hipMemcpyDeviceToHost, stream));
     PD_HIP(hipStreamSynchronize(stream));
+    clk.lap("pack: lists and patterns");
     return POLEE_OK;
 }
 
@@ -1347,13 +1419,17 @@ polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRu
     POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 0, 0xffu, flag, pos, pool0, n0));
     POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 1, 0xffu, flag, pos, l1, n1));
     POLEE_TRY(select_class(ctx, tmp, cand.p, cls.p, nrb, 2, 0xffu, flag, pos, l2, n2));
+    DevClock clk(stream);
+    clk.lap("candidates sorted, split");
     PackLists P0, P1;
     POLEE_TRY(run_pack(ctx, tmp, X, nnz_total, pool0, n0, (uint32_t)PSELL_NARROW_MAX, 0, 0u, P0));
     DevBuf<uint32_t> np_unsorted, pool1;
     POLEE_TRY(concat2(ctx, l1, n1, P0.left, P0.nleft, np_unsorted));
     const uint32_t np1 = n1 + P0.nleft;
     POLEE_TRY(sort_by_first_col(ctx, tmp, X, np_unsorted.p, np1, pool1));
+    clk.lap("(first pass)");
     POLEE_TRY(run_pack(ctx, tmp, X, nnz_total, pool1, np1, (uint32_t)PSELL_WIDE_MAX, 1, P0.npat, P1));
+    clk.lap("(second pass)");
     // the mixed streams: what found no company, in first-transcript order; BN: rows of <= 15 transcripts, B: the others; inside every
     // block of 1024 rows by descending length
     DevBuf<uint32_t> kb_unsorted, kb, rbn, wide;
@@ -1399,6 +1475,7 @@ polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRu
         needs_host = true;
         return POLEE_OK;
     }
+    clk.lap("mixed streams");
     // ---- the ordered rows of the sliced streams: A1 = exact runs, first-pass unions, second-pass narrow unions; A1M; A2; A2M; BN; B
     const uint32_t nA1 = (uint32_t)R.n_a1 + P0.count[0] + P1.count[0], nA1M = P0.count[1] + P1.count[1];
     const uint32_t nA2 = (uint32_t)R.n_a2 + P0.count[2] + P1.count[2], nA2M = P0.count[3] + P1.count[3];
@@ -1474,6 +1551,7 @@ polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRu
         }
     }
     PD_HIP(hipStreamSynchronize(stream));
+    clk.lap("ordered rows assembled");
     return POLEE_OK;
 }
 
