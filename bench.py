@@ -52,7 +52,7 @@ def source_id():
     `roofline.traffic` is emitted only when it equals this run's."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("loglik.hip", "loglik_internal.hpp", "psell_build.cpp", "wave.hpp", "common.hpp", "Makefile"):
+    for f in ("loglik.hip", "loglik_internal.hpp", "psell_build.cpp", "psell_device.hip", "psell_device.hpp", "wave.hpp", "common.hpp", "Makefile"):
         with open(os.path.join(ROOT, "polee_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
