@@ -322,6 +322,11 @@ polee_status polee_hclust(int64_t m, int64_t n, const void *colptr, int colptr_b
  * arguments, same output arrays. */
 polee_status polee_hclust_parallel(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
                                    int32_t *node_parent_idxs, int32_t *node_js);
+/* The same tree -- node for node the arrays polee_hclust_parallel gives -- built on the DEVICE (csrc/hclust_device.hip): per round the
+ * best live edge of every node by atomic maxima over the priorities, the mutually-best edges sorted by priority, their read
+ * sets united and the similarities to the neighbours of both halves counted by binary searches spread over the whole GPU. */
+polee_status polee_hclust_parallel_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                          const uint32_t *rowval, int32_t *node_parent_idxs, int32_t *node_js);
 
 /* ---- one sample over several GPUs -----------------------------------
  * X's rows (fragments) are sharded over the ranks in contiguous blocks; every rank creates its

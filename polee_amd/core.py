@@ -414,17 +414,23 @@ def host_cache_bytes():
     return int(f())
 
 
-def hclust(m, n, colptr, rowval, parallel=False):
+def hclust(m, n, colptr, rowval, parallel=False, device=False, ctx=None):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],
     i.e. what the prep HDF5 stores and PolyaTreeTransform(...) takes.  Runs on the host, as in the reference.
     parallel=True: the same joining rule in rounds of mutually-best merges on all host threads (polee_hclust_parallel;
-    a documented variant, not the reference's tree node for node)."""
+    a documented variant, not the reference's tree node for node).  device=True: that variant on the GPU
+    (polee_hclust_parallel_device: the same arrays as parallel=True)."""
     colptr = np.ascontiguousarray(colptr)
     if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
         colptr = colptr.astype(np.uint64)
     rowval = arr(rowval, np.uint32)
     parents, js = np.empty(2 * int(n) - 1, np.int32), np.empty(2 * int(n) - 1, np.int32)
+    if device:
+        ctx = ctx or default_context()
+        check(L.lib().polee_hclust_parallel_device(ctx._h, C.c_int64(int(m)), C.c_int64(int(n)), colptr.ctypes.data_as(C.c_void_p),
+                                                   int(colptr.dtype.itemsize), ptr(rowval, u32p), ptr(parents, L.i32p), ptr(js, L.i32p)), ctx._h)
+        return parents, js
     f = L.lib().polee_hclust_parallel if parallel else L.lib().polee_hclust
     check(f(C.c_int64(int(m)), C.c_int64(int(n)), colptr.ctypes.data_as(C.c_void_p), int(colptr.dtype.itemsize),
             ptr(rowval, u32p), ptr(parents, L.i32p), ptr(js, L.i32p)))
@@ -615,8 +621,8 @@ def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=
     tm = approx.treemethod
     with ThreadPoolExecutor(max_workers=1) as pool:
         fut = None
-        if tm in ("cluster", "cluster_parallel"):
-            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel")
+        if tm in ("cluster", "cluster_parallel", "cluster_device"):
+            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", ctx)
         sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx)
         if fut is not None:
             parents, js = fut.result()
@@ -649,6 +655,10 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
             if getattr(sample, "_csc", None) is None:
                 raise ValueError("tree construction needs the sample's CSC arrays")
             parents, js = hclust(sample.m, sample.n, *sample._csc, parallel=True)
+        elif approx.treemethod == "cluster_device":  # (the same variant built on the GPU, polee_hclust_parallel_device)
+            if getattr(sample, "_csc", None) is None:
+                raise ValueError("tree construction needs the sample's CSC arrays")
+            parents, js = hclust(sample.m, sample.n, *sample._csc, device=True, ctx=sample.ctx)
         elif approx.treemethod == "sequential":
             parents, js = list_nodes(sample.n)
         else:

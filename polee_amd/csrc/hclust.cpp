@@ -872,6 +872,20 @@ std::string hclust_build_rounds(int64_t m, int64_t n, const void *colptr, int co
 
 }  // namespace polee
 
+namespace polee {
+std::string hclust_finish_from_arrays(int64_t n, uint32_t num_nodes, const int32_t *left, const int32_t *right, const uint8_t *alive_in,
+                                      const uint32_t *set_len, const uint32_t *leaf_transcript, int32_t *node_parent_idxs, int32_t *node_js)
+{
+    std::vector<TreeNode> nodes(num_nodes);
+    std::vector<char> alive(num_nodes, 0);
+    for (uint32_t j = 1; j < num_nodes; ++j) {
+        nodes[j] = j <= (uint32_t)n ? TreeNode{leaf_transcript[j - 1] + 1, -1, -1} : TreeNode{0, left[j], right[j]};
+        alive[j] = (char)alive_in[j];
+    }
+    return finish_tree(n, nodes, alive, [&](uint32_t j) { return (size_t)set_len[j]; }, node_parent_idxs, node_js);
+}
+}  // namespace polee
+
 //  nothing may unwind through the C ABI: the builders allocate on the calling thread and inside
 // parallel_chunks workers (which hand the first exception back to the caller, common.hpp)
 template <class F>

@@ -8,7 +8,7 @@ Polya tree (hclust, or read it from a `--ptt-tree` file, :428-436), fit the appr
 load_samples_from_specification read.  The ingest that produces X (BAM -> fragments -> X, bias models) stays with
 the reference.
 
-    python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method cluster|cluster_parallel|sequential]
+    python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method cluster|cluster_parallel|cluster_device|sequential]
         [--ptt-tree tree.h5] [--no-efflen-jacobian] [--seed N] [--device D]
 
 `polee prep-salmon` (src/main.jl:723-750): the factored likelihood of `salmon quant -d` output on a given tree:
@@ -79,7 +79,7 @@ def main(argv=None):
     ap.add_argument("--salmon", default=None, metavar="salmon_quant_dir", help="prep-salmon: salmon quant -d output")
     ap.add_argument("--transcript-ids", default=None, metavar="ids.txt", help="with --salmon: transcript ids, tree order")
     ap.add_argument("-o", "--output", default="prepared-sample.h5", metavar="prepared-sample.h5")
-    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "cluster_parallel", "sequential"])
+    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "cluster_parallel", "cluster_device", "sequential"])
     ap.add_argument("--ptt-tree", default=None, metavar="tree.h5", help="use this tree topology (polee fit-tree output)")
     ap.add_argument("--no-efflen-jacobian", action="store_true")
     ap.add_argument("--seed", type=int, default=123456789)
