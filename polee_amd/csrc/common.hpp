@@ -13,6 +13,8 @@
 #include <new>
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,31 +77,151 @@ inline polee_status fail(polee_ctx *ctx, polee_status code, const char *fmt, ...
                                  hipGetErrorString(e__), __FILE__, __LINE__);              \
     } while (0)
 
+// Freed device buffers are KEPT (process-wide, per device, by size class) instead of going back through hipFree: the builders
+// allocate and free hundreds of buffers per sample, hipFree waits for the whole device, and with plain hipMalloc / hipFree every
+// few samples one of the first large allocations of a sample stalled for 2 - 3 s (tools/probe/prep_stages_one.py, 20 samples).
+// A block is given back together with an event recorded on the stream its owner worked on; whoever takes it next waits for
+// that event first (normally long complete) -- what hipFree guaranteed, for that one block only.  (The runtime's own
+// stream-ordered pool, hipMallocAsync, handed out blocks that overlapped live ones here: not used.)
+// POLEE_DEVICE_CACHE_MB: cap of the kept bytes (default 64 GiB; 0 = plain hipMalloc / hipFree); polee_host_cache_trim() frees them.
+class DevBlockCache {
+public:
+    static DevBlockCache &get()
+    {
+        static DevBlockCache *c = new DevBlockCache();  // (never destroyed: buffers may be released during process exit)
+        return *c;
+    }
+    static size_t size_class(size_t bytes)
+    {
+        if (bytes <= 4096) return 4096;
+        int p = 63 - __builtin_clzll((unsigned long long)bytes);
+        const size_t step = (size_t)1 << (p - 3);
+        return (bytes + step - 1) / step * step;
+    }
+    // a kept block of exactly this class on this device, or null
+    void *take(int device, size_t granted)
+    {
+        Block blk;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto range = free_.equal_range(granted);
+            auto it = range.first;
+            for (; it != range.second; ++it)
+                if (it->second.device == device) break;
+            if (it == range.second) return nullptr;
+            blk = it->second;
+            free_.erase(it);
+            kept_ -= granted;
+        }
+        if (blk.ev) {
+            (void)hipEventSynchronize(blk.ev);
+            (void)hipEventDestroy(blk.ev);
+        }
+        return blk.p;
+    }
+    // false: not kept (cache off or full, or the stream is gone) -- the caller frees it
+    bool give(int device, void *p, size_t granted, hipStream_t stream)
+    {
+        if (cap_ == 0 || granted > cap_) return false;
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev) (void)hipEventDestroy(ev);
+            return false;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        if (kept_ + granted > cap_) {
+            (void)hipEventDestroy(ev);
+            return false;
+        }
+        free_.emplace(granted, Block{p, ev, device});
+        kept_ += granted;
+        return true;
+    }
+    void trim()
+    {
+        std::multimap<size_t, Block> all;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            all.swap(free_);
+            kept_ = 0;
+        }
+        for (auto &kv : all) {
+            if (kv.second.ev) {
+                (void)hipEventSynchronize(kv.second.ev);
+                (void)hipEventDestroy(kv.second.ev);
+            }
+            (void)hipFree(kv.second.p);
+        }
+    }
+    size_t kept_bytes()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        return kept_;
+    }
+    bool enabled() const { return cap_ != 0; }
+
+private:
+    struct Block {
+        void *p;
+        hipEvent_t ev;
+        int device;
+    };
+    DevBlockCache()
+    {
+        const char *e = getenv("POLEE_DEVICE_CACHE_MB");
+        cap_ = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
+    }
+    std::mutex mu_;
+    std::multimap<size_t, Block> free_;
+    size_t kept_ = 0, cap_ = 0;
+};
+
 // Device buffer owned by a handle.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t granted = 0;             // bytes of the block behind p (its size class)
+    hipStream_t owner_stream = nullptr;  // the stream its owner works on (an event there marks the block free)
+    int owner_device = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !(granted && DevBlockCache::get().give(owner_device, p, granted, owner_stream))) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        granted = 0;
+        owner_stream = nullptr;
     }
     polee_status alloc(polee_ctx *ctx, size_t count)
     {
         if (count <= n && p) return POLEE_OK;
         release();
         if (count == 0) return POLEE_OK;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            return fail(ctx, POLEE_ERR_OOM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T),
-                        hipGetErrorString(e));
+        const size_t bytes = count * sizeof(T);
+        if (ctx && DevBlockCache::get().enabled()) {
+            granted = DevBlockCache::size_class(bytes);
+            owner_stream = ctx->stream;
+            owner_device = ctx->device;
+            p = static_cast<T *>(DevBlockCache::get().take(ctx->device, granted));
+        }
+        if (!p) {
+            hipError_t e = hipMalloc((void **)&p, granted ? granted : bytes);
+            if (e != hipSuccess && granted) {  // (memory is short: what is kept goes back first)
+                (void)hipGetLastError();
+                DevBlockCache::get().trim();
+                e = hipMalloc((void **)&p, granted);
+            }
+            if (e != hipSuccess) {
+                p = nullptr;
+                granted = 0;
+                (void)hipGetLastError();
+                return fail(ctx, POLEE_ERR_OOM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+            }
         }
         n = count;
         return POLEE_OK;
@@ -109,8 +231,13 @@ struct DevBuf {
         release();
         p = other.p;
         n = other.n;
+        granted = other.granted;
+        owner_stream = other.owner_stream;
+        owner_device = other.owner_device;
         other.p = nullptr;
         other.n = 0;
+        other.granted = 0;
+        other.owner_stream = nullptr;
     }
     polee_status upload(polee_ctx *ctx, const T *host, size_t count)
     {

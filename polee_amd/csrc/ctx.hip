@@ -34,7 +34,11 @@ extern "C" {
 const char *polee_version(void) { return "polee_hip 0.3 (gfx950); " POLEE_BUILD_INFO; }
 
 // the host builders keep their large scratch blocks for the next sample (common.hpp HugeBlockCache)
-void polee_host_cache_trim(void) { polee::HugeBlockCache::get().trim(); }
+void polee_host_cache_trim(void)
+{
+    polee::HugeBlockCache::get().trim();
+    polee::DevBlockCache::get().trim();  // (the kept device buffers too: common.hpp)
+}
 int64_t polee_host_cache_configure(int64_t cap_mb)
 {
     polee::HugeBlockCache &c = polee::HugeBlockCache::get();

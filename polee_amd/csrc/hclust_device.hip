@@ -761,10 +761,12 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
         if (E2.cap < E.cap) POLEE_TRY(E2.alloc(ctx, E.cap));
         hipLaunchKernelGGL(hd_compact_kernel, dim3(grid_for(ne)), dim3(256), 0, stream, ne, E.view(), eflag.p, epos.p, E2.view());
         POLEE_KERNEL_CHECK(ctx);
-        std::swap(E.src.p, E2.src.p); std::swap(E.src.n, E2.src.n);
-        std::swap(E.dst.p, E2.dst.p); std::swap(E.dst.n, E2.dst.n);
-        std::swap(E.sim.p, E2.sim.p); std::swap(E.sim.n, E2.sim.n);
-        std::swap(E.cap, E2.cap);
+        {
+            EdgeStore H;  // E <-> E2 (ownership moves with the blocks)
+            H.src.take(E.src); H.dst.take(E.dst); H.sim.take(E.sim); H.cap = E.cap;
+            E.src.take(E2.src); E.dst.take(E2.dst); E.sim.take(E2.sim); E.cap = E2.cap;
+            E2.src.take(H.src); E2.dst.take(H.dst); E2.sim.take(H.sim); E2.cap = H.cap;
+        }
         ne = nlive;
         if (T) POLEE_TRY(append_edges(ctx, tmp, T, tx.p, ty.p, sim.p, base, E, ne));
         HD_HIP(hipStreamSynchronize(stream));

@@ -62,3 +62,46 @@ def test_fit_on_the_parallel_tree_is_as_good_as_on_the_exact_tree(P, ctx, lm_fix
     assert abs(p - e) <= 2.0 * spread + 2e-6 * abs(e), (e, p, spread)
     # and the criterion can tell trees apart: a random tree loses many times that difference
     assert e - r > 10 * abs(p - e) and e - r > 2 * spread, (e, p, r, spread)
+
+
+def test_device_tree_is_the_host_variants_tree_node_for_node(P, ctx, lm_fixture):
+    """polee_hclust_parallel_device (csrc/hclust_device.hip: the rounds variant as kernels -- best edges by atomic maxima over
+    the total order of priorities, merges numbered in that order, unions and intersection counts by binary searches) against
+    polee_hclust_parallel, whose definition oracle/hclust_ref.py::hclust_rounds pins: the same serialised tree on random matrices
+    with many ties, empty columns and disconnected components (a single transcript, two), on the reference's real-data fixture,
+    on generated samples of every structure, and the same errors for malformed input."""
+    import scipy.sparse as sp
+    from tools import synth
+    rng = np.random.default_rng(8)
+    cases = []
+    for trial, (m, n) in enumerate([(60, 9), (300, 40), (500, 80), (40, 30), (3000, 300), (5, 1), (9, 2), (20000, 1500)]):
+        dens = [0.3, 0.08, 0.05, 0.02, 0.012, 0.5, 0.5, 0.002][trial]
+        X = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csc")
+        X.sort_indices()
+        cases.append((m, n, (X.indptr + 1).astype(np.uint32), (X.indices + 1).astype(np.uint32)))
+    f = lm_fixture
+    cases.append((f["m"], f["n"], f["colptr"], f["rowval"]))
+    for kw in (dict(), dict(literal=True), dict(dropout=0.3)):
+        s = synth.make_sample(6000, 400000, 8.0, 21, **kw)
+        c, r, _ = synth.to_csc(s)
+        cases.append((s["m"], s["n"], c, r))
+    for m, n, colptr, rowval in cases:
+        ph, jh = P.hclust(m, n, colptr, rowval, parallel=True)
+        pd, jd = P.hclust(m, n, colptr, rowval, device=True, ctx=ctx)
+        np.testing.assert_array_equal(ph, pd)
+        np.testing.assert_array_equal(jh, jd)
+    # the treemethod of the approximation
+    s = synth.make_sample(3000, 150000, 8.0, 5)
+    c, r, v = synth.to_csc(s)
+    smp = P.RNASeqSample(s["m"], s["n"], c, r, v, s["effective_lengths"], ctx=ctx)
+    out_h = P.approximate_likelihood(P.LogitSkewNormalPTTApprox("cluster_parallel"), smp, num_steps=30)
+    out_d = P.approximate_likelihood(P.LogitSkewNormalPTTApprox("cluster_device"), smp, num_steps=30)
+    np.testing.assert_array_equal(out_h["node_js"], out_d["node_js"])
+    np.testing.assert_array_equal(out_h["node_parent_idxs"], out_d["node_parent_idxs"])
+    # malformed input: the host variant's messages
+    with pytest.raises(Exception, match="not ascending"):
+        P.hclust(5, 2, np.array([1, 3, 4], np.uint64), np.array([2, 1, 3], np.uint32), device=True, ctx=ctx)
+    with pytest.raises(Exception, match="out of range"):
+        P.hclust(5, 2, np.array([1, 3, 4], np.uint64), np.array([1, 9, 3], np.uint32), device=True, ctx=ctx)
+    with pytest.raises(Exception, match="colptr"):
+        P.hclust(5, 2, np.array([1, 4, 3], np.uint64), np.array([1, 2, 3], np.uint32), device=True, ctx=ctx)

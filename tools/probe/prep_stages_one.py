@@ -10,9 +10,10 @@ smp = synth.make_sample(n, m, 8.0, 123456789, literal=bool(os.environ.get("POLEE
 colptr, rowval, nzval = synth.to_csc(smp)
 eff = smp["effective_lengths"]
 ctx = P.Context(0)
-for rep in range(3):
+for rep in range(int(os.environ.get("POLEE_PREP_REPS", "3"))):
     t = [time.time()]
-    parents, js = P.hclust(m, n, colptr, rowval, parallel=True); t.append(time.time())
+    parents, js = (P.hclust(m, n, colptr, rowval, device=True, ctx=ctx) if os.environ.get("POLEE_PREP_TREE") == "cluster_device"
+                   else P.hclust(m, n, colptr, rowval, parallel=True)); t.append(time.time())
     s = P.RNASeqSample(m, n, colptr, rowval, nzval, eff, ctx=ctx); t.append(time.time())
     tr = P.PolyaTreeTransform(parents, js, ctx=ctx); t.append(time.time())
     fit = P.LikelihoodApproximationFit(s, tr, num_steps=500, num_mc_samples=6, seed=rep); t.append(time.time())
