@@ -401,6 +401,7 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                         // (second pass only) what the part's groups may spend above CSR's cost of their rows, so that a
                         // few fragments without company do not cost a pass the mixed stream's extra launch
                         // (over_budget of the whole matrix's CSR bytes, shared out by the parts' candidate rows)
+                        double wide_allowance = pass_w == 1 ? PSELL_PACK_WIDE_RESERVE : 0.0;
                         double allowance = 0.0;
                         if (pass_w == 1 || relax0 > 1.0) {
                             for (size_t q = p0; q < p1; ++q) allowance += 8.0 * (double)(rowptr[pool[q] + 1] - rowptr[pool[q]]) + 4.0;
@@ -430,9 +431,18 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                                 // for its rows -- mixed tiles of some twenty unrelated fragments each --, and rows too long
                                 // for stream BN are kept at any cost; both within the allowance)
                                 if (!worth && ((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
-                                               (pass_w == 0 && cost <= relax0 * budget)) && cost - budget <= allowance) {
-                                    allowance -= cost - budget;
-                                    worth = true;
+                                               (pass_w == 0 && cost <= relax0 * budget))) {
+                                    const double over = cost - budget;
+                                    if (over <= allowance) {
+                                        allowance -= over;
+                                        worth = true;
+                                    } else if (pass_w == 1 && longest > (size_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
+                                        // (the part's own small reserve for rows too long for stream BN: with parts of 4 096
+                                        // rows the proportional allowance alone left a few hundred of them to stream B -- a
+                                        // launch of its own, 38 us per pass, for 0.003 % of the non-zeros)
+                                        wide_allowance -= over;
+                                        worth = true;
+                                    }
                                 }
                                 if (worth) {
                                     const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;

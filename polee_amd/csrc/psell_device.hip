@@ -1004,6 +1004,7 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
     uint32_t nu = 0, gs = 0, emitted = 0, npat = 0, pat_off = 0, nd = 0;
     const double relax = 2.0, relax0 = 2.0, mask_gain = 0.5;
     double allowance = (8.0 * (double)(P.plps[p1] - P.plps[p0]) + 4.0 * (double)(p1 - p0)) * P.factor;
+    double wide_allowance = P.pass_w == 1 ? PSELL_PACK_WIDE_RESERVE : 0.0;
     const uint64_t pat_base = P.plps[p0];
     auto close_group = [&]() {
         if (gs == 0) return;
@@ -1031,10 +1032,15 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
             const double budget = 8.0 * (double)total + 4.0 * (double)nrow;
             const double cost = fmin(dense_bytes, masked_bytes);
             bool worth = cost <= budget;
-            if (!worth && ((P.pass_w == 1 && (cost <= relax * budget || longest > (uint32_t)PSELL_MIXED_NARROW_MAX)) || (P.pass_w == 0 && cost <= relax0 * budget)) &&
-                cost - budget <= allowance) {
-                allowance -= cost - budget;
-                worth = true;
+            if (!worth && ((P.pass_w == 1 && (cost <= relax * budget || longest > (uint32_t)PSELL_MIXED_NARROW_MAX)) || (P.pass_w == 0 && cost <= relax0 * budget))) {
+                const double over = cost - budget;
+                if (over <= allowance) {
+                    allowance -= over;
+                    worth = true;
+                } else if (P.pass_w == 1 && longest > (uint32_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
+                    wide_allowance -= over;
+                    worth = true;
+                }
             }
             if (worth) {
                 const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
