@@ -310,9 +310,13 @@ set_comm!(f::LikelihoodApproximationFit, c) =
 # ---- tree construction: hclust + order_nodes (src/hclust.jl:193-319, 361-389) -----------------------------------
 "X in CSC, 1-based (colptr UInt32 or UInt64), as in the likelihood-matrix HDF5 -> (node_parent_idxs, node_js)"
 function hclust(m::Integer, n::Integer, colptr::Union{Vector{UInt32},Vector{UInt64}}, rowval::Vector{UInt32};
-                parallel::Bool=false)
+                parallel::Bool=false, device::Union{Nothing,Context}=nothing)
     parents, js = Vector{Int32}(undef, 2n - 1), Vector{Int32}(undef, 2n - 1)
-    if parallel   # rounds of mutually-best merges on all host threads: a variant, not hclust.jl's tree node for node
+    if device !== nothing   # the rounds variant built on the GPU: the same arrays as parallel = true
+        GC.@preserve colptr rowval parents js check(
+            ccall((:polee_hclust_parallel_device, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
+                  device.h, m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js), device.h)
+    elseif parallel   # rounds of mutually-best merges on all host threads: a variant, not hclust.jl's tree node for node
         GC.@preserve colptr rowval parents js check(
             ccall((:polee_hclust_parallel, LIB), Cint, (Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
                   m, n, colptr, sizeof(eltype(colptr)), rowval, parents, js))
