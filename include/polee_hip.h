@@ -74,6 +74,11 @@ const char *polee_version(void);
 void polee_host_cache_trim(void);
 int64_t polee_host_cache_configure(int64_t cap_mb);
 int64_t polee_host_cache_bytes(void);
+/* DEVICE buffers likewise: what the library frees on the device (the builders' scratch, handles' arrays) is kept by size class
+ * for the next allocation instead of going through hipFree / hipMalloc (a device-wide wait each, and multi-second stalls every few
+ * samples) -- up to POLEE_DEVICE_CACHE_MB megabytes (default 65536; 0: off).  polee_host_cache_trim frees these too;
+ * polee_device_cache_bytes = device bytes kept now. */
+int64_t polee_device_cache_bytes(void);
 
 /* ---- Polya tree transform ---------------------------------------------------------
  * Replaces PolyaTreeTransform (src/ptt.jl:6-27) and the three TF custom ops of

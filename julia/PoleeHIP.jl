@@ -577,6 +577,8 @@ end
 "cap (MB) of the host builders' scratch-block cache; cap_mb < 0 only queries.  Returns the cap in force."
 host_cache_configure(cap_mb::Integer=-1) = ccall((:polee_host_cache_configure, LIB), Int64, (Int64,), cap_mb)
 host_cache_bytes() = ccall((:polee_host_cache_bytes, LIB), Int64, ())
+"device bytes the library keeps for its next allocations (host_cache_trim() frees them too)"
+device_cache_bytes() = ccall((:polee_device_cache_bytes, LIB), Int64, ())
 
 # ---- trees from the TF-side index arrays; the three TF custom ops (src/tensorflow_ext/hsb_ops.cpp) -------------------
 "make_inverse_ptt_params(t) -- src/estimate.jl:461-500: (left_index, right_index, leaf_index), 0-based, -1 = none"

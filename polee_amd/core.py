@@ -414,6 +414,13 @@ def host_cache_bytes():
     return int(f())
 
 
+def device_cache_bytes():
+    """Device bytes the library keeps for its next allocations (polee_device_cache_bytes; host_cache_trim() frees them)."""
+    f = L.lib().polee_device_cache_bytes
+    f.restype, f.argtypes = C.c_int64, []
+    return int(f())
+
+
 def hclust(m, n, colptr, rowval, parallel=False, device=False, ctx=None):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],

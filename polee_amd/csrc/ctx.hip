@@ -46,6 +46,7 @@ int64_t polee_host_cache_configure(int64_t cap_mb)
     return (int64_t)(c.cap >> 20);
 }
 int64_t polee_host_cache_bytes(void) { return (int64_t)polee::HugeBlockCache::get().cached_bytes(); }
+int64_t polee_device_cache_bytes(void) { return (int64_t)polee::DevBlockCache::get().kept_bytes(); }
 
 polee_status polee_ctx_create(int device, polee_ctx **out)
 {

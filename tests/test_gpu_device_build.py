@@ -110,3 +110,34 @@ def test_errors_of_the_device_path_are_the_host_builders(P, ctx):
     # an empty matrix and a matrix of empty rows build (nothing to lay out)
     s = P.RNASeqSample(3, 4, np.ones(5, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.float32), ctx=ctx)
     assert s.info["num_slices"] == 0
+
+
+def test_device_buffers_are_kept_between_samples_and_freed_on_request(P, ctx, cases):
+    """common.hpp, DevBlockCache: what a build frees on the device is kept by size class (no hipFree / hipMalloc per buffer, whose
+    multi-second stalls every few samples DESIGN 5.1 records); a second build of the same sample allocates nothing new; the trim
+    hands everything back; results do not depend on whether blocks are fresh or reused."""
+    from polee_amd import core
+    from tools import synth
+    smp, _ = cases["literal"]
+    colptr, rowval, nzval = synth.to_csc(smp)
+    core.host_cache_trim()
+    assert core.device_cache_bytes() == 0
+    x = np.random.default_rng(5).dirichlet(np.ones(smp["n"])).astype(np.float32)
+    s1 = P.RNASeqSample(smp["m"], smp["n"], colptr, rowval, nzval, ctx=ctx)
+    s1.set_deterministic(True)
+    lp1, g1 = s1.log_likelihood(x)
+    t1 = P.hclust(smp["m"], smp["n"], colptr, rowval, device=True, ctx=ctx)
+    kept1 = core.device_cache_bytes()
+    assert kept1 > 0
+    del s1
+    s2 = P.RNASeqSample(smp["m"], smp["n"], colptr, rowval, nzval, ctx=ctx)  # (every block it needs is in the cache, dirty)
+    s2.set_deterministic(True)
+    lp2, g2 = s2.log_likelihood(x)
+    t2 = P.hclust(smp["m"], smp["n"], colptr, rowval, device=True, ctx=ctx)
+    assert lp1 == lp2 and np.array_equal(g1, g2)
+    assert np.array_equal(t1[0], t2[0]) and np.array_equal(t1[1], t2[1])
+    del s2
+    kept2 = core.device_cache_bytes()
+    assert kept2 <= 1.3 * (kept1 + 2 ** 26), (kept1, kept2)  # no growth from sample to sample
+    core.host_cache_trim()
+    assert core.device_cache_bytes() == 0
