@@ -318,6 +318,11 @@ __device__ inline uint32_t find_segment(const uint64_t *scan, uint32_t P, uint64
     }
     return lo;
 }
+__global__ void hd_diff_u64_kernel(uint32_t N, const uint64_t *a, const uint64_t *b, uint64_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = a[i] - b[i];
+}
 __global__ void hd_union_b_kernel(uint64_t nb, uint32_t P, const uint64_t *bscan, const uint32_t *plo, const uint32_t *phi, Nodes N,
                                   uint32_t *isdup, uint32_t *lba)
 {
@@ -616,7 +621,11 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
         lap("initial edges");
     }
     // ---- rounds
-    std::deque<DevBuf<uint32_t>> arenas;  // (one per round, kept to the end: a node's reads are a slice of its round's arena)
+    // one arena per round: a merged node's reads are a slice of its round's arena, which goes back (to the kept device buffers: the
+    // next round's arena is usually one of them) when the last of its nodes has been merged away
+    std::deque<DevBuf<uint32_t>> arenas;
+    std::vector<uint32_t> arena_first_id, arena_live;  // nodes [arena_first_id[r], arena_first_id[r + 1]) live in arena r
+    std::vector<uint32_t> h_plo, h_phi;
     uint32_t next_id = (uint32_t)n + 1;
     size_t rounds = 0, n_eval = 0;
     EdgeStore E2;
@@ -671,17 +680,12 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
         HD_HIP(hipMemcpyAsync(&tot_b, bscan.p + P, 8, hipMemcpyDeviceToHost, stream));
         HD_HIP(hipStreamSynchronize(stream));
         const uint64_t tot_a = tot_w - tot_b;
-        // ascan = slot - bscan (A's lengths): computed through a transform of the two scans
-        {
-            std::vector<uint64_t> hs((size_t)P + 1), hb((size_t)P + 1);
-            HD_HIP(hipMemcpyAsync(hs.data(), slot.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, stream));
-            HD_HIP(hipMemcpyAsync(hb.data(), bscan.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, stream));
-            HD_HIP(hipStreamSynchronize(stream));
-            for (size_t q = 0; q <= P; ++q) hs[q] -= hb[q];
-            HD_HIP(hipMemcpyAsync(ascan.p, hs.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, stream));
-            HD_HIP(hipStreamSynchronize(stream));
-        }
+        // ascan = slot - bscan (the scan of A's lengths)
+        hipLaunchKernelGGL(hd_diff_u64_kernel, dim3(grid_for((uint64_t)P + 1)), dim3(256), 0, stream, P + 1, slot.p, bscan.p, ascan.p);
+        POLEE_KERNEL_CHECK(ctx);
         arenas.emplace_back();
+        arena_first_id.push_back(base);
+        arena_live.push_back(P);
         DevBuf<uint32_t> &arena = arenas.back();
         POLEE_TRY(arena.alloc(ctx, (size_t)tot_w + 1));
         DevBuf<uint32_t> isdup, lba;
@@ -769,7 +773,17 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
         }
         ne = nlive;
         if (T) POLEE_TRY(append_edges(ctx, tmp, T, tx.p, ty.p, sim.p, base, E, ne));
+        h_plo.resize(P);
+        h_phi.resize(P);
+        HD_HIP(hipMemcpyAsync(h_plo.data(), plo.p, (size_t)P * 4, hipMemcpyDeviceToHost, stream));
+        HD_HIP(hipMemcpyAsync(h_phi.data(), phi.p, (size_t)P * 4, hipMemcpyDeviceToHost, stream));
         HD_HIP(hipStreamSynchronize(stream));
+        for (int half = 0; half < 2; ++half)
+            for (uint32_t x : half ? h_phi : h_plo) {
+                if (x <= (uint32_t)n) continue;  // (a leaf: its reads are a column of X)
+                const size_t r = (size_t)(std::upper_bound(arena_first_id.begin(), arena_first_id.end(), x) - arena_first_id.begin()) - 1;
+                if (--arena_live[r] == 0) arenas[r].release();
+            }
     }
     if (timing) fprintf(stderr, "[hclust/device]   %zu rounds, %zu similarity evaluations\n", rounds, n_eval);
     lap("joining in rounds");
