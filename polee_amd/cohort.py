@@ -138,10 +138,13 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
         return list(ex.map(job, enumerate(samples)))
 
 
-def _process_init(host_threads, cache_mb=None):
+def _process_init(host_threads, cache_mb=None, device_cache_mb=None):
     import os
     if host_threads:
         os.environ["POLEE_HOST_THREADS"] = str(int(host_threads))  # (read once, when the library first needs it)
+    if device_cache_mb is not None:
+        # every worker process keeps its own freed DEVICE buffers (csrc/common.hpp, DevBlockCache): the GPU's memory is shared out
+        os.environ.setdefault("POLEE_DEVICE_CACHE_MB", str(int(device_cache_mb)))
     if cache_mb is not None:
         # every worker process has its own scratch-block cache: the cohort's share of memory is divided between them
         # (four workers at the 8 GiB default pinned 32 GiB)
@@ -208,7 +211,9 @@ def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_t
     from . import core
     cache_mb = max(256, core.host_cache_configure(-1) // max(1, int(processes)))
     with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mp.get_context("spawn"),
-                             initializer=_process_init, initargs=(host_threads, cache_mb)) as ex:
+                             initializer=_process_init,
+                             # (device buffers kept per process: two thirds of a 288 GB GPU shared out, at most the library's default)
+                             initargs=(host_threads, cache_mb, min(65536, 196608 // max(1, int(processes))))) as ex:
         jobs = [(i, s, approx.treemethod, device, kwargs) for i, s in enumerate(samples)]
         for idx, params in ex.map(_process_job, jobs):
             if on_result is not None:
