@@ -139,7 +139,9 @@ __global__ void hd_leaf_tasks_kernel(int64_t n, int K, uint32_t *tx, uint32_t *t
 }
 
 // ---- |X n Y| of a list of tasks ---------------------------------------------------------------------------------------------
-constexpr uint32_t ISECT_CHUNK = 2048;  // elements of the smaller set per block
+constexpr uint32_t ISECT_CHUNK = 512;  // elements of the smaller set per WAVE (the waves of a block work on tasks of their own:
+                                       // a piece of work is a chain of dependent loads -- which task, its sets, where its run can
+                                       // hit -- and four times as many of them are in flight than with a block per piece)
 __global__ void hd_task_blocks_kernel(uint32_t T, const uint32_t *tx, const uint32_t *ty, Nodes N, uint32_t *nblk)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,26 +157,26 @@ __global__ void hd_task_blocks_kernel(uint32_t T, const uint32_t *tx, const uint
     }
     nblk[t] = nb;
 }
-// block -> task by binary search in the scan of the block counts; every thread looks its elements of the smaller set up in
+// wave -> (task, piece) by binary search in the scan of the piece counts; every lane looks its elements of the smaller set up in
 // the larger one
-__global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t T, const uint32_t *tx, const uint32_t *ty, Nodes N, const uint32_t *bscan,
-                                                       uint32_t *count)
+__global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t T, uint32_t npieces, const uint32_t *tx, const uint32_t *ty, Nodes N,
+                                                       const uint32_t *bscan, uint32_t *count)
 {
-    __shared__ uint32_t s_sum[4];
-    const uint32_t blk = blockIdx.x;
-    uint32_t lo = 0, hi = T;  // the last t with bscan[t] <= blk
+    const uint32_t piece = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (piece >= npieces) return;
+    uint32_t lo = 0, hi = T;  // the last t with bscan[t] <= piece
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (bscan[mid] <= blk) lo = mid; else hi = mid;
+        if (bscan[mid] <= piece) lo = mid; else hi = mid;
     }
-    const uint32_t t = lo, chunk = blk - bscan[t];
+    const uint32_t t = lo, chunk = piece - bscan[t];
     const uint32_t x = tx[t], y = ty[t];
     const uint32_t lx = N.set_len[x], ly = N.set_len[y];
     const uint32_t *ps = lx <= ly ? N.set_p[x] : N.set_p[y], *pb = lx <= ly ? N.set_p[y] : N.set_p[x];
     const uint32_t ls = min(lx, ly), lb = max(lx, ly);
     uint32_t c = 0;
     const uint32_t e0 = chunk * ISECT_CHUNK, e1 = min(ls, e0 + ISECT_CHUNK);
-    // the block's elements are a sorted run: its first and last bound the part of the larger set that can match
+    // the piece's elements are a sorted run: its first and last bound the part of the larger set that can match
     uint32_t wlo = 0, whi = lb;
     {
         const uint32_t vfirst = ps[e0], vlast = ps[e1 - 1];
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t T, const uint32_
         }
         whi = a;
     }
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    for (uint32_t e = e0 + lane; e < e1; e += 64) {
         const uint32_t v = ps[e];
         uint32_t a = wlo, b = whi;
         while (a < b) {
@@ -201,12 +203,7 @@ __global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t T, const uint32_
         c += a < whi && pb[a] == v;
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        if (tot) atomicAdd(&count[t], tot);
-    }
+    if (lane == 0 && c) atomicAdd(&count[t], c);
 }
 // Float64 quotient stored as Float32 (hclust.jl:143-152)
 __global__ void hd_sim_kernel(uint32_t T, const uint32_t *tx, const uint32_t *ty, Nodes N, const uint32_t *count, float *sim)
@@ -472,8 +469,8 @@ polee_status run_tasks(polee_ctx *ctx, Scratch &tmp, uint32_t T, const uint32_t 
     uint32_t nblocks = 0;
     HD_HIP(hipMemcpyAsync(&nblocks, bscan.p + T, 4, hipMemcpyDeviceToHost, stream));
     HD_HIP(hipStreamSynchronize(stream));
-    if (nblocks) {
-        hipLaunchKernelGGL(hd_isect_kernel, dim3(nblocks), dim3(256), 0, stream, T, tx, ty, N, bscan.p, count.p);
+    if (nblocks) {  // (pieces of work: four to a block)
+        hipLaunchKernelGGL(hd_isect_kernel, dim3((nblocks + 3) / 4), dim3(256), 0, stream, T, nblocks, tx, ty, N, bscan.p, count.p);
         POLEE_KERNEL_CHECK(ctx);
     }
     hipLaunchKernelGGL(hd_sim_kernel, dim3(grid_for(T)), dim3(256), 0, stream, T, tx, ty, N, count.p, sim.p);
