@@ -84,3 +84,31 @@ def test_parameter_tables_agree_and_restatement_is_smooth():
     expected = 0.5 * (((t0 + 0.3) ** 2).sum() - (t0 ** 2).sum()) + \
         0.5 * ((((b0 + 0.3) + 2.0) / 12.0) ** 2 - ((b0 + 2.0) / 12.0) ** 2).sum()
     np.testing.assert_allclose(l1 - l0, expected, rtol=1e-8, atol=1e-8)
+
+
+def test_density_restatements_agree_with_an_independent_library():
+    """The regression oracle (oracle/regression_ref.py) restates TFP's log-densities -- library-defined, no reference test pins
+    them ("parity unpinned").  SciPy's implementations of the same distributions are an independent statement of the
+    same definitions: InverseGamma(concentration, scale), HalfNormal(1), HalfCauchy(0, scale), Normal; SoftplusNormal is the
+    change of variables the restatement writes out (log q = Normal(u) - log sigmoid(u) at x = softplus(u)), checked against a
+    numerical derivative of the CDF."""
+    from scipy import stats
+    from oracle import regression_ref as RR
+    rng = np.random.default_rng(3)
+    x = np.exp(rng.normal(0, 1.5, size=200))
+    for a, b in ((0.5, 0.5), (0.001, 0.001), (3.2, 0.7), (12.0, 40.0)):
+        np.testing.assert_allclose(RR._invgamma_lp(x, a, b), stats.invgamma.logpdf(x, a, scale=b), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(RR._halfnormal_lp(x), stats.halfnorm.logpdf(x), rtol=1e-12, atol=1e-12)
+    for sc in (1.0, 10.0, 0.1):
+        np.testing.assert_allclose(RR._halfcauchy_lp(x, sc), stats.halfcauchy.logpdf(x, scale=sc), rtol=1e-12, atol=1e-12)
+    v = rng.normal(0, 3, size=200)
+    np.testing.assert_allclose(RR._normal_lp(v, 0.7, 2.5), stats.norm.logpdf(v, 0.7, 2.5), rtol=1e-12, atol=1e-12)
+    # SoftplusNormal(loc, scale): X = softplus(U), U ~ Normal(loc, scale): density of X by differentiating its CDF numerically
+    loc, scale = 0.3, 0.8
+    u = rng.normal(loc, scale, size=50)
+    xs = RR.softplus(u)
+    lq = RR._normal_lp(u, loc, scale) - RR.log_sigmoid(u)
+    inv = lambda y: np.log(np.expm1(y))  # softplus^-1
+    h = 1e-5
+    num = (stats.norm.cdf(inv(xs + h), loc, scale) - stats.norm.cdf(inv(xs - h), loc, scale)) / (2 * h)
+    np.testing.assert_allclose(lq, np.log(num), rtol=1e-5, atol=1e-6)
