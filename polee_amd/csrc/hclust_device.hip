@@ -157,50 +157,88 @@ __global__ void hd_task_blocks_kernel(uint32_t T, const uint32_t *tx, const uint
     }
     nblk[t] = nb;
 }
-// wave -> (task, piece) by binary search in the scan of the piece counts; every lane looks its elements of the smaller set up in
-// the larger one
-__global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t T, uint32_t npieces, const uint32_t *tx, const uint32_t *ty, Nodes N,
+// piece -> task (a task's pieces are consecutive)
+__global__ void hd_piece_map_kernel(uint32_t T, const uint32_t *bscan, uint32_t *pmap)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    for (uint32_t p = bscan[t]; p < bscan[t + 1]; ++p) pmap[p] = t;
+}
+// A piece = 512 consecutive elements of the smaller set, one wave.  What a piece costs is its chain of DEPENDENT loads, so the
+// chain is kept short: the task from a map; the part of the larger set the piece's sorted run can hit by a 64-ary search (every
+// lane probes one of 64 evenly spaced positions: two or three rounds instead of two binary searches); then every lane's eight
+// elements searched in lockstep (eight independent loads per round).
+__global__ __launch_bounds__(256) void hd_isect_kernel(uint32_t npieces, const uint32_t *pmap, const uint32_t *tx, const uint32_t *ty, Nodes N,
                                                        const uint32_t *bscan, uint32_t *count)
 {
     const uint32_t piece = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (piece >= npieces) return;
-    uint32_t lo = 0, hi = T;  // the last t with bscan[t] <= piece
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (bscan[mid] <= piece) lo = mid; else hi = mid;
-    }
-    const uint32_t t = lo, chunk = piece - bscan[t];
+    const uint32_t t = pmap[piece], chunk = piece - bscan[t];
     const uint32_t x = tx[t], y = ty[t];
     const uint32_t lx = N.set_len[x], ly = N.set_len[y];
     const uint32_t *ps = lx <= ly ? N.set_p[x] : N.set_p[y], *pb = lx <= ly ? N.set_p[y] : N.set_p[x];
     const uint32_t ls = min(lx, ly), lb = max(lx, ly);
-    uint32_t c = 0;
     const uint32_t e0 = chunk * ISECT_CHUNK, e1 = min(ls, e0 + ISECT_CHUNK);
-    // the piece's elements are a sorted run: its first and last bound the part of the larger set that can match
-    uint32_t wlo = 0, whi = lb;
+    const uint32_t vfirst = ps[e0], vlast = ps[e1 - 1];
+    // [wlo, whi): the elements of the larger set in [vfirst, vlast].  64-ary search: the answer lies in [a, b]; the lanes probe
+    // a, a + step, a + 2 step, ...: the probes that satisfy the predicate are a prefix (the set ascends)
+    uint32_t wlo, whi;
     {
-        const uint32_t vfirst = ps[e0], vlast = ps[e1 - 1];
-        uint32_t a = 0, b = lb;
+        uint32_t a = 0, b = lb;  // first position whose element is >= vfirst
         while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (pb[mid] < vfirst) a = mid + 1; else b = mid;
+            const uint32_t step = (b - a + 63u) / 64u;
+            const uint32_t pos = a + lane * step;
+            const uint32_t nb = (uint32_t)__popcll(__ballot(pos < b && pb[pos < b ? pos : a] < vfirst));
+            if (nb == 0) {
+                b = a;
+            } else {
+                const uint32_t na = a + (nb - 1) * step + 1;
+                b = min(a + nb * step, b);
+                a = na;
+            }
         }
         wlo = a;
-        b = lb;
+        b = lb;  // first position whose element is > vlast (not before wlo)
         while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (pb[mid] <= vlast) a = mid + 1; else b = mid;
+            const uint32_t step = (b - a + 63u) / 64u;
+            const uint32_t pos = a + lane * step;
+            const uint32_t nb = (uint32_t)__popcll(__ballot(pos < b && pb[pos < b ? pos : a] <= vlast));
+            if (nb == 0) {
+                b = a;
+            } else {
+                const uint32_t na = a + (nb - 1) * step + 1;
+                b = min(a + nb * step, b);
+                a = na;
+            }
         }
         whi = a;
     }
-    for (uint32_t e = e0 + lane; e < e1; e += 64) {
-        const uint32_t v = ps[e];
-        uint32_t a = wlo, b = whi;
-        while (a < b) {
-            const uint32_t mid = (a + b) >> 1;
-            if (pb[mid] < v) a = mid + 1; else b = mid;
+    uint32_t c = 0;
+    if (whi > wlo) {
+        constexpr int E = ISECT_CHUNK / 64;
+        uint32_t v[E], lo_[E], hi_[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = e0 + lane + 64u * (uint32_t)e;
+            v[e] = i < e1 ? ps[i] : 0xffffffffu;
+            lo_[e] = wlo;
+            hi_[e] = whi;
         }
-        c += a < whi && pb[a] == v;
+        const int rounds = 32 - __builtin_clz(whi - wlo);  // enough halvings for the widest interval
+        for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (lo_[e] < hi_[e]) {
+                    const uint32_t mid = (lo_[e] + hi_[e]) >> 1;
+                    if (pb[mid] < v[e]) lo_[e] = mid + 1; else hi_[e] = mid;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = e0 + lane + 64u * (uint32_t)e;
+            c += i < e1 && lo_[e] < whi && pb[lo_[e]] == v[e];
+        }
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if (lane == 0 && c) atomicAdd(&count[t], c);
@@ -470,7 +508,10 @@ polee_status run_tasks(polee_ctx *ctx, Scratch &tmp, uint32_t T, const uint32_t 
     HD_HIP(hipMemcpyAsync(&nblocks, bscan.p + T, 4, hipMemcpyDeviceToHost, stream));
     HD_HIP(hipStreamSynchronize(stream));
     if (nblocks) {  // (pieces of work: four to a block)
-        hipLaunchKernelGGL(hd_isect_kernel, dim3((nblocks + 3) / 4), dim3(256), 0, stream, T, nblocks, tx, ty, N, bscan.p, count.p);
+        DevBuf<uint32_t> pmap;
+        POLEE_TRY(pmap.alloc(ctx, nblocks));
+        hipLaunchKernelGGL(hd_piece_map_kernel, dim3(grid_for(T)), dim3(256), 0, stream, T, bscan.p, pmap.p);
+        hipLaunchKernelGGL(hd_isect_kernel, dim3((nblocks + 3) / 4), dim3(256), 0, stream, nblocks, pmap.p, tx, ty, N, bscan.p, count.p);
         POLEE_KERNEL_CHECK(ctx);
     }
     hipLaunchKernelGGL(hd_sim_kernel, dim3(grid_for(T)), dim3(256), 0, stream, T, tx, ty, N, count.p, sim.p);
