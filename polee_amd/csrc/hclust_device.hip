@@ -157,12 +157,11 @@ __global__ void hd_task_blocks_kernel(uint32_t T, const uint32_t *tx, const uint
     }
     nblk[t] = nb;
 }
-// piece -> task (a task's pieces are consecutive)
-__global__ void hd_piece_map_kernel(uint32_t T, const uint32_t *bscan, uint32_t *pmap)
+// piece -> task (a task's pieces are consecutive): the task's number at its first piece, then a running maximum
+__global__ void hd_piece_heads_kernel(uint32_t T, const uint32_t *nblk, const uint32_t *bscan, uint32_t *pmap)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    for (uint32_t p = bscan[t]; p < bscan[t + 1]; ++p) pmap[p] = t;
+    if (t < T && nblk[t]) pmap[bscan[t]] = t;
 }
 // A piece = 512 consecutive elements of the smaller set, one wave.  What a piece costs is its chain of DEPENDENT loads, so the
 // chain is kept short: the task from a map; the part of the larger set the piece's sorted run can hit by a 64-ary search (every
@@ -510,7 +509,14 @@ polee_status run_tasks(polee_ctx *ctx, Scratch &tmp, uint32_t T, const uint32_t 
     if (nblocks) {  // (pieces of work: four to a block)
         DevBuf<uint32_t> pmap;
         POLEE_TRY(pmap.alloc(ctx, nblocks));
-        hipLaunchKernelGGL(hd_piece_map_kernel, dim3(grid_for(T)), dim3(256), 0, stream, T, bscan.p, pmap.p);
+        HD_HIP(hipMemsetAsync(pmap.p, 0, (size_t)nblocks * 4, stream));
+        hipLaunchKernelGGL(hd_piece_heads_kernel, dim3(grid_for(T)), dim3(256), 0, stream, T, nblk.p, bscan.p, pmap.p);
+        {
+            size_t bytes = 0;
+            HD_HIP(rocprim::inclusive_scan(nullptr, bytes, pmap.p, pmap.p, (size_t)nblocks, rocprim::maximum<uint32_t>(), stream));
+            HD_HIP(tmp.need(bytes));
+            HD_HIP(rocprim::inclusive_scan(tmp.p, bytes, pmap.p, pmap.p, (size_t)nblocks, rocprim::maximum<uint32_t>(), stream));
+        }
         hipLaunchKernelGGL(hd_isect_kernel, dim3((nblocks + 3) / 4), dim3(256), 0, stream, nblocks, pmap.p, tx, ty, N, bscan.p, count.p);
         POLEE_KERNEL_CHECK(ctx);
     }
