@@ -618,6 +618,10 @@ class LikelihoodApproximationFit:
         return out
 
 
+import threading as _threading
+_host_tree_slot = _threading.Semaphore(1)  # treemethod "cluster_auto": one host-built tree at a time (it takes every host thread)
+
+
 def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=None, ks=None):
     """The two host-side stages of preparing a sample side by side: the tree heuristic (hclust*) on a helper thread while
     this thread builds the sample's device layout (RNASeqSample); both are C calls that release the GIL, and neither
@@ -628,7 +632,19 @@ def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=
     tm = approx.treemethod
     with ThreadPoolExecutor(max_workers=1) as pool:
         fut = None
-        if tm in ("cluster", "cluster_parallel", "cluster_device"):
+        if tm == "cluster_auto":
+            # The rounds variant is the SAME tree from the host (all host threads) and from the GPU: a cohort that is bound by the
+            # GPU gives the tree to the host CPUs whenever they are idle -- one host tree at a time -- and to the GPU otherwise.
+            on_host = _host_tree_slot.acquire(blocking=False)
+
+            def tree_job():
+                try:
+                    return hclust(m, n, colptr, rowval, parallel=on_host, device=not on_host, ctx=ctx)
+                finally:
+                    if on_host:
+                        _host_tree_slot.release()
+            fut = pool.submit(tree_job)
+        elif tm in ("cluster", "cluster_parallel", "cluster_device"):
             fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", ctx)
         sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx)
         if fut is not None:
@@ -662,7 +678,7 @@ def approximate_likelihood(approx, sample, t=None, gene_noninformative=False, us
             if getattr(sample, "_csc", None) is None:
                 raise ValueError("tree construction needs the sample's CSC arrays")
             parents, js = hclust(sample.m, sample.n, *sample._csc, parallel=True)
-        elif approx.treemethod == "cluster_device":  # (the same variant built on the GPU, polee_hclust_parallel_device)
+        elif approx.treemethod in ("cluster_device", "cluster_auto"):  # (the same variant built on the GPU, polee_hclust_parallel_device)
             if getattr(sample, "_csc", None) is None:
                 raise ValueError("tree construction needs the sample's CSC arrays")
             parents, js = hclust(sample.m, sample.n, *sample._csc, device=True, ctx=sample.ctx)

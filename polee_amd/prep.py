@@ -79,7 +79,7 @@ def main(argv=None):
     ap.add_argument("--salmon", default=None, metavar="salmon_quant_dir", help="prep-salmon: salmon quant -d output")
     ap.add_argument("--transcript-ids", default=None, metavar="ids.txt", help="with --salmon: transcript ids, tree order")
     ap.add_argument("-o", "--output", default="prepared-sample.h5", metavar="prepared-sample.h5")
-    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "cluster_parallel", "cluster_device", "sequential"])
+    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "cluster_parallel", "cluster_device", "cluster_auto", "sequential"])
     ap.add_argument("--ptt-tree", default=None, metavar="tree.h5", help="use this tree topology (polee fit-tree output)")
     ap.add_argument("--no-efflen-jacobian", action="store_true")
     ap.add_argument("--seed", type=int, default=123456789)

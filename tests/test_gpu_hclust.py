@@ -98,6 +98,15 @@ def test_device_tree_is_the_host_variants_tree_node_for_node(P, ctx, lm_fixture)
     out_d = P.approximate_likelihood(P.LogitSkewNormalPTTApprox("cluster_device"), smp, num_steps=30)
     np.testing.assert_array_equal(out_h["node_js"], out_d["node_js"])
     np.testing.assert_array_equal(out_h["node_parent_idxs"], out_d["node_parent_idxs"])
+    # "cluster_auto": the tree goes to the host CPUs when they are idle and to the GPU otherwise -- the same tree either way, so
+    # the placement cannot show in the result (three samples prepared side by side: at most one of them gets the host)
+    from concurrent.futures import ThreadPoolExecutor
+    auto = P.LogitSkewNormalPTTApprox("cluster_auto")
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        trees = list(ex.map(lambda _: P.sample_and_tree(auto, s["m"], s["n"], c, r, v, s["effective_lengths"], ctx=P.Context(0))[1], range(3)))
+    for tr in trees:
+        np.testing.assert_array_equal(tr.node_js, out_h["node_js"])
+        np.testing.assert_array_equal(tr.node_parent_idxs, out_h["node_parent_idxs"])
     # malformed input: the host variant's messages
     with pytest.raises(Exception, match="not ascending"):
         P.hclust(5, 2, np.array([1, 3, 4], np.uint64), np.array([2, 1, 3], np.uint32), device=True, ctx=ctx)

@@ -1,7 +1,8 @@
 """End-to-end preparation of a cohort of C2-size samples on one GPU: tree construction (host) + device layout build
 (host) + 500-iteration fit (device) per sample, `workers` samples in flight.
 usage: python tools/probe/prep_throughput.py [jobs] [workers ...]
-  POLEE_PREP_TREE=cluster_parallel   the rounds variant of the tree heuristic (polee_hclust_parallel)
+  POLEE_PREP_TREE=cluster_parallel   the rounds variant of the tree heuristic (polee_hclust_parallel); cluster_device: the same tree
+                                     built on the GPU; cluster_auto: on the host when its CPUs are idle, else on the GPU
   POLEE_PREP_PROCESSES=1             worker processes (approximate_likelihood_cohort_processes) instead of threads
                                      (approximate_likelihood_cohort); POLEE_PREP_HOST_THREADS threads per process
 The three distinct samples are generated once and kept as .npy files under /tmp; a worker maps the one it is given
