@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import numpy as np
 import polee_amd as P
 from tools import synth
-n, m = 200000, 30000000
+n, m = 200000, int(os.environ.get("POLEE_PREP_M", "30000000"))  # (POLEE_PREP_M=150000000: BASELINE's C5)
 smp = synth.make_sample(n, m, 8.0, 123456789, literal=bool(os.environ.get("POLEE_PREP_LITERAL")))
 colptr, rowval, nzval = synth.to_csc(smp)
 eff = smp["effective_lengths"]
