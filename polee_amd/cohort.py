@@ -138,8 +138,11 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
         return list(ex.map(job, enumerate(samples)))
 
 
-def _process_init(host_threads, cache_mb=None, device_cache_mb=None):
+def _process_init(host_threads, cache_mb=None, device_cache_mb=None, host_tree_slot=None):
     import os
+    if host_tree_slot is not None:  # treemethod "cluster_auto": the slot for host-built trees is the cohort's, not the process's
+        from . import core
+        core._host_tree_slot = host_tree_slot
     if host_threads:
         os.environ["POLEE_HOST_THREADS"] = str(int(host_threads))  # (read once, when the library first needs it)
     if device_cache_mb is not None:
@@ -206,14 +209,21 @@ def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_t
     from concurrent.futures import ProcessPoolExecutor
     samples = list(samples)
     out = [None] * len(samples)
+    mpctx = mp.get_context("spawn")
+    slot = None
+    if approx.treemethod == "cluster_auto":
+        # one host-built tree at a time ACROSS the processes (it may then use every usable CPU: the layouts are built on the GPU)
+        slot = mpctx.Semaphore(1)
+        if host_threads is None:
+            host_threads = usable_cpus()
     if host_threads is None:  # share the usable CPUs out (two host stages run side by side in every process)
         host_threads = max(2, usable_cpus() // max(1, int(processes)))
     from . import core
     cache_mb = max(256, core.host_cache_configure(-1) // max(1, int(processes)))
-    with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mp.get_context("spawn"),
+    with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mpctx,
                              initializer=_process_init,
                              # (device buffers kept per process: two thirds of a 288 GB GPU shared out, at most the library's default)
-                             initargs=(host_threads, cache_mb, min(65536, 196608 // max(1, int(processes))))) as ex:
+                             initargs=(host_threads, cache_mb, min(65536, 196608 // max(1, int(processes))), slot)) as ex:
         jobs = [(i, s, approx.treemethod, device, kwargs) for i, s in enumerate(samples)]
         for idx, params in ex.map(_process_job, jobs):
             if on_result is not None:

@@ -635,7 +635,7 @@ def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=
         if tm == "cluster_auto":
             # The rounds variant is the SAME tree from the host (all host threads) and from the GPU: a cohort that is bound by the
             # GPU gives the tree to the host CPUs whenever they are idle -- one host tree at a time -- and to the GPU otherwise.
-            on_host = _host_tree_slot.acquire(blocking=False)
+            on_host = _host_tree_slot.acquire(False)  # (non-blocking; positional: threading and multiprocessing name the argument differently)
 
             def tree_job():
                 try:
