@@ -82,7 +82,8 @@ inline polee_status fail(polee_ctx *ctx, polee_status code, const char *fmt, ...
 // few samples one of the first large allocations of a sample stalled for 2 - 3 s (tools/probe/prep_stages_one.py, 20 samples).
 // A block is given back together with an event recorded on the stream its owner worked on; whoever takes it next waits for
 // that event first (normally long complete) -- what hipFree guaranteed, for that one block only.  (The runtime's own
-// stream-ordered pool, hipMallocAsync, handed out blocks that overlapped live ones here: not used.)
+// stream-ordered pool, hipMallocAsync with an infinite release threshold, was tried first: under it freshly uploaded arrays read
+// back partly zeroed -- as if a block were handed out while a neighbour's memset still covered it -- in every run; not used.)
 // POLEE_DEVICE_CACHE_MB: cap of the kept bytes (default 64 GiB; 0 = plain hipMalloc / hipFree); polee_host_cache_trim() frees them.
 class DevBlockCache {
 public:
