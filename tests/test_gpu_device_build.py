@@ -141,3 +141,12 @@ def test_device_buffers_are_kept_between_samples_and_freed_on_request(P, ctx, ca
     assert kept2 <= 1.3 * (kept1 + 2 ** 26), (kept1, kept2)  # no growth from sample to sample
     core.host_cache_trim()
     assert core.device_cache_bytes() == 0
+
+
+def test_random_matrices_through_both_device_builders(P):
+    """tools/probe/fuzz_device_builders.py: random matrices of many shapes (unstructured; genes of up to 4 / 12 / 20 / 40 / 70 isoforms
+    with patterns, random subsets, strays and empty fragments; tiny and empty matrices; multiplicities; fragment order shuffled):
+    layouts byte for byte, trees node for node, against the host builders."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "fuzz_device_builders.py"), "60", "7"], capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0 and "mismatching 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
