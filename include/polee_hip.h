@@ -624,6 +624,9 @@ polee_status polee_xbuild_get(const polee_xbuild *xb, uint64_t *tcolptr, uint32_
 /* The likelihood handle straight from an xbuild result, without X leaving the device: rows_to_device -> layout kernels
  * (as polee_loglik_create_from_xt on polee_xbuild_get's arrays; ks_or_null: host array [rows]).  The xbuild handle stays valid. */
 polee_status polee_loglik_create_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, const int64_t *ks_or_null, polee_loglik **out);
+/* ... and the tree (polee_hclust_parallel_device) from the same result on the device: alignments -> X -> tree + layout -> fit
+ * without X visiting the host (the columns of X by a stable sort of the result's rows by transcript). */
+polee_status polee_hclust_parallel_device_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, int32_t *node_parent_idxs, int32_t *node_js);
 
 #ifdef __cplusplus
 }

@@ -868,7 +868,7 @@ m2_right, m1_is_flag16, cig1_ptr, cig2_ptr, cig_op, cig_len) in the layout of in
 as transcripts.jl:288-297 orders them).  Returns (tcolptr, trowval, tnzval, effective_lengths, row_fragment): the rows of X.
 """
 function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::Vector{Float32}, median::Integer;
-                                 strand_specificity::Real=0.9, alt_frag_model::Bool=false, return_sample::Bool=false)
+                                 strand_specificity::Real=0.9, alt_frag_model::Bool=false, return_sample::Bool=false, return_tree::Bool=false)
     n = length(T.seq); m = length(F.seq)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve T F pmf cdf begin
@@ -890,6 +890,12 @@ function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::
         GC.@preserve tcolptr trowval tnzval efflens rowfrag check(
             ccall((:polee_xbuild_get, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int64}),
                   h, tcolptr, trowval, tnzval, efflens, rowfrag), ctx.h)
+        if return_tree   # the clustering tree (rounds variant) from the result on the device
+            parents, js = Vector{Int32}(undef, 2n - 1), Vector{Int32}(undef, 2n - 1)
+            GC.@preserve parents js check(ccall((:polee_hclust_parallel_device_from_xbuild, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}),
+                                                ctx.h, h, parents, js), ctx.h)
+            return tcolptr, trowval, tnzval, efflens, rowfrag, parents, js
+        end
         if return_sample  # the likelihood handle straight from the result on the device (X never visits the host on its way in)
             r = Ref{Ptr{Cvoid}}(C_NULL)
             check(ccall((:polee_loglik_create_from_xbuild, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ref{Ptr{Cvoid}}), ctx.h, h, C_NULL, r), ctx.h)

@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "hclust_device.hpp"
+#include "loglik_internal.hpp"  // (xbuild_device_view)
 
 namespace polee {
 namespace {
@@ -563,12 +564,10 @@ polee_status append_edges(polee_ctx *ctx, Scratch &tmp, uint32_t T, const uint32
 
 }  // namespace
 
-polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
-                                  int32_t *node_parent_idxs, int32_t *node_js)
+// X by columns (CSC, 1-based) in DEVICE memory -> the tree
+static polee_status hclust_rounds_device_core(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_cp_p, uint64_t nnz, const uint32_t *d_rowval_p,
+                                              int32_t *node_parent_idxs, int32_t *node_js)
 {
-    if (n < 1 || m < 0 || !colptr || !node_parent_idxs || !node_js) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: bad argument");
-    if (colptr_bytes != 4 && colptr_bytes != 8) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr_bytes must be 4 or 8");
-    POLEE_TRY(use_device(ctx));
     hipStream_t stream = ctx->stream;
     static const bool timing = getenv("POLEE_BUILD_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -579,21 +578,17 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
         fprintf(stderr, "[hclust/device] %-24s %.3f s\n", what, now() - t_prev);
         t_prev = now();
     };
-    std::vector<uint64_t> cp((size_t)n + 1);
-    for (int64_t j = 0; j <= n; ++j)
-        cp[(size_t)j] = colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j] : reinterpret_cast<const uint64_t *>(colptr)[j];
-    if (cp[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr[0] must be 1 (1-based)");
-    for (int64_t j = 0; j < n; ++j)
-        if (cp[(size_t)j + 1] < cp[(size_t)j]) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr is not monotone");
-    const uint64_t nnz = cp[(size_t)n] - 1;
     if (2 * (uint64_t)n + 1 >= (1ull << 31) || nnz >= (1ull << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "hclust (device): matrix too large");
     const int K = 25;
     const uint32_t cap = 2 * (uint32_t)n + 1;
     Scratch tmp;
-    DevBuf<uint64_t> d_cp;
-    DevBuf<uint32_t> d_rowval, err;
-    POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
-    POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
+    struct {
+        const uint64_t *p;
+    } d_cp{d_cp_p};
+    struct {
+        const uint32_t *p;
+    } d_rowval{d_rowval_p};
+    DevBuf<uint32_t> err;
     POLEE_TRY(err.alloc(ctx, 1));
     HD_HIP(hipMemsetAsync(err.p, 0, 4, stream));
     // ---- leaves in the order of their median compatible read (hclust.jl:204-222; the sort is stable); columns validated
@@ -848,6 +843,105 @@ polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const vo
     return POLEE_OK;
 }
 
+polee_status hclust_rounds_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                  int32_t *node_parent_idxs, int32_t *node_js)
+{
+    if (n < 1 || m < 0 || !colptr || !node_parent_idxs || !node_js) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: bad argument");
+    if (colptr_bytes != 4 && colptr_bytes != 8) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr_bytes must be 4 or 8");
+    POLEE_TRY(use_device(ctx));
+    std::vector<uint64_t> cp((size_t)n + 1);
+    for (int64_t j = 0; j <= n; ++j)
+        cp[(size_t)j] = colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j] : reinterpret_cast<const uint64_t *>(colptr)[j];
+    if (cp[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr[0] must be 1 (1-based)");
+    for (int64_t j = 0; j < n; ++j)
+        if (cp[(size_t)j + 1] < cp[(size_t)j]) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: colptr is not monotone");
+    const uint64_t nnz = cp[(size_t)n] - 1;
+    if (nnz >= (1ull << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "hclust (device): matrix too large");
+    DevBuf<uint64_t> d_cp;
+    DevBuf<uint32_t> d_rowval;
+    POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
+    POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
+    return hclust_rounds_device_core(ctx, m, n, d_cp.p, nnz, d_rowval.p, node_parent_idxs, node_js);
+}
+
+namespace {
+// Xt (the rows of X, 1-based, device memory) -> X by columns: entries counted per transcript, a STABLE sort by transcript of
+// (transcript, fragment) pairs -- the fragments of a column come out ascending, as the clustering needs them
+__global__ void hx_count_kernel(uint64_t nnz, int64_t n, const uint32_t *trowval, uint32_t *counts, uint32_t *key, uint32_t *err)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const uint32_t t = trowval[k];
+    if (t < 1 || (int64_t)t > n) {
+        atomicMax(err, 1u);
+        key[k] = 0;
+        return;
+    }
+    key[k] = t - 1u;
+    atomicAdd(&counts[t - 1u], 1u);
+}
+__global__ void hx_rowids_kernel(int64_t m, const uint64_t *tcolptr, uint32_t *rowid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    for (uint64_t k = tcolptr[i] - 1; k < tcolptr[i + 1] - 1; ++k) rowid[k] = (uint32_t)i + 1u;
+}
+__global__ void hx_plus1_kernel(int64_t n1, uint64_t *cp)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n1) cp[j] += 1u;
+}
+}  // namespace
+
+polee_status hclust_rounds_device_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_tcolptr, const uint32_t *d_trowval,
+                                          int32_t *node_parent_idxs, int32_t *node_js)
+{
+    if (n < 1 || m < 0 || !d_tcolptr || !node_parent_idxs || !node_js) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: bad argument");
+    POLEE_TRY(use_device(ctx));
+    hipStream_t stream = ctx->stream;
+    uint64_t last = 0;
+    HD_HIP(hipMemcpyAsync(&last, d_tcolptr + m, 8, hipMemcpyDeviceToHost, stream));
+    HD_HIP(hipStreamSynchronize(stream));
+    const uint64_t nnz = last - 1;
+    if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "hclust (device): matrix too large");
+    Scratch tmp;
+    DevBuf<uint64_t> d_cp;
+    DevBuf<uint32_t> counts, key, key_s, rowid, rowval, err;
+    POLEE_TRY(d_cp.alloc(ctx, (size_t)n + 1));
+    POLEE_TRY(counts.alloc(ctx, (size_t)n + 1));
+    POLEE_TRY(key.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(key_s.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(rowid.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(rowval.alloc(ctx, (size_t)nnz + 1));
+    POLEE_TRY(err.alloc(ctx, 1));
+    HD_HIP(hipMemsetAsync(counts.p, 0, ((size_t)n + 1) * 4, stream));
+    HD_HIP(hipMemsetAsync(err.p, 0, 4, stream));
+    if (nnz) {
+        hipLaunchKernelGGL(hx_count_kernel, dim3(grid_for(nnz)), dim3(256), 0, stream, nnz, n, d_trowval, counts.p, key.p, err.p);
+        hipLaunchKernelGGL(hx_rowids_kernel, dim3(grid_for((uint64_t)m)), dim3(256), 0, stream, m, d_tcolptr, rowid.p);
+        POLEE_KERNEL_CHECK(ctx);
+    }
+    HD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(counts.p, ToU64()), d_cp.p, (uint64_t)0, (size_t)n + 1, stream));
+    hipLaunchKernelGGL(hx_plus1_kernel, dim3(grid_for((uint64_t)n + 1)), dim3(256), 0, stream, n + 1, d_cp.p);
+    POLEE_KERNEL_CHECK(ctx);
+    uint32_t h_err = 0;
+    HD_HIP(hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, stream));
+    HD_HIP(hipStreamSynchronize(stream));
+    if (h_err) return fail(ctx, POLEE_ERR_BAD_ARG, "hclust: transcript index out of range");
+    if (nnz) {
+        unsigned bits = 1;
+        while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)n) ++bits;
+        size_t bytes = 0;
+        HD_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, rowid.p, rowval.p, (size_t)nnz, 0, bits, stream));
+        HD_HIP(tmp.need(bytes));
+        HD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, rowid.p, rowval.p, (size_t)nnz, 0, bits, stream));
+    }
+    key.release();
+    key_s.release();
+    rowid.release();
+    return hclust_rounds_device_core(ctx, m, n, d_cp.p, nnz, rowval.p, node_parent_idxs, node_js);
+}
+
 }  // namespace polee
 
 extern "C" polee_status polee_hclust_parallel_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
@@ -855,4 +949,19 @@ extern "C" polee_status polee_hclust_parallel_device(polee_ctx *ctx, int64_t m, 
 {
     return polee::guarded(ctx, "polee_hclust_parallel_device",
                           [&] { return polee::hclust_rounds_device(ctx, m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js); });
+}
+
+extern "C" polee_status polee_hclust_parallel_device_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, int32_t *node_parent_idxs, int32_t *node_js)
+{
+    return polee::guarded(ctx, "polee_hclust_parallel_device_from_xbuild", [&]() -> polee_status {
+        polee_ctx *xctx = nullptr;
+        int64_t m = 0, n = 0;
+        const uint64_t *tcolptr = nullptr;
+        const uint32_t *trowval = nullptr;
+        const float *tnzval = nullptr;
+        POLEE_TRY(polee::xbuild_device_view(xb, &xctx, &m, &n, &tcolptr, &trowval, &tnzval));
+        if (!ctx || xctx->device != ctx->device) return polee::fail(ctx, POLEE_ERR_BAD_ARG, "polee_hclust_parallel_device_from_xbuild: the xbuild result lives on another device");
+        POLEE_HIP_TRY(ctx, hipStreamSynchronize(xctx->stream));
+        return polee::hclust_rounds_device_from_xt(ctx, m, n, tcolptr, trowval, node_parent_idxs, node_js);
+    });
 }

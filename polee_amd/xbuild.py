@@ -109,13 +109,14 @@ def order_mates(fragments):
 
 
 def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity=0.9,
-                            alt_frag_model=False, ctx=None, bias=None, return_bias=False, return_sample=False):
+                            alt_frag_model=False, ctx=None, bias=None, return_bias=False, return_sample=False, return_tree=False):
     """-> dict(m, n, nnz, tcolptr u64 [m+1], trowval u32, tnzval f32 (the rows of X, 1-based, what RNASeqSample(xt=...)
     takes), effective_lengths f32 [n], row_fragment i64 [m], kernel_ms).  The mates of a pair may come in any order
     (order_mates).  bias: a trained bias model (pack_bias) -> the reference's default BiasedFragModel
     (src/fragmodel.jl:174-445) instead of the SimplisticFragModel; return_bias adds left_bias / right_bias (the
     transcripts' bias vectors, compute_transcript_bias!).  return_sample adds "sample": the RNASeqSample made straight from the
-    result on the device (polee_loglik_create_from_xbuild: X never visits the host on its way into the likelihood)."""
+    result on the device (polee_loglik_create_from_xbuild: X never visits the host on its way into the likelihood); return_tree adds
+    "node_parent_idxs" / "node_js": the clustering tree of the rounds variant, built from the same result on the device."""
     from .core import default_context
     ctx = ctx or default_context()
     fragments = order_mates(fragments)
@@ -139,6 +140,11 @@ def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fr
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         check(L.lib().polee_xbuild_get(h, p(out["tcolptr"]), p(out["trowval"]), p(out["tnzval"]), p(out["effective_lengths"]),
                                        p(out["row_fragment"])), ctx._h)
+        if return_tree:  # the clustering tree (rounds variant) from the result where it lies: polee_hclust_parallel_device_from_xbuild
+            n_ = int(transcripts["n"])
+            parents, js = np.empty(2 * n_ - 1, np.int32), np.empty(2 * n_ - 1, np.int32)
+            check(L.lib().polee_hclust_parallel_device_from_xbuild(ctx._h, h, p(parents), p(js)), ctx._h)
+            out["node_parent_idxs"], out["node_js"] = parents, js
         if return_sample:
             from .core import RNASeqSample
             out["sample"] = RNASeqSample(out["m"], out["n"], None, None, None, effective_lengths=out["effective_lengths"], ctx=ctx, _xbuild=h)

@@ -107,7 +107,7 @@ def test_device_matches_oracle(n, m, alt, seed):
     pmf, cdf, med = synth_aln.fraglen_model(180.0, 60.0)
     Ts, Fs, Ms, keep = XB.pack(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt)
     o = OX.build(Ts, Fs, Ms, n)
-    g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt, ctx=ctx, return_sample=True)
+    g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.85, alt, ctx=ctx, return_sample=True, return_tree=True)
     assert g["m"] == o["m"] and g["nnz"] == o["nnz"] and g["m"] > 0.8 * m
     np.testing.assert_array_equal(g["row_fragment"], o["row_fragment"])
     np.testing.assert_array_equal(g["tcolptr"], o["tcolptr"])
@@ -127,6 +127,10 @@ def test_device_matches_oracle(n, m, alt, seed):
     # (... without visiting the host: polee_loglik_create_from_xbuild lays the result out where xbuild left it)
     sd = g["sample"]
     assert sd.built_on_device and sd.info["nnz"] == g["nnz"]
+    # ... and so does the tree: the rounds variant from the result on the device = from its columns on the host
+    ph, jh = P.hclust(g["m"], n, (X.indptr + 1).astype(np.uint64), (X.indices + 1).astype(np.uint32), parallel=True)
+    np.testing.assert_array_equal(g["node_parent_idxs"], ph)
+    np.testing.assert_array_equal(g["node_js"], jh)
     lpd, gradd = sd.log_likelihood(x)
     for k in range(2):
         lpo, go = so.log_likelihood(x[k])
