@@ -25,3 +25,21 @@ print("rows %d (%.1f %% of the pairs), non-zeros %d (%.2f per row); kernels: eff
       "= %.1f M pairs/s; whole call incl. upload / download %.2f s; source transcript present in %d of %d sampled rows"
       % (g["m"], 100.0 * g["m"] / m, g["nnz"], g["nnz"] / g["m"], k["efflen"], k["count"], k["fill"],
          m / (k["count"] + k["fill"]) / 1e3, wall, hit, len(range(0, g["m"], max(1, g["m"] // 20000)))))
+
+# ---- the whole device pipeline: alignment pairs -> X -> tree + layout -> 500-step fit, X never on the host
+if os.environ.get("POLEE_XB_PIPELINE", "1") != "0":
+    for rep in range(3):
+        t = [time.time()]
+        g = XB.build_likelihood_matrix(d["transcripts"], d["fragments"], pmf, cdf, med, 0.9, False, ctx=ctx, return_sample=True, return_tree=True)
+        t.append(time.time())
+        tr = P.PolyaTreeTransform(g["node_parent_idxs"], g["node_js"], ctx=ctx)
+        fit = P.LikelihoodApproximationFit(g["sample"], tr, num_steps=500, num_mc_samples=6, seed=rep)
+        t.append(time.time())
+        fit.run(500); fit.sync()
+        t.append(time.time())
+        mu = fit.params()
+        del fit, tr, g
+        t.append(time.time())
+        dd = np.diff(t)
+        print("alignment pairs -> X -> tree + layout (incl. the download of X for the caller) %.3f  handles %.3f  500-step fit %.3f  params+free %.3f | total %.3f s"
+              % (tuple(dd) + (dd.sum(),)), flush=True)
