@@ -149,3 +149,14 @@ end
     x = rand(10) .+ 0.1
     @test PoleeHIP.debug_fast_log(ctx, x) ≈ log.(x) rtol = 1e-14
 end
+
+@testset "device builders (csrc/psell_device.hip, csrc/hclust_device.hip)" begin
+    # the layout of the fixture is built on the device by default; the tree of the rounds variant is the same from the host and the GPU
+    @test PoleeHIP.built_on_device(s)
+    ph, jh = PoleeHIP.hclust(m, n, lm.colptr, lm.rowval; parallel=true)
+    pd, jd = PoleeHIP.hclust(m, n, lm.colptr, lm.rowval; device=ctx)
+    @test ph == pd && jh == jd
+    @test PoleeHIP.device_cache_bytes() >= 0
+    PoleeHIP.host_cache_trim()
+    @test PoleeHIP.device_cache_bytes() == 0
+end
