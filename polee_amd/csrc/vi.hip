@@ -186,6 +186,7 @@ struct polee_vi {
     LoglikRemap remap{nullptr, nullptr, nullptr, nullptr, false};
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
+    DevBuf<unsigned int> d_bwd_sync;  // the fused backward launch's epoch, finish count and per-chunk flags (vi_bwd_fused_kernel)
     DevBuf<int> d_flag;
     // gene_noninformative (opts.gene_of): gene of every transcript, members per gene, per-gene sums of a step
     DevBuf<int32_t> d_gene_of;
@@ -278,11 +279,19 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
                            vi->d_efflens.p, vi->d_part_c.p, nch_f, (int64_t)n, gp, vi->d_gene_c.p);
     }
     // backward: double-double prefix over leaves of u * (g - efflen term)
-    hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
-                       eff, vi->d_part_c.p, nch_f, vi->d_csum.p, gp, chunk_b);
-    if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
-    hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
-                       eff, vi->d_csum.p, gp, chunk_b, vi->d_C.p, own_b);
+    // (POLEE_VI_BWD_FUSED=1: reduce and apply in one launch -- its workgroups wait for each other's totals, so all of them must
+    // be resident: up to 4 per CU)
+    static const bool bwd_fused_env = getenv("POLEE_VI_BWD_FUSED") != nullptr && atoi(getenv("POLEE_VI_BWD_FUSED")) != 0;
+    if (bwd_fused_env && own_b && nch_b <= 4 * ctx->num_cus) {
+        hipLaunchKernelGGL((vi_bwd_fused_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p, eff, vi->d_part_c.p,
+                           nch_f, vi->d_csum.p, gp, chunk_b, vi->d_bwd_sync.p, vi->d_C.p);
+    } else {
+        hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
+                           eff, vi->d_part_c.p, nch_f, vi->d_csum.p, gp, chunk_b);
+        if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
+        hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
+                           eff, vi->d_csum.p, gp, chunk_b, vi->d_C.p, own_b);
+    }
     POLEE_KERNEL_CHECK(ctx);
     if (want_values) {
         hipLaunchKernelGGL((vi_values_finish_kernel<K>), dim3(1), dim3(256), 0, st, vi->d_part_ladj.p, nch_f,
@@ -562,6 +571,12 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         A(vi->d_part_c.alloc(ctx, nch * K));
         A(vi->d_part_ladj.alloc(ctx, nch * K));
         A(vi->d_csum.alloc(ctx, PSELL_MAX_K));
+        // (the fused backward launch's epoch / finish count / per-chunk flags: vi_bwd_fused_kernel)
+        const size_t nsync = (size_t)std::max(scan_num_chunks((int64_t)n), 1) + 2;
+        A(vi->d_bwd_sync.alloc(ctx, nsync));
+        std::vector<unsigned int> init(nsync, 0u);
+        init[0] = 1u;
+        A(vi->d_bwd_sync.upload(ctx, init.data(), init.size()));
     }
     {   // The forward scan's chunk offsets from the tree (vi_fwd_apply_kernel): for every chunk of the Euler tour the ENTER
         // entries still open at its first entry = the path from the root to that point.  One walk over the tour with a

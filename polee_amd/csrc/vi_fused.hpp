@@ -478,6 +478,76 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
     }
 }
 
+// backward reduce AND apply in one launch (POLEE_VI_BWD_FUSED=1): every workgroup publishes its chunk's total, waits for the
+// totals of the chunks before it (they are all resident: a few hundred workgroups), and goes on with the values still in its
+// registers -- the same arithmetic in the same order as the two launches.  sync[0] = the launch's epoch (the workgroup that
+// finishes last advances it), sync[1] = workgroups finished, sync[2 + b] = epoch at which chunk b's total was published.
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_fused_kernel(PttView v, const double *__restrict__ uleaf, const float *__restrict__ g,
+                                                                   const float *__restrict__ efflens, const double *__restrict__ part_c,
+                                                                   int nchunks_fwd, double *__restrict__ csum_out, GenePrior gp,
+                                                                   VD<K> *chunk_sums, unsigned int *sync, dd *__restrict__ C)
+{
+    __shared__ VD<K> smem[SCAN_THREADS / 64];
+    __shared__ double smd[4 * K];
+    const unsigned int epoch = __atomic_load_n(&sync[0], __ATOMIC_RELAXED);
+    double c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) c[d] = 0.0;
+    if (efflens) {
+        for (int ch = threadIdx.x; ch < nchunks_fwd; ch += SCAN_THREADS)
+#pragma unroll
+            for (int d = 0; d < K; ++d) c[d] += part_c[(size_t)ch * K + d];
+        block_sum_vec<K>(c, smd);
+        if (blockIdx.x == 0) store_vec_by_thread<K>(c, csum_out);
+    } else {
+#pragma unroll
+        for (int d = 0; d < K; ++d) c[d] = 1.0;
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    VD<K> val[SCAN_ITEMS];
+    VD<K> acc = ScanOps<VD<K>>::zero();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < v.n)
+            bwd_values<K>(v, base + j, uleaf, g, efflens, c, gp, val[j]);
+        else
+            val[j] = ScanOps<VD<K>>::zero();
+        acc = ScanOps<VD<K>>::add(acc, val[j]);
+    }
+    VD<K> tot;
+    VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
+    if (threadIdx.x == 0) {
+        chunk_sums[blockIdx.x] = tot;
+        __atomic_store_n(&sync[2 + blockIdx.x], epoch, __ATOMIC_RELEASE);
+    }
+    // the totals of the chunks before this one
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS)
+        while (__atomic_load_n(&sync[2 + i], __ATOMIC_ACQUIRE) != epoch) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    off = ScanOps<VD<K>>::add(chunk_prefix<VD<K>>(chunk_sums, blockIdx.x, smem), off);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < v.n) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) C[(size_t)(base + j) * K + d] = off.v[d];
+        }
+        off = ScanOps<VD<K>>::add(off, val[j]);
+        if (base + j == v.n - 1) {
+#pragma unroll
+            for (int d = 0; d < K; ++d) C[(size_t)v.n * K + d] = off.v[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = __atomic_add_fetch(&sync[1], 1u, __ATOMIC_ACQ_REL);
+        if (done == gridDim.x) {
+            __atomic_store_n(&sync[1], 0u, __ATOMIC_RELAXED);
+            __atomic_store_n(&sync[0], epoch + 1u == 0u ? 1u : epoch + 1u, __ATOMIC_RELEASE);
+        }
+    }
+}
+
 struct AdamConsts {
     double lr, rm, rv, eps, m_denom, v_denom;
     double inv_m_denom, inv_v_denom;  // reciprocals, computed once on the host (the update kernel is bound by its f64 instructions)
