@@ -115,7 +115,11 @@ public:
             kept_ -= granted;
         }
         if (blk.ev) {
-            (void)hipEventSynchronize(blk.ev);
+            if (hipEventSynchronize(blk.ev) != hipSuccess) {  // (should not happen: then the whole device, as hipFree would have waited)
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+                (void)hipGetLastError();
+            }
             (void)hipEventDestroy(blk.ev);
         }
         return blk.p;
@@ -124,6 +128,13 @@ public:
     bool give(int device, void *p, size_t granted, hipStream_t stream)
     {
         if (cap_ == 0 || granted > cap_) return false;
+        // a stream that is being captured into a graph: an event recorded there is a graph node, not a point in time -- the plain
+        // free then, as before (the regression model's captured step releases a temporary)
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return false;
+        }
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
             (void)hipGetLastError();
