@@ -547,6 +547,9 @@ inline void parallel_chunks(size_t count, size_t grain, F &&f)
 inline polee_status use_device(polee_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, POLEE_ERR_BAD_ARG, "null context");
+    // (every entry point starts here: an error some earlier call left behind on this thread -- a finaliser's, a call whose status
+    // nobody read -- must not be taken for the failure of this call's first kernel launch)
+    (void)hipGetLastError();
     POLEE_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return POLEE_OK;
 }
