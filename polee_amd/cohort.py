@@ -106,9 +106,13 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
     -- tree construction, device layout build -- takes seconds, so the samples are pipelined: every worker thread takes
     one sample through all stages on its own `Context` (= HIP stream); the C library releases the GIL, the host stages of
     some samples run under the device stage of others, and two fits that meet on the device share it (one's sparse pass
-    under the other's tree kernels, like `bench.py --samples-per-gpu`).  Two workers are the measured optimum (threads of
-    one process share the address space the builders fill and release; more samples in flight: worker PROCESSES,
-    `approximate_likelihood_cohort_processes`).
+    under the other's tree kernels, like `bench.py --samples-per-gpu`).  Since round 4 the layout -- and with
+    treemethod "cluster_device" / "cluster_auto" the tree -- is built on the GPU: the host side of a sample is loading and
+    uploading, the cohort is bound by the GPU, and 2 - 4 workers are the measured optimum (C2-size samples: 3.2 - 3.4 samples/s
+    with "cluster_auto", the tree on the host CPUs when they are idle and on the GPU otherwise -- the same tree either way;
+    DESIGN 5.1).  With the host builders (POLEE_DEVICE_BUILD=0, treemethod "cluster" / "cluster_parallel") threads of one
+    process share the address space the builders fill and release: two workers, or worker PROCESSES
+    (`approximate_likelihood_cohort_processes`).
 
     samples: iterable of zero-argument callables, each returning `(m, n, colptr, rowval, nzval, effective_lengths)`
              or the dict of `h5io.read_likelihood_matrix` (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
