@@ -4,8 +4,8 @@
 // in that order, similarities are quotients of integer counts (tests/test_gpu_hclust.py compares the arrays).
 //
 // Per round: the best live edge of every node (atomic max over the priorities), the edges that are the best of BOTH endpoints,
-// sorted by priority = the round's merges; their read sets united (every read finds its place in the union by a binary search in
-// the other set: no sequential merge), the candidates = neighbours of both halves, |new set n candidate| by binary searches
+// sorted by priority = the round's merges; their read sets united by merge path (tiles of 1 024 merged elements, each set read once,
+// consecutively), the candidates = neighbours of both halves, |new set n candidate| by binary searches
 // spread over as many blocks as the smaller set needs, the new edges appended, dead edges dropped.
 #include <algorithm>
 #include <chrono>
@@ -415,6 +415,116 @@ __global__ void hd_union_finish_kernel(uint32_t P, uint32_t base, const uint32_t
     N.set_len[k] = (uint32_t)(N.set_len[plo[q]] + N.set_len[phi[q]] - dups);
 }
 
+// ---- unions by merge path (the default) -----------------------------------------------------------------------------------------
+// The merged sequence of a pair (A first among equals) is cut into tiles of 1 024 elements; a tile's share of A and of B is found
+// by a binary search on its diagonal, both shares are read ONCE, consecutively, into LDS, every thread merges four elements, and an
+// element of B equal to the element of A in front of it is dropped.
+constexpr uint32_t MP_TILE = 1024;
+__global__ void hm_ntiles_kernel(uint32_t P, const uint32_t *wlen, uint32_t *ntile)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < P) ntile[q] = (wlen[q] + MP_TILE - 1) / MP_TILE;
+}
+__global__ void hm_heads_kernel(uint32_t P, const uint32_t *ntile, const uint32_t *tscan, uint32_t *tmap)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < P && ntile[q]) tmap[tscan[q]] = q;
+}
+__device__ inline uint32_t mp_split(const uint32_t *A, uint32_t la, const uint32_t *B, uint32_t lb, uint32_t d)
+{
+    uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ void hm_partition_kernel(uint32_t NT, const uint32_t *tmap, const uint32_t *tscan, const uint32_t *plo, const uint32_t *phi, Nodes N,
+                                    uint32_t *split)
+{
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= NT) return;
+    const uint32_t q = tmap[tile];
+    const uint32_t d = (tile - tscan[q]) * MP_TILE;
+    split[tile] = mp_split(N.set_p[plo[q]], N.set_len[plo[q]], N.set_p[phi[q]], N.set_len[phi[q]], d);
+}
+template <bool EMIT>
+__global__ __launch_bounds__(256) void hm_merge_kernel(uint32_t NT, const uint32_t *tmap, const uint32_t *tscan, const uint32_t *split, const uint32_t *plo,
+                                                       const uint32_t *phi, Nodes N, uint32_t *tile_count, const uint64_t *kscan, const uint64_t *slot,
+                                                       uint32_t *arena)
+{
+    __shared__ uint32_t sA[MP_TILE], sB[MP_TILE];
+    __shared__ uint32_t s_w[4];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= NT) return;
+    const uint32_t q = tmap[tile];
+    const uint32_t *A = N.set_p[plo[q]], *B = N.set_p[phi[q]];
+    const uint32_t la = N.set_len[plo[q]], lb = N.set_len[phi[q]];
+    const uint32_t lt = tile - tscan[q], d0 = lt * MP_TILE, d1 = min(d0 + MP_TILE, la + lb);
+    const uint32_t i0 = split[tile], i1 = (tile + 1 < NT && tmap[tile + 1] == q) ? split[tile + 1] : la;
+    const uint32_t j0 = d0 - i0, j1 = d1 - i1;
+    const uint32_t na = i1 - i0, nb = j1 - j0;
+    for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) sA[i] = A[i0 + i];
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) sB[i] = B[j0 + i];
+    const bool have_prev = i0 > 0;
+    const uint32_t prevA = have_prev ? A[i0 - 1] : 0u;
+    __syncthreads();
+    const uint32_t p0 = threadIdx.x * 4u, total = na + nb;
+    uint32_t keep[4], val[4], cnt = 0;
+    if (p0 < total) {
+        uint32_t ia = mp_split(sA, na, sB, nb, p0), ib = p0 - ia;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            keep[e] = 0;
+            val[e] = 0;
+            if (p0 + e < total) {
+                const bool fromA = ia < na && (ib >= nb || sA[ia] <= sB[ib]);
+                if (fromA) {
+                    val[e] = sA[ia++];
+                    keep[e] = 1;
+                } else {
+                    const uint32_t v = sB[ib++];
+                    const bool dup = ia > 0 ? sA[ia - 1] == v : (have_prev && prevA == v);
+                    val[e] = v;
+                    keep[e] = dup ? 0u : 1u;
+                }
+                cnt += keep[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = 0, val[e] = 0;
+    }
+    // exclusive prefix of cnt over the block
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += s_w[w];
+    const uint32_t excl = wbase + incl - cnt;
+    if (!EMIT) {
+        if (threadIdx.x == blockDim.x - 1) tile_count[tile] = excl + cnt;
+    } else {
+        uint32_t *out = arena + slot[q] + (kscan[tile] - kscan[tscan[q]]) + excl;
+        uint32_t k = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (keep[e]) out[k++] = val[e];
+    }
+}
+__global__ void hm_finish_kernel(uint32_t P, uint32_t base, const uint32_t *tscan, const uint64_t *kscan, const uint64_t *slot, uint32_t *arena, Nodes N)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P) return;
+    const uint32_t k = base + q;
+    N.set_p[k] = arena + slot[q];
+    N.set_len[k] = (uint32_t)(kscan[tscan[q + 1]] - kscan[tscan[q]]);
+}
+
 // ---- candidates -------------------------------------------------------------------------------------------------------------
 // the live neighbours of both halves of every merge, new ids applied: (merge, neighbour) keys, sorted and made unique
 __global__ void hd_cand_flag_kernel(uint64_t ne, Edges E, Nodes N, uint32_t *flag)
@@ -727,28 +837,67 @@ static polee_status hclust_rounds_device_core(polee_ctx *ctx, int64_t m, int64_t
         arena_live.push_back(P);
         DevBuf<uint32_t> &arena = arenas.back();
         POLEE_TRY(arena.alloc(ctx, (size_t)tot_w + 1));
-        DevBuf<uint32_t> isdup, lba;
-        POLEE_TRY(isdup.alloc(ctx, (size_t)tot_b + 1));
-        POLEE_TRY(lba.alloc(ctx, (size_t)tot_b + 1));
-        POLEE_TRY(dscan.alloc(ctx, (size_t)tot_b + 1));
-        HD_HIP(hipMemsetAsync(isdup.p + tot_b, 0, 4, stream));
-        if (tot_b) {
-            hipLaunchKernelGGL(hd_union_b_kernel, dim3(grid_for(tot_b)), dim3(256), 0, stream, tot_b, P, bscan.p, plo.p, phi.p, N, isdup.p, lba.p);
+        // (default; POLEE_HCLUST_MERGE_PATH=0: a binary search per element instead -- 19 ms of kernels per tree at C2 against 3.9 ms)
+        static const bool merge_path = getenv("POLEE_HCLUST_MERGE_PATH") == nullptr || atoi(getenv("POLEE_HCLUST_MERGE_PATH")) != 0;
+        if (merge_path) {
+            DevBuf<uint32_t> ntile, tscan, tmap, split, tcount;
+            DevBuf<uint64_t> kscan;
+            POLEE_TRY(ntile.alloc(ctx, (size_t)P + 1));
+            POLEE_TRY(tscan.alloc(ctx, (size_t)P + 1));
+            HD_HIP(hipMemsetAsync(ntile.p + P, 0, 4, stream));
+            hipLaunchKernelGGL(hm_ntiles_kernel, dim3(grid_for(P)), dim3(256), 0, stream, P, wlen.p, ntile.p);
             POLEE_KERNEL_CHECK(ctx);
-        }
-        HD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(isdup.p, ToU64()), dscan.p, (uint64_t)0, (size_t)tot_b + 1, stream));
-        if (tot_b) {
-            hipLaunchKernelGGL(hd_union_place_b_kernel, dim3(grid_for(tot_b)), dim3(256), 0, stream, tot_b, P, bscan.p, phi.p, N, isdup.p, dscan.p, lba.p,
+            HD_HIP(exclusive_sum(tmp, ntile.p, tscan.p, 0u, (size_t)P + 1, stream));
+            uint32_t NT = 0;
+            HD_HIP(hipMemcpyAsync(&NT, tscan.p + P, 4, hipMemcpyDeviceToHost, stream));
+            HD_HIP(hipStreamSynchronize(stream));
+            POLEE_TRY(tmap.alloc(ctx, (size_t)NT + 1));
+            POLEE_TRY(split.alloc(ctx, (size_t)NT + 1));
+            POLEE_TRY(tcount.alloc(ctx, (size_t)NT + 1));
+            POLEE_TRY(kscan.alloc(ctx, (size_t)NT + 1));
+            HD_HIP(hipMemsetAsync(tmap.p, 0, ((size_t)NT + 1) * 4, stream));
+            HD_HIP(hipMemsetAsync(tcount.p + NT, 0, 4, stream));
+            hipLaunchKernelGGL(hm_heads_kernel, dim3(grid_for(P)), dim3(256), 0, stream, P, ntile.p, tscan.p, tmap.p);
+            {
+                size_t bytes = 0;
+                HD_HIP(rocprim::inclusive_scan(nullptr, bytes, tmap.p, tmap.p, (size_t)NT, rocprim::maximum<uint32_t>(), stream));
+                HD_HIP(tmp.need(bytes));
+                HD_HIP(rocprim::inclusive_scan(tmp.p, bytes, tmap.p, tmap.p, (size_t)NT, rocprim::maximum<uint32_t>(), stream));
+            }
+            hipLaunchKernelGGL(hm_partition_kernel, dim3(grid_for(NT)), dim3(256), 0, stream, NT, tmap.p, tscan.p, plo.p, phi.p, N, split.p);
+            hipLaunchKernelGGL((hm_merge_kernel<false>), dim3(NT), dim3(256), 0, stream, NT, tmap.p, tscan.p, split.p, plo.p, phi.p, N, tcount.p,
+                               (const uint64_t *)nullptr, slot.p, arena.p);
+            POLEE_KERNEL_CHECK(ctx);
+            HD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(tcount.p, ToU64()), kscan.p, (uint64_t)0, (size_t)NT + 1, stream));
+            hipLaunchKernelGGL((hm_merge_kernel<true>), dim3(NT), dim3(256), 0, stream, NT, tmap.p, tscan.p, split.p, plo.p, phi.p, N, tcount.p, kscan.p,
                                slot.p, arena.p);
+            hipLaunchKernelGGL(hm_finish_kernel, dim3(grid_for(P)), dim3(256), 0, stream, P, base, tscan.p, kscan.p, slot.p, arena.p, N);
+            POLEE_KERNEL_CHECK(ctx);
+            HD_HIP(hipStreamSynchronize(stream));
+        } else {
+            DevBuf<uint32_t> isdup, lba;
+            POLEE_TRY(isdup.alloc(ctx, (size_t)tot_b + 1));
+            POLEE_TRY(lba.alloc(ctx, (size_t)tot_b + 1));
+            POLEE_TRY(dscan.alloc(ctx, (size_t)tot_b + 1));
+            HD_HIP(hipMemsetAsync(isdup.p + tot_b, 0, 4, stream));
+            if (tot_b) {
+                hipLaunchKernelGGL(hd_union_b_kernel, dim3(grid_for(tot_b)), dim3(256), 0, stream, tot_b, P, bscan.p, plo.p, phi.p, N, isdup.p, lba.p);
+                POLEE_KERNEL_CHECK(ctx);
+            }
+            HD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(isdup.p, ToU64()), dscan.p, (uint64_t)0, (size_t)tot_b + 1, stream));
+            if (tot_b) {
+                hipLaunchKernelGGL(hd_union_place_b_kernel, dim3(grid_for(tot_b)), dim3(256), 0, stream, tot_b, P, bscan.p, phi.p, N, isdup.p, dscan.p, lba.p,
+                                   slot.p, arena.p);
+                POLEE_KERNEL_CHECK(ctx);
+            }
+            if (tot_a) {
+                hipLaunchKernelGGL(hd_union_place_a_kernel, dim3(grid_for(tot_a)), dim3(256), 0, stream, tot_a, P, ascan.p, bscan.p, plo.p, phi.p, N, dscan.p,
+                                   slot.p, arena.p);
+                POLEE_KERNEL_CHECK(ctx);
+            }
+            hipLaunchKernelGGL(hd_union_finish_kernel, dim3(grid_for(P)), dim3(256), 0, stream, P, base, plo.p, phi.p, bscan.p, dscan.p, slot.p, arena.p, N);
             POLEE_KERNEL_CHECK(ctx);
         }
-        if (tot_a) {
-            hipLaunchKernelGGL(hd_union_place_a_kernel, dim3(grid_for(tot_a)), dim3(256), 0, stream, tot_a, P, ascan.p, bscan.p, plo.p, phi.p, N, dscan.p,
-                               slot.p, arena.p);
-            POLEE_KERNEL_CHECK(ctx);
-        }
-        hipLaunchKernelGGL(hd_union_finish_kernel, dim3(grid_for(P)), dim3(256), 0, stream, P, base, plo.p, phi.p, bscan.p, dscan.p, slot.p, arena.p, N);
-        POLEE_KERNEL_CHECK(ctx);
         // ---- candidates: the live neighbours of both halves
         DevBuf<uint32_t> eflag, epos;
         POLEE_TRY(eflag.alloc(ctx, (size_t)ne + 1));
