@@ -514,22 +514,31 @@ __device__ inline void ring_refill(WaveStream &ws, uint32_t ring_lds, int target
     ws.islot = islot;
 }
 
-// The slice loop of one wave over its share of a tile of the WIDE stream (16 x 16 x 4 matrix tiles; the narrow stream has
-// its own loop, narrow_stream below; this one is written for any width -- with WMAXR <= 16 and its packed variant for sets
-// of <= 8 it was the narrow stream's loop until the outer-product formulation).  RB = ring bytes per active wave, WMAXR =
-// widest transcript set of the stream.  `extras` = vector-memory operations issued AFTER the primed ring pieces and before
-// the first refill (the previous tile's flush, the next tile's prefetch): they are younger than the primed pieces
-// and older than every other piece, so only waits for primed pieces have to allow for them.
-template <int K, uint32_t RB, int WMAXR, bool WANT_LP, bool HAS_KS>
-__device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
-                                      uint32_t aux_lds, double &lpacc, int dbg
+// The slice loop of one wave over its share of a tile of the WIDE stream (A2: transcript sets of 17..32; 16 x 16 x 4 matrix
+// tiles -- the narrow stream has its own loop, narrow_stream below).  `extras` = vector-memory operations issued AFTER the
+// primed ring pieces and before the first refill (the previous tile's flush, the next tile's prefetch): they are younger than
+// the primed pieces and older than every other piece, so only waits for primed pieces have to allow for them.
+//
+// Round 5: ALL FOUR waves of the workgroup work on a wide tile, each with the narrow streams' 7 KiB ring (until round 4 two
+// waves with 14 KiB rings did, the other two waited at the tile's barrier: 15 % of all wave time on the SURVEY 8(d)
+// generator, 40 % on inputs of wide sets).  A wide slice is up to 2 + 32 rows of 256 bytes and does not fit such a ring
+// together with any look-ahead, so it passes through in TWO STAGES:
+//   stage A   header + transcripts 0..15 (4 352 bytes): the phase-1 operands of steps 0..3 AND the phase-2 operands of the
+//             first 16-row tile are read into registers (32), the bytes are released, the DMA for what follows goes out,
+//             phase 1 runs over the first sixteen transcripts;
+//   stage B   transcripts 16..w-1 (+ the multiplicities): phase 1 over them, the weights, the phase-2 operands of the
+//             second tile (in the registers the phase-1 operands have left), release, then both tiles' phase 2.
+// At any time the ring holds at most 4 352 bytes of the current slice + the look-ahead.
+template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS>
+__device__ inline void wide_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
-                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
+                                   , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
 #endif
-                                      )
+                                   )
 {
-    constexpr int RPFULL = (int)(RB / 1024u);
-    const int RP = ((dbg >> 8) & 15) ? min(RPFULL, (WMAXR > 16 ? 2 : 1) * ((dbg >> 8) & 15)) : RPFULL;  // (experiment: pieces requested ahead)
+    constexpr int RP = (int)(RB / 1024u);
+    constexpr uint32_t STAGE_A = 256u + 16u * 256u;  // header + sixteen rows
+    static_assert(STAGE_A + 2046u <= RB && (PSELL_WIDE_MAX - 16 + 1) * 256u + 2046u <= RB, "a stage of a wide slice (+ ks row) must fit the ring");
     // (computed here, opaquely: the lane constants below are then recomputed per tile -- a few dozen instructions --
     // instead of being hoisted out of the kernel's tile loop, kept alive across it and spilled)
     const int lane = wave_lane();
@@ -542,14 +551,14 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
     //       D1[e]: lane (tt, q), register v  =  S[16 q + 4 v + e][tt]
     //   weights   W = ks / S, in place (v_rcp_f32)
     //   phase 2   G[t][k] += sum_r V[t][r] W[k][r]      M = t, N = k, inner = r = 16 q + (0..15)
-    //       A[tt][kk=q] = V[tt][16 q + 4 j + e]   -- four 16-byte LDS reads
+    //       A[tt][kk=q] = V[16 mt + tt][16 q + 4 j + e]   -- four 16-byte LDS reads per 16-row tile mt
     //       B[kk=q][tt] = W[tt][16 q + 4 j + e]   = D1[e][j] of THIS lane: the weights never leave the registers
     //       D2 (rows 4 q + v, column tt) stays in registers for the whole run of slices sharing the set.
     // Rows are stored ROTATED (element r of row t at position (r + 4 t) & 63) so that the 16 lanes of every
     // 16-byte read hit 16 different bank groups.  Columns tt >= K are padding (B = 0 there).
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NT = (WMAXR + 15) / 16;  // 16-row tiles of transcripts (phase 2)
-    constexpr int NS = (WMAXR + 3) / 4;    // steps of 4 transcripts (phase 1)
+    constexpr int NT = 2;  // 16-row tiles of transcripts (phase 2)
+    constexpr int NS = 8;  // steps of 4 transcripts (phase 1)
     const int tt = lane & 15, q = lane >> 4;
     f32x4 acc0[NT], acc1[NT];  // two accumulation chains per tile (dependent MFMA latency 40 > issue 32)
     uint2 colq[NT];            // tile-local ids of transcripts 16 mt + 4 q + (0..3) of the current run, 16 bit each
@@ -566,26 +575,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
     LogAcc lpl;       // (WANT_LP) log of the product of this lane's row sums; with multiplicities: lp2 = sum ks log2 s
     lpl.init();
     double lp2 = 0.0;
-    bool pend_packed = false;  // the run accumulates in the packed (two 8 x 8 blocks) layout
     auto flush = [&]() {
-        if (NT == 1 && pend_packed) {
-            // D[(h, t)][(h', k)]: lane (n = tt, q), register v holds row m = 4 q + v; useful where h = q >> 1 equals
-            // h' = tt >> 3: transcript t = 4 (q & 1) + v (colq was read for q & 1), draw k = tt & 7
-            f32x4 sum = acc0[0] + acc1[0];
-            const unsigned cid[4] = {colq[0].x & 0xffffu, colq[0].x >> 16, colq[0].y & 0xffffu, colq[0].y >> 16};
-            // the two halves' blocks (lanes (tt < 8, q < 2) and (tt + 8, q + 2)) meet in the lower lane: one add per
-            // address, in a fixed order
-#pragma unroll
-            for (int v = 0; v < 4; ++v) sum[v] += __shfl(sum[v], lane + 40, 64);
-            const bool mine = q < 2 && tt < K && tt < 8;
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (mine && 4 * q + v < pend_w && sum[v] != 0.0f) atomicAdd(gw + cid[v] * K + tt, sum[v]);
-            acc0[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pend_w = 0;
-            return;
-        }
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             if (16 * mt < pend_w) {
@@ -593,7 +583,7 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
                 const unsigned cid[4] = {colq[mt].x & 0xffffu, colq[mt].x >> 16, colq[mt].y & 0xffffu, colq[mt].y >> 16};
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
-                    if (tt < K && 16 * mt + 4 * q + v < pend_w && sum[v] != 0.0f)
+                    if (tt < K && 16 * mt + 4 * q + v < pend_w && sum[v] != 0.0f && !(dbg & 2))
                         atomicAdd(gw + cid[v] * K + tt, sum[v]);
                 acc0[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -602,31 +592,34 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         pend_w = 0;
     };
 
-    // Operand addresses.  A slice starts at a multiple of 256 bytes and the ring holds whole 256-byte rows, so a row
-    // never straddles the ring's end: address = ring + wrap(pos_r + 256 + 256 t) + (offset inside the row), and for a
-    // lane the row t and the offset are constants.  Rows t >= w of a step (B = 0 there) read whatever follows the slice
-    // in the ring -- stream bytes or the zeros the ring was initialised with, always finite.
-    // (the narrow stream keeps these constants in registers; the wide one, short of registers, recomputes them)
-    constexpr bool PRE = NT == 1;
+    // Operand addresses.  A slice starts at a multiple of 256 bytes and the ring holds whole 256-byte rows, so a row never
+    // straddles the ring's end: address = ring + wrap(stage base + 256 x row) + (offset inside the row).  Rows t >= w of a
+    // step (B = 0 there) or of the second tile (their D2 rows are never used) read whatever follows the slice in the ring --
+    // stream bytes or the zeros the ring was initialised with, always finite.
     const uint32_t q256 = 256u * (uint32_t)q;
     auto k2f = [&](int st) -> uint32_t { return ring_lds + (uint32_t)((tt + 4 * st + q) & 15) * 16u; };  // phase 1, step st: row 4 st + q, chunk (tt + row) & 15
     auto c2f = [&](int mt, int j) -> uint32_t { return ring_lds + (uint32_t)((4 * q + j + 16 * mt + tt) & 15) * 16u; };  // phase 2, tile mt: row 16 mt + tt
-    uint32_t k2[PRE ? NS : 1];
-    if (PRE) {
-#pragma unroll
-        for (int st = 0; st < NS; ++st) k2[PRE ? st : 0] = k2f(st);
-    }
-    uint32_t c2[PRE ? 4 : 1];
-    if (PRE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c2[PRE ? j : 0] = c2f(0, j);
-    }
     auto lds_f4 = [](uint32_t a) -> f32x4 {
         return *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>((uintptr_t)a);
     };
+    auto wrap = [&](uint32_t a) -> uint32_t { return min(a, a - RB); };  // a < 2 RB: a mod RB (unsigned wrap-around)
 
-    uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
+    uint32_t pos = 0;    // byte offset of the ring's tail inside this wave's range (a slice start, or STAGE_A behind one)
     uint32_t pos_r = 0;  // pos modulo the ring size
+    auto wait_for = [&](uint32_t upto) {  // bytes [pos, pos + upto) of the wave's range must have landed
+        const int need = (int)((pos + upto + 1023u) >> 10);
+        if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);  // (only with a shortened look-ahead: experiments)
+        // (wave-uniform: said explicitly, or the ladder below is compiled with vector compares and exec masks)
+        int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
+        wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
+    };
+    auto release = [&](uint32_t nbytes) {  // the first nbytes behind the tail are consumed: the DMA for what follows goes out
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pos += nbytes;
+        pos_r += nbytes;
+        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
+        ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
+    };
     for (int si = 0; si < ws.nsl; ++si) {
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
@@ -635,125 +628,97 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
         const uint32_t units = off_next - off;
         const int w = (int)(units / 2u) - 1 - (HAS_KS ? 1 : 0);  // 256-byte header (column ids) + w rows of 64 values (+ ks row)
         const uint32_t bytes = units * 128u;
-        // all pieces covering [pos, pos+bytes) must have landed
-        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the short non-matrix sections of a slice win the issue arbitration (-2.5 %)
+        const bool two = w > 16;  // (always, as the builders fill this stream; a narrower slice passes in one stage)
+        if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the short non-matrix sections of a slice win the issue arbitration
         STAMP(1);  // slice bookkeeping
-        {
-            const int need = (int)((pos + bytes + 1023u) >> 10);
-            if (ws.issued < need) ring_refill<RB>(ws, ring_lds, need);  // (only with a shortened look-ahead: experiments)
-            // (wave-uniform: said explicitly, or the ladder below is compiled with vector compares and exec masks)
-            int allowed = ws.issued - need + (need <= ws.primed ? extras : 0);
-            wait_vm_outstanding(__builtin_amdgcn_readfirstlane(allowed));
-        }
+        wait_for(two ? STAGE_A : bytes);
         STAMP(2);  // waiting for the DMA
-        auto ring_at = [&](uint32_t rel) -> const char * {  // rel < RB: offset relative to the slice start
-            uint32_t a = pos_r + rel;
-            a = a >= RB ? a - RB : a;
-            return ring + a;
-        };
         if (pend_w != 0 && !(flags & 2)) flush();
-        if (pend_w == 0) {  // a new run: the tile-local ids of its transcripts and their x rows
-            pend_packed = NT == 1 && K <= 8 && w <= 8 && !(dbg & 32);
+        if (pend_w == 0) {  // a new run: the tile-local ids of its transcripts and their x rows (all in the header)
+            const char *hdr = ring + pos_r;
 #pragma unroll
-            for (int mt = 0; mt < NT; ++mt)
-                colq[mt] = *reinterpret_cast<const uint2 *>(ring_at((uint32_t)(32 * mt + 8 * (pend_packed ? (q & 1) : q))));
+            for (int mt = 0; mt < NT; ++mt) colq[mt] = *reinterpret_cast<const uint2 *>(hdr + 32 * mt + 8 * q);
             int cl[NS];
 #pragma unroll
-            for (int st = 0; st < NS; ++st)
-                cl[st] = *reinterpret_cast<const uint16_t *>(ring_at((uint32_t)(2 * min(4 * st + q, w - 1))));
+            for (int st = 0; st < NS; ++st) cl[st] = *reinterpret_cast<const uint16_t *>(hdr + 2 * min(4 * st + q, w - 1));
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 const float xv = xw[cl[st] * K + min(tt, K - 1)];
                 xq[st] = (tt < K && 4 * st + q < w) ? xv : 0.0f;
             }
         }
-
         STAMP(3);  // run change: flush + column lookup
-        // operand reads: for the narrow stream (one 16-row tile) both phases' reads are issued together up front;
-        // the wide stream reads per group of 4 steps / per tile, to stay inside the register budget
-        constexpr bool WIDE = NT > 1;
-        // (with multiplicities the ks row is read after phase 1; the debug switch that skips phase 1 skips the reads)
-        const bool EARLY_REFILL = !WIDE && !HAS_KS && !(dbg & 4);
-        auto wrap = [&](uint32_t a) -> uint32_t { return min(a, a - RB); };  // a < 2 RB: a mod RB (unsigned wrap-around)
-        auto read_tile = [&](int mt, f32x4 (&dst)[4]) {
-            // rows t >= w read whatever follows in the ring: their D2 rows are never used
-            const uint32_t row = wrap(pos_r + 256u + 256u * (uint32_t)(16 * mt + tt));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = lds_f4(row + (PRE ? c2[PRE ? j : 0] : c2f(mt, j)));
-        };
-        // Narrow sets (w <= 8) use HALF the phase-2 instructions: the 16 x 16 tile holds two 8 x 8 problems, rows
-        // m = (h, t) and columns n = (h', k) with h, h' the halves {j = 0, 1} / {j = 2, 3} of every lane group's 16
-        // fragments; the diagonal blocks h = h' are the two halves' contributions to G[t][k], the others are unused.
-        //     A[(h, t)][kk = q] = V[t][16 q + 4 (jj + 2 h) + e]          two 16-byte reads per lane instead of four
-        //     B[kk = q][(h', k)] = W[k][16 q + 4 (jj + 2 h') + e]        lanes tt < 8: their own D1[e][jj];
-        //                                                                lanes tt >= 8: D1[e][jj + 2] of lane tt - 8 (DPP)
-        const bool packed = !WIDE && K <= 8 && w <= 8 && !(dbg & 32);
-        f32x4 av2[4];
-        if (!WIDE) {
-            if (packed) {
-                const uint32_t row = wrap(pos_r + 256u + 256u * (uint32_t)(tt & 7));
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    av2[jj] = lds_f4(row + ring_lds + (uint32_t)((4 * q + jj + 2 * (tt >> 3) + (tt & 7)) & 15) * 16u);
-            } else {
-                read_tile(0, av2);
-            }
-        }
-        // phase 1
+
         f32x4 d1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) d1[e] = f32x4{ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR, ROWSUM_FLOOR};
-        if (!(dbg & 4)) {
+        f32x4 av1[4], av2a[4], av2b[4];
+        auto phase1 = [&](int st0) {
 #pragma unroll
-            for (int g0 = 0; g0 < NS; g0 += 4) {
-                if (4 * g0 < w) {
-                    f32x4 av1[4];
+            for (int u = 0; u < 4; ++u) {
+                if (4 * (st0 + u) < w) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int st = g0 + u;
-                        if (st < NS && 4 * st < w) av1[u] = lds_f4(wrap((pos_r + 256u + 1024u * (uint32_t)st) + q256) + (PRE ? k2[PRE ? st : 0] : k2f(st)));
-                    }
-                    if (EARLY_REFILL) {
-                        // narrow stream: every operand of the slice is now on its way into registers; once the LDS
-                        // reads have landed the slice's ring bytes are free, so the DMA for the pieces behind it is
-                        // issued BEFORE the two MFMA phases instead of after them
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        STAMP(11);  // operand reads landed
-                        pos += bytes;
-                        pos_r += bytes;
-                        pos_r = pos_r >= RB ? pos_r - RB : pos_r;
-                        ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
-                        STAMP(6);  // refill
-                    }
-                    if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int st = g0 + u;
-                        if (st < NS && 4 * st < w) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                d1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[u][e], xq[st], d1[e], 0, 0, 0);
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) d1[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[u][e], xq[st0 + u], d1[e], 0, 0, 0);
                 }
             }
+        };
+        // ---- stage A: transcripts 0..15
+        {
+            const uint32_t rows = pos_r + 256u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * u < w) av1[u] = lds_f4(wrap(rows + 1024u * (uint32_t)u + q256) + k2f(u));
+            const uint32_t row = wrap(rows + 256u * (uint32_t)tt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av2a[j] = lds_f4(row + c2f(0, j));
         }
-#ifdef POLEE_STAMPS
-        asm volatile("s_nop 0" : "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]));  // (the stamp waits for the MFMA results)
-        STAMP(14);  // phase 1 MFMAs
-#endif
+        f32x4 kv[4];
+        if (HAS_KS && !two) {
+            const uint32_t kr = wrap(pos_r + 256u + 256u * (uint32_t)w) + 64u * (uint32_t)q;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) kv[v] = lds_f4(ring_lds + kr + 16u * (uint32_t)v);
+        }
+        if (two) {
+            release(STAGE_A);
+            STAMP(6);  // refill
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+            phase1(0);
+            // ---- stage B: transcripts 16..w-1; the tail now stands at row 16
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(3);
+            STAMP(14);  // phase 1 MFMAs
+            wait_for(bytes - STAGE_A);
+            STAMP(2);  // waiting for the DMA
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (4 * (4 + u) < w) av1[u] = lds_f4(wrap(pos_r + 1024u * (uint32_t)u + q256) + k2f(4 + u));
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+            phase1(4);
+            // the second tile's phase-2 operands (rows t >= w: whatever lies there), in the registers the phase-1 operands have left
+            const uint32_t row = wrap(pos_r + 256u * (uint32_t)tt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av2b[j] = lds_f4(row + c2f(1, j));
+            if (HAS_KS) {  // the multiplicities travel with the slice (its last row): ks of fragments 16 q + 4 v + (0..3)
+                const uint32_t kr = wrap(pos_r + 256u * (uint32_t)(w - 16)) + 64u * (uint32_t)q;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) kv[v] = lds_f4(ring_lds + kr + 16u * (uint32_t)v);
+            }
+            release(bytes - STAGE_A);
+            STAMP(6);  // refill
+        } else {
+            release(bytes);
+            STAMP(6);  // refill
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+            phase1(0);
+        }
         // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt
         if (HAS_KS) {
-            // the multiplicities travel with the slice (its last row): no global load in this loop
-            const f32x4 *kp = reinterpret_cast<const f32x4 *>(ring_at(256u + (uint32_t)w * 256u) + 64 * q);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const f32x4 kv = kp[v];  // ks of fragments 16 q + 4 v + (0..3)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sv = d1[e][v];
-                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lp2 += ks_log2(kv[e], sv);
-                    d1[e][v] = kv[e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
+                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lp2 += ks_log2(kv[v][e], sv);
+                    d1[e][v] = kv[v][e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
                 }
             }
         } else {
@@ -766,48 +731,27 @@ __device__ inline void uniform_stream(WaveStream &ws, const char *ring, int extr
                     d1[e][v] = __builtin_amdgcn_rcpf(sv);
                 }
         }
-
-        STAMP(4);  // phase 1
-        if (!(dbg & 2) && packed) {
+        STAMP(4);  // phase 1 + weights
+        if (!(dbg & 2)) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                float b[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)  // row_shr:8 into lanes 8..15 of every row of 16 (bank mask 0xc); lanes 0..7 keep their own
-                    b[e] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d1[e][jj]), __float_as_int(d1[e][jj + 2]),
-                                                                      0x118, 0xf, 0xc, false));
-                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][0], b[0], acc0[0], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][1], b[1], acc1[0], 0, 0, 0);
-                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][2], b[2], acc0[0], 0, 0, 0);
-                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[jj][3], b[3], acc1[0], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2a[j][0], d1[0][j], acc0[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2a[j][1], d1[1][j], acc1[0], 0, 0, 0);
+                acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2a[j][2], d1[2][j], acc0[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2a[j][3], d1[3][j], acc1[0], 0, 0, 0);
             }
-        } else if (!(dbg & 2)) {
+            if (two) {
 #pragma unroll
-            for (int mt = 0; mt < NT; ++mt) {
-                if (16 * mt < w) {
-                    if (WIDE) read_tile(mt, av2);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][0], d1[0][j], acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][1], d1[1][j], acc1[mt], 0, 0, 0);
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][2], d1[2][j], acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2[j][3], d1[3][j], acc1[mt], 0, 0, 0);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2b[j][0], d1[0][j], acc0[1], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2b[j][1], d1[1][j], acc1[1], 0, 0, 0);
+                    acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2b[j][2], d1[2][j], acc0[1], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2b[j][3], d1[3][j], acc1[1], 0, 0, 0);
                 }
             }
         }
         pend_w = w;
         STAMP(5);  // phase 2
-
-        // the slice is consumed: refill the ring behind it
-        if (!EARLY_REFILL) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pos += bytes;
-            pos_r += bytes;
-            pos_r = pos_r >= RB ? pos_r - RB : pos_r;
-            ring_refill<RB>(ws, ring_lds, min(ws.npieces, (int)(pos >> 10) + RP));
-        }
-        STAMP(6);  // refill
     }
     if (pend_w != 0) flush();
     if (WANT_LP) lpacc += HAS_KS ? lp2 * 0.693147180559945309417 : lpl.log_value();
@@ -1740,7 +1684,7 @@ __global__ void single_lp_finish_kernel(const double *__restrict__ part, int nbl
 }
 
 // LDS layout of the streaming kernel:
-//   [rings: 4 x 7 KiB (A1) or 2 x 14 KiB (A2)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
+//   [rings: 4 x 7 KiB (all kinds but A2M) or 2 x 14 KiB (A2M)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
 template <int K>
 constexpr uint32_t stream_ring_total()
@@ -1805,13 +1749,12 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     unsigned long long t_tile0 = t_wg0;
 #endif
 
-    // 0 = A1 (dense narrow), 2 = A1M (masked narrow); 1 = A2 (dense wide), 3 = A2M (masked wide) -- the odd kinds: two active
-    // waves, 14 KiB rings; the schedule holds no others
-    // 4 = BN (mixed narrow: four waves, 7 KiB rings)
+    // 0 = A1 (dense narrow), 2 = A1M (masked narrow), 1 = A2 (dense wide, in two stages per slice: wide_stream), 4 = BN (mixed
+    // narrow): four waves, 7 KiB rings; 3 = A2M (masked wide): two active waves, 14 KiB rings; the schedule holds no others
     auto kind_of = [&](uint32_t tile) -> int { return (int)tile < A.tiles_a1 ? 0 : ((int)tile < A.tiles_a1m ? 2 : ((int)tile < A.tiles_a2 ? 1 : ((int)tile < A.tiles_a ? 3 : 4))); };
     // this wave's share [sb, se) of an A tile's slices: a contiguous block, so that runs stay inside one wave
     auto share = [&](int kind, const PosDesc &t, uint32_t &sb, uint32_t &se) {
-        const int nw = (kind & 1) ? 2 : 4;
+        const int nw = kind == 3 ? 2 : 4;
         uint32_t a1 = t.c1, a2 = t.c2, a3 = t.c3;
         asm volatile("" : "+s"(a1), "+s"(a2), "+s"(a3));  // (opaque: or the selects below become an indexed load of a PosDesc kept in scratch memory)
         const uint32_t lo = wave == 0 ? t.s0 : (wave == 1 ? a1 : (wave == 2 ? a2 : a3));
@@ -1863,7 +1806,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
         ws.gsrc = reinterpret_cast<const uint8_t *>(uniform_ptr(A.data + (size_t)cb * 128));
-        if (!(kind & 1)) {
+        if (kind != 3) {
             ring_refill<STREAM_RB1>(ws, lds_addr(rings + wave * STREAM_RB1), min(ws.npieces, ahead ? min(ahead, (int)(STREAM_RB1 / 1024u)) : (int)(STREAM_RB1 / 1024u)));
         } else {
             ring_refill<STREAM_RB2>(ws, lds_addr(rings + (wave < 2 ? wave : 0) * STREAM_RB2), min(ws.npieces, ahead ? min(2 * ahead, (int)(STREAM_RB2 / 1024u)) : (int)(STREAM_RB2 / 1024u)));
@@ -1943,7 +1886,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #endif
             );
         } else {
-            uniform_stream<K, STREAM_RB2, PSELL_WIDE_MAX, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+            wide_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                            , st_acc, st_last
 #endif
@@ -1958,7 +1901,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         young = 0;
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
-        const bool early = more && ((kind_of(nxt.tile) ^ kind) & 1) == 0;  // (the narrow kinds share a ring geometry, and so do the wide ones)
+        const bool early = more && (kind_of(nxt.tile) == 3) == (kind == 3);  // (all kinds but the wide masked one share a ring geometry)
         if (early) start_ring(nxt);
         STAMP(13);  // starting the next ring (before the barrier)
         lds_barrier();  // every wave's contributions are in gw
@@ -2039,7 +1982,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         v += __shfl_xor(v, 32, 64);
         if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
     }
-    if (dyn && threadIdx.x == 0) {
+    if (dyn && wave == 0 && wave_lane() == 0) {  // (not threadIdx.x: kept alive across the tile loop it is spilled)
         // Every draw of this launch has been made before the last workgroup arrives here: the draws are this thread's own
         // earlier atomics, ordered before its arrival by the RELEASE half of the increment; the workgroup that sees G - 1
         // ACQUIRES all of them before it resets the counters for the next launch (the ordering is now stated,
@@ -2174,7 +2117,7 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     // a uniform slice of w transcripts occupies (w+1)*256 bytes and may start 768 bytes into a 1 KiB piece
     static_assert((PSELL_NARROW_MAX + 2) * 256 + 1024 <= STREAM_RB1, "A1 slices (+ ks row) must fit their ring");
     static_assert(((PSELL_MIXED_NARROW_MAX * 384 + 255) & ~255) + 256 + 1024 <= STREAM_RB1, "BN slices (+ ks row) must fit their ring");
-    static_assert((PSELL_WIDE_MAX + 3) * 256 + 1024 <= STREAM_RB2, "A2 / A2M slices (+ ks row) must fit their ring");
+    static_assert((PSELL_WIDE_MAX + 3) * 256 + 1024 <= STREAM_RB2, "A2M slices (+ ks row) must fit their ring");  // (A2: wide_stream's own assertion)
     const size_t lds = stream_lds_bytes<K, DET>();
     int &occ = ll->occ_cache[K][LP ? 1 : 0][KS ? 1 : 0][DET ? 1 : 0];
     if (occ == 0) {
@@ -2484,7 +2427,7 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
         uint32_t *cut = &ll->tile_cut[(size_t)3 * t];
         cut[0] = cut[1] = cut[2] = s1;
         if (t >= h.num_tiles_s) continue;
-        const int nw = h.stream_of_tile(t) != PSELL_A2 && h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
+        const int nw = h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
         // (experiment, POLEE_CUT_MODEL="a,b,c": cost = a + b x groups of four transcripts + c x (1 + groups) when the slice
         // starts a new run -- the flush of the previous set and the column lookup of the new one)
         static const char *cut_env = getenv("POLEE_CUT_MODEL");
@@ -2801,7 +2744,12 @@ static polee_status polee_loglik_create_from_xbuild_impl(polee_ctx *ctx, const p
     POLEE_HIP_TRY(ctx, hipStreamSynchronize(xctx->stream));
     bool done = false;
     polee_status st = POLEE_OK;
-    if (psell_device_enabled() && m < ((int64_t)1 << 32) - 1) {
+    uint64_t nnz_dev = 0;  // (the device builder numbers non-zeros in 32 bits, as the from_xt path checks: ADVICE r4)
+    if (m > 0) {
+        POLEE_HIP_TRY(ctx, hipMemcpy(&nnz_dev, tcolptr + m, sizeof nnz_dev, hipMemcpyDeviceToHost));
+        nnz_dev -= 1;
+    }
+    if (psell_device_enabled() && nnz_dev < (1ull << 32) - 1 && m < ((int64_t)1 << 32) - 1) {
         PsellDevCSR C;
         DevBuf<int64_t> d_ks;
         if (ks) POLEE_TRY(d_ks.upload(ctx, ks, (size_t)m));

@@ -9,7 +9,7 @@
 //     column-major:  float val[w][64]; uint16 lcol[w][64];   w = longest row of the slice
 //     (shorter rows are padded with val = 0).  One wave-instruction therefore loads 256
 //     contiguous bytes of values and 128 of indices -- fully coalesced, no row pointers.
-//   * Consecutive slices form a TILE (64 / 64 / 8 / 16 / 16 / 16 slices in streams A1 / A1M / A2 / A2M / BN / B), the unit of work of one
+//   * Consecutive slices form a TILE (64 / 64 / 32 / 16 / 64 / 16 slices in streams A1 / A1M / A2 / A2M / BN / B), the unit of work of one
 //     256-thread workgroup.  A tile owns a dictionary of the distinct transcripts its rows touch
 //     (dict: local id u16 -> transcript id u32; the tile is closed before the dictionary would
 //     pass 128 entries).  Every tile's dictionary starts at a multiple of 4 entries (padded with
@@ -70,7 +70,7 @@ constexpr int PSELL_MAX_TILE_COLS = 1024;     // hard limit = longest supported 
 constexpr int PSELL_TILE_COLS_TARGET = 128;   // a tile is closed when its dictionary would grow past this
 constexpr int PSELL_DICT_ALIGN = 4;           // a tile's dictionary starts at a multiple of this many entries
 constexpr int PSELL_TILE_SLICES_A1 = 64;      // slices per tile (= per workgroup) in each stream
-constexpr int PSELL_TILE_SLICES_A2 = 8;
+constexpr int PSELL_TILE_SLICES_A2 = 32;     // (round 5: all four waves work on a wide tile -- 8 slices until then, for two)
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x1fffffffu;  // slice_off entries carry the slice flags in bits 29..31
