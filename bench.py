@@ -31,9 +31,13 @@ WORKLOADS = {
     "c1": (1000, 100000, 2.2),
     # REAL-STRUCTURE workload: the reference's likelihood-matrix fixture (tests/golden) tiled block-diagonally 639 times
     "fixture": (313 * 639, 19743 * 639, 42775 / 19743),
+    # ... at full size: every fragment of the tiled fixture nine times (seeded value factors): 113.5 M fragments, 246 M non-zeros
+    "fixture_full": (313 * 639, 19743 * 639 * 9, 42775 / 19743),
     "small": (20000, 3000000, 8.0),
     "c2": (200000, 30000000, 8.0),
     "c5": (200000, 150000000, 8.0),
+    # probe input of WIDE transcript sets (genes of ~20 isoforms: 87 % of the non-zeros in stream A2), C2's nnz
+    "wide": (200000, 12000000, 20.0),
     # secondary metric: regression steps/s, S samples x F = 2 factors x n transcripts; own code path
     "c3": (200000, 6, 2),
     "c4": (200000, 8, 2),
@@ -255,6 +259,11 @@ def roofline_of(info, st0, st1, m, n, K, deterministic=False):
     return {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        #  which of the two figures is which, in the line itself:
+        "frac_definition": "physical: bytes the device layout really moves per launch / kernel time / peak.  SURVEY 8(d)'s "
+                           "figure -- ALGORITHMIC (CSR-equivalent) bytes of the same rows / the same time / peak -- is "
+                           "`effective_frac` (= frac_survey_8d)",
+        "frac_survey_8d": effective / HBM_PEAK_GBS,
         "definition": "achieved = bytes the device layout moves per launch (slice streams + x / gradient windows) / "
                       "kernel time; effective_* = SURVEY 8(d)'s CSR-equivalent bytes of the same rows / the same time",
         "kernel": "loglik_stream_kernel<%d, false, false, %s>" % (K, "true" if deterministic else "false"),
@@ -382,8 +391,8 @@ def main():
     for si in range(S):
         t0 = time.time()
         # (row-sharded: every rank generates the same sample and keeps its block of fragments)
-        if args.workload == "fixture":
-            smp_i = synth.tile_fixture(639)
+        if args.workload in ("fixture", "fixture_full"):
+            smp_i = synth.tile_fixture(639, copies=9 if args.workload == "fixture_full" else 1)
         else:
             smp_i = synth.make_sample(n, m, mean_nnz, seed=sample_seed(args.seed, 0 if args.row_shard else rank * S + si),
                                       dropout=args.set_diversity, literal=args.literal_subsets)
@@ -455,10 +464,14 @@ def main():
             if ((cap.get("draws"), cap.get("tree"), cap.get("nnz"), cap.get("source_id")) == (K, args.tree, info["nnz"], sid)
                     and not args.deterministic):
                 traffic = cap.get("hbm_bytes_per_launch")
+                # where the figure comes from: a PMC capture of THIS build (source_id) on this workload, not of this run
+                roof["traffic_source"] = {"file": "profiles/traffic_%s.json" % args.workload, "captured": cap.get("captured"),
+                                          "commit": cap.get("commit"), "source_id": cap.get("source_id"),
+                                          "pmc": cap.get("source")}
         except Exception:
             traffic = None
     roof["traffic"] = traffic
-    input_name = ("tiled_real_fixture_x639" if args.workload == "fixture" else
+    input_name = ("tiled_real_fixture_x639" if args.workload == "fixture" else "tiled_real_fixture_x639_depth9" if args.workload == "fixture_full" else
                   ("literal_subsets" if args.literal_subsets else "gene_patterns") + ("_dropout_%g" % args.set_diversity if args.set_diversity else ""))
 
     out = {
@@ -479,6 +492,7 @@ def main():
                         "K=%d draws per VI iteration, %s tree; set structure: %s" % (
                             args.workload.upper(), n, m, info["nnz"], info["nnz"] / m, K, args.tree,
                             "the reference's real fixture tiled x639" if args.workload == "fixture" else
+                            "the reference's real fixture tiled x639, every fragment 9 times (seeded value factors)" if args.workload == "fixture_full" else
                             ("every fragment its own random subset of its gene's isoforms (SURVEY 8(d) literally)"
                              if args.literal_subsets else "one of <= 12 compatibility patterns per gene (generator of rounds 1-3)")
                             + (", per-entry dropout %g" % args.set_diversity if args.set_diversity else "")),
@@ -518,7 +532,9 @@ def main():
         gc.collect()
         for name, make in (("gene_patterns" if args.literal_subsets else "literal_subsets",
                             lambda: synth.make_sample(n, m, mean_nnz, seed=sample_seed(args.seed, 0), literal=not args.literal_subsets)),
-                           ("tiled_real_fixture_x639", lambda: synth.tile_fixture(639))):
+                           ("tiled_real_fixture_x639", lambda: synth.tile_fixture(639)),
+                           # (round 5) the same set structure at C2's size: every fragment nine times, 246 M non-zeros
+                           ("tiled_real_fixture_x639_depth9", lambda: synth.tile_fixture(639, copies=9))):
             try:
                 smp_o = make()
                 roof["by_input"][name] = measure_other_input(P, synth, ctx, name, smp_o, args, K)

@@ -73,6 +73,11 @@ polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n
 polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *view);
 void polee_debug_psell_free(polee_psell_debug *p);
 
+/* Debug mode of the kept device buffers (POLEE_DEVICE_CACHE_POISON=1 in the environment before the library's first allocation;
+ * csrc/common.hpp DevBlockCache): a released block is filled with a pattern on its owner's stream and the pattern is verified
+ * when the block is handed out again or freed.  Counts so far: blocks verified, blocks found overwritten, words overwritten. */
+void polee_debug_device_cache_poison(int64_t *checked_blocks, int64_t *bad_blocks, int64_t *bad_words);
+
 /* Process every slice with the mixed-slice kernel (the uniform streams' LDS-DMA kernel is bypassed): two
  * different algorithms over the same layout, used by the full-size cross-check test. */
 polee_status polee_debug_loglik_force_mixed(polee_loglik *ll, int on);

@@ -142,8 +142,16 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
         return list(ex.map(job, enumerate(samples)))
 
 
-def _process_init(host_threads, cache_mb=None, device_cache_mb=None, host_tree_slot=None):
+def _process_init(host_threads, cache_mb=None, device_share=None, host_tree_slot=None):
+    """device_share = (device, processes): this worker's cap on kept device buffers is its share of HALF the device's
+    memory as the runtime reports it (hipMemGetInfo), at most 64 GiB (it was a constant sized for 288 GB)."""
     import os
+    device_cache_mb = None
+    if device_share is not None and "POLEE_DEVICE_CACHE_MB" not in os.environ:
+        from . import core
+        device, processes = device_share
+        _, total = core.Context(device).mem_info()  # (asks the runtime; the block cache is not constructed before its first use)
+        device_cache_mb = min(65536, (int(total) // 2 // max(1, int(processes))) >> 20)
     if host_tree_slot is not None:  # treemethod "cluster_auto": the slot for host-built trees is the cohort's, not the process's
         from . import core
         core._host_tree_slot = host_tree_slot
@@ -226,8 +234,8 @@ def approximate_likelihood_cohort_processes(approx, samples, processes=4, host_t
     cache_mb = max(256, core.host_cache_configure(-1) // max(1, int(processes)))
     with ProcessPoolExecutor(max_workers=max(1, int(processes)), mp_context=mpctx,
                              initializer=_process_init,
-                             # (device buffers kept per process: two thirds of a 288 GB GPU shared out, at most the library's default)
-                             initargs=(host_threads, cache_mb, min(65536, 196608 // max(1, int(processes))), slot)) as ex:
+                             # (device buffers kept per process: half the GPU's memory shared out, asked of the runtime by the worker)
+                             initargs=(host_threads, cache_mb, (device, int(processes)), slot)) as ex:
         jobs = [(i, s, approx.treemethod, device, kwargs) for i, s in enumerate(samples)]
         for idx, params in ex.map(_process_job, jobs):
             if on_result is not None:

@@ -414,6 +414,14 @@ def host_cache_bytes():
     return int(f())
 
 
+def device_cache_poison_stats():
+    """Debug mode POLEE_DEVICE_CACHE_POISON=1 (csrc/common.hpp): (blocks verified, blocks found overwritten after their release,
+    words overwritten) so far; zeros when the mode is off."""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    L.lib().polee_debug_device_cache_poison(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 def device_cache_bytes():
     """Device bytes the library keeps for its next allocations (polee_device_cache_bytes; host_cache_trim() frees them)."""
     f = L.lib().polee_device_cache_bytes
@@ -644,6 +652,13 @@ def sample_and_tree(approx, m, n, colptr, rowval, nzval, effective_lengths, ctx=
 
 def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths, ctx, ks, others):
     from concurrent.futures import ThreadPoolExecutor
+    #  the tree job runs beside the layout build on a helper thread: it gets a context -- a HIP stream and an error
+    # slot -- of its OWN on the same device, kept with the caller's context.  On one shared context the two builders' kernels
+    # queued behind each other on one stream, every stream synchronisation of either waited for both, and both threads wrote
+    # the context's error string.
+    tree_ctx = getattr(ctx, "_tree_ctx", None)
+    if tree_ctx is None and tm in ("cluster_auto", "cluster_device"):
+        tree_ctx = ctx._tree_ctx = Context(ctx.device)
     with ThreadPoolExecutor(max_workers=1) as pool:
         fut = None
         if tm == "cluster_auto":
@@ -656,13 +671,13 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
 
             def tree_job():
                 try:
-                    return hclust(m, n, colptr, rowval, parallel=on_host, device=not on_host, ctx=ctx)
+                    return hclust(m, n, colptr, rowval, parallel=on_host, device=not on_host, ctx=tree_ctx)
                 finally:
                     if on_host:
                         _host_tree_slot.release()
             fut = pool.submit(tree_job)
         elif tm in ("cluster", "cluster_parallel", "cluster_device"):
-            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", ctx)
+            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", tree_ctx or ctx)
         sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx)
         if fut is not None:
             parents, js = fut.result()

@@ -77,6 +77,11 @@ inline polee_status fail(polee_ctx *ctx, polee_status code, const char *fmt, ...
                                  hipGetErrorString(e__), __FILE__, __LINE__);              \
     } while (0)
 
+// Debug mode of the kept device buffers (POLEE_DEVICE_CACHE_POISON=1): ctx.hip
+void dev_poison_fill(void *p, size_t bytes, hipStream_t stream);  // fills the block with a pattern, on the stream
+size_t dev_poison_bad_words(void *p, size_t bytes);               // 32-bit words that no longer hold it (synchronous)
+void dev_poison_report(size_t granted, size_t bad_words, const char *where);
+
 // Freed device buffers are KEPT (process-wide, per device, by size class) instead of going back through hipFree: the builders
 // allocate and free hundreds of buffers per sample, hipFree waits for the whole device, and with plain hipMalloc / hipFree every
 // few samples one of the first large allocations of a sample stalled for 2 - 3 s (tools/probe/prep_stages_one.py, 20 samples).
@@ -84,7 +89,8 @@ inline polee_status fail(polee_ctx *ctx, polee_status code, const char *fmt, ...
 // that event first (normally long complete) -- what hipFree guaranteed, for that one block only.  (The runtime's own
 // stream-ordered pool, hipMallocAsync with an infinite release threshold, was tried first: under it freshly uploaded arrays read
 // back partly zeroed -- as if a block were handed out while a neighbour's memset still covered it -- in every run; not used.)
-// POLEE_DEVICE_CACHE_MB: cap of the kept bytes (default 64 GiB; 0 = plain hipMalloc / hipFree); polee_host_cache_trim() frees them.
+// POLEE_DEVICE_CACHE_MB: cap of the kept bytes (default: a quarter of the device's memory, at most 64 GiB; 0 = plain hipMalloc /
+// hipFree); polee_host_cache_trim() frees them, and so does every allocation of this library that fails.
 class DevBlockCache {
 public:
     static DevBlockCache &get()
@@ -122,6 +128,7 @@ public:
             }
             (void)hipEventDestroy(blk.ev);
         }
+        if (poison_) dev_poison_report(granted, dev_poison_bad_words(blk.p, granted), "taken from the cache");
         return blk.p;
     }
     // false: not kept (cache off or full, or the stream is gone) -- the caller frees it
@@ -135,6 +142,10 @@ public:
             (void)hipGetLastError();
             return false;
         }
+        // debug mode: the block is filled with a pattern ON THE OWNER'S STREAM -- behind everything the owner queued there --
+        // and the pattern is verified when the block is taken again or freed: a kernel of ANOTHER stream (or a late one of
+        // this stream) that still writes to the block after its owner released it shows up as overwritten words
+        if (poison_) dev_poison_fill(p, granted, stream);
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
             (void)hipGetLastError();
@@ -142,6 +153,7 @@ public:
             return false;
         }
         std::lock_guard<std::mutex> g(mu_);
+        learn_cap();
         if (kept_ + granted > cap_) {
             (void)hipEventDestroy(ev);
             return false;
@@ -163,6 +175,7 @@ public:
                 (void)hipEventSynchronize(kv.second.ev);
                 (void)hipEventDestroy(kv.second.ev);
             }
+            if (poison_) dev_poison_report(kv.first, dev_poison_bad_words(kv.second.p, kv.first), "freed by trim");
             (void)hipFree(kv.second.p);
         }
     }
@@ -172,6 +185,7 @@ public:
         return kept_;
     }
     bool enabled() const { return cap_ != 0; }
+    bool poisoning() const { return poison_; }
 
 private:
     struct Block {
@@ -181,12 +195,34 @@ private:
     };
     DevBlockCache()
     {
+        const char *pz = getenv("POLEE_DEVICE_CACHE_POISON");
+        poison_ = pz && atoi(pz) != 0;
         const char *e = getenv("POLEE_DEVICE_CACHE_MB");
-        cap_ = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
+        if (e) {
+            cap_ = (size_t)atoll(e) << 20;
+            cap_known_ = true;
+        } else {
+            cap_ = (size_t)64 << 30;  // (until the first give() on a device: then a share of that device's memory, below)
+        }
+    }
+    // Default cap: a quarter of the device's TOTAL memory -- 72 GiB on a 288 GB MI355X, never more than 64 GiB --
+    // asked of the runtime at the first block given back (the constructor may run before any device is selected).  Other
+    // users of the device (RCCL, PyTorch, another process) see the kept bytes as used memory: polee_host_cache_trim() returns
+    // them, every failed allocation of this library trims and retries, and a cohort's worker processes get their shares
+    // from the same query (polee_amd/cohort.py).
+    void learn_cap()
+    {
+        if (cap_known_) return;
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess && t > 0) cap_ = std::min((size_t)64 << 30, t / 4);
+        (void)hipGetLastError();
+        cap_known_ = true;
     }
     std::mutex mu_;
     std::multimap<size_t, Block> free_;
     size_t kept_ = 0, cap_ = 0;
+    bool cap_known_ = false;
+    bool poison_ = false;
 };
 
 // Device buffer owned by a handle.
@@ -223,10 +259,10 @@ struct DevBuf {
         }
         if (!p) {
             hipError_t e = hipMalloc((void **)&p, granted ? granted : bytes);
-            if (e != hipSuccess && granted) {  // (memory is short: what is kept goes back first)
+            if (e != hipSuccess && DevBlockCache::get().kept_bytes() > 0) {  // (memory is short: what is kept goes back first)
                 (void)hipGetLastError();
                 DevBlockCache::get().trim();
-                e = hipMalloc((void **)&p, granted);
+                e = hipMalloc((void **)&p, granted ? granted : bytes);
             }
             if (e != hipSuccess) {
                 p = nullptr;
@@ -269,6 +305,27 @@ struct DevBuf {
                                               ctx->stream));
         POLEE_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return POLEE_OK;
+    }
+};
+
+// rocPRIM's temporary storage of the device builders, grown on demand: a DevBuf, so that it comes from (and goes back to) the kept
+// blocks instead of hipMalloc / hipFree -- hipFree waits for the whole device -- and an allocation that fails trims the cache and
+// retries like every other (the builders' own Scratch used plain hipMalloc and returned the error).
+struct DevScratch {
+    polee_ctx *ctx;
+    DevBuf<uint8_t> buf;
+    void *p = nullptr;
+    size_t bytes = 0;
+    explicit DevScratch(polee_ctx *c) : ctx(c) {}
+    hipError_t need(size_t b)
+    {
+        if (b <= bytes) return hipSuccess;
+        p = nullptr;
+        bytes = 0;
+        if (buf.alloc(ctx, b) != POLEE_OK) return hipErrorOutOfMemory;  // (releases the smaller block first)
+        p = buf.p;
+        bytes = b;
+        return hipSuccess;
     }
 };
 

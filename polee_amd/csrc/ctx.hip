@@ -21,6 +21,48 @@ void ctx_release(polee_ctx *ctx)
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+// ---- debug mode of the kept device buffers (common.hpp, DevBlockCache; POLEE_DEVICE_CACHE_POISON=1) -------------------------
+constexpr uint32_t POISON_WORD = 0xA5C3F00Du;
+__global__ void poison_fill_kernel(uint32_t *p, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = POISON_WORD;
+}
+__global__ void poison_check_kernel(const uint32_t *p, size_t words, unsigned long long *bad)
+{
+    unsigned long long b = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) b += p[i] != POISON_WORD;
+    if (b) atomicAdd(bad, b);
+}
+static std::atomic<long long> g_poison_checked{0}, g_poison_bad_blocks{0}, g_poison_bad_words{0};
+void dev_poison_fill(void *p, size_t bytes, hipStream_t stream)
+{
+    const size_t words = bytes / 4;
+    if (!words) return;
+    hipLaunchKernelGGL(poison_fill_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 4096)), dim3(256), 0, stream, (uint32_t *)p, words);
+    (void)hipGetLastError();
+}
+size_t dev_poison_bad_words(void *p, size_t bytes)
+{
+    const size_t words = bytes / 4;
+    if (!words) return 0;
+    unsigned long long *d_bad = nullptr, bad = 0;
+    if (hipMalloc((void **)&d_bad, sizeof bad) != hipSuccess) return 0;
+    (void)hipMemset(d_bad, 0, sizeof bad);
+    hipLaunchKernelGGL(poison_check_kernel, dim3((unsigned)std::min<size_t>((words + 255) / 256, 4096)), dim3(256), 0, nullptr, (const uint32_t *)p, words, d_bad);
+    (void)hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);  // (the block's own event has been waited for by the caller)
+    (void)hipFree(d_bad);
+    (void)hipGetLastError();
+    return (size_t)bad;
+}
+void dev_poison_report(size_t granted, size_t bad_words, const char *where)
+{
+    ++g_poison_checked;
+    if (!bad_words) return;
+    ++g_poison_bad_blocks;
+    g_poison_bad_words += (long long)bad_words;
+    fprintf(stderr, "*** polee_hip: a kept device block of %zu bytes was WRITTEN after its owner released it (%zu words differ; %s)\n",
+            granted, bad_words, where);
+}
 }  // namespace polee
 
 using namespace polee;
@@ -47,6 +89,14 @@ int64_t polee_host_cache_configure(int64_t cap_mb)
 }
 int64_t polee_host_cache_bytes(void) { return (int64_t)polee::HugeBlockCache::get().cached_bytes(); }
 int64_t polee_device_cache_bytes(void) { return (int64_t)polee::DevBlockCache::get().kept_bytes(); }
+
+// debug mode POLEE_DEVICE_CACHE_POISON=1: blocks verified so far, blocks found overwritten, words overwritten (0 when off)
+void polee_debug_device_cache_poison(int64_t *checked_blocks, int64_t *bad_blocks, int64_t *bad_words)
+{
+    if (checked_blocks) *checked_blocks = (int64_t)polee::g_poison_checked.load();
+    if (bad_blocks) *bad_blocks = (int64_t)polee::g_poison_bad_blocks.load();
+    if (bad_words) *bad_words = (int64_t)polee::g_poison_bad_words.load();
+}
 
 polee_status polee_ctx_create(int device, polee_ctx **out)
 {

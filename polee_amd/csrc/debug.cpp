@@ -39,9 +39,9 @@ polee_status polee_debug_ptt_plan(const int32_t *node_parent_idxs, const int32_t
     return POLEE_OK;
 }
 
-polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
-                                     const uint32_t *rowval, const float *nzval, const int64_t *ks,
-                                     polee_psell_debug **out)
+static polee_status debug_psell_build_impl(int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                           const uint32_t *rowval, const float *nzval, const int64_t *ks,
+                                           polee_psell_debug **out)
 {
     if (!colptr || !out) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
     BVec<uint64_t> rowptr;
@@ -62,9 +62,9 @@ polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, i
 
 // The layout with some of the builder's stages run on the device (bit 0: stage 1, bit 1: stage 2, bit 2: stage 3) and the rest
 // on the host, each continuing from the other's output: every mix must give the bytes polee_debug_psell_build gives.
-polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
-                                            const uint32_t *rowval, const float *nzval, const int64_t *ks, int device_stages,
-                                            polee_psell_debug **out)
+static polee_status debug_psell_build_device_impl(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                                  const uint32_t *rowval, const float *nzval, const int64_t *ks, int device_stages,
+                                                  polee_psell_debug **out)
 {
     if (!ctx || !colptr || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "null argument");
     POLEE_TRY(use_device(ctx));
@@ -140,6 +140,20 @@ polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n
     }
     *out = p.release();
     return POLEE_OK;
+}
+
+// (the builders allocate through std::vector / BVec / new -- nothing may unwind through the C ABI)
+polee_status polee_debug_psell_build(int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                     const float *nzval, const int64_t *ks, polee_psell_debug **out)
+{
+    return guarded(nullptr, "polee_debug_psell_build", [&] { return debug_psell_build_impl(m, n, colptr, colptr_bytes, rowval, nzval, ks, out); });
+}
+polee_status polee_debug_psell_build_device(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes,
+                                            const uint32_t *rowval, const float *nzval, const int64_t *ks, int device_stages,
+                                            polee_psell_debug **out)
+{
+    return guarded(ctx, "polee_debug_psell_build_device",
+                   [&] { return debug_psell_build_device_impl(ctx, m, n, colptr, colptr_bytes, rowval, nzval, ks, device_stages, out); });
 }
 
 polee_status polee_debug_psell_view(const polee_psell_debug *p, polee_psell_view *v)

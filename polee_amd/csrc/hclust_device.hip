@@ -25,24 +25,7 @@ namespace {
 
 #define HD_HIP(expr) POLEE_HIP_TRY(ctx, expr)
 
-struct Scratch {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~Scratch()
-    {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t need(size_t b)
-    {
-        if (b <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        const hipError_t e = hipMalloc(&p, b);
-        if (e == hipSuccess) bytes = b;
-        return e;
-    }
-};
+typedef DevScratch Scratch;  // (common.hpp: a kept block; trims and retries when memory is short)
 template <typename In, typename Out, typename T>
 hipError_t exclusive_sum(Scratch &tmp, In in, Out out, T init, size_t count, hipStream_t stream)
 {
@@ -691,7 +674,7 @@ static polee_status hclust_rounds_device_core(polee_ctx *ctx, int64_t m, int64_t
     if (2 * (uint64_t)n + 1 >= (1ull << 31) || nnz >= (1ull << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "hclust (device): matrix too large");
     const int K = 25;
     const uint32_t cap = 2 * (uint32_t)n + 1;
-    Scratch tmp;
+    Scratch tmp(ctx);
     struct {
         const uint64_t *p;
     } d_cp{d_cp_p};
@@ -1053,7 +1036,7 @@ polee_status hclust_rounds_device_from_xt(polee_ctx *ctx, int64_t m, int64_t n, 
     HD_HIP(hipStreamSynchronize(stream));
     const uint64_t nnz = last - 1;
     if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1) return fail(ctx, POLEE_ERR_UNSUPPORTED, "hclust (device): matrix too large");
-    Scratch tmp;
+    Scratch tmp(ctx);
     DevBuf<uint64_t> d_cp;
     DevBuf<uint32_t> counts, key, key_s, rowid, rowval, err;
     POLEE_TRY(d_cp.alloc(ctx, (size_t)n + 1));

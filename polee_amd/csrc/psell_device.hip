@@ -570,24 +570,7 @@ __global__ void s3_flags_kernel(uint32_t S, const uint8_t *slice_flags, uint32_t
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
-struct Scratch {  // rocPRIM's temporary storage, grown on demand
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~Scratch()
-    {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t need(size_t b)
-    {
-        if (b <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        const hipError_t e = hipMalloc(&p, b);
-        if (e == hipSuccess) bytes = b;
-        return e;
-    }
-};
+typedef DevScratch Scratch;  // (common.hpp: a kept block; trims and retries when memory is short)
 
 template <typename In, typename Out, typename T>
 hipError_t exclusive_sum(Scratch &tmp, In in, Out out, T init, size_t count, hipStream_t stream)
@@ -773,7 +756,7 @@ polee_status psell_device_stage1(polee_ctx *ctx, const PsellDevIn &X, PsellHost 
     if (m == 0) return POLEE_OK;
     const int binsh = psell_bin_shift();
     const unsigned TB = 256;
-    Scratch tmp;
+    Scratch tmp(ctx);
     DevBuf<uint64_t> keys, keys_c, keys_s;
     DevBuf<uint32_t> keep, is_single, kscan, sscan, rows_c, rows_s, single_rows;
     DevBuf<double> term, lsum;
@@ -1408,7 +1391,7 @@ polee_status psell_device_stage2(polee_ctx *ctx, const PsellDevIn &X, PsellDevRu
 {
     hipStream_t stream = ctx->stream;
     needs_host = false;
-    Scratch tmp;
+    Scratch tmp(ctx);
     const unsigned TB = 256;
     const uint64_t nnz_total = (uint64_t)out.nnz;
     // candidates in the order of their first transcript; by length: <= 16 first pass, 17..32 second pass, longer: mixed streams
@@ -1613,7 +1596,7 @@ polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const Psel
     static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
     const uint32_t seg_rows = (uint32_t)(seg_env >= 64 ? seg_env : (size_t)1 << 18);
     const uint32_t max_segs = Nr / seg_rows + 8;
-    Scratch tmp;
+    Scratch tmp(ctx);
     DevBuf<uint32_t> rlen, head, endflag, hscan, escan, st_start, endpos, nseg_d;
     DevBuf<uint64_t> lenps, totals;
     DevBuf<SegDesc> segs;
@@ -1980,7 +1963,7 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
         PD_HIP(hipStreamSynchronize(stream));
         return POLEE_OK;
     }
-    Scratch tmp;
+    Scratch tmp(ctx);
     DevBuf<uint64_t> d_cp;
     DevBuf<uint32_t> d_rowval, key, key_s, idx, idx_s, counts, err;
     DevBuf<float> d_nzval;

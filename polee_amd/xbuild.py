@@ -123,8 +123,8 @@ def build_likelihood_matrix(transcripts, fragments, fraglen_pmf, fraglen_cdf, fr
     T, F, M, keep = pack(transcripts, fragments, fraglen_pmf, fraglen_cdf, fraglen_median, strand_specificity, alt_frag_model)
     h = C.c_void_p()
     if bias is not None:
-        if bias.get("m1_reverse") is not None and "_mate_swap" in fragments:
-            raise ValueError("order the mates (order_mates) before deriving m1_reverse")
+        # (m1_is_flag16 and bias["m1_reverse"] describe the LONE mate of a single-end fragment -- m2_left == 0, which
+        # order_mates never swaps -- so reordering the mates of pairs leaves both valid; transcripts.jl:288-297, :486)
         Bs, keep_b = pack_bias(bias)
         check(L.lib().polee_xbuild_run_biased(ctx._h, C.byref(T), C.byref(F), C.byref(M), C.byref(Bs), C.byref(h)), ctx._h)
     else:

@@ -129,15 +129,18 @@ def test_c2_three_vi_iterations_match_oracle(P, c2):
         assert ok.mean() >= 0.99, (key, ok.mean())
 
 
-def test_c5_loglik_and_gradient_match_oracle_at_k6(P):
-    """BASELINE configs[4] (n = 200 000 x m = 150 M fragments, 1.2 G non-zeros) at the production K = 6 against the
+@pytest.mark.parametrize("literal", [False, True], ids=["patterns", "literal"])
+def test_c5_loglik_and_gradient_match_oracle_at_k6(P, literal):
+    """(literal: every fragment its own random subset of its gene's isoforms, SURVEY 8(d) read literally -- the generator of
+    bench.py's headline; VERDICT r4 item 6a: the C5 bench line of that input now has its oracle twin.)
+    BASELINE configs[4] (n = 200 000 x m = 150 M fragments, 1.2 G non-zeros) at the production K = 6 against the
     ORACLE: lp and x_grad are sums over fragments, so the oracle runs on five blocks of 30 M rows and the blocks are
     added (the arithmetic of the row-sharded fit, tests/test_multiproc.py); the device makes one pass over the whole
     matrix.  lp 1e-6, gradient 1e-4 (+ 1e-6 of the largest entry)."""
     from tools import synth
     from polee_amd.cohort import take_rows
     m5, K, nblocks = 150_000_000, 6, 5
-    smp = synth.make_sample(N, m5, NNZ_PER_FRAG, seed=987654321)
+    smp = synth.make_sample(N, m5, NNZ_PER_FRAG, seed=987654321, literal=literal)
     ctx = P.Context(0)
     s = P.RNASeqSample(m5, N, None, None, None, smp["effective_lengths"], ctx=ctx,
                        xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
@@ -167,7 +170,7 @@ def test_c5_loglik_and_gradient_match_oracle_at_k6(P):
         scale = np.abs(go[k]).max()
         worst = max(worst, float((np.abs(g[k] - go[k]) / (np.abs(go[k]) + 1e-2 * scale)).max()))
         np.testing.assert_allclose(g[k], go[k], rtol=1e-4, atol=1e-6 * scale)
-    print("C5 K=6 vs the f64 oracle (five 30 M-row blocks): worst weighted gradient error %.3g" % worst)
+    print("C5 K=6 (%s) vs the f64 oracle (five 30 M-row blocks): worst weighted gradient error %.3g" % ("literal" if literal else "patterns", worst))
 
 
 def test_c1_whole_fit_replayed_against_oracle(P):

@@ -95,12 +95,14 @@ def test_diverse_sets_with_multiplicities_and_deterministic_mode(P, ctx):
     np.testing.assert_allclose(lp1, lp3, rtol=1e-9)
 
 
-@pytest.mark.parametrize("reps", [5, 639])
-def test_tiled_real_fixture_matches_oracle(P, ctx, reps):
+@pytest.mark.parametrize("reps,copies", [(5, 1), (639, 1), (7, 3), (639, 9)])
+def test_tiled_real_fixture_matches_oracle(P, ctx, reps, copies):
     """REAL-STRUCTURE workload: the reference's likelihood matrix tiled block-diagonally (639 x = n 200 007 transcripts,
-    m 12.6 M fragments, 27 M non-zeros, the real distribution of set sizes)."""
+    m 12.6 M fragments, 27 M non-zeros, the real distribution of set sizes); copies = 9: every fragment nine times -- the
+    same sets at BASELINE C2's size, 113.5 M fragments and 246 M non-zeros (bench.py's by_input
+    `tiled_real_fixture_x639_depth9`)."""
     from tools import synth
-    smp = synth.tile_fixture(reps)
+    smp = synth.tile_fixture(reps, copies=copies)
     n, m = smp["n"], smp["m"]
     s = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ctx,
                        xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))

@@ -4,7 +4,7 @@ committed evidence under profiles/: <tag>_kernel_stats.csv, <tag>_pmc.json, <tag
 traffic_<workload>.json (HBM bytes per launch of the dominant kernel, from the PMC counters,
 corrected as MI355X_MICROARCH.md 'HBM' prescribes: FETCH_SIZE counts 64 B per 128-B request of a
 wide coalesced stream on gfx950 -> x2; WRITE_SIZE is exact; both are in KiB)."""
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, shutil, subprocess, sys, time
 
 tag = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
@@ -45,7 +45,11 @@ if dom:
                "source": "profiles/%s_pmc.json" % tag,
                # the capture is valid for this workload only (bench.py emits `traffic` when these match its run)
                "draws": cfg.get("draws"), "tree": cfg.get("tree"), "nnz": cfg.get("nnz"),
-               "source_id": (bench or {}).get("detail", {}).get("source_id")},
+               "source_id": (bench or {}).get("detail", {}).get("source_id"),
+               # when and on which commit the counters were collected (bench.py copies both into roofline.traffic_source)
+               "captured": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(os.path.join(src, "summary.json")))),
+               "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+                         + ("+dirty" if subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "polee_amd", "bench.py"], capture_output=True, text=True).stdout.strip() else "")},
               open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8
     lines += ["", "## Dominant kernel `%s`" % dom[0][:60], "",

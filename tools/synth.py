@@ -111,11 +111,14 @@ def make_tree(gene, seed=1, kind="hclust"):
     return parents, js
 
 
-def tile_fixture(reps, golden_dir=None):
+def tile_fixture(reps, golden_dir=None, copies=1):
     """REAL-STRUCTURE workload: the reference's likelihood-matrix fixture (tests/golden, m = 19 743 fragments x n = 313
     transcripts, 42 775 non-zeros, 496 distinct transcript sets) tiled block-diagonally `reps` times -- reps = 639 gives
     n ~ 200 k, m ~ 12.6 M with the real distribution of set sizes and run lengths.  Same dict as make_sample (gene =
-    one pseudo-gene per 4 transcripts of a block, only used to build a tree)."""
+    one pseudo-gene per 4 transcripts of a block, only used to build a tree).
+    copies > 1: every fragment of a block `copies` times -- the same transcript set, the copies' probabilities scaled by
+    seeded factors in [0.5, 1.5) -- i.e. the fixture's set structure at a deeper sequencing depth: reps = 639, copies = 9
+    gives m = 113.5 M fragments and 246 M non-zeros, BASELINE C2's size."""
     import scipy.sparse as sp
     g = golden_dir or os.path.join(os.path.dirname(_HERE), "tests", "golden")
     d = np.load(os.path.join(g, "mBr_M_6w_1.likelihood-matrix.npz"))
@@ -123,6 +126,11 @@ def tile_fixture(reps, golden_dir=None):
     X = sp.csc_matrix((d["nzval"].astype(np.float32), d["rowval"].astype(np.int64) - 1, d["colptr"].astype(np.int64) - 1),
                       shape=(m0, n0)).tocsr()
     X.sort_indices()
+    if copies > 1:
+        rng = np.random.default_rng(20260504)
+        X = sp.vstack([X] + [sp.csr_matrix((X.data * rng.uniform(0.5, 1.5, X.nnz).astype(np.float32), X.indices, X.indptr), shape=X.shape)
+                             for _ in range(copies - 1)]).tocsr()
+        m0 *= copies
     nnz0 = X.nnz
     m, n = m0 * reps, n0 * reps
     ptr0 = X.indptr.astype(np.uint64)
