@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--literal-subsets", action="store_true", help="(kept for scripts) same as --generator literal")
     ap.add_argument("--no-by-input", action="store_true",
                     help="skip the two extra inputs of roofline.by_input (the other generator and the tiled real fixture)")
+    ap.add_argument("--cu-partition", action="store_true",
+                    help="with --samples-per-gpu S: every fit on its own S-th of the GPU's compute units (CU-masked streams)")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
@@ -398,7 +400,7 @@ def main():
                                       dropout=args.set_diversity, literal=args.literal_subsets)
         parents, js = synth.make_tree(smp_i["gene"], seed=args.seed, kind=args.tree)
         t_gen += time.time() - t0
-        ctx_i = P.Context(local_rank if world > 1 else 0)
+        ctx_i = P.Context(local_rank if world > 1 else 0, partition=(si, S) if args.cu_partition and S > 1 else None)
         t0 = time.time()
         xt_i, m_i = (smp_i["tcolptr"], smp_i["trowval"], smp_i["tnzval"]), m
         if args.row_shard:

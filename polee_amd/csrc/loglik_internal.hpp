@@ -91,6 +91,10 @@ constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice 
 // bound by instruction latency -- 4 096 rows give BASELINE's C2 a few thousand waves; a group is cut once per chunk: 0.02 % of them)
 constexpr uint32_t PSELL_PACK_CHUNK = 1u << 12;
 constexpr double PSELL_PACK_WIDE_RESERVE = 32768.0;  // bytes above CSR a part of the second pass may spend on rows too long for stream BN, beyond its allowance
+// a leftover slice is stored MASKED only when that saves this share of its bytes (both builders; the host one reads
+// POLEE_PSELL_MASK_GAIN / POLEE_PSELL_MASK_GAIN_WIDE): the masked bodies issue ~5 more vector instructions per transcript of the
+// union, and a wide masked tile closes on its dictionary after a handful of slices (two waves, 14 KiB rings)
+constexpr double PSELL_MASK_GAIN_NARROW = 0.5, PSELL_MASK_GAIN_WIDE = 0.5;
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 

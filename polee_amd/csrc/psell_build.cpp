@@ -330,7 +330,8 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
         // every fragment its own subset -6 %, tiled real fixture -1.3 %, generator as built -0.4 %: the kernel is bound by the
         // instructions it issues, not by bytes, and a masked slice costs ~5 more vector instructions per transcript of the
         // union -- it only pays when it halves the slice)
-        static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.5;
+        static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : PSELL_MASK_GAIN_NARROW;
+        static const double mask_gain_wide = getenv("POLEE_PSELL_MASK_GAIN_WIDE") ? atof(getenv("POLEE_PSELL_MASK_GAIN_WIDE")) : PSELL_MASK_GAIN_WIDE;
         static const double over_budget = getenv("POLEE_PSELL_OVER_BUDGET") ? atof(getenv("POLEE_PSELL_OVER_BUDGET")) : 0.02;
         static const double relax = getenv("POLEE_PSELL_RELAX") ? atof(getenv("POLEE_PSELL_RELAX")) : 2.0;
         // (first pass: a narrow slice up to twice CSR's cost still beats what its rows meet further down -- a wide masked
@@ -425,27 +426,39 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                                 const double dense_bytes = 256.0 * (double)(uni.size() + 1 + ks_rows);
                                 const double masked_bytes = no_mask ? 1e30 : 256.0 * (double)(longest + (narrow ? 1 : 2) + ks_rows);
                                 const double budget = 8.0 * (double)total + 4.0 * (double)(c1 - c0);  // (CSR's cost of these rows)
-                                const double cost = std::min(dense_bytes, masked_bytes);
-                                bool worth = cost <= budget;
-                                // (second pass: a slice up to `relax` times CSR's cost is still better than what is left
-                                // for its rows -- mixed tiles of some twenty unrelated fragments each --, and rows too long
-                                // for stream BN are kept at any cost; both within the allowance)
-                                if (!worth && ((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
-                                               (pass_w == 0 && cost <= relax0 * budget))) {
+                                // is a slice of `cost` bytes acceptable?  Within CSR's cost of its rows, or (second pass: a slice
+                                // up to `relax` times CSR's cost is still better than what is left for its rows -- mixed tiles
+                                // of some twenty unrelated fragments each --, and rows too long for stream BN are kept at any
+                                // cost) above it within the allowance, which it then spends
+                                auto accept = [&](double cost) -> bool {
+                                    if (cost <= budget) return true;
+                                    if (!((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
+                                          (pass_w == 0 && cost <= relax0 * budget)))
+                                        return false;
                                     const double over = cost - budget;
                                     if (over <= allowance) {
                                         allowance -= over;
-                                        worth = true;
-                                    } else if (pass_w == 1 && longest > (size_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
+                                        return true;
+                                    }
+                                    if (pass_w == 1 && longest > (size_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
                                         // (the part's own small reserve for rows too long for stream BN: with parts of 4 096
                                         // rows the proportional allowance alone left a few hundred of them to stream B -- a
                                         // launch of its own, 38 us per pass, for 0.003 % of the non-zeros)
                                         wide_allowance -= over;
-                                        worth = true;
+                                        return true;
                                     }
+                                    return false;
+                                };
+                                // the form the KERNEL prefers (masked only when that saves `gain` of the slice's bytes; a wide
+                                // union has its own gain, loglik_internal.hpp), then -- round 5: the slice is accepted at the
+                                // cost of the form it is stored in -- the other form if that one is cheaper
+                                bool masked = masked_bytes < (1.0 - (narrow ? mask_gain : mask_gain_wide)) * dense_bytes;
+                                bool worth = accept(masked ? masked_bytes : dense_bytes);
+                                if (!worth && (masked ? dense_bytes < masked_bytes : masked_bytes < dense_bytes)) {
+                                    masked = !masked;
+                                    worth = accept(masked ? masked_bytes : dense_bytes);
                                 }
                                 if (worth) {
-                                    const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
                                     // (narrow groups, dense and masked alike, stay in ONE list in the order they were formed: their
                                     // slices share the tiles -- and the dictionaries -- of their genomic neighbourhood; the kind is
                                     // per slice.  POLEE_PSELL_SPLIT_MASKED=1: masked narrow slices in tiles of their own, as in round 3)
