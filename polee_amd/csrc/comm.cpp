@@ -17,6 +17,8 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
@@ -54,6 +56,8 @@ Rccl *rccl(std::string &err)
             r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
             r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
             r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+            r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(dlsym(r.lib, "ncclReduceScatter"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
             r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
             r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
@@ -85,7 +89,22 @@ polee_status comm_allreduce_device(polee_comm *c, void *buf, size_t count, bool 
     std::string err;
     Rccl *r = rccl(err);
     if (!r) return fail(c->ctx, POLEE_ERR_UNSUPPORTED, "%s", err.c_str());
-    const ncclResult_t rc = r->AllReduce(buf, buf, count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<ncclComm_t>(c->comm), c->ctx->stream);
+    const ncclDataType_t dt = f64 ? ncclFloat64 : ncclFloat32;
+    const ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
+    // POLEE_COMM_ALGO=rs_ag: the exchange as an explicit reduce-scatter + all-gather, in place
+    // (every rank reduces its own 1 / nranks of the buffer, then the parts are gathered) -- what a ring all-reduce does inside,
+    // as two calls, so that the first multi-GPU runs can compare both; a count the ranks do not divide takes the all-reduce.
+    static const bool rs_ag = getenv("POLEE_COMM_ALGO") && strcmp(getenv("POLEE_COMM_ALGO"), "rs_ag") == 0;
+    if (rs_ag && r->ReduceScatter && r->AllGather && count % (size_t)c->nranks == 0) {
+        const size_t chunk = count / (size_t)c->nranks;
+        char *mine = static_cast<char *>(buf) + (size_t)c->rank * chunk * (f64 ? sizeof(double) : sizeof(float));
+        ncclResult_t rc = r->ReduceScatter(buf, mine, chunk, dt, ncclSum, comm, c->ctx->stream);
+        if (rc == ncclSuccess) rc = r->AllGather(mine, buf, chunk, dt, comm, c->ctx->stream);
+        if (rc != ncclSuccess)
+            return fail(c->ctx, POLEE_ERR_COMM, "ncclReduceScatter / ncclAllGather failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
+        return POLEE_OK;
+    }
+    const ncclResult_t rc = r->AllReduce(buf, buf, count, dt, ncclSum, comm, c->ctx->stream);
     if (rc != ncclSuccess)
         return fail(c->ctx, POLEE_ERR_HIP, "ncclAllReduce failed: %s", r->GetErrorString ? r->GetErrorString(rc) : "?");
     return POLEE_OK;

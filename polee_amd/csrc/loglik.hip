@@ -490,10 +490,6 @@ struct WaveStream {
     int issued, islot;    // pieces requested so far; ring slot of the next one
     int primed;           // pieces requested before the tile's loop started
     const uint8_t *gsrc;  // start of the byte range (wave-uniform)
-    // (round 4) an A1 tile holds its dense slices first and its masked ones behind them: the wave runs the dense loop over
-    // slices [0, ndense) of its share and the masked loop over [ndense, nsl), the ring position carried from one to the other
-    uint32_t pos, pos_r;
-    int ndense;
 };
 
 template <uint32_t RB>
@@ -819,7 +815,7 @@ __device__ inline void quad_transpose(float &a0, float &a1, float &a2, float &a3
 // exactly the quad transposes of the phase-1 registers: no second LDS pass, and the slice's ring bytes are free before
 // the first matrix instruction.
 template <int K, uint32_t RB, bool WANT_LP, bool HAS_KS, bool MASKED>
-__device__ inline void narrow_stream(WaveStream &ws, int si0, int si1, const char *ring, int extras, const float *xw, float *gw,
+__device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extras, const float *xw, float *gw,
                                      uint32_t aux_lds, double &lpacc, int dbg
 #ifdef POLEE_STAMPS
                                      , unsigned long long (&st_acc)[NSTAMP], unsigned long long &st_last
@@ -914,9 +910,9 @@ __device__ inline void narrow_stream(WaveStream &ws, int si0, int si1, const cha
         }
     };
 
-    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws.pos);      // byte offset of the current slice inside this wave's range
-    uint32_t pos_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws.pos_r);  // pos modulo the ring size
-    for (int si = si0; si < si1; ++si) {
+    uint32_t pos = 0;    // byte offset of the current slice inside this wave's range
+    uint32_t pos_r = 0;  // pos modulo the ring size
+    for (int si = 0; si < ws.nsl; ++si) {
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si);
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, si + 1);
         const uint32_t off = e0 & PSELL_OFF_MASK, off_next = e1 & PSELL_OFF_MASK;
@@ -1136,8 +1132,6 @@ __device__ inline void narrow_stream(WaveStream &ws, int si0, int si1, const cha
         STAMP(5);  // phase 2
     }
     if (pend_w != 0) flush();
-    ws.pos = pos;
-    ws.pos_r = pos_r;
     if (WANT_LP) {
         // into the caller's accumulator, whose lane l < 16 collects draw l: the sixteen blocks' sums of draw 4 kg + j
 #pragma unroll
@@ -1791,17 +1785,11 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     const int ahead = (dbg >> 8) & 15;  // (experiment: pieces requested ahead; 0 = the whole ring)
     auto start_ring = [&](const PosDesc &t) {
         const int kind = kind_of(t.tile);
-        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data; ws.pos = 0u; ws.pos_r = 0u; ws.ndense = 0;
+        ws.nsl = 0; ws.npieces = 0; ws.issued = 0; ws.islot = 0; ws.primed = 0; ws.ent = 0u; ws.gsrc = A.data;
         uint32_t sb, se;
         share(kind, t, sb, se);
         ws.ent = entb[wave * 64 + wave_lane()];
         ws.nsl = (int)(se - sb);
-        ws.pos = 0u;
-        ws.pos_r = 0u;
-        {   // dense slices of the share (they come first): lanes [0, nsl) whose offset word has the MASKED bit clear
-            const bool dense = wave_lane() < ws.nsl && ((ws.ent >> PSELL_FLAG_MASKED_BIT) & 1u) == 0u;
-            ws.ndense = __builtin_popcountll(__ballot(dense));
-        }
         const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, 0) & PSELL_OFF_MASK;
         const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ws.ent, ws.nsl) & PSELL_OFF_MASK;  // 128-byte units
         ws.npieces = (int)(((ce - cb) * 128u + 1023u) >> 10);
@@ -1853,22 +1841,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         }
         STAMP(0);  // between tiles: prefetch issue
         if (kind == 0) {
-            // an A1 tile: this wave's dense slices, then (round 4) the masked slices of leftover fragments that ride in the
-            // tile -- the same two loops as before, one after the other over the same ring, dictionary and windows
-            const int nd = __builtin_amdgcn_readfirstlane(ws.ndense);
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, 0, nd, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif
             );
-            if (nd < ws.nsl)
-                narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, nd, ws.nsl, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
-#ifdef POLEE_STAMPS
-                                                                                 , st_acc, st_last
-#endif
-                );
         } else if (kind == 2) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, 0, ws.nsl, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
                                                                              , st_acc, st_last
 #endif
@@ -2007,6 +1986,64 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 }
 
 
+// Cost model of the schedules, MEASURED: time of every tile of a C2 sample from a clock read per tile (diagnostic build
+// POLEE_TILE_CYCLES, tools/probe/tile_cycles.py), regressed per stream on the bytes the tile streams: cycles = fixed + per KiB x
+// KiB, R^2 0.6 - 0.9, mean error per tile ~15 % (round 5, profiles/r05_tile_cycles_*.txt: the wide stream on four waves):
+//     A1 8.7 k + 350   A1M 9 k + 750   A2 8.7 k + 310   A2M 5 k + 1400   BN 2 k + 3100
+// (dense slices cost what their bytes cost; masked ones also the matrix-core work of their union; the wide masked stream runs
+// on two of the four waves; BN sweeps lane per fragment).  The first model -- bytes + 4 KiB, x 1.5 for the wide streams -- left
+// the slowest workgroup 25 - 30 % above the mean.
+static const double TILE_COST_FIXED[PSELL_NSTREAMS] = {8700.0, 9000.0, 8700.0, 5000.0, 2000.0, 2000.0};
+static const double TILE_COST_PER_KIB[PSELL_NSTREAMS] = {350.0, 750.0, 310.0, 1400.0, 3100.0, 3100.0};
+static double slices_cost(const PsellHost &h, int stream, uint32_t sa, uint32_t sb)
+{
+    const double kib = 0.125 * (double)((h.slice_off[sb] & PSELL_OFF_MASK) - (h.slice_off[sa] & PSELL_OFF_MASK));
+    static const bool old_cost = getenv("POLEE_OLD_COST") != nullptr;  // (A/B)
+    if (old_cost) return (kib * 1024.0 + 4096.0) * (stream == PSELL_A2 || stream == PSELL_A2M ? 1.5 : 1.0);
+    return TILE_COST_FIXED[stream] + TILE_COST_PER_KIB[stream] * kib;
+}
+// The waves of a workgroup take contiguous blocks of the slices [sa, sb) of tile t with about equal matrix-core work (phase 1:
+// 4 ceil(w / 4) instructions, phase 2: 8 for w <= 8, else 16 per 16 transcripts; + a fixed part): cut[0..2] = the boundaries.
+// (needs the slice metadata: only while the handle is being created)
+static void wave_cuts(const PsellHost &h, int64_t t, uint32_t s0, uint32_t s1, uint32_t cut[3])
+{
+    cut[0] = cut[1] = cut[2] = s1;
+    if (t >= h.num_tiles_s) return;
+    static const bool bytes_cut = getenv("POLEE_BYTES_CUT") != nullptr;  // (A/B: the waves' shares balanced on bytes)
+    const int nw = h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
+    // (experiment, POLEE_CUT_MODEL="a,b,c": cost = a + b x groups of four transcripts + c x (1 + groups) when the slice
+    // starts a new run -- the flush of the previous set and the column lookup of the new one)
+    static const char *cut_env = getenv("POLEE_CUT_MODEL");
+    static double cm[3] = {0, 0, 0};
+    static const bool cut_custom = cut_env && sscanf(cut_env, "%lf,%lf,%lf", &cm[0], &cm[1], &cm[2]) == 3;
+    auto cost = [&](uint32_t sl) {
+        const int w = h.slice_w[sl];
+        if (bytes_cut) return 512.0 + 128.0 * (double)((h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK));
+        if (h.stream_of_tile(t) == PSELL_BN) return 6.0 * w + 4.0;  // (instructions per entry, not matrix-core work)
+        if (cut_custom) {
+            const double ng = (double)((w + 3) / 4);
+            const bool cont = (h.slice_flags[sl] & 2) != 0 && sl > s0;
+            return cm[0] + cm[1] * ng + (cont ? 0.0 : cm[2] * (1.0 + ng));
+        }
+        return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
+    };
+    double total = 0.0;
+    for (uint32_t sl = s0; sl < s1; ++sl) total += cost(sl);
+    double acc = 0.0;
+    int wv = 1;
+    for (uint32_t sl = s0; sl < s1 && wv < nw; ++sl) {
+        acc += cost(sl);
+        // a wave owns at most 63 slices (one offset per lane + the end)
+        while (wv < nw && (acc >= total * wv / nw || sl + 1 - (wv == 1 ? s0 : cut[wv - 2]) >= 63u)) cut[wv++ - 1] = sl + 1;
+    }
+    // (the last wave takes what is left: if that is more than 63 slices -- cheap slices at the tile's start -- cut
+    // by count instead; the builder keeps a tile within 63 slices per active wave)
+    if (s1 - (nw > 1 ? cut[nw - 2] : s0) > 63u) {
+        const uint32_t per = (s1 - s0 + (uint32_t)nw - 1) / (uint32_t)nw;
+        for (int q = 1; q < nw; ++q) cut[q - 1] = std::min(s1, s0 + per * (uint32_t)q);
+    }
+}
+
 // Static schedule of the streaming kernel for a grid of G workgroups: the uniform tiles sorted by cost, dealt to the
 // workgroups in snake order (equal sums), and inside every workgroup's list the wide tiles (stream A2, two active
 // waves) spread evenly between the A1 tiles.
@@ -2066,11 +2103,6 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
     ll->sched_grid = G;
     if (!ll->d_sched_dyn.p) {
         // the dynamic schedule's list (any grid): the tiles by descending cost, POS_NONE behind them
-        std::vector<PosDesc> dynl(order.size() + (size_t)4 * 4 * 256 + 64);
-        for (auto &d : dynl) {
-            d = PosDesc();
-            d.tile = POS_NONE;
-        }
         // Order: inside every stream by descending cost; the streams MERGED at equal pace (a tile's key is its rank
         // among its stream's tiles divided by their number), so that every stretch of the list holds the streams in
         // their overall proportions -- while a workgroup is on a wide tile (two of its four waves at work) its
@@ -2088,19 +2120,69 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
             }
             if (!plain) std::stable_sort(dorder.begin(), dorder.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         }
+        // Round 5: GUIDED positions.  A position of the list is a tile -- or, towards the END of the list, a PART of a tile (a
+        // range of its slices under the same dictionary).  The workgroups finish within one position of each other, and with ~10
+        // tiles of 40 - 140 k cycles per workgroup that was 7 % (C2, every fragment its own subset) to 27 % (the tiled real
+        // fixture, 3 tiles per workgroup) of the launch (profiles/r05_tile_cycles_*.txt: slowest workgroup / mean).  As in
+        // guided self-scheduling a position may cost at most (work still ahead in the list) / (workgroups), and at least twice
+        // a tile's fixed cost: the first ~90 % of the work goes out in whole tiles, the rest in ever smaller parts.
+        // (needs the slices' sizes: the list is built while the handle is being created; POLEE_DYN_NO_SPLIT=1: whole tiles)
+        static const bool no_split = getenv("POLEE_DYN_NO_SPLIT") != nullptr;
+        const bool can_split = !no_split && !h.slice_w.empty() && h.slice_off.size() > h.tile_slice[(size_t)h.num_tiles_s];
+        double remaining = 0.0;
+        for (uint32_t t : dorder) remaining += (double)ll->tile_cost[t];
+        std::vector<PosDesc> plist;
+        plist.reserve(dorder.size() + (size_t)4 * (size_t)G);
         for (size_t i = 0; i < dorder.size(); ++i) {
             const uint32_t t = dorder[i];
-            PosDesc &d = dynl[i];
-            d.tile = t;
-            d.s0 = h.tile_slice[t];
-            d.s1 = h.tile_slice[t + 1];
-            d.d0 = h.tile_dict[t];
-            d.L = h.tile_cols[t];
-            d.c1 = ll->tile_cut[(size_t)3 * t];
-            d.c2 = ll->tile_cut[(size_t)3 * t + 1];
-            d.c3 = ll->tile_cut[(size_t)3 * t + 2];
+            const int st = h.stream_of_tile(t);
+            const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
+            const double cost = (double)ll->tile_cost[t];
+            const double cap = std::max(2.0 * TILE_COST_FIXED[st], remaining / (double)G);
+            remaining -= cost;
+            const uint32_t min_slices = st == PSELL_A2M ? 2u : 4u;  // (a slice per active wave)
+            uint32_t parts = 1;
+            if (can_split && cost > cap) parts = (uint32_t)std::min<double>(std::ceil(cost / cap), (double)((s1 - s0) / min_slices));
+            parts = std::max(parts, 1u);
+            const uint32_t u0 = h.slice_off[s0] & PSELL_OFF_MASK, u1 = h.slice_off[s1] & PSELL_OFF_MASK;
+            uint32_t sa = s0;
+            for (uint32_t q = 0; q < parts; ++q) {
+                uint32_t sb = s1;
+                if (q + 1 < parts) {  // the part ends where its share of the tile's bytes does (at least min_slices further on)
+                    const uint32_t target = u0 + (uint32_t)((uint64_t)(u1 - u0) * (q + 1) / parts);
+                    sb = sa + min_slices;
+                    while (sb < s1 && (h.slice_off[sb] & PSELL_OFF_MASK) < target) ++sb;
+                    sb = std::min(sb, s1 - min_slices * (parts - 1 - q));
+                }
+                PosDesc d = PosDesc();
+                d.tile = t;
+                d.s0 = sa;
+                d.s1 = sb;
+                d.d0 = h.tile_dict[t];
+                d.L = h.tile_cols[t];
+                if (parts == 1) {
+                    d.c1 = ll->tile_cut[(size_t)3 * t];
+                    d.c2 = ll->tile_cut[(size_t)3 * t + 1];
+                    d.c3 = ll->tile_cut[(size_t)3 * t + 2];
+                } else {
+                    uint32_t cut[3];
+                    wave_cuts(h, t, sa, sb, cut);
+                    d.c1 = cut[0];
+                    d.c2 = cut[1];
+                    d.c3 = cut[2];
+                }
+                plist.push_back(d);
+                sa = sb;
+            }
         }
-        ll->dyn_pad = dynl.size() - order.size();
+        ll->dyn_positions = plist.size();
+        std::vector<PosDesc> dynl(plist.size() + (size_t)4 * 4 * 256 + 64);
+        for (auto &d : dynl) {
+            d = PosDesc();
+            d.tile = POS_NONE;
+        }
+        std::copy(plist.begin(), plist.end(), dynl.begin());
+        ll->dyn_pad = dynl.size() - plist.size();
         POLEE_TRY(ll->d_sched_dyn.upload(ll->ctx, dynl));
         std::vector<unsigned int> zero(2, 0u);
         POLEE_TRY(ll->d_dyn_ctr.upload(ll->ctx, zero));
@@ -2400,66 +2482,11 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     // what the streaming kernel's schedule needs, before the bulk vectors go: the relative cost of every tile
     // (bytes it streams; the latency-bound streams weigh more per byte), the x windows, the usual grid's schedule
     ll->dict_len = (int64_t)h.dict.size();
-    // Cost model of the static schedule, MEASURED: time of every tile of a C2 sample (generator as built and with dropout
-    // 0.3) from a clock read per tile (diagnostic build POLEE_TILE_CYCLES, tools/probe/tile_cycles.py), regressed per
-    // stream on the bytes the tile streams: cycles = fixed + per KiB x KiB, R^2 0.6 - 0.9, mean error per tile ~15 %:
-    //     A1 8.7 k + 350   A1M 9 k + 750   A2 5 k + 620   A2M 5 k + 1400   BN 2 k + 3100
-    // (dense narrow slices cost what their bytes cost; masked ones also the matrix-core work of their union; the wide
-    // streams run on two of the four waves; BN sweeps lane per fragment).  The first model -- bytes + 4 KiB, x 1.5 for the
-    // wide streams -- left the slowest workgroup 25 - 30 % above the mean.
     ll->tile_cost.assign((size_t)h.num_tiles, 0.0f);
-    static const bool old_cost = getenv("POLEE_OLD_COST") != nullptr;  // (A/B)
-    for (int64_t t = 0; t < h.num_tiles; ++t) {
-        const double kib = 0.125 * (double)((h.slice_off[h.tile_slice[t + 1]] & PSELL_OFF_MASK) - (h.slice_off[h.tile_slice[t]] & PSELL_OFF_MASK));
-        static const double fixed[PSELL_NSTREAMS] = {8700.0, 9000.0, 5000.0, 5000.0, 2000.0, 2000.0};
-        static const double per_kib[PSELL_NSTREAMS] = {350.0, 750.0, 620.0, 1400.0, 3100.0, 3100.0};
-        const int st = h.stream_of_tile(t);
-        double c = fixed[st] + per_kib[st] * kib;
-        if (old_cost) c = (kib * 1024.0 + 4096.0) * (st == PSELL_A2 || st == PSELL_A2M ? 1.5 : 1.0);
-        ll->tile_cost[(size_t)t] = (float)c;
-    }
-    // the waves of a uniform tile take contiguous blocks of its slices with about equal matrix-core work
-    // (phase 1: 4 ceil(w / 4) instructions, phase 2: 8 for w <= 8, else 16 per 16 transcripts; + a fixed part)
-    static const bool bytes_cut = getenv("POLEE_BYTES_CUT") != nullptr;  // (A/B: the waves' shares balanced on bytes)
+    for (int64_t t = 0; t < h.num_tiles; ++t)
+        ll->tile_cost[(size_t)t] = (float)slices_cost(h, h.stream_of_tile(t), h.tile_slice[t], h.tile_slice[t + 1]);
     ll->tile_cut.assign((size_t)3 * h.num_tiles, 0u);
-    for (int64_t t = 0; t < h.num_tiles; ++t) {
-        const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
-        uint32_t *cut = &ll->tile_cut[(size_t)3 * t];
-        cut[0] = cut[1] = cut[2] = s1;
-        if (t >= h.num_tiles_s) continue;
-        const int nw = h.stream_of_tile(t) != PSELL_A2M ? 4 : 2;
-        // (experiment, POLEE_CUT_MODEL="a,b,c": cost = a + b x groups of four transcripts + c x (1 + groups) when the slice
-        // starts a new run -- the flush of the previous set and the column lookup of the new one)
-        static const char *cut_env = getenv("POLEE_CUT_MODEL");
-        static double cm[3] = {0, 0, 0};
-        static const bool cut_custom = cut_env && sscanf(cut_env, "%lf,%lf,%lf", &cm[0], &cm[1], &cm[2]) == 3;
-        auto cost = [&](uint32_t sl) {
-            const int w = h.slice_w[sl];
-            if (bytes_cut) return 512.0 + 128.0 * (double)((h.slice_off[sl + 1] & PSELL_OFF_MASK) - (h.slice_off[sl] & PSELL_OFF_MASK));
-            if (h.stream_of_tile(t) == PSELL_BN) return 6.0 * w + 4.0;  // (instructions per entry, not matrix-core work)
-            if (cut_custom) {
-                const double ng = (double)((w + 3) / 4);
-                const bool cont = (h.slice_flags[sl] & 2) != 0 && sl > s0;
-                return cm[0] + cm[1] * ng + (cont ? 0.0 : cm[2] * (1.0 + ng));
-            }
-            return 4.0 * ((w + 3) / 4) + (w <= 8 ? 8.0 : 16.0 * ((w + 15) / 16)) + 10.0;
-        };
-        double total = 0.0;
-        for (uint32_t sl = s0; sl < s1; ++sl) total += cost(sl);
-        double acc = 0.0;
-        int wv = 1;
-        for (uint32_t sl = s0; sl < s1 && wv < nw; ++sl) {
-            acc += cost(sl);
-            // a wave owns at most 63 slices (one offset per lane + the end)
-            while (wv < nw && (acc >= total * wv / nw || sl + 1 - (wv == 1 ? s0 : cut[wv - 2]) >= 63u)) cut[wv++ - 1] = sl + 1;
-        }
-        // (the last wave takes what is left: if that is more than 63 slices -- cheap slices at the tile's start -- cut
-        // by count instead; the builder keeps a tile within 63 slices per active wave)
-        if (s1 - (nw > 1 ? cut[nw - 2] : s0) > 63u) {
-            const uint32_t per = (s1 - s0 + (uint32_t)nw - 1) / (uint32_t)nw;
-            for (int q = 1; q < nw; ++q) cut[q - 1] = std::min(s1, s0 + per * (uint32_t)q);
-        }
-    }
+    for (int64_t t = 0; t < h.num_tiles; ++t) wave_cuts(h, t, h.tile_slice[t], h.tile_slice[t + 1], &ll->tile_cut[(size_t)3 * t]);
     {   // deterministic mode: the dictionary entries of every transcript, ascending (= tile order), padding left out
         std::vector<uint32_t> ptr((size_t)ll->n + 1, 0), slots;
         for (int64_t t = 0; t < h.num_tiles_s; ++t)

@@ -74,8 +74,7 @@ constexpr int PSELL_TILE_SLICES_A2 = 32;     // (round 5: all four waves work on
 constexpr int PSELL_TILE_SLICES_B = 16;
 constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x1fffffffu;  // slice_off entries carry the slice flags in bits 29..31
-constexpr uint32_t PSELL_FLAG_MASKED_BIT = 29;    // bit 29: a MASKED slice (round 4: masked narrow slices ride in the A1 tiles of their
-                                                  // genomic neighbourhood -- shared dictionaries, no tiles of their own; the kind is per slice)
+constexpr uint32_t PSELL_FLAG_MASKED_BIT = 29;    // bit 29: a MASKED slice (set for every slice of streams A1M / A2M; the cross-check kernel reads it)
 constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, four groups of four transcripts: narrow_stream)
 constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two 16-row MFMA tiles: uniform_stream)
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
@@ -91,10 +90,6 @@ constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice 
 // bound by instruction latency -- 4 096 rows give BASELINE's C2 a few thousand waves; a group is cut once per chunk: 0.02 % of them)
 constexpr uint32_t PSELL_PACK_CHUNK = 1u << 12;
 constexpr double PSELL_PACK_WIDE_RESERVE = 32768.0;  // bytes above CSR a part of the second pass may spend on rows too long for stream BN, beyond its allowance
-// a leftover slice is stored MASKED only when that saves this share of its bytes (both builders; the host one reads
-// POLEE_PSELL_MASK_GAIN / POLEE_PSELL_MASK_GAIN_WIDE): the masked bodies issue ~5 more vector instructions per transcript of the
-// union, and a wide masked tile closes on its dictionary after a handful of slices (two waves, 14 KiB rings)
-constexpr double PSELL_MASK_GAIN_NARROW = 0.5, PSELL_MASK_GAIN_WIDE = 0.5;
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)
 
@@ -213,6 +208,7 @@ struct polee_loglik {
     polee::DevBuf<polee::PosDesc> d_sched_dyn;  // dynamic schedule: the tiles by descending cost + POS_NONE padding
     polee::DevBuf<unsigned int> d_dyn_ctr;      // {positions drawn, workgroups done}: zero between launches
     size_t dyn_pad = 0;
+    size_t dyn_positions = 0;  // positions of the dynamic list (tiles, and parts of tiles towards its end)
     std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
     std::vector<uint32_t> tile_cut;  // [3 * num_tiles] slice boundaries between the waves of a uniform tile
     int64_t dict_len = 0;

@@ -289,7 +289,6 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                          const int64_t *ks, PsellRuns &R, PsellHost &out, PsellRows &W)
 {
     W = PsellRows();
-    const int binsh = psell_bin_shift();
     BuildClock clk;
     auto sublap = [&](const char *w) { clk.sublap(w); };
     BVec<uint32_t> &rows = W.rows, &run_end = W.run_end, &row_gid = W.row_gid;
@@ -330,21 +329,16 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
         // every fragment its own subset -6 %, tiled real fixture -1.3 %, generator as built -0.4 %: the kernel is bound by the
         // instructions it issues, not by bytes, and a masked slice costs ~5 more vector instructions per transcript of the
         // union -- it only pays when it halves the slice)
-        static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : PSELL_MASK_GAIN_NARROW;
-        static const double mask_gain_wide = getenv("POLEE_PSELL_MASK_GAIN_WIDE") ? atof(getenv("POLEE_PSELL_MASK_GAIN_WIDE")) : PSELL_MASK_GAIN_WIDE;
+        static const double mask_gain = getenv("POLEE_PSELL_MASK_GAIN") ? atof(getenv("POLEE_PSELL_MASK_GAIN")) : 0.5;
         static const double over_budget = getenv("POLEE_PSELL_OVER_BUDGET") ? atof(getenv("POLEE_PSELL_OVER_BUDGET")) : 0.02;
         static const double relax = getenv("POLEE_PSELL_RELAX") ? atof(getenv("POLEE_PSELL_RELAX")) : 2.0;
         // (first pass: a narrow slice up to twice CSR's cost still beats what its rows meet further down -- a wide masked
         // slice, 4 - 10 x the cycles -- within the same global allowance; tiled real fixture -3 % kernel time, others +-0.7 %)
         static const double relax0 = getenv("POLEE_PSELL_RELAX0") ? atof(getenv("POLEE_PSELL_RELAX0")) : 2.0;
         static const size_t max_group = getenv("POLEE_PSELL_MAX_GROUP") ? (size_t)atoll(getenv("POLEE_PSELL_MAX_GROUP")) : (size_t)1 << 14;
-        // Round 4 experiment, OFF by default: POLEE_PSELL_MERGE_MASKED=1 lets the masked narrow slices
-        // of leftover fragments ride in the A1 tiles of their genomic bin (kind flag per slice; the kernel runs its dense
-        // loop, then its masked loop over a wave's share) instead of closing tiles of their own after ~10 slices.
-        // Measured at C2 size, same box (profiles/r04_mixed_tiles_ab.txt): tiled real fixture -2.3 % kernel time, every
-        // fragment its own subset +1.5 %, dropout 0.3 +2.6 %, generator patterns +-0: the saved tile overhead is paid back
-        // by the second loop's start in every wave of every tile.  (ONE loop over both kinds compiled 17 % slower.)
-        static const bool split_masked = getenv("POLEE_PSELL_MERGE_MASKED") == nullptr;
+        // (Round 4 tried masked narrow slices riding in the A1 tiles of their genomic bin -- a per-slice kind flag, the kernel's dense
+        // loop followed by its masked loop per wave: no net gain, profiles/r04_mixed_tiles_ab.txt -- and round 5 removed it: the
+        // second loop cost the streaming kernel 15 KB of code, which every input paid for)
         const size_t ks_rows = ks ? 1 : 0;
         if (!no_union && !rb.empty()) {
             BVec<uint64_t> k2(rb.size());
@@ -426,43 +420,32 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
                                 const double dense_bytes = 256.0 * (double)(uni.size() + 1 + ks_rows);
                                 const double masked_bytes = no_mask ? 1e30 : 256.0 * (double)(longest + (narrow ? 1 : 2) + ks_rows);
                                 const double budget = 8.0 * (double)total + 4.0 * (double)(c1 - c0);  // (CSR's cost of these rows)
-                                // is a slice of `cost` bytes acceptable?  Within CSR's cost of its rows, or (second pass: a slice
-                                // up to `relax` times CSR's cost is still better than what is left for its rows -- mixed tiles
-                                // of some twenty unrelated fragments each --, and rows too long for stream BN are kept at any
-                                // cost) above it within the allowance, which it then spends
-                                auto accept = [&](double cost) -> bool {
-                                    if (cost <= budget) return true;
-                                    if (!((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
-                                          (pass_w == 0 && cost <= relax0 * budget)))
-                                        return false;
+                                const double cost = std::min(dense_bytes, masked_bytes);
+                                bool worth = cost <= budget;
+                                // (second pass: a slice up to `relax` times CSR's cost is still better than what is left
+                                // for its rows -- mixed tiles of some twenty unrelated fragments each --, and rows too long
+                                // for stream BN are kept at any cost; both within the allowance)
+                                if (!worth && ((pass_w == 1 && (cost <= relax * budget || longest > (size_t)PSELL_MIXED_NARROW_MAX)) ||
+                                               (pass_w == 0 && cost <= relax0 * budget))) {
                                     const double over = cost - budget;
                                     if (over <= allowance) {
                                         allowance -= over;
-                                        return true;
-                                    }
-                                    if (pass_w == 1 && longest > (size_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
+                                        worth = true;
+                                    } else if (pass_w == 1 && longest > (size_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
                                         // (the part's own small reserve for rows too long for stream BN: with parts of 4 096
                                         // rows the proportional allowance alone left a few hundred of them to stream B -- a
                                         // launch of its own, 38 us per pass, for 0.003 % of the non-zeros)
                                         wide_allowance -= over;
-                                        return true;
+                                        worth = true;
                                     }
-                                    return false;
-                                };
-                                // the form the KERNEL prefers (masked only when that saves `gain` of the slice's bytes; a wide
-                                // union has its own gain, loglik_internal.hpp), then -- round 5: the slice is accepted at the
-                                // cost of the form it is stored in -- the other form if that one is cheaper
-                                bool masked = masked_bytes < (1.0 - (narrow ? mask_gain : mask_gain_wide)) * dense_bytes;
-                                bool worth = accept(masked ? masked_bytes : dense_bytes);
-                                if (!worth && (masked ? dense_bytes < masked_bytes : masked_bytes < dense_bytes)) {
-                                    masked = !masked;
-                                    worth = accept(masked ? masked_bytes : dense_bytes);
                                 }
+                                // (Round 5 tried accepting a slice at the cost of the form it is STORED in -- the dense form, which the
+                                // kernel prefers unless masking halves the slice, may cost more than the minimum the slice is accepted
+                                // at -- and a separate gain for wide unions: more masked slices and more rows left to the mixed
+                                // streams, the pass 0.06 - 0.12 ms SLOWER on two inputs, profiles/r05_mask_gain_sweep.txt.  Not kept.)
                                 if (worth) {
-                                    // (narrow groups, dense and masked alike, stay in ONE list in the order they were formed: their
-                                    // slices share the tiles -- and the dictionaries -- of their genomic neighbourhood; the kind is
-                                    // per slice.  POLEE_PSELL_SPLIT_MASKED=1: masked narrow slices in tiles of their own, as in round 3)
-                                    RowList &dst = narrow ? (masked && split_masked ? U.masked1 : U.dense1) : (masked ? U.masked2 : U.dense2);
+                                    const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
+                                    RowList &dst = narrow ? (masked ? U.masked1 : U.dense1) : (masked ? U.masked2 : U.dense2);
                                     for (size_t q = c0; q < c1; ++q) {
                                         dst.rows.push_back(group[q]);
                                         dst.ends.push_back(q + 1 == c1 ? 1u : 0u);
@@ -632,43 +615,6 @@ std::string psell_stage2(int64_t m, int64_t n, const uint64_t *rowptr, const uin
             out.stream_nnz[PSELL_C] = (int64_t)out.csr_col.size();
             out.stream_bytes[PSELL_C] = (int64_t)(8 * out.csr_col.size() + 4 * (rcsr.size() + 1));
         }
-        // Round 4 experiment: the slices of leftover groups (dense unions and masked slices) FOLLOW all the run slices of their
-        // stream, in tiles of their own -- which close on the 128-entry dictionary after ~10 slices of 12 - 16 transcripts
-        // each, and a tile's fixed cost (~9 k cycles: barriers, flush, ring start) then weighs 3 - 10 x what it does in a tile
-        // of 64 run slices.  Now they follow the runs OF THEIR GENOMIC BIN (first transcript / 256, the runs' own sort key):
-        // the runs' dictionary already holds most of a leftover group's transcripts (the same genes), so the group's slices
-        // ride in those tiles.  A stable sort of the stream's rows by (bin, run before group); a group's rows share one key
-        // (the bin of its union's first transcript), so slices stay intact.
-        // (the same experiment's second half, POLEE_PSELL_INTERLEAVE=1; off by default: no measurable gain on its own)
-        static const bool no_interleave = getenv("POLEE_PSELL_INTERLEAVE") == nullptr;
-        auto interleave = [&](RowList &L) {
-            const size_t N = L.rows.size();
-            if (N == 0 || no_interleave) return;
-            bool any_run = false, any_group = false;
-            for (size_t q = 0; q < N && !(any_run && any_group); ++q) (L.form[q] == 0 ? any_run : any_group) = true;
-            if (!any_run || !any_group) return;
-            BVec<uint64_t> key(N);
-            BVec<uint32_t> idx(N);
-            parallel_chunks(N, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
-                for (size_t q = lo; q < hi; ++q) {
-                    const uint32_t first = L.form[q] == 0 ? col[rowptr[L.rows[q]]] : patterns[L.gid[q]][0];
-                    key[q] = ((uint64_t)(first >> binsh) << 1) | (L.form[q] == 0 ? 0u : 1u);
-                    idx[q] = (uint32_t)q;
-                }
-            });
-            radix_sort_pairs(key, idx);
-            RowList R;
-            R.rows.resize(N); R.ends.resize(N); R.form.resize(N); R.gid.resize(N);
-            parallel_chunks(N, (size_t)1 << 18, [&](size_t lo, size_t hi, unsigned) {
-                for (size_t q = lo; q < hi; ++q) {
-                    const uint32_t o = idx[q];
-                    R.rows[q] = L.rows[o]; R.ends[q] = L.ends[o]; R.form[q] = L.form[o]; R.gid[q] = L.gid[o];
-                }
-            });
-            L.rows.swap(R.rows); L.ends.swap(R.ends); L.form.swap(R.form); L.gid.swap(R.gid);
-        };
-        interleave(S1);
-        interleave(S2);
         out.rows_a1 = (int64_t)S1.rows.size();
         out.rows_a1m = out.rows_a1 + (int64_t)S1M.rows.size();
         out.rows_a2 = out.rows_a1m + (int64_t)S2.rows.size();

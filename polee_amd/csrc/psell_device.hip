@@ -985,7 +985,7 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
     const uint32_t p0 = blockIdx.x * S2_CHUNK, p1 = min(P.Np, p0 + S2_CHUNK);
     uint32_t u_reg = 0xffffffffu;  // the open group's union, ascending: lane j holds its j-th transcript (j < nu)
     uint32_t nu = 0, gs = 0, emitted = 0, npat = 0, pat_off = 0, nd = 0;
-    const double relax = 2.0, relax0 = 2.0, mask_gain = PSELL_MASK_GAIN_NARROW, mask_gain_wide = PSELL_MASK_GAIN_WIDE;
+    const double relax = 2.0, relax0 = 2.0, mask_gain = 0.5;
     double allowance = (8.0 * (double)(P.plps[p1] - P.plps[p0]) + 4.0 * (double)(p1 - p0)) * P.factor;
     double wide_allowance = P.pass_w == 1 ? PSELL_PACK_WIDE_RESERVE : 0.0;
     const uint64_t pat_base = P.plps[p0];
@@ -1013,28 +1013,20 @@ __global__ __launch_bounds__(64) void s2_pack_kernel(S2Pack P)
             const double dense_bytes = 256.0 * (double)(nu + 1 + (uint32_t)P.ks_rows);
             const double masked_bytes = 256.0 * (double)(longest + (narrow ? 1u : 2u) + (uint32_t)P.ks_rows);
             const double budget = 8.0 * (double)total + 4.0 * (double)nrow;
-            auto accept = [&](double cost) -> bool {  // (psell_build.cpp, close_group: the same operations in the same order)
-                if (cost <= budget) return true;
-                if (!((P.pass_w == 1 && (cost <= relax * budget || longest > (uint32_t)PSELL_MIXED_NARROW_MAX)) || (P.pass_w == 0 && cost <= relax0 * budget)))
-                    return false;
+            const double cost = fmin(dense_bytes, masked_bytes);
+            bool worth = cost <= budget;
+            if (!worth && ((P.pass_w == 1 && (cost <= relax * budget || longest > (uint32_t)PSELL_MIXED_NARROW_MAX)) || (P.pass_w == 0 && cost <= relax0 * budget))) {
                 const double over = cost - budget;
                 if (over <= allowance) {
                     allowance -= over;
-                    return true;
-                }
-                if (P.pass_w == 1 && longest > (uint32_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
+                    worth = true;
+                } else if (P.pass_w == 1 && longest > (uint32_t)PSELL_MIXED_NARROW_MAX && over <= wide_allowance) {
                     wide_allowance -= over;
-                    return true;
+                    worth = true;
                 }
-                return false;
-            };
-            bool masked = masked_bytes < (1.0 - (narrow ? mask_gain : mask_gain_wide)) * dense_bytes;
-            bool worth = accept(masked ? masked_bytes : dense_bytes);
-            if (!worth && (masked ? dense_bytes < masked_bytes : masked_bytes < dense_bytes)) {
-                masked = !masked;
-                worth = accept(masked ? masked_bytes : dense_bytes);
             }
             if (worth) {
+                const bool masked = masked_bytes < (1.0 - mask_gain) * dense_bytes;
                 const uint32_t dest = narrow ? (masked ? 1u : 0u) : (masked ? 3u : 2u);
                 if (lane < nrow) {
                     P.rec_row[p0 + emitted + lane] = row;
@@ -1877,8 +1869,8 @@ bool psell_device_enabled()
         if (const char *e = getenv("POLEE_DEVICE_BUILD")) return atoi(e) != 0;
         // the host builder's experiment knobs are the host builder's
         for (const char *k : {"POLEE_PSELL_BINSH", "POLEE_PSELL_NO_SINGLES", "POLEE_PSELL_NO_RUNS", "POLEE_PSELL_MIN_UNIFORM", "POLEE_PSELL_NO_UNION",
-                              "POLEE_PSELL_NO_MASK", "POLEE_PSELL_MASK_GAIN", "POLEE_PSELL_MASK_GAIN_WIDE", "POLEE_PSELL_OVER_BUDGET", "POLEE_PSELL_RELAX", "POLEE_PSELL_RELAX0",
-                              "POLEE_PSELL_MAX_GROUP", "POLEE_PSELL_MERGE_MASKED", "POLEE_PSELL_INTERLEAVE", "POLEE_PSELL_NO_BN", "POLEE_PSELL_NO_CSR",
+                              "POLEE_PSELL_NO_MASK", "POLEE_PSELL_MASK_GAIN", "POLEE_PSELL_OVER_BUDGET", "POLEE_PSELL_RELAX", "POLEE_PSELL_RELAX0",
+                              "POLEE_PSELL_MAX_GROUP", "POLEE_PSELL_NO_BN", "POLEE_PSELL_NO_CSR",
                               "POLEE_PSELL_CSR_MIN_SHARE", "POLEE_TILE_PER_WG"})
             if (getenv(k)) return false;
         return true;
