@@ -499,7 +499,10 @@ class Comm:
         communicator's own ncclCommCount / ncclCommUserRank."""
         t, n, r = C.c_int32(), C.c_int32(), C.c_int32()
         check(L.lib().polee_comm_info(self._h, C.byref(t), C.byref(n), C.byref(r)), self.ctx._h)
-        return dict(transport={1: "rccl", 2: "host"}.get(t.value, "?"), count=n.value, rank=r.value)
+        import os
+        return dict(transport={1: "rccl", 2: "host"}.get(t.value, "?"), count=n.value, rank=r.value,
+                    # (RCCL transport: POLEE_COMM_ALGO=rs_ag exchanges by reduce-scatter + all-gather instead of one all-reduce)
+                    algo=os.environ.get("POLEE_COMM_ALGO", "allreduce") if t.value == 1 else "host all-reduce")
 
     def allreduce_sum(self, values):
         """Sum of a float32 array over the ranks (polee_allreduce_sum_f32)."""

@@ -152,9 +152,13 @@ struct PsellArgs {
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
     // dynamic schedule (the default; the deterministic mode keeps the static one): the tiles in descending order of their
     // cost, POS_NONE behind them; workgroup b starts with positions b, b + G, b + 2 G and draws every further position
-    // from the counter dyn_ctr[0] (+ 3 G); dyn_ctr[1] counts the workgroups that are done -- the last one resets both
+    // from the counter dyn_ctr[0] (+ 3 G).  The counter is NEVER reset: a launch makes exactly one draw per position of the list
+    // (a workgroup draws once per tile it takes), so the next launch's draws start at dyn_base + positions -- the host keeps
+    // dyn_base (round 5: the last workgroup used to reset the counter behind an acquire-release arrival count; that fence --
+    // an L2 write-back and invalidate per WORKGROUP, 1 024 per launch -- cost 25 us of a 250 us pass, see launch_stream)
     const PosDesc *sched_dyn;
     unsigned int *dyn_ctr;
+    unsigned int dyn_base;
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
     float *gwin;            // [dict entries][K], laid out like xwin
     double *lpwin;          // [grid][K] per-workgroup log-likelihood sums
@@ -1931,7 +1935,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #endif
         if (!more) break;
         cur = nxt;
-        if (wave == 0) p2 = dyn ? 3u * G + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) : p2 + G;
+        if (wave == 0) p2 = dyn ? 3u * G + ((uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) - A.dyn_base) : p2 + G;
         {
             const uint32_t *dp = descb + (round & 1u) * 64u;
             nxt.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[0]);
@@ -1960,16 +1964,6 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (wave_lane() < K) atomicAdd(A.lp + wave_lane(), v);
-    }
-    if (dyn && wave == 0 && wave_lane() == 0) {  // (not threadIdx.x: kept alive across the tile loop it is spilled)
-        // Every draw of this launch has been made before the last workgroup arrives here: the draws are this thread's own
-        // earlier atomics, ordered before its arrival by the RELEASE half of the increment; the workgroup that sees G - 1
-        // ACQUIRES all of them before it resets the counters for the next launch (the ordering is now stated,
-        // not implied by the per-tile s_waitcnt).  Should a launch fail, the host zeroes the counters (loglik_eval_device).
-        if (__hip_atomic_fetch_add(A.dyn_ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1u) {
-            __hip_atomic_store(A.dyn_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.dyn_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 #ifdef POLEE_TILE_CYCLES
     if (threadIdx.x == 0 && blockIdx.x < 4096) atomicAdd(&g_wg_cycles[blockIdx.x], __builtin_amdgcn_s_memtime() - t_wg0);
@@ -2120,60 +2114,23 @@ static polee_status ensure_schedule(polee_loglik *ll, int G)
             }
             if (!plain) std::stable_sort(dorder.begin(), dorder.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         }
-        // Round 5: GUIDED positions.  A position of the list is a tile -- or, towards the END of the list, a PART of a tile (a
-        // range of its slices under the same dictionary).  The workgroups finish within one position of each other, and with ~10
-        // tiles of 40 - 140 k cycles per workgroup that was 7 % (C2, every fragment its own subset) to 27 % (the tiled real
-        // fixture, 3 tiles per workgroup) of the launch (profiles/r05_tile_cycles_*.txt: slowest workgroup / mean).  As in
-        // guided self-scheduling a position may cost at most (work still ahead in the list) / (workgroups), and at least twice
-        // a tile's fixed cost: the first ~90 % of the work goes out in whole tiles, the rest in ever smaller parts.
-        // (needs the slices' sizes: the list is built while the handle is being created; POLEE_DYN_NO_SPLIT=1: whole tiles)
-        static const bool no_split = getenv("POLEE_DYN_NO_SPLIT") != nullptr;
-        const bool can_split = !no_split && !h.slice_w.empty() && h.slice_off.size() > h.tile_slice[(size_t)h.num_tiles_s];
-        double remaining = 0.0;
-        for (uint32_t t : dorder) remaining += (double)ll->tile_cost[t];
+        // (Round 5 tried GUIDED positions -- towards the end of the list a position was a PART of a tile, at most (work still ahead)
+        // / (workgroups) cycles, so that the workgroups finish closer together: the extra positions' fixed cost outweighed the
+        // better balance on every input, +0.7 .. +4 % kernel time, profiles/r05_guided_positions_ab.txt.  Whole tiles.)
         std::vector<PosDesc> plist;
-        plist.reserve(dorder.size() + (size_t)4 * (size_t)G);
+        plist.reserve(dorder.size());
         for (size_t i = 0; i < dorder.size(); ++i) {
             const uint32_t t = dorder[i];
-            const int st = h.stream_of_tile(t);
-            const uint32_t s0 = h.tile_slice[t], s1 = h.tile_slice[t + 1];
-            const double cost = (double)ll->tile_cost[t];
-            const double cap = std::max(2.0 * TILE_COST_FIXED[st], remaining / (double)G);
-            remaining -= cost;
-            const uint32_t min_slices = st == PSELL_A2M ? 2u : 4u;  // (a slice per active wave)
-            uint32_t parts = 1;
-            if (can_split && cost > cap) parts = (uint32_t)std::min<double>(std::ceil(cost / cap), (double)((s1 - s0) / min_slices));
-            parts = std::max(parts, 1u);
-            const uint32_t u0 = h.slice_off[s0] & PSELL_OFF_MASK, u1 = h.slice_off[s1] & PSELL_OFF_MASK;
-            uint32_t sa = s0;
-            for (uint32_t q = 0; q < parts; ++q) {
-                uint32_t sb = s1;
-                if (q + 1 < parts) {  // the part ends where its share of the tile's bytes does (at least min_slices further on)
-                    const uint32_t target = u0 + (uint32_t)((uint64_t)(u1 - u0) * (q + 1) / parts);
-                    sb = sa + min_slices;
-                    while (sb < s1 && (h.slice_off[sb] & PSELL_OFF_MASK) < target) ++sb;
-                    sb = std::min(sb, s1 - min_slices * (parts - 1 - q));
-                }
-                PosDesc d = PosDesc();
-                d.tile = t;
-                d.s0 = sa;
-                d.s1 = sb;
-                d.d0 = h.tile_dict[t];
-                d.L = h.tile_cols[t];
-                if (parts == 1) {
-                    d.c1 = ll->tile_cut[(size_t)3 * t];
-                    d.c2 = ll->tile_cut[(size_t)3 * t + 1];
-                    d.c3 = ll->tile_cut[(size_t)3 * t + 2];
-                } else {
-                    uint32_t cut[3];
-                    wave_cuts(h, t, sa, sb, cut);
-                    d.c1 = cut[0];
-                    d.c2 = cut[1];
-                    d.c3 = cut[2];
-                }
-                plist.push_back(d);
-                sa = sb;
-            }
+            PosDesc d = PosDesc();
+            d.tile = t;
+            d.s0 = h.tile_slice[t];
+            d.s1 = h.tile_slice[t + 1];
+            d.d0 = h.tile_dict[t];
+            d.L = h.tile_cols[t];
+            d.c1 = ll->tile_cut[(size_t)3 * t];
+            d.c2 = ll->tile_cut[(size_t)3 * t + 1];
+            d.c3 = ll->tile_cut[(size_t)3 * t + 2];
+            plist.push_back(d);
         }
         ll->dyn_positions = plist.size();
         std::vector<PosDesc> dynl(plist.size() + (size_t)4 * 4 * 256 + 64);
@@ -2219,6 +2176,9 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     if (!DET && !static_sched && (size_t)3 * (size_t)G + 8 <= ll->dyn_pad) {
         A.sched_dyn = ll->d_sched_dyn.p;
         A.dyn_ctr = ll->d_dyn_ctr.p;
+        // (the counter runs on from launch to launch, modulo 2^32: this launch's draws are dyn_base, dyn_base + 1, ...)
+        A.dyn_base = ll->dyn_base;
+        ll->dyn_base += (uint32_t)ll->dyn_positions;
     }
     if (DET) {
         POLEE_TRY(ll->d_gwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512));
@@ -2257,7 +2217,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     const uint32_t *csr_col = rm && rm->csr_col ? rm->csr_col : ll->d_csr_col.p;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, rm ? rm->dict : ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, nullptr, nullptr};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
@@ -2345,8 +2305,10 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
         case 7: st = launch_k<7>(ll, d_x, d_g, d_lp); break;
         default: st = launch_k<8>(ll, d_x, d_g, d_lp); break;
     }
-    if (st != POLEE_OK && ll->d_dyn_ctr.p)  // a failed launch may have left draws behind: the next pass must start at position 0
+    if (st != POLEE_OK && ll->d_dyn_ctr.p) {  // a failed launch may have made only some of its draws: counter and base start over
         (void)hipMemsetAsync(ll->d_dyn_ctr.p, 0, 2 * sizeof(unsigned int), ctx->stream);
+        ll->dyn_base = 0;
+    }
     ll->cur_remap = nullptr;
     // stream S; a caller whose forward kernel has already written cnt / x into g only needs the log-likelihood's share
     if (st == POLEE_OK && ll->has_singles && !(remap && remap->singles_in_g && !d_lp)) {

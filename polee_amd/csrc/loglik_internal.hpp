@@ -206,9 +206,10 @@ struct polee_loglik {
     polee::DevBuf<polee::PosDesc> d_sched;
     int sched_grid = 0;
     polee::DevBuf<polee::PosDesc> d_sched_dyn;  // dynamic schedule: the tiles by descending cost + POS_NONE padding
-    polee::DevBuf<unsigned int> d_dyn_ctr;      // {positions drawn, workgroups done}: zero between launches
+    polee::DevBuf<unsigned int> d_dyn_ctr;      // [0]: positions drawn so far, running on from launch to launch ([1] unused)
     size_t dyn_pad = 0;
-    size_t dyn_positions = 0;  // positions of the dynamic list (tiles, and parts of tiles towards its end)
+    size_t dyn_positions = 0;  // positions of the dynamic list = draws a launch makes
+    uint32_t dyn_base = 0;     // the counter's value when the next launch starts (modulo 2^32)
     std::vector<float> tile_cost;  // relative cost of every tile (bytes it streams, weighted by stream)
     std::vector<uint32_t> tile_cut;  // [3 * num_tiles] slice boundaries between the waves of a uniform tile
     int64_t dict_len = 0;

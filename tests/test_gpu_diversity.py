@@ -141,6 +141,31 @@ def test_matrix_without_any_structure_matches_oracle(P, ctx):
     _check_against_oracle(P, sk, so, n, m, 4, rng, ks=ks)
 
 
+def test_matrix_without_any_structure_matches_oracle(P, ctx):
+    """A random sparse matrix (every fragment in other transcripts than its neighbours): nothing for equivalence classes,
+    unions or tile dictionaries to exploit -- its rows stay in CSR (stream C, loglik_csr_kernel), the layout is no larger
+    than CSR, and the pass still matches the oracle (with and without multiplicities)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    X = sp.random(60000, 5000, density=0.0008, random_state=5, format="csr", dtype=np.float32)
+    X.data = rng.uniform(1e-9, 1e-3, X.nnz).astype(np.float32)
+    X = X[np.flatnonzero(np.diff(X.indptr) > 0)]
+    X.sort_indices()
+    m, n = X.shape
+    xt = ((X.indptr + 1).astype(np.uint64), (X.indices + 1).astype(np.uint32), X.data)
+    s = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=xt)
+    info = s.info
+    assert info["stream_nnz"][6] > 0.9 * X.nnz and sum(info["stream_nnz"]) == X.nnz
+    assert info["stream_bytes"] < 1.03 * (8 * X.nnz + 4 * (m + 1))
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    so = O.Sample(m, n, (Xc.indptr + 1).astype(np.uint64), (Xc.indices + 1).astype(np.uint32), Xc.data)
+    _check_against_oracle(P, s, so, n, m, 6, rng)
+    ks = rng.integers(1, 9, m).astype(np.int64)
+    sk = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=xt, ks=ks)
+    _check_against_oracle(P, sk, so, n, m, 4, rng, ks=ks)
+
+
 def test_masked_slices_riding_in_dense_tiles_match_oracle():
     """Round 4 experiment kept behind POLEE_PSELL_MERGE_MASKED / POLEE_PSELL_INTERLEAVE (off by default: no net gain,
     profiles/r04_mixed_tiles_ab.txt): masked narrow slices inside the A1 tiles of their genomic bin, the kernel's dense loop

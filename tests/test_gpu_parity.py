@@ -466,7 +466,9 @@ def test_deterministic_mode_is_bitwise_reproducible(P, ctx, lm_fixture, prep_fix
     for _ in range(3):
         lp2, g2 = s.log_likelihood(x)
         assert np.array_equal(lp1, lp2) and np.array_equal(g1, g2)
-    np.testing.assert_allclose(lp1, lp0, rtol=1e-12)
+    # (lp: a lane keeps the float32 PRODUCT of its row sums' mantissas, so the value depends on which slices a lane saw -- the
+    # static and the dynamic schedule cut the tiles differently: ~1e-11 relative)
+    np.testing.assert_allclose(lp1, lp0, rtol=1e-9)
     np.testing.assert_allclose(g1, g0, rtol=2e-5, atol=1e-6 * np.abs(g0).max())
     so = O.Sample(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"])
     for k in range(6):
@@ -787,6 +789,30 @@ def test_row_sharded_fit_with_one_rank_equals_the_plain_fit(P, ctx, lm_fixture, 
     for a, b in zip(out[0][0], out[1][0]):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(out[0][1][1], out[1][1][1], rtol=1e-6)  # expected log-likelihood trace
+
+
+def test_reduce_scatter_all_gather_exchange_with_one_rank():
+    """POLEE_COMM_ALGO=rs_ag (comm.cpp): the exchange as ncclReduceScatter + ncclAllGather, in place.  With one rank both are
+    the identity; what runs here is the call path -- RCCL symbols bound, in-place offsets, a count the ranks divide and one
+    they do not (1 divides everything: the second call is the same path) -- on the only transport a one-GPU box has.  The
+    library reads the switch once per process: a child process."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r)
+        import numpy as np
+        import polee_amd as P
+        ctx = P.Context(0)
+        comm = P.Comm(ctx, 1, 0)
+        assert comm.info()["algo"] == "rs_ag" and comm.info()["transport"] == "rccl", comm.info()
+        for n in (10, 1200000, 7):
+            v = np.random.default_rng(n).normal(size=n).astype(np.float32)
+            np.testing.assert_array_equal(comm.allreduce_sum(v), v)
+        print("ok")
+    """) % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POLEE_COMM_ALGO="rs_ag"), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
 
 
 def test_handles_release_device_memory(P, lm_fixture, prep_fixture):

@@ -14,6 +14,7 @@ for input in $INPUTS; do
     literal) ARGS="--workload c2 --generator literal --no-by-input" ;;
     wide) ARGS="--workload wide --generator literal --no-by-input" ;;
     fixture) ARGS="--workload fixture" ;;
+    fixture_full) ARGS="--workload fixture_full" ;;
     c5) ARGS="--workload c5 --generator literal --no-by-input" ;;
   esac
   for rep in $(seq 1 ${REPS:-2}); do
