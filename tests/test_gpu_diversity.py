@@ -139,64 +139,3 @@ def test_matrix_without_any_structure_matches_oracle(P, ctx):
     ks = rng.integers(1, 9, m).astype(np.int64)
     sk = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=xt, ks=ks)
     _check_against_oracle(P, sk, so, n, m, 4, rng, ks=ks)
-
-
-def test_matrix_without_any_structure_matches_oracle(P, ctx):
-    """A random sparse matrix (every fragment in other transcripts than its neighbours): nothing for equivalence classes,
-    unions or tile dictionaries to exploit -- its rows stay in CSR (stream C, loglik_csr_kernel), the layout is no larger
-    than CSR, and the pass still matches the oracle (with and without multiplicities)."""
-    import scipy.sparse as sp
-    rng = np.random.default_rng(3)
-    X = sp.random(60000, 5000, density=0.0008, random_state=5, format="csr", dtype=np.float32)
-    X.data = rng.uniform(1e-9, 1e-3, X.nnz).astype(np.float32)
-    X = X[np.flatnonzero(np.diff(X.indptr) > 0)]
-    X.sort_indices()
-    m, n = X.shape
-    xt = ((X.indptr + 1).astype(np.uint64), (X.indices + 1).astype(np.uint32), X.data)
-    s = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=xt)
-    info = s.info
-    assert info["stream_nnz"][6] > 0.9 * X.nnz and sum(info["stream_nnz"]) == X.nnz
-    assert info["stream_bytes"] < 1.03 * (8 * X.nnz + 4 * (m + 1))
-    Xc = X.tocsc()
-    Xc.sort_indices()
-    so = O.Sample(m, n, (Xc.indptr + 1).astype(np.uint64), (Xc.indices + 1).astype(np.uint32), Xc.data)
-    _check_against_oracle(P, s, so, n, m, 6, rng)
-    ks = rng.integers(1, 9, m).astype(np.int64)
-    sk = P.RNASeqSample(m, n, None, None, None, ctx=ctx, xt=xt, ks=ks)
-    _check_against_oracle(P, sk, so, n, m, 4, rng, ks=ks)
-
-
-def test_masked_slices_riding_in_dense_tiles_match_oracle():
-    """Round 4 experiment kept behind POLEE_PSELL_MERGE_MASKED / POLEE_PSELL_INTERLEAVE (off by default: no net gain,
-    profiles/r04_mixed_tiles_ab.txt): masked narrow slices inside the A1 tiles of their genomic bin, the kernel's dense loop
-    followed by its masked loop per wave.  The builder reads the switches once per process: a child process."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys; sys.path.insert(0, %r)
-        import numpy as np
-        import polee_amd as P
-        from oracle import oracle as O
-        from tools import synth
-        ctx = P.Context(0)
-        for kw in (dict(dropout=0.3), dict(literal=True)):
-            n, m = 3000, 400000
-            smp = synth.make_sample(n, m, 8.0, seed=7, **kw)
-            s = P.RNASeqSample(m, n, None, None, None, smp["effective_lengths"], ctx=ctx, xt=(smp["tcolptr"], smp["trowval"], smp["tnzval"]))
-            info = s.info
-            assert info["stream_nnz"][1] > 0.02 * smp["nnz"] and info["stream_tiles"][1] == 0, info  # masked slices, no tiles of their own
-            colptr, rowval, nzval = synth.to_csc(smp)
-            so = O.Sample(m, n, colptr, rowval, nzval)
-            rng = np.random.default_rng(3)
-            x = rng.gamma(0.3, size=(6, n)).astype(np.float32) + np.float32(1e-7)
-            x /= x.sum(axis=1, keepdims=True)
-            lp, g = s.log_likelihood(x)
-            for k in range(6):
-                lpo, go = so.log_likelihood(x[k])
-                assert abs(lp[k] - lpo) <= 1e-6 * abs(lpo)
-                np.testing.assert_allclose(g[k], go, rtol=1e-4, atol=1e-6 * np.abs(go).max())
-        print("ok")
-    """) % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, POLEE_PSELL_MERGE_MASKED="1", POLEE_PSELL_INTERLEAVE="1"),
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
