@@ -297,7 +297,7 @@ def measure_other_input(P, synth, ctx, name, smp, args, K):
         pre.sync()
         del pre
     fit = P.LikelihoodApproximationFit(sample, tree, num_steps=args.warmup + args.steps, num_mc_samples=K, seed=args.seed,
-                                       profile=True, deterministic=args.deterministic)
+                                       profile=max(1, args.profile_every), deterministic=args.deterministic)
     fit.run(args.warmup)
     fit.sync()
     st0 = fit.stats()
@@ -345,6 +345,9 @@ def main():
     ap.add_argument("--literal-subsets", action="store_true", help="(kept for scripts) same as --generator literal")
     ap.add_argument("--no-by-input", action="store_true",
                     help="skip the two extra inputs of roofline.by_input (the other generator and the tiled real fixture)")
+    ap.add_argument("--profile-every", type=int, default=4, metavar="N",
+                    help="bracket every N-th sparse pass of the timed region with HIP events (the roofline's kernel time); "
+                         "bracketing every pass puts ~20 us of gaps into each C2 iteration (profiles/r05_event_gaps.txt)")
     ap.add_argument("--cu-partition", action="store_true",
                     help="with --samples-per-gpu S: every fit on its own S-th of the GPU's compute units (CU-masked streams)")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
@@ -412,7 +415,7 @@ def main():
         tree_i = P.PolyaTreeTransform(parents, js, ctx=ctx_i)
         t_build += time.time() - t0
         fits.append(P.LikelihoodApproximationFit(sample_i, tree_i, num_steps=max(total, 1), num_mc_samples=K,
-                                                 seed=args.seed, profile=True, comm=comm, deterministic=args.deterministic))
+                                                 seed=args.seed, profile=max(1, args.profile_every), comm=comm, deterministic=args.deterministic))
         ctxs.append(ctx_i)
         if si == 0:
             smp, sample, tree, info = smp_i, sample_i, tree_i, sample_i.info
@@ -455,6 +458,9 @@ def main():
     elapsed = ranks.max(elapsed)  # slowest rank
 
     roof = roofline_of(info, st0, st1, m, n, K, args.deterministic)
+    roof["event_sampling"] = ("every launch of the timed region is bracketed by HIP events" if args.profile_every <= 1 else
+                              "every %d-th launch of the timed region is bracketed by HIP events on the library's stream (`launches` of "
+                              "them): four event records per pass are ~20 us of stream gaps per C2 iteration" % args.profile_every)
     sid = source_id()
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/profile.sh): a capture is
     # valid for the build and the workload it was taken with -- otherwise null

@@ -251,7 +251,8 @@ typedef struct {
     double adam_rv;                    /* 0.9  */
     double adam_rm;                    /* 0.7  */
     double max_mu_step, max_omega_step, max_alpha_step; /* 0.2, 0.2, 0.02 */
-    int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events  */
+    int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events; N > 1: every N-th launch (four
+                                    event records per pass cost ~20 us of stream gaps per iteration at C2) */
     int32_t deterministic;       /* 1: this fit's likelihood passes run in deterministic mode (the handle's own  */
                                  /* polee_loglik_set_deterministic setting is untouched)                         */
     const int32_t *gene_of;      /* optional HOST int32[n]: gene index of every transcript (0-based, -1 = none   */

@@ -2276,7 +2276,9 @@ polee_status loglik_eval_device(polee_loglik *ll, const float *d_x, int K, float
     // (profiling: one pair of events brackets the dominant launch, a second pair the whole pass -- the x-window gather in
     // front of it and the mixed stream's launch behind it)
     hipEvent_t e0 = nullptr, e1 = nullptr, p0 = nullptr, p1 = nullptr;
-    if (ll->profile) {
+    // (profile = N > 1: every N-th pass only.  Four event records per pass are four barrier packets in the stream -- measured
+    // with rocprofv3, round 5: 22 us of idle gaps per VI iteration when EVERY pass is bracketed, 5 % of a C2 step)
+    if (ll->profile && (ll->prof_every <= 1 || ll->prof_tick++ % (uint64_t)ll->prof_every == 0)) {
         if (ll->prof_used + 4 > ll->prof_events.size()) {
             if (ll->prof_events.size() >= 8192) POLEE_TRY(ll->profile_collect());
             while (ll->prof_used + 4 > ll->prof_events.size()) {

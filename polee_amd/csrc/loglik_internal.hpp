@@ -225,6 +225,8 @@ struct polee_loglik {
     polee::DevBuf<double> d_g_rows, d_lp;
     // profiling of the sparse kernel
     bool profile = false;
+    int prof_every = 1;        // bracket every prof_every-th pass with events (polee_vi_opts.profile = N)
+    uint64_t prof_tick = 0;
     hipEvent_t cur_e0 = nullptr, cur_e1 = nullptr;  // bracket the dominant launch of the current pass
     hipEvent_t cur_p0 = nullptr, cur_p1 = nullptr;  // bracket the whole pass
     std::vector<hipEvent_t> prof_events;

@@ -548,6 +548,7 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     vi->n = t->n;
     vi->K = o.num_mc_samples;
     ll->profile = o.profile != 0;
+    ll->prof_every = o.profile > 1 ? o.profile : 1;
     // (opts.deterministic belongs to THIS fit: applied around its likelihood passes, the handle's own setting restored)
     const size_t n = vi->n, nm1 = std::max<size_t>(n - 1, 1), K = vi->K;
     polee_status s = POLEE_OK;
@@ -735,6 +736,7 @@ polee_status polee_vi_run(polee_vi *vi, int32_t nsteps)
     if (!vi) return fail(nullptr, POLEE_ERR_BAD_ARG, "null handle");
     POLEE_TRY(use_device(vi->ctx));
     vi->ll->profile = vi->o.profile != 0;
+    vi->ll->prof_every = vi->o.profile > 1 ? vi->o.profile : 1;
     for (int32_t i = 0; i < nsteps; ++i) POLEE_TRY(vi->one_step(true, !vi->o.gradonly, false));
     return POLEE_OK;
 }
