@@ -348,8 +348,6 @@ def main():
     ap.add_argument("--profile-every", type=int, default=4, metavar="N",
                     help="bracket every N-th sparse pass of the timed region with HIP events (the roofline's kernel time); "
                          "bracketing every pass puts ~20 us of gaps into each C2 iteration (profiles/r05_event_gaps.txt)")
-    ap.add_argument("--cu-partition", action="store_true",
-                    help="with --samples-per-gpu S: every fit on its own S-th of the GPU's compute units (CU-masked streams)")
     ap.add_argument("--samples-per-gpu", type=int, default=1,
                     help="fits run concurrently on one GPU, each on its own stream (cohort mode; the headline uses 1)")
     args = ap.parse_args()
@@ -403,7 +401,7 @@ def main():
                                       dropout=args.set_diversity, literal=args.literal_subsets)
         parents, js = synth.make_tree(smp_i["gene"], seed=args.seed, kind=args.tree)
         t_gen += time.time() - t0
-        ctx_i = P.Context(local_rank if world > 1 else 0, partition=(si, S) if args.cu_partition and S > 1 else None)
+        ctx_i = P.Context(local_rank if world > 1 else 0)
         t0 = time.time()
         xt_i, m_i = (smp_i["tcolptr"], smp_i["trowval"], smp_i["tnzval"]), m
         if args.row_shard:

@@ -55,11 +55,6 @@ typedef struct polee_regression polee_regression; /* regression model + surrogat
 
 /* ---- context -------------------------------------------------------------------- */
 polee_status polee_ctx_create(int device, polee_ctx **out);
-/* A context on ONE PART of the GPU's compute units: part `part` (0-based) of `nparts` equal contiguous ranges of CUs (a HIP stream
- * with a CU mask).  For fits that share a GPU -- a cohort prepared `nparts` samples at a time (the reference prepares samples one
- * after the other, main.jl:560-660): each fit's kernels stay on its own CUs, so one fit's tree kernels run beside the other's
- * sparse pass.  Everything created under the context (samples, trees, fits) runs there. */
-polee_status polee_ctx_create_partition(int device, int part, int nparts, polee_ctx **out);
 void polee_ctx_destroy(polee_ctx *ctx);
 const char *polee_last_error(const polee_ctx *ctx_or_null);
 polee_status polee_ctx_synchronize(polee_ctx *ctx);

@@ -25,14 +25,9 @@ end
 
 mutable struct Context
     h::Ptr{Cvoid}
-    # partition = (part, nparts): the stream runs on that part of the GPU's compute units (polee_ctx_create_partition)
-    function Context(device::Integer=0; partition::Union{Nothing,Tuple{Int,Int}}=nothing)
+    function Context(device::Integer=0)
         r = Ref{Ptr{Cvoid}}(C_NULL)
-        if partition === nothing
-            check(ccall((:polee_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
-        else
-            check(ccall((:polee_ctx_create_partition, LIB), Cint, (Cint, Cint, Cint, Ref{Ptr{Cvoid}}), device, partition[1], partition[2], r))
-        end
+        check(ccall((:polee_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, r))
         c = new(r[])
         finalizer(c -> ccall((:polee_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.h), c)
         return c

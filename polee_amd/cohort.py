@@ -99,7 +99,7 @@ def shard_regression_inputs(vars, x_init, F_arr, sample_scales, world_size, rank
                 x_init_mean=x_init.astype(np.float64).mean(axis=0).astype(np.float32))
 
 
-def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_result=None, cu_partition=False, **kwargs):
+def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_result=None, **kwargs):
     """`approximate_likelihood` (likelihood-approximation.jl:395-624) for the samples of a cohort, `workers` of them in
     flight on ONE GPU.  Per sample the reference's `prep-sample` (main.jl:560-660) builds the tree from X on the CPU
     (hclust.jl), then fits; here a fit occupies the GPU for a fraction of a second while the host side of the same sample
@@ -118,22 +118,10 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
              or the dict of `h5io.read_likelihood_matrix` (the likelihood-matrix HDF5's arrays, rnaseq_sample.jl:505-519) -- called inside the worker, so that at most
              `workers` matrices are in host memory at a time -- or of such tuples.
     on_result(index, params): optional callback as results arrive (e.g. the prep HDF5 writer); else a list is returned.
-    cu_partition: every worker's context on its own `workers`-th of the GPU's compute units (polee_ctx_create_partition):
-             the fits then do not queue behind each other's persistent launches.
     kwargs: passed to `approximate_likelihood` (num_steps, num_mc_samples, seed, gene_noninformative, ...).
     Returns the list of params dicts in the order of `samples` (None where `on_result` consumed them)."""
-    import itertools
-    import threading
     from concurrent.futures import ThreadPoolExecutor
     from . import core
-    slots, local = itertools.count(), threading.local()
-
-    def make_context():
-        if not cu_partition or workers < 2:
-            return core.Context(device)
-        if not hasattr(local, "slot"):
-            local.slot = next(slots) % int(workers)  # (one pool thread = one part of the GPU for the cohort's lifetime)
-        return core.Context(device, partition=(local.slot, int(workers)))
 
     def job(item):
         idx, src = item
@@ -141,7 +129,7 @@ def approximate_likelihood_cohort(approx, samples, workers=2, device=0, on_resul
         if isinstance(lm, dict):  # h5io.read_likelihood_matrix
             lm = tuple(lm[key] for key in ("m", "n", "colptr", "rowval", "nzval", "effective_lengths"))
         m, n, colptr, rowval, nzval, efflens = lm
-        ctx = make_context()
+        ctx = core.Context(device)
         sample, tree = core.sample_and_tree(approx, m, n, colptr, rowval, nzval, efflens, ctx=ctx)  # (side by side)
         params = core.approximate_likelihood(approx, sample, tree, **kwargs)
         del sample, tree

@@ -13,16 +13,10 @@ LIKAP_NUM_MC_SAMPLES = 6   # src/constants.jl:65
 class Context:
     """One GPU + one HIP stream (polee_ctx)."""
 
-    def __init__(self, device=0, partition=None):
-        """partition = (part, nparts): the context's stream runs on that part of the GPU's compute units only
-        (polee_ctx_create_partition) -- for fits that share a GPU."""
+    def __init__(self, device=0):
         self._h = C.c_void_p()
-        if partition is None:
-            check(L.lib().polee_ctx_create(int(device), C.byref(self._h)))
-        else:
-            check(L.lib().polee_ctx_create_partition(int(device), int(partition[0]), int(partition[1]), C.byref(self._h)))
+        check(L.lib().polee_ctx_create(int(device), C.byref(self._h)))
         self.device = int(device)
-        self.partition = partition
 
     def close(self):
         if self._h:
@@ -667,7 +661,7 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
     # the context's error string.
     tree_ctx = getattr(ctx, "_tree_ctx", None)
     if tree_ctx is None and tm in ("cluster_auto", "cluster_device"):
-        tree_ctx = ctx._tree_ctx = Context(ctx.device, partition=getattr(ctx, "partition", None))
+        tree_ctx = ctx._tree_ctx = Context(ctx.device)
     with ThreadPoolExecutor(max_workers=1) as pool:
         fut = None
         if tm == "cluster_auto":

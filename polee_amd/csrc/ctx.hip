@@ -98,19 +98,7 @@ void polee_debug_device_cache_poison(int64_t *checked_blocks, int64_t *bad_block
     if (bad_words) *bad_words = (int64_t)polee::g_poison_bad_words.load();
 }
 
-static polee_status ctx_create_impl(int device, int part, int nparts, polee_ctx **out);
-polee_status polee_ctx_create(int device, polee_ctx **out) { return ctx_create_impl(device, 0, 1, out); }
-// A context whose stream runs on ONE PART of the GPU's compute units (hipExtStreamCreateWithCUMask): part `part` of `nparts`
-// equal, contiguous ranges of CUs -- whole XCDs when nparts divides 8.  Fits that share a GPU (a cohort) each get a partition: one
-// fit's latency-bound tree kernels then run beside the other fit's sparse pass instead of queueing behind a launch that fills
-// every CU's LDS.  num_cus of the context = the partition's, so persistent grids size themselves to it.
-polee_status polee_ctx_create_partition(int device, int part, int nparts, polee_ctx **out)
-{
-    if (nparts < 1 || part < 0 || part >= nparts) return fail(nullptr, POLEE_ERR_BAD_ARG, "polee_ctx_create_partition: part %d of %d", part, nparts);
-    return ctx_create_impl(device, part, nparts, out);
-}
-
-static polee_status ctx_create_impl(int device, int part, int nparts, polee_ctx **out)
+polee_status polee_ctx_create(int device, polee_ctx **out)
 {
     if (!out) return fail(nullptr, POLEE_ERR_BAD_ARG, "polee_ctx_create: null out pointer");
     *out = nullptr;
@@ -137,15 +125,7 @@ static polee_status ctx_create_impl(int device, int part, int nparts, polee_ctx 
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
     ctx->lds_per_block = prop.sharedMemPerBlock;
-    if (nparts > 1) {
-        const int total = ctx->num_cus, c0 = (int)((int64_t)total * part / nparts), c1 = (int)((int64_t)total * (part + 1) / nparts);
-        if (c1 <= c0) return bail(hipErrorInvalidValue, "CU partition (more parts than compute units)");
-        std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
-        for (int c = c0; c < c1; ++c) mask[(size_t)c >> 5] |= 1u << (c & 31);
-        if ((e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data())) != hipSuccess)
-            return bail(e, "hipExtStreamCreateWithCUMask");
-        ctx->num_cus = c1 - c0;
-    } else if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e, "hipEventCreate");

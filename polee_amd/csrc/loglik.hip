@@ -759,7 +759,7 @@ __device__ inline void wide_stream(WaveStream &ws, const char *ring, int extras,
 
 
 // ---- the slice loop of the narrow stream (transcript sets of <= 16): batched outer products ---------------------------
-// With K <= 8 draws the 16-column MFMA tile of uniform_stream is at most half used.  v_mfma_f32_4x4x1_16b_f32 computes
+// With K <= 8 draws the 16-column MFMA tile of wide_stream is at most half used.  v_mfma_f32_4x4x1_16b_f32 computes
 // sixteen independent 4 x 4 outer products D[b][i][j] += A[b][i] B[b][j] (A in lane 4 b + i, B in lane 4 b + j, D in
 // register i of lane 4 b + j) in 8 cycles, a quarter of the 16 x 16 x 4 tile's 32, and fits the problem exactly:
 //   phase 1   S[r][k] = sum_t V[t][r] x[c_t][k]    block b = fragments 4 b + (0..3), i = fragment, j = draw (k = 4 kg + j,
@@ -833,7 +833,7 @@ __device__ inline void narrow_stream(WaveStream &ws, const char *ring, int extra
     static_assert(WMAX == 16, "four groups of four transcripts");
     constexpr int KG = (K + 3) / 4;
     constexpr int RP = (int)(RB / 1024u);
-    const int lane = wave_lane();  // (see uniform_stream: per-tile lane constants instead of spilled ones)
+    const int lane = wave_lane();  // (see wide_stream: per-tile lane constants instead of spilled ones)
     const uint32_t ring_lds = lds_addr(ring);
     const uint32_t xw_lds = lds_addr(xw), gw_lds = lds_addr(gw);
     const int j = lane & 3, b = lane >> 2;
@@ -1593,7 +1593,7 @@ __global__ __launch_bounds__(256) void xwin_gather_kernel(const uint32_t *__rest
 
 // deterministic mode, second kernel: g[j][k] += the windows' values of transcript j (tslot lists its dictionary entries,
 // ascending = tile order).  A thread per (j, k) walks a short list; a transcript present in more than GWIN_HEAVY tiles
-// gets a whole wave (gwin_reduce_heavy_kernel): lane l sums entries l, l + 64, ... in order and the 64 partial sums are
+// gets a block per draw (gwin_reduce_heavy_kernel): thread t sums entries t, t + 256, ... in order and a wave's 64 partial sums are
 // combined by a fixed shuffle tree -- a fixed order either way.  Block 0 also adds the workgroups' log-likelihood sums in
 // workgroup order.
 constexpr uint32_t GWIN_HEAVY = 32;
@@ -1617,21 +1617,26 @@ __global__ void gwin_reduce_kernel(const uint32_t *__restrict__ tslot_ptr, const
     for (uint32_t e = b; e < e1; ++e) s += gwin[(size_t)tslot[e] * K + k];
     g[gmap ? (size_t)gmap[j] * K + k : (size_t)i] += s;
 }
-__global__ __launch_bounds__(64) void gwin_reduce_heavy_kernel(const uint32_t *__restrict__ heavy,
-                                                             const uint32_t *__restrict__ tslot_ptr,
-                                                             const uint32_t *__restrict__ tslot,
-                                                             const float *__restrict__ gwin, int K, float *__restrict__ g,
-                                                             const uint32_t *__restrict__ gmap)
+// (round 5: a block of 256 threads per (heavy transcript, draw) -- it was one wave per transcript looping over the draws, 25 us per
+// pass for a handful of transcripts; the order is still fixed: thread t sums entries t, t + 256, ..., a wave's 64 partial sums meet
+// in a fixed shuffle tree, the four waves' sums are added in wave order)
+__global__ __launch_bounds__(256) void gwin_reduce_heavy_kernel(const uint32_t *__restrict__ heavy,
+                                                              const uint32_t *__restrict__ tslot_ptr,
+                                                              const uint32_t *__restrict__ tslot,
+                                                              const float *__restrict__ gwin, int K, float *__restrict__ g,
+                                                              const uint32_t *__restrict__ gmap)
 {
+    __shared__ float part[4];
     const uint32_t j = heavy[blockIdx.x];
+    const int k = (int)blockIdx.y;
     const uint32_t b = tslot_ptr[j], e1 = tslot_ptr[j + 1];
-    for (int k = 0; k < K; ++k) {
-        float s = 0.0f;
-        for (uint32_t e = b + threadIdx.x; e < e1; e += 64) s += gwin[(size_t)tslot[e] * K + k];
+    float s = 0.0f;
+    for (uint32_t e = b + threadIdx.x; e < e1; e += 256) s += gwin[(size_t)tslot[e] * K + k];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-        if (threadIdx.x == 0) g[(size_t)(gmap ? gmap[j] : j) * K + k] += s;
-    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) g[(size_t)(gmap ? gmap[j] : j) * K + k] += ((part[0] + part[1]) + part[2]) + part[3];
 }
 
 // Stream S (loglik_internal.hpp): fragments with ONE compatible transcript were collapsed at build time into cnt[j] (the
@@ -1821,7 +1826,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     (void)prefetch(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     start_ring(cur);
-    int young = 0;  // vector-memory operations issued after the ring was started (see uniform_stream)
+    int young = 0;  // vector-memory operations issued after the ring was started (see wide_stream)
     lds_barrier();
     int buf = 0;
     for (uint32_t round = 0;; ++round) {
@@ -2197,7 +2202,7 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
                            ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, G, A.lp, gmap);
         if (ll->d_theavy.n > 0)
-            hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n), dim3(64), 0, st, ll->d_theavy.p,
+            hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n, (unsigned)K), dim3(256), 0, st, ll->d_theavy.p,
                                ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g, gmap);
     }
     return POLEE_OK;

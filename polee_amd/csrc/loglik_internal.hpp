@@ -76,10 +76,10 @@ constexpr int PSELL_MAX_K = 8;
 constexpr uint32_t PSELL_OFF_MASK = 0x1fffffffu;  // slice_off entries carry the slice flags in bits 29..31
 constexpr uint32_t PSELL_FLAG_MASKED_BIT = 29;    // bit 29: a MASKED slice (set for every slice of streams A1M / A2M; the cross-check kernel reads it)
 constexpr int PSELL_NARROW_MAX = 16;        // widest transcript set of stream A1 (7 KiB LDS ring, four groups of four transcripts: narrow_stream)
-constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of stream A2 (14 KiB LDS ring, two 16-row MFMA tiles: uniform_stream)
+constexpr int PSELL_WIDE_MAX = 32;          // widest transcript set of streams A2 / A2M (two 16-row MFMA tiles: wide_stream, in two stages through the 7 KiB ring; A2M: 14 KiB rings)
 // Uniform slices store fragment r of transcript row t at this position of the row's 64 values, chosen per stream so that
 // the kernel's LDS operand reads are bank-conflict free: A1 (batched 4 x 4 outer products, narrow_stream) r ^ (t & 3);
-// A2 (16 x 16 x 4 tiles, uniform_stream) a rotation by 4 t.
+// A2 (16 x 16 x 4 tiles, wide_stream) a rotation by 4 t.
 enum : int { PSELL_A1 = 0, PSELL_A1M = 1, PSELL_A2 = 2, PSELL_A2M = 3, PSELL_BN = 4, PSELL_B = 5, PSELL_C = 6, PSELL_S = 7, PSELL_NSTREAMS = 8 };  // streams, in tile order (C and S have no tiles)
 constexpr int PSELL_MIXED_NARROW_MAX = 15;  // longest row of stream BN (its slices pass through the narrow streams' 7 KiB rings)
 constexpr int PSELL_TILE_SLICES_A2M = 16;

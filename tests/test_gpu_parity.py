@@ -791,29 +791,6 @@ def test_row_sharded_fit_with_one_rank_equals_the_plain_fit(P, ctx, lm_fixture, 
     np.testing.assert_allclose(out[0][1][1], out[1][1][1], rtol=1e-6)  # expected log-likelihood trace
 
 
-def test_fit_on_a_partition_of_the_compute_units_equals_the_fit_on_the_whole_gpu(P, ctx, lm_fixture, prep_fixture):
-    """polee_ctx_create_partition: a context whose stream runs on half (a third) of the GPU's compute units -- for fits that share
-    a GPU.  The same noise gives the same fit as on the whole GPU, up to the float32 summation order of the gradient (the
-    persistent launch sizes itself to the partition's compute units, so the tiles are dealt differently)."""
-    f = lm_fixture
-    K, steps = 4, 6
-    z0 = O.randn(steps * K * (f["n"] - 1), 11)
-    ref = None
-    for part in (None, (1, 2), (0, 3)):
-        c = ctx if part is None else P.Context(0, partition=part)
-        s = _gpu_sample(P, c, f)
-        t = P.PolyaTreeTransform(prep_fixture["node_parent_idxs"], prep_fixture["node_js"], ctx=c)
-        got = P.approximate_likelihood(P.LogitSkewNormalPTTApprox(), s, t, num_steps=steps, num_mc_samples=K, z0=z0, gradonly=False)
-        if ref is None:
-            ref = got
-            continue
-        np.testing.assert_allclose(got["lp_mean"], ref["lp_mean"], rtol=1e-6)
-        for key in ("mu", "omega", "alpha"):
-            assert np.isclose(got[key], ref[key], rtol=1e-3, atol=1e-3).mean() > 0.99, (part, key)
-    with pytest.raises(P.PoleeError):
-        P.Context(0, partition=(2, 2))
-
-
 def test_reduce_scatter_all_gather_exchange_with_one_rank():
     """POLEE_COMM_ALGO=rs_ag (comm.cpp): the exchange as ncclReduceScatter + ncclAllGather, in place.  With one rank both are
     the identity; what runs here is the call path -- RCCL symbols bound, in-place offsets, a count the ranks divide and one

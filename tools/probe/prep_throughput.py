@@ -3,7 +3,6 @@
 usage: python tools/probe/prep_throughput.py [jobs] [workers ...]
   POLEE_PREP_TREE=cluster_parallel   the rounds variant of the tree heuristic (polee_hclust_parallel); cluster_device: the same tree
                                      built on the GPU; cluster_auto: on the host when its CPUs are idle, else on the GPU
-  POLEE_PREP_CU_PARTITION=1          (worker threads) every worker on its own part of the GPU's compute units (CU-masked streams)
   POLEE_PREP_PROCESSES=1             worker processes (approximate_likelihood_cohort_processes) instead of threads
                                      (approximate_likelihood_cohort); POLEE_PREP_HOST_THREADS threads per process
 The three distinct samples are generated once and kept as .npy files under /tmp; a worker maps the one it is given
@@ -54,7 +53,7 @@ def main():
         if procs:
             out = P.approximate_likelihood_cohort_processes(approx, loaders, processes=w, host_threads=ht, num_steps=500)
         else:
-            out = P.approximate_likelihood_cohort(approx, loaders, workers=w, num_steps=500, cu_partition=bool(os.environ.get("POLEE_PREP_CU_PARTITION")))
+            out = P.approximate_likelihood_cohort(approx, loaders, workers=w, num_steps=500)
         dt = time.time() - t0
         ok = all(np.isfinite(o["mu"]).all() for o in out)
         print("workers %2d: %d samples in %.1f s = %.2f samples/s (%.2f s per sample), finite %s"
