@@ -672,12 +672,31 @@ __device__ inline void wide_stream(WaveStream &ws, const char *ring, int extras,
 #pragma unroll
             for (int j = 0; j < 4; ++j) av2a[j] = lds_f4(row + c2f(0, j));
         }
-        f32x4 kv[4];
-        if (HAS_KS && !two) {
-            const uint32_t kr = wrap(pos_r + 256u + 256u * (uint32_t)w) + 64u * (uint32_t)q;
+        // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt.  With multiplicities (the slice's last row:
+        // ks of fragments 16 q + 4 v + (0..3) at `kr`) they are read four at a time, so the weights come BEFORE the release.
+        auto weights = [&](uint32_t kr) {
+            if (HAS_KS) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) kv[v] = lds_f4(ring_lds + kr + 16u * (uint32_t)v);
-        }
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 kv = lds_f4(ring_lds + kr + 16u * (uint32_t)v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = d1[e][v];
+                        if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lp2 += ks_log2(kv[e], sv);
+                        d1[e][v] = kv[e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float sv = d1[e][v];
+                        if (WANT_LP) lpl.mul(sv, sv > 2.0f * ROWSUM_FLOOR);
+                        d1[e][v] = __builtin_amdgcn_rcpf(sv);
+                    }
+            }
+        };
         if (two) {
             release(STAGE_A);
             STAMP(6);  // refill
@@ -697,39 +716,22 @@ __device__ inline void wide_stream(WaveStream &ws, const char *ring, int extras,
             const uint32_t row = wrap(pos_r + 256u * (uint32_t)tt);
 #pragma unroll
             for (int j = 0; j < 4; ++j) av2b[j] = lds_f4(row + c2f(1, j));
-            if (HAS_KS) {  // the multiplicities travel with the slice (its last row): ks of fragments 16 q + 4 v + (0..3)
-                const uint32_t kr = wrap(pos_r + 256u * (uint32_t)(w - 16)) + 64u * (uint32_t)q;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) kv[v] = lds_f4(ring_lds + kr + 16u * (uint32_t)v);
-            }
+            if (HAS_KS) weights(wrap(pos_r + 256u * (uint32_t)(w - 16)) + 64u * (uint32_t)q);
             release(bytes - STAGE_A);
+            STAMP(6);  // refill
+            if (!HAS_KS) weights(0u);
+        } else if (HAS_KS) {
+            if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
+            phase1(0);
+            weights(wrap(pos_r + 256u + 256u * (uint32_t)w) + 64u * (uint32_t)q);
+            release(bytes);
             STAMP(6);  // refill
         } else {
             release(bytes);
             STAMP(6);  // refill
             if (!(dbg & 16)) __builtin_amdgcn_s_setprio(0);
             phase1(0);
-        }
-        // weights, in place: d1[e][v] belongs to fragment r = 16 q + 4 v + e, draw tt
-        if (HAS_KS) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sv = d1[e][v];
-                    if (WANT_LP && sv > 2.0f * ROWSUM_FLOOR) lp2 += ks_log2(kv[v][e], sv);
-                    d1[e][v] = kv[v][e] * __builtin_amdgcn_rcpf(sv);  // (padded lanes: ks = 0)
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float sv = d1[e][v];
-                    if (WANT_LP) lpl.mul(sv, sv > 2.0f * ROWSUM_FLOOR);
-                    d1[e][v] = __builtin_amdgcn_rcpf(sv);
-                }
+            weights(0u);
         }
         STAMP(4);  // phase 1 + weights
         if (!(dbg & 2)) {
@@ -1687,7 +1689,7 @@ __global__ void single_lp_finish_kernel(const double *__restrict__ part, int nbl
 }
 
 // LDS layout of the streaming kernel:
-//   [rings: 4 x 7 KiB (all kinds but A2M) or 2 x 14 KiB (A2M)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64]
+//   [rings: 4 x 7 KiB (all kinds but A2M) or 2 x 14 KiB (A2M)][xw 0][xw 1][gw (x 4 in deterministic mode)][ids 0][ids 1][ent 4 x 64][desc 2 x 64][aux 16]
 constexpr uint32_t STREAM_RB1 = 7168u, STREAM_RB2 = 14336u, STREAM_RINGS = 28672u;
 template <int K>
 constexpr uint32_t stream_ring_total()
@@ -1711,8 +1713,10 @@ constexpr uint32_t stream_lds_bytes()  // (deterministic mode: one gradient wind
 template <int K, bool WANT_LP, bool HAS_KS, bool DET>
 // (The instances that also return lp carry the log accumulators across the slice loops: at four waves per SIMD -- 128
 // registers -- they spill, and a spill's reload drains the LDS-DMA ring (measured: 1.40 ms per pass instead of 0.25).  They run
-// three workgroups per CU, 170 registers, no scratch.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WANT_LP ? 3 : 4, WANT_LP ? 3 : 4)))
+// three workgroups per CU, 170 registers, no scratch.  Round 5: so do the instances with multiplicities (the factored likelihood of
+// salmon's equivalence classes) -- the wide stream's two-stage body holds 32 operand registers across its second stage, and with the
+// ks row on top the 128-register instance spilled 11 registers inside the slice loops.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((WANT_LP || HAS_KS) ? 3 : 4, (WANT_LP || HAS_KS) ? 3 : 4)))
 void loglik_stream_kernel(PsellArgs A, int dbg)
 {
     extern __shared__ float lds[];
@@ -1733,14 +1737,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
     const uint32_t G = gridDim.x;
     // Static schedule: every workgroup walks its own column.  Dynamic schedule: one list, longest tile first; a workgroup
     // owns its next two tiles (the next one's x window, ids and offsets are on their way while the current one streams)
-    // and, while a tile streams, wave 0 draws the position after those from a global counter -- one atomic per tile, its
-    // result read at the tile's end.  Workgroups then finish within one (small, late) tile of each other whatever the
+    // and wave 0 draws the position after those from a global counter -- one atomic per tile, issued when the tile's slices are
+    // done and read at the next tile's start, behind the barriers and the flush.  Workgroups then finish within one (small, late) tile of each other whatever the
     // cost model says: with the static lists the slowest workgroup was 20 - 30 % above the mean (tile times depend on
     // what the neighbours on the CU are doing, not only on the tile).
     const bool dyn = A.dyn_ctr != nullptr;
     const PosDesc *__restrict__ sched = dyn ? A.sched_dyn : A.sched;
     uint32_t p2 = blockIdx.x + 2u * G;  // (wave 0) position of the tile after the next one
-    unsigned int drawn = 0u;
     const uint8_t *__restrict__ xwin_b = reinterpret_cast<const uint8_t *>(A.xwin);
 #ifdef POLEE_STAMPS
     unsigned long long st_acc[NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1841,44 +1844,44 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
             asm volatile("v_and_b32_e32 %0, 7, %1\n\tv_lshlrev_b32_e32 %0, 2, %0" : "=v"(off8) : "v"(wave_lane()));
             dma_256(uniform_ptr(sched + p2), off8, lds_addr(descb + (round & 1u) * 64u));
             ++young;
-            if (dyn) {
-                // (a compiler-visible atomic with a result: the compiler waits for it where `drawn` is read, after this
-                // tile's queue has been drained anyway; until then it is one more young operation for the counted waits)
-                if (wave_lane() == 0) drawn = __hip_atomic_fetch_add(A.dyn_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++young;
-            }
         }
         STAMP(0);  // between tiles: prefetch issue
-        if (kind == 0) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+        // (Round 5 tried WORK STEALING inside the workgroup here -- a wave that had finished its share of the tile's slices stole the
+        // tail half of the longest remaining share with an LDS compare-and-swap, the owners taking every slice with an LDS atomic
+        // add: correct, and 5 - 12 % SLOWER on every input, profiles/r05_work_stealing_ab.txt.  The static shares stay.)
+        {
+            const int extras = young;
+            if (kind == 0) {
+                narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, false>(ws, rings + wave * STREAM_RB1, extras, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
-                                                                             , st_acc, st_last
+                                                                                 , st_acc, st_last
 #endif
-            );
-        } else if (kind == 2) {
-            narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+                );
+            } else if (kind == 2) {
+                narrow_stream<K, STREAM_RB1, WANT_LP, HAS_KS, true>(ws, rings + wave * STREAM_RB1, extras, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
-                                                                             , st_acc, st_last
+                                                                                 , st_acc, st_last
 #endif
-            );
-        } else if (kind == 4) {
-            mixed_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
+                );
+            } else if (kind == 4) {
+                mixed_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, extras, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
 #ifdef POLEE_STAMPS
-                                                         , st_acc, st_last
+                                                             , st_acc, st_last
 #endif
-            );
-        } else if (kind == 3) {
-            wide_masked_stream<K, STREAM_RB2, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
+                );
+            } else if (kind == 3) {
+                wide_masked_stream<K, STREAM_RB2, WANT_LP, HAS_KS>(ws, rings + (wave < 2 ? wave : 0) * STREAM_RB2, extras, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lds_addr(auxz), lp_a, dbg
 #ifdef POLEE_STAMPS
-                                                               , st_acc, st_last
+                                                                   , st_acc, st_last
 #endif
-            );
-        } else {
-            wide_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, young, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
+                );
+            } else {
+                wide_stream<K, STREAM_RB1, WANT_LP, HAS_KS>(ws, rings + wave * STREAM_RB1, extras, xw_of(buf), gw + (DET ? (uint32_t)wave * (XWB / 4u) : 0u), lp_a, dbg
 #ifdef POLEE_STAMPS
-                                                                           , st_acc, st_last
+                                                                               , st_acc, st_last
 #endif
-            );
+                );
+            }
         }
 #ifdef POLEE_STAMPS
         n_slices += (unsigned long long)ws.nsl;
@@ -1887,6 +1890,18 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also: the next tile's prefetch has landed)
         STAMP(7);  // draining the queue after the last slice
         young = 0;
+        unsigned int drawn = 0u;  // (this tile's draw: defined and consumed inside one iteration, or it is carried -- and spilled -- around the loop)
+        if (dyn && wave == 0) {
+            // The draw of the position after the next two (one per tile: the host counts on that, dyn_base).  Issued HERE, with the
+            // queue empty, and read at the next tile's start: its latency passes behind the barriers and the flush, and its result
+            // occupies a register only until then (until round 5 it was issued at the tile's start and its register was live across the
+            // slice loops: same box, C2 patterns 0.238 -> 0.226 ms, literal 0.325 -> 0.316).  Inline assembly: the compiler must not
+            // wait for it (a compiler-visible atomic is waited for with vmcnt(0), which would drain the ring that has just been started).
+            if (wave_lane() == 0) {
+                const unsigned int one = 1u;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(A.dyn_ctr), "v"(one) : "memory");
+            }
+        }
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
         const bool early = more && (kind_of(nxt.tile) == 3) == (kind == 3);  // (all kinds but the wide masked one share a ring geometry)
@@ -1940,7 +1955,17 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
 #endif
         if (!more) break;
         cur = nxt;
-        if (wave == 0) p2 = dyn ? 3u * G + ((uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) - A.dyn_base) : p2 + G;
+        if (wave == 0) {
+            if (dyn) {
+                // younger than the draw: the pieces of the ring that has just been started and this wave's part of the flush
+                wait_vm_outstanding(__builtin_amdgcn_readfirstlane(ws.primed + young));
+                uint32_t ticket;
+                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ticket) : "v"(drawn));
+                p2 = 3u * G + (ticket - A.dyn_base);
+            } else {
+                p2 += G;
+            }
+        }
         {
             const uint32_t *dp = descb + (round & 1u) * 64u;
             nxt.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)dp[0]);
