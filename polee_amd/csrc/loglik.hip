@@ -1893,14 +1893,13 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         unsigned int drawn = 0u;  // (this tile's draw: defined and consumed inside one iteration, or it is carried -- and spilled -- around the loop)
         if (dyn && wave == 0) {
             // The draw of the position after the next two (one per tile: the host counts on that, dyn_base).  Issued HERE, with the
-            // queue empty, and read at the next tile's start: its latency passes behind the barriers and the flush, and its result
-            // occupies a register only until then (until round 5 it was issued at the tile's start and its register was live across the
-            // slice loops: same box, C2 patterns 0.238 -> 0.226 ms, literal 0.325 -> 0.316).  Inline assembly: the compiler must not
-            // wait for it (a compiler-visible atomic is waited for with vmcnt(0), which would drain the ring that has just been started).
-            if (wave_lane() == 0) {
-                const unsigned int one = 1u;
-                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(A.dyn_ctr), "v"(one) : "memory");
-            }
+            // queue empty, and read at the end of this iteration, behind the barriers and the flush: the result occupies a register
+            // only in between (until round 5 it was issued at the tile's start and lived across the slice loops).  A compiler-visible
+            // atomic: the compiler waits for it with vmcnt(0) where it is read -- by then the next ring's first pieces, requested
+            // before the barrier, have had the barrier, the flush and the second barrier to arrive.  (An inline-assembly atomic with a
+            // counted wait was tried first: the compiler, unaware that the register is still in flight, copied it -- wrong tickets,
+            // tiles skipped; caught by the C2-size oracle tests.)
+            if (wave_lane() == 0) drawn = __hip_atomic_fetch_add(A.dyn_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // a wave that is done starts the next tile's ring BEFORE the barrier when that ring is its own LDS (same kind
         // of uniform tile); otherwise the ring area may still be in use by a slower wave
@@ -1957,11 +1956,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         cur = nxt;
         if (wave == 0) {
             if (dyn) {
-                // younger than the draw: the pieces of the ring that has just been started and this wave's part of the flush
-                wait_vm_outstanding(__builtin_amdgcn_readfirstlane(ws.primed + young));
-                uint32_t ticket;
-                asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ticket) : "v"(drawn));
-                p2 = 3u * G + (ticket - A.dyn_base);
+                p2 = 3u * G + ((uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) - A.dyn_base);
             } else {
                 p2 += G;
             }
