@@ -234,6 +234,22 @@ def test_bench_gpus_n_launches_n_ranks(world):
     assert d["host_threads_per_rank"] == max(1, usable_cpus() // world)
 
 
+def test_scale_script_launches_every_rank_count(tmp_path):
+    """tools/scale.sh (one command for the first run on a multi-GPU node) through the same dry-run hook:
+    1, 2 and 8 ranks of the weak and the row-sharded C2 launch, one summary line each, every rank seen."""
+    env = dict(os.environ, POLEE_BENCH_BACKEND="gloo", POLEE_BENCH_DRY="1", OMP_NUM_THREADS="1", RANKS="1 2 8",
+               WORKLOADS="weak rowshard", OUT=str(tmp_path), STEPS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "POLEE_HOST_THREADS"):
+        env.pop(k, None)
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale.sh"), "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = open(os.path.join(str(tmp_path), "summary.txt")).read().strip().splitlines()
+    assert len(lines) == 5, lines  # weak x {1, 2, 8} + row-sharded x {2, 8}
+    for ln in lines:
+        assert "FAILED" not in ln, ln
+    assert "weak      ranks 8: dry run, 8 ranks seen" in lines and "rowshard  ranks 2: dry run, 2 ranks seen" in lines
+
+
 def test_usable_cpus_is_positive_and_within_the_affinity_mask():
     import os
     from polee_amd.cohort import usable_cpus

@@ -11,11 +11,12 @@ ROOT=$(pwd)
 OUT=${OUT:-$ROOT/gpurun_out/scale}; mkdir -p "$OUT"
 NGPU=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 1)
 MAX=${1:-$NGPU}
+WORKLOADS=${WORKLOADS:-"weak rowshard c3 c4"}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 : > "$OUT/summary.txt"
 for N in ${RANKS:-1 2 4 8}; do
   [ "$N" -gt "$MAX" ] && continue
-  for W in weak rowshard c3 c4; do
+  for W in $WORKLOADS; do
     case $W in
       weak) ARGS="--workload c2 --no-by-input --cpu-steps 0" ;;
       rowshard) ARGS="--workload c2 --row-shard --no-by-input --cpu-steps 0" ;;
@@ -28,7 +29,10 @@ for N in ${RANKS:-1 2 4 8}; do
 import json, sys
 try:
     j = json.loads(open(sys.argv[3]).read())
-    print("%-9s ranks %s: %10.1f %s  (%.4f ms/step, scaling %s, comm %s)" % (sys.argv[1], sys.argv[2], j["value"], j["unit"], j["ms_per_step"], j["scaling"], j["config"].get("comm")))
+    if j.get("dry_run"):  # (POLEE_BENCH_DRY=1: the launch path only -- tests/test_multiproc.py)
+        print("%-9s ranks %s: dry run, %d ranks seen" % (sys.argv[1], sys.argv[2], j["ranks_seen"]))
+    else:
+        print("%-9s ranks %s: %10.1f %s  (%.4f ms/step, scaling %s, comm %s)" % (sys.argv[1], sys.argv[2], j["value"], j["unit"], j["ms_per_step"], j["scaling"], j["config"].get("comm")))
 except Exception as e:
     print("%-9s ranks %s: FAILED (%s)" % (sys.argv[1], sys.argv[2], e))
 PY
