@@ -532,6 +532,19 @@ polee_status polee_regression_weights(polee_regression *reg, float *weights);
  * defined by `noise` (host, num_noise values) or, when NULL, by the device RNG with `seed`; no update. */
 polee_status polee_regression_eval(polee_regression *reg, const float *noise_or_null, uint64_t seed, float *loss,
                                    float *grad_or_null);
+/* classify (models/polee_regression.py:342-413): the design matrix of the (testing) samples is a latent variable -- a relaxed one-hot
+ * row per sample whose logits are the only new trainable quantity -- while everything the fitted model shares stays fixed.  The
+ * host side (polee_amd/regression.py, RNASeqLinearRegression.classify; the Julia caller models/classify.jl does the same through
+ * PyCall) draws the relaxed rows and owns the logits; the device model over the testing samples provides:
+ *   _set_design     the step's design matrix, f32 [S][F] (replaces the one given at creation; from then on every evaluation also
+ *                   computes d loss / d design -- the observation model's term, -sum_j a[s][j] w_eff[f][j]);
+ *   _set_trainable  Adam of polee_regression_fit moves the flat parameters [begin, end) only (the testing samples' qx_loc /
+ *                   qx_softplus_scale blocks; begin == end with point estimates); default: all of them;
+ *   _design_grad    d loss / d design of the last evaluation or fit step, f32 [S][F].
+ * Transcript-level model on one GPU (the gene-level classify, :601-651, is not built). */
+polee_status polee_regression_set_design(polee_regression *reg, const float *design);
+polee_status polee_regression_set_trainable(polee_regression *reg, int64_t begin, int64_t end);
+polee_status polee_regression_design_grad(polee_regression *reg, float *grad);
 /* niter steps of fit() (models/polee_regression.py:303-340): draw, loss + gradient, Adam(2e-3, 0.9, 0.999, 1e-7).
  * noise (optional, tests): host [niter][num_noise].  loss_trace (optional): f32 [niter]. */
 polee_status polee_regression_fit(polee_regression *reg, int32_t niter, uint64_t seed, const float *noise_or_null,

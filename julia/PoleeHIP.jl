@@ -841,6 +841,23 @@ end
 function set_normal_likelihood!(r::Regression, loc::Vector{Float32}, scale::Vector{Float32})
     GC.@preserve loc scale check(ccall((:polee_regression_set_normal_likelihood, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), r.h, loc, scale), r.ctx.h)
 end
+# classify (models/polee_regression.py:342-413), the device part: the relaxed design rows of one step go in with set_design!, fit
+# (one step) moves only the flat parameters [first, last] (1-based, inclusive; an empty range freezes them all), and
+# design_gradient returns d loss / d design of the last evaluation.  The relaxed one-hot rows, their density and the logits' Adam are
+# host arithmetic on S x F numbers (polee_amd/regression.py classify is the worked example).
+function set_design!(r::Regression, design::Matrix{Float32})
+    d = permutedims(design)  # C order [S][F]
+    GC.@preserve d check(ccall((:polee_regression_set_design, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, d), r.ctx.h)
+end
+function set_trainable!(r::Regression, first::Integer, last::Integer)
+    check(ccall((:polee_regression_set_trainable, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), r.h, Int64(first - 1), Int64(last)), r.ctx.h)
+end
+function design_gradient(r::Regression, S::Integer, F::Integer)
+    g = Matrix{Float32}(undef, F, S)
+    GC.@preserve g check(ccall((:polee_regression_design_grad, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.h, g), r.ctx.h)
+    return permutedims(g)
+end
+
 "the kernel-regression weights of the mean-variance prior, Float32 [degree*n] (models/polee_regression.py:436-460)"
 function regression_weights(r::Regression, degree::Integer=15)
     w = Vector{Float32}(undef, degree * r.n)

@@ -725,8 +725,8 @@ __global__ void reg_adam_kernel(int64_t count, float *p, const float *g, float *
                                 const float *loss, float *trace, uint32_t *tick)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && trace) trace[tick[1]++] = loss[0];  // (also when nothing is trainable: count may be 0)
     if (i >= count) return;
-    if (i == 0 && trace) trace[tick[1]++] = loss[0];
     const float lr_t = lr_dev[0];
     const float gi = g[i];
     const float mi = 0.9f * m[i] + 0.1f * gi;
@@ -734,6 +734,48 @@ __global__ void reg_adam_kernel(int64_t count, float *p, const float *g, float *
     m[i] = mi;
     vv[i] = vi;
     p[i] -= lr_t * mi / (sqrtf(vi) + 1e-7f);
+}
+
+// ---- classify (models/polee_regression.py:342-413): the design matrix of the testing samples is a latent variable, so the loss needs
+// its gradient with respect to F[s][f].  F enters through the observation model only, x[s][j] ~ Normal(sum_f F[s][f] w_eff[f][j] + bias[j]
+// - scale[s], x_scale[j]):  d(-log p)/dF[s][f] = -sum_j a[s][j] w_eff[f][j]  with a = (x - mu) / x_scale^2 -- the quantities of
+// reg_data_kernel, recomputed here for the same draw (a kernel of its own: the hot data kernel stays as it is).  dF: [REG_SLOTS][S][F],
+// block b adds into copy b % REG_SLOTS; the reader sums the copies.
+__global__ __launch_bounds__(REG_BLOCK) void reg_design_grad_kernel(RegView v, const float *__restrict__ p, const float *__restrict__ eps,
+                                                                   const float *__restrict__ design, const float *__restrict__ W,
+                                                                   const float *__restrict__ ss, const float *__restrict__ x,
+                                                                   float *__restrict__ dF)
+{
+    __shared__ float s_weff[REG_MAXF][REG_BLOCK];
+    const int tid = threadIdx.x;
+    const int64_t jj = (int64_t)blockIdx.x * REG_BLOCK + tid;
+    const bool live = jj < v.n;
+    const int64_t j = live ? jj : v.n - 1;
+    const int F = v.F, deg = v.deg, n = v.n;
+    const int64_t Fn = v.Fn();
+    for (int f = 0; f < F; ++f) {
+        const int64_t idx = (int64_t)f * n + j;
+        const float w = p[v.o_cols() + 8 * Fn + idx] + softplusf(p[v.o_cols() + 9 * Fn + idx]) * eps[v.e_cols() + 4 * Fn + idx];
+        float wd = 0.0f;
+        if (v.use_distortion)
+            for (int d = 0; d < deg; ++d) wd += p[v.o_dist() + f * deg + d] * W[(int64_t)d * n + j];
+        s_weff[f][tid] = w + wd;
+    }
+    const float b = p[v.o_bias_loc() + j] + softplusf(p[v.o_bias_s() + j]) * eps[v.e_bias() + j];
+    const float xsz = softplusf(p[v.o_xs_loc() + j] + softplusf(p[v.o_xs_s() + j]) * eps[v.e_xs() + j]);
+    const float inv = frcp(xsz), inv2 = inv * inv;
+    float *out = dF + (int64_t)(blockIdx.x % REG_SLOTS) * v.S * F;
+    for (int s = 0; s < v.S; ++s) {
+        float xl = b;
+        for (int f = 0; f < F; ++f) xl += design[s * F + f] * s_weff[f][tid];
+        const int64_t sj = (int64_t)s * n + j;
+        const float xv = v.point ? p[v.o_qx_loc() + sj] : x[sj];
+        const float a = live ? (xv - (xl - ss[s])) * inv2 : 0.0f;
+        for (int f = 0; f < F; ++f) {
+            const float t = wave_sum(-a * s_weff[f][tid]);
+            if ((tid & 63) == 0) atomicAdd(out + s * F + f, t);
+        }
+    }
 }
 
 }  // namespace polee
@@ -792,6 +834,11 @@ struct polee_regression {
     int64_t num_iso_stats() const { return (int64_t)(vi.F + 2) * vi.n + REG_SLOTS; }
     polee_comm *comm = nullptr;  // samples sharded over ranks: one all-reduce of d_stats per step
     int64_t num_stats() const { return (int64_t)(v.F + 2) * v.n + REG_SLOTS; }
+    // classify (models/polee_regression.py:342-413): the design matrix is replaced per step (polee_regression_set_design), every
+    // evaluation also leaves d loss / d design in d_dF, and Adam only moves the flat parameters [train_lo, train_hi)
+    bool want_dgrad = false;
+    DevBuf<float> d_dF;  // [REG_SLOTS][S][F]
+    int64_t train_lo = 0, train_hi = -1;  // (-1: all of them)
 };
 
 namespace {
@@ -904,6 +951,13 @@ polee_status reg_prior_pass(polee_regression *r)
 polee_status reg_eval_device(polee_regression *r)
 {
     POLEE_TRY(reg_data_pass(r));
+    if (r->want_dgrad) {
+        const RegView &v = r->v;
+        POLEE_HIP_TRY(r->ctx, hipMemsetAsync(r->d_dF.p, 0, sizeof(float) * (size_t)REG_SLOTS * v.S * v.F, r->ctx->stream));
+        hipLaunchKernelGGL(reg_design_grad_kernel, dim3((unsigned)ceil_div(v.n, REG_BLOCK)), dim3(REG_BLOCK), 0, r->ctx->stream, v,
+                           r->d_p.p, r->d_eps.p, r->d_design.p, r->d_W.p, r->d_ss.p, r->d_x.p, r->d_dF.p);
+        POLEE_KERNEL_CHECK(r->ctx);
+    }
     if (r->comm && r->comm->nranks > 1)
         POLEE_TRY(comm_allreduce_device(r->comm, r->d_stats.p, (size_t)r->num_stats(), false));
     return reg_prior_pass(r);
@@ -942,9 +996,10 @@ polee_status reg_enqueue_step(polee_regression *r, const float *noise, bool want
     hipLaunchKernelGGL(reg_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, r->d_tick.p, r->d_lr.p, r->lr);
     POLEE_TRY(reg_fill_noise(r, noise, 0, 0, true));
     POLEE_TRY(reg_eval_device(r));
-    hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, P, r->d_p.p,
-                       r->d_g.p, r->d_m.p, r->d_v.p, r->d_lr.p, r->d_loss.p, want_trace ? r->d_trace.p : nullptr,
-                       r->d_tick.p);
+    const int64_t lo = r->train_hi < 0 ? 0 : r->train_lo, cnt = r->train_hi < 0 ? P : r->train_hi - r->train_lo;
+    hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)std::max<int64_t>(ceil_div(cnt, 256), 1)), dim3(256), 0, ctx->stream, cnt,
+                       r->d_p.p + lo, r->d_g.p + lo, r->d_m.p + lo, r->d_v.p + lo, r->d_lr.p, r->d_loss.p,
+                       want_trace ? r->d_trace.p : nullptr, r->d_tick.p);
     if (r->gene_ap)
         hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)ceil_div(r->num_iso_params(), 256)), dim3(256), 0, ctx->stream,
                            r->num_iso_params(), r->d_ip.p, r->d_ig.p, r->d_im.p, r->d_iv.p, r->d_lr.p, r->d_loss.p,
@@ -1358,6 +1413,49 @@ polee_status polee_debug_regression_prior_pass(polee_regression *r, const float 
     POLEE_TRY(reg_prior_pass(r));
     POLEE_TRY(r->d_loss.download(r->ctx, loss, 1));
     if (grad) POLEE_TRY(r->d_g.download(r->ctx, grad, (size_t)r->v.num_params()));
+    return POLEE_OK;
+}
+
+// ---- classify (models/polee_regression.py:342-413) ---------------------------------------------------------------------------------
+polee_status polee_regression_set_design(polee_regression *r, const float *design)
+{
+    if (!r || !design) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (r->gene_ap || r->v.fixed_ab > 0.0f || (r->comm && r->comm->nranks > 1))
+        return fail(ctx, POLEE_ERR_UNSUPPORTED, "polee_regression_set_design: the transcript-level model on one GPU only");
+    if (!r->want_dgrad) {
+        POLEE_TRY(r->d_dF.alloc(ctx, (size_t)REG_SLOTS * r->v.S * r->v.F));
+        r->want_dgrad = true;
+        r->drop_graph();  // (the captured step gains a kernel)
+    }
+    return r->d_design.upload(ctx, design, (size_t)r->v.S * r->v.F);  // (same buffer: a captured step reads the new values)
+}
+
+polee_status polee_regression_set_trainable(polee_regression *r, int64_t begin, int64_t end)
+{
+    if (!r) return fail(nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    if (begin < 0 || end < begin || end > r->v.num_params()) return fail(r->ctx, POLEE_ERR_BAD_ARG, "polee_regression_set_trainable: [%lld, %lld) of %lld parameters", (long long)begin, (long long)end, (long long)r->v.num_params());
+    r->train_lo = begin;
+    r->train_hi = end;
+    r->drop_graph();
+    return POLEE_OK;
+}
+
+polee_status polee_regression_design_grad(polee_regression *r, float *grad)
+{
+    if (!r || !grad) return fail(r ? r->ctx : nullptr, POLEE_ERR_BAD_ARG, "null argument");
+    polee_ctx *ctx = r->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (!r->want_dgrad) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_regression_design_grad: call polee_regression_set_design first");
+    const size_t SF = (size_t)r->v.S * r->v.F;
+    std::vector<float> h(SF * REG_SLOTS);
+    POLEE_TRY(r->d_dF.download(ctx, h.data(), h.size()));
+    for (size_t i = 0; i < SF; ++i) {
+        double acc = 0.0;
+        for (int c = 0; c < REG_SLOTS; ++c) acc += (double)h[(size_t)c * SF + i];
+        grad[i] = (float)acc;
+    }
     return POLEE_OK;
 }
 

@@ -30,6 +30,26 @@ PARAM_TABLE = [
 ]
 
 
+def _softmax(a):
+    e = np.exp(a - a.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def relaxed_onehot_terms(logits, y, T):
+    """RelaxedOneHotCategorical(temperature T, logits) at y on the simplex (Maddison et al. 2017, eq. 10; TFP builds it as
+    Exp(ExpRelaxedOneHotCategorical)):  log q(y) = lgamma(K) + (K - 1) log T + sum_k (logits_k - (T + 1) log y_k)
+    - K logsumexp_k(logits_k - T log y_k).  Returns (log q [S], d log q / d logits at fixed y [S, K], d log q / d y [S, K])."""
+    logits, y = np.asarray(logits, np.float64), np.asarray(y, np.float64)
+    K = logits.shape[1]
+    ly = np.log(y)
+    u = logits - T * ly
+    mx = u.max(axis=1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(u - mx).sum(axis=1))
+    sm = np.exp(u - lse[:, None])
+    lq = math.lgamma(K) + (K - 1) * math.log(T) + (logits - (T + 1.0) * ly).sum(axis=1) - K * lse
+    return lq, 1.0 - K * sm, (-(T + 1.0) + K * T * sm) / y
+
+
 def _softplus(x):
     return np.logaddexp(0.0, x).astype(np.float32)
 
@@ -67,6 +87,12 @@ class RNASeqLinearRegression:
             raise ValueError("x_scale_hinges must hold kernel_regression_degree values")
         self.use_point_estimates = bool(use_point_estimates)
         self.likelihood_model = likelihood_model
+        # (kept for classify(): the testing model is created with the training model's settings)
+        self._ctor = dict(x_bias_loc0=float(x_bias_loc0), x_bias_scale0=float(x_bias_scale0), use_distortion=bool(use_distortion),
+                          scale_penalty=float(scale_penalty), kernel_regression_bandwidth=float(kernel_regression_bandwidth),
+                          x_scale_hinges=None if hg is None else hg.copy(),
+                          x_init_mean=(x0.astype(np.float64).mean(axis=0) if x_init_mean is None
+                                       else np.asarray(x_init_mean, np.float64).reshape(-1)))
         if (not self.use_point_estimates and likelihood_model is None and normal_likelihood is None
                 and gene_likelihood is None):
             raise ValueError("a likelihood model is needed unless use_point_estimates")
@@ -216,6 +242,87 @@ class RNASeqLinearRegression:
               self.ctx._h)
         return float(loss[0]), g
 
+    # ---- classify (models/polee_regression.py:342-413)
+    def set_design(self, F):
+        Fm = arr(np.atleast_2d(F), np.float32)
+        if Fm.shape != (self.num_samples, self.num_factors):
+            raise ValueError("the design matrix must be [S, F]")
+        check(L.lib().polee_regression_set_design(self._h, ptr(Fm, f32p)), self.ctx._h)
+        self.design = Fm
+
+    def design_gradient(self):
+        """d loss / d design [S, F] of the last evaluation or fit step (after set_design)."""
+        g = np.empty((self.num_samples, self.num_factors), np.float32)
+        check(L.lib().polee_regression_design_grad(self._h, ptr(g, f32p)), self.ctx._h)
+        return g
+
+    def _shared_size(self):
+        """flat parameters in front of qx_loc: everything the samples share (the layout of include/polee_hip.h)"""
+        F, n, d = self.num_factors, self.num_features, self.kernel_regression_degree
+        return 4 + F * d + 2 * d + 10 * F * n + 4 * n
+
+    def classify(self, x_init, likelihood_model, surrogate_likelihood_model, sample_scales, use_point_estimates, niter,
+                 extra_training_vars=(), seed=123456789, return_trace=False):
+        """classify (models/polee_regression.py:342-413): class probabilities [S_test, F] of testing samples under the FITTED model.
+        Their design matrix is latent -- F ~ OneHotCategorical(uniform) per sample, surrogate RelaxedOneHotCategorical(T, logits)
+        with the temperature annealed from 5 to 0.5 over the run (:385-391) -- everything the fitted model shares keeps its
+        surrogate, and the trainable variables are the logits (+ the testing samples' qx_loc / qx_softplus_scale unless
+        use_point_estimates), Adam at 1e-3 (:400).  `likelihood_model`: the testing samples' RNASeqApproxLikelihood (None with point
+        estimates); `surrogate_likelihood_model` is part of the reference's signature only.  Per step the device model over the testing
+        samples draws every latent but F, evaluates the loss and the gradients (polee_regression_fit, one step) and returns d loss / d F;
+        the relaxed rows, their density and the logits' Adam are a few dozen numbers per step and stay on the host.
+        Returns softmax(logits) (:407), with return_trace also the loss trace."""
+        if extra_training_vars or isinstance(self, (RNASeqGeneLinearRegression, RNASeqGeneIsoformLinearRegression, RNASeqJointLinearRegression,
+                                                    RNASeqNormalTranscriptLinearRegression)):
+            raise NotImplementedError("classify is built for the transcript-level model (the one models/imputation.jl uses)")
+        x0 = arr(np.atleast_2d(x_init), np.float32)
+        S, K, n = x0.shape[0], self.num_factors, self.num_features
+        c = self._ctor
+        test = RNASeqLinearRegression(
+            np.full((S, K), 1.0 / K, np.float32), x0, None if use_point_estimates else likelihood_model, c["x_bias_loc0"],
+            c["x_bias_scale0"], c["x_scale_hinges"] if c["x_scale_hinges"] is not None else self._default_hinges(),
+            sample_scales, c["use_distortion"], c["scale_penalty"], use_point_estimates, self.kernel_regression_degree,
+            c["kernel_regression_bandwidth"], ctx=self.ctx, x_init_mean=c["x_init_mean"])
+        ns = self._shared_size()
+        flat = np.concatenate([self.get_flat_params()[:ns], x0.reshape(-1), np.full(S * n, -1.0, np.float32)]).astype(np.float32)
+        test.set_flat_params(flat)
+        lib = L.lib()
+        check(lib.polee_regression_set_learning_rate(test._h, C.c_float(1e-3)), self.ctx._h)
+        check(lib.polee_regression_set_trainable(test._h, C.c_int64(ns if not use_point_estimates else test.num_params),
+                                                 C.c_int64(test.num_params)), self.ctx._h)
+        rng = np.random.default_rng(seed)
+        logits = np.zeros((S, K))
+        m, v = np.zeros_like(logits), np.zeros_like(logits)
+        trace = np.empty(int(niter), np.float64)
+        for step in range(1, int(niter) + 1):
+            T = 5.0 if step == 1 else 5.0 * 0.1 ** (step / float(niter))  # (trace_fn :385-391 anneals AFTER a step)
+            gum = -np.log(-np.log(rng.uniform(1e-12, 1.0, size=(S, K))))
+            y = _softmax((logits + gum) / T)
+            test.set_design(y)
+            dev_loss = test._fit_steps(1, seed + step)[0]
+            lq, dl_direct, dl_dy = relaxed_onehot_terms(logits, y, T)
+            dy = dl_dy + test.design_gradient().astype(np.float64)
+            grad = dl_direct + (y * (dy - (y * dy).sum(axis=1, keepdims=True))) / T  # through y = softmax((logits + g) / T)
+            trace[step - 1] = float(dev_loss) + lq.sum() + S * math.log(K)  # - log p(F) = log K per sample (uniform prior, :349-351)
+            m = 0.9 * m + 0.1 * grad
+            v = 0.999 * v + 0.001 * grad * grad
+            lr_t = 1e-3 * math.sqrt(1.0 - 0.999 ** step) / (1.0 - 0.9 ** step)
+            logits -= lr_t * m / (np.sqrt(v) + 1e-7)
+        probs = _softmax(logits)
+        return (probs, trace) if return_trace else probs
+
+    def _fit_steps(self, niter, seed):
+        """polee_regression_fit without the download of every variable that fit() returns: the loss trace only"""
+        trace = np.empty(int(niter), np.float32)
+        check(L.lib().polee_regression_fit(self._h, int(niter), C.c_uint64(seed), None, ptr(trace, f32p)), self.ctx._h)
+        return trace
+
+    def _default_hinges(self):
+        """choose_knots (src/polee.py:69-76) over the training samples' column means, as polee_regression_create derives them"""
+        mean, d = self._ctor["x_init_mean"], self.kernel_regression_degree
+        lo, hi = float(mean.min()), float(mean.max())
+        return np.array([lo + (k + 1) * (hi - lo) / (d + 1) for k in range(d)], np.float32)
+
     def fit(self, niter, seed=123456789, noise=None, return_trace=False):
         """fit (models/polee_regression.py:303-340): returns (qx_loc, qw_loc, qw_scale, qx_bias_loc, qx_scale)."""
         z = None if noise is None else arr(noise, np.float32).reshape(-1)
@@ -245,6 +352,15 @@ class RNASeqTranscriptLinearRegression(RNASeqLinearRegression):
         super().__init__(F_arr, x_init, lik, math.log(1.0 / num_features), 12.0, x_scale_hinges, sample_scales,
                          use_distortion, scale_penalty, use_point_estimates, kernel_regression_degree,
                          kernel_regression_bandwidth, ctx=ctx, comm=comm, x_init_mean=x_init_mean)
+
+
+    def classify(self, vars, x_init, sample_scales, use_point_estimates, niter, seed=123456789, return_trace=False):
+        """classify (models/polee_regression.py:462-483, as models/imputation.jl:208-213 calls it): `vars` are the TESTING samples'
+        likelihood variables (or their RNASeqApproxLikelihood); unused with point estimates."""
+        lik = None
+        if not use_point_estimates:
+            lik = vars if isinstance(vars, RNASeqApproxLikelihood) else RNASeqApproxLikelihood(vars, ctx=self.ctx)
+        return super().classify(x_init, lik, None, sample_scales, use_point_estimates, niter, seed=seed, return_trace=return_trace)
 
 
 class RNASeqGeneLinearRegression(RNASeqLinearRegression):

@@ -195,6 +195,81 @@ def test_fit_recovers_planted_effect(P, ctx):
     assert np.median(np.abs(w1[planted])) > 5 * np.median(np.abs(w1[others]))
 
 
+def test_design_gradient_matches_finite_differences_of_the_loss(P, ctx):
+    """classify (models/polee_regression.py:342-413) needs d loss / d design: polee_regression_design_grad against central
+    differences of the device's own loss over the design entries, same noise (float32 loss: a step of 1e-2 on entries of
+    size 0.3..0.7, tolerance 2 % of the gradient's scale), with and without point estimates and distortion."""
+    rng = np.random.default_rng(41)
+    S, F, n = 4, 3, 300
+    vars_, _, x_init = _problem(rng, S, F, n)
+    ss = P.estimate_sample_scales(x_init)
+    for point, dist in ((False, True), (True, False)):
+        design = P.regression._softmax(rng.normal(size=(S, F))).astype(np.float32)
+        reg = P.RNASeqTranscriptLinearRegression(vars_, x_init, design, ss, dist, 1.0, point, ctx=ctx, kernel_regression_degree=5)
+        p0 = reg.get_flat_params()
+        p0 += rng.normal(0, 0.05, size=p0.size).astype(np.float32)  # (away from the initial values)
+        reg.set_flat_params(p0)
+        noise = rng.normal(size=reg.num_noise).astype(np.float32)
+        reg.set_design(design)
+        reg.loss_and_gradients(noise)
+        g = reg.design_gradient().astype(np.float64)
+        fd = np.zeros_like(g)
+        h = 1e-2
+        for s_ in range(S):
+            for f in range(F):
+                d = design.astype(np.float64).copy()
+                d[s_, f] += h
+                reg.set_design(d)
+                lp = reg.loss_and_gradients(noise)[0]
+                d[s_, f] -= 2 * h
+                reg.set_design(d)
+                lm = reg.loss_and_gradients(noise)[0]
+                fd[s_, f] = (lp - lm) / (2 * h)
+        np.testing.assert_allclose(g, fd, rtol=0.02, atol=0.02 * np.abs(fd).max())
+
+
+def test_classify_recovers_the_classes_of_held_out_samples(P, ctx):
+    """classify (models/polee_regression.py:342-413) end to end: a model fitted on eight samples of two classes (one-hot design,
+    a planted effect in 30 of 400 transcripts), then four held-out samples whose classes are unknown: the returned class
+    probabilities put every sample in its class, with point estimates and with the approximate likelihood."""
+    rng = np.random.default_rng(35)
+    S, St, F, n = 8, 4, 2, 400
+    tree = random_tree(n, rng)
+    li, ri, fi = O.make_inverse_ptt_params(*tree)
+    to = O.PTT(*tree)
+    base = rng.normal(0, 1.0, size=n)
+    effect = np.zeros(n)
+    planted = rng.choice(n, 30, replace=False)
+    effect[planted] = rng.choice([-3.0, 3.0], size=30)
+    cls = np.array([0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 1, 0])
+    mus, xs = [], []
+    for s_ in range(S + St):
+        logx = base + cls[s_] * effect + rng.normal(0, 0.05, size=n)
+        x = np.exp(logx - logx.max())
+        x /= x.sum()
+        y = np.clip(to.inverse_transform(x.astype(np.float32))[0], 1e-6, 1 - 1e-6)
+        mus.append(np.log(y) - np.log1p(-y))
+        xs.append(np.log(x))
+    mu, x_all = np.array(mus, np.float32), np.array(xs, np.float32)
+
+    def vars_of(rows):
+        k = len(rows)
+        return dict(efflen=np.full((k, n), 1000.0, np.float32), la_mu=mu[rows], la_sigma=np.full((k, n - 1), 0.05, np.float32),
+                    la_alpha=np.zeros((k, n - 1), np.float32), left_index=li[None], right_index=ri[None], leaf_index=fi[None])
+    train, test = np.arange(S), np.arange(S, S + St)
+    design = np.zeros((S, F), np.float32)
+    design[np.arange(S), cls[:S]] = 1.0
+    ss = P.estimate_sample_scales(x_all)
+    reg = P.RNASeqTranscriptLinearRegression(vars_of(train), x_all[train], design, ss[train], True, 1.0, False, ctx=ctx)
+    reg.fit(2500, seed=5)
+    for point in (True, False):
+        probs, trace = reg.classify(vars_of(test), x_all[test], ss[test], point, 1500, seed=9, return_trace=True)
+        assert probs.shape == (St, F) and np.all(np.isfinite(trace))
+        np.testing.assert_allclose(probs.sum(axis=1), 1.0, rtol=1e-6)
+        assert np.array_equal(probs.argmax(axis=1), cls[test]), probs
+        assert probs[np.arange(St), cls[test]].min() > 0.8, probs
+
+
 def test_regression_argument_errors(P, ctx):
     rng = np.random.default_rng(34)
     vars_, design, x_init = _problem(rng, 2, 2, 20)

@@ -112,3 +112,41 @@ def test_density_restatements_agree_with_an_independent_library():
     h = 1e-5
     num = (stats.norm.cdf(inv(xs + h), loc, scale) - stats.norm.cdf(inv(xs - h), loc, scale)) / (2 * h)
     np.testing.assert_allclose(lq, np.log(num), rtol=1e-5, atol=1e-6)
+
+
+def test_relaxed_onehot_density_and_its_derivatives():
+    """classify's surrogate for the latent design rows (models/polee_regression.py:372-376): RelaxedOneHotCategorical(T, logits).
+    The restated density (Maddison et al. 2017, eq. 10) integrates to 1 over the simplex (K = 2: a one-dimensional quadrature),
+    agrees with the density of y = softmax((logits + Gumbel) / T) found by a histogram of draws, and its two derivatives
+    (at fixed y w.r.t. the logits; w.r.t. y) match central differences."""
+    rng = np.random.default_rng(2)
+    for T in (5.0, 0.7):
+        logits = np.array([[0.3, -0.8]])
+        t = np.linspace(1e-6, 1 - 1e-6, 400001)
+        y = np.stack([t, 1 - t], axis=1)
+        lq = R.relaxed_onehot_terms(np.repeat(logits, len(t), 0), y, T)[0]
+        assert abs(np.trapz(np.exp(lq), t) - 1.0) < 2e-3
+        g = -np.log(-np.log(rng.uniform(size=(400000, 2))))
+        draws = R._softmax((logits + g) / T)[:, 0]
+        hist, edges = np.histogram(draws, bins=40, range=(0, 1), density=True)
+        mid = 0.5 * (edges[1:] + edges[:-1])
+        want = np.exp(R.relaxed_onehot_terms(np.repeat(logits, 40, 0), np.stack([mid, 1 - mid], 1), T)[0])
+        inner = np.zeros(40, bool)
+        inner[3:37] = True
+        inner &= want > 0.2  # (bins with at least ~2 000 of the 400 000 draws)
+        assert inner.sum() >= 10
+        np.testing.assert_allclose(hist[inner], want[inner], rtol=0.08)
+    K, S = 4, 3
+    logits = rng.normal(size=(S, K))
+    y = R._softmax(rng.normal(size=(S, K)))
+    T = 1.7
+    lq, d_logits, d_y = R.relaxed_onehot_terms(logits, y, T)
+    h = 1e-6
+    for s_ in range(S):
+        for k in range(K):
+            e = np.zeros((S, K))
+            e[s_, k] = h
+            fd = (R.relaxed_onehot_terms(logits + e, y, T)[0][s_] - R.relaxed_onehot_terms(logits - e, y, T)[0][s_]) / (2 * h)
+            assert abs(fd - d_logits[s_, k]) < 1e-6 * (1 + abs(fd))
+            fd = (R.relaxed_onehot_terms(logits, y + e, T)[0][s_] - R.relaxed_onehot_terms(logits, y - e, T)[0][s_]) / (2 * h)
+            assert abs(fd - d_y[s_, k]) < 1e-5 * (1 + abs(fd))
