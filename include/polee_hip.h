@@ -635,6 +635,21 @@ polee_status polee_xbuild_sizes(const polee_xbuild *xb, int64_t *rows, int64_t *
 /* copies the result to host arrays (any pointer may be NULL) */
 polee_status polee_xbuild_get(const polee_xbuild *xb, uint64_t *tcolptr, uint32_t *trowval, float *tnzval,
                               float *effective_lengths, int64_t *row_fragment);
+/* X (by columns, 1-based: polee_loglik_create's arguments) uploaded ONCE for the two device builders that read it when a sample is
+ * prepared from host arrays -- the tree (PolyaTreeTransform(X, :cluster), ptt.jl:35-52 -> hclust.jl:180-330) and the layout
+ * (RNASeqSample, likelihood.jl:2-41's X).  polee_loglik_create + polee_hclust_parallel_device each upload their own copy: 2.9 GB over
+ * PCIe at C2 instead of 1.9 GB.  The handle may be used from two contexts of the same device at once (the builders only read it) and
+ * must outlive both calls.  POLEE_ERR_UNSUPPORTED when rows or non-zeros need more than 32 bits (the host paths take those). */
+typedef struct polee_devx polee_devx;
+polee_status polee_devx_upload(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                               const float *nzval, polee_devx **out);
+/* nzval may be NULL in polee_devx_upload and follow here: the tree needs colptr + rowval only and can start while the values are on
+ * their way (what sample_and_tree of the Python mirror does) */
+polee_status polee_devx_upload_values(polee_devx *dx, const float *nzval);
+void polee_devx_destroy(polee_devx *dx);
+/* as polee_loglik_create / polee_hclust_parallel_device on the arrays the handle was made from: the same layout byte for byte, the same tree */
+polee_status polee_loglik_create_from_devx(polee_ctx *ctx, const polee_devx *dx, const int64_t *ks_or_null, polee_loglik **out);
+polee_status polee_hclust_parallel_device_from_devx(polee_ctx *ctx, const polee_devx *dx, int32_t *node_parent_idxs, int32_t *node_js);
 /* The likelihood handle straight from an xbuild result, without X leaving the device: rows_to_device -> layout kernels
  * (as polee_loglik_create_from_xt on polee_xbuild_get's arrays; ks_or_null: host array [rows]).  The xbuild handle stays valid. */
 polee_status polee_loglik_create_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, const int64_t *ks_or_null, polee_loglik **out);

@@ -718,6 +718,40 @@ mutable struct DeviceSampleHandle
 end
 const AnySample = Union{DeviceSample,DeviceSampleHandle}
 
+"X by columns on the device, uploaded once for the tree and the layout (polee_devx_upload): `sample_from_devx`, `hclust_from_devx`"
+mutable struct DeviceX
+    h::Ptr{Cvoid}
+    ctx::Context
+    m::Int
+    n::Int
+    function DeviceX(ctx::Context, m, n, colptr::Union{Vector{UInt32},Vector{UInt64}}, rowval::Vector{UInt32}, nzval::Vector{Float32})
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve colptr rowval nzval check(
+            ccall((:polee_devx_upload, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{UInt32}, Ptr{Float32}, Ref{Ptr{Cvoid}}),
+                  ctx.h, m, n, colptr, sizeof(eltype(colptr)), rowval, isempty(nzval) ? C_NULL : pointer(nzval), r), ctx.h)
+        x = new(r[], ctx, m, n)
+        finalizer(x -> ccall((:polee_devx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), x)
+        return x
+    end
+end
+"the values after the fact (DeviceX(..., nzval) with an empty nzval uploads colptr + rowval only: enough for the tree)"
+upload_values!(x::DeviceX, nzval::Vector{Float32}) =
+    GC.@preserve nzval check(ccall((:polee_devx_upload_values, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), x.h, nzval), x.ctx.h)
+function sample_from_devx(ctx::Context, x::DeviceX; ks::Union{Nothing,Vector{Int64}}=nothing)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ks check(ccall((:polee_loglik_create_from_devx, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+                                ctx.h, x.h, ks === nothing ? C_NULL : ks, r), ctx.h)
+    s = DeviceSampleHandle(r[], ctx, x.m, x.n)
+    finalizer(s -> ccall((:polee_loglik_destroy, LIB), Cvoid, (Ptr{Cvoid},), s.h), s)
+    return s
+end
+function hclust_from_devx(ctx::Context, x::DeviceX)
+    parents, js = Vector{Int32}(undef, 2 * x.n - 1), Vector{Int32}(undef, 2 * x.n - 1)
+    GC.@preserve parents js check(ccall((:polee_hclust_parallel_device_from_devx, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}),
+                                        ctx.h, x.h, parents, js), ctx.h)
+    return parents, js
+end
+
 "mirror of `polee_loglik_info` (include/polee_hip.h): field order and types must stay in step with the header"
 mutable struct LoglikInfo
     m::Int64; n::Int64; nnz::Int64; num_slices::Int64; num_tiles::Int64; padded_nnz::Int64

@@ -87,7 +87,7 @@ def lib():
         L.polee_ptt_n.restype = C.c_int32
         L.polee_ptt_n.argtypes = [C.c_void_p]
         for name in ("polee_ctx_destroy", "polee_ptt_destroy", "polee_loglik_destroy", "polee_vi_destroy",
-                     "polee_approx_destroy", "polee_debug_psell_free", "polee_comm_destroy"):
+                     "polee_approx_destroy", "polee_debug_psell_free", "polee_comm_destroy", "polee_devx_destroy"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
         L.polee_vi_default_opts.restype = None

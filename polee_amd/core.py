@@ -1,5 +1,6 @@
 """Host-side mirror of the reference interface over the C ABI (see package docstring)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -182,12 +183,44 @@ def inv_hsb_grad(y_grad, ladj_grad, y, left_index, right_index=None, leaf_index=
     return bp
 
 
+class DeviceX:
+    """X by columns (1-based CSC, the likelihood-matrix HDF5 arrays) in device memory, uploaded once for the two device builders
+    that read it (polee_devx_upload): `RNASeqSample(..., devx=dx)` and `hclust(..., devx=dx)`.  Read-only: both may run at once,
+    each on its own context of the same device."""
+
+    def __init__(self, m, n, colptr, rowval, nzval, ctx=None):
+        self.ctx = ctx or default_context()
+        self.m, self.n = int(m), int(n)
+        colptr = np.ascontiguousarray(colptr)
+        if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
+            colptr = colptr.astype(np.uint64)
+        rowval = arr(rowval, np.uint32)
+        nzval = None if nzval is None else arr(nzval, np.float32)  # (None: upload_values follows)
+        self._csc = (colptr, rowval)
+        self._h = C.c_void_p()
+        check(L.lib().polee_devx_upload(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n), colptr.ctypes.data_as(C.c_void_p),
+                                        int(colptr.dtype.itemsize), ptr(rowval, u32p), ptr(nzval, f32p), C.byref(self._h)), self.ctx._h)
+
+    def upload_values(self, nzval):
+        """the non-zeros' values after the fact: the tree reads colptr + rowval only and may already be running"""
+        nzval = arr(nzval, np.float32)
+        check(L.lib().polee_devx_upload_values(self._h, ptr(nzval, f32p)), self.ctx._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().polee_devx_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
 class RNASeqSample:
     """The numeric part of RNASeqSample (src/rnaseq_sample.jl:6-23): X (m x n CSC, 1-based
     colptr/rowval exactly as in the likelihood-matrix HDF5, :505-519) + effective_lengths,
     resident on the GPU.  `ks` = row multiplicities for the factored likelihood."""
 
-    def __init__(self, m, n, colptr, rowval, nzval, effective_lengths=None, ks=None, ctx=None, xt=None, _xbuild=None):
+    def __init__(self, m, n, colptr, rowval, nzval, effective_lengths=None, ks=None, ctx=None, xt=None, _xbuild=None, devx=None):
         self.ctx = ctx or default_context()
         self.m, self.n = int(m), int(n)
         self.effective_lengths = None if effective_lengths is None else arr(effective_lengths, np.float32)
@@ -196,6 +229,9 @@ class RNASeqSample:
         ks_a = None if ks is None else arr(ks, np.int64)
         if _xbuild is not None:  # an xbuild result, still on the device (polee_amd.xbuild.build_likelihood_matrix(return_sample=True))
             check(L.lib().polee_loglik_create_from_xbuild(self.ctx._h, _xbuild, ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
+        elif devx is not None:  # X already on the device (DeviceX): no second upload
+            self._csc = devx._csc
+            check(L.lib().polee_loglik_create_from_devx(self.ctx._h, devx._h, ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
         elif xt is not None:
             tp, tr, tv = arr(xt[0], np.uint64), arr(xt[1], np.uint32), arr(xt[2], np.float32)
             check(L.lib().polee_loglik_create_from_xt(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n), ptr(tp, u64p),
@@ -429,13 +465,18 @@ def device_cache_bytes():
     return int(f())
 
 
-def hclust(m, n, colptr, rowval, parallel=False, device=False, ctx=None):
+def hclust(m, n, colptr, rowval, parallel=False, device=False, ctx=None, devx=None):
     """hclust + order_nodes (hclust.jl:193-319, 361-389): the tree heuristic behind PolyaTreeTransform(X, :cluster)
     (ptt.jl:35-52).  X in CSC, 1-based (likelihood-matrix HDF5 arrays) -> (node_parent_idxs, node_js), int32 [2n-1],
     i.e. what the prep HDF5 stores and PolyaTreeTransform(...) takes.  Runs on the host, as in the reference.
     parallel=True: the same joining rule in rounds of mutually-best merges on all host threads (polee_hclust_parallel;
     a documented variant, not the reference's tree node for node).  device=True: that variant on the GPU
-    (polee_hclust_parallel_device: the same arrays as parallel=True)."""
+    (polee_hclust_parallel_device: the same arrays as parallel=True); devx: from a DeviceX instead of the host arrays."""
+    if devx is not None:
+        ctx = ctx or devx.ctx
+        parents, js = np.empty(2 * int(devx.n) - 1, np.int32), np.empty(2 * int(devx.n) - 1, np.int32)
+        check(L.lib().polee_hclust_parallel_device_from_devx(ctx._h, devx._h, ptr(parents, L.i32p), ptr(js, L.i32p)), ctx._h)
+        return parents, js
     colptr = np.ascontiguousarray(colptr)
     if colptr.dtype not in (np.dtype(np.uint32), np.dtype(np.uint64)):
         colptr = colptr.astype(np.uint64)
@@ -662,8 +703,20 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
     tree_ctx = getattr(ctx, "_tree_ctx", None)
     if tree_ctx is None and tm in ("cluster_auto", "cluster_device"):
         tree_ctx = ctx._tree_ctx = Context(ctx.device)
+    # One device copy of X when the tree is built on the device too: 1.9 GB over PCIe at C2 instead of 2.9 GB.
+    # POLEE_SHARED_X=0: each builder uploads its own (A/B).
+    share_x = os.environ.get("POLEE_SHARED_X", "1") != "0" and int(m) < 2 ** 32 - 1
     with ThreadPoolExecutor(max_workers=1) as pool:
         fut = None
+        devx = None
+
+        def shared():
+            try:
+                return DeviceX(m, n, colptr, rowval, None, ctx=ctx) if share_x else None  # (the values follow once the tree job is off)
+            except L.PoleeError as e:  # (more than 32 bits of non-zeros: the host paths)
+                if "32 bits" in str(e):
+                    return None
+                raise
         if tm == "cluster_auto":
             # The rounds variant is the SAME tree from the host (all host threads) and from the GPU: a cohort that is bound by the
             # GPU gives the tree to the host CPUs whenever they are idle -- one host tree at a time -- and to the GPU otherwise.
@@ -671,17 +724,23 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
             # instead of 0.45 s -- or when the slot is shared with other processes, whose fits this one cannot see)
             busy = others > 0 or not isinstance(_host_tree_slot, _threading.Semaphore)
             on_host = busy and _host_tree_slot.acquire(False)  # (non-blocking; positional: threading and multiprocessing name the argument differently)
+            if not on_host:
+                devx = shared()
 
             def tree_job():
                 try:
-                    return hclust(m, n, colptr, rowval, parallel=on_host, device=not on_host, ctx=tree_ctx)
+                    return hclust(m, n, colptr, rowval, parallel=on_host, device=not on_host, ctx=tree_ctx, devx=devx)
                 finally:
                     if on_host:
                         _host_tree_slot.release()
             fut = pool.submit(tree_job)
         elif tm in ("cluster", "cluster_parallel", "cluster_device"):
-            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", tree_ctx or ctx)
-        sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx)
+            if tm == "cluster_device":
+                devx = shared()
+            fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", tree_ctx or ctx, devx)
+        if devx is not None:
+            devx.upload_values(nzval)
+        sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx, devx=devx)
         if fut is not None:
             parents, js = fut.result()
         elif tm == "sequential":

@@ -1083,6 +1083,16 @@ extern "C" polee_status polee_hclust_parallel_device(polee_ctx *ctx, int64_t m, 
                           [&] { return polee::hclust_rounds_device(ctx, m, n, colptr, colptr_bytes, rowval, node_parent_idxs, node_js); });
 }
 
+extern "C" polee_status polee_hclust_parallel_device_from_devx(polee_ctx *ctx, const polee_devx *dx, int32_t *node_parent_idxs, int32_t *node_js)
+{
+    return polee::guarded(ctx, "polee_hclust_parallel_device_from_devx", [&]() -> polee_status {
+        if (!ctx || !dx || !node_parent_idxs || !node_js) return polee::fail(ctx, POLEE_ERR_BAD_ARG, "polee_hclust_parallel_device_from_devx: null argument");
+        if (dx->ctx->device != ctx->device) return polee::fail(ctx, POLEE_ERR_BAD_ARG, "polee_hclust_parallel_device_from_devx: X lives on another device");
+        POLEE_TRY(polee::use_device(ctx));
+        return polee::hclust_rounds_device_core(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, node_parent_idxs, node_js);
+    });
+}
+
 extern "C" polee_status polee_hclust_parallel_device_from_xbuild(polee_ctx *ctx, const polee_xbuild *xb, int32_t *node_parent_idxs, int32_t *node_js)
 {
     return polee::guarded(ctx, "polee_hclust_parallel_device_from_xbuild", [&]() -> polee_status {

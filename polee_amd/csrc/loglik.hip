@@ -150,7 +150,7 @@ struct PsellArgs {
     int tiles_s;              // [tiles_a, tiles_s): BN (mixed narrow); the persistent launch's share ends here
     const float *xwin;      // x window of every tile: xwin[e * K + k] = x[dict[e]][k]
     const PosDesc *sched;   // [rounds + 1][grid] static schedule, POS_NONE-terminated columns
-    // dynamic schedule (the default; the deterministic mode keeps the static one): the tiles in descending order of their
+    // dynamic schedule (the default; the deterministic mode keeps the static one only when lp is wanted): the tiles in descending order of their
     // cost, POS_NONE behind them; workgroup b starts with positions b, b + G, b + 2 G and draws every further position
     // from the counter dyn_ctr[0] (+ 3 G).  The counter is NEVER reset: a launch makes exactly one draw per position of the list
     // (a workgroup draws once per tile it takes), so the next launch's draws start at dyn_base + positions -- the host keeps
@@ -1615,8 +1615,21 @@ __global__ void gwin_reduce_kernel(const uint32_t *__restrict__ tslot_ptr, const
     const int k = (int)(i - j * K);
     const uint32_t b = tslot_ptr[j], e1 = tslot_ptr[j + 1];
     if (e1 - b > GWIN_HEAVY) return;
+    // (four entries' loads in flight at a time; the additions stay in list order)
     float s = 0.0f;
-    for (uint32_t e = b; e < e1; ++e) s += gwin[(size_t)tslot[e] * K + k];
+    uint32_t e = b;
+    for (; e + 4 <= e1; e += 4) {
+        const uint32_t t0 = tslot[e], t1 = tslot[e + 1], t2 = tslot[e + 2], t3 = tslot[e + 3];
+        const float a0 = gwin[(size_t)t0 * K + k], a1 = gwin[(size_t)t1 * K + k], a2 = gwin[(size_t)t2 * K + k], a3 = gwin[(size_t)t3 * K + k];
+        s = (((s + a0) + a1) + a2) + a3;
+    }
+    if (e + 2 <= e1) {
+        const uint32_t t0 = tslot[e], t1 = tslot[e + 1];
+        const float a0 = gwin[(size_t)t0 * K + k], a1 = gwin[(size_t)t1 * K + k];
+        s = (s + a0) + a1;
+        e += 2;
+    }
+    if (e < e1) s += gwin[(size_t)tslot[e] * K + k];
     g[gmap ? (size_t)gmap[j] * K + k : (size_t)i] += s;
 }
 // (round 5: a block of 256 threads per (heavy transcript, draw) -- it was one wave per transcript looping over the draws, 25 us per
@@ -2198,7 +2211,10 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
     POLEE_TRY(ensure_schedule(ll, G));  // (built at creation for the usual grid: no host work here)
     A.sched = ll->d_sched.p;
     static const bool static_sched = getenv("POLEE_STATIC_SCHED") != nullptr;  // (A/B)
-    if (!DET && !static_sched && (size_t)3 * (size_t)G + 8 <= ll->dyn_pad) {
+    // (The deterministic mode draws its tiles too: a tile's gradient goes to the TILE's slot of gwin, in wave order, whichever
+    // workgroup works on it.  Only lp with DET keeps the static lists -- its partial sums are per workgroup.)
+    static const bool det_static = getenv("POLEE_DET_STATIC") != nullptr;  // (A/B)
+    if (!(DET && (LP || det_static)) && !static_sched && (size_t)3 * (size_t)G + 8 <= ll->dyn_pad) {
         A.sched_dyn = ll->d_sched_dyn.p;
         A.dyn_ctr = ll->d_dyn_ctr.p;
         // (the counter runs on from launch to launch, modulo 2^32: this launch's draws are dyn_base, dyn_base + 1, ...)
@@ -2847,6 +2863,92 @@ polee_status polee_loglik_create(polee_ctx *ctx, int64_t m, int64_t n, const voi
                                  const uint32_t *rowval, const float *nzval, const int64_t *ks, polee_loglik **out)
 {
     return guarded(ctx, "polee_loglik_create", [&] { return polee_loglik_create_impl(ctx, m, n, colptr, colptr_bytes, rowval, nzval, ks, out); });
+}
+
+// ---- X on the device, once, for the tree and the layout ------------------------------------------------------
+polee_status polee_devx_upload(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                               const float *nzval, polee_devx **out)
+{
+    return guarded(ctx, "polee_devx_upload", [&]() -> polee_status {
+        POLEE_TRY(use_device(ctx));
+        if (!colptr || !out || m < 0 || n < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_devx_upload: bad argument");
+        std::vector<uint64_t> cp;
+        uint64_t nnz = 0;
+        POLEE_TRY(psell_check_colptr(ctx, n, colptr, colptr_bytes, cp, nnz));
+        if (nnz > 0 && !rowval) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_devx_upload: bad argument");
+        if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1)
+            return fail(ctx, POLEE_ERR_UNSUPPORTED, "polee_devx_upload: the device builders number rows and non-zeros in 32 bits (use polee_loglik_create / polee_hclust_parallel)");
+        polee_devx *dx = new (std::nothrow) polee_devx();
+        if (!dx) return fail(ctx, POLEE_ERR_OOM, "out of host memory");
+        dx->ctx = ctx;
+        dx->m = m;
+        dx->n = n;
+        dx->nnz = nnz;
+        polee_status st = dx->cp.upload(ctx, cp.data(), cp.size());
+        if (st == POLEE_OK && nnz) st = dx->rowval.upload(ctx, rowval, (size_t)nnz);
+        if (st == POLEE_OK && nnz && nzval) st = dx->nzval.upload(ctx, nzval, (size_t)nnz);
+        if (st != POLEE_OK) {
+            delete dx;
+            return st;
+        }
+        ctx_retain(ctx);
+        *out = dx;
+        return POLEE_OK;
+    });
+}
+
+polee_status polee_devx_upload_values(polee_devx *dx, const float *nzval)
+{
+    if (!dx) return fail(nullptr, POLEE_ERR_BAD_ARG, "polee_devx_upload_values: null argument");
+    polee_ctx *ctx = dx->ctx;
+    return guarded(ctx, "polee_devx_upload_values", [&]() -> polee_status {
+        POLEE_TRY(use_device(ctx));
+        if (dx->nnz && !nzval) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_devx_upload_values: null argument");
+        if (dx->nnz) POLEE_TRY(dx->nzval.upload(ctx, nzval, (size_t)dx->nnz));
+        return POLEE_OK;
+    });
+}
+
+void polee_devx_destroy(polee_devx *dx)
+{
+    if (!dx) return;
+    polee_ctx *ctx = dx->ctx;
+    (void)hipSetDevice(ctx->device);
+    dx->cp.release();
+    dx->rowval.release();
+    dx->nzval.release();
+    delete dx;
+    ctx_release(ctx);
+}
+
+polee_status polee_loglik_create_from_devx(polee_ctx *ctx, const polee_devx *dx, const int64_t *ks, polee_loglik **out)
+{
+    return guarded(ctx, "polee_loglik_create_from_devx", [&]() -> polee_status {
+        POLEE_TRY(use_device(ctx));
+        if (!dx || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: null argument");
+        if (dx->ctx->device != ctx->device) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: X lives on another device");
+        if (dx->nnz && !dx->nzval.p) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: the values have not been uploaded (polee_devx_upload_values)");
+        if (!psell_device_enabled())
+            return fail(ctx, POLEE_ERR_UNSUPPORTED, "polee_loglik_create_from_devx: the device builder is switched off (POLEE_DEVICE_BUILD=0 or a host-builder knob)");
+        bool done = false;
+        polee_status st = POLEE_OK;
+        {
+            PsellDevCSR C;
+            if ((st = psell_device_rows_from_dev_csc(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, dx->nzval.p, ks, C, nullptr)) != POLEE_OK) return st;
+            st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+        }
+        if (st != POLEE_OK || done) return st;
+        // the host builder's case (a real share of rows without any structure): through host arrays, as polee_loglik_create would
+        std::vector<uint64_t> h_cp((size_t)dx->n + 1);
+        std::vector<uint32_t> h_row((size_t)dx->nnz);
+        std::vector<float> h_val((size_t)dx->nnz);
+        POLEE_TRY(dx->cp.download(ctx, h_cp.data(), h_cp.size()));
+        if (dx->nnz) {
+            POLEE_TRY(dx->rowval.download(ctx, h_row.data(), h_row.size()));
+            POLEE_TRY(dx->nzval.download(ctx, h_val.data(), h_val.size()));
+        }
+        return polee_loglik_create_impl(ctx, dx->m, dx->n, h_cp.data(), 8, h_row.data(), h_val.data(), ks, out);
+    });
 }
 
 void polee_loglik_destroy(polee_loglik *ll) { loglik_release(ll); }

@@ -181,6 +181,17 @@ polee_status xbuild_device_view(const polee_xbuild *xb, polee_ctx **ctx, int64_t
                                 const uint32_t **trowval, const float **tnzval);
 }  // namespace polee
 
+// X by columns in device memory, uploaded ONCE for the two builders that read it (polee_devx_upload): the tree wants colptr + rowval,
+// the layout all three.  1-based as the caller's arrays are; colptr widened to 64 bits.
+struct polee_devx {
+    polee_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0;
+    uint64_t nnz = 0;
+    polee::DevBuf<uint64_t> cp;
+    polee::DevBuf<uint32_t> rowval;
+    polee::DevBuf<float> nzval;
+};
+
 struct polee_loglik {
     polee_ctx *ctx = nullptr;
     int refs = 1;

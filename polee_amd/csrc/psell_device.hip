@@ -1930,25 +1930,14 @@ polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, con
     return POLEE_OK;
 }
 
-polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
-                                        const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host)
+// X by columns ALREADY on the device (1-based colptr as 64-bit words, 1-based rowval: polee_devx, or this file's own upload) -> rows.
+// own_rowval: this call's private copy, released as soon as the keys are made (peak memory); a shared copy stays.
+polee_status psell_device_rows_from_dev_csc(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_cp, uint64_t nnz, const uint32_t *d_rowval,
+                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval)
 {
     hipStream_t stream = ctx->stream;
-    needs_host = false;
     C.m = m;
     C.n = n;
-    if (colptr_bytes != 4 && colptr_bytes != 8) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr_bytes must be 4 or 8");
-    std::vector<uint64_t> cp((size_t)n + 1);
-    for (int64_t j = 0; j <= n; ++j)
-        cp[(size_t)j] = colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j] : reinterpret_cast<const uint64_t *>(colptr)[j];
-    if (cp[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr[0] must be 1 (1-based)");
-    for (int64_t j = 0; j < n; ++j)
-        if (cp[(size_t)j + 1] < cp[(size_t)j]) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr is not monotone");
-    const uint64_t nnz = cp[(size_t)n] - 1;
-    if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1) {
-        needs_host = true;
-        return POLEE_OK;
-    }
     if (nnz > 0 && m < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: rowval out of range");
     if (ks) {
         POLEE_TRY(C.ks.upload(ctx, ks, (size_t)m));
@@ -1964,19 +1953,14 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
         return POLEE_OK;
     }
     Scratch tmp(ctx);
-    DevBuf<uint64_t> d_cp;
-    DevBuf<uint32_t> d_rowval, key, key_s, idx, idx_s, counts, err;
-    DevBuf<float> d_nzval;
-    POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
-    POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
-    POLEE_TRY(d_nzval.upload(ctx, nzval, (size_t)nnz));
+    DevBuf<uint32_t> key, key_s, idx, idx_s, counts, err;
     POLEE_TRY(key.alloc(ctx, (size_t)nnz));
     POLEE_TRY(idx.alloc(ctx, (size_t)nnz));
     POLEE_TRY(counts.alloc(ctx, (size_t)m + 1));
     POLEE_TRY(err.alloc(ctx, 1));
     PD_HIP(hipMemsetAsync(counts.p, 0, ((size_t)m + 1) * 4, stream));
     PD_HIP(hipMemsetAsync(err.p, 0, 4, stream));
-    hipLaunchKernelGGL(s0_rowkeys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, (uint64_t)m, d_rowval.p, key.p, idx.p, counts.p,
+    hipLaunchKernelGGL(s0_rowkeys_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, (uint64_t)m, d_rowval, key.p, idx.p, counts.p,
                        err.p);
     POLEE_KERNEL_CHECK(ctx);
     uint32_t h_err = 0;
@@ -1984,7 +1968,7 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
     PD_HIP(exclusive_sum(tmp, rocprim::make_transform_iterator(counts.p, ToU64()), C.rowptr.p, (uint64_t)0, (size_t)m + 1, stream));
     PD_HIP(hipStreamSynchronize(stream));
     if (h_err) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: rowval out of range");
-    d_rowval.release();
+    if (own_rowval) own_rowval->release();
     counts.release();
     POLEE_TRY(key_s.alloc(ctx, (size_t)nnz));
     POLEE_TRY(idx_s.alloc(ctx, (size_t)nnz));
@@ -1996,10 +1980,49 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
         PD_HIP(tmp.need(bytes));
         PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, idx.p, idx_s.p, (size_t)nnz, 0, bits, stream));
     }
-    hipLaunchKernelGGL(s0_gather_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, n, d_cp.p, idx_s.p, d_nzval.p, C.col.p, C.val.p);
+    hipLaunchKernelGGL(s0_gather_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, n, d_cp, idx_s.p, d_nzval, C.col.p, C.val.p);
     POLEE_KERNEL_CHECK(ctx);
     PD_HIP(hipStreamSynchronize(stream));
     return POLEE_OK;
+}
+
+// the checks polee_loglik_create makes of a 1-based colptr, widened to 64 bits; nnz out
+polee_status psell_check_colptr(polee_ctx *ctx, int64_t n, const void *colptr, int colptr_bytes, std::vector<uint64_t> &cp, uint64_t &nnz)
+{
+    if (colptr_bytes != 4 && colptr_bytes != 8) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr_bytes must be 4 or 8");
+    cp.resize((size_t)n + 1);
+    for (int64_t j = 0; j <= n; ++j)
+        cp[(size_t)j] = colptr_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(colptr)[j] : reinterpret_cast<const uint64_t *>(colptr)[j];
+    if (cp[0] != 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr[0] must be 1 (1-based)");
+    for (int64_t j = 0; j < n; ++j)
+        if (cp[(size_t)j + 1] < cp[(size_t)j]) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: colptr is not monotone");
+    nnz = cp[(size_t)n] - 1;
+    return POLEE_OK;
+}
+
+polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
+                                        const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host)
+{
+    needs_host = false;
+    C.m = m;
+    C.n = n;
+    std::vector<uint64_t> cp;
+    uint64_t nnz = 0;
+    POLEE_TRY(psell_check_colptr(ctx, n, colptr, colptr_bytes, cp, nnz));
+    if (nnz >= (1ull << 32) - 1 || m >= ((int64_t)1 << 32) - 1) {
+        needs_host = true;
+        return POLEE_OK;
+    }
+    if (nnz > 0 && m < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "likelihood matrix: rowval out of range");
+    DevBuf<uint64_t> d_cp;
+    DevBuf<uint32_t> d_rowval;
+    DevBuf<float> d_nzval;
+    if (nnz) {
+        POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
+        POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
+        POLEE_TRY(d_nzval.upload(ctx, nzval, (size_t)nnz));
+    }
+    return psell_device_rows_from_dev_csc(ctx, m, n, d_cp.p, nnz, d_rowval.p, d_nzval.p, ks, C, &d_rowval);
 }
 
 // all three stages on the device.  needs_host: the layout is the host builder's to make (see psell_device_stage2).

@@ -78,6 +78,10 @@ polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const Psel
 // row on the device) or from Xt (1-based; host arrays, or device arrays: an xbuild result)
 polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, const void *colptr, int colptr_bytes, const uint32_t *rowval,
                                         const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host);
+// ... from X by columns already in device memory (polee_devx: one copy for the tree and the layout)
+polee_status psell_device_rows_from_dev_csc(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_cp, uint64_t nnz, const uint32_t *d_rowval,
+                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval);
+polee_status psell_check_colptr(polee_ctx *ctx, int64_t n, const void *colptr, int colptr_bytes, std::vector<uint64_t> &cp, uint64_t &nnz);
 polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr, const uint32_t *trowval, const float *tnzval,
                                        const int64_t *ks, bool on_device, PsellDevCSR &C);
 // POLEE_DEVICE_BUILD=0 turns the device builder off; so does any of the host builder's experiment knobs

@@ -114,3 +114,66 @@ def test_device_tree_is_the_host_variants_tree_node_for_node(P, ctx, lm_fixture)
         P.hclust(5, 2, np.array([1, 3, 4], np.uint64), np.array([1, 9, 3], np.uint32), device=True, ctx=ctx)
     with pytest.raises(Exception, match="colptr"):
         P.hclust(5, 2, np.array([1, 4, 3], np.uint64), np.array([1, 2, 3], np.uint32), device=True, ctx=ctx)
+
+
+def test_one_device_copy_of_x_serves_the_tree_and_the_layout(P, ctx, lm_fixture):
+    """polee_devx_upload + polee_loglik_create_from_devx + polee_hclust_parallel_device_from_devx: X crosses
+    PCIe once.  The same layout as polee_loglik_create (the layout's statistics, and bitwise the same gradient and lp in the
+    deterministic mode) and the same tree as polee_hclust_parallel_device, on the reference's fixture and on generated samples
+    (with multiplicities too); sample_and_tree takes that path for the device tree, the two builders on two contexts at once;
+    argument errors."""
+    from tools import synth
+    rng = np.random.default_rng(3)
+    f = lm_fixture
+    cases = [(f["m"], f["n"], f["colptr"], f["rowval"], f["nzval"], None)]
+    for kw in (dict(), dict(literal=True), dict(dropout=0.3)):
+        s = synth.make_sample(6000, 400000, 8.0, 22, **kw)
+        c, r, v = synth.to_csc(s)
+        cases.append((s["m"], s["n"], c, r, v, None))
+    s = synth.make_sample(2000, 50000, 6.0, 23)
+    c, r, v = synth.to_csc(s)
+    cases.append((s["m"], s["n"], c, r, v, rng.integers(1, 9, size=s["m"]).astype(np.int64)))
+    for m, n, colptr, rowval, nzval, ks in cases:
+        dx = P.DeviceX(m, n, colptr, rowval, nzval, ctx=ctx)
+        a = P.RNASeqSample(m, n, colptr, rowval, nzval, ks=ks, ctx=ctx)
+        b = P.RNASeqSample(m, n, None, None, None, ks=ks, ctx=ctx, devx=dx)
+        assert a.built_on_device and b.built_on_device
+        assert a.info == b.info
+        a.set_deterministic(True)
+        b.set_deterministic(True)
+        xs = rng.uniform(0.5, 1.5, size=(3, n)).astype(np.float32)
+        xs /= xs.sum(axis=1, keepdims=True)
+        la, ga = a.log_likelihood(xs)
+        lb, gb = b.log_likelihood(xs)
+        np.testing.assert_array_equal(ga, gb)
+        np.testing.assert_array_equal(la, lb)
+        pa, ja = P.hclust(m, n, colptr, rowval, device=True, ctx=ctx)
+        pb, jb = P.hclust(m, n, None, None, devx=dx, ctx=ctx)
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ja, jb)
+        del dx
+    # sample_and_tree: shared copy (the default) against one upload per builder
+    import os
+    m, n, colptr, rowval, nzval, _ = cases[1]
+    dev = P.LogitSkewNormalPTTApprox("cluster_device")
+    smp1, t1 = P.sample_and_tree(dev, m, n, colptr, rowval, nzval, None, ctx=ctx)
+    os.environ["POLEE_SHARED_X"] = "0"
+    try:
+        smp0, t0 = P.sample_and_tree(dev, m, n, colptr, rowval, nzval, None, ctx=ctx)
+    finally:
+        del os.environ["POLEE_SHARED_X"]
+    np.testing.assert_array_equal(t1.node_js, t0.node_js)
+    np.testing.assert_array_equal(t1.node_parent_idxs, t0.node_parent_idxs)
+    assert smp1.info == smp0.info
+    with pytest.raises(Exception, match="colptr"):
+        P.DeviceX(5, 2, np.array([1, 4, 3], np.uint64), np.array([1, 2, 3], np.uint32), np.ones(3, np.float32), ctx=ctx)
+    dx = P.DeviceX(5, 2, np.array([1, 3, 4], np.uint64), np.array([1, 2, 3], np.uint32), None, ctx=ctx)
+    with pytest.raises(Exception, match="values have not been uploaded"):
+        P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx)
+    dx.upload_values(np.ones(3, np.float32))
+    assert P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx).info["nnz"] == 3
+    dx = P.DeviceX(5, 2, np.array([1, 3, 4], np.uint64), np.array([1, 9, 3], np.uint32), np.ones(3, np.float32), ctx=ctx)
+    with pytest.raises(Exception, match="out of range"):
+        P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx)
+    with pytest.raises(Exception, match="out of range"):
+        P.hclust(5, 2, None, None, devx=dx, ctx=ctx)
