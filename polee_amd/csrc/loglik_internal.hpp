@@ -89,6 +89,10 @@ constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice 
 // leftover rows are packed in independent chunks of this many candidates (host: a thread each; device: a WAVE each, whose walk is
 // bound by instruction latency -- 4 096 rows give BASELINE's C2 a few thousand waves; a group is cut once per chunk: 0.02 % of them)
 constexpr uint32_t PSELL_PACK_CHUNK = 1u << 12;
+// Stage 3 cuts the streams into segments whose tiles are made independently (a tile never spans two).  The mixed streams are walked
+// ROW BY ROW (every row its own set), the uniform ones stretch by stretch: a mixed segment is this many rows, not the 2^18 of the
+// others -- on the device a segment is one wave's work, and one 19 k-row segment of stream BN was the whole tile walk's time.
+constexpr uint32_t PSELL_MIXED_SEG_ROWS = 1u << 12;
 constexpr double PSELL_PACK_WIDE_RESERVE = 32768.0;  // bytes above CSR a part of the second pass may spend on rows too long for stream BN, beyond its allowance
 constexpr int PSELL_MIN_UNIFORM_ROWS = 32;  // smallest run remainder stored as a padded uniform slice
 constexpr int PSELL_MIN_UNION_ROWS = 1;     // smallest group of leftover rows stored as a union slice (1: every row of <= 32 transcripts is in a uniform slice)

@@ -681,8 +681,9 @@ std::string psell_stage3(int64_t m, int64_t n, const uint64_t *rowptr, const uin
         const size_t bounds[PSELL_NSTREAMS + 1] = {0, (size_t)out.rows_a1, (size_t)out.rows_a1m, (size_t)out.rows_a2, (size_t)out.rows_a, (size_t)out.rows_s, rows.size()};
         for (int st = 0; st < PSELL_NSTREAMS; ++st) {
             size_t a = bounds[st];
+            const size_t step = (st == PSELL_B || st == PSELL_BN) ? std::min(SEG_ROWS, (size_t)PSELL_MIXED_SEG_ROWS) : SEG_ROWS;
             while (a < bounds[st + 1]) {
-                size_t e = std::min(bounds[st + 1], a + SEG_ROWS);
+                size_t e = std::min(bounds[st + 1], a + step);
                 if (e < bounds[st + 1]) {
                     if (st != PSELL_B && st != PSELL_BN) {
                         while (e < bounds[st + 1] && !run_end[e - 1]) ++e;  // uniform streams: end on a closed slice

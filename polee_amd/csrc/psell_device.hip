@@ -6,6 +6,7 @@
 // What is sequential in the host builder stays sequential here, one WAVE per independent piece (a segment of a stream in
 // stage 3), with the 64 lanes spread over the transcripts of a set; everything per row, per slice and per byte is parallel.
 #include <cstring>
+#include <type_traits>
 #include <chrono>
 #include <cstdio>
 #include <hip/hip_runtime.h>
@@ -93,8 +94,9 @@ __global__ void s3_segments_kernel(S3In A, uint32_t seg_rows, SegDesc *segs, uin
     for (int st = 0; st < 6; ++st) {
         uint64_t a = A.bounds[st];
         const uint64_t end = A.bounds[st + 1];
+        const uint64_t step = (st == PSELL_B || st == PSELL_BN) ? (seg_rows < PSELL_MIXED_SEG_ROWS ? seg_rows : PSELL_MIXED_SEG_ROWS) : seg_rows;
         while (a < end) {
-            uint64_t e = a + seg_rows < end ? a + seg_rows : end;
+            uint64_t e = a + step < end ? a + step : end;
             if (e < end) {
                 if (st != PSELL_B && st != PSELL_BN) {
                     while (e < end && !A.run_end[e - 1]) ++e;
@@ -162,7 +164,7 @@ struct S3Seq {
     const SegAux *aux;
     uint32_t nseg;
     const uint32_t *rlen, *st_start, *escan;
-    uint32_t *stamps;  // [waves][n]: the tile in which a transcript was last registered (the tile ids of a wave never repeat)
+    uint32_t *stamps;  // [waves][n], uniform streams: the tile in which a transcript was last registered (the tile ids of a wave never repeat)
     uint32_t *t_s0, *t_cols, *t_dstart;
     uint32_t *dict_s;
     uint32_t *srec_ri, *srec_n;  // mixed streams: first row and number of rows of every slice, at (ra - bounds[BN]) + slice
@@ -175,11 +177,44 @@ struct S3Seq {
 // while the tile's dictionary holds its transcripts or has room for them; a tile closes on its slice count).  One wave per
 // segment.  In the uniform streams the slices are known beforehand (they end where run_end says), and all rows of a stretch
 // ask the same question of the dictionary -- so the wave steps from stretch to stretch, not from row to row.
+// (Round 5, the MIXED streams -- row by row, every row its own set.  "Is this transcript in the current tile's dictionary?" was a table
+// of stamps in global memory and the walk a chain of dependent global loads, four per row (row id, row start, column, stamp -- the
+// stamp twice), 1.1 us per row: ONE segment of 11 - 19 k rows of stream BN took 12 - 21 ms on one wave while the ~115 others, 3 - 5 ms
+// each, had long finished.  Now, for these streams: the dictionary is a hash set in LDS (the same question, the same answers, the same
+// output); the rows' starts, lengths and -- for rows of at most 16 columns, all of stream BN -- columns arrive 64 rows at a time, a lane
+// each, all loads of a batch in flight together, handed over through LDS; the short rows' loop body holds no global load, so nothing
+// waits for the dictionary STORES (a vmcnt(0) per row was ~1 us); and a mixed segment is 4 096 rows (PSELL_MIXED_SEG_ROWS).  Tile
+// walk at C2: 12 / 21.5 ms -> 5.3 ms, the uniform streams' longest segment.  The same batching of the uniform streams' stretches was
+// tried and hung the GPU on the first test input for a reason not found in the time there was: not kept.)
+constexpr uint32_t S3_BCOLS = 16;
+constexpr uint32_t S3_TAB_BITS = 12, S3_TAB = 1u << S3_TAB_BITS;  // (a tile's dictionary holds at most PSELL_MAX_TILE_COLS = 1 024 entries)
+static_assert(PSELL_MAX_TILE_COLS * 2 <= (int)S3_TAB, "the hash set of a tile's dictionary");
+
 __global__ __launch_bounds__(64) void s3_tiles_kernel(S3Seq P)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t tab[S3_TAB];  // mixed streams: column + 1 of the current tile's dictionary entries, 0 = free
+    __shared__ uint32_t scol[64][PSELL_WIDE_MAX + 1];  // the column sets of a batch of 64 stretches (uniform streams) or 64 short rows (mixed)
     const uint32_t lane = lane_id();
-    uint32_t *stamp = P.stamps + (size_t)blockIdx.x * P.A.n;
+    uint32_t *stamp = P.stamps + (size_t)blockIdx.x * P.A.n;  // uniform streams: the tile in which a transcript was last registered
     uint32_t tile_id = 1;
+    auto tab_clear = [&]() {
+        for (uint32_t i = lane; i < S3_TAB; i += 64) tab[i] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto tab_has = [&](uint32_t c) -> bool {
+        uint32_t slot = (c * 2654435761u) >> (32 - S3_TAB_BITS);
+        for (uint32_t probes = 0; probes < S3_TAB; ++probes) {  // (bounded: a full table cannot occur, and must not hang the GPU if it does)
+            const uint32_t v = tab[slot];
+            if (v == c + 1u) return true;
+            if (v == 0u) return false;
+            slot = (slot + 1u) & (S3_TAB - 1u);
+        }
+        return false;
+    };
+    auto tab_put = [&](uint32_t c) {  // (c is not in the set; other lanes insert other columns at the same time)
+        uint32_t slot = (c * 2654435761u) >> (32 - S3_TAB_BITS);
+        for (uint32_t probes = 0; probes < S3_TAB && atomicCAS(&tab[slot], 0u, c + 1u) != 0u; ++probes) slot = (slot + 1u) & (S3_TAB - 1u);
+    };
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = atomicAdd(P.next_seg, 1u);
@@ -189,6 +224,7 @@ __global__ __launch_bounds__(64) void s3_tiles_kernel(S3Seq P)
         const SegAux aux = P.aux[k];
         const int st = (int)seg.stream;
         const uint32_t cap = P.caps[st];
+        const unsigned long long t_seg0 = wall_clock64();  // (POLEE_BUILD_TIMING: the segment's time in SegOut.pad, 10 ns units)
         uint32_t ntile = 0, nsl = 0, dict_n = 0, tile_cols = 0, pending = 0, tile_d0 = 0, tile_s0 = 0;
         uint32_t *dict_out = P.dict_s + aux.dbase;
         auto close_tile = [&]() {
@@ -205,6 +241,7 @@ __global__ __launch_bounds__(64) void s3_tiles_kernel(S3Seq P)
             ++tile_id;
             tile_cols = 0;
             pending = 0;
+            if (st > PSELL_A2M) tab_clear();
         };
         if (st <= PSELL_A2M) {
             for (uint32_t s = aux.st0; s < aux.st1; ++s) {
@@ -258,44 +295,80 @@ __global__ __launch_bounds__(64) void s3_tiles_kernel(S3Seq P)
                 ++pending;
                 in_slice = 0;
             };
-            for (uint32_t ri = seg.ra; ri < seg.rb; ++ri) {
-                const uint32_t *set = P.A.col + P.A.rowptr[P.A.rows[ri]];
-                const uint32_t w = P.rlen[ri];
-                for (;;) {
-                    uint32_t fresh = 0;
-                    for (uint32_t base = 0; base < w; base += 64) {
+            tab_clear();
+            for (uint32_t ri0 = seg.ra; ri0 < seg.rb; ri0 += 64) {
+                const uint32_t nb = min(64u, seg.rb - ri0);
+                unsigned long long my_b = 0ull;
+                uint32_t my_w = 0u;
+                if (lane < nb) {
+                    my_b = P.A.rowptr[P.A.rows[ri0 + lane]];
+                    my_w = P.rlen[ri0 + lane];
+                }
+                auto row_start = [&](uint32_t q) -> const uint32_t * {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_b, (int)q);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_b >> 32), (int)q);
+                    return P.A.col + (((unsigned long long)hi << 32) | lo);
+                };
+                {   // the batch's short rows (all of stream BN): lane r fetches row r's columns, all loads in flight at once, into LDS
+                    uint32_t v[S3_BCOLS];
+                    const uint32_t *mine = P.A.col + my_b;
+#pragma unroll
+                    for (uint32_t tt = 0; tt < S3_BCOLS; ++tt) v[tt] = (my_w <= S3_BCOLS && tt < my_w) ? mine[tt] : 0u;
+#pragma unroll
+                    for (uint32_t tt = 0; tt < S3_BCOLS; ++tt) scol[lane][tt] = v[tt];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                // (two bodies: a short row's columns come from LDS and its body holds no global LOAD -- with one in it the compiler
+                // waits with vmcnt(0) at the top of every row, i.e. for the previous row's dictionary stores, ~1 us)
+                auto do_row = [&](auto short_tag, uint32_t q, uint32_t w) {
+                    constexpr bool SHORT = decltype(short_tag)::value;
+                    const uint32_t ri = ri0 + q;
+                    const uint32_t *set = SHORT ? nullptr : row_start(q);
+                    const uint32_t c0 = SHORT ? scol[q][lane < S3_BCOLS ? lane : 0u] : 0u;
+                    bool fr0 = false;  // (short rows: the first pass's answer serves the second -- a tile closed in between empties the set)
+                    for (;;) {
+                        uint32_t fresh = 0;
+                        for (uint32_t base = 0; base < (SHORT ? 1u : w); base += 64) {
+                            const uint32_t i = base + lane;
+                            const uint32_t c = SHORT ? c0 : (i < w ? set[i] : 0u);
+                            fr0 = i < w && !tab_has(c);
+                            fresh += (uint32_t)__popcll(__ballot(fr0));
+                        }
+                        if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && in_slice == 0 && pending == 0)) break;
+                        close_slice();
+                        close_tile();
+                    }
+                    for (uint32_t base = 0; base < (SHORT ? 1u : w); base += 64) {
                         const uint32_t i = base + lane;
-                        fresh += (uint32_t)__popcll(__ballot(i < w && stamp[set[i < w ? i : 0]] != tile_id));
+                        const uint32_t c = SHORT ? c0 : (i < w ? set[i] : 0u);
+                        const bool fr = SHORT ? fr0 : (i < w && !tab_has(c));
+                        const uint64_t bal = __ballot(fr);
+                        if (fr) {
+                            tab_put(c);
+                            dict_out[dict_n + (uint32_t)__popcll(bal & lanes_below())] = c;
+                        }
+                        const uint32_t cnt = (uint32_t)__popcll(bal);
+                        dict_n += cnt;
+                        tile_cols += cnt;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: a wave's LDS operations complete in order)
                     }
-                    if (tile_cols + fresh <= (uint32_t)PSELL_TILE_COLS_TARGET || (tile_cols == 0 && in_slice == 0 && pending == 0)) break;
-                    close_slice();
-                    close_tile();
-                }
-                for (uint32_t base = 0; base < w; base += 64) {
-                    const uint32_t i = base + lane;
-                    const uint32_t c = i < w ? set[i] : 0u;
-                    const bool fr = i < w && stamp[c] != tile_id;
-                    const uint64_t bal = __ballot(fr);
-                    if (fr) {
-                        stamp[c] = tile_id;
-                        dict_out[dict_n + (uint32_t)__popcll(bal & lanes_below())] = c;
+                    if (in_slice == 0) slice_start = ri;
+                    ++in_slice;
+                    if (in_slice == (uint32_t)PSELL_LANES) {
+                        close_slice();
+                        if (pending >= cap) close_tile();
                     }
-                    const uint32_t cnt = (uint32_t)__popcll(bal);
-                    dict_n += cnt;
-                    tile_cols += cnt;
-                }
-                __threadfence_block();
-                if (in_slice == 0) slice_start = ri;
-                ++in_slice;
-                if (in_slice == (uint32_t)PSELL_LANES) {
-                    close_slice();
-                    if (pending >= cap) close_tile();
+                };
+                for (uint32_t q = 0; q < nb; ++q) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)my_w, (int)q);
+                    if (w <= S3_BCOLS) do_row(std::true_type{}, q, w);
+                    else do_row(std::false_type{}, q, w);
                 }
             }
             close_slice();
             close_tile();
         }
-        if (lane == 0) P.outs[k] = SegOut{ntile, nsl, dict_n, 0u};
+        if (lane == 0) P.outs[k] = SegOut{ntile, nsl, dict_n, (uint32_t)(wall_clock64() - t_seg0)};
     }
 }
 
@@ -373,8 +446,13 @@ __device__ inline SliceSet uniform_set(const S3In &A, const uint32_t *rlen, uint
 // per slice (one wave per tile, a lane per slice): its rows, width, bytes and flags
 __global__ __launch_bounds__(64) void s3_size_kernel(S3Size P)
 {
+    // (the totals: summed per tile in LDS, one global atomic per tile and counter -- every slice adding to the same four global words was
+    // 2.4 M same-address atomics at C2, most of this kernel's 8.7 ms)
+    __shared__ unsigned long long acc[25];
     const uint32_t t = blockIdx.x;
     if (t >= P.num_tiles) return;
+    if (lane_id() < 25) acc[lane_id()] = 0ull;
+    __syncthreads();
     const uint32_t k = P.tile_seg[t];
     const SegDesc seg = P.segs[k];
     const SegAux x = P.aux[k];
@@ -438,11 +516,13 @@ __global__ __launch_bounds__(64) void s3_size_kernel(S3Size P)
         P.slice_flags[s] = flags;
         P.slice_w[s] = (uint8_t)min(w, 255u);
         const int ss = masked && st == PSELL_A1 ? PSELL_A1M : st;
-        atomicAdd(&P.stats[ss], (unsigned long long)nr);
-        atomicAdd(&P.stats[8 + ss], nnz);
-        atomicAdd(&P.stats[16 + ss], (unsigned long long)bytes);
-        atomicAdd(&P.stats[24], (unsigned long long)stored * 64ull);
+        atomicAdd(&acc[ss], (unsigned long long)nr);
+        atomicAdd(&acc[8 + ss], nnz);
+        atomicAdd(&acc[16 + ss], (unsigned long long)bytes);
+        atomicAdd(&acc[24], (unsigned long long)stored * 64ull);
     }
+    __syncthreads();
+    if (lane_id() < 25 && acc[lane_id()] != 0ull) atomicAdd(&P.stats[lane_id()], acc[lane_id()]);
 }
 
 struct S3Emit {
@@ -607,45 +687,75 @@ struct S1Counters {
 
 // sort key of every row (first transcript's bin, length, hash of the set); empty rows and rows with ONE transcript drop out --
 // the latter counted per transcript (stream S), their k log X_ij left in `term`
-__global__ void s1_keys_kernel(PsellDevIn X, int binsh, uint64_t *keys, uint32_t *keep, uint32_t *is_single, double *term,
-                               unsigned long long *scnt, S1Counters *ctr)
+__global__ __launch_bounds__(256) void s1_keys_kernel(PsellDevIn X, int binsh, uint64_t *keys, uint32_t *keep, uint32_t *is_single, double *term,
+                                                     unsigned long long *scnt, S1Counters *ctr)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)X.m) return;
-    const uint64_t b = X.rowptr[i], e = X.rowptr[i + 1];
-    uint64_t key = ~0ull;
-    uint32_t single = 0;
-    double tm = 0.0;
-    if (e < b) {
-        atomicMax(&ctr->err, 1u);
-    } else if (e == b) {
-        atomicAdd(&ctr->empties, 1ull);
-    } else if (e - b > (uint64_t)PSELL_MAX_TILE_COLS) {
-        atomicMax(&ctr->err, 2u);
-    } else if (e - b == 1 && X.col[b] < (uint64_t)X.n && X.val[b] > 0.0f && (!X.ks || X.ks[i] >= 0)) {
-        const long long k = X.ks ? X.ks[i] : 1;
-        atomicAdd(&scnt[X.col[b]], (unsigned long long)k);
-        tm = (double)k * log((double)X.val[b]);
-        single = 1;
-        atomicAdd(&ctr->singles, 1ull);
-        atomicMax(&ctr->max_row, 1u);
-    } else {
-        const uint64_t len = e - b;
-        uint32_t h = 0x12345u;
-        const uint32_t first = X.col[b];
-        for (uint64_t k = b; k < e; ++k) {
-            const uint32_t c = X.col[k];
-            if (c >= (uint64_t)X.n) atomicMax(&ctr->err, 3u);
-            if (k > b && c <= X.col[k - 1]) atomicMax(&ctr->err, 4u);
-            h = mix32_dev(h, c);
-        }
-        atomicMax(&ctr->max_row, (uint32_t)len);
-        key = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)(len < 255 ? len : 255) << 32) | h;
+    // (the counters: per thread, then per block, then ONE global atomic per block and counter -- a fixed grid walks the rows.  Every
+    // row's atomicMax / atomicAdd on the same four words, even wave-aggregated, was most of this kernel's 7.3 ms at C2.)
+    __shared__ unsigned long long sh_cnt[2];
+    __shared__ uint32_t sh_u[2];
+    if (threadIdx.x < 2) {
+        sh_cnt[threadIdx.x] = 0ull;
+        sh_u[threadIdx.x] = 0u;
     }
-    keys[i] = key;
-    keep[i] = key != ~0ull;
-    is_single[i] = single;
-    term[i] = tm;
+    __syncthreads();
+    uint32_t my_err = 0, my_max = 0, n_empty = 0, n_single = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)X.m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = X.rowptr[i], e = X.rowptr[i + 1];
+        uint64_t key = ~0ull;
+        uint32_t single = 0;
+        double tm = 0.0;
+        if (e < b) {
+            my_err = max(my_err, 1u);
+        } else if (e == b) {
+            ++n_empty;
+        } else if (e - b > (uint64_t)PSELL_MAX_TILE_COLS) {
+            my_err = max(my_err, 2u);
+        } else if (e - b == 1 && X.col[b] < (uint64_t)X.n && X.val[b] > 0.0f && (!X.ks || X.ks[i] >= 0)) {
+            const long long k = X.ks ? X.ks[i] : 1;
+            atomicAdd(&scnt[X.col[b]], (unsigned long long)k);
+            tm = (double)k * log((double)X.val[b]);
+            single = 1;
+            ++n_single;
+            my_max = max(my_max, 1u);
+        } else {
+            const uint64_t len = e - b;
+            uint32_t h = 0x12345u;
+            const uint32_t first = X.col[b];
+            for (uint64_t k = b; k < e; ++k) {
+                const uint32_t c = X.col[k];
+                if (c >= (uint64_t)X.n) my_err = max(my_err, 3u);
+                if (k > b && c <= X.col[k - 1]) my_err = max(my_err, 4u);
+                h = mix32_dev(h, c);
+            }
+            my_max = max(my_max, (uint32_t)len);
+            key = ((uint64_t)(first >> binsh) << 40) | ((uint64_t)(len < 255 ? len : 255) << 32) | h;
+        }
+        keys[i] = key;
+        keep[i] = key != ~0ull;
+        is_single[i] = single;
+        term[i] = tm;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_err = max(my_err, (uint32_t)__shfl_xor((int)my_err, d, 64));
+        my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, d, 64));
+        n_empty += (uint32_t)__shfl_xor((int)n_empty, d, 64);
+        n_single += (uint32_t)__shfl_xor((int)n_single, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (my_err) atomicMax(&sh_u[0], my_err);
+        if (my_max) atomicMax(&sh_u[1], my_max);
+        if (n_empty) atomicAdd(&sh_cnt[0], (unsigned long long)n_empty);
+        if (n_single) atomicAdd(&sh_cnt[1], (unsigned long long)n_single);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sh_u[0]) atomicMax(&ctr->err, sh_u[0]);
+        if (sh_u[1]) atomicMax(&ctr->max_row, sh_u[1]);
+        if (sh_cnt[0]) atomicAdd(&ctr->empties, sh_cnt[0]);
+        if (sh_cnt[1]) atomicAdd(&ctr->singles, sh_cnt[1]);
+    }
 }
 
 __global__ void s1_compact_kernel(uint64_t m, const uint64_t *keys, const uint32_t *keep, const uint32_t *kscan, const uint32_t *is_single,
@@ -775,7 +885,7 @@ polee_status psell_device_stage1(polee_ctx *ctx, const PsellDevIn &X, PsellHost 
     PD_HIP(hipMemsetAsync(ctr.p, 0, sizeof(S1Counters), stream));
     PD_HIP(hipMemsetAsync(keep.p + m, 0, 4, stream));
     PD_HIP(hipMemsetAsync(is_single.p + m, 0, 4, stream));
-    hipLaunchKernelGGL(s1_keys_kernel, dim3((unsigned)((m + TB - 1) / TB)), dim3(TB), 0, stream, X, binsh, keys.p, keep.p, is_single.p, term.p,
+    hipLaunchKernelGGL(s1_keys_kernel, dim3((unsigned)std::min<uint64_t>(((uint64_t)m + TB - 1) / TB, 8192)), dim3(TB), 0, stream, X, binsh, keys.p, keep.p, is_single.p, term.p,
                        scnt.p, ctr.p);
     POLEE_KERNEL_CHECK(ctx);
     PD_HIP(exclusive_sum(tmp, keep.p, kscan.p, 0u, (size_t)m + 1, stream));
@@ -1595,7 +1705,7 @@ polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const Psel
     for (int q = 0; q < 7; ++q) A.bounds[q] = (uint32_t)W.bounds[q];
     static const size_t seg_env = getenv("POLEE_PSELL_SEG_ROWS") ? (size_t)atoll(getenv("POLEE_PSELL_SEG_ROWS")) : 0;  // (tests)
     const uint32_t seg_rows = (uint32_t)(seg_env >= 64 ? seg_env : (size_t)1 << 18);
-    const uint32_t max_segs = Nr / seg_rows + 8;
+    const uint32_t max_segs = Nr / seg_rows + (uint32_t)(W.bounds[6] - W.bounds[4]) / std::min<uint32_t>(seg_rows, PSELL_MIXED_SEG_ROWS) + 8;
     Scratch tmp(ctx);
     DevBuf<uint32_t> rlen, head, endflag, hscan, escan, st_start, endpos, nseg_d;
     DevBuf<uint64_t> lenps, totals;
@@ -1679,6 +1789,19 @@ polee_status psell_device_stage3(polee_ctx *ctx, const PsellDevIn &X, const Psel
     std::vector<SegOut> h_outs(nseg);
     PD_HIP(hipMemcpyAsync(h_outs.data(), outs.p, sizeof(SegOut) * nseg, hipMemcpyDeviceToHost, stream));
     PD_HIP(hipStreamSynchronize(stream));
+    if (getenv("POLEE_BUILD_TIMING")) {  // where the tile walk's time goes: per segment
+        std::vector<uint32_t> ord(nseg);
+        for (uint32_t k = 0; k < nseg; ++k) ord[k] = k;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return h_outs[a].pad > h_outs[b].pad; });
+        double sum = 0.0;
+        for (uint32_t k = 0; k < nseg; ++k) sum += h_outs[k].pad * 1e-5;
+        fprintf(stderr, "[psell device build]   . tile walk: %u segments on %u waves, %.2f ms of wave time in all; the longest:\n", nseg, nwaves, sum);
+        for (uint32_t q = 0; q < std::min<uint32_t>(nseg, 6); ++q) {
+            const uint32_t k = ord[q];
+            fprintf(stderr, "[psell device build]       stream %u rows %u stretches %u tiles %u slices %u: %.2f ms\n", h_segs[k].stream, h_segs[k].rb - h_segs[k].ra,
+                    h_aux[k].st1 - h_aux[k].st0, h_outs[k].ntiles, h_outs[k].nslices, h_outs[k].pad * 1e-5);
+        }
+    }
 
     // ---- the final numbering: segments concatenated in order (psell_build.cpp, "concatenate the fragments")
     std::vector<SegFinal> h_fin(nseg);
