@@ -1969,7 +1969,8 @@ __global__ void s0_rowkeys_kernel(uint64_t nnz, uint64_t m, const uint32_t *rowv
     idx[k] = (uint32_t)k;
     atomicAdd(&counts[r - 1u], 1u);
 }
-__global__ void s0_gather_kernel(uint64_t nnz, int64_t n, const uint64_t *colptr, const uint32_t *idx, const float *nzval, uint32_t *col, float *val)
+// (two kernels: the columns need colptr and the sorted positions only, so they are found while the VALUES are still on their way up)
+__global__ void s0_gather_col_kernel(uint64_t nnz, int64_t n, const uint64_t *colptr, const uint32_t *idx, uint32_t *col)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
@@ -1981,7 +1982,11 @@ __global__ void s0_gather_kernel(uint64_t nnz, int64_t n, const uint64_t *colptr
         if (colptr[mid] - 1u <= (uint64_t)k) lo = mid + 1; else hi = mid;
     }
     col[i] = (uint32_t)(lo - 1);
-    val[i] = nzval[k];
+}
+__global__ void s0_gather_val_kernel(uint64_t nnz, const uint32_t *idx, const float *nzval, float *val)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nnz) val[i] = nzval[idx[i]];
 }
 
 }  // namespace
@@ -2056,7 +2061,8 @@ polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, con
 // X by columns ALREADY on the device (1-based colptr as 64-bit words, 1-based rowval: polee_devx, or this file's own upload) -> rows.
 // own_rowval: this call's private copy, released as soon as the keys are made (peak memory); a shared copy stays.
 polee_status psell_device_rows_from_dev_csc(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_cp, uint64_t nnz, const uint32_t *d_rowval,
-                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval)
+                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval,
+                                            const float *late_nzval, DevBuf<float> *late_buf)
 {
     hipStream_t stream = ctx->stream;
     C.m = m;
@@ -2103,7 +2109,25 @@ polee_status psell_device_rows_from_dev_csc(polee_ctx *ctx, int64_t m, int64_t n
         PD_HIP(tmp.need(bytes));
         PD_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, idx.p, idx_s.p, (size_t)nnz, 0, bits, stream));
     }
-    hipLaunchKernelGGL(s0_gather_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, n, d_cp, idx_s.p, d_nzval, C.col.p, C.val.p);
+    hipLaunchKernelGGL(s0_gather_col_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, n, d_cp, idx_s.p, C.col.p);
+    POLEE_KERNEL_CHECK(ctx);
+    if (late_nzval) {
+        // the caller's values go up NOW, on a stream of their own, beside the sort and the column search queued above (8 ms of kernels
+        // under a 20 ms copy at C2); the block came out of the cache behind a host wait, so nothing else of any stream touches it
+        hipStream_t up = nullptr;
+        PD_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        polee_status st = late_buf->alloc(ctx, (size_t)nnz);
+        hipError_t e = hipSuccess;
+        if (st == POLEE_OK) {
+            e = hipMemcpyAsync(late_buf->p, late_nzval, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess) e = hipStreamSynchronize(up);
+        }
+        (void)hipStreamDestroy(up);
+        if (st != POLEE_OK) return st;
+        PD_HIP(e);
+        d_nzval = late_buf->p;
+    }
+    hipLaunchKernelGGL(s0_gather_val_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, nnz, idx_s.p, d_nzval, C.val.p);
     POLEE_KERNEL_CHECK(ctx);
     PD_HIP(hipStreamSynchronize(stream));
     return POLEE_OK;
@@ -2143,9 +2167,10 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
     if (nnz) {
         POLEE_TRY(d_cp.upload(ctx, cp.data(), cp.size()));
         POLEE_TRY(d_rowval.upload(ctx, rowval, (size_t)nnz));
-        POLEE_TRY(d_nzval.upload(ctx, nzval, (size_t)nnz));
     }
-    return psell_device_rows_from_dev_csc(ctx, m, n, d_cp.p, nnz, d_rowval.p, d_nzval.p, ks, C, &d_rowval);
+    static const bool serial = getenv("POLEE_SERIAL_UPLOAD") != nullptr;  // (A/B: the values before the kernels, on the same stream)
+    if (serial && nnz) POLEE_TRY(d_nzval.upload(ctx, nzval, (size_t)nnz));
+    return psell_device_rows_from_dev_csc(ctx, m, n, d_cp.p, nnz, d_rowval.p, d_nzval.p, ks, C, &d_rowval, serial ? nullptr : nzval, &d_nzval);
 }
 
 // all three stages on the device.  needs_host: the layout is the host builder's to make (see psell_device_stage2).

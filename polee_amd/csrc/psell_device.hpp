@@ -80,7 +80,8 @@ polee_status psell_device_rows_from_csc(polee_ctx *ctx, int64_t m, int64_t n, co
                                         const float *nzval, const int64_t *ks, PsellDevCSR &C, bool &needs_host);
 // ... from X by columns already in device memory (polee_devx: one copy for the tree and the layout)
 polee_status psell_device_rows_from_dev_csc(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *d_cp, uint64_t nnz, const uint32_t *d_rowval,
-                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval);
+                                            const float *d_nzval, const int64_t *ks, PsellDevCSR &C, DevBuf<uint32_t> *own_rowval,
+                                            const float *late_nzval = nullptr, DevBuf<float> *late_buf = nullptr);  // (host values, uploaded beside the sort)
 polee_status psell_check_colptr(polee_ctx *ctx, int64_t n, const void *colptr, int colptr_bytes, std::vector<uint64_t> &cp, uint64_t &nnz);
 polee_status psell_device_rows_from_xt(polee_ctx *ctx, int64_t m, int64_t n, const uint64_t *tcolptr, const uint32_t *trowval, const float *tnzval,
                                        const int64_t *ks, bool on_device, PsellDevCSR &C);
