@@ -647,8 +647,10 @@ polee_status polee_devx_upload(polee_ctx *ctx, int64_t m, int64_t n, const void 
  * their way (what sample_and_tree of the Python mirror does) */
 polee_status polee_devx_upload_values(polee_devx *dx, const float *nzval);
 void polee_devx_destroy(polee_devx *dx);
-/* as polee_loglik_create / polee_hclust_parallel_device on the arrays the handle was made from: the same layout byte for byte, the same tree */
-polee_status polee_loglik_create_from_devx(polee_ctx *ctx, const polee_devx *dx, const int64_t *ks_or_null, polee_loglik **out);
+/* as polee_loglik_create / polee_hclust_parallel_device on the arrays the handle was made from: the same layout byte for byte, the same tree.
+ * nzval_or_null: the values, if the handle has none yet -- they go up beside the layout's first kernels (row keys, sort, column search
+ * need colptr + rowval only) and stay in the handle. */
+polee_status polee_loglik_create_from_devx(polee_ctx *ctx, polee_devx *dx, const float *nzval_or_null, const int64_t *ks_or_null, polee_loglik **out);
 polee_status polee_hclust_parallel_device_from_devx(polee_ctx *ctx, const polee_devx *dx, int32_t *node_parent_idxs, int32_t *node_js);
 /* The likelihood handle straight from an xbuild result, without X leaving the device: rows_to_device -> layout kernels
  * (as polee_loglik_create_from_xt on polee_xbuild_get's arrays; ks_or_null: host array [rows]).  The xbuild handle stays valid. */

@@ -737,10 +737,10 @@ end
 "the values after the fact (DeviceX(..., nzval) with an empty nzval uploads colptr + rowval only: enough for the tree)"
 upload_values!(x::DeviceX, nzval::Vector{Float32}) =
     GC.@preserve nzval check(ccall((:polee_devx_upload_values, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), x.h, nzval), x.ctx.h)
-function sample_from_devx(ctx::Context, x::DeviceX; ks::Union{Nothing,Vector{Int64}}=nothing)
-    r = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve ks check(ccall((:polee_loglik_create_from_devx, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
-                                ctx.h, x.h, ks === nothing ? C_NULL : ks, r), ctx.h)
+function sample_from_devx(ctx::Context, x::DeviceX; ks::Union{Nothing,Vector{Int64}}=nothing, nzval::Union{Nothing,Vector{Float32}}=nothing)
+    r = Ref{Ptr{Cvoid}}(C_NULL)   # nzval: the values, if the handle has none yet (uploaded beside the layout's first kernels)
+    GC.@preserve ks nzval check(ccall((:polee_loglik_create_from_devx, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+                                      ctx.h, x.h, nzval === nothing ? C_NULL : nzval, ks === nothing ? C_NULL : ks, r), ctx.h)
     s = DeviceSampleHandle(r[], ctx, x.m, x.n)
     finalizer(s -> ccall((:polee_loglik_destroy, LIB), Cvoid, (Ptr{Cvoid},), s.h), s)
     return s

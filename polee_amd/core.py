@@ -229,9 +229,10 @@ class RNASeqSample:
         ks_a = None if ks is None else arr(ks, np.int64)
         if _xbuild is not None:  # an xbuild result, still on the device (polee_amd.xbuild.build_likelihood_matrix(return_sample=True))
             check(L.lib().polee_loglik_create_from_xbuild(self.ctx._h, _xbuild, ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
-        elif devx is not None:  # X already on the device (DeviceX): no second upload
+        elif devx is not None:  # X already on the device (DeviceX): no second upload (nzval: only if the handle has no values yet)
             self._csc = devx._csc
-            check(L.lib().polee_loglik_create_from_devx(self.ctx._h, devx._h, ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
+            nz = None if nzval is None else arr(nzval, np.float32)
+            check(L.lib().polee_loglik_create_from_devx(self.ctx._h, devx._h, ptr(nz, f32p), ptr(ks_a, i64p), C.byref(self._h)), self.ctx._h)
         elif xt is not None:
             tp, tr, tv = arr(xt[0], np.uint64), arr(xt[1], np.uint32), arr(xt[2], np.float32)
             check(L.lib().polee_loglik_create_from_xt(self.ctx._h, C.c_int64(self.m), C.c_int64(self.n), ptr(tp, u64p),
@@ -712,7 +713,7 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
 
         def shared():
             try:
-                return DeviceX(m, n, colptr, rowval, None, ctx=ctx) if share_x else None  # (the values follow once the tree job is off)
+                return DeviceX(m, n, colptr, rowval, None, ctx=ctx) if share_x else None  # (the values go up with the layout, beside its first kernels)
             except L.PoleeError as e:  # (more than 32 bits of non-zeros: the host paths)
                 if "32 bits" in str(e):
                     return None
@@ -738,8 +739,6 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
             if tm == "cluster_device":
                 devx = shared()
             fut = pool.submit(hclust, m, n, colptr, rowval, tm == "cluster_parallel", tm == "cluster_device", tree_ctx or ctx, devx)
-        if devx is not None:
-            devx.upload_values(nzval)
         sample = RNASeqSample(m, n, colptr, rowval, nzval, effective_lengths, ks=ks, ctx=ctx, devx=devx)
         if fut is not None:
             parents, js = fut.result()

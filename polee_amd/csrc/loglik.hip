@@ -2921,20 +2921,22 @@ void polee_devx_destroy(polee_devx *dx)
     ctx_release(ctx);
 }
 
-polee_status polee_loglik_create_from_devx(polee_ctx *ctx, const polee_devx *dx, const int64_t *ks, polee_loglik **out)
+polee_status polee_loglik_create_from_devx(polee_ctx *ctx, polee_devx *dx, const float *nzval, const int64_t *ks, polee_loglik **out)
 {
     return guarded(ctx, "polee_loglik_create_from_devx", [&]() -> polee_status {
         POLEE_TRY(use_device(ctx));
         if (!dx || !out) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: null argument");
         if (dx->ctx->device != ctx->device) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: X lives on another device");
-        if (dx->nnz && !dx->nzval.p) return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: the values have not been uploaded (polee_devx_upload_values)");
+        if (dx->nnz && !dx->nzval.p && !nzval)
+            return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: the values have not been uploaded (polee_devx_upload_values, or pass them here)");
+        const float *late = dx->nnz && !dx->nzval.p ? nzval : nullptr;  // (go up beside the first kernels, into the handle)
         if (!psell_device_enabled())
             return fail(ctx, POLEE_ERR_UNSUPPORTED, "polee_loglik_create_from_devx: the device builder is switched off (POLEE_DEVICE_BUILD=0 or a host-builder knob)");
         bool done = false;
         polee_status st = POLEE_OK;
         {
             PsellDevCSR C;
-            if ((st = psell_device_rows_from_dev_csc(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, dx->nzval.p, ks, C, nullptr)) != POLEE_OK) return st;
+            if ((st = psell_device_rows_from_dev_csc(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, dx->nzval.p, ks, C, nullptr, late, &dx->nzval)) != POLEE_OK) return st;
             st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
         }
         if (st != POLEE_OK || done) return st;

@@ -172,6 +172,12 @@ def test_one_device_copy_of_x_serves_the_tree_and_the_layout(P, ctx, lm_fixture)
         P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx)
     dx.upload_values(np.ones(3, np.float32))
     assert P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx).info["nnz"] == 3
+    # ... or the values come with the layout call (they go up beside its first kernels and stay in the handle)
+    m, n, colptr, rowval, nzval, _ = cases[1]
+    dx = P.DeviceX(m, n, colptr, rowval, None, ctx=ctx)
+    late = P.RNASeqSample(m, n, None, None, nzval, ctx=ctx, devx=dx)
+    again = P.RNASeqSample(m, n, None, None, None, ctx=ctx, devx=dx)
+    assert late.info == smp0.info and again.info == smp0.info
     dx = P.DeviceX(5, 2, np.array([1, 3, 4], np.uint64), np.array([1, 9, 3], np.uint32), np.ones(3, np.float32), ctx=ctx)
     with pytest.raises(Exception, match="out of range"):
         P.RNASeqSample(5, 2, None, None, None, ctx=ctx, devx=dx)
