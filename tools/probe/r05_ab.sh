@@ -20,7 +20,7 @@ for input in $INPUTS; do
   for rep in $(seq 1 ${REPS:-2}); do
     for i in "${!ARR[@]}"; do
       IFS=';' read -r name lib envs <<< "${ARR[$i]}"
-      env POLEE_HIP_LIB=$GRAFT_REPO_ROOT/polee_amd/csrc/$lib $envs timeout 900 python3 bench.py $ARGS $EXTRA_ARGS --steps ${STEPS:-100} --warmup 5 --cpu-steps 0 --prewarm ${PREWARM:-300} 2> $OUT/${input}_${i}_$rep.err | tail -1 > $OUT/${input}_${i}_$rep.json
+      env POLEE_HIP_LIB=$GRAFT_REPO_ROOT/polee_amd/csrc/$lib $envs timeout -k 5 200 python3 bench.py $ARGS $EXTRA_ARGS --steps ${STEPS:-100} --warmup 5 --cpu-steps 0 --prewarm ${PREWARM:-300} 2> $OUT/${input}_${i}_$rep.err | tail -1 > $OUT/${input}_${i}_$rep.json
       python3 - "$input" "$name" $OUT/${input}_${i}_$rep.json <<'PY'
 import sys, json
 try:
