@@ -179,10 +179,10 @@ typedef struct {
 polee_status polee_loglik_get_info(const polee_loglik *ll, polee_loglik_info *info);
 /* Deterministic mode ("fixed reduction order ... bitwise stable"): the gradient (and lp) of a pass is
  * summed in a fixed order -- per wave, per tile, then per transcript in tile order -- instead of with float atomics, so
- * that two evaluations on the same inputs agree bit for bit (and with them a whole fit with the same noise).  About 25 %
- * slower (three workgroups per CU instead of four, a second small kernel).  Fragments in the per-tile kernel's stream
- * (polee_loglik_info.stream_tiles[5] > 0: more than 32 transcripts, as a rule) are still added with float atomics: the
- * guarantee holds when that stream is empty.  Default off. */
+ * that two evaluations on the same inputs agree bit for bit (and with them a whole fit with the same noise), whichever
+ * workgroup takes which tile.  About 11 % slower (three workgroups per CU instead of four, a second small kernel).  Rows kept
+ * in CSR (polee_loglik_info.stream_rows[6] > 0: fragments without any set structure, none in any input met so far) are
+ * still added with float atomics: the guarantee holds when that stream is empty.  Default off. */
 polee_status polee_loglik_set_deterministic(polee_loglik *ll, int on);
 
 /* log_likelihood (src/likelihood.jl:36-56) for K expression vectors at once:

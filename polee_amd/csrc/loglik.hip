@@ -161,7 +161,8 @@ struct PsellArgs {
     unsigned int dyn_base;
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
     float *gwin;            // [dict entries][K], laid out like xwin
-    double *lpwin;          // [grid][K] per-workgroup log-likelihood sums
+    double *lpwin;          // [grid][K] per-workgroup log-likelihood sums, then [stream B's tiles][K] (lp_slot0 on)
+    int lp_slot0;
 };
 
 template <int K, bool WANT_LP, bool HAS_KS>
@@ -194,7 +195,13 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
     for (int k = 0; k < K; ++k) lpacc[k] = 0.0;
 
     const int stream = tile < A.tiles_a1 ? PSELL_A1 : (tile < A.tiles_a1m ? PSELL_A1M : (tile < A.tiles_a2 ? PSELL_A2 : (tile < A.tiles_a ? PSELL_A2M : (tile < A.tiles_s ? PSELL_BN : PSELL_B))));
-    for (uint32_t s = s0 + wave; s < s1; s += 4) {
+    // Deterministic mode, stream B (rows of more than 32 transcripts: rare, a fraction of a per cent of the non-zeros where they
+    // occur at all): ONE wave takes all slices of the tile in order -- a wave's LDS adds retire in program order, four waves' do
+    // not -- and the tile's sums are STORED to its slots of gwin, which gwin_reduce_kernel adds in tile order like every other
+    // tile's; its lp goes to a slot of lpwin.  (Round 5: these tiles added with float atomics, and a sample that had any was not
+    // bitwise reproducible -- one gradient entry moving by an ulp between launches on a 3 M-fragment sample with 699 such rows.)
+    const bool det = A.gwin != nullptr && tile >= A.tiles_s;
+    for (uint32_t s = det ? (wave == 0 ? s0 : s1) : s0 + wave; s < s1; s += det ? 1u : 4u) {
         const uint32_t off = slice_off[s] & PSELL_OFF_MASK;
         const uint32_t units = (slice_off[s + 1] & PSELL_OFF_MASK) - off;
         // compact slices (uniform streams): uint16 lcol[128] header, then float val[w][64];
@@ -263,7 +270,8 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
     for (int i = threadIdx.x; i < L * K; i += 256) {
         const int l = i / K, k = i - l * K;
         const float v = gw[i];
-        if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
+        if (det) A.gwin[(size_t)(d0 + l) * K + k] = v;
+        else if (v != 0.0f) atomicAdd(g + (size_t)dict[d0 + l] * K + k, v);
     }
     if (WANT_LP) {
 #pragma unroll
@@ -273,7 +281,11 @@ __device__ inline void psell_tile_body(const PsellArgs &A, int tile, float *xw, 
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
             if (lane == 0) lp_red[wave] = v;
             __syncthreads();
-            if (threadIdx.x == 0) atomicAdd(lp + k, lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3]);
+            if (threadIdx.x == 0) {
+                const double sum = lp_red[0] + lp_red[1] + lp_red[2] + lp_red[3];
+                if (det) A.lpwin[(size_t)(A.lp_slot0 + (tile - A.tiles_s)) * K + k] = sum;
+                else atomicAdd(lp + k, sum);
+            }
             __syncthreads();
         }
     }
@@ -2221,26 +2233,14 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         A.dyn_base = ll->dyn_base;
         ll->dyn_base += (uint32_t)ll->dyn_positions;
     }
-    if (DET) {
-        POLEE_TRY(ll->d_gwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512));
-        POLEE_TRY(ll->d_lpwin.alloc(ctx, (size_t)4 * ctx->num_cus * PSELL_MAX_K));
-        A.gwin = ll->d_gwin.p;
-        A.lpwin = ll->d_lpwin.p;
-    }
+    // (DET: A.gwin / A.lpwin are the caller's, and so is the reduce launch behind this one and stream B's: launch_variant)
     if (!ll->xwin_ready)
         hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, A.dict,
                            A.x, ll->dict_len, ll->d_xwin.p);
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);
-    if (DET) {
-        const uint32_t *gmap = ll->cur_remap ? ll->cur_remap->index_of : nullptr;
-        hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
-                           ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, G, A.lp, gmap);
-        if (ll->d_theavy.n > 0)
-            hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n, (unsigned)K), dim3(256), 0, st, ll->d_theavy.p,
-                               ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g, gmap);
-    }
+    A.lp_slot0 = G;  // (DET: stream B's tiles put their lp behind the workgroups')
     return POLEE_OK;
 }
 
@@ -2258,7 +2258,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     const uint32_t *csr_col = rm && rm->csr_col ? rm->csr_col : ll->d_csr_col.p;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, rm ? rm->dict : ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, 0u, nullptr, nullptr};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
@@ -2267,17 +2267,32 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
         POLEE_HIP_TRY(ctx, hipFuncSetAttribute((const void *)loglik_psell_kernel<K, LP, KS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     if (!no_ring) {
+        const bool det = ll->deterministic;
+        if (det) {  // every tile's sums go to its slots of gwin; a transcript's slots are added in tile order afterwards
+            POLEE_TRY(ll->d_gwin.alloc(ctx, (size_t)ll->dict_len * PSELL_MAX_K + 512));
+            POLEE_TRY(ll->d_lpwin.alloc(ctx, ((size_t)4 * ctx->num_cus + (size_t)tiles_b) * PSELL_MAX_K));
+            A.gwin = ll->d_gwin.p;
+            A.lpwin = ll->d_lpwin.p;
+        }
         if (h.num_tiles_s > 0) {
-            if (ll->deterministic)
+            if (det)
                 POLEE_TRY((launch_stream<K, LP, KS, true>(ll, A, dbg)));
             else
                 POLEE_TRY((launch_stream<K, LP, KS, false>(ll, A, dbg)));
         }
         if (tiles_b > 0) {
-            // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes (with
-            // float atomics: a sample that has such rows is not bitwise reproducible in deterministic mode either)
+            // rows with more than 32 transcripts (rare) live in mixed tiles, which the per-tile kernel takes (float atomics; in the
+            // deterministic mode one wave per tile and stores to the tile's slots, see psell_tile_body)
             hipLaunchKernelGGL((loglik_psell_kernel<K, LP, KS>), dim3((unsigned)tiles_b), dim3(256), lds_psell, st, A,
                                (int)h.num_tiles_s, (const uint32_t *)nullptr);
+        }
+        if (det) {
+            const uint32_t *gmap = ll->cur_remap ? ll->cur_remap->index_of : nullptr;
+            hipLaunchKernelGGL(gwin_reduce_kernel, dim3((unsigned)ceil_div(ll->n * K, 256)), dim3(256), 0, st, ll->d_tslot_ptr.p,
+                               ll->d_tslot.p, ll->d_gwin.p, K, ll->n, A.g, LP ? ll->d_lpwin.p : nullptr, A.lp_slot0 + (int)tiles_b, A.lp, gmap);
+            if (ll->d_theavy.n > 0)
+                hipLaunchKernelGGL(gwin_reduce_heavy_kernel, dim3((unsigned)ll->d_theavy.n, (unsigned)K), dim3(256), 0, st, ll->d_theavy.p,
+                                   ll->d_tslot_ptr.p, ll->d_tslot.p, ll->d_gwin.p, K, A.g, gmap);
         }
         if (ll->csr_rows > 0)  // stream C: rows kept in CSR (float atomics: like stream B, outside the deterministic guarantee)
             hipLaunchKernelGGL((loglik_csr_kernel<K, LP, KS>), dim3((unsigned)ceil_div(ll->csr_rows, 256)), dim3(256), 0, st,
@@ -2494,12 +2509,12 @@ static polee_status loglik_finish_create(polee_ctx *ctx, polee_loglik *ll, polee
     for (int64_t t = 0; t < h.num_tiles; ++t) wave_cuts(h, t, h.tile_slice[t], h.tile_slice[t + 1], &ll->tile_cut[(size_t)3 * t]);
     {   // deterministic mode: the dictionary entries of every transcript, ascending (= tile order), padding left out
         std::vector<uint32_t> ptr((size_t)ll->n + 1, 0), slots;
-        for (int64_t t = 0; t < h.num_tiles_s; ++t)
+        for (int64_t t = 0; t < h.num_tiles; ++t)  // (stream B's tiles too: their sums go through gwin in the deterministic mode)
             for (uint32_t l = 0; l < h.tile_cols[t]; ++l) ++ptr[(size_t)h.dict[h.tile_dict[t] + l] + 1];
         for (int64_t j = 0; j < ll->n; ++j) ptr[(size_t)j + 1] += ptr[(size_t)j];
         slots.resize(ptr[(size_t)ll->n]);
         std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
-        for (int64_t t = 0; t < h.num_tiles_s; ++t)
+        for (int64_t t = 0; t < h.num_tiles; ++t)
             for (uint32_t l = 0; l < h.tile_cols[t]; ++l) {
                 const uint32_t e = h.tile_dict[t] + l;
                 slots[cur[h.dict[e]]++] = e;

@@ -4,6 +4,8 @@ against the CPU oracle on the same seeded inputs.  Run with `pytest -m gpu` on a
 Tolerances: the north star asks for 1e-4 relative on log-likelihood and posterior-mean
 effects; integer/index structure is exact.  Tighter bounds are used where the arithmetic
 allows (f64 tree, f32 sparse sums)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -488,6 +490,57 @@ def test_deterministic_mode_is_bitwise_reproducible(P, ctx, lm_fixture, prep_fix
         assert np.array_equal(a, b)
     assert np.array_equal(fits[0][1][1], fits[1][1][1])  # the E[lp] trace too
     s.set_deterministic(False)
+
+
+def test_deterministic_gradients_do_not_depend_on_the_tile_schedule():
+    """Round 5: the deterministic mode draws its tiles from the global counter like the default (only lp keeps the static lists).  A
+    tile's sums go to the TILE's slot in wave order and a transcript's slots are added in tile order, so which workgroup took
+    which tile must not show: gradient-only passes over a sample of ~3 000 tiles, repeated (the draws differ from launch to
+    launch), give the same bits, and the same bits as a process that runs the static lists (POLEE_DET_STATIC=1).  The sample has
+    699 rows of more than 32 transcripts (stream B, the per-tile kernel): until this test they added with float atomics and one
+    gradient entry moved by an ulp between launches, whatever the schedule; in this mode the kernel now gives a tile to one wave and
+    stores its sums to the tile's slots (psell_tile_body).  Passes with lp are compared too."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import polee_amd as P
+from tools import synth
+smp = synth.make_sample(20000, 3000000, 8.0, 77, literal=True)
+c, r, v = synth.to_csc(smp)
+ctx = P.Context(0)
+s = P.RNASeqSample(smp["m"], smp["n"], c, r, v, ctx=ctx)
+assert s.info["stream_rows"][5] > 0  # (rows of more than 32 transcripts, stream B: one wave per tile and the tile's slots in this mode)
+assert s.info["stream_rows"][6] == 0  # (stream C -- rows without any structure -- adds with float atomics: outside the guarantee)
+s.set_deterministic(True)
+x = np.random.default_rng(5).dirichlet(np.ones(smp["n"]), size=6).astype(np.float32)
+hs = set()
+for _ in range(6):
+    lp, g = s.log_likelihood(x, gradonly=True)
+    hs.add(hashlib.sha256(np.ascontiguousarray(g).tobytes()).hexdigest())
+assert len(hs) == 1, hs
+hl = set()
+for _ in range(4):  # with lp (the static lists): value and gradient, bit for bit
+    lp, g = s.log_likelihood(x)
+    hl.add(hashlib.sha256(np.ascontiguousarray(g).tobytes() + np.ascontiguousarray(lp).tobytes()).hexdigest())
+assert len(hl) == 1, hl
+print("HASH", hs.pop(), s.info["num_tiles"])
+""" % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."),)
+    out = []
+    for static in (False, True):
+        env = dict(os.environ)
+        env.pop("POLEE_DET_STATIC", None)
+        if static:
+            env["POLEE_DET_STATIC"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+        assert int(line[2]) > 900  # (enough tiles for the schedules to differ)
+        out.append(line[1])
+    assert out[0] == out[1], out
 
 
 def _expected_loglik(so, to, mu, omega, alpha, efflens, ndraws, seed):
