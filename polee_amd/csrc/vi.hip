@@ -186,7 +186,13 @@ struct polee_vi {
     LoglikRemap remap{nullptr, nullptr, nullptr, nullptr, false};
     DevBuf<double> d_ys, d_lyy, d_uleaf, d_part_c, d_part_ladj, d_csum, d_lp, d_ladj_el, d_rows, d_elbo, d_lptrace;
     DevBuf<dd> d_C;
-    DevBuf<unsigned int> d_bwd_sync;  // the fused backward launch's epoch, finish count and per-chunk flags (vi_bwd_fused_kernel)
+    // backward (vi_bwd_local_kernel): the chunks' totals / offsets, the first node of every chunk's run, the prefix rows that
+    // chunk-crossing nodes read (bit per leaf position), the subtree sums of the nodes inside one chunk [2][K][n-1]
+    DevBuf<dd> d_chunk_bu;
+    DevBuf<int32_t> d_node_start;
+    DevBuf<uint32_t> d_need;
+    DevBuf<double> d_H;
+    int32_t bu_ch = 0;
     DevBuf<int> d_flag;
     // gene_noninformative (opts.gene_of): gene of every transcript, members per gene, per-gene sums of a step
     DevBuf<int32_t> d_gene_of;
@@ -217,10 +223,9 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     if (vi->leaf_order) lview.leaf_tid = nullptr;
     const LoglikRemap *remap = vi->leaf_order ? &vi->remap : nullptr;
     const uint32_t *index_of = vi->leaf_order ? vi->d_index_of.p : nullptr;
-    const int nch_f = scan_num_chunks(t->TL), nch_b = scan_num_chunks(n);
+    const int nch_f = scan_num_chunks(t->TL);
     const float *eff = o.use_efflen_jacobian ? vi->d_efflens.p : nullptr;
     VK<K> *chunk_f = reinterpret_cast<VK<K> *>(t->d_chunk.p);
-    VD<K> *chunk_b = reinterpret_cast<VD<K> *>(t->d_chunk.p);
     const NoiseSrc noise = vi->noise();
 
     // sample
@@ -234,7 +239,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     }
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
     // (up to 2048 chunks every apply workgroup sums the totals of the chunks before it itself: no spine launch)
-    const int own_f = nch_f <= 2048, own_b = nch_b <= 2048;
+    const int own_f = nch_f <= 2048;
     const bool open_lists = vi->d_open_ptr.p != nullptr;
     // (Experiment, POLEE_VI_XWIN_FOLD=1: the forward kernel also writes the sparse pass's x windows through the slot lists,
     // so that the gather launch in front of the pass goes.  Measured at C2: the pass loses its 6.9 us gather, the forward
@@ -256,6 +261,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
                        xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
                        xwin_here ? vi->ll->d_xwin.p : nullptr,
                        remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
+    if (eff) hipLaunchKernelGGL((vi_csum_finish_kernel<K>), dim3(1), dim3(256), 0, st, (const double *)vi->d_part_c.p, nch_f, vi->d_csum.p);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
@@ -278,19 +284,41 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         hipLaunchKernelGGL((vi_gene_sums_kernel<K>), dim3((unsigned)ceil_div((int64_t)n, 256)), dim3(256), 0, st, vi->d_x.p,
                            vi->d_efflens.p, vi->d_part_c.p, nch_f, (int64_t)n, gp, vi->d_gene_c.p);
     }
-    // backward: double-double prefix over leaves of u * (g - efflen term)
-    // (POLEE_VI_BWD_FUSED=1: reduce and apply in one launch -- its workgroups wait for each other's totals, so all of them must
-    // be resident: up to 4 per CU)
-    static const bool bwd_fused_env = getenv("POLEE_VI_BWD_FUSED") != nullptr && atoi(getenv("POLEE_VI_BWD_FUSED")) != 0;
-    if (bwd_fused_env && own_b && nch_b <= 4 * ctx->num_cus) {
-        hipLaunchKernelGGL((vi_bwd_fused_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p, eff, vi->d_part_c.p,
-                           nch_f, vi->d_csum.p, gp, chunk_b, vi->d_bwd_sync.p, vi->d_C.p);
-    } else {
-        hipLaunchKernelGGL((vi_bwd_reduce_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
-                           eff, vi->d_part_c.p, nch_f, vi->d_csum.p, gp, chunk_b);
-        if (!own_b) hipLaunchKernelGGL((scan_spine_kernel<VD<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_b, nch_b);
-        hipLaunchKernelGGL((vi_bwd_apply_kernel<K>), dim3(nch_b), dim3(SCAN_THREADS), 0, st, lview, vi->d_uleaf.p, vi->d_g.p,
-                           eff, vi->d_csum.p, gp, chunk_b, vi->d_C.p, own_b);
+    // backward + update: the chunk-local double-double prefix of u * (g - efflen term), the chunks' offsets, the update
+    AdamConsts a;
+    // adam_learning_rate(step_num - 1) (likelihood-approximation.jl:107-110, 497)
+    a.lr = std::max(o.adam_min_learning_rate,
+                    o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));
+    a.rm = o.adam_rm;
+    a.rv = o.adam_rv;
+    a.eps = o.adam_eps;
+    a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
+    a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
+    a.inv_m_denom = 1.0 / a.m_denom;
+    a.inv_v_denom = 1.0 / a.v_denom;
+    a.max_mu = o.max_mu_step;
+    a.max_omega = o.max_omega_step;
+    a.max_alpha = o.max_alpha_step;
+    a.first = step_num == 1;
+    // the update also draws the next iteration's samples (one launch and one pass over the parameters less),
+    // unless the caller's noise table ends here
+    const bool sample_next = apply && !(o.z0 && step_num + 1 > o.num_steps);
+    const UpdArgs ua{vi->d_ys.p, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p, vi->d_vm.p, vi->d_mo.p, vi->d_vo.p,
+                     vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p, hook_outputs ? vi->d_ygrad.p : nullptr,
+                     hook_outputs ? vi->d_mug.p : nullptr, hook_outputs ? vi->d_omg.p : nullptr,
+                     hook_outputs ? vi->d_alg.p : nullptr, sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p, vi->d_zcur.p, step_num};
+    {
+        const int nch_bu = (int)ceil_div((int64_t)n, bu_ch<K>());
+        VD<K> *chunk_bu = reinterpret_cast<VD<K> *>(vi->d_chunk_bu.p);
+        const BwdArgs<K> ba{lview, vi->d_uleaf.p, vi->d_g.p, eff, vi->d_csum.p, gp, chunk_bu, vi->d_C.p, (const uint32_t *)vi->d_need.p,
+                            (const int32_t *)vi->d_node_start.p, vi->d_H.p};
+        hipLaunchKernelGGL((vi_bwd_local_kernel<K>), dim3(nch_bu), dim3(256), 0, st, ba);
+        if (nm1 > 0) {
+            hipLaunchKernelGGL((vi_bwd_spine_kernel<K>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_bu, nch_bu);
+            hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
+                               (const double *)vi->d_H.p, (const VD<K> *)chunk_bu, (const dd *)vi->d_C.p, ua, noise);
+        }
+        if (nm1 > 0) vi->ahead_step = apply ? (sample_next ? step_num + 1 : 0) : step_num;
     }
     POLEE_KERNEL_CHECK(ctx);
     if (want_values) {
@@ -302,35 +330,6 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         hipLaunchKernelGGL(vi_xgrad_rows_kernel, dim3((unsigned)ceil_div((int64_t)n * K, 256)), dim3(256), 0, st,
                            vi->d_g.p, eff, vi->d_csum.p, gp, K, (int64_t)n, vi->d_xgrad_rows.p, index_of);
         POLEE_KERNEL_CHECK(ctx);
-    }
-    // update
-    if (nm1 > 0) {
-        AdamConsts a;
-        // adam_learning_rate(step_num - 1) (likelihood-approximation.jl:107-110, 497)
-        a.lr = std::max(o.adam_min_learning_rate,
-                        o.adam_initial_learning_rate * std::exp(-o.adam_learning_rate_decay * (double)(step_num - 1)));
-        a.rm = o.adam_rm;
-        a.rv = o.adam_rv;
-        a.eps = o.adam_eps;
-        a.m_denom = 1 - std::pow(o.adam_rm, (double)step_num);
-        a.v_denom = 1 - std::pow(o.adam_rv, (double)step_num);
-        a.inv_m_denom = 1.0 / a.m_denom;
-        a.inv_v_denom = 1.0 / a.v_denom;
-        a.max_mu = o.max_mu_step;
-        a.max_omega = o.max_omega_step;
-        a.max_alpha = o.max_alpha_step;
-        a.first = step_num == 1;
-        // the update also draws the next iteration's samples (one launch and one pass over the parameters less),
-        // unless the caller's noise table ends here
-        const bool sample_next = apply && !(o.z0 && step_num + 1 > o.num_steps);
-        hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
-                           vi->d_ys.p, vi->d_C.p, noise, step_num, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p,
-                           vi->d_vm.p, vi->d_mo.p, vi->d_vo.p, vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p,
-                           hook_outputs ? vi->d_ygrad.p : nullptr, hook_outputs ? vi->d_mug.p : nullptr,
-                           hook_outputs ? vi->d_omg.p : nullptr, hook_outputs ? vi->d_alg.p : nullptr,
-                           sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p, vi->d_zcur.p);
-        POLEE_KERNEL_CHECK(ctx);
-        vi->ahead_step = apply ? (sample_next ? step_num + 1 : 0) : step_num;
     }
     if (want_values && apply && vi->step < vi->trace_cap) {
         hipLaunchKernelGGL(vi_trace_kernel, dim3(1), dim3(64), 0, st, vi->d_lp.p, vi->d_ladj_el.p, vi->d_rows.p, K,
@@ -571,13 +570,33 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         const size_t nch = (size_t)std::max(scan_num_chunks(3 * (int64_t)n - 2), 1);
         A(vi->d_part_c.alloc(ctx, nch * K));
         A(vi->d_part_ladj.alloc(ctx, nch * K));
-        A(vi->d_csum.alloc(ctx, PSELL_MAX_K));
-        // (the fused backward launch's epoch / finish count / per-chunk flags: vi_bwd_fused_kernel)
-        const size_t nsync = (size_t)std::max(scan_num_chunks((int64_t)n), 1) + 2;
-        A(vi->d_bwd_sync.alloc(ctx, nsync));
-        std::vector<unsigned int> init(nsync, 0u);
-        init[0] = 1u;
-        A(vi->d_bwd_sync.upload(ctx, init.data(), init.size()));
+        A(vi->d_csum.alloc(ctx, 2 * PSELL_MAX_K));
+    }
+    {   // backward tables (vi_bwd_local_kernel): internal nodes in DFS pre-order have non-decreasing lo
+        const PttPlan &pl = t->plans[0];
+        const int CH = K <= 6 ? bu_ch<6>() : bu_ch<8>();
+        vi->bu_ch = CH;
+        const int nch_bu = (int)ceil_div((int64_t)n, CH);
+        std::vector<int32_t> node_start((size_t)nch_bu + 1, (int32_t)(n - 1));
+        std::vector<uint32_t> need((n + 1 + 31) / 32 + 1, 0u);
+        bool monotone = true;
+        int c = 0;
+        for (size_t k = 0; k + 1 < n; ++k) {
+            if (k > 0 && pl.lo[k] < pl.lo[k - 1]) monotone = false;
+            for (; c <= pl.lo[k] / CH; ++c) node_start[(size_t)c] = (int32_t)k;
+            const int64_t end = std::min<int64_t>(((int64_t)pl.lo[k] / CH + 1) * CH, (int64_t)n);
+            if (pl.hi1[k] > end)
+                for (int32_t b : {pl.lo[k], pl.mid[k], pl.hi1[k]}) need[(size_t)b >> 5] |= 1u << (b & 31);
+        }
+        if (!monotone) A(fail(ctx, POLEE_ERR_BAD_ARG, "tree plan: internal nodes are not in DFS pre-order"));
+        A(vi->d_node_start.upload(ctx, node_start));
+        A(vi->d_need.upload(ctx, need));
+        A(vi->d_chunk_bu.alloc(ctx, ((size_t)nch_bu + 1) * K));
+        A(vi->d_H.alloc(ctx, 2 * K * nm1));
+        // (row n of C is exported by the kernel when a node needs it, unless n is a multiple of the chunk size: then it is the
+        // zero first row of a chunk past the end)
+        if (s == POLEE_OK && hipMemsetAsync(vi->d_C.p, 0, sizeof(dd) * (n + 1) * K, ctx->stream) != hipSuccess)
+            A(fail(ctx, POLEE_ERR_HIP, "memset failed"));
     }
     {   // The forward scan's chunk offsets from the tree (vi_fwd_apply_kernel): for every chunk of the Euler tour the ENTER
         // entries still open at its first entry = the path from the root to that point.  One walk over the tour with a

@@ -478,76 +478,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
     }
 }
 
-// backward reduce AND apply in one launch (POLEE_VI_BWD_FUSED=1): every workgroup publishes its chunk's total, waits for the
-// totals of the chunks before it (they are all resident: a few hundred workgroups), and goes on with the values still in its
-// registers -- the same arithmetic in the same order as the two launches.  sync[0] = the launch's epoch (the workgroup that
-// finishes last advances it), sync[1] = workgroups finished, sync[2 + b] = epoch at which chunk b's total was published.
-template <int K>
-__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_fused_kernel(PttView v, const double *__restrict__ uleaf, const float *__restrict__ g,
-                                                                   const float *__restrict__ efflens, const double *__restrict__ part_c,
-                                                                   int nchunks_fwd, double *__restrict__ csum_out, GenePrior gp,
-                                                                   VD<K> *chunk_sums, unsigned int *sync, dd *__restrict__ C)
-{
-    __shared__ VD<K> smem[SCAN_THREADS / 64];
-    __shared__ double smd[4 * K];
-    const unsigned int epoch = __atomic_load_n(&sync[0], __ATOMIC_RELAXED);
-    double c[K];
-#pragma unroll
-    for (int d = 0; d < K; ++d) c[d] = 0.0;
-    if (efflens) {
-        for (int ch = threadIdx.x; ch < nchunks_fwd; ch += SCAN_THREADS)
-#pragma unroll
-            for (int d = 0; d < K; ++d) c[d] += part_c[(size_t)ch * K + d];
-        block_sum_vec<K>(c, smd);
-        if (blockIdx.x == 0) store_vec_by_thread<K>(c, csum_out);
-    } else {
-#pragma unroll
-        for (int d = 0; d < K; ++d) c[d] = 1.0;
-    }
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-    VD<K> val[SCAN_ITEMS];
-    VD<K> acc = ScanOps<VD<K>>::zero();
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < v.n)
-            bwd_values<K>(v, base + j, uleaf, g, efflens, c, gp, val[j]);
-        else
-            val[j] = ScanOps<VD<K>>::zero();
-        acc = ScanOps<VD<K>>::add(acc, val[j]);
-    }
-    VD<K> tot;
-    VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
-    if (threadIdx.x == 0) {
-        chunk_sums[blockIdx.x] = tot;
-        __atomic_store_n(&sync[2 + blockIdx.x], epoch, __ATOMIC_RELEASE);
-    }
-    // the totals of the chunks before this one
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS)
-        while (__atomic_load_n(&sync[2 + i], __ATOMIC_ACQUIRE) != epoch) __builtin_amdgcn_s_sleep(1);
-    __syncthreads();
-    off = ScanOps<VD<K>>::add(chunk_prefix<VD<K>>(chunk_sums, blockIdx.x, smem), off);
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < v.n) {
-#pragma unroll
-            for (int d = 0; d < K; ++d) C[(size_t)(base + j) * K + d] = off.v[d];
-        }
-        off = ScanOps<VD<K>>::add(off, val[j]);
-        if (base + j == v.n - 1) {
-#pragma unroll
-            for (int d = 0; d < K; ++d) C[(size_t)v.n * K + d] = off.v[d];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int done = __atomic_add_fetch(&sync[1], 1u, __ATOMIC_ACQ_REL);
-        if (done == gridDim.x) {
-            __atomic_store_n(&sync[1], 0u, __ATOMIC_RELAXED);
-            __atomic_store_n(&sync[0], epoch + 1u == 0u ? 1u : epoch + 1u, __ATOMIC_RELEASE);
-        }
-    }
-}
-
 struct AdamConsts {
     double lr, rm, rv, eps, m_denom, v_denom;
     double inv_m_denom, inv_v_denom;  // reciprocals, computed once on the host (the update kernel is bound by its f64 instructions)
@@ -572,44 +502,50 @@ __device__ inline void adam_one(float &p, float &m, float &v, float grad, const 
     p = (float)((double)p + delta);
 }
 
-// update: one thread per internal node k, all K draws.
+// Everything the per-node update needs besides the node's two subtree sums.
+struct UpdArgs {
+    double *ys;
+    float *mu, *omega, *alpha, *m_mu, *v_mu, *m_omega, *v_omega, *m_alpha, *v_alpha;
+    AdamConsts adam;
+    int apply;
+    int *nonfinite_step;
+    double *y_grad_out;
+    float *mu_grad_out, *omega_grad_out, *alpha_grad_out;
+    int sample_next;
+    double y_eps;
+    double *lyy;
+    float *zcur;
+    int step;
+};
+
+// update of internal node k, all K draws.  hr[d] / hl[d] = sum of u * x_grad over the leaves of the node's right / left
+// subtree for draw d (leaf positions [lo, mid) / [mid, hi1)).
 //   y_grad[k] = H_l / y - H_r / (1 - y)   (closed form of ptt.jl:167-209, see ptt.hip)
 //   logit_normal_transform_gradients! (logitnormal.jl:38-55),
 //   sinh_asinh_transform_gradients! (sinh_arcsinh.jl:29-38) with cosh(c) = sqrt(1+zs^2), tanh(c) = zs/cosh(c),
 //   omega_grad += sigma * sigma_grad (likelihood-approximation.jl:547-549), / K (:552-557), ADAM.
 template <int K, typename Noise>
-__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys, const dd *__restrict__ C, Noise noise,
-                                                         int step,
-                                                         float *mu, float *omega, float *alpha, float *m_mu, float *v_mu,
-                                                         float *m_omega, float *v_omega, float *m_alpha, float *v_alpha,
-                                                         AdamConsts adam, int apply, int *nonfinite_step,
-                                                         double *y_grad_out, float *mu_grad_out, float *omega_grad_out,
-                                                         float *alpha_grad_out, int sample_next, double y_eps, double *lyy,
-                                                         float *zcur)
+__device__ inline void update_node(const UpdArgs &A, const Noise &noise, int64_t k, int lo, int mid, int hi1, const double (&hr)[K],
+                                   const double (&hl)[K])
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nm1 = v.n - 1;
-    if (k >= nm1) return;
-    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    const int64_t nm1 = noise.nm1;
     const double cnt_r = (double)(mid - lo - 1), cnt_l = (double)(hi1 - mid - 1);
-    const float muk = mu[k], omk = omega[k], alk = alpha[k];
+    const float muk = A.mu[k], omk = A.omega[k], alk = A.alpha[k];
     const float sigma = expf(omk), sa = sinhf(alk), ca = coshf(alk);
-    const dd *Clo = C + (size_t)lo * K, *Cmid = C + (size_t)mid * K, *Chi = C + (size_t)hi1 * K;
     float mu_g = 0.f, om_g = 0.f, al_g = 0.f;
     float p_mu = muk, p_om = omk, p_al = alk;
 #pragma unroll
     for (int d = 0; d < K; ++d) {
-        const dd cm = Cmid[d];
-        const double Hr = cnt_r + dd_diff(cm, Clo[d]);
-        const double Hl = cnt_l + dd_diff(Chi[d], cm);
-        const double y = ys[k * K + d];
+        const double Hr = cnt_r + hr[d];
+        const double Hl = cnt_l + hl[d];
+        const double y = A.ys[k * K + d];
         const double dyy = y * (1 - y);
         // H_l / y - H_r / (1 - y) over the common denominator: one f64 division per draw instead of two (the kernel is
         // bound by the f64 instructions it issues; a division is 14 of them)
         const double ygd = (Hl * (1 - y) - Hr * y) / dyy;
-        if (y_grad_out) y_grad_out[(int64_t)d * nm1 + k] = ygd;
+        if (A.y_grad_out) A.y_grad_out[(int64_t)d * nm1 + k] = ygd;
         const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
-        const float z0 = zcur[k * K + d];  // this iteration's draw, left by the sampling step
+        const float z0 = A.zcur[k * K + d];  // this iteration's draw, left by the sampling step
         const float zs = sinh_asinh(sa, ca, z0);
         const float cc = sqrtf(fmaf(zs, zs, 1.0f));  // cosh(alpha + asinh z0)
         mu_g = (float)((double)mu_g + dyy * (double)yg);  // mu_grad accumulates across draws in f32
@@ -625,29 +561,247 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, double *ys,
     mu_g /= (float)K;
     om_g /= (float)K;
     al_g /= (float)K;
-    if (mu_grad_out) mu_grad_out[k] = mu_g;
-    if (omega_grad_out) omega_grad_out[k] = om_g;
-    if (alpha_grad_out) alpha_grad_out[k] = al_g;
+    if (A.mu_grad_out) A.mu_grad_out[k] = mu_g;
+    if (A.omega_grad_out) A.omega_grad_out[k] = om_g;
+    if (A.alpha_grad_out) A.alpha_grad_out[k] = al_g;
     // (the gradient test hook, apply == 0, reports its gradients to the caller and must not leave a flag behind for a
     // step that was never applied)
-    if (apply && !(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(nonfinite_step, 0, step);
-    if (apply) {
-        float p = muk, mm = m_mu[k], vv = v_mu[k];
-        adam_one(p, mm, vv, mu_g, adam, adam.max_mu);
-        mu[k] = p; m_mu[k] = mm; v_mu[k] = vv;
+    if (A.apply && !(isfinite(mu_g) && isfinite(om_g) && isfinite(al_g))) atomicCAS(A.nonfinite_step, 0, A.step);
+    if (A.apply) {
+        float p = muk, mm = A.m_mu[k], vv = A.v_mu[k];
+        adam_one(p, mm, vv, mu_g, A.adam, A.adam.max_mu);
+        A.mu[k] = p; A.m_mu[k] = mm; A.v_mu[k] = vv;
         p_mu = p;
-        p = omk; mm = m_omega[k]; vv = v_omega[k];
-        adam_one(p, mm, vv, om_g, adam, adam.max_omega);
-        omega[k] = p; m_omega[k] = mm; v_omega[k] = vv;
+        p = omk; mm = A.m_omega[k]; vv = A.v_omega[k];
+        adam_one(p, mm, vv, om_g, A.adam, A.adam.max_omega);
+        A.omega[k] = p; A.m_omega[k] = mm; A.v_omega[k] = vv;
         p_om = p;
-        p = alk; mm = m_alpha[k]; vv = v_alpha[k];
-        adam_one(p, mm, vv, al_g, adam, adam.max_alpha);
-        alpha[k] = p; m_alpha[k] = mm; v_alpha[k] = vv;
+        p = alk; mm = A.m_alpha[k]; vv = A.v_alpha[k];
+        adam_one(p, mm, vv, al_g, A.adam, A.adam.max_alpha);
+        A.alpha[k] = p; A.m_alpha[k] = mm; A.v_alpha[k] = vv;
         p_al = p;
     }
     // look-ahead: the next iteration's draws from the parameters just written (this thread is the only one that
     // touches node k's ys / lyy, and its reads of ys[k] are done)
-    if (sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, step + 1, k, y_eps, ys, lyy, zcur, nullptr);
+    if (A.sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, A.step + 1, k, A.y_eps, A.ys, A.lyy, A.zcur, nullptr);
+}
+
+// ---- backward + update, round 6 ----------------------------------------------------------------------------------------
+// The backward pass used to be a GLOBAL double-double prefix over the leaves (a reduce launch for the chunk totals, an apply
+// launch that re-read the leaves and added every chunk's offset, 19 MB of prefix rows) and the update gathered three rows of
+// it per node.  Now:
+//   vi_bwd_local_kernel : a workgroup owns a chunk of bu_ch(K) leaves.  It builds the chunk's LOCAL exclusive double-double
+//                         prefix in LDS (no offset from the chunks before it: nothing to wait for, one read of the leaves).
+//                         Internal nodes in DFS pre-order have non-decreasing lo, so the nodes whose leaf range STARTS in the
+//                         chunk are one run of k (node_start): for every node of the run whose range also ENDS in the chunk
+//                         the workgroup takes the two subtree sums as differences of LDS rows and writes them, draw-major,
+//                         to H -- two doubles per node and draw, read back coalesced by the update.  Subtree sums inside a
+//                         chunk never see a prefix that left the workgroup.
+//   vi_bwd_spine_kernel : the chunks' totals -> exclusive chunk offsets (one workgroup).
+//   vi_update_k_kernel  : a thread per node.  The few nodes whose range crosses a chunk boundary (about chunks x depth of them)
+//                         take prefix(b) = off[chunk of b] + row b, from the rows the first kernel exported for them
+//                         (need bits: a static set of the tree).
+// Depth-independent like the scan it replaces: a caterpillar tree sends (almost) every node down the second path.
+template <int K>
+__host__ __device__ constexpr int bu_ch() { return K <= 6 ? 512 : 256; }  // leaves per workgroup (LDS: (ch + 1) K 16 B)
+
+template <int K>
+struct BwdArgs {
+    PttView v;  // (leaf-order view)
+    const double *uleaf;
+    const float *g, *efflens;
+    const double *csum;  // [2][K]: sum x / efflen and its reciprocal (vi_csum_finish)
+    GenePrior gp;
+    VD<K> *chunk_tot;          // [nch + 1] the chunks' totals; the spine turns them into exclusive offsets, [nch] = all leaves
+    dd *C;                     // [n + 1][K] chunk-local exclusive prefix rows, written only where need says so
+    const uint32_t *need;      // bit pos: row pos is read by a node that crosses chunks
+    const int32_t *node_start; // [nch + 1] first node k whose lo lies in chunk c
+    double *H;                 // [2][K][n - 1] sums over the right / left subtree's leaves, nodes inside one chunk
+};
+
+// sums x / efflen over the forward pass's per-chunk partials: out[d] = sum, out[K + d] = 1 / sum.  Runs as one extra workgroup
+// of the sparse pass's x-window gather (loglik.hip) or, without that launch, on its own.
+template <int K>
+__device__ inline void csum_finish_block(const double *__restrict__ part_c, int nparts, double *__restrict__ out, double *smem /* 4 K */)
+{
+    double c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) c[d] = 0.0;
+    for (int ch = threadIdx.x; ch < nparts; ch += 256)
+#pragma unroll
+        for (int d = 0; d < K; ++d) c[d] += part_c[(size_t)ch * K + d];
+    block_sum_vec<K>(c, smem);
+#pragma unroll
+    for (int d = 0; d < K; ++d)
+        if (threadIdx.x == d) {
+            out[d] = c[d];
+            out[K + d] = 1.0 / c[d];
+        }
+}
+template <int K>
+__global__ __launch_bounds__(256) void vi_csum_finish_kernel(const double *__restrict__ part_c, int nparts, double *__restrict__ out)
+{
+    __shared__ double smd[4 * K];
+    csum_finish_block<K>(part_c, nparts, out, smd);
+}
+
+// a = u * x_grad at leaf position pos (bwd_values with the reciprocal of sum x / efflen at hand)
+template <int K>
+__device__ inline void bwd_leaf(const PttView &v, int64_t pos, const double *__restrict__ uleaf, const float *__restrict__ g,
+                                const float *__restrict__ efflens, const double *c, const double *inv_c, const GenePrior &gp,
+                                double (&a)[K])
+{
+    const int tid = v.leaf_tid ? v.leaf_tid[pos] : (int)pos;  // (leaf-order mode: see vi_fwd_apply_kernel)
+    const float inv_lf = efflens ? 1.0f / efflens[tid] : 0.0f;
+    const float nl = (float)v.n * inv_lf;  // Int * Float32 -> Float32 in the reference
+    int gene = -1, kg = 0;
+    if (gp.gene_of) {
+        gene = gp.gene_of[tid];
+        kg = gene >= 0 ? gp.gene_k[gene] : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        double xg = (double)g[(size_t)tid * K + d];
+        if (efflens) xg -= (double)nl * inv_c[d];
+        if (gp.gene_of) {
+            const double cc = c[d], inv_l = (double)inv_lf;
+            const double xlg = kg > 1 ? -(double)(kg - 1) / gp.gene_c[(size_t)gene * K + d] : 0.0;
+            xg += xlg * (inv_l / cc) + inv_l * (gp.M / (cc * cc));
+        }
+        a[d] = uleaf[(size_t)pos * K + d] * xg;
+    }
+}
+
+__device__ inline dd two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
+{
+    constexpr int CH = bu_ch<K>(), LPT = CH / 256;
+    __shared__ dd P[(CH + 1) * K];
+    __shared__ VD<K> wtot[4];
+    const PttView &v = B.v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double c[K], inv_c[K];
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        c[d] = B.efflens ? B.csum[d] : 1.0;
+        inv_c[d] = B.efflens ? B.csum[K + d] : 1.0;
+    }
+    const int64_t base = (int64_t)blockIdx.x * CH, p0 = base + (int64_t)threadIdx.x * LPT;
+    double a[LPT][K];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+        if (p0 + j < v.n)
+            bwd_leaf<K>(v, p0 + j, B.uleaf, B.g, B.efflens, c, inv_c, B.gp, a[j]);
+        else
+#pragma unroll
+            for (int d = 0; d < K; ++d) a[j][d] = 0.0;
+    }
+    VD<K> s;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        s.v[d] = dd_make(a[0][d]);
+        if constexpr (LPT == 2) s.v[d] = two_sum(a[0][d], a[1][d]);
+    }
+    const VD<K> inc = wave_inclusive_scan<VD<K>>(s);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    VD<K> off = ScanOps<VD<K>>::shfl_up(inc, 1);
+    if (lane == 0) off = ScanOps<VD<K>>::zero();
+    for (int w = 0; w < wave; ++w) off = ScanOps<VD<K>>::add(wtot[w], off);  // (wave-uniform trip count)
+    const bool exp0 = p0 <= v.n && ((B.need[p0 >> 5] >> (p0 & 31)) & 1u);
+#pragma unroll
+    for (int d = 0; d < K; ++d) P[(size_t)(threadIdx.x * LPT) * K + d] = off.v[d];
+    if (exp0)
+#pragma unroll
+        for (int d = 0; d < K; ++d) B.C[(size_t)p0 * K + d] = off.v[d];
+    if constexpr (LPT == 2) {
+        const int64_t p1 = p0 + 1;
+        const bool exp1 = p1 <= v.n && ((B.need[p1 >> 5] >> (p1 & 31)) & 1u);
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const dd o1 = dd_add(off.v[d], dd_make(a[0][d]));
+            P[(size_t)(threadIdx.x * LPT + 1) * K + d] = o1;
+            if (exp1) B.C[(size_t)p1 * K + d] = o1;
+        }
+    }
+    if (threadIdx.x == 255) {  // the chunk's total = the last thread's inclusive prefix
+        VD<K> tot;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            tot.v[d] = dd_add(off.v[d], s.v[d]);
+            P[(size_t)CH * K + d] = tot.v[d];
+        }
+        B.chunk_tot[blockIdx.x] = tot;
+    }
+    __syncthreads();
+    // the nodes whose range starts in this chunk and ends in it: both subtree sums from LDS rows
+    const int64_t end = min(base + CH, (int64_t)v.n), nm1 = (int64_t)v.n - 1;
+    const int32_t k1 = B.node_start[blockIdx.x + 1];
+    for (int32_t k = B.node_start[blockIdx.x] + (int32_t)threadIdx.x; k < k1; k += 256) {
+        const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+        if (hi1 > end) continue;
+        const dd *Plo = P + (size_t)(lo - base) * K, *Pmid = P + (size_t)(mid - base) * K, *Phi = P + (size_t)(hi1 - base) * K;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const dd pm = Pmid[d];
+            B.H[(size_t)d * nm1 + k] = dd_diff(pm, Plo[d]);
+            B.H[(size_t)(K + d) * nm1 + k] = dd_diff(Phi[d], pm);
+        }
+    }
+}
+
+// exclusive double-double scan of the chunks' totals, in place; [nch] = the sum over all leaves
+template <int K>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_spine_kernel(VD<K> *chunk_tot, int nch)
+{
+    __shared__ VD<K> smem[SCAN_THREADS / 64];
+    const int per = (nch + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int b = min((int)threadIdx.x * per, nch), e = min(b + per, nch);
+    VD<K> acc = ScanOps<VD<K>>::zero();
+    for (int i = b; i < e; ++i) acc = ScanOps<VD<K>>::add(acc, chunk_tot[i]);
+    VD<K> tot;
+    VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
+    for (int i = b; i < e; ++i) {
+        const VD<K> t = chunk_tot[i];
+        chunk_tot[i] = off;
+        off = ScanOps<VD<K>>::add(off, t);
+    }
+    if (threadIdx.x == 0) chunk_tot[nch] = tot;
+}
+
+// update: one thread per internal node k, all K draws
+template <int K, typename Noise>
+__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const double *__restrict__ H, const VD<K> *__restrict__ chunk_off,
+                                                         const dd *__restrict__ C, UpdArgs A, Noise noise)
+{
+    constexpr int CH = bu_ch<K>();
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nm1 = (int64_t)v.n - 1;
+    if (k >= nm1) return;
+    const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
+    double hr[K], hl[K];
+    if ((int64_t)hi1 <= min(((int64_t)lo / CH + 1) * CH, (int64_t)v.n)) {
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            hr[d] = H[(size_t)d * nm1 + k];
+            hl[d] = H[(size_t)(K + d) * nm1 + k];
+        }
+    } else {  // crosses chunks: a boundary's global prefix = its chunk's offset + its chunk-local row
+        const dd *Plo = C + (size_t)lo * K, *Pmid = C + (size_t)mid * K, *Phi = C + (size_t)hi1 * K;
+        const dd *Olo = chunk_off[lo / CH].v, *Omid = chunk_off[mid / CH].v, *Ohi = chunk_off[hi1 / CH].v;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const dd gm = dd_add(Omid[d], Pmid[d]);
+            hr[d] = dd_diff(gm, dd_add(Olo[d], Plo[d]));
+            hl[d] = dd_diff(dd_add(Ohi[d], Phi[d]), gm);
+        }
+    }
+    update_node<K, Noise>(A, noise, k, lo, mid, hi1, hr, hl);
 }
 
 // ---- point optimisation (OptimizePTTApprox, likelihood-approximation.jl:149-242), K = 1 ------------------
