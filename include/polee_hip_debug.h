@@ -91,6 +91,8 @@ polee_status polee_debug_regression_prior_pass(polee_regression *reg, const floa
 
 /* fast_log (csrc/scan.hpp), the double-precision log of the tree kernels, element-wise (tests check it against libm) */
 polee_status polee_debug_fast_log(polee_ctx *ctx, const double *x, int64_t count, double *out);
+/* fast_exp (csrc/scan.hpp), the double-precision exp of the VI loop's forward kernel (leaf u = exp of a path sum of edge logs) */
+polee_status polee_debug_fast_exp(polee_ctx *ctx, const double *x, int64_t count, double *out);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,11 @@ inline unsigned blocks(int64_t len) { return (unsigned)ceil_div(len, 256); }
 }  // namespace
 
 namespace polee {
+__global__ void fast_exp_kernel(double *x, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) x[i] = fast_exp(x[i]);
+}
 __global__ void fast_log_kernel(double *x, int64_t count)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,6 +352,18 @@ polee_status polee_gene_noninformative_prior(polee_ctx *ctx, const float *efflen
                        d_sums.p, d_sums.p + K, d_g.p);
     POLEE_KERNEL_CHECK(ctx);
     return d_g.download(ctx, x_grad, tot);
+}
+
+// test hook (include/polee_hip_debug.h): the forward kernel's double-precision exp, element-wise
+polee_status polee_debug_fast_exp(polee_ctx *ctx, const double *x, int64_t count, double *out)
+{
+    POLEE_TRY(use_device(ctx));
+    if (!x || !out || count < 1) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<double> d;
+    POLEE_TRY(d.upload(ctx, x, (size_t)count));
+    hipLaunchKernelGGL(fast_exp_kernel, dim3(blocks(count)), dim3(256), 0, ctx->stream, d.p, count);
+    POLEE_KERNEL_CHECK(ctx);
+    return d.download(ctx, out, (size_t)count);
 }
 
 // test hook (include/polee_hip_debug.h): the tree kernels' double-precision log, element-wise

@@ -1589,10 +1589,37 @@ extern "C" int polee_debug_read_stamps(unsigned long long *out)
 // start at multiples of 4 entries, so a tile's window starts 16-byte aligned).  One pass over 4 B x K per entry.
 template <int K>
 __global__ __launch_bounds__(256) void xwin_gather_kernel(const uint32_t *__restrict__ dict, const float *__restrict__ x,
-                                                         int64_t entries, float *__restrict__ xwin)
+                                                         int64_t entries, float *__restrict__ xwin,
+                                                         const double *__restrict__ side_part, int side_nparts,
+                                                         double *__restrict__ side_out)
 {
     // a thread per dictionary entry: K adjacent floats in, K adjacent floats out (8-byte accesses when K is even)
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = ((int64_t)blockIdx.x - (side_part ? 1 : 0)) * blockDim.x + threadIdx.x;
+    if (side_part && blockIdx.x == 0) {
+        // the caller's side job (polee_loglik::side_part), one workgroup in front of the gather's (it starts first): column sums of side_part in a fixed
+        // order (thread t adds rows t, t + 256, ...; a wave's 64 partial sums by a fixed shuffle tree, the four waves in order) and
+        // their reciprocals
+        __shared__ double sm[4 * K];
+        double c[K];
+#pragma unroll
+        for (int d = 0; d < K; ++d) c[d] = 0.0;
+        for (int r = threadIdx.x; r < side_nparts; r += 256)
+#pragma unroll
+            for (int d = 0; d < K; ++d) c[d] += side_part[(size_t)r * K + d];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) c[d] += __shfl_down(c[d], o, 64);
+            if ((threadIdx.x & 63) == 0) sm[(threadIdx.x >> 6) * K + d] = c[d];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < K) {
+            const double t = ((sm[threadIdx.x] + sm[K + threadIdx.x]) + sm[2 * K + threadIdx.x]) + sm[3 * K + threadIdx.x];
+            side_out[threadIdx.x] = t;
+            side_out[K + threadIdx.x] = 1.0 / t;
+        }
+        return;
+    }
     if (e >= entries) return;
     const float *src = x + (size_t)dict[e] * K;
     float *dst = xwin + (size_t)e * K;
@@ -2234,9 +2261,12 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         ll->dyn_base += (uint32_t)ll->dyn_positions;
     }
     // (DET: A.gwin / A.lpwin are the caller's, and so is the reduce launch behind this one and stream B's: launch_variant)
-    if (!ll->xwin_ready)
-        hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256)), dim3(256), 0, st, A.dict,
-                           A.x, ll->dict_len, ll->d_xwin.p);
+    if (!ll->xwin_ready) {
+        const bool side = ll->side_part != nullptr && !ll->side_done;
+        hipLaunchKernelGGL((xwin_gather_kernel<K>), dim3((unsigned)ceil_div(ll->dict_len, 256) + (side ? 1u : 0u)), dim3(256), 0, st, A.dict,
+                           A.x, ll->dict_len, ll->d_xwin.p, side ? ll->side_part : nullptr, ll->side_nparts, ll->side_out);
+        if (side) ll->side_done = true;
+    }
     if (ll->cur_e0) (void)hipEventRecord(ll->cur_e0, st);
     hipLaunchKernelGGL((loglik_stream_kernel<K, LP, KS, DET>), dim3((unsigned)G), dim3(256), lds, st, A, dbg);
     if (ll->cur_e1) (void)hipEventRecord(ll->cur_e1, st);

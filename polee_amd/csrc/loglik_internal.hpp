@@ -204,6 +204,13 @@ struct polee_loglik {
     bool device_built = false;  // the slice stream was laid out on the device (psell_device.hip)
     bool force_mixed = false;  // debug: process every slice with the mixed-slice kernel
     bool xwin_ready = false;   // (per call) the x windows are already filled
+    // (per call) a small job of the caller's that rides along with the x-window gather as one extra workgroup: out[d] = sum
+    // over nparts rows of part[.][d], out[K + d] = its reciprocal (the VI loop's sum x / efflen).  side_done tells the caller
+    // whether a launch took it.
+    const double *side_part = nullptr;
+    int side_nparts = 0;
+    double *side_out = nullptr;
+    bool side_done = false;
     polee::PsellHost host;  // metadata kept; bulk vectors are released after upload unless debugging
     polee::DevBuf<uint8_t> d_data;
     polee::DevBuf<uint32_t> d_slice_off, d_tile_slice, d_tile_dict, d_dict;

@@ -33,14 +33,15 @@ __device__ inline void philox_randn4(uint64_t seed, uint32_t step, uint32_t grou
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        // Box-Muller on two 24-bit uniforms in (0,1)
+        // Box-Muller on two 24-bit uniforms in (0,1), on the hardware's transcendental units: v_log_f32 (log2), v_sqrt_f32 and
+        // v_sin_f32 / v_cos_f32, which take their argument in revolutions -- sin(2 pi u2) is v_sin_f32(u2), no range reduction.
+        // (~1e-6 absolute on a draw: noise, not arithmetic the reference defines; libm's logf + sincosf were ~250 instructions
+        // per node of the VI update, a tenth of the kernel)
         const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float r = sqrtf(-2.0f * logf(u1));
-        float sn, cs;
-        sincosf(6.28318530717958647692f * u2, &sn, &cs);
-        z[2 * h] = r * cs;
-        z[2 * h + 1] = r * sn;
+        const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __log2f(u1));  // sqrt(-2 ln u1)
+        z[2 * h] = r * __builtin_amdgcn_cosf(u2);
+        z[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
     }
 }
 __device__ inline float philox_randn(uint64_t seed, uint32_t step, uint32_t draw, uint32_t k)

@@ -175,6 +175,7 @@ struct polee_vi {
     polee_comm *comm = nullptr;  // row-sharded fit: sum the likelihood gradient (and lp) over ranks each pass
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<float> d_zcur;  // [n-1][K] the current iteration's N(0,1) draws
+    DevBuf<float> d_y32;   // [n-1][K] and the logistic values they give (sample_node)
     DevBuf<uint32_t> d_open_ptr, d_open_code;  // per forward-scan chunk: the tour's ENTER entries still open at its start
     // Leaf-order mode (round 4): this fit numbers the transcripts by their position among the tree's leaves.  d_x, d_g,
     // d_efflens and d_gene_of are indexed by leaf position -- the tree kernels' accesses to them are contiguous where
@@ -233,13 +234,14 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // (skipped when the previous update already drew this step's samples, see below)
     if (nm1 > 0 && (vi->ahead_step != step_num || want_values)) {
         hipLaunchKernelGGL((vi_sample_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st,
-                           vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, noise, step_num, o.y_eps, vi->d_ys.p, vi->d_lyy.p,
+                           vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, noise, step_num, vi->d_y32.p,
                            vi->d_zcur.p, want_values ? vi->d_ladj_el.p : nullptr);
         POLEE_KERNEL_CHECK(ctx);
     }
     // forward: xs = clamp(transform!(ys)) (likelihood-approximation.jl:525-526); also zeroes g
     // (up to 2048 chunks every apply workgroup sums the totals of the chunks before it itself: no spine launch)
     const int own_f = nch_f <= 2048;
+    const YRows ysrc{vi->d_y32.p, o.y_eps};
     const bool open_lists = vi->d_open_ptr.p != nullptr;
     // (Experiment, POLEE_VI_XWIN_FOLD=1: the forward kernel also writes the sparse pass's x windows through the slot lists,
     // so that the gather launch in front of the pass goes.  Measured at C2: the pass loses its 6.9 us gather, the forward
@@ -249,28 +251,36 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     if (open_lists) {
         // (the chunks' offsets come from the tree's open-edge lists: no reduce launch)
     } else if (nch_f > 1) {
-        hipLaunchKernelGGL((vi_fwd_reduce_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
+        hipLaunchKernelGGL((vi_fwd_reduce_kernel<K, YRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, ysrc, chunk_f);
         if (!own_f) hipLaunchKernelGGL((scan_spine_kernel<VK<K>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
     } else {
         POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
     }
-    hipLaunchKernelGGL((vi_fwd_apply_kernel<K>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, vi->d_lyy.p, chunk_f,
+    hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
                        vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
                        eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
                        (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
                        xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
                        xwin_here ? vi->ll->d_xwin.p : nullptr,
                        remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
-    if (eff) hipLaunchKernelGGL((vi_csum_finish_kernel<K>), dim3(1), dim3(256), 0, st, (const double *)vi->d_part_c.p, nch_f, vi->d_csum.p);
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
     {
         const bool det_saved = vi->ll->deterministic;
         if (o.deterministic) vi->ll->deterministic = true;
+        // (sum x / efflen over the forward kernel's per-chunk partials rides along with the pass's x-window gather)
+        vi->ll->side_part = eff ? vi->d_part_c.p : nullptr;
+        vi->ll->side_nparts = nch_f;
+        vi->ll->side_out = vi->d_csum.p;
+        vi->ll->side_done = false;
         const polee_status ls = loglik_eval_device(vi->ll, vi->d_x.p, K, vi->d_g.p, want_values ? vi->d_lp.p : nullptr, xwin_here, remap);
         vi->ll->deterministic = det_saved;
+        const bool side_done = vi->ll->side_done;
+        vi->ll->side_part = nullptr;
         POLEE_TRY(ls);
+        if (eff && !side_done)  // (a pass without the gather launch)
+            hipLaunchKernelGGL((vi_csum_finish_kernel<K>), dim3(1), dim3(256), 0, st, (const double *)vi->d_part_c.p, nch_f, vi->d_csum.p);
     }
     if (vi->comm) {  // this rank saw only its block of fragments: x_grad and lp are sums over fragments
         POLEE_TRY(comm_allreduce_device(vi->comm, vi->d_g.p, (size_t)n * K, false));
@@ -303,10 +313,10 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     // the update also draws the next iteration's samples (one launch and one pass over the parameters less),
     // unless the caller's noise table ends here
     const bool sample_next = apply && !(o.z0 && step_num + 1 > o.num_steps);
-    const UpdArgs ua{vi->d_ys.p, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p, vi->d_vm.p, vi->d_mo.p, vi->d_vo.p,
+    const UpdArgs ua{vi->d_y32.p, vi->d_mu.p, vi->d_omega.p, vi->d_alpha.p, vi->d_mm.p, vi->d_vm.p, vi->d_mo.p, vi->d_vo.p,
                      vi->d_ma.p, vi->d_va.p, a, apply ? 1 : 0, vi->d_flag.p, hook_outputs ? vi->d_ygrad.p : nullptr,
                      hook_outputs ? vi->d_mug.p : nullptr, hook_outputs ? vi->d_omg.p : nullptr,
-                     hook_outputs ? vi->d_alg.p : nullptr, sample_next ? 1 : 0, o.y_eps, vi->d_lyy.p, vi->d_zcur.p, step_num};
+                     hook_outputs ? vi->d_alg.p : nullptr, sample_next ? 1 : 0, o.y_eps, vi->d_zcur.p, step_num};
     {
         const int nch_bu = (int)ceil_div((int64_t)n, bu_ch<K>());
         VD<K> *chunk_bu = reinterpret_cast<VD<K> *>(vi->d_chunk_bu.p);
@@ -314,7 +324,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
                             (const int32_t *)vi->d_node_start.p, vi->d_H.p};
         hipLaunchKernelGGL((vi_bwd_local_kernel<K>), dim3(nch_bu), dim3(256), 0, st, ba);
         if (nm1 > 0) {
-            hipLaunchKernelGGL((vi_bwd_spine_kernel<K>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_bu, nch_bu);
+            hipLaunchKernelGGL((vi_bwd_spine_kernel<K>), dim3(1), dim3(64 * K), 0, st, chunk_bu, nch_bu);
             hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
                                (const double *)vi->d_H.p, (const VD<K> *)chunk_bu, (const dd *)vi->d_C.p, ua, noise);
         }
@@ -560,10 +570,11 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         A(b->alloc(ctx, nm1));
     A(vi->d_x.alloc(ctx, n * K));
     A(vi->d_zcur.alloc(ctx, nm1 * K));
+    A(vi->d_y32.alloc(ctx, nm1 * K));
     A(vi->d_g.alloc(ctx, n * K));
     A(vi->d_x_rows.alloc(ctx, n * K));
-    A(vi->d_ys.alloc(ctx, nm1 * K));
-    A(vi->d_lyy.alloc(ctx, nm1 * 2 * K));
+    A(vi->d_ys.alloc(ctx, nm1));  // (initial values; the point optimisation's y)
+    if (g_vi_plain_order) A(vi->d_lyy.alloc(ctx, nm1 * 2));  // (the point optimisation's edge logs)
     A(vi->d_uleaf.alloc(ctx, n * K));
     A(vi->d_C.alloc(ctx, (n + 1) * K));
     {
@@ -835,6 +846,14 @@ polee_status polee_vi_get_trace(polee_vi *vi, double *elbo, double *lp_mean)
     return POLEE_OK;
 }
 
+#ifdef POLEE_VI_STAMPS
+// diagnostic build only: the tree kernels' phase stamps of their last launches, [4][2048][8] (vi_fused.hpp)
+polee_status polee_debug_vi_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(polee::g_vi_stamps), sizeof(unsigned long long) * 4 * 2048 * 8) == hipSuccess ? POLEE_OK : POLEE_ERR_HIP;
+}
+#endif
+
 polee_status polee_vi_export_noise(polee_vi *vi, int32_t step, float *z0)
 {
     if (!vi || !z0 || step < 1) return fail(nullptr, POLEE_ERR_BAD_ARG, "bad argument");
@@ -919,12 +938,12 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         hipLaunchKernelGGL(point_sample_kernel, dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, vi->d_mu.p, nm1,
                            vi->d_ys.p, vi->d_lyy.p);
         if (nch_f > 1) {
-            hipLaunchKernelGGL((vi_fwd_reduce_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f);
+            hipLaunchKernelGGL((vi_fwd_reduce_kernel<1, LogRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f);
             hipLaunchKernelGGL((scan_spine_kernel<VK<1>>), dim3(1), dim3(SCAN_THREADS), 0, st, chunk_f, nch_f);
         } else {
             POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<1>), st));
         }
-        hipLaunchKernelGGL((vi_fwd_apply_kernel<1>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, vi->d_lyy.p, chunk_f,
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<1, LogRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
                            vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr, (const float *)nullptr);

@@ -15,6 +15,19 @@
 
 namespace polee {
 
+// diagnostic build (-DPOLEE_VI_STAMPS, tools/probe/vi_stamps.py): thread 0 of every workgroup stamps the clock at the phase
+// boundaries of the tree kernels (after waiting for the phase's memory operations, so the build is slower than the product)
+#ifdef POLEE_VI_STAMPS
+__device__ unsigned long long g_vi_stamps[4][2048][8];
+#define VI_STAMP(kern, slot)                                                                                        \
+    do {                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) g_vi_stamps[kern][blockIdx.x][slot] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define VI_STAMP(kern, slot) do {} while (0)
+#endif
+
 template <int K>
 struct VK {
     double v[K];
@@ -109,14 +122,20 @@ __device__ inline void store_vec_by_thread(const double (&v)[K], double *out)
 // asinh + sinh per draw (src/sinh_arcsinh.jl:14-15)
 __device__ inline float sinh_asinh(float sa, float ca, float z0) { return fmaf(sa, sqrtf(fmaf(z0, z0, 1.0f)), ca * z0); }
 
-// sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform! (logitnormal.jl:8-20) ->
-// clamp!(ys, eps, 1-eps) (likelihood-approximation.jl:523).  ys [n-1][K]; lyy [n-1][2][K]: [0] = log(1-y)
-// (right edge), [1] = log y (left edge).  ladj_out [K][2] = (skew, logit-normal) sums when non-null.
+// sample: sinh_asinh_transform! (sinh_arcsinh.jl:10-23) -> logit_normal_transform! (logitnormal.jl:8-20).  What is kept per
+// node and draw is the Float32 logistic value y32 [n-1][K] (4 bytes): the clamp of likelihood-approximation.jl:523 and the two
+// edge logs log y / log(1 - y) are applied where the value is read (clamped_y, YRows) -- round 6: the f64 ys and the [n-1][2][K]
+// f64 edge logs this kernel used to write were 29 MB of the iteration's 200 MB, and another 29 MB read back by the forward
+// kernel.  ladj_out [K][2] = (skew, logit-normal) sums when non-null.
+__device__ inline double clamped_y(float y32, double y_eps)
+{
+    const double y = (double)y32;
+    return y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
+}
 // one node's K draws (shared by the sample kernel and the update kernel's look-ahead)
 template <int K, typename Noise>
-__device__ inline void sample_node(float m, float om, float al, const Noise &noise, int step, int64_t k, double y_eps,
-                                   double *__restrict__ ys, double *__restrict__ lyy, float *__restrict__ zcur,
-                                   double *lsum)
+__device__ inline void sample_node(float m, float om, float al, const Noise &noise, int step, int64_t k,
+                                   float *__restrict__ y32, float *__restrict__ zcur, double *lsum)
 {
     const float sigma = expf(om);
     const float sa = sinhf(al), ca = coshf(al);
@@ -127,24 +146,21 @@ __device__ inline void sample_node(float m, float om, float al, const Noise &noi
         const float z0 = zall[d];
         zcur[k * K + d] = z0;  // kept for this iteration's update (no second pass through the generator)
         const float zs = sinh_asinh(sa, ca, z0);
-        double y = (double)(1.0f / (1.0f + expf(-(m + zs * sigma))));
+        const float yf = 1.0f / (1.0f + expf(-(m + zs * sigma)));
         if (lsum) {
+            const double y = (double)yf;
             // log cosh(c) - 0.5 log1p(z0^2) with cosh(c) = sqrt(1 + sinh(c)^2)
             lsum[d] = 0.5 * (double)log1pf(zs * zs) - 0.5 * (double)log1pf(z0 * z0);
             lsum[K + d] = log((double)sigma * y * (1 - y));
         }
-        y = y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
-        ys[k * K + d] = y;
-        lyy[(k * 2 + 0) * K + d] = fast_log(1.0 - y);  // log1p(-y): y is clamped to [eps, 1 - eps]
-        lyy[(k * 2 + 1) * K + d] = fast_log(y);
+        y32[k * K + d] = yf;
     }
 }
 
 template <int K, typename Noise>
 __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restrict__ mu, const float *__restrict__ omega,
                                                          const float *__restrict__ alpha, Noise noise, int step,
-                                                         double y_eps, double *__restrict__ ys,
-                                                         double *__restrict__ lyy, float *__restrict__ zcur,
+                                                         float *__restrict__ y32, float *__restrict__ zcur,
                                                          double *__restrict__ ladj_out)
 {
     __shared__ double smem[4 * 2 * K];
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restric
 #pragma unroll
     for (int d = 0; d < 2 * K; ++d) lsum[d] = 0.0;
     if (k < noise.nm1)
-        sample_node<K, Noise>(mu[k], omega[k], alpha[k], noise, step, k, y_eps, ys, lyy, zcur, ladj_out ? lsum : nullptr);
+        sample_node<K, Noise>(mu[k], omega[k], alpha[k], noise, step, k, y32, zcur, ladj_out ? lsum : nullptr);
     if (ladj_out) {
         block_sum_vec<2 * K>(lsum, smem);
 #pragma unroll
@@ -162,8 +178,35 @@ __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restric
     }
 }
 
-template <int K>
-__device__ inline VK<K> tour_value(uint32_t code, const double *__restrict__ lyy, VK<K> &edge)
+// Where a tour entry's edge log comes from: rows of precomputed logs (LogRows: lyy [n-1][2][K] f64, [0] = log(1-y) the right
+// edge, [1] = log y the left edge -- the point optimisation), or the VI loop's Float32 y rows, clamped and logged here (YRows).
+struct LogRows {
+    const double *lyy;
+    template <int K>
+    __device__ inline void edge(uint32_t k, uint32_t left, double (&e)[K]) const
+    {
+        const double *p = lyy + ((size_t)k * 2 + left) * K;
+#pragma unroll
+        for (int d = 0; d < K; ++d) e[d] = p[d];
+    }
+};
+struct YRows {
+    const float *y32;
+    double y_eps;
+    template <int K>
+    __device__ inline void edge(uint32_t k, uint32_t left, double (&e)[K]) const
+    {
+        const float *p = y32 + (size_t)k * K;
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            const double y = clamped_y(p[d], y_eps);
+            e[d] = fast_log(left ? y : 1.0 - y);  // (log1p(-y): y is clamped to [eps, 1 - eps])
+        }
+    }
+};
+
+template <int K, typename Src>
+__device__ inline VK<K> tour_value(uint32_t code, const Src &src, VK<K> &edge)
 {
     // edge = log of this entry's edge factor (0 for the root); value = +edge on ENTER, -edge on EXIT, 0 on LEAF
     VK<K> val;
@@ -172,9 +215,7 @@ __device__ inline VK<K> tour_value(uint32_t code, const double *__restrict__ lyy
 #pragma unroll
         for (int d = 0; d < K; ++d) edge.v[d] = 0.0;
     } else {
-        const double *p = lyy + ((size_t)(code >> 4) * 2 + ((code >> 3) & 1u)) * K;
-#pragma unroll
-        for (int d = 0; d < K; ++d) edge.v[d] = p[d];
+        src.template edge<K>(code >> 4, (code >> 3) & 1u, edge.v);
     }
 #pragma unroll
     for (int d = 0; d < K; ++d) val.v[d] = type == TOUR_ENTER ? edge.v[d] : (type == TOUR_EXIT ? -edge.v[d] : 0.0);
@@ -193,8 +234,8 @@ __device__ inline T chunk_prefix(const T *__restrict__ chunk_sums, int chunk, T 
     return tot;
 }
 
-template <int K>
-__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, const double *__restrict__ lyy,
+template <int K, typename Src>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, Src lyy,
                                                                     VK<K> *__restrict__ chunk_sums)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
@@ -202,7 +243,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, 
     VK<K> acc = ScanOps<VK<K>>::zero(), edge;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j)
-        if (base + j < v.TL) acc = ScanOps<VK<K>>::add(acc, tour_value<K>(v.tour_code[base + j], lyy, edge));
+        if (base + j < v.TL) acc = ScanOps<VK<K>>::add(acc, tour_value<K, Src>(v.tour_code[base + j], lyy, edge));
     VK<K> tot;
     (void)block_exclusive_scan<VK<K>>(acc, smem, &tot);
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
@@ -211,8 +252,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, 
 // forward apply: leaves get u = exp(prefix + own edge); x = clamp(max(f32(u), 1e-16)) (ptt.jl:138-139,
 // likelihood-approximation.jl:526) written to xs[tid][K]; g[tid][K] is zeroed for the likelihood pass;
 // per-chunk partial sums of x/efflen (likelihood.jl:97-100) and, if wanted, of log u over internal nodes.
-template <int K>
-__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, const double *__restrict__ lyy,
+template <int K, typename Src>
+__global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, Src lyy,
                                                                    const VK<K> *__restrict__ chunk_offsets,
                                                                    double *__restrict__ uleaf, float *__restrict__ xs,
                                                                    float *__restrict__ g,
@@ -228,6 +269,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
+    __shared__ double spre[K];  // the chunk's offset from the open-edge list
     // x windows of the sparse pass (loglik_internal.hpp): a transcript's x row also goes to its slot in every tile
     // dictionary that holds it (tslot lists) -- the gather launch in front of the pass is gone.  A thread writes up to
     // XW_INLINE slots itself; transcripts in more tiles are written by the whole workgroup afterwards.
@@ -238,30 +280,72 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
     if (xwin && threadIdx.x == 0) xw_count = 0;
     if (xwin) __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // The kernel is bound by its dependent memory round trips, not by arithmetic: every load whose address does not depend on
+    // another load is issued here, in front of the first barrier (the compiler does not move loads across one).
+    //   trip 1: the thread's tour entries (code, target) and the bounds of the chunk's open-edge list
+    //   trip 2: the entries' edge logs (lyy rows), the list's codes, the leaves' effective lengths / single counts
+    //   trip 3: the open edges' logs
     VK<K> val[SCAN_ITEMS], edge[SCAN_ITEMS];
     uint32_t code[SCAN_ITEMS];
-    VK<K> acc = ScanOps<VK<K>>::zero();
+    int tgt[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         code[j] = base + j < v.TL ? v.tour_code[base + j] : (4u | TOUR_LEAF);
-        val[j] = tour_value<K>(code[j], lyy, edge[j]);
+        tgt[j] = base + j < v.TL ? v.tour_tgt[base + j] : 0;
+    }
+    VI_STAMP(0, 0);
+    const int lane = threadIdx.x & 63;
+    uint32_t ob = 0, oe = 0;
+    if (open_ptr) {
+        ob = open_ptr[blockIdx.x];
+        oe = open_ptr[blockIdx.x + 1];
+    }
+    // (the list is the path from the root, rarely longer than a wave: the first wave sums it alone -- the edge logs are K
+    // double logs per entry -- and leaves the sum in LDS in front of the scan's barriers)
+    const bool first_wave = threadIdx.x < 64;
+    const uint32_t ocode0 = first_wave && ob + lane < oe ? open_code[ob + lane] : (4u | TOUR_LEAF);
+    VK<K> acc = ScanOps<VK<K>>::zero();
+    float inv_l_[SCAN_ITEMS], sc_[SCAN_ITEMS];
+    int ltid[SCAN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        val[j] = tour_value<K, Src>(code[j], lyy, edge[j]);
         if (base + j >= v.TL) val[j] = ScanOps<VK<K>>::zero();
         acc = ScanOps<VK<K>>::add(acc, val[j]);
+        const bool leaf = (code[j] & 3u) == TOUR_LEAF && base + j < v.TL;
+        // (leaf-order mode, v.leaf_tid == null: the fit numbers the transcripts by leaf position, so xs, g, efflens
+        // and single_cnt are indexed by pos and a chunk's leaves write one contiguous piece of each)
+        ltid[j] = leaf ? (v.leaf_tid ? v.leaf_tid[tgt[j]] : tgt[j]) : 0;
+        inv_l_[j] = leaf && efflens ? 1.0f / efflens[ltid[j]] : 0.0f;
+        // stream S of the sparse pass (loglik_internal.hpp): the fragments compatible with this transcript alone
+        // add cnt / x to its gradient -- g starts from that instead of 0
+        sc_[j] = leaf && single_cnt ? single_cnt[ltid[j]] : 0.0f;
     }
+    VI_STAMP(0, 1);
+    if (open_ptr && first_wave) {
+        // The chunk's offset = the tour prefix in front of it.  Every ENTER before the chunk whose EXIT lies before it too has
+        // cancelled, so the prefix is the sum of the edge logs of the nodes that are OPEN at the chunk's first entry -- the
+        // path from the root to that point, a list fixed by the tree (open_ptr / open_code, built once per fit): with it the
+        // forward pass needs no reduce launch and no pass over the other chunks' totals.
+        VK<K> edge2;
+        VK<K> pre = tour_value<K, Src>(ocode0, lyy, edge2);  // (ENTER codes: + the edge's log; the filler is a root LEAF: 0)
+        for (uint32_t e = ob + 64 + lane; e < oe; e += 64) pre = ScanOps<VK<K>>::add(pre, tour_value<K, Src>(open_code[e], lyy, edge2));
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) pre.v[d] += __shfl_xor(pre.v[d], o, 64);
+            if (lane == 0) spre[d] = pre.v[d];
+        }
+    }
+    VI_STAMP(0, 2);
     VK<K> tot;
     VK<K> off = block_exclusive_scan<VK<K>>(acc, smem, &tot);
-    // The chunk's offset = the tour prefix in front of it.  Every ENTER before the chunk whose EXIT lies before it too has
-    // cancelled, so the prefix is the sum of the edge logs of the nodes that are OPEN at the chunk's first entry -- the
-    // path from the root to that point, a list fixed by the tree (open_ptr / open_code, built once per fit): with it the
-    // forward pass needs no reduce launch and no pass over the other chunks' totals.  Without the lists (very deep trees):
-    // chunk_offsets holds the chunks' exclusive offsets (after a spine pass) or, with own_prefix, their totals.
+    VI_STAMP(0, 3);
+    // Without the lists (very deep trees): chunk_offsets holds the chunks' exclusive offsets (after a spine pass) or, with
+    // own_prefix, their totals.
     if (open_ptr) {
-        VK<K> acc2 = ScanOps<VK<K>>::zero(), edge2;
-        for (uint32_t e = open_ptr[blockIdx.x] + threadIdx.x; e < open_ptr[blockIdx.x + 1]; e += SCAN_THREADS)
-            acc2 = ScanOps<VK<K>>::add(acc2, tour_value<K>(open_code[e], lyy, edge2));  // (ENTER codes: + the edge's log)
-        VK<K> pre;
-        (void)block_exclusive_scan<VK<K>>(acc2, smem, &pre);
-        off = ScanOps<VK<K>>::add(pre, off);
+#pragma unroll
+        for (int d = 0; d < K; ++d) off.v[d] += spre[d];  // (written in front of the scan's barriers)
     } else {
         off = ScanOps<VK<K>>::add(own_prefix ? chunk_prefix<VK<K>>(chunk_offsets, blockIdx.x, smem) : chunk_offsets[blockIdx.x], off);
     }
@@ -274,17 +358,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
         if (base + j < v.TL) {
             const uint32_t type = code[j] & 3u;
             if (type == TOUR_LEAF) {
-                const int pos = v.tour_tgt[base + j];
-                // (leaf-order mode, v.leaf_tid == null: the fit numbers the transcripts by leaf position, so xs, g, efflens
-                // and single_cnt are indexed by pos and a chunk's leaves write one contiguous piece of each)
-                const int tid = v.leaf_tid ? v.leaf_tid[pos] : pos;
-                const float inv_l = efflens ? 1.0f / efflens[tid] : 0.0f;
-                // stream S of the sparse pass (loglik_internal.hpp): the fragments compatible with this transcript alone
-                // add cnt / x to its gradient -- g starts from that instead of 0
-                const float sc = single_cnt ? single_cnt[tid] : 0.0f;
+                const int pos = tgt[j];
+                const int tid = ltid[j];
+                const float inv_l = inv_l_[j];
+                const float sc = sc_[j];
 #pragma unroll
                 for (int d = 0; d < K; ++d) {
-                    const double u = exp(inc.v[d] + edge[j].v[d]);
+                    const double u = fast_exp(inc.v[d] + edge[j].v[d]);
                     uleaf[(size_t)pos * K + d] = u;
                     float x = (float)u;
                     x = (float)fmax((double)x, 1e-16);
@@ -327,10 +407,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, c
             }
         }
     }
+    VI_STAMP(0, 4);
     if (part_c) {
         block_sum_vec<K>(pc, smd);
         store_vec_by_thread<K>(pc, part_c + (size_t)blockIdx.x * K);
     }
+    VI_STAMP(0, 5);
     if (part_ladj) {
         block_sum_vec<K>(pl, smd);
         store_vec_by_thread<K>(pl, part_ladj + (size_t)blockIdx.x * K);
@@ -478,6 +560,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_apply_kernel(PttView v, c
     }
 }
 
+// 1 / x for a finite positive x well inside the normal range (the update kernel's denominators: y (1 - y) with y clamped to
+// [y_eps, 1 - y_eps], sqrt(v) + eps): the hardware estimate and two Newton steps, ~1 ulp, a fifth of a division's instructions
+__device__ inline double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 struct AdamConsts {
     double lr, rm, rv, eps, m_denom, v_denom;
     double inv_m_denom, inv_v_denom;  // reciprocals, computed once on the host (the update kernel is bound by its f64 instructions)
@@ -497,14 +589,14 @@ __device__ inline void adam_one(float &p, float &m, float &v, float grad, const 
     }
     // adam_update_params! (likelihood-approximation.jl:136-146) -- ascent, clamped step
     const double pm = (double)m * a.inv_m_denom, pv = (double)v * a.inv_v_denom;  // (m / (1 - rm^t) up to an ulp of double)
-    double delta = a.lr * pm / (sqrt(pv) + a.eps);
+    double delta = a.lr * pm * fast_rcp(sqrt(pv) + a.eps);
     delta = delta < -max_step ? -max_step : (delta > max_step ? max_step : delta);
     p = (float)((double)p + delta);
 }
 
 // Everything the per-node update needs besides the node's two subtree sums.
 struct UpdArgs {
-    double *ys;
+    float *y32;  // [n-1][K] this iteration's logistic values (sample_node); the next iteration's after the update
     float *mu, *omega, *alpha, *m_mu, *v_mu, *m_omega, *v_omega, *m_alpha, *v_alpha;
     AdamConsts adam;
     int apply;
@@ -513,7 +605,6 @@ struct UpdArgs {
     float *mu_grad_out, *omega_grad_out, *alpha_grad_out;
     int sample_next;
     double y_eps;
-    double *lyy;
     float *zcur;
     int step;
 };
@@ -538,11 +629,10 @@ __device__ inline void update_node(const UpdArgs &A, const Noise &noise, int64_t
     for (int d = 0; d < K; ++d) {
         const double Hr = cnt_r + hr[d];
         const double Hl = cnt_l + hl[d];
-        const double y = A.ys[k * K + d];
+        const double y = clamped_y(A.y32[k * K + d], A.y_eps);
         const double dyy = y * (1 - y);
-        // H_l / y - H_r / (1 - y) over the common denominator: one f64 division per draw instead of two (the kernel is
-        // bound by the f64 instructions it issues; a division is 14 of them)
-        const double ygd = (Hl * (1 - y) - Hr * y) / dyy;
+        // H_l / y - H_r / (1 - y) over the common denominator, times its reciprocal (y is clamped: fast_rcp's range)
+        const double ygd = (Hl * (1 - y) - Hr * y) * fast_rcp(dyy);
         if (A.y_grad_out) A.y_grad_out[(int64_t)d * nm1 + k] = ygd;
         const float yg = (float)ygd;  // y_grad is a Float32 array in the reference
         const float z0 = A.zcur[k * K + d];  // this iteration's draw, left by the sampling step
@@ -558,6 +648,7 @@ __device__ inline void update_node(const UpdArgs &A, const Noise &noise, int64_t
         al_g += zs / cc;
         om_g += sigma * sg;
     }
+    VI_STAMP(2, 2);
     mu_g /= (float)K;
     om_g /= (float)K;
     al_g /= (float)K;
@@ -581,9 +672,10 @@ __device__ inline void update_node(const UpdArgs &A, const Noise &noise, int64_t
         A.alpha[k] = p; A.m_alpha[k] = mm; A.v_alpha[k] = vv;
         p_al = p;
     }
+    VI_STAMP(2, 3);
     // look-ahead: the next iteration's draws from the parameters just written (this thread is the only one that
-    // touches node k's ys / lyy, and its reads of ys[k] are done)
-    if (A.sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, A.step + 1, k, A.y_eps, A.ys, A.lyy, A.zcur, nullptr);
+    // touches node k's y32 / zcur, and its reads of them are done)
+    if (A.sample_next) sample_node<K, Noise>(p_mu, p_om, p_al, noise, A.step + 1, k, A.y32, A.zcur, nullptr);
 }
 
 // ---- backward + update, round 6 ----------------------------------------------------------------------------------------
@@ -692,7 +784,24 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
         c[d] = B.efflens ? B.csum[d] : 1.0;
         inv_c[d] = B.efflens ? B.csum[K + d] : 1.0;
     }
+    VI_STAMP(1, 0);
     const int64_t base = (int64_t)blockIdx.x * CH, p0 = base + (int64_t)threadIdx.x * LPT;
+    const int64_t end = min(base + CH, (int64_t)v.n), nm1 = (int64_t)v.n - 1;
+    // (the first nodes' ranges are loaded here, in front of the barriers: the node phase then starts without a memory round trip)
+    constexpr int PRE = LPT;
+    const int32_t k0 = B.node_start[blockIdx.x] + (int32_t)threadIdx.x, k1 = B.node_start[blockIdx.x + 1];
+    int32_t kp[PRE];
+    int plo[PRE], pmid[PRE], phi[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        kp[i] = k0 + i * 256;
+        const bool in = kp[i] < k1;
+        plo[i] = in ? v.lo[kp[i]] : 0;
+        pmid[i] = in ? v.mid[kp[i]] : 0;
+        phi[i] = in ? v.hi1[kp[i]] : 0;
+    }
+    const bool exp0 = p0 <= v.n && ((B.need[p0 >> 5] >> (p0 & 31)) & 1u);
+    const bool exp1 = LPT == 2 && p0 + 1 <= v.n && ((B.need[(p0 + 1) >> 5] >> ((p0 + 1) & 31)) & 1u);
     double a[LPT][K];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
@@ -708,13 +817,14 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
         s.v[d] = dd_make(a[0][d]);
         if constexpr (LPT == 2) s.v[d] = two_sum(a[0][d], a[1][d]);
     }
+    VI_STAMP(1, 1);
     const VD<K> inc = wave_inclusive_scan<VD<K>>(s);
+    VI_STAMP(1, 2);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
     VD<K> off = ScanOps<VD<K>>::shfl_up(inc, 1);
     if (lane == 0) off = ScanOps<VD<K>>::zero();
     for (int w = 0; w < wave; ++w) off = ScanOps<VD<K>>::add(wtot[w], off);  // (wave-uniform trip count)
-    const bool exp0 = p0 <= v.n && ((B.need[p0 >> 5] >> (p0 & 31)) & 1u);
 #pragma unroll
     for (int d = 0; d < K; ++d) P[(size_t)(threadIdx.x * LPT) * K + d] = off.v[d];
     if (exp0)
@@ -722,7 +832,6 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
         for (int d = 0; d < K; ++d) B.C[(size_t)p0 * K + d] = off.v[d];
     if constexpr (LPT == 2) {
         const int64_t p1 = p0 + 1;
-        const bool exp1 = p1 <= v.n && ((B.need[p1 >> 5] >> (p1 & 31)) & 1u);
 #pragma unroll
         for (int d = 0; d < K; ++d) {
             const dd o1 = dd_add(off.v[d], dd_make(a[0][d]));
@@ -739,13 +848,12 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
         }
         B.chunk_tot[blockIdx.x] = tot;
     }
+    VI_STAMP(1, 3);
     __syncthreads();
+    VI_STAMP(1, 4);
     // the nodes whose range starts in this chunk and ends in it: both subtree sums from LDS rows
-    const int64_t end = min(base + CH, (int64_t)v.n), nm1 = (int64_t)v.n - 1;
-    const int32_t k1 = B.node_start[blockIdx.x + 1];
-    for (int32_t k = B.node_start[blockIdx.x] + (int32_t)threadIdx.x; k < k1; k += 256) {
-        const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
-        if (hi1 > end) continue;
+    auto node = [&](int32_t k, int lo, int mid, int hi1) {
+        if (hi1 > end) return;  // crosses chunks: the update adds chunk offsets to exported rows
         const dd *Plo = P + (size_t)(lo - base) * K, *Pmid = P + (size_t)(mid - base) * K, *Phi = P + (size_t)(hi1 - base) * K;
 #pragma unroll
         for (int d = 0; d < K; ++d) {
@@ -753,26 +861,52 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
             B.H[(size_t)d * nm1 + k] = dd_diff(pm, Plo[d]);
             B.H[(size_t)(K + d) * nm1 + k] = dd_diff(Phi[d], pm);
         }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+        if (kp[i] < k1) node(kp[i], plo[i], pmid[i], phi[i]);
+    for (int32_t k = k0 + PRE * 256; k < k1; k += 256) node(k, v.lo[k], v.mid[k], v.hi1[k]);
+    VI_STAMP(1, 5);
 }
 
-// exclusive double-double scan of the chunks' totals, in place; [nch] = the sum over all leaves
+// exclusive double-double scan of the chunks' totals, in place; [nch] = the sum over all leaves.  One workgroup, one WAVE per
+// draw: a lane adds its run of chunks, the wave scans the 64 runs, the lane walks its run again -- no barrier, no LDS, and a
+// sixth of the dependent double-double chain a K-wide scan element has (this launch sits between the backward kernel and the
+// update: its latency is the iteration's).
 template <int K>
-__global__ __launch_bounds__(SCAN_THREADS) void vi_bwd_spine_kernel(VD<K> *chunk_tot, int nch)
+__global__ __launch_bounds__(64 * K) void vi_bwd_spine_kernel(VD<K> *chunk_tot, int nch)
 {
-    __shared__ VD<K> smem[SCAN_THREADS / 64];
-    const int per = (nch + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int b = min((int)threadIdx.x * per, nch), e = min(b + per, nch);
-    VD<K> acc = ScanOps<VD<K>>::zero();
-    for (int i = b; i < e; ++i) acc = ScanOps<VD<K>>::add(acc, chunk_tot[i]);
-    VD<K> tot;
-    VD<K> off = block_exclusive_scan<VD<K>>(acc, smem, &tot);
-    for (int i = b; i < e; ++i) {
-        const VD<K> t = chunk_tot[i];
-        chunk_tot[i] = off;
-        off = ScanOps<VD<K>>::add(off, t);
+    const int d = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (nch + 63) / 64;
+    const int b = min(lane * per, nch), e = min(b + per, nch);
+    constexpr int FAST = 8;  // runs of up to FAST chunks are held in registers: all loads in flight at once
+    dd t[FAST];
+    dd acc{0.0, 0.0};
+    if (per <= FAST) {
+#pragma unroll
+        for (int i = 0; i < FAST; ++i) t[i] = b + i < e ? chunk_tot[b + i].v[d] : dd{0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < FAST; ++i) acc = dd_add(acc, t[i]);
+    } else {
+        for (int i = b; i < e; ++i) acc = dd_add(acc, chunk_tot[i].v[d]);
     }
-    if (threadIdx.x == 0) chunk_tot[nch] = tot;
+    const dd inc = wave_inclusive_scan<dd>(acc);
+    dd off = ScanOps<dd>::shfl_up(inc, 1);
+    if (lane == 0) off = dd{0.0, 0.0};
+    if (per <= FAST) {
+#pragma unroll
+        for (int i = 0; i < FAST; ++i) {
+            if (b + i < e) chunk_tot[b + i].v[d] = off;
+            off = dd_add(off, t[i]);
+        }
+    } else {
+        for (int i = b; i < e; ++i) {
+            const dd ti = chunk_tot[i].v[d];
+            chunk_tot[i].v[d] = off;
+            off = dd_add(off, ti);
+        }
+    }
+    if (lane == 63) chunk_tot[nch].v[d] = inc;
 }
 
 // update: one thread per internal node k, all K draws
@@ -781,6 +915,7 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
                                                          const dd *__restrict__ C, UpdArgs A, Noise noise)
 {
     constexpr int CH = bu_ch<K>();
+    VI_STAMP(2, 0);
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nm1 = (int64_t)v.n - 1;
     if (k >= nm1) return;
     const int lo = v.lo[k], mid = v.mid[k], hi1 = v.hi1[k];
@@ -801,7 +936,9 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
             hl[d] = dd_diff(dd_add(Ohi[d], Phi[d]), gm);
         }
     }
+    VI_STAMP(2, 1);
     update_node<K, Noise>(A, noise, k, lo, mid, hi1, hr, hl);
+    VI_STAMP(2, 6);
 }
 
 // ---- point optimisation (OptimizePTTApprox, likelihood-approximation.jl:149-242), K = 1 ------------------

@@ -85,11 +85,20 @@ def test_device_tree_is_the_host_variants_tree_node_for_node(P, ctx, lm_fixture)
         s = synth.make_sample(6000, 400000, 8.0, 21, **kw)
         c, r, _ = synth.to_csc(s)
         cases.append((s["m"], s["n"], c, r))
+    from oracle import hclust_ref
     for m, n, colptr, rowval in cases:
         ph, jh = P.hclust(m, n, colptr, rowval, parallel=True)
         pd, jd = P.hclust(m, n, colptr, rowval, device=True, ctx=ctx)
         np.testing.assert_array_equal(ph, pd)
         np.testing.assert_array_equal(jh, jd)
+        # ... and against the ORACLE itself (oracle/hclust_ref.py::hclust_rounds, the sequential dict-and-set restatement of the
+        # variant's definition), directly, wherever the pure-Python oracle finishes in seconds: every case but the 6 000-transcript
+        # samples, for which the comparison above with the host twin (itself compared with the oracle in the CPU suite,
+        # tests/test_layouts.py) stands
+        if n <= 1500:
+            pr, jr = hclust_ref.hclust_rounds(m, n, colptr, rowval)
+            np.testing.assert_array_equal(pd, pr)
+            np.testing.assert_array_equal(jd, jr)
     # the treemethod of the approximation
     s = synth.make_sample(3000, 150000, 8.0, 5)
     c, r, v = synth.to_csc(s)

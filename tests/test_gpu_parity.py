@@ -1013,6 +1013,28 @@ def test_fast_log_is_a_double_precision_log(P, ctx):
     assert eo[0] == -np.inf and np.isnan(eo[1]) and eo[2] == np.inf and np.isnan(eo[3])
 
 
+def test_fast_exp_is_a_double_precision_exp(P, ctx):
+    """The VI loop's forward kernel exponentiates a path sum of edge logs per leaf and draw (csrc/scan.hpp's fast_exp, under half
+    of libm's instructions): <= 2 ulp wherever the result is a normal number, 0 below the underflow threshold, NaN kept."""
+    import ctypes as C
+    from polee_amd import _lib as L
+    rng = np.random.default_rng(41)
+    x = np.concatenate([-10.0 ** rng.uniform(-17, 2.85, 300000), rng.uniform(-1, 1, 50000), rng.uniform(-40, 0, 100000),
+                        [0.0, -0.0, -1e-300, -0.34657359027997264, 0.34657359027997264, -708.0, 5.0, 100.0]])
+    out = np.empty_like(x)
+    L.check(L.lib().polee_debug_fast_exp(ctx._h, x.ctypes.data_as(L.f64p), C.c_int64(x.size), out.ctypes.data_as(L.f64p)),
+            ctx._h)
+    ref = np.exp(x)
+    normal = ref > 2.3e-308
+    ulp = np.abs(out - ref)[normal] / np.spacing(ref[normal])
+    assert out[x == 0.0].min() == 1.0 and ulp.max() <= 2, (ulp.max(), x[normal][ulp.argmax()])
+    assert np.all(np.abs(out - ref)[~normal] <= 1e-307)
+    edge = np.array([-746.0, -1e6, -np.inf, np.nan])
+    eo = np.empty_like(edge)
+    L.check(L.lib().polee_debug_fast_exp(ctx._h, edge.ctypes.data_as(L.f64p), C.c_int64(4), eo.ctypes.data_as(L.f64p)), ctx._h)
+    assert eo[0] == 0.0 and eo[1] == 0.0 and eo[2] == 0.0 and np.isnan(eo[3])
+
+
 def test_cohort_pipeline_matches_sequential_fits(P, lm_fixture):
     """approximate_likelihood_cohort: several samples in flight on one GPU (a worker thread and a HIP stream each, host
     stages of one under the device stage of another) give what one-at-a-time calls give: the same tree node for node,

@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r06_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 if [ "$MODE" = tests ]; then
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu -k "vi or fit or optimize or degenerate or trajectory or replay or c1 or c2 or cohort" > $OUT/tests.log 2>&1
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu -k "vi or fit or optimize or degenerate or trajectory or replay or c1 or c2 or cohort or fast_" > $OUT/tests.log 2>&1
   echo "tests rc=$?" >> $OUT/tests.log; tail -5 $OUT/tests.log
 fi
 timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-by-input "$@" > $OUT/bench.json 2> $OUT/bench.err
