@@ -176,6 +176,7 @@ struct polee_vi {
     DevBuf<float> d_efflens, d_mu, d_omega, d_alpha, d_mm, d_vm, d_mo, d_vo, d_ma, d_va, d_z0, d_x, d_g;
     DevBuf<float> d_zcur;  // [n-1][K] the current iteration's N(0,1) draws
     DevBuf<float> d_y32;   // [n-1][K] and the logistic values they give (sample_node)
+    DevBuf<float> d_u32;   // [n][K] leaf u of the forward pass (leaf order), unclamped, for the backward pass
     DevBuf<uint32_t> d_open_ptr, d_open_code;  // per forward-scan chunk: the tour's ENTER entries still open at its start
     // Leaf-order mode (round 4): this fit numbers the transcripts by their position among the tree's leaves.  d_x, d_g,
     // d_efflens and d_gene_of are indexed by leaf position -- the tree kernels' accesses to them are contiguous where
@@ -224,7 +225,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     if (vi->leaf_order) lview.leaf_tid = nullptr;
     const LoglikRemap *remap = vi->leaf_order ? &vi->remap : nullptr;
     const uint32_t *index_of = vi->leaf_order ? vi->d_index_of.p : nullptr;
-    const int nch_f = scan_num_chunks(t->TL);
+    const int nch_f = fwd_num_chunks(t->TL);
     const float *eff = o.use_efflen_jacobian ? vi->d_efflens.p : nullptr;
     VK<K> *chunk_f = reinterpret_cast<VK<K> *>(t->d_chunk.p);
     const NoiseSrc noise = vi->noise();
@@ -256,8 +257,8 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     } else {
         POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
     }
-    hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
-                       vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
+    hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows, float>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
+                       vi->d_u32.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
                        eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
                        (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
                        xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
@@ -320,7 +321,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     {
         const int nch_bu = (int)ceil_div((int64_t)n, bu_ch<K>());
         VD<K> *chunk_bu = reinterpret_cast<VD<K> *>(vi->d_chunk_bu.p);
-        const BwdArgs<K> ba{lview, vi->d_uleaf.p, vi->d_g.p, eff, vi->d_csum.p, gp, chunk_bu, vi->d_C.p, (const uint32_t *)vi->d_need.p,
+        const BwdArgs<K> ba{lview, vi->d_u32.p, vi->d_g.p, eff, vi->d_csum.p, gp, chunk_bu, vi->d_C.p, (const uint32_t *)vi->d_need.p,
                             (const int32_t *)vi->d_node_start.p, vi->d_H.p};
         hipLaunchKernelGGL((vi_bwd_local_kernel<K>), dim3(nch_bu), dim3(256), 0, st, ba);
         if (nm1 > 0) {
@@ -575,7 +576,8 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     A(vi->d_x_rows.alloc(ctx, n * K));
     A(vi->d_ys.alloc(ctx, nm1));  // (initial values; the point optimisation's y)
     if (g_vi_plain_order) A(vi->d_lyy.alloc(ctx, nm1 * 2));  // (the point optimisation's edge logs)
-    A(vi->d_uleaf.alloc(ctx, n * K));
+    A(vi->d_u32.alloc(ctx, n * K));
+    if (g_vi_plain_order) A(vi->d_uleaf.alloc(ctx, n));  // (the point optimisation's f64 leaf u)
     A(vi->d_C.alloc(ctx, (n + 1) * K));
     {
         const size_t nch = (size_t)std::max(scan_num_chunks(3 * (int64_t)n - 2), 1);
@@ -616,13 +618,13 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         static const bool no_open = getenv("POLEE_VI_NO_OPEN_LISTS") != nullptr;  // (A/B)
         const std::vector<uint32_t> &code = t->plans[0].tour_code;
         const int64_t TL = t->TL;
-        const int nch = std::max(scan_num_chunks(TL), 1);
+        const int nch = std::max(fwd_num_chunks(TL), 1);
         const size_t limit = (size_t)8 << 20;
         std::vector<uint32_t> optr((size_t)nch + 1, 0), ocode, stack;
         bool ok = !no_open && t->T == 1 && (int64_t)code.size() == TL;
         for (int64_t e = 0; ok && e < TL; ++e) {
-            if (e % SCAN_CHUNK == 0) {
-                optr[(size_t)(e / SCAN_CHUNK)] = (uint32_t)ocode.size();
+            if (e % FWD_CHUNK == 0) {
+                optr[(size_t)(e / FWD_CHUNK)] = (uint32_t)ocode.size();
                 ocode.insert(ocode.end(), stack.begin(), stack.end());
                 if (ocode.size() > limit) ok = false;
             }
@@ -930,7 +932,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
     const int32_t n = vi->n;
     const int64_t nm1 = n - 1;
     const PttView view = t->view();
-    const int nch_f = scan_num_chunks(t->TL), nch_b = scan_num_chunks(n);
+    const int nch_f = fwd_num_chunks(t->TL), nch_b = scan_num_chunks(n);
     VK<1> *chunk_f = reinterpret_cast<VK<1> *>(t->d_chunk.p);
     VD<1> *chunk_b = reinterpret_cast<VD<1> *>(t->d_chunk.p);
     polee_status rc = POLEE_OK;
@@ -943,7 +945,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         } else {
             POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<1>), st));
         }
-        hipLaunchKernelGGL((vi_fwd_apply_kernel<1, LogRows>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f,
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<1, LogRows, double>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
                            vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr, (const float *)nullptr);

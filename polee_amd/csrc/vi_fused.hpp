@@ -205,6 +205,13 @@ struct YRows {
     }
 };
 
+// The VI loop's forward kernels take FWD_ITEMS tour entries per thread.  (Three per thread -- 782 workgroups at C2, all resident
+// at four waves per SIMD where two per thread are 1 172 workgroups in two rounds -- was tried with the kernel held to 128
+// VGPRs: 28.6 us against 29.0, and 9 spilled registers, whose scratch the runtime allocates lazily per queue.  Not kept.)
+constexpr int FWD_ITEMS = 2;
+constexpr int FWD_CHUNK = SCAN_THREADS * FWD_ITEMS;
+inline int fwd_num_chunks(int64_t len) { return (int)((len + FWD_CHUNK - 1) / FWD_CHUNK); }
+
 template <int K, typename Src>
 __device__ inline VK<K> tour_value(uint32_t code, const Src &src, VK<K> &edge)
 {
@@ -239,23 +246,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, 
                                                                     VK<K> *__restrict__ chunk_sums)
 {
     __shared__ VK<K> smem[SCAN_THREADS / 64];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    const int64_t base = (int64_t)blockIdx.x * FWD_CHUNK + (int64_t)threadIdx.x * FWD_ITEMS;
     VK<K> acc = ScanOps<VK<K>>::zero(), edge;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j)
+    for (int j = 0; j < FWD_ITEMS; ++j)
         if (base + j < v.TL) acc = ScanOps<VK<K>>::add(acc, tour_value<K, Src>(v.tour_code[base + j], lyy, edge));
     VK<K> tot;
     (void)block_exclusive_scan<VK<K>>(acc, smem, &tot);
     if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
 }
 
+// (UT: the type leaf u is kept in for the backward pass.  The VI loop keeps Float32 -- u multiplies an x gradient that comes out
+// of f32 sums, the reference's own gradient intermediates are Float32 (ptt.jl:186-200 with T = Float32), and the f64 rows were
+// 9.6 MB written and read back per iteration; the point optimisation keeps f64.)
 // forward apply: leaves get u = exp(prefix + own edge); x = clamp(max(f32(u), 1e-16)) (ptt.jl:138-139,
 // likelihood-approximation.jl:526) written to xs[tid][K]; g[tid][K] is zeroed for the likelihood pass;
 // per-chunk partial sums of x/efflen (likelihood.jl:97-100) and, if wanted, of log u over internal nodes.
-template <int K, typename Src>
+template <int K, typename Src, typename UT>
 __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, Src lyy,
                                                                    const VK<K> *__restrict__ chunk_offsets,
-                                                                   double *__restrict__ uleaf, float *__restrict__ xs,
+                                                                   UT *__restrict__ uleaf, float *__restrict__ xs,
                                                                    float *__restrict__ g,
                                                                    const float *__restrict__ efflens, float clamp_lo,
                                                                    float clamp_hi, double *__restrict__ part_c,
@@ -279,17 +289,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
     __shared__ int xw_count;
     if (xwin && threadIdx.x == 0) xw_count = 0;
     if (xwin) __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    const int64_t base = (int64_t)blockIdx.x * FWD_CHUNK + (int64_t)threadIdx.x * FWD_ITEMS;
     // The kernel is bound by its dependent memory round trips, not by arithmetic: every load whose address does not depend on
     // another load is issued here, in front of the first barrier (the compiler does not move loads across one).
     //   trip 1: the thread's tour entries (code, target) and the bounds of the chunk's open-edge list
     //   trip 2: the entries' edge logs (lyy rows), the list's codes, the leaves' effective lengths / single counts
     //   trip 3: the open edges' logs
-    VK<K> val[SCAN_ITEMS], edge[SCAN_ITEMS];
-    uint32_t code[SCAN_ITEMS];
-    int tgt[SCAN_ITEMS];
+    VK<K> w[FWD_ITEMS];  // the entries' edge logs: +w on ENTER, -w on EXIT in the scan; a LEAF adds it to its prefix
+    uint32_t code[FWD_ITEMS];
+    int tgt[FWD_ITEMS];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
+    for (int j = 0; j < FWD_ITEMS; ++j) {
         code[j] = base + j < v.TL ? v.tour_code[base + j] : (4u | TOUR_LEAF);
         tgt[j] = base + j < v.TL ? v.tour_tgt[base + j] : 0;
     }
@@ -305,13 +315,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
     const bool first_wave = threadIdx.x < 64;
     const uint32_t ocode0 = first_wave && ob + lane < oe ? open_code[ob + lane] : (4u | TOUR_LEAF);
     VK<K> acc = ScanOps<VK<K>>::zero();
-    float inv_l_[SCAN_ITEMS], sc_[SCAN_ITEMS];
-    int ltid[SCAN_ITEMS];
+    float inv_l_[FWD_ITEMS], sc_[FWD_ITEMS];
+    int ltid[FWD_ITEMS];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        val[j] = tour_value<K, Src>(code[j], lyy, edge[j]);
-        if (base + j >= v.TL) val[j] = ScanOps<VK<K>>::zero();
-        acc = ScanOps<VK<K>>::add(acc, val[j]);
+    for (int j = 0; j < FWD_ITEMS; ++j) {
+        acc = ScanOps<VK<K>>::add(acc, tour_value<K, Src>(code[j], lyy, w[j]));  // (past the end: a root LEAF, 0)
         const bool leaf = (code[j] & 3u) == TOUR_LEAF && base + j < v.TL;
         // (leaf-order mode, v.leaf_tid == null: the fit numbers the transcripts by leaf position, so xs, g, efflens
         // and single_cnt are indexed by pos and a chunk's leaves write one contiguous piece of each)
@@ -353,8 +361,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
 #pragma unroll
     for (int d = 0; d < K; ++d) pc[d] = pl[d] = 0.0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        const VK<K> inc = ScanOps<VK<K>>::add(off, val[j]);
+    for (int j = 0; j < FWD_ITEMS; ++j) {
+        const uint32_t tj = code[j] & 3u;
+        VK<K> inc;
+#pragma unroll
+        for (int d = 0; d < K; ++d) inc.v[d] = tj == TOUR_ENTER ? off.v[d] + w[j].v[d] : (tj == TOUR_EXIT ? off.v[d] - w[j].v[d] : off.v[d]);
         if (base + j < v.TL) {
             const uint32_t type = code[j] & 3u;
             if (type == TOUR_LEAF) {
@@ -364,8 +375,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
                 const float sc = sc_[j];
 #pragma unroll
                 for (int d = 0; d < K; ++d) {
-                    const double u = fast_exp(inc.v[d] + edge[j].v[d]);
-                    uleaf[(size_t)pos * K + d] = u;
+                    const double u = fast_exp(inc.v[d] + w[j].v[d]);
+                    uleaf[(size_t)pos * K + d] = (UT)u;
                     float x = (float)u;
                     x = (float)fmax((double)x, 1e-16);
                     x = fminf(fmaxf(x, clamp_lo), clamp_hi);
@@ -700,7 +711,7 @@ __host__ __device__ constexpr int bu_ch() { return K <= 6 ? 512 : 256; }  // lea
 template <int K>
 struct BwdArgs {
     PttView v;  // (leaf-order view)
-    const double *uleaf;
+    const float *uleaf;  // [n][K] leaf u, unclamped, as Float32 (the VI loop's forward kernel)
     const float *g, *efflens;
     const double *csum;  // [2][K]: sum x / efflen and its reciprocal (vi_csum_finish)
     GenePrior gp;
@@ -739,7 +750,7 @@ __global__ __launch_bounds__(256) void vi_csum_finish_kernel(const double *__res
 
 // a = u * x_grad at leaf position pos (bwd_values with the reciprocal of sum x / efflen at hand)
 template <int K>
-__device__ inline void bwd_leaf(const PttView &v, int64_t pos, const double *__restrict__ uleaf, const float *__restrict__ g,
+__device__ inline void bwd_leaf(const PttView &v, int64_t pos, const float *__restrict__ uleaf, const float *__restrict__ g,
                                 const float *__restrict__ efflens, const double *c, const double *inv_c, const GenePrior &gp,
                                 double (&a)[K])
 {
@@ -760,7 +771,7 @@ __device__ inline void bwd_leaf(const PttView &v, int64_t pos, const double *__r
             const double xlg = kg > 1 ? -(double)(kg - 1) / gp.gene_c[(size_t)gene * K + d] : 0.0;
             xg += xlg * (inv_l / cc) + inv_l * (gp.M / (cc * cc));
         }
-        a[d] = uleaf[(size_t)pos * K + d] * xg;
+        a[d] = (double)uleaf[(size_t)pos * K + d] * xg;
     }
 }
 
@@ -787,19 +798,6 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
     VI_STAMP(1, 0);
     const int64_t base = (int64_t)blockIdx.x * CH, p0 = base + (int64_t)threadIdx.x * LPT;
     const int64_t end = min(base + CH, (int64_t)v.n), nm1 = (int64_t)v.n - 1;
-    // (the first nodes' ranges are loaded here, in front of the barriers: the node phase then starts without a memory round trip)
-    constexpr int PRE = LPT;
-    const int32_t k0 = B.node_start[blockIdx.x] + (int32_t)threadIdx.x, k1 = B.node_start[blockIdx.x + 1];
-    int32_t kp[PRE];
-    int plo[PRE], pmid[PRE], phi[PRE];
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) {
-        kp[i] = k0 + i * 256;
-        const bool in = kp[i] < k1;
-        plo[i] = in ? v.lo[kp[i]] : 0;
-        pmid[i] = in ? v.mid[kp[i]] : 0;
-        phi[i] = in ? v.hi1[kp[i]] : 0;
-    }
     const bool exp0 = p0 <= v.n && ((B.need[p0 >> 5] >> (p0 & 31)) & 1u);
     const bool exp1 = LPT == 2 && p0 + 1 <= v.n && ((B.need[(p0 + 1) >> 5] >> ((p0 + 1) & 31)) & 1u);
     double a[LPT][K];
@@ -810,6 +808,23 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
         else
 #pragma unroll
             for (int d = 0; d < K; ++d) a[j][d] = 0.0;
+    }
+    // (the first nodes' ranges are loaded here, in front of the barriers -- the node phase then starts without a memory round
+    // trip -- and BEHIND the leaves' loads: loads return in order, and these wait for node_start first)
+    constexpr int PRE = LPT;
+    // (node_start through the vector memory path -- a lane-dependent zero in the index: a scalar load would stall the wave
+    // on its counter in front of the leaves' arithmetic)
+    const uint32_t vz = threadIdx.x >> 12;
+    const int32_t k0 = B.node_start[blockIdx.x + vz] + (int32_t)threadIdx.x, k1 = B.node_start[blockIdx.x + 1 + vz];
+    int32_t kp[PRE];
+    int plo[PRE], pmid[PRE], phi[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        kp[i] = k0 + i * 256;
+        const bool in = kp[i] < k1;
+        plo[i] = in ? v.lo[kp[i]] : 0;
+        pmid[i] = in ? v.mid[kp[i]] : 0;
+        phi[i] = in ? v.hi1[kp[i]] : 0;
     }
     VD<K> s;
 #pragma unroll
