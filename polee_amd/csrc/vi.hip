@@ -193,7 +193,7 @@ struct polee_vi {
     DevBuf<dd> d_chunk_bu;
     DevBuf<int32_t> d_node_start;
     DevBuf<uint32_t> d_need;
-    DevBuf<double> d_H;
+    DevBuf<float> d_H;
     int32_t bu_ch = 0;
     DevBuf<int> d_flag;
     // gene_noninformative (opts.gene_of): gene of every transcript, members per gene, per-gene sums of a step
@@ -327,7 +327,7 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
         if (nm1 > 0) {
             hipLaunchKernelGGL((vi_bwd_spine_kernel<K>), dim3(1), dim3(64 * K), 0, st, chunk_bu, nch_bu);
             hipLaunchKernelGGL((vi_update_k_kernel<K, NoiseSrc>), dim3((unsigned)ceil_div(nm1, 256)), dim3(256), 0, st, view,
-                               (const double *)vi->d_H.p, (const VD<K> *)chunk_bu, (const dd *)vi->d_C.p, ua, noise);
+                               (const float *)vi->d_H.p, (const VD<K> *)chunk_bu, (const dd *)vi->d_C.p, ua, noise);
         }
         if (nm1 > 0) vi->ahead_step = apply ? (sample_next ? step_num + 1 : 0) : step_num;
     }

@@ -719,7 +719,9 @@ struct BwdArgs {
     dd *C;                     // [n + 1][K] chunk-local exclusive prefix rows, written only where need says so
     const uint32_t *need;      // bit pos: row pos is read by a node that crosses chunks
     const int32_t *node_start; // [nch + 1] first node k whose lo lies in chunk c
-    double *H;                 // [2][K][n - 1] sums over the right / left subtree's leaves, nodes inside one chunk
+    float *H;                  // [2][K][n - 1] sums over the right / left subtree's leaves, nodes inside one chunk.  Float32:
+                               // one rounding of a double-double difference -- the reference's own subtree gradients are
+                               // Float32 sums of Float32 (ptt.jl:186-200, T = Float32), and y_grad is a Float32 array
 };
 
 // sums x / efflen over the forward pass's per-chunk partials: out[d] = sum, out[K + d] = 1 / sum.  Runs as one extra workgroup
@@ -873,8 +875,8 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
 #pragma unroll
         for (int d = 0; d < K; ++d) {
             const dd pm = Pmid[d];
-            B.H[(size_t)d * nm1 + k] = dd_diff(pm, Plo[d]);
-            B.H[(size_t)(K + d) * nm1 + k] = dd_diff(Phi[d], pm);
+            B.H[(size_t)d * nm1 + k] = (float)dd_diff(pm, Plo[d]);
+            B.H[(size_t)(K + d) * nm1 + k] = (float)dd_diff(Phi[d], pm);
         }
     };
 #pragma unroll
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(64 * K) void vi_bwd_spine_kernel(VD<K> *chunk_tot, 
 
 // update: one thread per internal node k, all K draws
 template <int K, typename Noise>
-__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const double *__restrict__ H, const VD<K> *__restrict__ chunk_off,
+__global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const float *__restrict__ H, const VD<K> *__restrict__ chunk_off,
                                                          const dd *__restrict__ C, UpdArgs A, Noise noise)
 {
     constexpr int CH = bu_ch<K>();
@@ -938,8 +940,8 @@ __global__ __launch_bounds__(256) void vi_update_k_kernel(PttView v, const doubl
     if ((int64_t)hi1 <= min(((int64_t)lo / CH + 1) * CH, (int64_t)v.n)) {
 #pragma unroll
         for (int d = 0; d < K; ++d) {
-            hr[d] = H[(size_t)d * nm1 + k];
-            hl[d] = H[(size_t)(K + d) * nm1 + k];
+            hr[d] = (double)H[(size_t)d * nm1 + k];
+            hl[d] = (double)H[(size_t)(K + d) * nm1 + k];
         }
     } else {  // crosses chunks: a boundary's global prefix = its chunk's offset + its chunk-local row
         const dd *Plo = C + (size_t)lo * K, *Pmid = C + (size_t)mid * K, *Phi = C + (size_t)hi1 * K;
