@@ -211,6 +211,10 @@ def regression_bench(args):
     trace = reg.fit(args.steps, seed=args.seed, return_trace=True)[-1]  # synchronises before returning
     barrier()
     elapsed = ranks.max(time.perf_counter() - t0)
+    ar = None
+    if comm is not None:  # (the first N > 1 run describes itself: the exchange's own HIP-event time on every rank)
+        ar = {"count_f32": (F + 2) * n, "ms_avg_per_rank": ranks.gather(comm.allreduce_ms((F + 2) * n)),
+              "what": "one all-reduce of (F+2) n f32 on the model's stream between two HIP events, mean of 20 calls behind an untimed first one"}
     if rank == 0:
         emit(({
             "metric": "regression steps/sec", "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
@@ -222,7 +226,7 @@ def regression_bench(args):
                        "parallelism": "samples sharded over %d GPU(s), %d on rank 0, one all-reduce of (F+2) n f32 "
                                       "statistics per step" % (world, reg.num_samples) if world > 1 else "1 GPU",
                        "comm": comm.info() if comm is not None else None},
-            "detail": {"loss_first": float(trace[0]), "loss_last": float(trace[-1]),
+            "detail": {"build": P.version(), "allreduce": ar, "loss_first": float(trace[0]), "loss_last": float(trace[-1]),
                        "finite": bool(np.all(np.isfinite(trace))), "parameters": reg.num_params,
                        "note": "latency / gather bound (SURVEY.md 8(d)): no roofline claim for this step"},
         }))
@@ -328,8 +332,12 @@ def main():
     ap.add_argument("--row-shard", action="store_true",
                     help="ONE sample for the whole job: its fragments are sharded over the GPUs and the likelihood "
                          "gradient is all-reduced once per pass (RCCL); strong scaling.  Default: one sample per GPU.")
-    ap.add_argument("--deterministic", action="store_true",
-                    help="fixed-order gradient sums (bitwise reproducible; polee_loglik_set_deterministic) instead of atomics")
+    ap.add_argument("--deterministic", dest="deterministic", action="store_true", default=None,
+                    help="fixed-order gradient sums (bitwise reproducible; polee_loglik_set_deterministic) instead of atomics. "
+                         "Default: on for --row-shard with more than one rank (SURVEY 8(e): repeated N-rank runs of one sample are "
+                         "bitwise stable), off otherwise")
+    ap.add_argument("--no-deterministic", dest="deterministic", action="store_false",
+                    help="float atomics even when the sample is row-sharded over several ranks")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="VI iterations of a THROWAWAY fit of the same sample run before the warmup steps, so that the GPU "
                          "is at its sustained clocks when the short timed region starts (a real fit is 500 iterations; "
@@ -360,6 +368,8 @@ def main():
         return regression_bench(args)
 
     world, rank, local_rank, dist, backend = init_ranks()
+    if args.deterministic is None:  # (determinism is the multi-GPU default of a shared sample)
+        args.deterministic = bool(args.row_shard and world > 1)
     if os.environ.get("POLEE_BENCH_DRY") == "1":
         # launch-path test hook for boxes without a GPU (tests/test_multiproc.py): rendezvous, barrier, max-over-ranks
         # and the JSON relay only -- no fit runs and no rate is reported
@@ -511,12 +521,20 @@ def main():
         },
         "roofline": roof,
         "detail": {
+            "build": P.version(),  # (compiler + loglik.hip tuning flags: a compiler bump that drops one costs up to 17 %)
             "source_id": sid, "hip_event_ms_per_step": ev_ms / args.steps, "prewarm_steps": args.prewarm, "gen_s": t_gen, "device_layout_build_s": t_build,
             "padded_nnz_ratio": info["padded_nnz"] / max(info["nnz"], 1), "num_tiles": info["num_tiles"],
             "max_tile_cols": info["max_tile_cols"],
         },
     }
 
+    if world > 1:  # the first N > 1 run describes itself: every rank's kernel time, and the exchange's own time
+        out["detail"]["kernel_ms_avg_per_rank"] = ranks.gather(roof["kernel_ms_avg"])
+        out["detail"]["pass_ms_avg_per_rank"] = ranks.gather(roof["pass_ms_avg"])
+        if comm is not None:
+            ar = comm.allreduce_ms(n * K)
+            out["detail"]["allreduce"] = {"count_f32": n * K, "ms_avg_per_rank": ranks.gather(ar), "what": "one all-reduce of K*n f32 on the fit's stream "
+                                          "between two HIP events, mean of 20 calls behind an untimed first one", "comm": comm.info()}
     main_entry = {"input": input_name, "n": n, "m": m, "nnz": info["nnz"], "value": out["value"], "unit": "VI iters/s",
                   "ms_per_step": out["ms_per_step"], "kernel_ms_avg": roof["kernel_ms_avg"], "pass_ms_avg": roof["pass_ms_avg"],
                   "frac": roof["frac"], "achieved": roof["achieved"], "effective_frac": roof["effective_frac"],

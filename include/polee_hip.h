@@ -649,7 +649,10 @@ polee_status polee_devx_upload_values(polee_devx *dx, const float *nzval);
 void polee_devx_destroy(polee_devx *dx);
 /* as polee_loglik_create / polee_hclust_parallel_device on the arrays the handle was made from: the same layout byte for byte, the same tree.
  * nzval_or_null: the values, if the handle has none yet -- they go up beside the layout's first kernels (row keys, sort, column search
- * need colptr + rowval only) and stay in the handle. */
+ * need colptr + rowval only) and stay in the handle: at most ONE call that passes values may run on a handle at a time (the
+ * handle's value buffer is written by it; calls on a handle that already holds its values only read it and may run side by side).
+ * With the device layout builder switched off (POLEE_DEVICE_BUILD=0 or a host-builder knob) the layout is built on the host from
+ * the handle's arrays, as polee_loglik_create would. */
 polee_status polee_loglik_create_from_devx(polee_ctx *ctx, polee_devx *dx, const float *nzval_or_null, const int64_t *ks_or_null, polee_loglik **out);
 polee_status polee_hclust_parallel_device_from_devx(polee_ctx *ctx, const polee_devx *dx, int32_t *node_parent_idxs, int32_t *node_js);
 /* The likelihood handle straight from an xbuild result, without X leaving the device: rows_to_device -> layout kernels

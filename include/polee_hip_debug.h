@@ -89,6 +89,10 @@ polee_status polee_debug_regression_data_pass(polee_regression *reg, const float
 polee_status polee_debug_regression_prior_pass(polee_regression *reg, const float *stats, float *loss,
                                                float *grad_or_null);
 
+/* `reps` all-reduces of `count` f32 on the communicator's stream between two HIP events: *ms_avg per call (the first,
+ * untimed call sets the connections up).  bench.py reports it next to the N > 1 rates. */
+polee_status polee_debug_comm_allreduce_ms(polee_comm *comm, int64_t count, int32_t reps, double *ms_avg);
+
 /* fast_log (csrc/scan.hpp), the double-precision log of the tree kernels, element-wise (tests check it against libm) */
 polee_status polee_debug_fast_log(polee_ctx *ctx, const double *x, int64_t count, double *out);
 /* fast_exp (csrc/scan.hpp), the double-precision exp of the VI loop's forward kernel (leaf u = exp of a path sum of edge logs) */

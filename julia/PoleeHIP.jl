@@ -958,6 +958,67 @@ function build_likelihood_matrix(ctx::Context, T, F, pmf::Vector{Float32}, cdf::
     end
 end
 
+# ---- the same under the BiasedFragModel (src/fragmodel.jl:174-445 with a TRAINED bias model; training stays upstream) ----------
+struct XbBiasModel
+    tseq_ptr::Ptr{Int64}; tseq::Ptr{UInt8}; seqbias_len::Int32; ps_ctx::Int32
+    orders_left::Ptr{Int32}; orders_right::Ptr{Int32}; ps_left::Ptr{Float32}; ps_right::Ptr{Float32}
+    gc_nbins::Int32; gc_bins::Ptr{Float32}; pos_p::Float64; pos_terms::Ptr{Float64}; pos_maxtlen::Int32
+    num_fraglens::Int32; high_prob_fraglens::Ptr{Int32}; m1_reverse::Ptr{UInt8}
+end
+"""
+    build_likelihood_matrix_biased(ctx, T, F, pmf, cdf, median, B; strand_specificity, alt_frag_model, return_bias)
+
+As build_likelihood_matrix with the reference's default BiasedFragModel (polee_xbuild_run_biased): B is a NamedTuple in the layout of
+polee_xb_biasmodel (include/polee_hip.h): tseq_ptr, tseq (0 A, 1 C, 2 G, 3 T, 4 other), orders_left / orders_right (Int32 [20], -1 =
+position not in the model), ps_left / ps_right (Float32 [20][4][ps_ctx] row-major), gc_bins, high_prob_fraglens, and optionally
+pos_p / pos_terms (PositionalBiasModel; `nothing` = use_pos_bias false) and m1_reverse (`nothing` when every fragment is paired).
+Returns (tcolptr, trowval, tnzval, effective_lengths, row_fragment) and, with return_bias, the transcripts' left / right bias
+vectors (polee_xbuild_get_bias, laid out like tseq).
+"""
+function build_likelihood_matrix_biased(ctx::Context, T, F, pmf::Vector{Float32}, cdf::Vector{Float32}, median::Integer, B;
+                                        strand_specificity::Real=0.9, alt_frag_model::Bool=false, return_bias::Bool=false)
+    n = length(T.seq); m = length(F.seq)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    pos_terms = get(B, :pos_terms, nothing); m1_reverse = get(B, :m1_reverse, nothing)
+    ps_ctx = div(length(B.ps_left), 20 * 4)
+    GC.@preserve T F pmf cdf B pos_terms m1_reverse begin
+        ts = XbTranscripts(n, pointer(T.seq), pointer(T.strand), pointer(T.exon_ptr), pointer(T.exon_first), pointer(T.exon_last))
+        fs = XbFragments(m, pointer(F.seq), pointer(F.strand), pointer(F.m1_left), pointer(F.m1_right), pointer(F.m2_left),
+                         pointer(F.m2_right), pointer(F.m1_is_flag16), pointer(F.cig1_ptr), pointer(F.cig2_ptr), pointer(F.cig_op),
+                         pointer(F.cig_len))
+        ms = XbFragModel(pointer(pmf), pointer(cdf), median, strand_specificity, alt_frag_model)
+        bm = XbBiasModel(pointer(B.tseq_ptr), pointer(B.tseq), 20, ps_ctx, pointer(B.orders_left), pointer(B.orders_right),
+                         pointer(B.ps_left), pointer(B.ps_right), length(B.gc_bins), pointer(B.gc_bins),
+                         pos_terms === nothing ? 0.0 : Float64(B.pos_p), pos_terms === nothing ? Ptr{Float64}(C_NULL) : pointer(pos_terms),
+                         pos_terms === nothing ? 0 : length(pos_terms), length(B.high_prob_fraglens), pointer(B.high_prob_fraglens),
+                         m1_reverse === nothing ? Ptr{UInt8}(C_NULL) : pointer(m1_reverse))
+        check(ccall((:polee_xbuild_run_biased, LIB), Cint,
+                    (Ptr{Cvoid}, Ref{XbTranscripts}, Ref{XbFragments}, Ref{XbFragModel}, Ref{XbBiasModel}, Ref{Ptr{Cvoid}}),
+                    ctx.h, ts, fs, ms, bm, out), ctx.h)
+    end
+    h = out[]
+    try
+        rows, nnz = Ref{Int64}(0), Ref{Int64}(0)
+        check(ccall((:polee_xbuild_sizes, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    h, rows, nnz, C_NULL, C_NULL, C_NULL), ctx.h)
+        tcolptr, trowval, tnzval = Vector{UInt64}(undef, rows[] + 1), Vector{UInt32}(undef, nnz[]), Vector{Float32}(undef, nnz[])
+        efflens, rowfrag = Vector{Float32}(undef, n), Vector{Int64}(undef, rows[])
+        GC.@preserve tcolptr trowval tnzval efflens rowfrag check(
+            ccall((:polee_xbuild_get, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt64}, Ptr{UInt32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int64}),
+                  h, tcolptr, trowval, tnzval, efflens, rowfrag), ctx.h)
+        if return_bias
+            len = Int(B.tseq_ptr[end])
+            left, right = Vector{Float32}(undef, len), Vector{Float32}(undef, len)
+            GC.@preserve left right check(ccall((:polee_xbuild_get_bias, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float64}),
+                                                h, left, right, C_NULL), ctx.h)
+            return tcolptr, trowval, tnzval, efflens, rowfrag, left, right
+        end
+        return tcolptr, trowval, tnzval, efflens, rowfrag
+    finally
+        ccall((:polee_xbuild_destroy, LIB), Cvoid, (Ptr{Cvoid},), h)
+    end
+end
+
 "fast_log of the tree kernels (csrc/scan.hpp), element-wise on the device: the tests compare it with Base.log"
 function debug_fast_log(ctx::Context, x::Vector{Float64})
     out = similar(x)

@@ -17,7 +17,7 @@ would use).  Names, argument meaning and error behaviour follow the reference:
 All numerics run in libpolee_hip.so on the GPU; nothing here computes on the CPU.
 """
 from ._lib import PoleeError, NonFiniteError, lib, LIB_PATH  # noqa: F401
-from .core import (Context, Comm, HostComm, hclust, host_cache_trim, sample_and_tree, PolyaTreeTransform, make_inverse_ptt_params, hsb, inv_hsb, inv_hsb_grad,  # noqa: F401
+from .core import (Context, Comm, HostComm, version, hclust, host_cache_trim, sample_and_tree, PolyaTreeTransform, make_inverse_ptt_params, hsb, inv_hsb, inv_hsb_grad,  # noqa: F401
                    RNASeqSample, DeviceX, log_likelihood, factored_log_likelihood,
                    effective_length_jacobian_adjustment, gene_noninformative_prior, LogitSkewNormalPTTApprox, approximate_likelihood,
                    LikelihoodApproximationFit, ApproxLikelihoodSampler, RNASeqApproxLikelihood,

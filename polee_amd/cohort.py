@@ -75,6 +75,16 @@ class Ranks:
     def sum(self, value):
         return self._reduce(value, self.dist.ReduceOp.SUM if self.dist is not None else None)
 
+    def gather(self, value):
+        """Every rank's value, in rank order (a list of floats), on every rank."""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+        t = torch.zeros(self.world, dtype=torch.float64, device=self.device or "cpu")
+        t[self.rank] = float(value)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
     def aggregate_throughput(self, local_units, local_seconds):
         """Whole-job rate = units of all ranks / slowest rank's time."""
         return self.sum(local_units) / self.max(local_seconds)

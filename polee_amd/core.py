@@ -62,6 +62,11 @@ def default_context():
     return _default_ctx
 
 
+def version():
+    """polee_version(): the library's version, the compiler it was built with and loglik.hip's tuning flags in use."""
+    return L.lib().polee_version().decode()
+
+
 def make_inverse_ptt_params(node_parent_idxs, node_js):
     """src/ptt.jl:293-309 -> (left_index, right_index, leaf_index), 0-based, -1 = none."""
     p, j = arr(node_parent_idxs, np.int32), arr(node_js, np.int32)
@@ -540,6 +545,13 @@ class Comm:
                     # (RCCL transport: POLEE_COMM_ALGO=rs_ag exchanges by reduce-scatter + all-gather instead of one all-reduce)
                     algo=os.environ.get("POLEE_COMM_ALGO", "allreduce") if t.value == 1 else "host all-reduce")
 
+    def allreduce_ms(self, count, reps=20):
+        """HIP-event time of one all-reduce of `count` f32 on the library's stream, averaged over `reps` calls behind an untimed
+        first one (polee_debug_comm_allreduce_ms): what the exchange itself adds to a row-sharded pass or a regression step."""
+        ms = C.c_double()
+        check(L.lib().polee_debug_comm_allreduce_ms(self._h, C.c_int64(int(count)), C.c_int32(int(reps)), C.byref(ms)), self.ctx._h)
+        return ms.value
+
     def allreduce_sum(self, values):
         """Sum of a float32 array over the ranks (polee_allreduce_sum_f32)."""
         v = arr(values, np.float32).copy()
@@ -577,8 +589,11 @@ class LikelihoodApproximationFit:
 
     def __init__(self, sample, t, efflens=None, num_steps=LIKAP_NUM_STEPS, num_mc_samples=LIKAP_NUM_MC_SAMPLES,
                  use_efflen_jacobian=True, gradonly=True, seed=123456789, z0=None, profile=False, comm=None,
-                 gene_transcripts=None, adam=None, deterministic=False):
+                 gene_transcripts=None, adam=None, deterministic=None):
         """gene_transcripts (Dict gene -> 1-based transcript indexes, or gene_of int[n]): gene_noninformative = true.
+        deterministic: fixed-order gradient sums (bitwise reproducible) instead of float atomics; None = on when the sample is
+        shared by more than one rank (comm.world_size > 1: repeated N-rank fits of one sample are bitwise stable),
+        off otherwise.
         adam: optional overrides of the optimiser constants of polee_vi_opts (adam_initial_learning_rate, adam_rm,
         max_mu_step, ...; defaults = the reference's, constants.jl:48-65)."""
         self.sample, self.t, self.ctx = sample, t, sample.ctx
@@ -597,7 +612,10 @@ class LikelihoodApproximationFit:
             if self._z0.size != num_steps * num_mc_samples * (sample.n - 1):
                 raise ValueError("z0 must have num_steps*num_mc_samples*(n-1) elements")
             o.z0 = ptr(self._z0, f32p)
-        o.deterministic = int(bool(deterministic))
+        if deterministic is None:
+            deterministic = comm is not None and getattr(comm, "world_size", 1) > 1
+        self.deterministic = bool(deterministic)
+        o.deterministic = int(self.deterministic)
         for key, val in (adam or {}).items():
             if not (key.startswith("adam_") or key.startswith("max_")) or not hasattr(o, key):
                 raise ValueError("unknown optimiser constant %r" % (key,))
@@ -714,8 +732,8 @@ def _sample_and_tree(approx, tm, m, n, colptr, rowval, nzval, effective_lengths,
         def shared():
             try:
                 return DeviceX(m, n, colptr, rowval, None, ctx=ctx) if share_x else None  # (the values go up with the layout, beside its first kernels)
-            except L.PoleeError as e:  # (more than 32 bits of non-zeros: the host paths)
-                if "32 bits" in str(e):
+            except L.PoleeError as e:  # (POLEE_ERR_UNSUPPORTED: more than 32 bits of rows or non-zeros -- the host paths)
+                if e.status == 5:
                     return None
                 raise
         if tm == "cluster_auto":

@@ -193,6 +193,36 @@ void polee_comm_destroy(polee_comm *c)
     ctx_release(ctx);
 }
 
+// bench hook (include/polee_hip_debug.h): `reps` all-reduces of `count` f32 of a zeroed device buffer on the library's stream,
+// bracketed by HIP events: *ms_avg = the exchange's own time per call (what a row-sharded pass or a regression step adds)
+polee_status polee_debug_comm_allreduce_ms(polee_comm *c, int64_t count, int32_t reps, double *ms_avg)
+{
+    if (!c) return fail(nullptr, POLEE_ERR_BAD_ARG, "null communicator");
+    polee_ctx *ctx = c->ctx;
+    POLEE_TRY(use_device(ctx));
+    if (count < 1 || reps < 1 || !ms_avg) return fail(ctx, POLEE_ERR_BAD_ARG, "bad argument");
+    DevBuf<float> d;
+    POLEE_TRY(d.alloc(ctx, (size_t)count));
+    POLEE_HIP_TRY(ctx, hipMemsetAsync(d.p, 0, sizeof(float) * (size_t)count, ctx->stream));
+    POLEE_TRY(comm_allreduce_device(c, d.p, (size_t)count, false));  // (first call: connection set-up, not timed)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    POLEE_HIP_TRY(ctx, hipEventCreate(&e0));
+    hipError_t he = hipEventCreate(&e1);
+    polee_status st = POLEE_OK;
+    if (he == hipSuccess) he = hipEventRecord(e0, ctx->stream);
+    for (int32_t i = 0; i < reps && he == hipSuccess && st == POLEE_OK; ++i) st = comm_allreduce_device(c, d.p, (size_t)count, false);
+    if (he == hipSuccess) he = hipEventRecord(e1, ctx->stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st != POLEE_OK) return st;
+    if (he != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "all-reduce timing failed: %s", hipGetErrorString(he));
+    *ms_avg = (double)ms / reps;
+    return POLEE_OK;
+}
+
 polee_status polee_allreduce_sum_f32(polee_comm *c, float *buf, int64_t count)
 {
     if (!c) return fail(nullptr, POLEE_ERR_BAD_ARG, "null communicator");

@@ -2975,26 +2975,35 @@ polee_status polee_loglik_create_from_devx(polee_ctx *ctx, polee_devx *dx, const
         if (dx->nnz && !dx->nzval.p && !nzval)
             return fail(ctx, POLEE_ERR_BAD_ARG, "polee_loglik_create_from_devx: the values have not been uploaded (polee_devx_upload_values, or pass them here)");
         const float *late = dx->nnz && !dx->nzval.p ? nzval : nullptr;  // (go up beside the first kernels, into the handle)
-        if (!psell_device_enabled())
-            return fail(ctx, POLEE_ERR_UNSUPPORTED, "polee_loglik_create_from_devx: the device builder is switched off (POLEE_DEVICE_BUILD=0 or a host-builder knob)");
-        bool done = false;
-        polee_status st = POLEE_OK;
-        {
-            PsellDevCSR C;
-            if ((st = psell_device_rows_from_dev_csc(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, dx->nzval.p, ks, C, nullptr, late, &dx->nzval)) != POLEE_OK) return st;
-            st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+        // (device builder switched off -- POLEE_DEVICE_BUILD=0 or a host-builder knob: straight to the host layout builder below,
+        // as polee_loglik_create would; the handle's copy of X still saves the tree builder its upload)
+        if (psell_device_enabled()) {
+            bool done = false;
+            polee_status st = POLEE_OK;
+            {
+                PsellDevCSR C;
+                if ((st = psell_device_rows_from_dev_csc(ctx, dx->m, dx->n, dx->cp.p, dx->nnz, dx->rowval.p, dx->nzval.p, ks, C, nullptr, late, &dx->nzval)) != POLEE_OK) return st;
+                st = loglik_create_on_device(ctx, C.view(), ks != nullptr, out, done);
+            }
+            if (st != POLEE_OK || done) return st;
         }
-        if (st != POLEE_OK || done) return st;
         // the host builder's case (a real share of rows without any structure): through host arrays, as polee_loglik_create would
         std::vector<uint64_t> h_cp((size_t)dx->n + 1);
         std::vector<uint32_t> h_row((size_t)dx->nnz);
-        std::vector<float> h_val((size_t)dx->nnz);
+        std::vector<float> h_val;
         POLEE_TRY(dx->cp.download(ctx, h_cp.data(), h_cp.size()));
+        const float *vals = nullptr;
         if (dx->nnz) {
             POLEE_TRY(dx->rowval.download(ctx, h_row.data(), h_row.size()));
-            POLEE_TRY(dx->nzval.download(ctx, h_val.data(), h_val.size()));
+            if (dx->nzval.p) {
+                h_val.resize((size_t)dx->nnz);
+                POLEE_TRY(dx->nzval.download(ctx, h_val.data(), h_val.size()));
+                vals = h_val.data();
+            } else {
+                vals = nzval;  // (values that were to go up late never did: the caller's host array is the source)
+            }
         }
-        return polee_loglik_create_impl(ctx, dx->m, dx->n, h_cp.data(), 8, h_row.data(), h_val.data(), ks, out);
+        return polee_loglik_create_impl(ctx, dx->m, dx->n, h_cp.data(), 8, h_row.data(), vals, ks, out);
     });
 }
 

@@ -257,13 +257,23 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     } else {
         POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<K>), st));
     }
-    hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows, float>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
-                       vi->d_u32.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
-                       eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
-                       (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
-                       xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
-                       xwin_here ? vi->ll->d_xwin.p : nullptr,
-                       remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
+    if (want_values) {
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows, float, true>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
+                           vi->d_u32.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
+                           eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
+                           (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
+                           xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
+                           xwin_here ? vi->ll->d_xwin.p : nullptr,
+                           remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
+    } else {
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<K, YRows, float, false>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, lview, ysrc, chunk_f,
+                           vi->d_u32.p, vi->d_x.p, vi->d_g.p, eff, (float)o.y_eps, (float)(1.0 - o.y_eps),
+                           eff ? vi->d_part_c.p : nullptr, want_values ? vi->d_part_ladj.p : nullptr, nch_f > 1 ? own_f : 0,
+                           (const uint32_t *)vi->d_open_ptr.p, (const uint32_t *)vi->d_open_code.p,
+                           xwin_here ? (const uint32_t *)vi->ll->d_tslot_ptr.p : nullptr, xwin_here ? (const uint32_t *)vi->ll->d_tslot.p : nullptr,
+                           xwin_here ? vi->ll->d_xwin.p : nullptr,
+                           remap && remap->singles_in_g ? (const float *)vi->d_single_leaf.p : nullptr);
+    }
     POLEE_KERNEL_CHECK(ctx);
     // likelihood
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
@@ -945,7 +955,7 @@ polee_status polee_optimize_ptt(polee_loglik *ll, polee_ptt *t, const float *eff
         } else {
             POLEE_HIP_TRY(ctx, hipMemsetAsync(chunk_f, 0, sizeof(VK<1>), st));
         }
-        hipLaunchKernelGGL((vi_fwd_apply_kernel<1, LogRows, double>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f,
+        hipLaunchKernelGGL((vi_fwd_apply_kernel<1, LogRows, double, false>), dim3(nch_f), dim3(SCAN_THREADS), 0, st, view, LogRows{vi->d_lyy.p}, chunk_f,
                            vi->d_uleaf.p, vi->d_x.p, vi->d_g.p, vi->d_efflens.p, (float)o.y_eps, (float)(1.0 - o.y_eps),
                            vi->d_part_c.p, (double *)nullptr, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, (float *)nullptr, (const float *)nullptr);

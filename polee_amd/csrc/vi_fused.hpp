@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void vi_sample_k_kernel(const float *__restric
 struct LogRows {
     const double *lyy;
     template <int K>
+    __device__ inline double edge_one(uint32_t k, uint32_t left, int d) const { return lyy[((size_t)k * 2 + left) * K + d]; }
+    template <int K>
     __device__ inline void edge(uint32_t k, uint32_t left, double (&e)[K]) const
     {
         const double *p = lyy + ((size_t)k * 2 + left) * K;
@@ -193,6 +195,12 @@ struct LogRows {
 struct YRows {
     const float *y32;
     double y_eps;
+    template <int K>
+    __device__ inline double edge_one(uint32_t k, uint32_t left, int d) const
+    {
+        const double y = clamped_y(y32[(size_t)k * K + d], y_eps);
+        return fast_log(left ? y : 1.0 - y);
+    }
     template <int K>
     __device__ inline void edge(uint32_t k, uint32_t left, double (&e)[K]) const
     {
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_reduce_kernel(PttView v, 
 // forward apply: leaves get u = exp(prefix + own edge); x = clamp(max(f32(u), 1e-16)) (ptt.jl:138-139,
 // likelihood-approximation.jl:526) written to xs[tid][K]; g[tid][K] is zeroed for the likelihood pass;
 // per-chunk partial sums of x/efflen (likelihood.jl:97-100) and, if wanted, of log u over internal nodes.
-template <int K, typename Src, typename UT>
+template <int K, typename Src, typename UT, bool LADJ>
 __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, Src lyy,
                                                                    const VK<K> *__restrict__ chunk_offsets,
                                                                    UT *__restrict__ uleaf, float *__restrict__ xs,
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
     __shared__ VK<K> smem[SCAN_THREADS / 64];
     __shared__ double smd[4 * K];
     __shared__ double spre[K];  // the chunk's offset from the open-edge list
+    __shared__ double smd2[LADJ ? 4 * K : 1];
     // x windows of the sparse pass (loglik_internal.hpp): a transcript's x row also goes to its slot in every tile
     // dictionary that holds it (tslot lists) -- the gather launch in front of the pass is gone.  A thread writes up to
     // XW_INLINE slots itself; transcripts in more tiles are written by the whole workgroup afterwards.
@@ -310,10 +319,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
         ob = open_ptr[blockIdx.x];
         oe = open_ptr[blockIdx.x + 1];
     }
-    // (the list is the path from the root, rarely longer than a wave: the first wave sums it alone -- the edge logs are K
-    // double logs per entry -- and leaves the sum in LDS in front of the scan's barriers)
-    const bool first_wave = threadIdx.x < 64;
-    const uint32_t ocode0 = first_wave && ob + lane < oe ? open_code[ob + lane] : (4u | TOUR_LEAF);
+    // (the list is the path from the root, rarely longer than a wave: every wave takes the entries' codes and sums the edge logs
+    // of ITS draws -- wave w the draws w, w + 4 -- so the K double logs per entry are spread over the four waves; the sums go to
+    // LDS in front of the scan's barriers)
+    const int wave = threadIdx.x >> 6;
+    const uint32_t ocode0 = ob + lane < oe ? open_code[ob + lane] : (4u | TOUR_LEAF);
     VK<K> acc = ScanOps<VK<K>>::zero();
     float inv_l_[FWD_ITEMS], sc_[FWD_ITEMS];
     int ltid[FWD_ITEMS];
@@ -330,19 +340,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
         sc_[j] = leaf && single_cnt ? single_cnt[ltid[j]] : 0.0f;
     }
     VI_STAMP(0, 1);
-    if (open_ptr && first_wave) {
+    if (open_ptr) {
         // The chunk's offset = the tour prefix in front of it.  Every ENTER before the chunk whose EXIT lies before it too has
         // cancelled, so the prefix is the sum of the edge logs of the nodes that are OPEN at the chunk's first entry -- the
         // path from the root to that point, a list fixed by the tree (open_ptr / open_code, built once per fit): with it the
         // forward pass needs no reduce launch and no pass over the other chunks' totals.
-        VK<K> edge2;
-        VK<K> pre = tour_value<K, Src>(ocode0, lyy, edge2);  // (ENTER codes: + the edge's log; the filler is a root LEAF: 0)
-        for (uint32_t e = ob + 64 + lane; e < oe; e += 64) pre = ScanOps<VK<K>>::add(pre, tour_value<K, Src>(open_code[e], lyy, edge2));
 #pragma unroll
-        for (int d = 0; d < K; ++d) {
+        for (int dd_ = 0; dd_ < (K + 3) / 4; ++dd_) {
+            const int d = wave + 4 * dd_;  // (wave-uniform)
+            if (d < K) {
+                // (ENTER codes: + the edge's log; the filler is a root LEAF: 0)
+                double pre = (ocode0 & 4u) ? 0.0 : lyy.template edge_one<K>(ocode0 >> 4, (ocode0 >> 3) & 1u, d);
+                for (uint32_t e = ob + 64 + lane; e < oe; e += 64) {
+                    const uint32_t oc = open_code[e];
+                    pre += lyy.template edge_one<K>(oc >> 4, (oc >> 3) & 1u, d);
+                }
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) pre.v[d] += __shfl_xor(pre.v[d], o, 64);
-            if (lane == 0) spre[d] = pre.v[d];
+                for (int o = 32; o >= 1; o >>= 1) pre += __shfl_xor(pre, o, 64);
+                if (lane == 0) spre[d] = pre;
+            }
         }
     }
     VI_STAMP(0, 2);
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
                         }
                     }
                 }
-            } else if (type == TOUR_ENTER && part_ladj) {
+            } else if (LADJ && type == TOUR_ENTER) {
 #pragma unroll
                 for (int d = 0; d < K; ++d) pl[d] += inc.v[d];
             }
@@ -419,15 +435,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
         }
     }
     VI_STAMP(0, 4);
-    if (part_c) {
-        block_sum_vec<K>(pc, smd);
-        store_vec_by_thread<K>(pc, part_c + (size_t)blockIdx.x * K);
+    // the chunk's partial sums: a wave's 64 values by a shuffle tree, the four waves' through LDS in wave order -- one barrier
+    if (part_c || LADJ) {
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            double a = pc[d], b = LADJ ? pl[d] : 0.0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                a += __shfl_xor(a, o, 64);
+                if (LADJ) b += __shfl_xor(b, o, 64);
+            }
+            if (lane == 0) {
+                smd[wave * K + d] = a;
+                if (LADJ) smd2[wave * K + d] = b;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < K) {
+            const int d = threadIdx.x;
+            if (part_c) part_c[(size_t)blockIdx.x * K + d] = ((smd[d] + smd[K + d]) + smd[2 * K + d]) + smd[3 * K + d];
+            if (LADJ) part_ladj[(size_t)blockIdx.x * K + d] = ((smd2[d] + smd2[K + d]) + smd2[2 * K + d]) + smd2[3 * K + d];
+        }
     }
     VI_STAMP(0, 5);
-    if (part_ladj) {
-        block_sum_vec<K>(pl, smd);
-        store_vec_by_thread<K>(pl, part_ladj + (size_t)blockIdx.x * K);
-    }
 }
 
 // gene_noninformative_prior! (likelihood.jl:114-159) inside the loop: gene_of == nullptr = off.

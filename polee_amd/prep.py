@@ -8,8 +8,14 @@ Polya tree (hclust, or read it from a `--ptt-tree` file, :428-436), fit the appr
 load_samples_from_specification read.  The ingest that produces X (BAM -> fragments -> X, bias models) stays with
 the reference.
 
-    python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method cluster|cluster_parallel|cluster_device|sequential]
+    python -m polee_amd.prep likelihood-matrix.h5 -o prepared-sample.h5 [--tree-method auto|cluster|cluster_parallel|cluster_device|cluster_auto|sequential]
         [--ptt-tree tree.h5] [--no-efflen-jacobian] [--seed N] [--device D]
+
+--tree-method (default auto): "cluster" is the reference's heuristic merge for merge (src/hclust.jl:193-319) -- a serial
+priority-queue loop, 3.7 s on one host thread at 200 000 transcripts.  "cluster_auto" / "cluster_parallel" / "cluster_device" build
+the ROUNDS variant (mutually-best pairs merged per round; 82-86 % of its clades are the reference tree's, the fit on it is as good:
+tests/test_gpu_hclust.py), the same tree from the host threads or the GPU, 0.09-0.45 s.  "auto" takes the reference's order up to
+AUTO_EXACT_MAX_N transcripts (where it costs well under a second) and the rounds variant above, and says which tree it built.
 
 `polee prep-salmon` (src/main.jl:723-750): the factored likelihood of `salmon quant -d` output on a given tree:
 
@@ -26,6 +32,22 @@ from .core import (Context, LogitSkewNormalPTTApprox, PolyaTreeTransform, RNASeq
                    sample_and_tree)
 
 
+# --tree-method auto: the reference-order tree up to this many transcripts, the rounds variant above (the
+# out-of-the-box path at GENCODE size was ten times slower than the documented one)
+AUTO_EXACT_MAX_N = 20000
+
+
+def resolve_tree_method(method, n):
+    """(treemethod, note) for --tree-method `method` on n transcripts."""
+    if method != "auto":
+        return method, None
+    if n <= AUTO_EXACT_MAX_N:
+        return "cluster", "tree: the reference's merge order (hclust.jl), n = %d <= %d" % (n, AUTO_EXACT_MAX_N)
+    return "cluster_auto", ("tree: the ROUNDS variant of the heuristic (cluster_auto: host threads or GPU, the same tree), n = %d > %d; "
+                            "--tree-method cluster builds the reference's merge order instead (serial: seconds at this size)"
+                            % (n, AUTO_EXACT_MAX_N))
+
+
 def approximate_likelihood_to_file(approx, likelihood_matrix_filename, output_filename, use_efflen_jacobian=True,
                                    tree_topology_input_filename=None, seed=123456789, ctx=None, args=""):
     """Returns the params dict that was written (mu, omega, alpha, node_parent_idxs, node_js) plus timings."""
@@ -33,6 +55,10 @@ def approximate_likelihood_to_file(approx, likelihood_matrix_filename, output_fi
     t0 = time.time()
     lm = h5io.read_likelihood_matrix(likelihood_matrix_filename)
     t_read = time.time() - t0
+    note = None
+    if approx.treemethod == "auto":
+        tm, note = resolve_tree_method("auto", int(lm["n"]))
+        approx = LogitSkewNormalPTTApprox(tm)
     t0 = time.time()
     if tree_topology_input_filename is not None:  # likelihood-approximation.jl:428-433
         sample = RNASeqSample(lm["m"], lm["n"], lm["colptr"], lm["rowval"], lm["nzval"], lm["effective_lengths"], ctx=ctx)
@@ -47,6 +73,8 @@ def approximate_likelihood_to_file(approx, likelihood_matrix_filename, output_fi
     t_fit = time.time() - t0
     h5io.write_approximation(output_filename, lm["m"], lm["n"], lm["effective_lengths"], params, args=args)
     params["timings"] = {"read_s": t_read, "device_layout_and_tree_s": t_layout, "fit_s": t_fit}
+    params["tree_method"] = "file" if tree_topology_input_filename is not None else approx.treemethod
+    params["tree_note"] = note if tree_topology_input_filename is None else None
     return params
 
 
@@ -79,7 +107,8 @@ def main(argv=None):
     ap.add_argument("--salmon", default=None, metavar="salmon_quant_dir", help="prep-salmon: salmon quant -d output")
     ap.add_argument("--transcript-ids", default=None, metavar="ids.txt", help="with --salmon: transcript ids, tree order")
     ap.add_argument("-o", "--output", default="prepared-sample.h5", metavar="prepared-sample.h5")
-    ap.add_argument("--tree-method", default="cluster", choices=["cluster", "cluster_parallel", "cluster_device", "cluster_auto", "sequential"])
+    ap.add_argument("--tree-method", default="auto", choices=["auto", "cluster", "cluster_parallel", "cluster_device", "cluster_auto", "sequential"],
+                    help="auto (default): the reference's merge order up to %d transcripts, the rounds variant (cluster_auto) above" % AUTO_EXACT_MAX_N)
     ap.add_argument("--ptt-tree", default=None, metavar="tree.h5", help="use this tree topology (polee fit-tree output)")
     ap.add_argument("--no-efflen-jacobian", action="store_true")
     ap.add_argument("--seed", type=int, default=123456789)
@@ -105,8 +134,10 @@ def main(argv=None):
                                             tree_topology_input_filename=a.ptt_tree, seed=a.seed,
                                             ctx=Context(a.device), args=" ".join(argv or sys.argv[1:]))
     t = params["timings"]
-    print("wrote %s (n=%d): read %.2f s, device layout and tree %.2f s, fit %.2f s"
-          % (a.output, len(params["mu"]) + 1, t["read_s"], t["device_layout_and_tree_s"], t["fit_s"]))
+    if params.get("tree_note"):
+        print(params["tree_note"])
+    print("wrote %s (n=%d): read %.2f s, device layout and tree (%s) %.2f s, fit %.2f s"
+          % (a.output, len(params["mu"]) + 1, t["read_s"], params["tree_method"], t["device_layout_and_tree_s"], t["fit_s"]))
     return 0
 
 

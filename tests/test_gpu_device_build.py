@@ -150,3 +150,33 @@ def test_random_matrices_through_both_device_builders(P):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "fuzz_device_builders.py"), "60", "7"], capture_output=True,
                        text=True, timeout=1200)
     assert r.returncode == 0 and "mismatching 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_shared_x_with_the_device_layout_builder_switched_off():
+    """with POLEE_DEVICE_BUILD=0 (documented in README / cohort.py) and the tree on the device, sample_and_tree sends the
+    layout through polee_loglik_create_from_devx -- which must then build it on the host from the handle's arrays instead of
+    failing: the same fit as with the device builder (a subprocess: the switch is read once per process)."""
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import polee_amd as P
+from tools import synth
+s = synth.make_sample(3000, 150000, 8.0, 5)
+c, r, v = synth.to_csc(s)
+ctx = P.Context(0)
+smp, tree = P.sample_and_tree(P.LogitSkewNormalPTTApprox("cluster_device"), s["m"], s["n"], c, r, v, s["effective_lengths"], ctx=ctx)
+xs = np.full((2, s["n"]), 1.0 / s["n"], np.float32)
+lp, g = smp.log_likelihood(xs)
+print("RESULT %%d %%r %%r" %% (int(smp.built_on_device), float(lp[0]), float(np.abs(g).sum())))
+""" % ROOT
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, POLEE_DEVICE_BUILD=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+        out[flag] = (float(line[2]), float(line[3]))
+        assert int(line[1]) == int(flag), line  # (the layout really came from the builder the switch names)
+    # the same likelihood through either layout builder (f32 sums in a different order: 1e-5)
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-5 * abs(out["1"][0]), out
+    assert abs(out["0"][1] - out["1"][1]) <= 1e-4 * abs(out["1"][1]), out

@@ -53,11 +53,18 @@ def _hooks():
 def test_bench_row_shard_two_ranks():
     d = _bench(["--gpus", "2", "--workload", "c1", "--steps", "20", "--warmup", "3", "--row-shard"], **_hooks())
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # the first N > 1 run describes itself: determinism on by default, the build, every rank's kernel time, the exchange's time
+    assert d["config"]["deterministic"] is True and "hipcc" in d["detail"]["build"]
+    assert len(d["detail"]["kernel_ms_avg_per_rank"]) == 2 and all(v > 0 for v in d["detail"]["kernel_ms_avg_per_rank"])
+    assert len(d["detail"]["allreduce"]["ms_avg_per_rank"]) == 2 and all(v > 0 for v in d["detail"]["allreduce"]["ms_avg_per_rank"])
+    d2 = _bench(["--gpus", "2", "--workload", "c1", "--steps", "5", "--warmup", "1", "--row-shard", "--no-deterministic"], **_hooks())
+    assert d2["config"]["deterministic"] is False
 
 
 def test_bench_regression_two_ranks():
     d = _bench(["--gpus", "2", "--workload", "c3", "--steps", "20", "--warmup", "3"], **_hooks())
     assert d["n_gpus"] == 2 and d["detail"]["finite"]
+    assert "hipcc" in d["detail"]["build"] and len(d["detail"]["allreduce"]["ms_avg_per_rank"]) == 2
 
 
 ROW_FIT_WORKER = r'''
@@ -96,6 +103,12 @@ t = P.PolyaTreeTransform(pr["node_parent_idxs"], pr["node_js"], ctx=ctx)
 fit = P.LikelihoodApproximationFit(s, t, num_steps=steps, num_mc_samples=K, z0=z0, comm=comm, gradonly=False)
 fit.run(steps); fit.sync()
 mine = np.concatenate(fit.params())
+# ... and once more: a sample shared by several ranks is fitted with fixed-order gradient sums unless told otherwise (VERDICT r5
+# item 5), so the second fit is the first one bit for bit
+fit_b = P.LikelihoodApproximationFit(s, t, num_steps=steps, num_mc_samples=K, z0=z0, comm=comm, gradonly=False)
+fit_b.run(steps); fit_b.sync()
+again = np.concatenate(fit_b.params())
+det_default = bool(fit.deterministic and fit_b.deterministic)
 # the same fit on the whole sample, one rank's own stream, no communicator
 s1 = P.RNASeqSample(m, n, None, None, None, d["effective_lengths"], ctx=ctx, xt=(tp, tr, tv))
 f1 = P.LikelihoodApproximationFit(s1, t, num_steps=steps, num_mc_samples=K, z0=z0, gradonly=False)
@@ -105,6 +118,7 @@ allp = [None] * world
 dist.all_gather_object(allp, mine)
 if rank == 0:
     print(json.dumps({"replica_diff": float(max(np.abs(a - allp[0]).max() for a in allp)),
+                      "rerun_diff": float(np.abs(mine - again).max()), "deterministic_default": det_default,
                       "vs_whole": float(np.abs(mine - whole).max()), "scale": float(np.abs(whole).max()),
                       "lp_shard": float(fit.trace()[1][-1]), "lp_whole": float(f1.trace()[1][-1])}))
 dist.destroy_process_group()
@@ -132,5 +146,6 @@ def test_two_rank_row_sharded_fit_equals_single_rank(tmp_path, transport):
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["replica_diff"] == 0.0
+    assert d["deterministic_default"] and d["rerun_diff"] == 0.0  # two consecutive row-sharded fits: bitwise equal
     assert d["vs_whole"] < 2e-3 * d["scale"]
     assert abs(d["lp_shard"] - d["lp_whole"]) < 1e-5 * abs(d["lp_whole"])

@@ -117,3 +117,14 @@ def test_loader_builds_device_likelihood(tmp_path, prep_fixture):
     # device-RNG initial values are the same statistic: close to the supplied-noise mean on the expressed transcripts
     big = ls2.x0_values[0] > 1e-3
     assert np.abs(np.log(ls.x0_values[0][big] / ls2.x0_values[0][big])).max() < 1.0
+
+
+def test_prep_tree_method_auto_names_the_tree_it_builds():
+    """python -m polee_amd.prep --tree-method auto (the default): the reference's merge order for small annotations, the rounds
+    variant above a stated size, and a note that says which -- an explicit choice is passed through untouched."""
+    from polee_amd import prep
+    assert prep.resolve_tree_method("cluster", 10 ** 6) == ("cluster", None)
+    tm, note = prep.resolve_tree_method("auto", prep.AUTO_EXACT_MAX_N)
+    assert tm == "cluster" and "reference" in note
+    tm, note = prep.resolve_tree_method("auto", prep.AUTO_EXACT_MAX_N + 1)
+    assert tm == "cluster_auto" and "ROUNDS" in note and "--tree-method cluster" in note

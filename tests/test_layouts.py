@@ -26,6 +26,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.polee_version()
 
 
+def test_every_public_export_has_a_julia_binding():
+    """The host side of the boundary is Julia (BASELINE north_star): every function include/polee_hip.h declares is bound by
+    a ccall in julia/PoleeHIP.jl (the two that were not, polee_xbuild_run_biased / polee_xbuild_get_bias).  The
+    binding has never run -- there is no Julia in the image -- so this checks names, not behaviour."""
+    src = open(os.path.join(ROOT, "include", "polee_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(polee_[a-z0-9_]+)\s*\(", src))
+    jl = open(os.path.join(ROOT, "julia", "PoleeHIP.jl")).read()
+    missing = [n for n in sorted(names) if (":" + n) not in jl]
+    assert len(names) > 100 and not missing, missing
+
+
 def test_context_fails_loudly_without_gpu():
     from polee_amd import Context, PoleeError
     try:
