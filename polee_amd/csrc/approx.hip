@@ -116,11 +116,27 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
 }
 
 // lp[s] = node terms + sum x - (n-1) log A + sum log efflen - log(R), R = Bn / A   (:384-400)
+// (partials != nullptr: the gradient scan's per-chunk partial sums are finished here too -- dots[s][0..1], what a
+// reduce_partials_kernel launch did: one single-workgroup launch per call less)
 __global__ __launch_bounds__(256) void approx_finish_lp_kernel(ApproxView a, const double *acc, const double *npart,
-                                                               int nblk, const double *sum_log_l, float *lp)
+                                                               int nblk, const double *sum_log_l, float *lp,
+                                                               const double *partials, int nchunks, double *dots)
 {
     __shared__ double smd[4];
     const int s = blockIdx.x;
+    if (partials) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int c = threadIdx.x; c < nchunks; c += 256) {
+            s0 += partials[((int64_t)s * nchunks + c) * 2 + 0];
+            s1 += partials[((int64_t)s * nchunks + c) * 2 + 1];
+        }
+        s0 = block_sum_f64(s0, smd);
+        s1 = block_sum_f64(s1, smd);
+        if (threadIdx.x == 0) {
+            dots[(int64_t)s * 2 + 0] = s0;
+            dots[(int64_t)s * 2 + 1] = s1;
+        }
+    }
     double nodes = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) nodes += npart[(int64_t)s * nblk + b];
     nodes = block_sum_f64(nodes, smd);
@@ -278,6 +294,7 @@ struct polee_approx {
     DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
     DevBuf<double> d_sum_log_l, d_acc, d_npart, d_tpair, d_dots;
     DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
+    DevBuf<uint32_t> d_open_ptr, d_open_code;  // the trees' open-edge lists (build_open_lists): the gradient scan's chunk offsets
     DevBuf<int32_t> d_gptr, d_gidx;  // genes as CSR over transcripts (gene-level wrapper), set by approx_set_genes
     int32_t G = 0;
     ApproxView view() const { return ApproxView{S, n, d_efflens.p, d_mu.p, d_sigma.p, d_alpha.p}; }
@@ -377,6 +394,20 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
     A(ap->d_xgrad.alloc(ctx, sn));
     A(ap->d_lp.alloc(ctx, S));
     if (st == POLEE_OK) st = ap->t->reserve(S);
+    if (st == POLEE_OK && !getenv("POLEE_APPROX_NO_OPEN_LISTS")) {  // (A/B)
+        // the gradient scan's chunk offsets from the trees (build_open_lists): kept unless the trees are so deep that the lists
+        // would pass 32 M entries in all -- the three-phase scan stays for those
+        std::vector<uint32_t> optr, ocode;
+        bool ok = true;
+        for (const PttPlan &pl : ap->t->plans)
+            ok = ok && (int64_t)pl.tour_code.size() == ap->t->TL &&
+                 build_open_lists(pl.tour_code.data(), ap->t->TL, SCAN_CHUNK, (size_t)32 << 20, optr, ocode);
+        if (ok) {
+            if (ocode.empty()) ocode.push_back(4u | TOUR_LEAF);  // (never read)
+            A(ap->d_open_ptr.upload(ctx, optr));
+            A(ap->d_open_code.upload(ctx, ocode));
+        }
+    }
     if (st != POLEE_OK) {
         polee_approx_destroy(ap);
         return st;
@@ -417,16 +448,27 @@ polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, flo
     if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
                        ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_tpair.p : nullptr);
-    hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
-                       (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp);
+    if (!grad)
+        hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
+                           (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp, (const double *)nullptr, 0, (double *)nullptr);
     POLEE_KERNEL_CHECK(ctx);
     if (grad) {
         ApproxGradLoad gl{t->view(), ap->d_tpair.p};
         ApproxGradEmit ge{gl, ap->view(), d_x, ap->d_acc.p, ap->d_bp.p};
-        e = run_scan_partial<dd>(st, S, t->TL, t->d_chunk.p, t->d_part.p, gl, ge);
+        if (ap->d_open_ptr.p) {
+            // (chunk offsets from the trees' open-edge lists: the reduce launch and the spine of the three-phase scan are not needed)
+            const int nch = scan_num_chunks(t->TL);
+            hipLaunchKernelGGL((scan_apply_partial_open_kernel<ApproxGradLoad, ApproxGradEmit>), dim3(nch, S), dim3(SCAN_THREADS), 0, st, gl, ge,
+                               t->TL, nch, (const uint32_t *)ap->d_open_ptr.p, (const uint32_t *)ap->d_open_code.p, t->T == 1 ? 0 : 1, t->d_part.p);
+            e = hipGetLastError();
+        } else {
+            e = run_scan_partial<dd>(st, S, t->TL, t->d_chunk.p, t->d_part.p, gl, ge);
+        }
         if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(S), dim3(SCAN_THREADS), 0, st, t->d_part.p,
-                           scan_num_chunks(t->TL), ap->d_dots.p, 2);
+        // (lp and the scan's two dot products in one single-workgroup launch per sample)
+        hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
+                           (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp, (const double *)t->d_part.p, scan_num_chunks(t->TL),
+                           ap->d_dots.p);
         hipLaunchKernelGGL(approx_finish_grad_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), 0, st,
                            ap->view(), d_x, ap->d_acc.p, ap->d_dots.p, ap->d_bp.p, d_x_grad);
         POLEE_KERNEL_CHECK(ctx);

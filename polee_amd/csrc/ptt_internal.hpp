@@ -232,6 +232,90 @@ inline hipError_t run_scan_partial(hipStream_t stream, int rows, int64_t len, T 
     return hipGetLastError();
 }
 
+// The open-edge lists of an Euler tour cut into chunks of `chunk` entries: for every chunk the ENTER codes still open at its
+// first entry = the path from the root to that point.  A chunk's offset in the tour's prefix is the sum of their values (every
+// ENTER whose EXIT lies before the chunk has cancelled), so a scan that has the lists needs no reduce launch and no spine:
+// the VI loop's forward kernel (vi.hip) and the approximation density's gradient scan (approx.hip) use them.  optr gets
+// nchunks + 1 offsets into ocode (appended to; offsets are absolute positions in ocode).  false when the lists would pass
+// `limit` entries (a caterpillar tree of 200 000 leaves needs n^2 / chunk of them) or the tour is malformed.
+inline bool build_open_lists(const uint32_t *code, int64_t TL, int chunk, size_t limit, std::vector<uint32_t> &optr,
+                             std::vector<uint32_t> &ocode)
+{
+    std::vector<uint32_t> stack;
+    for (int64_t e = 0; e < TL; ++e) {
+        if (e % chunk == 0) {
+            optr.push_back((uint32_t)ocode.size());
+            ocode.insert(ocode.end(), stack.begin(), stack.end());
+            if (ocode.size() > limit) return false;
+        }
+        const uint32_t type = code[(size_t)e] & 3u;
+        if (type == TOUR_ENTER) stack.push_back(code[(size_t)e]);
+        else if (type == TOUR_EXIT) {
+            if (stack.empty()) return false;
+            stack.pop_back();
+        }
+    }
+    optr.push_back((uint32_t)ocode.size());
+    return true;
+}
+
+// scan_apply_partial_kernel with the chunk offsets taken from open-edge lists (build_open_lists with chunk = SCAN_CHUNK):
+// Load must offer `double term(int row, uint32_t code)`, the value of an ENTER entry.  open_ptr is [trees][nchunks + 1] (a
+// tree's offsets are absolute positions in open_code), shared by the rows of a tree.
+template <typename Load, typename Emit>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_partial_open_kernel(Load load, Emit emit, int64_t len, int nchunks,
+                                                                              const uint32_t *__restrict__ open_ptr,
+                                                                              const uint32_t *__restrict__ open_code, int tree_of_row_stride,
+                                                                              double *partials /* [rows][nchunks][2] or null */)
+{
+    __shared__ dd smem[SCAN_THREADS / 64];
+    __shared__ double smd[SCAN_THREADS / 64];
+    __shared__ dd spre;
+    const int row = blockIdx.y, chunk = blockIdx.x;
+    const int64_t base = (int64_t)chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // (the first wave sums the open edges' values, a double-double shuffle tree, and leaves the sum in LDS in front of the
+    // block scan's barriers)
+    if (threadIdx.x < 64) {
+        const uint32_t *op = open_ptr + (size_t)(row * tree_of_row_stride) * (nchunks + 1);
+        const uint32_t ob = op[chunk], oe = op[chunk + 1];
+        dd pre{0.0, 0.0};
+        for (uint32_t e = ob + threadIdx.x; e < oe; e += 64) pre = dd_add(pre, dd_make(load.term(row, open_code[e])));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pre = dd_add(pre, dd{__shfl_xor(pre.hi, o, 64), __shfl_xor(pre.lo, o, 64)});
+        if (threadIdx.x == 0) spre = pre;
+    }
+    dd v[SCAN_ITEMS];
+    dd acc{0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = (base + j < len) ? load(row, base + j) : dd{0.0, 0.0};
+        acc = dd_add(acc, v[j]);
+    }
+    dd tot;
+    dd off = block_exclusive_scan<dd>(acc, smem, &tot);
+    off = dd_add(spre, off);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        dd inc = dd_add(off, v[j]);
+        if (base + j < len) {
+            double p0, p1;
+            emit(row, base + j, off, inc, p0, p1);
+            s0 += p0;
+            s1 += p1;
+        }
+        off = inc;
+    }
+    if (partials) {
+        s0 = block_sum_f64(s0, smd);
+        s1 = block_sum_f64(s1, smd);
+        if (threadIdx.x == 0) {
+            partials[((int64_t)row * nchunks + chunk) * 2 + 0] = s0;
+            partials[((int64_t)row * nchunks + chunk) * 2 + 1] = s1;
+        }
+    }
+}
+
 // Sums the per-chunk partials of each row: out[row][0..1].  One workgroup per row.
 __global__ void reduce_partials_kernel(const double *partials, int nchunks, double *out, int out_stride);
 

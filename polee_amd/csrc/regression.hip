@@ -146,13 +146,13 @@ __global__ void reg_tick_kernel(uint32_t *tick, float *lr_t, float lr)
 
 // seed / step: immediates, or (tick != nullptr) read from the device clock
 __global__ void reg_noise_kernel(int64_t count, uint64_t seed, uint32_t step, const uint64_t *seed_dev,
-                                 const uint32_t *tick, uint64_t salt, float *eps)
+                                 const uint32_t *tick, uint64_t salt, float *eps, uint32_t tick_ahead = 0u)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q * 4 >= count) return;
     if (tick) {
         seed = seed_dev[0];
-        step = tick[0];
+        step = tick[0] + tick_ahead;  // (tick_ahead = 1: the clock is advanced later in the step, reg_finish_kernel)
     }
     seed ^= salt;
     float z[4];
@@ -160,6 +160,34 @@ __global__ void reg_noise_kernel(int64_t count, uint64_t seed, uint32_t step, co
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (q * 4 + i < count) eps[q * 4 + i] = z[i];
+}
+
+// One launch per step for both noise segments and the draw of x (round 6: the tick, two noise launches and reg_sample_x_kernel
+// were four ~5 us launches of a ~290 us step).  The step number is the device clock's NEXT value, tick[0] + 1: the clock
+// itself is advanced by reg_finish_kernel, the step's last single-workgroup launch in front of Adam.  Segment 0 = the latents
+// every rank shares (salt 0), segment 1 = the x noise of this rank's samples (salted): the same Philox blocks, in the same
+// places, as two reg_noise_kernel launches.  A thread of segment 1 also writes x = qx_loc + softplus(qx_scale) eps for its
+// four entries (x == nullptr: point estimates, no draw).
+__global__ void reg_draw_kernel(RegView v, int64_t shared, int64_t own, const uint64_t *seed_dev, const uint32_t *tick, uint64_t salt,
+                                const float *__restrict__ p, float *__restrict__ eps, float *__restrict__ x)
+{
+    const int64_t nq0 = (shared + 3) / 4;
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool seg1 = q >= nq0;
+    if (seg1) q -= nq0;
+    const int64_t count = seg1 ? own : shared;
+    if (q * 4 >= count) return;
+    const uint64_t seed = seed_dev[0] ^ (seg1 ? salt : (uint64_t)0);
+    const uint32_t step = tick[0] + 1u;
+    float z[4];
+    philox_randn4(seed ^ 0x7265677265737369ull, step, (uint32_t)(q >> 32), (uint32_t)q, z);
+    float *e = eps + (seg1 ? shared : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (q * 4 + i < count) {
+            e[q * 4 + i] = z[i];
+            if (seg1 && x) x[q * 4 + i] = p[v.o_qx_loc() + q * 4 + i] + softplusf(p[v.o_qx_s() + q * 4 + i]) * z[i];
+        }
 }
 
 // t_s = logsumexp_j qx_loc[s][j]   (qx_sample_scale, models/polee_regression.py:300-301)
@@ -677,9 +705,13 @@ __global__ __launch_bounds__(REG_BLOCK) void reg_cols_kernel(RegView v, const fl
 // (it leaves every accumulator it has read at zero for the next step: no memsets between steps)
 __global__ __launch_bounds__(64) void reg_finish_kernel(RegView v, const float *p, const float *eps, float *small,
                                                         float *stats, double *loss_acc, float *g, float *loss_out,
-                                                        const float *extra_loss)
+                                                        const float *extra_loss, uint32_t *tick, float *lr_t, float lr)
 {
     const int lane = threadIdx.x, nred = v.num_red();
+    if (tick && lane == 0) {  // the device clock of fit(): this step's number and Adam's bias-corrected rate (reg_tick_kernel)
+        const double t = (double)(++tick[0]);
+        lr_t[0] = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    }
     auto slots = [&](int i) {  // sum of accumulator i over its copies
         float t = 0.0f;
         for (int k = 0; k < REG_SLOTS; ++k) {
@@ -798,6 +830,8 @@ struct polee_regression {
         if (graph) (void)hipGraphExecDestroy(graph);
         graph = nullptr;
     }
+    bool tick_in_finish = false;  // (per step) reg_finish_kernel advances the device clock: fit()'s steps
+    bool x_drawn = false;         // (per step) reg_draw_kernel has written x: reg_data_pass skips reg_sample_x_kernel
     bool lse_valid = false;  // d_lse holds the log-sum-exp of a nearby qx_loc (shift of the multi-block kernel)
     DevBuf<float> d_lik_loc, d_lik_scale;  // point estimates + their scale: the Normal likelihood variant
     DevBuf<double> d_acc;
@@ -859,8 +893,9 @@ polee_status reg_data_pass(polee_regression *r)
         } else
             hipLaunchKernelGGL(reg_lse_kernel, dim3(v.S), dim3(1024), 0, st, v, r->d_p.p, r->d_lse.p);
         r->lse_valid = true;
-        hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
-                           r->d_eps.p, r->d_x.p);
+        if (!r->x_drawn)
+            hipLaunchKernelGGL(reg_sample_x_kernel, dim3((unsigned)ceil_div(sn, 256)), dim3(256), 0, st, v, r->d_p.p,
+                               r->d_eps.p, r->d_x.p);
         POLEE_KERNEL_CHECK(ctx);
         if (r->gene_ap) {
             if (r->joint)
@@ -939,10 +974,11 @@ polee_status reg_prior_pass(polee_regression *r)
                            r->vi, r->d_ip.p, r->d_ieps.p, (const float *)nullptr, r->d_istats.p, r->d_ig.p, r->d_iacc.p,
                            r->d_ismall.p);
         hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, r->vi, r->d_ip.p, r->d_ieps.p, r->d_ismall.p,
-                           r->d_istats.p, r->d_iacc.p, r->d_ig.p, r->d_iloss.p, (const float *)nullptr);
+                           r->d_istats.p, r->d_iacc.p, r->d_ig.p, r->d_iloss.p, (const float *)nullptr, (uint32_t *)nullptr, (float *)nullptr, 0.0f);
     }
     hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(64), 0, st, v, r->d_p.p, r->d_eps.p, r->d_small.p,
-                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p, (r->iso_reg || r->joint) ? r->d_iloss.p : (const float *)nullptr);
+                       r->d_stats.p, r->d_acc.p, r->d_g.p, r->d_loss.p, (r->iso_reg || r->joint) ? r->d_iloss.p : (const float *)nullptr,
+                       r->tick_in_finish ? r->d_tick.p : (uint32_t *)nullptr, r->d_lr.p, r->lr);
     POLEE_KERNEL_CHECK(ctx);
     return POLEE_OK;
 }
@@ -993,9 +1029,30 @@ polee_status reg_enqueue_step(polee_regression *r, const float *noise, bool want
 {
     polee_ctx *ctx = r->ctx;
     const int64_t P = r->v.num_params();
-    hipLaunchKernelGGL(reg_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, r->d_tick.p, r->d_lr.p, r->lr);
-    POLEE_TRY(reg_fill_noise(r, noise, 0, 0, true));
-    POLEE_TRY(reg_eval_device(r));
+    if (noise) {  // the caller's noise: uploaded; the clock ticks in its own launch
+        hipLaunchKernelGGL(reg_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, r->d_tick.p, r->d_lr.p, r->lr);
+        POLEE_TRY(reg_fill_noise(r, noise, 0, 0, true));
+        POLEE_TRY(reg_eval_device(r));
+    } else {
+        // device RNG: one launch draws every latent of the step number the clock is ABOUT to show and x with it; the clock is
+        // advanced by reg_finish_kernel (in front of Adam, behind everything that reads the noise)
+        const int64_t ne = r->v.num_noise(), shared = r->v.e_x(), own = ne - shared;
+        const uint64_t salt = 0xD1B54A32D192ED03ull * (uint64_t)(r->comm ? r->comm->rank + 1 : 1);
+        const bool with_x = !r->v.point && own == (int64_t)r->v.S * r->v.n;
+        hipLaunchKernelGGL(reg_draw_kernel, dim3((unsigned)ceil_div((shared + 3) / 4 + (own + 3) / 4, 256)), dim3(256), 0, ctx->stream, r->v,
+                           shared, own, (const uint64_t *)r->d_seed.p, (const uint32_t *)r->d_tick.p, salt, (const float *)r->d_p.p, r->d_eps.p,
+                           with_x ? r->d_x.p : (float *)nullptr);
+        if (r->gene_ap)
+            hipLaunchKernelGGL(reg_noise_kernel, dim3((unsigned)ceil_div(ceil_div(r->num_iso_noise(), 4), 256)), dim3(256), 0,
+                               ctx->stream, r->num_iso_noise(), (uint64_t)0, 0u, (const uint64_t *)r->d_seed.p, (const uint32_t *)r->d_tick.p,
+                               salt ^ 0x69736f666f726d73ull, r->d_ieps.p, 1u);
+        r->tick_in_finish = true;
+        r->x_drawn = with_x;
+        const polee_status es = reg_eval_device(r);
+        r->tick_in_finish = false;
+        r->x_drawn = false;
+        POLEE_TRY(es);
+    }
     const int64_t lo = r->train_hi < 0 ? 0 : r->train_lo, cnt = r->train_hi < 0 ? P : r->train_hi - r->train_lo;
     hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)std::max<int64_t>(ceil_div(cnt, 256), 1)), dim3(256), 0, ctx->stream, cnt,
                        r->d_p.p + lo, r->d_g.p + lo, r->d_m.p + lo, r->d_v.p + lo, r->d_lr.p, r->d_loss.p,

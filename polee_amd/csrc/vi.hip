@@ -628,24 +628,10 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
         static const bool no_open = getenv("POLEE_VI_NO_OPEN_LISTS") != nullptr;  // (A/B)
         const std::vector<uint32_t> &code = t->plans[0].tour_code;
         const int64_t TL = t->TL;
-        const int nch = std::max(fwd_num_chunks(TL), 1);
         const size_t limit = (size_t)8 << 20;
-        std::vector<uint32_t> optr((size_t)nch + 1, 0), ocode, stack;
-        bool ok = !no_open && t->T == 1 && (int64_t)code.size() == TL;
-        for (int64_t e = 0; ok && e < TL; ++e) {
-            if (e % FWD_CHUNK == 0) {
-                optr[(size_t)(e / FWD_CHUNK)] = (uint32_t)ocode.size();
-                ocode.insert(ocode.end(), stack.begin(), stack.end());
-                if (ocode.size() > limit) ok = false;
-            }
-            const uint32_t type = code[(size_t)e] & 3u;
-            if (type == TOUR_ENTER) stack.push_back(code[(size_t)e]);
-            else if (type == TOUR_EXIT) {
-                if (stack.empty()) ok = false; else stack.pop_back();
-            }
-        }
+        std::vector<uint32_t> optr, ocode;
+        const bool ok = !no_open && t->T == 1 && (int64_t)code.size() == TL && build_open_lists(code.data(), TL, FWD_CHUNK, limit, optr, ocode);
         if (ok) {
-            optr[(size_t)nch] = (uint32_t)ocode.size();
             if (ocode.empty()) ocode.push_back(4u | TOUR_LEAF);  // (never read)
             A(vi->d_open_ptr.upload(ctx, optr));
             A(vi->d_open_code.upload(ctx, ocode));
