@@ -187,7 +187,10 @@ polee_status polee_loglik_set_deterministic(polee_loglik *ll, int on);
 
 /* log_likelihood (src/likelihood.jl:36-56) for K expression vectors at once:
  * xs f32 [K][n] -> x_grad f64 [K][n] = sum_i X_ij / s_i  (x ks_i if factored);
- * lp [K] = sum_i log s_i (x ks_i) unless lp_or_null == NULL ("gradonly"). 1 <= K <= 8. */
+ * lp [K] = sum_i log s_i (x ks_i) unless lp_or_null == NULL ("gradonly"). 1 <= K <= 8.
+ * A polee_loglik supports ONE evaluation in flight at a time (polee_loglik_eval, or a polee_vi / polee_regression step that uses
+ * the handle): the dynamic tile schedule keeps a per-handle counter on the device and its base on the host, and two threads or
+ * streams evaluating the same handle at once would hand out wrong tiles.  Different handles are independent. */
 polee_status polee_loglik_eval(polee_loglik *ll, const float *xs, int32_t K, double *x_grad,
                                double *lp_or_null);
 /* effective_length_jacobian_adjustment! (src/likelihood.jl:93-110), batched:

@@ -87,8 +87,10 @@ constexpr int PSELL_TILE_SLICES_BN = 64;
 constexpr uint32_t psell_row_pos(int stream, uint32_t t, uint32_t r) { return stream == PSELL_A1 ? (r ^ (t & 3u)) : (stream == PSELL_A2 ? ((r + 4u * t) & 63u) : r); }
 constexpr uint16_t PSELL_NO_COL = 0x8000u;  // header entries of a masked slice past its union (0x8000xxxx is a finite float)
 // leftover rows are packed in independent chunks of this many candidates (host: a thread each; device: a WAVE each, whose walk is
-// bound by instruction latency -- 4 096 rows give BASELINE's C2 a few thousand waves; a group is cut once per chunk: 0.02 % of them)
-constexpr uint32_t PSELL_PACK_CHUNK = 1u << 12;
+// bound by instruction latency -- a group is cut once per chunk.  2 048 since round 6 (4 096 before): polee_loglik_create 0.080 / 0.096 s
+// -> 0.073 / 0.084 s at C2 patterns / literal with the pass's time unchanged within run-to-run noise on the three inputs of
+// profiles/r05_pack_chunk_ab.txt; 1 024 saves another 6 % of the build and costs the tiled real fixture 1 % of its pass)
+constexpr uint32_t PSELL_PACK_CHUNK = 1u << 11;
 // Stage 3 cuts the streams into segments whose tiles are made independently (a tile never spans two).  The mixed streams are walked
 // ROW BY ROW (every row its own set), the uniform ones stretch by stretch: a mixed segment is this many rows, not the 2^18 of the
 // others -- on the device a segment is one wave's work, and one 19 k-row segment of stream BN was the whole tile walk's time.
