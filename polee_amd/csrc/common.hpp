@@ -119,6 +119,7 @@ public:
             blk = it->second;
             free_.erase(it);
             kept_ -= granted;
+            kept_dev_[device] -= granted;
         }
         if (blk.ev) {
             if (hipEventSynchronize(blk.ev) != hipSuccess) {  // (should not happen: then the whole device, as hipFree would have waited)
@@ -154,12 +155,13 @@ public:
         }
         std::lock_guard<std::mutex> g(mu_);
         learn_cap();
-        if (kept_ + granted > cap_) {
+        if (kept_dev_[device] + granted > cap_) {  // (the cap is per device: a quarter of ITS memory, whatever the other devices keep)
             (void)hipEventDestroy(ev);
             return false;
         }
         free_.emplace(granted, Block{p, ev, device});
         kept_ += granted;
+        kept_dev_[device] += granted;
         return true;
     }
     void trim()
@@ -169,6 +171,7 @@ public:
             std::lock_guard<std::mutex> g(mu_);
             all.swap(free_);
             kept_ = 0;
+            kept_dev_.clear();
         }
         for (auto &kv : all) {
             if (kv.second.ev) {
@@ -205,8 +208,8 @@ private:
             cap_ = (size_t)64 << 30;  // (until the first give() on a device: then a share of that device's memory, below)
         }
     }
-    // Default cap: a quarter of the device's TOTAL memory -- 72 GiB on a 288 GB MI355X, never more than 64 GiB --
-    // asked of the runtime at the first block given back (the constructor may run before any device is selected).  Other
+    // Default cap, PER DEVICE: a quarter of a device's TOTAL memory -- 72 GiB on a 288 GB MI355X, never more than 64 GiB;
+    // the devices of one node are alike, so the figure is asked once -- asked of the runtime at the first block given back (the constructor may run before any device is selected).  Other
     // users of the device (RCCL, PyTorch, another process) see the kept bytes as used memory: polee_host_cache_trim() returns
     // them, every failed allocation of this library trims and retries, and a cohort's worker processes get their shares
     // from the same query (polee_amd/cohort.py).
@@ -220,7 +223,8 @@ private:
     }
     std::mutex mu_;
     std::multimap<size_t, Block> free_;
-    size_t kept_ = 0, cap_ = 0;
+    size_t kept_ = 0, cap_ = 0;      // kept_: all devices (kept_bytes()); cap_: per device
+    std::map<int, size_t> kept_dev_;  // bytes kept per device (one process may drive several GPUs)
     bool cap_known_ = false;
     bool poison_ = false;
 };

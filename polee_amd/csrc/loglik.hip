@@ -159,6 +159,9 @@ struct PsellArgs {
     const PosDesc *sched_dyn;
     unsigned int *dyn_ctr;
     unsigned int dyn_base;
+    unsigned int dyn_last;  // the list's last (POS_NONE) slot: a draw is clamped to it, so that a counter that has fallen out of step
+                            // with the host's base (an asynchronous fault, two evaluations of one handle at once) ends the
+                            // workgroup's walk instead of indexing past the list
     // deterministic mode: every tile's window is stored (not added) and a second kernel sums the windows of a transcript
     float *gwin;            // [dict entries][K], laid out like xwin
     double *lpwin;          // [grid][K] per-workgroup log-likelihood sums, then [stream B's tiles][K] (lp_slot0 on)
@@ -2008,7 +2011,7 @@ void loglik_stream_kernel(PsellArgs A, int dbg)
         cur = nxt;
         if (wave == 0) {
             if (dyn) {
-                p2 = 3u * G + ((uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) - A.dyn_base);
+                p2 = min(3u * G + ((uint32_t)__builtin_amdgcn_readfirstlane((int)drawn) - A.dyn_base), A.dyn_last);
             } else {
                 p2 += G;
             }
@@ -2258,6 +2261,7 @@ static polee_status launch_stream(polee_loglik *ll, PsellArgs &A, int dbg)
         A.dyn_ctr = ll->d_dyn_ctr.p;
         // (the counter runs on from launch to launch, modulo 2^32: this launch's draws are dyn_base, dyn_base + 1, ...)
         A.dyn_base = ll->dyn_base;
+        A.dyn_last = (unsigned int)(ll->dyn_positions + ll->dyn_pad - 1);
         ll->dyn_base += (uint32_t)ll->dyn_positions;
     }
     // (DET: A.gwin / A.lpwin are the caller's, and so is the reduce launch behind this one and stream B's: launch_variant)
@@ -2288,7 +2292,7 @@ static polee_status launch_variant(polee_loglik *ll, const float *d_x, float *d_
     const uint32_t *csr_col = rm && rm->csr_col ? rm->csr_col : ll->d_csr_col.p;
     PsellArgs A{ll->d_data.p, ll->d_slice_off.p, ll->d_tile_slice.p, ll->d_tile_dict.p, rm ? rm->dict : ll->d_dict.p,
                 ll->d_slice_ks.p, d_x, d_g, d_lp, lcap_all, (int)h.num_tiles_a,
-                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, 0u, nullptr, nullptr, 0};
+                (int)h.num_tiles_a1, (int)h.num_tiles_a1m, (int)h.num_tiles_a2, (int)h.num_tiles_s, ll->d_xwin.p, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, 0};
     const size_t lds_psell = (size_t)2 * lcap_all * K * sizeof(float);
     // The attribute belongs to (device, kernel instance): set before every launch that needs it (a host-side table
     // write), so that a second context on another GPU of the same process gets it too; checked.
