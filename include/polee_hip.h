@@ -252,7 +252,9 @@ typedef struct {
     int32_t profile;             /* 1: bracket every sparse-kernel launch with HIP events; N > 1: every N-th launch (four
                                     event records per pass cost ~20 us of stream gaps per iteration at C2) */
     int32_t deterministic;       /* 1: this fit's likelihood passes run in deterministic mode (the handle's own  */
-                                 /* polee_loglik_set_deterministic setting is untouched)                         */
+                                 /* polee_loglik_set_deterministic setting is untouched); -1: float atomics;      */
+                                 /* 0 (default): deterministic exactly when the sample is shared by more than    */
+                                 /* one rank (polee_vi_set_comm), so that repeated N-rank fits are bitwise equal  */
     const int32_t *gene_of;      /* optional HOST int32[n]: gene index of every transcript (0-based, -1 = none   */
                                  /* known) = gene_noninformative = true (likelihood-approximation.jl:475-491,     */
                                  /* 535-538: gene_noninformative_prior! after the effective-length adjustment,   */

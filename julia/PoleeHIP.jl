@@ -133,8 +133,10 @@ approximate_likelihood(::LogitSkewNormalPTTApprox, sample) replacement: returns 
 function approximate_likelihood(s::DeviceSample, t::PolyaTreeTransform, efflens::Vector{Float32};
                                 use_efflen_jacobian::Bool=true, seed::Integer=123456789,
                                 gene_transcripts::Union{Nothing,Dict{String,Vector{Int}}}=nothing,  # gene_noninformative
-                                deterministic::Bool=false)
-    o = ViOpts(); o.use_efflen_jacobian = use_efflen_jacobian; o.seed = seed; o.deterministic = deterministic
+                                deterministic::Union{Nothing,Bool}=nothing)
+    # (polee_vi_opts.deterministic: 0 = the library's rule, on exactly when the sample is shared by more than one rank; 1 on; -1 off)
+    o = ViOpts(); o.use_efflen_jacobian = use_efflen_jacobian; o.seed = seed
+    o.deterministic = deterministic === nothing ? 0 : (deterministic ? 1 : -1)
     # the reference's Dict{gene id -> transcript indexes} (likelihood-approximation.jl:475-487) as gene_of[n]
     gene_of = Int32[]
     if gene_transcripts !== nothing && !isempty(gene_transcripts)

@@ -612,10 +612,9 @@ class LikelihoodApproximationFit:
             if self._z0.size != num_steps * num_mc_samples * (sample.n - 1):
                 raise ValueError("z0 must have num_steps*num_mc_samples*(n-1) elements")
             o.z0 = ptr(self._z0, f32p)
-        if deterministic is None:
-            deterministic = comm is not None and getattr(comm, "world_size", 1) > 1
-        self.deterministic = bool(deterministic)
-        o.deterministic = int(self.deterministic)
+        # (polee_vi_opts.deterministic: 0 = the library's rule -- on exactly when the sample is shared by more than one rank --, 1 on, -1 off)
+        o.deterministic = 0 if deterministic is None else (1 if deterministic else -1)
+        self.deterministic = (comm is not None and getattr(comm, "world_size", 1) > 1) if deterministic is None else bool(deterministic)
         for key, val in (adam or {}).items():
             if not (key.startswith("adam_") or key.startswith("max_")) or not hasattr(o, key):
                 raise ValueError("unknown optimiser constant %r" % (key,))

@@ -279,7 +279,8 @@ static polee_status vi_step_k(polee_vi *vi, bool apply, bool want_values, bool h
     if (want_values) POLEE_HIP_TRY(ctx, hipMemsetAsync(vi->d_lp.p, 0, sizeof(double) * PSELL_MAX_K, st));
     {
         const bool det_saved = vi->ll->deterministic;
-        if (o.deterministic) vi->ll->deterministic = true;
+        // (0 = by default exactly when the sample is shared by more than one rank; -1 = never)
+        if (o.deterministic > 0 || (o.deterministic == 0 && vi->comm && vi->comm->nranks > 1)) vi->ll->deterministic = true;
         // (sum x / efflen over the forward kernel's per-chunk partials rides along with the pass's x-window gather)
         vi->ll->side_part = eff ? vi->d_part_c.p : nullptr;
         vi->ll->side_nparts = nch_f;

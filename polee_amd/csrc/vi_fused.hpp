@@ -379,9 +379,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
 #pragma unroll
     for (int j = 0; j < FWD_ITEMS; ++j) {
         const uint32_t tj = code[j] & 3u;
-        VK<K> inc;
+        // (the running prefix is advanced in place: + the edge's log on ENTER, - on EXIT, unchanged by a LEAF)
 #pragma unroll
-        for (int d = 0; d < K; ++d) inc.v[d] = tj == TOUR_ENTER ? off.v[d] + w[j].v[d] : (tj == TOUR_EXIT ? off.v[d] - w[j].v[d] : off.v[d]);
+        for (int d = 0; d < K; ++d) off.v[d] = tj == TOUR_ENTER ? off.v[d] + w[j].v[d] : (tj == TOUR_EXIT ? off.v[d] - w[j].v[d] : off.v[d]);
+        const VK<K> &inc = off;
         if (base + j < v.TL) {
             const uint32_t type = code[j] & 3u;
             if (type == TOUR_LEAF) {
@@ -421,7 +422,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
                 for (int d = 0; d < K; ++d) pl[d] += inc.v[d];
             }
         }
-        off = inc;
     }
     if (xwin) {
         __syncthreads();
