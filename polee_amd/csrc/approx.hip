@@ -68,6 +68,55 @@ struct ApproxLeafLoad {
 // same-address atomic per block serialised ~800 deep per sample and dominated this kernel)
 // tpair (optional) [S][n-1][2]: the node's two tour terms of InvHSBGrad, -1/u -+ ..., for its left ([0]) and right ([1])
 // edge -- one 8-byte gather per tour element in the scan instead of three plus arithmetic
+// 1 / x by the hardware estimate and two Newton steps (~1 ulp) for normal positive x; anything else (0, denormal, inf, nan) through the
+// division, whose special cases the callers' tests pin
+__device__ inline double approx_rcp(double x)
+{
+    if (!(x > 1e-300 && x < 1e300)) return 1.0 / x;
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// one internal node of sample s given the sums of q over its left / right subtree: lp + ladj contribution, and (tpair) its two tour terms
+__device__ inline double approx_node_terms(const ApproxView &a, int s, int64_t k, int64_t nm1, double ul, double ur, double *tpair)
+{
+    // (The kernels that call this are bound by the instructions they issue -- 12.8 M nodes at S = 64 -- so: reciprocals by rcp +
+    // Newton where the operand is a normal positive number, and the hyperbolics of :437-443 through their identities:
+    // z = sinh(asinh(z_std) - alpha) = z_std cosh(alpha) - sqrt(1 + z_std^2) sinh(alpha), cosh(alpha - asinh(z_std)) = sqrt(1 + z^2).)
+    const double u = ul + ur, iu = approx_rcp(u);
+    const double y = ul * iu;                                   // hsb_ops.cpp:230
+    double ladj = -fast_log(u);                                 // hsb_ops.cpp:231
+    const double y_log = fast_log(y), y_1mlog = fast_log(1.0 - y);  // :418-419 (log1p(-y))
+    const float y_logit = (float)(y_log - y_1mlog);             // :421
+    ladj += (double)(float)(-y_log - y_1mlog);                  // :423-425
+    const float muk = a.mu[(int64_t)s * nm1 + k], sg = a.sigma[(int64_t)s * nm1 + k];
+    const float al = a.alpha[(int64_t)s * nm1 + k];
+    const float isg = 1.0f / sg;
+    const float z_std = (y_logit - muk) * isg;                  // :430
+    ladj -= (double)logf(sg);                                   // :432
+    const float root = sqrtf(fmaf(z_std, z_std, 1.0f));         // cosh(asinh(z_std))
+    const float z = z_std * coshf(al) - root * sinhf(al);       // :437-438
+    ladj += (double)(0.5f * log1pf(z * z) - 0.5f * log1pf(z_std * z_std));  // :440-443: log cosh(alpha - asinh(z_std)) = log sqrt(1 + z^2)
+    const double lp = (-1.8378770664093453 - (double)(z * z)) / 2.0;              // :448, log(2 pi)
+    if (tpair) {
+        // d(lp + ladj)/d y_logit, then d y_logit / d y and the -log y - log1p(-y) term
+        // with c = asinh(z_std) - alpha: sinh(c) = z, cosh(c) = sqrt(1 + z^2) (no f64 hyperbolics needed)
+        const double zs = z_std, zd = (double)z, ch = sqrt(1.0 + zd * zd);
+        const double rs = approx_rcp(sqrt(1.0 + zs * zs));
+        const double d_lp = -zd * ch * rs;
+        const double d_la = zd * approx_rcp(ch) * rs - zs * rs * rs;
+        const double d_logit = (d_lp + d_la) * (double)isg;
+        const double iy = approx_rcp(y), i1y = approx_rcp(1 - y);
+        const double y_grad = d_logit * iy * i1y + (i1y - iy);
+        double *tp = tpair + ((int64_t)s * nm1 + k) * 2;
+        tp[0] = -iu + (-y) * iu * y_grad;
+        tp[1] = -iu + (1.0 - y) * iu * y_grad;
+    }
+    return lp + ladj;
+}
+
 __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double *npart, double *tpair)
 {
     __shared__ double smd[4];
@@ -81,38 +130,100 @@ __global__ void approx_nodes_kernel(PttView v, ApproxView a, const dd *C, double
         const dd *Cr = C + (int64_t)s * (v.n + 1);
         const double ur = dd_diff(Cr[mid], Cr[lo]);
         const double ul = dd_diff(Cr[hi1], Cr[mid]);
-        const double u = ul + ur;
-        const double y = ul / u;                                    // hsb_ops.cpp:230
-        double ladj = -fast_log(u);                                 // hsb_ops.cpp:231
-        const double y_log = fast_log(y), y_1mlog = fast_log(1.0 - y);  // :418-419 (log1p(-y))
-        const float y_logit = (float)(y_log - y_1mlog);             // :421
-        ladj += (double)(float)(-y_log - y_1mlog);                  // :423-425
-        const float muk = a.mu[(int64_t)s * nm1 + k], sg = a.sigma[(int64_t)s * nm1 + k];
-        const float al = a.alpha[(int64_t)s * nm1 + k];
-        const float z_std = (y_logit - muk) / sg;                   // :430
-        ladj -= (double)logf(sg);                                   // :432
-        const float z_asinh = asinhf(z_std);                        // :437
-        const float z = sinhf(z_asinh - al);                        // :438
-        ladj += (double)(logf(coshf(al - z_asinh)) - 0.5f * log1pf(z_std * z_std));  // :440-443
-        const double lp = (-1.8378770664093453 - (double)(z * z)) / 2.0;              // :448, log(2 pi)
-        contrib = lp + ladj;
-        if (tpair) {
-            // d(lp + ladj)/d y_logit, then d y_logit / d y and the -log y - log1p(-y) term
-            // with c = asinh(z_std) - alpha: sinh(c) = z, cosh(c) = sqrt(1 + z^2) (no f64 hyperbolics needed)
-            const double zs = z_std, zd = (double)z, ch = sqrt(1.0 + zd * zd);
-            const double rs = 1.0 / sqrt(1.0 + zs * zs);
-            const double d_lp = -zd * ch * rs;
-            const double d_la = zd / ch * rs - zs * rs * rs;
-            const double d_logit = (d_lp + d_la) / (double)sg;
-            const double y_grad = d_logit / (y * (1 - y)) + (-1 / y + 1 / (1 - y));
-            const double iu = 1.0 / u;
-            double *tp = tpair + ((int64_t)s * nm1 + k) * 2;
-            tp[0] = -iu + (-y) * iu * y_grad;
-            tp[1] = -iu + (1.0 - y) * iu * y_grad;
-        }
+        contrib = approx_node_terms(a, s, k, nm1, ul, ur, tpair);
     }
     contrib = block_sum_f64(contrib, smd);
     if (threadIdx.x == 0) npart[(int64_t)s * gridDim.x + blockIdx.x] = contrib;
+}
+
+// Round 6: the leaf prefix and the node terms in ONE launch per chunk of leaves (what vi_bwd_local_kernel does for the VI loop).
+// A workgroup owns APX_CH leaf positions of sample s: it builds their chunk-LOCAL exclusive double-double prefix of q in LDS -- no
+// offset from other chunks, so no reduce launch -- and, internal nodes in DFS pre-order having non-decreasing lo, evaluates every
+// node whose leaf range starts AND ends in the chunk (node_start: the run of k that starts there) straight from LDS rows: the
+// [S][n+1] prefix array (205 MB at S = 64, written once and gathered three times per node) never exists.  The nodes that cross
+// chunks (a static list per tree) follow in approx_cross_nodes_kernel behind the spine, from the rows exported for them.
+constexpr int APX_CH = 512;
+struct ApproxChunkTables {
+    const int32_t *node_start;  // [trees][nch + 1]
+    const uint32_t *need;       // [trees][need_words]: bit pos = row pos is read by a crossing node
+    const int32_t *cross;       // the trees' crossing nodes, concatenated
+    const int32_t *cross_ptr;   // [trees + 1]
+    int nch, need_words, max_cross_blocks;
+};
+__global__ __launch_bounds__(256) void approx_leaf_nodes_kernel(PttView v, ApproxView a, ApproxChunkTables T, const float *__restrict__ x,
+                                                                const double *__restrict__ acc, dd *__restrict__ C /* [S][n+1], exported rows */,
+                                                                dd *__restrict__ chunk_tot /* [S][nch+1] */, double *__restrict__ npart,
+                                                                int npart_stride, double *tpair)
+{
+    __shared__ dd P[APX_CH + 1];
+    __shared__ dd wtot[4];
+    __shared__ double smd[4];
+    const int s = blockIdx.y, tree = v.tree(s), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nm1 = v.n - 1, base = (int64_t)blockIdx.x * APX_CH, p0 = base + 2 * (int64_t)threadIdx.x;
+    const int64_t end = min(base + APX_CH, (int64_t)v.n);
+    const uint32_t *need = T.need + (size_t)tree * T.need_words;
+    double q0 = 0.0, q1 = 0.0;
+    if (p0 < v.n) q0 = (double)approx_q(a, x, acc, s, v.leaf_tid[(int64_t)tree * v.n + p0]);
+    if (p0 + 1 < v.n) q1 = (double)approx_q(a, x, acc, s, v.leaf_tid[(int64_t)tree * v.n + p0 + 1]);
+    const bool exp0 = p0 <= v.n && ((need[p0 >> 5] >> (p0 & 31)) & 1u);
+    const bool exp1 = p0 + 1 <= v.n && ((need[(p0 + 1) >> 5] >> ((p0 + 1) & 31)) & 1u);
+    const int32_t *ns = T.node_start + (size_t)tree * (T.nch + 1);
+    const int32_t k0 = ns[blockIdx.x] + (int32_t)threadIdx.x, k1 = ns[blockIdx.x + 1];
+    const dd sm{q0 + q1, (q0 - ((q0 + q1) - ((q0 + q1) - q0))) + (q1 - ((q0 + q1) - q0))};  // (TwoSum)
+    const dd inc = wave_inclusive_scan<dd>(sm);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    dd off = ScanOps<dd>::shfl_up(inc, 1);
+    if (lane == 0) off = dd{0.0, 0.0};
+    for (int w = 0; w < wave; ++w) off = dd_add(wtot[w], off);
+    const dd o1 = dd_add(off, dd_make(q0));
+    P[2 * threadIdx.x] = off;
+    P[2 * threadIdx.x + 1] = o1;
+    dd *Cr = C + (int64_t)s * (v.n + 1);
+    if (exp0) Cr[p0] = off;
+    if (exp1) Cr[p0 + 1] = o1;
+    if (threadIdx.x == 255) {
+        const dd tot = dd_add(off, sm);
+        P[APX_CH] = tot;
+        chunk_tot[(int64_t)s * (T.nch + 1) + blockIdx.x] = tot;
+        if (blockIdx.x == 0) chunk_tot[(int64_t)s * (T.nch + 1) + T.nch] = dd{0.0, 0.0};  // (the spine turns it into the sum over all leaves)
+    }
+    __syncthreads();
+    double contrib = 0.0;
+    const int64_t tb = (int64_t)tree * nm1;
+    for (int32_t k = k0; k < k1; k += 256) {
+        const int lo = v.lo[tb + k], mid = v.mid[tb + k], hi1 = v.hi1[tb + k];
+        if (hi1 > end) continue;  // crosses chunks: approx_cross_nodes_kernel
+        const dd pm = P[mid - base];
+        contrib += approx_node_terms(a, s, k, nm1, dd_diff(P[hi1 - base], pm), dd_diff(pm, P[lo - base]), tpair);
+    }
+    contrib = block_sum_f64(contrib, smd);
+    if (threadIdx.x == 0) npart[(int64_t)s * npart_stride + blockIdx.x] = contrib;
+}
+__global__ __launch_bounds__(256) void approx_cross_nodes_kernel(PttView v, ApproxView a, ApproxChunkTables T, const dd *__restrict__ C,
+                                                                 const dd *__restrict__ chunk_off, double *__restrict__ npart,
+                                                                 int npart_stride, double *tpair)
+{
+    __shared__ double smd[4];
+    const int s = blockIdx.y, tree = v.tree(s);
+    const int64_t nm1 = v.n - 1, tb = (int64_t)tree * nm1;
+    const int32_t c0 = T.cross_ptr[tree], c1 = T.cross_ptr[tree + 1];
+    const int32_t i = c0 + (int32_t)(blockIdx.x * 256 + threadIdx.x);
+    double contrib = 0.0;
+    if (i < c1) {
+        const int32_t k = T.cross[i];
+        const int lo = v.lo[tb + k], mid = v.mid[tb + k], hi1 = v.hi1[tb + k];
+        const dd *Cr = C + (int64_t)s * (v.n + 1), *Or = chunk_off + (int64_t)s * (T.nch + 1);
+        // (a boundary at a chunk's first position has the local prefix 0 by definition: its row is not exported -- row n of a tree
+        // whose n is a multiple of the chunk size has no owner at all)
+        auto G = [&](int b) { return b % APX_CH == 0 ? Or[b / APX_CH] : dd_add(Or[b / APX_CH], Cr[b]); };
+        const dd gm = G(mid);
+        const double ur = dd_diff(gm, G(lo));
+        const double ul = dd_diff(G(hi1), gm);
+        contrib = approx_node_terms(a, s, k, nm1, ul, ur, tpair);
+    }
+    contrib = block_sum_f64(contrib, smd);
+    if (threadIdx.x == 0) npart[(int64_t)s * npart_stride + T.nch + blockIdx.x] = contrib;
 }
 
 // lp[s] = node terms + sum x - (n-1) log A + sum log efflen - log(R), R = Bn / A   (:384-400)
@@ -294,6 +405,12 @@ struct polee_approx {
     DevBuf<float> d_efflens, d_mu, d_sigma, d_alpha;
     DevBuf<double> d_sum_log_l, d_acc, d_npart, d_tpair, d_dots;
     DevBuf<float> d_x, d_lp, d_xgrad, d_bp, d_z0;
+    // the chunked leaf + node pass (approx_leaf_nodes_kernel): per tree the first node of every chunk's run, the prefix rows crossing
+    // nodes read, the crossing nodes; the chunks' totals / offsets [S][nch + 1]
+    DevBuf<int32_t> d_node_start, d_cross, d_cross_ptr;
+    DevBuf<uint32_t> d_need;
+    DevBuf<dd> d_chunk_tot;
+    int nch = 0, need_words = 0, max_cross_blocks = 0;
     DevBuf<uint32_t> d_open_ptr, d_open_code;  // the trees' open-edge lists (build_open_lists): the gradient scan's chunk offsets
     DevBuf<int32_t> d_gptr, d_gidx;  // genes as CSR over transcripts (gene-level wrapper), set by approx_set_genes
     int32_t G = 0;
@@ -394,6 +511,43 @@ polee_status polee_approx_create(polee_ctx *ctx, int32_t S, int32_t n, const flo
     A(ap->d_xgrad.alloc(ctx, sn));
     A(ap->d_lp.alloc(ctx, S));
     if (st == POLEE_OK) st = ap->t->reserve(S);
+    if (st == POLEE_OK && !getenv("POLEE_APPROX_NO_CHUNKS")) {  // (A/B: the three-phase leaf scan + approx_nodes_kernel)
+        // tables of approx_leaf_nodes_kernel, per tree: internal nodes in DFS pre-order have non-decreasing lo
+        const int nch = (int)ceil_div(n, APX_CH), need_words = (n + 1 + 31) / 32 + 1;
+        std::vector<int32_t> node_start, cross, cross_ptr(1, 0);
+        std::vector<uint32_t> need;
+        bool ok = true;
+        int max_cross = 0;
+        for (const PttPlan &pl : ap->t->plans) {
+            const size_t ns0 = node_start.size(), nd0 = need.size();
+            node_start.resize(ns0 + (size_t)nch + 1, (int32_t)(n - 1));
+            need.resize(nd0 + (size_t)need_words, 0u);
+            int c = 0;
+            for (int k = 0; k + 1 < n; ++k) {
+                if (k > 0 && pl.lo[(size_t)k] < pl.lo[(size_t)k - 1]) ok = false;
+                for (; c <= pl.lo[(size_t)k] / APX_CH; ++c) node_start[ns0 + (size_t)c] = k;
+                const int64_t end = std::min<int64_t>(((int64_t)pl.lo[(size_t)k] / APX_CH + 1) * APX_CH, (int64_t)n);
+                if (pl.hi1[(size_t)k] > end) {
+                    cross.push_back(k);
+                    for (int32_t b : {pl.lo[(size_t)k], pl.mid[(size_t)k], pl.hi1[(size_t)k]}) need[nd0 + ((size_t)b >> 5)] |= 1u << (b & 31);
+                }
+            }
+            max_cross = std::max(max_cross, (int)cross.size() - cross_ptr.back());
+            cross_ptr.push_back((int32_t)cross.size());
+        }
+        if (ok) {
+            if (cross.empty()) cross.push_back(0);
+            ap->nch = nch;
+            ap->need_words = need_words;
+            ap->max_cross_blocks = (int)ceil_div(max_cross, 256);
+            A(ap->d_node_start.upload(ctx, node_start));
+            A(ap->d_need.upload(ctx, need));
+            A(ap->d_cross.upload(ctx, cross));
+            A(ap->d_cross_ptr.upload(ctx, cross_ptr));
+            A(ap->d_chunk_tot.alloc(ctx, (size_t)S * ((size_t)nch + 1)));
+            A(ap->d_npart.alloc(ctx, (size_t)S * (size_t)std::max<int64_t>(ceil_div(n - 1, 256), (int64_t)nch + ap->max_cross_blocks)));
+        }
+    }
     if (st == POLEE_OK && !getenv("POLEE_APPROX_NO_OPEN_LISTS")) {  // (A/B)
         // the gradient scan's chunk offsets from the trees (build_open_lists): kept unless the trees are so deep that the lists
         // would pass 32 M entries in all -- the three-phase scan stays for those
@@ -442,15 +596,29 @@ polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, flo
     const unsigned nb = (unsigned)std::min<int64_t>(ceil_div(n, 256), 40);
     hipLaunchKernelGGL(approx_sums_kernel, dim3(nb, S), dim3(256), 0, st, ap->view(), d_x, ap->d_acc.p);
     POLEE_KERNEL_CHECK(ctx);
-    ApproxLeafLoad load{t->view(), ap->view(), d_x, ap->d_acc.p};
-    LeafPrefixEmit emit{n, t->d_C.p};
-    hipError_t e = run_scan_partial<dd>(st, S, n, t->d_chunk.p, nullptr, load, emit);
-    if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
-                       ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_tpair.p : nullptr);
+    int nblk = (int)ceil_div(nm1, 256);
+    if (ap->d_node_start.p) {
+        const ApproxChunkTables T{ap->d_node_start.p, ap->d_need.p, ap->d_cross.p, ap->d_cross_ptr.p, ap->nch, ap->need_words, ap->max_cross_blocks};
+        nblk = ap->nch + ap->max_cross_blocks;
+        hipLaunchKernelGGL(approx_leaf_nodes_kernel, dim3((unsigned)ap->nch, S), dim3(256), 0, st, t->view(), ap->view(), T, d_x,
+                           (const double *)ap->d_acc.p, t->d_C.p, ap->d_chunk_tot.p, ap->d_npart.p, nblk, grad ? ap->d_tpair.p : nullptr);
+        if (ap->max_cross_blocks > 0) {
+            hipLaunchKernelGGL((scan_spine_kernel<dd>), dim3(S), dim3(SCAN_THREADS), 0, st, ap->d_chunk_tot.p, ap->nch + 1);
+            hipLaunchKernelGGL(approx_cross_nodes_kernel, dim3((unsigned)ap->max_cross_blocks, S), dim3(256), 0, st, t->view(), ap->view(), T,
+                               (const dd *)t->d_C.p, (const dd *)ap->d_chunk_tot.p, ap->d_npart.p, nblk, grad ? ap->d_tpair.p : nullptr);
+        }
+    } else {
+        ApproxLeafLoad load{t->view(), ap->view(), d_x, ap->d_acc.p};
+        LeafPrefixEmit emit{n, t->d_C.p};
+        hipError_t e0 = run_scan_partial<dd>(st, S, n, t->d_chunk.p, nullptr, load, emit);
+        if (e0 != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e0));
+        hipLaunchKernelGGL(approx_nodes_kernel, dim3((unsigned)ceil_div(nm1, 256), S), dim3(256), 0, st, t->view(),
+                           ap->view(), t->d_C.p, ap->d_npart.p, grad ? ap->d_tpair.p : nullptr);
+    }
+    hipError_t e = hipSuccess;
     if (!grad)
         hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
-                           (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp, (const double *)nullptr, 0, (double *)nullptr);
+                           nblk, ap->d_sum_log_l.p, d_lp, (const double *)nullptr, 0, (double *)nullptr);
     POLEE_KERNEL_CHECK(ctx);
     if (grad) {
         ApproxGradLoad gl{t->view(), ap->d_tpair.p};
@@ -467,7 +635,7 @@ polee_status polee_approx_logprob_device(polee_approx *ap, const float *d_x, flo
         if (e != hipSuccess) return fail(ctx, POLEE_ERR_HIP, "scan launch failed: %s", hipGetErrorString(e));
         // (lp and the scan's two dot products in one single-workgroup launch per sample)
         hipLaunchKernelGGL(approx_finish_lp_kernel, dim3(S), dim3(256), 0, st, ap->view(), ap->d_acc.p, ap->d_npart.p,
-                           (int)ceil_div(nm1, 256), ap->d_sum_log_l.p, d_lp, (const double *)t->d_part.p, scan_num_chunks(t->TL),
+                           nblk, ap->d_sum_log_l.p, d_lp, (const double *)t->d_part.p, scan_num_chunks(t->TL),
                            ap->d_dots.p);
         hipLaunchKernelGGL(approx_finish_grad_kernel, dim3((unsigned)ceil_div(n, 256), S), dim3(256), 0, st,
                            ap->view(), d_x, ap->d_acc.p, ap->d_dots.p, ap->d_bp.p, d_x_grad);

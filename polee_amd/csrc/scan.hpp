@@ -84,13 +84,14 @@ __device__ inline T block_exclusive_scan(T v, T *smem, T *total)
     T inc = wave_inclusive_scan<T>(v);
     if (lane == 63) smem[wave] = inc;
     __syncthreads();
+    // (the same sums in the same order as adding every wave's total under a mask -- 0 + x is exact -- in about half the adds: the
+    // offset's loop has a wave-uniform trip count; a K-wide double-double add is ~70 instructions and these scans are bound by
+    // the instructions they issue)
     T woff = ScanOps<T>::zero();
-    T tot = ScanOps<T>::zero();
+    for (int w = 0; w < wave; ++w) woff = ScanOps<T>::add(woff, smem[w]);
+    T tot = smem[0];
 #pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-        if (w < wave) woff = ScanOps<T>::add(woff, smem[w]);
-        tot = ScanOps<T>::add(tot, smem[w]);
-    }
+    for (int w = 1; w < SCAN_THREADS / 64; ++w) tot = ScanOps<T>::add(tot, smem[w]);
     __syncthreads();
     // exclusive = (wave offset) + (inclusive of previous lane)
     T prev = ScanOps<T>::shfl_up(inc, 1);
