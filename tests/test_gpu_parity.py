@@ -373,6 +373,68 @@ def test_vi_single_step_gradients_match_oracle(P, ctx, lm_fixture, prep_fixture,
         assert (np.abs(orc / K - ref) <= 1e-4 * np.abs(ref) + 1e-4 * fac * (noise / K + 1)).all(), name
 
 
+@pytest.mark.parametrize("kind,K", [("spine", 6), ("random", 6), ("balanced", 8), ("spine", 8), ("random", 3)])
+def test_vi_subtree_sums_across_chunks_and_sixteen_decades(P, ctx, kind, K):
+    """The VI loop's backward pass (round 6: a chunk-local double-double prefix per 512 leaves -- 256 for K > 6 --, the nodes inside a
+    chunk from LDS rows, the chunk-crossing ones through exported rows + chunk offsets, subtree sums kept as Float32) on trees of
+    3 000 leaves, i.e. several chunks: a caterpillar (every node crosses chunks), a random and a balanced tree; parameters spread
+    so that the leaves' u spans more than sixteen decades (hard part 2: tiny subtrees beside large ones).  y_grad of every
+    draw against the f64 restatement of ptt.jl:167-209 fed with the oracle's x gradient, in the reference's own rounding class
+    (its gradient intermediates are Float32: 2e-5 of the two cancelling terms), and the three parameter gradients."""
+    from tools import synth
+    n, m = 3000, 60000
+    smp = synth.make_sample(n, m, 4.0, 17)
+    colptr, rowval, nzval = synth.to_csc(smp)
+    eff = smp["effective_lengths"]
+    rng = np.random.default_rng(5)
+    parents, js = random_tree(n, rng, kind)
+    s = P.RNASeqSample(m, n, colptr, rowval, nzval, eff, ctx=ctx)
+    t = P.PolyaTreeTransform(parents, js, ctx=ctx)
+    so, to = O.Sample(m, n, colptr, rowval, nzval), O.PTT(parents, js)
+    mu = rng.normal(0, 3.0, n - 1).astype(np.float32)
+    if kind == "spine":
+        # a caterpillar multiplies n - 1 factors along its spine: in f64 the reference's own recursion underflows (1 / u = inf) unless
+        # the factor towards the larger subtree stays near 1 -- so y ~ 0.9975 towards it (the chain's u decays to 5e-4), noise on
+        # top, and forty extreme nodes for tiny subtrees
+        import ctypes as C
+        from polee_amd import _lib as L
+        N = 2 * n - 1
+        code = np.zeros(3 * n - 2, np.uint32); tgt = np.zeros(3 * n - 2, np.int32); ltid = np.zeros(n, np.int32)
+        lo, mid, hi1 = (np.zeros(n - 1, np.int32) for _ in range(3))
+        depth = C.c_int32()
+        pp, jj = np.ascontiguousarray(parents, np.int32), np.ascontiguousarray(js, np.int32)
+        L.check(L.lib().polee_debug_ptt_plan(L.ptr(pp, L.i32p), L.ptr(jj, L.i32p), N, L.ptr(code, L.u32p), L.ptr(tgt, L.i32p),
+                                             L.ptr(ltid, L.i32p), L.ptr(lo, L.i32p), L.ptr(mid, L.i32p), L.ptr(hi1, L.i32p), C.byref(depth)))
+        left_bigger = (hi1 - mid) > (mid - lo)  # y multiplies the LEFT child (ptt.jl:147)
+        mu = (np.where(left_bigger, 6.0, -6.0) + rng.normal(0, 0.5, n - 1)).astype(np.float32)
+        mu[rng.integers(0, n - 1, 40)] = rng.choice([-18.0, 18.0], 40).astype(np.float32)
+    omega = rng.normal(-1.5, 0.3, n - 1).astype(np.float32)
+    alpha = rng.normal(0, 0.2, n - 1).astype(np.float32)
+    fit = P.LikelihoodApproximationFit(s, t, num_steps=2, num_mc_samples=K, gradonly=False, seed=7)
+    fit.set_params(mu, omega, alpha)
+    z0 = fit.export_noise(1)
+    out = fit.eval_gradients()
+    span = []
+    mu_acc, noise = np.zeros(n - 1), np.zeros(n - 1)
+    for d in range(K):
+        r = O.vi_draw_gradients(so, to, eff, mu, omega, alpha, z0[d])
+        np.testing.assert_allclose(out["xs"][d], r["xs"], rtol=2e-5)
+        np.testing.assert_allclose(out["x_grad"][d], r["x_grad"], rtol=1e-4, atol=1e-6 * np.abs(r["x_grad"]).max())
+        yg64, term = _ygrad_f64(to, r["ys"], r["x_grad"])
+        bad = np.abs(out["y_grad"][d] - yg64) > 2e-5 * (term + 1)
+        assert not bad.any(), (kind, K, d, int(bad.sum()), float((np.abs(out["y_grad"][d] - yg64) / (term + 1)).max()))
+        span.append((r["xs"].min(), r["xs"].max()))
+        dyy = r["ys"] * (1 - r["ys"])
+        mu_acc += dyy * yg64 + (1 - 2 * r["ys"])
+        noise += dyy * term
+    assert min(a for a, _ in span) <= 1.001e-10 and max(b for _, b in span) > 1e-3, span  # (xs is clamped at 1e-10: u goes far below)
+    # mu's gradient, the K-draw mean of dyy y_grad + (1 - 2 y) (logitnormal.jl:50-52), against the same chain in f64 from yg64 (the
+    # oracle's own Float32 recursion overflows on the caterpillar's extreme nodes: 1 / u is not a Float32)
+    ref = mu_acc / K
+    ok = np.abs(out["mu_grad"] - ref) <= 1e-4 * np.abs(ref) + 1e-5 * (noise / K + 1)
+    assert ok.all(), (kind, K, int((~ok).sum()))
+
+
 def test_vi_trajectory_with_supplied_noise(P, ctx, lm_fixture, prep_fixture):
     """Five full iterations (sampling, likelihood, backward, ADAM) with identical z0 on both sides."""
     f = lm_fixture
