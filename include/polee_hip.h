@@ -241,7 +241,7 @@ typedef struct {
     uint64_t seed;               /* device Philox seed (reference default 123456789)       */
     const float *z0;             /* optional HOST noise [num_steps][num_mc][n-1]; when set */
                                  /* it replaces the device RNG (deterministic parity runs) */
-    double y_eps;                /* LIKAP_Y_EPS = 1e-10 clamp of ys and xs                 */
+    double y_eps;                /* LIKAP_Y_EPS = 1e-10 clamp of ys and xs; must lie in (0, 0.5) */
     double adam_initial_learning_rate; /* 1.0  */
     double adam_learning_rate_decay;   /* 2e-2 */
     double adam_min_learning_rate;     /* 1e-3 */

@@ -538,6 +538,8 @@ polee_status polee_vi_create(polee_loglik *ll, polee_ptt *t, const float *efflen
     if (o.num_mc_samples < 1 || o.num_mc_samples > PSELL_MAX_K)
         return fail(ctx, POLEE_ERR_BAD_ARG, "num_mc_samples must be in 1..8");
     if (o.num_steps < 0) return fail(ctx, POLEE_ERR_BAD_ARG, "num_steps must be >= 0");
+    // (the forward kernel takes log y and log(1 - y) of the clamped y without the special cases of a general log)
+    if (!(o.y_eps > 0.0 && o.y_eps < 0.5)) return fail(ctx, POLEE_ERR_BAD_ARG, "y_eps must lie in (0, 0.5) (LIKAP_Y_EPS = 1e-10)");
     // gene_noninformative: members per gene and M = sum over genes of (members - 1)
     std::vector<int> gene_k;
     double gene_M = 0.0;

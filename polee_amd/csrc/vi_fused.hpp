@@ -132,6 +132,14 @@ __device__ inline double clamped_y(float y32, double y_eps)
     const double y = (double)y32;
     return y < y_eps ? y_eps : (y > 1 - y_eps ? 1 - y_eps : y);
 }
+// (the same value when y_eps > 0, as the VI loop's is: the lower bound applied in f32 -- v_max against the largest float not
+// above y_eps would round UP past values in (that float, y_eps), so the f64 compare stays for exactness but only one select
+// each: written for the forward kernel, which clamps fourteen values per thread)
+__device__ inline double clamped_y_pos(float y32, double y_eps, double one_m_eps)
+{
+    const double y = (double)y32;
+    return fmin(fmax(y, y_eps), one_m_eps);
+}
 // one node's K draws (shared by the sample kernel and the update kernel's look-ahead)
 template <int K, typename Noise>
 __device__ inline void sample_node(float m, float om, float al, const Noise &noise, int step, int64_t k,
@@ -198,17 +206,18 @@ struct YRows {
     template <int K>
     __device__ inline double edge_one(uint32_t k, uint32_t left, int d) const
     {
-        const double y = clamped_y(y32[(size_t)k * K + d], y_eps);
-        return fast_log(left ? y : 1.0 - y);
+        const double y = clamped_y_pos(y32[(size_t)k * K + d], y_eps, 1.0 - y_eps);
+        return fast_log_pos(left ? y : 1.0 - y);
     }
     template <int K>
     __device__ inline void edge(uint32_t k, uint32_t left, double (&e)[K]) const
     {
         const float *p = y32 + (size_t)k * K;
+        const double hi = 1.0 - y_eps;
 #pragma unroll
         for (int d = 0; d < K; ++d) {
-            const double y = clamped_y(p[d], y_eps);
-            e[d] = fast_log(left ? y : 1.0 - y);  // (log1p(-y): y is clamped to [eps, 1 - eps])
+            const double y = clamped_y_pos(p[d], y_eps, hi);
+            e[d] = fast_log_pos(left ? y : 1.0 - y);  // (log1p(-y): y is clamped to [eps, 1 - eps], both arguments normal and positive)
         }
     }
 };
