@@ -47,6 +47,18 @@ __host__ __device__ inline double dd_diff(dd a, dd b)
     return r.hi + r.lo;
 }
 
+// A double moved between lanes by DPP (data-parallel primitives: the lane permutation is part of a VALU move, no LDS round trip as
+// ds_bpermute makes).  Lanes whose source lies outside the permutation's range, or whose row is masked off, receive 0 -- the
+// identity of every scan here.  CTRL: 0x110 + n = row_shr:n (within rows of 16 lanes), 0x142 / 0x143 = row_bcast:15 / :31 (the last
+// lane of a row / of the first two rows to the rows behind: gfx9), 0x138 = wave_shr:1.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_f64(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false));
+}
+
 template <typename T>
 struct ScanOps;
 template <>
@@ -54,25 +66,37 @@ struct ScanOps<double> {
     __device__ static double zero() { return 0.0; }
     __device__ static double add(double a, double b) { return a + b; }
     __device__ static double shfl_up(double v, int d) { return __shfl_up(v, d, 64); }
+    template <int CTRL, int ROW_MASK>
+    __device__ static double dpp(double v) { return dpp_f64<CTRL, ROW_MASK>(v); }
 };
 template <>
 struct ScanOps<dd> {
     __device__ static dd zero() { return dd{0.0, 0.0}; }
     __device__ static dd add(dd a, dd b) { return dd_add(a, b); }
     __device__ static dd shfl_up(dd v, int d) { return dd{__shfl_up(v.hi, d, 64), __shfl_up(v.lo, d, 64)}; }
+    template <int CTRL, int ROW_MASK>
+    __device__ static dd dpp(dd v) { return dd{dpp_f64<CTRL, ROW_MASK>(v.hi), dpp_f64<CTRL, ROW_MASK>(v.lo)}; }
 };
 
-// Inclusive scan across the 64 lanes of a wave.
+// Inclusive scan across the 64 lanes of a wave: four shifts inside the rows of 16 lanes, then the rows' totals handed on
+// (row 0 -> 1 and 2 -> 3, then rows 0-1 -> 2-3) -- six adds per lane like the shuffle form it replaces (round 6), whose six
+// ds_bpermute round trips and per-step selects it does without.
 template <typename T>
 __device__ inline T wave_inclusive_scan(T v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T o = ScanOps<T>::shfl_up(v, d);
-        if (lane >= d) v = ScanOps<T>::add(o, v);
-    }
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x111, 0xf>(v), v);
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x112, 0xf>(v), v);
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x114, 0xf>(v), v);
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x118, 0xf>(v), v);
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x142, 0xa>(v), v);
+    v = ScanOps<T>::add(ScanOps<T>::template dpp<0x143, 0xc>(v), v);
     return v;
+}
+// the value of the lane below (lane 0: the zero element)
+template <typename T>
+__device__ inline T wave_shift_up_one(T v)
+{
+    return ScanOps<T>::template dpp<0x138, 0xf>(v);
 }
 
 // Exclusive scan of one value per thread across a 256-thread block; also returns the
@@ -94,8 +118,7 @@ __device__ inline T block_exclusive_scan(T v, T *smem, T *total)
     for (int w = 1; w < SCAN_THREADS / 64; ++w) tot = ScanOps<T>::add(tot, smem[w]);
     __syncthreads();
     // exclusive = (wave offset) + (inclusive of previous lane)
-    T prev = ScanOps<T>::shfl_up(inc, 1);
-    if (lane == 0) prev = ScanOps<T>::zero();
+    const T prev = wave_shift_up_one<T>(inc);
     *total = tot;
     return ScanOps<T>::add(woff, prev);
 }

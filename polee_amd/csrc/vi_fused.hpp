@@ -59,6 +59,14 @@ struct ScanOps<VK<K>> {
         for (int d = 0; d < K; ++d) r.v[d] = __shfl_up(a.v[d], dist, 64);
         return r;
     }
+    template <int CTRL, int ROW_MASK>
+    __device__ static VK<K> dpp(const VK<K> &a)
+    {
+        VK<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = dpp_f64<CTRL, ROW_MASK>(a.v[d]);
+        return r;
+    }
 };
 template <int K>
 struct ScanOps<VD<K>> {
@@ -81,6 +89,14 @@ struct ScanOps<VD<K>> {
         VD<K> r;
 #pragma unroll
         for (int d = 0; d < K; ++d) r.v[d] = dd{__shfl_up(a.v[d].hi, dist, 64), __shfl_up(a.v[d].lo, dist, 64)};
+        return r;
+    }
+    template <int CTRL, int ROW_MASK>
+    __device__ static VD<K> dpp(const VD<K> &a)
+    {
+        VD<K> r;
+#pragma unroll
+        for (int d = 0; d < K; ++d) r.v[d] = dd{dpp_f64<CTRL, ROW_MASK>(a.v[d].hi), dpp_f64<CTRL, ROW_MASK>(a.v[d].lo)};
         return r;
     }
 };
@@ -878,8 +894,7 @@ __global__ __launch_bounds__(256) void vi_bwd_local_kernel(BwdArgs<K> B)
     VI_STAMP(1, 2);
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    VD<K> off = ScanOps<VD<K>>::shfl_up(inc, 1);
-    if (lane == 0) off = ScanOps<VD<K>>::zero();
+    VD<K> off = wave_shift_up_one<VD<K>>(inc);
     for (int w = 0; w < wave; ++w) off = ScanOps<VD<K>>::add(wtot[w], off);  // (wave-uniform trip count)
 #pragma unroll
     for (int d = 0; d < K; ++d) P[(size_t)(threadIdx.x * LPT) * K + d] = off.v[d];
