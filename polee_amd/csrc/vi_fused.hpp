@@ -380,9 +380,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
                     const uint32_t oc = open_code[e];
                     pre += lyy.template edge_one<K>(oc >> 4, (oc >> 3) & 1u, d);
                 }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) pre += __shfl_xor(pre, o, 64);
-                if (lane == 0) spre[d] = pre;
+                pre = wave_inclusive_scan<double>(pre);  // (DPP: the wave's sum lands in its last lane)
+                if (lane == 63) spre[d] = pre;
             }
         }
     }
@@ -460,17 +459,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void vi_fwd_apply_kernel(PttView v, S
         }
     }
     VI_STAMP(0, 4);
-    // the chunk's partial sums: a wave's 64 values by a shuffle tree, the four waves' through LDS in wave order -- one barrier
+    // the chunk's partial sums: a wave's 64 values by a DPP scan, the four waves' through LDS in wave order -- one barrier
     if (part_c || LADJ) {
 #pragma unroll
         for (int d = 0; d < K; ++d) {
-            double a = pc[d], b = LADJ ? pl[d] : 0.0;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                a += __shfl_xor(a, o, 64);
-                if (LADJ) b += __shfl_xor(b, o, 64);
-            }
-            if (lane == 0) {
+            const double a = wave_inclusive_scan<double>(pc[d]);  // (DPP: the wave's sum lands in its last lane)
+            const double b = LADJ ? wave_inclusive_scan<double>(pl[d]) : 0.0;
+            if (lane == 63) {
                 smd[wave * K + d] = a;
                 if (LADJ) smd2[wave * K + d] = b;
             }
