@@ -305,10 +305,10 @@ __device__ inline double fast_exp(double x)
 
 __device__ inline double block_sum_f64(double v, double *smem4)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    // (a wave's sum by a DPP scan -- it lands in the last lane -- instead of a six-step shuffle tree through LDS)
+    v = wave_inclusive_scan<double>(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) smem4[wave] = v;
+    if (lane == 63) smem4[wave] = v;
     __syncthreads();
     double r = 0.0;
     if (threadIdx.x == 0)

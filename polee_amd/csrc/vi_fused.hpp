@@ -109,10 +109,8 @@ __device__ inline void block_sum_vec(double (&v)[K], double *smem)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d < K; ++d) {
-        double s = v[d];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) smem[wave * K + d] = s;
+        const double s = wave_inclusive_scan<double>(v[d]);  // (DPP: the wave's sum lands in its last lane)
+        if (lane == 63) smem[wave * K + d] = s;
     }
     __syncthreads();
     if (threadIdx.x < K) {
