@@ -280,9 +280,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_partial_open_kernel(L
         const uint32_t ob = op[chunk], oe = op[chunk + 1];
         dd pre{0.0, 0.0};
         for (uint32_t e = ob + threadIdx.x; e < oe; e += 64) pre = dd_add(pre, dd_make(load.term(row, open_code[e])));
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) pre = dd_add(pre, dd{__shfl_xor(pre.hi, o, 64), __shfl_xor(pre.lo, o, 64)});
-        if (threadIdx.x == 0) spre = pre;
+        pre = wave_inclusive_scan<dd>(pre);  // (DPP: the wave's sum lands in its last lane)
+        if (threadIdx.x == 63) spre = pre;
     }
     dd v[SCAN_ITEMS];
     dd acc{0.0, 0.0};
